@@ -1,0 +1,191 @@
+/*
+ * rcf_hip.h -- C ABI of librcf_hip.so: the FusionNet forward/backward hot path of
+ * nesl/radar-camera-fusion-depth as hand-written HIP kernels for MI355X (gfx950).
+ *
+ * The reference has no native code and no FFI: its hot path is the stock torch.nn
+ * modules called from src/net_utils.py / src/networks.py / src/fusionnet_model.py.  Each entry point
+ * below therefore cites the reference Python interface (file:line, relative to the reference root)
+ * whose computation it replaces; INTEGRATION.md shows the ctypes binding a reference maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked host.
+ *   - activations are fp32, NHWC contiguous: x[n][y][x][c].  Weights cross the boundary in the
+ *     reference's own layout, OIHW contiguous (torch.nn.Conv2d.weight, src/net_utils.py:63).
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); it never
+ *     synchronises, allocates or frees.  Workspaces are caller-owned; sizes come from *_query.
+ *   - stateless and re-entrant.  Return value: 0 = ok; RCF_E* < 0 = invalid argument /
+ *     unsupported shape; > 0 = a hipError_t from a launch.  Nothing throws or aborts.
+ */
+#ifndef RCF_HIP_H
+#define RCF_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCF_OK 0
+#define RCF_EINVAL (-1)      /* null pointer, non-positive extent, inconsistent shape */
+#define RCF_EUNSUPPORTED (-2) /* shape outside what the kernels implement */
+
+#define RCF_GATHER_DIRECT 0     /* source 1 is read as is */
+#define RCF_GATHER_NEAREST 1    /* source 1 is nearest-upsampled to (h_in,w_in): F.interpolate(x,size), src/net_utils.py:196 */
+#define RCF_GATHER_ZERO_INSERT 2 /* source 1 is zero-dilated by 2 (transposed conv: dgrad of a stride-2 conv) */
+
+#define RCF_W_FORWARD 0 /* weight tensor is used as stored: out channel O, in channel I */
+#define RCF_W_DGRAD 1   /* flipped taps and swapped roles: this conv maps dZ (O channels) to dX (a slice of I) */
+
+#define RCF_ACT_NONE 0
+#define RCF_ACT_LEAKY_RELU 1 /* negative_slope 0.20, src/net_utils.py:15 */
+
+/* Implicit-GEMM convolution descriptor: out[n,oy,ox,:] = sum_taps W[tap] . in[n, oy*stride-pad+ky, ox*stride-pad+kx, :]
+ * where `in` is the channel concatenation [source1 | source2] (torch.cat([deconv, skip], 1), src/net_utils.py:565)
+ * and source 1 may be gathered (nearest upsample / zero insert).  */
+typedef struct rcf_conv_desc {
+    int n;              /* batch */
+    int h_in, w_in;     /* logical input extent seen by the conv */
+    int c1, c2;         /* channels of source 1 and source 2 (c2 == 0: single source) */
+    int h_src1, w_src1; /* physical extent of source 1 (== h_in,w_in for RCF_GATHER_DIRECT) */
+    int gather1;        /* RCF_GATHER_* */
+    int h_out, w_out, c_out;
+    int ksize;          /* 1, 3 or 7 */
+    int stride;         /* 1 or 2 */
+    int pad;            /* ksize/2 for the reference's Conv2d (src/net_utils.py:61); ksize-1-pad for its dgrad */
+    int w_mode;         /* RCF_W_FORWARD / RCF_W_DGRAD */
+    int w_o, w_i;       /* dims of the OIHW weight tensor this conv is packed from */
+    int w_i_off;        /* RCF_W_DGRAD: first input channel of the dX slice produced (c_out channels) */
+    int accumulate;     /* out += result instead of out = result */
+} rcf_conv_desc;
+
+typedef struct rcf_conv_info {
+    size_t packed_weight_floats; /* size of the packed-weight buffer for rcf_conv2d_pack_weights */
+    int n_partials;              /* rows of the per-workgroup BN-statistics partial buffer [n_partials][2][c_out] */
+    size_t wgrad_workspace_floats; /* workspace for rcf_conv2d_wgrad on the same (forward) descriptor */
+    int kernel_id;               /* which tile configuration was selected (for profiling/logs) */
+    int wgrad_kernel_id;         /* same for the weight-gradient kernel of a forward descriptor (0: none) */
+} rcf_conv_info;
+
+const char* rcf_version(void);
+/* 1 when the library was built with the gfx950 code object this process can launch (a device is present). */
+int rcf_device_ok(void);
+
+int rcf_conv2d_query(const rcf_conv_desc* d, rcf_conv_info* info);
+
+/* OIHW -> kernel layout [n-tile][k-chunk][tap][BN][CK].  Replaces nothing in the reference; it is the
+ * price of keeping torch.nn.Conv2d.weight's layout at the boundary. */
+int rcf_conv2d_pack_weights(const rcf_conv_desc* d, const float* w_oihw, float* packed, void* stream);
+
+/* torch.nn.Conv2d.forward, bias=False (src/net_utils.py:85); with gather1=NEAREST also the F.interpolate of
+ * UpConv2d.forward (src/net_utils.py:195-198); with c2>0 also the torch.cat of DecoderBlock.forward
+ * (src/net_utils.py:564-569).  With w_mode=DGRAD it is the input gradient autograd computes for that conv.
+ * stat_partials (nullable): per-workgroup sum and sum-of-squares of the outputs per channel, consumed by
+ * rcf_bn_finalize -- the batch statistics of torch.nn.BatchNorm2d (src/net_utils.py:82,86). */
+int rcf_conv2d_fwd(const rcf_conv_desc* d, const float* in1, const float* in2, const float* packed,
+                   float* out, float* stat_partials, void* stream);
+
+/* Weight gradient of the conv described by the FORWARD descriptor d: dw[o][i][ky][kx] (OIHW, same layout as
+ * the parameter) = sum over pixels of in[...] * dz[...].  Replaces autograd's conv weight backward behind
+ * loss.backward() (src/fusionnet_main.py:398). */
+int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const float* in2, const float* dz,
+                     float* dw_oihw, float* workspace, void* stream);
+
+/* BatchNorm2d batch statistics -> affine coefficients.  partials: [n_partials][2][c] from rcf_conv2d_fwd.
+ * coef: [4][c] = scale (gamma*invstd), shift (beta-mean*scale), mean, invstd.
+ * training != 0: batch statistics, and running_mean/var are updated with `momentum` (unbiased variance),
+ * exactly torch.nn.BatchNorm2d(eps=1e-5, momentum=0.1) in train mode (src/net_utils.py:82).
+ * training == 0: coefficients from the running statistics (eval mode); partials is ignored. */
+int rcf_bn_finalize(const float* partials, int n_partials, int c, double count,
+                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, int training, float* coef, void* stream);
+
+/* out = act(z*scale+shift); with res != NULL: out = lrelu(act(z*scale+shift) + res), the tail of
+ * ResNetBlock.forward (src/net_utils.py:309-323).  n_pix = N*H*W. */
+int rcf_bn_act_fwd(const float* z, const float* coef, const float* res, float* out,
+                   long long n_pix, int c, int act, void* stream);
+
+/* skip = sigmoid(BN_w(zw)) * BN_p(zp) + img : FusionNetEncoder 'weight_and_project' fusion (src/networks.py:863-866). */
+int rcf_fuse_fwd(const float* zw, const float* coef_w, const float* zp, const float* coef_p,
+                 const float* img, float* out, long long n_pix, int c, void* stream);
+
+/* Backward of rcf_bn_act_fwd, two passes around a per-channel reduction (BatchNorm2d backward).
+ * reduce: partials[n_blocks][2][c] = (sum g, sum g*xhat), g = dout * act'(.) (* lrelu'(out) when has_res).
+ * n_blocks for a given (n_pix, c) comes from rcf_ew_blocks. */
+int rcf_ew_blocks(long long n_pix, int c);
+int rcf_bn_act_bwd_reduce(const float* dout, const float* z, const float* coef, const float* out,
+                          float* partials, long long n_pix, int c, int act, int has_res, void* stream);
+/* bcoef[2][c] = (sum g / M, sum g*xhat / M); dgamma[c], dbeta[c] (accumulate == 0: overwrite). */
+int rcf_bn_bwd_finalize(const float* partials, int n_blocks, int partial_stride, int c, double count,
+                        float* bcoef, float* dgamma, float* dbeta, void* stream);
+/* dz = scale * (g - bcoef0 - xhat*bcoef1); dres (nullable) = dout*lrelu'(out), accumulated when dres_accumulate. */
+int rcf_bn_act_bwd_apply(const float* dout, const float* z, const float* coef, const float* out,
+                         const float* bcoef, float* dz, float* dres, int dres_accumulate,
+                         long long n_pix, int c, int act, int has_res, void* stream);
+
+/* Backward of rcf_fuse_fwd. partials[n_blocks][4][c]: (sum gw, sum gw*xhat_w, sum gp, sum gp*xhat_p). */
+int rcf_fuse_bwd_reduce(const float* dout, const float* zw, const float* coef_w, const float* zp,
+                        const float* coef_p, float* partials, long long n_pix, int c, void* stream);
+int rcf_fuse_bwd_apply(const float* dout, const float* zw, const float* coef_w, const float* zp,
+                       const float* coef_p, const float* bcoef_w, const float* bcoef_p,
+                       float* dzw, float* dzp, float* dimg, int dimg_accumulate,
+                       long long n_pix, int c, void* stream);
+
+/* torch.nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (src/networks.py:392-395, :875-876).
+ * idx: one byte per output element = winning tap (ky*3+kx), first maximum in scan order as in PyTorch. */
+int rcf_maxpool3x3s2_fwd(const float* in, float* out, unsigned char* idx, int n, int h, int w, int c, void* stream);
+int rcf_maxpool3x3s2_bwd(const float* dout, const unsigned char* idx, float* din, int din_accumulate,
+                         int n, int h, int w, int c, void* stream);
+
+/* Backward of the nearest upsample folded into rcf_conv2d_fwd: dsrc[n,sy,sx,:] = sum of dup over the fan-out. */
+int rcf_upsample_nearest_bwd(const float* dup, float* dsrc, int dsrc_accumulate,
+                             int n, int h_up, int w_up, int h_src, int w_src, int c, void* stream);
+
+/* output0 (3x3, C -> 1, no BN, no activation; src/networks.py:1548-1555) fused with the depth map
+ * d = min/(sigmoid(o)+min/max) of FusionNetModel.forward (src/fusionnet_model.py:162-165).
+ * w: [1][C][3][3] OIHW.  logit and depth: [N][H][W]. */
+int rcf_head_fwd(const float* x, const float* w, float* logit, float* depth,
+                 int n, int h, int w_, int c, float min_depth, float max_depth, void* stream);
+/* dlogit = ddepth * d(depth)/d(logit). */
+int rcf_head_bwd_logit(const float* ddepth, const float* logit, float* dlogit, long long n_pix,
+                       float min_depth, float max_depth, void* stream);
+int rcf_head_bwd_dgrad(const float* dlogit, const float* w, float* dx, int n, int h, int w_, int c, void* stream);
+size_t rcf_head_wgrad_workspace_floats(int n, int h, int w_, int c);
+int rcf_head_bwd_wgrad(const float* x, const float* dlogit, float* dw, float* workspace,
+                       int n, int h, int w_, int c, void* stream);
+
+/* Masked L1 of FusionNetModel.compute_loss, loss_func='l1' (src/fusionnet_model.py:209-253;
+ * src/fusionnet_losses.py:19-32): ground truth is zeroed where lidar > 0, then
+ * loss = mean|d-gt| over gt>0 + w_lidar * mean|d-lidar| over lidar>0.
+ * sums (device, double[4]) = (sum|d-gt|, count gt, sum|d-lidar|, count lidar): local to this rank, so a
+ * data-parallel caller can all-reduce it before the backward.  workspace: rcf_loss_workspace_floats. */
+size_t rcf_loss_workspace_floats(long long n_pix);
+int rcf_l1_loss_fwd(const float* depth, const float* gt, const float* lidar, float* workspace,
+                    double* sums, long long n_pix, void* stream);
+/* loss[0..2] = total, supervised, lidar from (possibly all-reduced) sums. */
+int rcf_l1_loss_value(const double* sums, float w_lidar, float* loss, void* stream);
+/* ddepth = upstream * (sign(d-gt)/count_gt [gt>0] + w_lidar*sign(d-lidar)/count_lidar [lidar>0]); upstream nullable (=1). */
+int rcf_l1_loss_bwd(const float* depth, const float* gt, const float* lidar, const double* sums,
+                    const float* upstream, float w_lidar, float* ddepth, long long n_pix, void* stream);
+
+/* torch.optim.Adam step (src/fusionnet_main.py:307-312, :399) over one flat parameter arena.
+ * step is the 1-based step count; weight_decay is the L2 form Adam uses (added to the gradient). */
+int rcf_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, void* stream);
+
+/* NCHW (the reference's public tensor layout) <-> NHWC (kernel layout). */
+int rcf_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, void* stream);
+int rcf_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, void* stream);
+
+/* Radar point -> dense map scatter of radarnet_main.forward (src/radarnet_main.py:563-589):
+ * crops [K][H][Wc] are sigmoid responses; values < 0.5 are zeroed, crop k is pasted at columns
+ * [x_k - Wc/2, x_k + Wc/2) of a W-wide canvas, the maximum response and its argmax point are taken per
+ * pixel, and the argmax is replaced by that point's depth z_k.  strict_reference != 0 reproduces the
+ * reference's int64 in-place replacement chain (truncation and re-replacement quirk);
+ * 0 gives depth = z[argmax].  points: [K][3] (x px, y px, z m).  depth/response: [H][W]. */
+int rcf_radar_scatter(const float* crops, const float* points, int k, int h, int w, int wc,
+                      int strict_reference, float* depth, float* response, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

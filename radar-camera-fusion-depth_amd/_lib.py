@@ -1,0 +1,95 @@
+'''
+ctypes binding of librcf_hip.so (include/rcf_hip.h).  There is NO fallback: if the library is missing
+or a call returns non-zero the product path raises.  Build with ``python -c "import __graft_entry__ as g; g.build()"``.
+'''
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librcf_hip.so')
+
+RCF_GATHER_DIRECT, RCF_GATHER_NEAREST, RCF_GATHER_ZERO_INSERT = 0, 1, 2
+RCF_W_FORWARD, RCF_W_DGRAD = 0, 1
+RCF_ACT_NONE, RCF_ACT_LEAKY_RELU = 0, 1
+
+
+class ConvDesc(Structure):
+    _fields_ = [(n, c_int) for n in (
+        'n', 'h_in', 'w_in', 'c1', 'c2', 'h_src1', 'w_src1', 'gather1', 'h_out', 'w_out', 'c_out',
+        'ksize', 'stride', 'pad', 'w_mode', 'w_o', 'w_i', 'w_i_off', 'accumulate')]
+
+
+class ConvInfo(Structure):
+    _fields_ = [('packed_weight_floats', c_size_t), ('n_partials', c_int),
+                ('wgrad_workspace_floats', c_size_t), ('kernel_id', c_int), ('wgrad_kernel_id', c_int)]
+
+
+_P = c_void_p
+_SIGNATURES = {
+    'rcf_version': (c_char_p, []),
+    'rcf_device_ok': (c_int, []),
+    'rcf_conv2d_query': (c_int, [POINTER(ConvDesc), POINTER(ConvInfo)]),
+    'rcf_conv2d_pack_weights': (c_int, [POINTER(ConvDesc), _P, _P, _P]),
+    'rcf_conv2d_fwd': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    'rcf_conv2d_wgrad': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    'rcf_bn_finalize': (c_int, [_P, c_int, c_int, c_double, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P]),
+    'rcf_bn_act_fwd': (c_int, [_P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
+    'rcf_fuse_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, _P]),
+    'rcf_ew_blocks': (c_int, [c_longlong, c_int]),
+    'rcf_bn_act_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P]),
+    'rcf_bn_bwd_finalize': (c_int, [_P, c_int, c_int, c_int, c_double, _P, _P, _P, _P]),
+    'rcf_bn_act_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_longlong, c_int, c_int, c_int, _P]),
+    'rcf_fuse_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, _P]),
+    'rcf_fuse_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_longlong, c_int, _P]),
+    'rcf_maxpool3x3s2_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'rcf_maxpool3x3s2_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'rcf_upsample_nearest_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'rcf_head_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
+    'rcf_head_bwd_logit': (c_int, [_P, _P, _P, c_longlong, c_float, c_float, _P]),
+    'rcf_head_bwd_dgrad': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'rcf_head_wgrad_workspace_floats': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'rcf_head_bwd_wgrad': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'rcf_loss_workspace_floats': (c_size_t, [c_longlong]),
+    'rcf_l1_loss_fwd': (c_int, [_P, _P, _P, _P, _P, c_longlong, _P]),
+    'rcf_l1_loss_value': (c_int, [_P, c_float, _P, _P]),
+    'rcf_l1_loss_bwd': (c_int, [_P, _P, _P, _P, _P, c_float, _P, c_longlong, _P]),
+    'rcf_adam_step': (c_int, [_P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
+    'rcf_nchw_to_nhwc': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    'rcf_nhwc_to_nchw': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    'rcf_radar_scatter': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+}
+'''Every symbol include/rcf_hip.h declares, with its ctypes signature.'''
+
+_lib = None
+
+
+class RcfError(RuntimeError):
+    pass
+
+
+def load():
+    '''Load librcf_hip.so once.  Raises RcfError (never falls back) when it is absent or incomplete.'''
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RcfError('librcf_hip.so not found at %s -- the HIP extension is required; run '
+                       '__graft_entry__.build() (hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise RcfError('librcf_hip.so does not export %s (stale build?)' % name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: 'invalid argument', -2: 'unsupported shape'}.get(rc, 'hipError_t %d' % rc)
+        raise RcfError('%s failed: %s' % (what, kind))

@@ -1,0 +1,424 @@
+// BatchNorm2d (training + eval), LeakyReLU, the ResNet residual tail and the 'weight_and_project' fusion of
+// FusionNet, forward and backward, for NHWC fp32 tensors on gfx950.
+//
+// Replaces, on the reference's hot path: torch.nn.BatchNorm2d + LeakyReLU inside net_utils.Conv2d.forward
+// (src/net_utils.py:84-91), the tail of ResNetBlock.forward (src/net_utils.py:309-323), the fusion at
+// src/networks.py:863-866 and their autograd backward.
+//
+// All kernels are HBM-bound streams.  Thread t of a 256-thread block owns channel group (t % C4) (4 channels,
+// one 16-byte access) for every pixel it visits, so per-channel coefficients live in registers and the
+// per-channel reductions of the backward are in-register sums -> one LDS pass per block -> one partial row per
+// block (deterministic; the tiny cross-block sum runs in fp64 in the finalize kernels).
+#include "rcf_common.h"
+
+namespace {
+
+constexpr int EW_MAX_BLOCKS = 2048;
+
+__host__ __device__ inline bool c4_ok(int c) {
+    if (c < 4 || (c & 3)) return false;
+    const int c4 = c >> 2;
+    return (c4 & (c4 - 1)) == 0 && c4 <= 256;
+}
+
+inline int ew_blocks(long long n_pix, int c) {
+    const int ppb = 256 / (c >> 2);
+    long long b = (n_pix + ppb - 1) / ppb;
+    if (b > EW_MAX_BLOCKS) b = EW_MAX_BLOCKS;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+struct Coef4 {
+    f32x4 scale, shift, mean, invstd;
+};
+
+__device__ __forceinline__ Coef4 load_coef(const float* __restrict__ coef, int c, int cg) {
+    Coef4 k;
+    k.scale = *reinterpret_cast<const f32x4*>(coef + 0 * c + cg * 4);
+    k.shift = *reinterpret_cast<const f32x4*>(coef + 1 * c + cg * 4);
+    k.mean = *reinterpret_cast<const f32x4*>(coef + 2 * c + cg * 4);
+    k.invstd = *reinterpret_cast<const f32x4*>(coef + 3 * c + cg * 4);
+    return k;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p, size_t i) { return *reinterpret_cast<const f32x4*>(p + i); }
+__device__ __forceinline__ void st4(float* p, size_t i, f32x4 v) { *reinterpret_cast<f32x4*>(p + i) = v; }
+
+// ---------------------------------------------------------------- forward
+__global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ coef,
+                                                         const float* __restrict__ res, float* __restrict__ out,
+                                                         long long n_pix, int c, int act) {
+    const int c4n = c >> 2;
+    const int cg = threadIdx.x % c4n;
+    const int pl = threadIdx.x / c4n;
+    const int ppb = 256 / c4n;
+    const Coef4 k = load_coef(coef, c, cg);
+    for (long long p = (long long)blockIdx.x * ppb + pl; p < n_pix; p += (long long)gridDim.x * ppb) {
+        const size_t i = (size_t)p * c + cg * 4;
+        f32x4 y = ld4(z, i) * k.scale + k.shift;
+        if (act == RCF_ACT_LEAKY_RELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = rcf_lrelu(y[j]);
+        }
+        if (res != nullptr) {
+            const f32x4 r = ld4(res, i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = rcf_lrelu(y[j] + r[j]);
+        }
+        st4(out, i, y);
+    }
+}
+
+__global__ void __launch_bounds__(256) fuse_fwd_kernel(const float* __restrict__ zw, const float* __restrict__ coef_w,
+                                                       const float* __restrict__ zp, const float* __restrict__ coef_p,
+                                                       const float* __restrict__ img, float* __restrict__ out,
+                                                       long long n_pix, int c) {
+    const int c4n = c >> 2;
+    const int cg = threadIdx.x % c4n;
+    const int pl = threadIdx.x / c4n;
+    const int ppb = 256 / c4n;
+    const Coef4 kw = load_coef(coef_w, c, cg);
+    const Coef4 kp = load_coef(coef_p, c, cg);
+    for (long long p = (long long)blockIdx.x * ppb + pl; p < n_pix; p += (long long)gridDim.x * ppb) {
+        const size_t i = (size_t)p * c + cg * 4;
+        const f32x4 yw = ld4(zw, i) * kw.scale + kw.shift;
+        const f32x4 yp = ld4(zp, i) * kp.scale + kp.shift;
+        const f32x4 im = ld4(img, i);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (1.f / (1.f + expf(-yw[j]))) * yp[j] + im[j];
+        st4(out, i, o);
+    }
+}
+
+// ---------------------------------------------------------------- block reduction of NS per-channel sums
+// Each thread holds s[NS][4] for its channel group; result row layout: partial[blk][NS][c].
+template <int NS>
+__device__ __forceinline__ void block_reduce_store(const float (&s)[NS][4], float* __restrict__ partial_row, int c,
+                                                   int cg, int pl, float* sm) {
+    const int c4n = c >> 2;
+    const int ppb = 256 / c4n;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm[(pl * NS + q) * c + cg * 4 + j] = s[q][j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < NS * c; e += 256) {
+        float t = 0.f;
+        for (int r = 0; r < ppb; ++r) t += sm[r * NS * c + e];
+        partial_row[e] = t;
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+                                                                const float* __restrict__ coef, const float* __restrict__ out,
+                                                                float* __restrict__ partials, long long n_pix, int c, int act,
+                                                                int has_res) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int c4n = c >> 2;
+    const int cg = threadIdx.x % c4n;
+    const int pl = threadIdx.x / c4n;
+    const int ppb = 256 / c4n;
+    const Coef4 k = load_coef(coef, c, cg);
+    float s[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (long long p = (long long)blockIdx.x * ppb + pl; p < n_pix; p += (long long)gridDim.x * ppb) {
+        const size_t i = (size_t)p * c + cg * 4;
+        f32x4 g = ld4(dout, i);
+        const f32x4 zz = ld4(z, i);
+        if (has_res) {
+            const f32x4 o = ld4(out, i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] *= rcf_lrelu_grad(o[j]);
+        }
+        const f32x4 y = zz * k.scale + k.shift;
+        const f32x4 xh = (zz - k.mean) * k.invstd;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (act == RCF_ACT_LEAKY_RELU) g[j] *= rcf_lrelu_grad(y[j]);
+            s[0][j] += g[j];
+            s[1][j] += g[j] * xh[j];
+        }
+    }
+    block_reduce_store<2>(s, partials + (size_t)blockIdx.x * 2 * c, c, cg, pl, sm);
+}
+
+__global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+                                                               const float* __restrict__ coef, const float* __restrict__ out,
+                                                               const float* __restrict__ bcoef, float* __restrict__ dz,
+                                                               float* __restrict__ dres, int dres_accumulate, long long n_pix,
+                                                               int c, int act, int has_res) {
+    const int c4n = c >> 2;
+    const int cg = threadIdx.x % c4n;
+    const int pl = threadIdx.x / c4n;
+    const int ppb = 256 / c4n;
+    const Coef4 k = load_coef(coef, c, cg);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bcoef + cg * 4);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bcoef + c + cg * 4);
+    for (long long p = (long long)blockIdx.x * ppb + pl; p < n_pix; p += (long long)gridDim.x * ppb) {
+        const size_t i = (size_t)p * c + cg * 4;
+        f32x4 g = ld4(dout, i);
+        const f32x4 zz = ld4(z, i);
+        if (has_res) {
+            const f32x4 o = ld4(out, i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] *= rcf_lrelu_grad(o[j]);
+            if (dres != nullptr) {
+                f32x4 d = g;
+                if (dres_accumulate) d += ld4(dres, i);
+                st4(dres, i, d);
+            }
+        }
+        const f32x4 y = zz * k.scale + k.shift;
+        const f32x4 xh = (zz - k.mean) * k.invstd;
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gj = g[j];
+            if (act == RCF_ACT_LEAKY_RELU) gj *= rcf_lrelu_grad(y[j]);
+            r[j] = k.scale[j] * (gj - b0[j] - xh[j] * b1[j]);
+        }
+        st4(dz, i, r);
+    }
+}
+
+__global__ void __launch_bounds__(256) fuse_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ zw,
+                                                              const float* __restrict__ coef_w, const float* __restrict__ zp,
+                                                              const float* __restrict__ coef_p, float* __restrict__ partials,
+                                                              long long n_pix, int c) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int c4n = c >> 2;
+    const int cg = threadIdx.x % c4n;
+    const int pl = threadIdx.x / c4n;
+    const int ppb = 256 / c4n;
+    const Coef4 kw = load_coef(coef_w, c, cg);
+    const Coef4 kp = load_coef(coef_p, c, cg);
+    float s[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[q][j] = 0.f;
+    for (long long p = (long long)blockIdx.x * ppb + pl; p < n_pix; p += (long long)gridDim.x * ppb) {
+        const size_t i = (size_t)p * c + cg * 4;
+        const f32x4 g = ld4(dout, i);
+        const f32x4 a = ld4(zw, i);
+        const f32x4 b = ld4(zp, i);
+        const f32x4 yw = a * kw.scale + kw.shift;
+        const f32x4 yp = b * kp.scale + kp.shift;
+        const f32x4 xw = (a - kw.mean) * kw.invstd;
+        const f32x4 xp = (b - kp.mean) * kp.invstd;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sg = 1.f / (1.f + expf(-yw[j]));
+            const float gw = g[j] * yp[j] * sg * (1.f - sg);
+            const float gp = g[j] * sg;
+            s[0][j] += gw;
+            s[1][j] += gw * xw[j];
+            s[2][j] += gp;
+            s[3][j] += gp * xp[j];
+        }
+    }
+    block_reduce_store<4>(s, partials + (size_t)blockIdx.x * 4 * c, c, cg, pl, sm);
+}
+
+__global__ void __launch_bounds__(256) fuse_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ zw,
+                                                             const float* __restrict__ coef_w, const float* __restrict__ zp,
+                                                             const float* __restrict__ coef_p, const float* __restrict__ bcw,
+                                                             const float* __restrict__ bcp, float* __restrict__ dzw,
+                                                             float* __restrict__ dzp, float* __restrict__ dimg,
+                                                             int dimg_accumulate, long long n_pix, int c) {
+    const int c4n = c >> 2;
+    const int cg = threadIdx.x % c4n;
+    const int pl = threadIdx.x / c4n;
+    const int ppb = 256 / c4n;
+    const Coef4 kw = load_coef(coef_w, c, cg);
+    const Coef4 kp = load_coef(coef_p, c, cg);
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(bcw + cg * 4);
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(bcw + c + cg * 4);
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(bcp + cg * 4);
+    const f32x4 p1 = *reinterpret_cast<const f32x4*>(bcp + c + cg * 4);
+    for (long long p = (long long)blockIdx.x * ppb + pl; p < n_pix; p += (long long)gridDim.x * ppb) {
+        const size_t i = (size_t)p * c + cg * 4;
+        const f32x4 g = ld4(dout, i);
+        const f32x4 a = ld4(zw, i);
+        const f32x4 b = ld4(zp, i);
+        const f32x4 yw = a * kw.scale + kw.shift;
+        const f32x4 yp = b * kp.scale + kp.shift;
+        const f32x4 xw = (a - kw.mean) * kw.invstd;
+        const f32x4 xp = (b - kp.mean) * kp.invstd;
+        f32x4 rw, rp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sg = 1.f / (1.f + expf(-yw[j]));
+            const float gw = g[j] * yp[j] * sg * (1.f - sg);
+            const float gp = g[j] * sg;
+            rw[j] = kw.scale[j] * (gw - w0[j] - xw[j] * w1[j]);
+            rp[j] = kp.scale[j] * (gp - p0[j] - xp[j] * p1[j]);
+        }
+        st4(dzw, i, rw);
+        st4(dzp, i, rp);
+        if (dimg != nullptr) {
+            f32x4 d = g;
+            if (dimg_accumulate) d += ld4(dimg, i);
+            st4(dimg, i, d);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- finalize kernels (one block per channel)
+__device__ __forceinline__ double block_sum_double(double v, double* smd) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) smd[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += smd[w];
+    return t;
+}
+
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ partials, int n_partials, int c,
+                                                          double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float momentum, float eps,
+                                                          int training, float* __restrict__ coef) {
+    __shared__ double smd[8];
+    const int ch = blockIdx.x;
+    double mean, var;
+    if (training) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = threadIdx.x; r < n_partials; r += blockDim.x) {
+            s1 += (double)partials[((size_t)r * 2 + 0) * c + ch];
+            s2 += (double)partials[((size_t)r * 2 + 1) * c + ch];
+        }
+        s1 = block_sum_double(s1, smd);
+        s2 = block_sum_double(s2, smd);
+        mean = s1 / count;
+        var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+    } else {
+        mean = (double)running_mean[ch];
+        var = (double)running_var[ch];
+    }
+    if (threadIdx.x == 0) {
+        const double invstd = 1.0 / sqrt(var + (double)eps);
+        const double scale = (double)gamma[ch] * invstd;
+        coef[0 * c + ch] = (float)scale;
+        coef[1 * c + ch] = (float)((double)beta[ch] - mean * scale);
+        coef[2 * c + ch] = (float)mean;
+        coef[3 * c + ch] = (float)invstd;
+        if (training) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[ch] = (float)((1.0 - (double)momentum) * (double)running_mean[ch] + (double)momentum * mean);
+            running_var[ch] = (float)((1.0 - (double)momentum) * (double)running_var[ch] + (double)momentum * unbiased);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __restrict__ partials, int n_blocks, int stride,
+                                                             int c, double count, float* __restrict__ bcoef,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int ch = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = threadIdx.x; r < n_blocks; r += 64) {
+        s1 += (double)partials[(size_t)r * stride + ch];
+        s2 += (double)partials[(size_t)r * stride + c + ch];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s1 += __shfl_xor(s1, off);
+        s2 += __shfl_xor(s2, off);
+    }
+    if (threadIdx.x == 0) {
+        bcoef[ch] = (float)(s1 / count);
+        bcoef[c + ch] = (float)(s2 / count);
+        dbeta[ch] = (float)s1;
+        dgamma[ch] = (float)s2;
+    }
+}
+
+}   // namespace
+
+extern "C" int rcf_ew_blocks(long long n_pix, int c) {
+    if (n_pix <= 0 || !c4_ok(c)) return RCF_EINVAL;
+    return ew_blocks(n_pix, c);
+}
+
+extern "C" int rcf_bn_finalize(const float* partials, int n_partials, int c, double count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               int training, float* coef, void* stream) {
+    if (c <= 0 || !gamma || !beta || !running_mean || !running_var || !coef) return RCF_EINVAL;
+    if (training && (!partials || n_partials <= 0 || count <= 0.0)) return RCF_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, partials, n_partials, c, count, gamma,
+                       beta, running_mean, running_var, momentum, eps, training, coef);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_bn_act_fwd(const float* z, const float* coef, const float* res, float* out, long long n_pix, int c,
+                              int act, void* stream) {
+    if (!z || !coef || !out || n_pix <= 0) return RCF_EINVAL;
+    if (!c4_ok(c)) return RCF_EUNSUPPORTED;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, z, coef, res, out,
+                       n_pix, c, act);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_fuse_fwd(const float* zw, const float* coef_w, const float* zp, const float* coef_p, const float* img,
+                            float* out, long long n_pix, int c, void* stream) {
+    if (!zw || !coef_w || !zp || !coef_p || !img || !out || n_pix <= 0) return RCF_EINVAL;
+    if (!c4_ok(c)) return RCF_EUNSUPPORTED;
+    hipLaunchKernelGGL(fuse_fwd_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, zw, coef_w, zp, coef_p,
+                       img, out, n_pix, c);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_bn_act_bwd_reduce(const float* dout, const float* z, const float* coef, const float* out, float* partials,
+                                     long long n_pix, int c, int act, int has_res, void* stream) {
+    if (!dout || !z || !coef || !partials || n_pix <= 0 || (has_res && !out)) return RCF_EINVAL;
+    if (!c4_ok(c)) return RCF_EUNSUPPORTED;
+    const int ppb = 256 / (c >> 2);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), (size_t)ppb * 2 * c * sizeof(float),
+                       (hipStream_t)stream, dout, z, coef, out, partials, n_pix, c, act, has_res);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_bn_bwd_finalize(const float* partials, int n_blocks, int partial_stride, int c, double count, float* bcoef,
+                                   float* dgamma, float* dbeta, void* stream) {
+    if (!partials || n_blocks <= 0 || c <= 0 || partial_stride < 2 * c || count <= 0.0 || !bcoef || !dgamma || !dbeta)
+        return RCF_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(64), 0, (hipStream_t)stream, partials, n_blocks, partial_stride, c,
+                       count, bcoef, dgamma, dbeta);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_bn_act_bwd_apply(const float* dout, const float* z, const float* coef, const float* out, const float* bcoef,
+                                    float* dz, float* dres, int dres_accumulate, long long n_pix, int c, int act, int has_res,
+                                    void* stream) {
+    if (!dout || !z || !coef || !bcoef || !dz || n_pix <= 0 || (has_res && !out)) return RCF_EINVAL;
+    if (!c4_ok(c)) return RCF_EUNSUPPORTED;
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, dout, z, coef, out,
+                       bcoef, dz, dres, dres_accumulate, n_pix, c, act, has_res);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_fuse_bwd_reduce(const float* dout, const float* zw, const float* coef_w, const float* zp,
+                                   const float* coef_p, float* partials, long long n_pix, int c, void* stream) {
+    if (!dout || !zw || !coef_w || !zp || !coef_p || !partials || n_pix <= 0) return RCF_EINVAL;
+    if (!c4_ok(c)) return RCF_EUNSUPPORTED;
+    const int ppb = 256 / (c >> 2);
+    hipLaunchKernelGGL(fuse_bwd_reduce_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), (size_t)ppb * 4 * c * sizeof(float),
+                       (hipStream_t)stream, dout, zw, coef_w, zp, coef_p, partials, n_pix, c);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_fuse_bwd_apply(const float* dout, const float* zw, const float* coef_w, const float* zp, const float* coef_p,
+                                  const float* bcoef_w, const float* bcoef_p, float* dzw, float* dzp, float* dimg,
+                                  int dimg_accumulate, long long n_pix, int c, void* stream) {
+    if (!dout || !zw || !coef_w || !zp || !coef_p || !bcoef_w || !bcoef_p || !dzw || !dzp || n_pix <= 0) return RCF_EINVAL;
+    if (!c4_ok(c)) return RCF_EUNSUPPORTED;
+    hipLaunchKernelGGL(fuse_bwd_apply_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, dout, zw, coef_w, zp,
+                       coef_p, bcoef_w, bcoef_p, dzw, dzp, dimg, dimg_accumulate, n_pix, c);
+    return rcf_launch_status();
+}

@@ -1,0 +1,586 @@
+// The remaining (HBM-bound) pieces of the FusionNet training step on gfx950: max pool, nearest-upsample
+// backward, the 3x3 C->1 output head fused with the depth map, masked L1 loss, Adam, layout transforms and the
+// radar point->grid scatter.  Reference citations are in include/rcf_hip.h next to each entry point.
+#include "rcf_common.h"
+
+namespace {
+
+inline unsigned nblk(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+// ---------------------------------------------------------------- MaxPool2d(3, 2, 1)
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          unsigned char* __restrict__ idx, int n, int h, int w, int c, int ho,
+                                                          int wo) {
+    const int c4n = c >> 2;
+    const long long total = (long long)n * ho * wo * c4n;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        long long t = g;
+        const int cg = t % c4n; t /= c4n;
+        const int ox = t % wo; t /= wo;
+        const int oy = t % ho;
+        const int img = t / ho;
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned bi[4] = {0, 0, 0, 0};
+        bool any = false;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if (iy < 0 || iy >= h) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if (ix < 0 || ix >= w) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((size_t)img * h + iy) * w + ix) * c + cg * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!any || v[j] > best[j] || v[j] != v[j]) { best[j] = v[j]; bi[j] = ky * 3 + kx; }
+                }
+                any = true;
+            }
+        }
+        const size_t o = (((size_t)img * ho + oy) * wo + ox) * c + cg * 4;
+        *reinterpret_cast<f32x4*>(out + o) = best;
+        *reinterpret_cast<unsigned*>(idx + o) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    }
+}
+
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ idx,
+                                                          float* __restrict__ din, int acc, int n, int h, int w, int c, int ho,
+                                                          int wo) {
+    const int c4n = c >> 2;
+    const long long total = (long long)n * h * w * c4n;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        long long t = g;
+        const int cg = t % c4n; t /= c4n;
+        const int ix = t % w; t /= w;
+        const int iy = t % h;
+        const int img = t / h;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        // output rows whose 3-window [2oy-1, 2oy+1] contains iy
+        const int oy_lo = iy >> 1, oy_hi = (iy + 1) >> 1;
+        const int ox_lo = ix >> 1, ox_hi = (ix + 1) >> 1;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            if (oy >= ho) continue;
+            const int ky = iy - (oy * 2 - 1);
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                if (ox >= wo) continue;
+                const unsigned tap = ky * 3 + (ix - (ox * 2 - 1));
+                const size_t o = (((size_t)img * ho + oy) * wo + ox) * c + cg * 4;
+                const unsigned pk = *reinterpret_cast<const unsigned*>(idx + o);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dout + o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (((pk >> (8 * j)) & 0xffu) == tap) s[j] += d[j];
+            }
+        }
+        const size_t i = (((size_t)img * h + iy) * w + ix) * c + cg * 4;
+        if (acc) s += *reinterpret_cast<const f32x4*>(din + i);
+        *reinterpret_cast<f32x4*>(din + i) = s;
+    }
+}
+
+// ---------------------------------------------------------------- nearest upsample backward
+__device__ __forceinline__ int nearest_src(int dst, float scale, int n_src) {
+    return min((int)floorf((float)dst * scale), n_src - 1);
+}
+// [lo, hi) of destination indices that map to source index s (the map is monotone non-decreasing)
+__device__ __forceinline__ void nearest_range(int s, float scale, int n_src, int n_dst, int* lo, int* hi) {
+    int d = (int)((float)s / scale) - 2;
+    if (d < 0) d = 0;
+    while (d < n_dst && nearest_src(d, scale, n_src) < s) ++d;
+    *lo = d;
+    while (d < n_dst && nearest_src(d, scale, n_src) == s) ++d;
+    *hi = d;
+}
+
+__global__ void __launch_bounds__(256) upsample_bwd_kernel(const float* __restrict__ dup, float* __restrict__ dsrc, int acc,
+                                                           int n, int hu, int wu, int hs, int ws, int c, float sy, float sx) {
+    const int c4n = c >> 2;
+    const long long total = (long long)n * hs * ws * c4n;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        long long t = g;
+        const int cg = t % c4n; t /= c4n;
+        const int x = t % ws; t /= ws;
+        const int y = t % hs;
+        const int img = t / hs;
+        int y0, y1, x0, x1;
+        nearest_range(y, sy, hs, hu, &y0, &y1);
+        nearest_range(x, sx, ws, wu, &x0, &x1);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int yy = y0; yy < y1; ++yy)
+            for (int xx = x0; xx < x1; ++xx)
+                s += *reinterpret_cast<const f32x4*>(dup + (((size_t)img * hu + yy) * wu + xx) * c + cg * 4);
+        const size_t i = (((size_t)img * hs + y) * ws + x) * c + cg * 4;
+        if (acc) s += *reinterpret_cast<const f32x4*>(dsrc + i);
+        *reinterpret_cast<f32x4*>(dsrc + i) = s;
+    }
+}
+
+// ---------------------------------------------------------------- output head: conv3x3 C->1 + depth map
+// One lane per (pixel, 4-channel group): a pixel's C channels are one contiguous run, so each wave load is
+// fully coalesced; the C/4 partial dot products are combined with lane shuffles.
+__global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                       float* __restrict__ logit, float* __restrict__ depth, int n, int h, int w,
+                                                       int c, float dmin, float dmax) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [tap][c]
+    const int c4n = c >> 2;
+    for (int i = threadIdx.x; i < 9 * c; i += 256) wl[(i % 9) * c + i / 9] = wgt[i];   // OIHW [1][c][3][3] -> [tap][c]
+    __syncthreads();
+    const long long npix = (long long)n * h * w;
+    const long long total = npix * c4n;
+    const long long span = (long long)gridDim.x * 256;
+    const long long iters = (total + span - 1) / span;
+    for (long long it = 0; it < iters; ++it) {
+        const long long g = it * span + (long long)blockIdx.x * 256 + threadIdx.x;
+        const bool live = g < total;
+        const long long p = live ? g / c4n : 0;
+        const int cg = live ? (int)(g % c4n) : 0;
+        const int px = p % w;
+        const int py = (p / w) % h;
+        const long long img = p / ((long long)w * h);
+        float s = 0.f;
+        if (live) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = py - 1 + ky;
+                if (iy < 0 || iy >= h) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = px - 1 + kx;
+                    if (ix < 0 || ix >= w) continue;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((img * h + iy) * w + ix) * c + cg * 4);
+                    const f32x4 k = *reinterpret_cast<const f32x4*>(wl + (ky * 3 + kx) * c + cg * 4);
+                    s += v[0] * k[0] + v[1] * k[1] + v[2] * k[2] + v[3] * k[3];
+                }
+            }
+        }
+        for (int off = 1; off < c4n; off <<= 1) s += __shfl_xor(s, off);
+        if (live && cg == 0) {
+            logit[p] = s;
+            depth[p] = dmin / (1.f / (1.f + expf(-s)) + dmin / dmax);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) head_bwd_logit_kernel(const float* __restrict__ ddepth, const float* __restrict__ logit,
+                                                             float* __restrict__ dlogit, long long n, float dmin, float dmax) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float sg = 1.f / (1.f + expf(-logit[i]));
+        const float den = sg + dmin / dmax;
+        dlogit[i] = ddepth[i] * (-dmin / (den * den)) * sg * (1.f - sg);
+    }
+}
+
+__global__ void __launch_bounds__(256) head_bwd_dgrad_kernel(const float* __restrict__ dl, const float* __restrict__ wgt,
+                                                             float* __restrict__ dx, int n, int h, int w, int c) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    const int c4n = c >> 2;
+    for (int i = threadIdx.x; i < 9 * c; i += 256) wl[(i % 9) * c + i / 9] = wgt[i];
+    __syncthreads();
+    const long long total = (long long)n * h * w * c4n;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const long long p = g / c4n;
+        const int cg = (int)(g % c4n);
+        const int px = p % w;
+        const int py = (p / w) % h;
+        const long long img = p / ((long long)w * h);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        // forward: o[q] = sum x[q + (ky-1,kx-1)] w[tap]  =>  dx[p] = sum_tap dl[p - (ky-1,kx-1)] w[tap]
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int qy = py + 1 - ky;
+            if (qy < 0 || qy >= h) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int qx = px + 1 - kx;
+                if (qx < 0 || qx >= w) continue;
+                const float d = dl[(img * h + qy) * w + qx];
+                s += d * *reinterpret_cast<const f32x4*>(wl + (ky * 3 + kx) * c + cg * 4);
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + p * c + cg * 4) = s;
+    }
+}
+
+constexpr int HEAD_WG_BLOCKS = 1024;
+
+__global__ void __launch_bounds__(256) head_bwd_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dl,
+                                                             float* __restrict__ ws, int n, int h, int w, int c) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int c4n = c >> 2;
+    const int cg = threadIdx.x % c4n;
+    const int pl = threadIdx.x / c4n;
+    const int ppb = 256 / c4n;
+    float acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = 0.f;
+    const long long npix = (long long)n * h * w;
+    for (long long p = (long long)blockIdx.x * ppb + pl; p < npix; p += (long long)gridDim.x * ppb) {
+        const int px = p % w;
+        const int py = (p / w) % h;
+        const long long img = p / ((long long)w * h);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + p * c + cg * 4);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int qy = py + 1 - ky;
+            if (qy < 0 || qy >= h) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int qx = px + 1 - kx;
+                if (qx < 0 || qx >= w) continue;
+                const float d = dl[(img * h + qy) * w + qx];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[ky * 3 + kx][j] += d * v[j];
+            }
+        }
+    }
+    // block reduce: sm[pl][tap][c]
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm[(pl * 9 + t) * c + cg * 4 + j] = acc[t][j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 9 * c; e += 256) {
+        float s = 0.f;
+        for (int r = 0; r < ppb; ++r) s += sm[r * 9 * c + e];
+        ws[(size_t)blockIdx.x * 9 * c + e] = s;
+    }
+}
+
+// ws[nb][tap][c] -> dw OIHW [1][c][3][3]
+__global__ void __launch_bounds__(64) head_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nb,
+                                                               int c) {
+    const int e = blockIdx.x;   // tap*c + ch
+    double s = 0.0;
+    for (int r = threadIdx.x; r < nb; r += 64) s += (double)ws[(size_t)r * 9 * c + e];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (threadIdx.x == 0) dw[(e % c) * 9 + e / c] = (float)s;
+}
+
+// ---------------------------------------------------------------- masked L1 loss
+constexpr int LOSS_BLOCKS = 1024;
+
+__global__ void __launch_bounds__(256) l1_loss_partial_kernel(const float* __restrict__ d, const float* __restrict__ gt,
+                                                              const float* __restrict__ lidar, float* __restrict__ ws,
+                                                              long long n) {
+    __shared__ float sm[4][4];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float dv = d[i], l = lidar[i];
+        const float g = l > 0.f ? 0.f : gt[i];   // mask out ground truth where lidar is available
+        if (g > 0.f) { s[0] += fabsf(dv - g); s[1] += 1.f; }
+        if (l > 0.f) { s[2] += fabsf(dv - l); s[3] += 1.f; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s[q] += __shfl_xor(s[q], off);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        for (int q = 0; q < 4; ++q) sm[wave][q] = s[q];
+    __syncthreads();
+    if (threadIdx.x < 4) ws[blockIdx.x * 4 + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) l1_loss_final_kernel(const float* __restrict__ ws, int nb, double* __restrict__ sums) {
+    __shared__ double sm[4][4];
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r = threadIdx.x; r < nb; r += 256)
+        for (int q = 0; q < 4; ++q) s[q] += (double)ws[r * 4 + q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s[q] += __shfl_xor(s[q], off);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        for (int q = 0; q < 4; ++q) sm[wave][q] = s[q];
+    __syncthreads();
+    if (threadIdx.x < 4) sums[threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+__global__ void l1_loss_value_kernel(const double* __restrict__ sums, float w_lidar, float* __restrict__ loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double ls = sums[0] / sums[1];          // mean over an empty set is NaN, as F.l1_loss
+        const double ll = w_lidar > 0.f ? sums[2] / sums[3] : 0.0;
+        loss[0] = (float)(ls + (double)w_lidar * ll);
+        loss[1] = (float)ls;
+        loss[2] = (float)ll;
+    }
+}
+
+__global__ void __launch_bounds__(256) l1_loss_bwd_kernel(const float* __restrict__ d, const float* __restrict__ gt,
+                                                          const float* __restrict__ lidar, const double* __restrict__ sums,
+                                                          const float* __restrict__ upstream, float w_lidar,
+                                                          float* __restrict__ dd, long long n) {
+    const float up = upstream ? upstream[0] : 1.f;
+    const float kg = (float)((double)up / sums[1]);
+    const float kl = w_lidar > 0.f ? (float)((double)up * (double)w_lidar / sums[3]) : 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float dv = d[i], l = lidar[i];
+        const float g = l > 0.f ? 0.f : gt[i];
+        float r = 0.f;
+        if (g > 0.f) { const float e = dv - g; r += kg * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)); }
+        if (l > 0.f && w_lidar > 0.f) { const float e = dv - l; r += kl * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)); }
+        dd[i] = r;
+    }
+}
+
+// ---------------------------------------------------------------- Adam over one flat arena
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                   float wd, float step_size, float inv_bc2_sqrt) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+// ---------------------------------------------------------------- layout
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int c,
+                                                           long long hw) {
+    const long long total = (long long)n * c * hw;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const int ch = o % c;
+        const long long p = (o / c) % hw;
+        const long long img = o / ((long long)c * hw);
+        out[o] = in[(img * c + ch) * hw + p];
+    }
+}
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int c,
+                                                           long long hw) {
+    const long long total = (long long)n * c * hw;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const long long p = o % hw;
+        const int ch = (o / hw) % c;
+        const long long img = o / ((long long)c * hw);
+        out[o] = in[(img * hw + p) * c + ch];
+    }
+}
+
+// ---------------------------------------------------------------- radar point -> dense map scatter
+// One thread per output pixel, looping over the K points in order (K <= ~100).  The canvas is W + 2*pad wide
+// (pad = Wc/2); crop k occupies canvas columns [int(x_k) - pad, int(x_k) + pad); the output is canvas columns
+// [pad, pad + W).  Crop rows are the bottom `hc` rows of the canvas.
+__global__ void __launch_bounds__(256) radar_scatter_kernel(const float* __restrict__ crops, const float* __restrict__ pts, int k,
+                                                            int h, int w, int hc, int wc, int strict, float* __restrict__ depth,
+                                                            float* __restrict__ resp) {
+    const int pad = wc / 2;
+    const long long total = (long long)h * w;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const int x = g % w;
+        const int y = g / w;
+        const int cx = x + pad;           // canvas column
+        const int cy = y - (h - hc);      // crop row
+        float best = 0.f;                 // torch.max over tiles of a zero canvas: first max wins, all-zero -> index 0
+        int arg = 0;
+        bool first = true;
+        for (int i = 0; i < k; ++i) {
+            const int x0 = (int)pts[i * 3 + 0] - pad;
+            float v = 0.f;
+            const int u = cx - x0;
+            if (cy >= 0 && u >= 0 && u < 2 * pad && u < wc) {
+                v = crops[((size_t)i * hc + cy) * wc + u];
+                if (v < 0.5f) v = 0.f;    // thresholding any response less than 0.5 to 0
+            }
+            if (first || v > best) { best = v; arg = i; first = false; }
+        }
+        float dz;
+        if (strict) {
+            // reference: int64 `output` holds the argmax; for point_idx in order: where(output == idx, z_idx, output),
+            // z truncated toward zero on the int64 fill, applied in place and sequentially.
+            long long o = arg;
+            for (int i = 0; i < k; ++i)
+                if (o == (long long)i) o = (long long)pts[i * 3 + 2];
+            dz = (float)o;
+        } else {
+            dz = pts[arg * 3 + 2];
+        }
+        if (best == 0.f) dz = 0.f;        // leave as 0s if we did not predict
+        depth[g] = dz;
+        resp[g] = best;
+    }
+}
+
+}   // namespace
+
+extern "C" int rcf_maxpool3x3s2_fwd(const float* in, float* out, unsigned char* idx, int n, int h, int w, int c, void* stream) {
+    if (!in || !out || !idx || n <= 0 || h <= 0 || w <= 0 || c <= 0) return RCF_EINVAL;
+    if (c & 3) return RCF_EUNSUPPORTED;
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long long total = (long long)n * ho * wo * (c >> 2);
+    unsigned b = nblk(total, 256); if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, in, out, idx, n, h, w, c, ho, wo);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_maxpool3x3s2_bwd(const float* dout, const unsigned char* idx, float* din, int din_accumulate, int n, int h,
+                                    int w, int c, void* stream) {
+    if (!dout || !idx || !din || n <= 0 || h <= 0 || w <= 0 || c <= 0) return RCF_EINVAL;
+    if (c & 3) return RCF_EUNSUPPORTED;
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long long total = (long long)n * h * w * (c >> 2);
+    unsigned b = nblk(total, 256); if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, dout, idx, din, din_accumulate, n, h, w, c,
+                       ho, wo);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_upsample_nearest_bwd(const float* dup, float* dsrc, int dsrc_accumulate, int n, int h_up, int w_up,
+                                        int h_src, int w_src, int c, void* stream) {
+    if (!dup || !dsrc || n <= 0 || h_up <= 0 || w_up <= 0 || h_src <= 0 || w_src <= 0 || c <= 0) return RCF_EINVAL;
+    if (c & 3) return RCF_EUNSUPPORTED;
+    const long long total = (long long)n * h_src * w_src * (c >> 2);
+    unsigned b = nblk(total, 256); if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, dup, dsrc, dsrc_accumulate, n, h_up, w_up,
+                       h_src, w_src, c, (float)h_src / (float)h_up, (float)w_src / (float)w_up);
+    return rcf_launch_status();
+}
+
+static bool head_c_ok(int c) {
+    if (c < 4 || (c & 3)) return false;
+    const int c4 = c >> 2;
+    return (c4 & (c4 - 1)) == 0 && c4 <= 64;
+}
+
+extern "C" int rcf_head_fwd(const float* x, const float* w, float* logit, float* depth, int n, int h, int w_, int c,
+                            float min_depth, float max_depth, void* stream) {
+    if (!x || !w || !logit || !depth || n <= 0 || h <= 0 || w_ <= 0) return RCF_EINVAL;
+    if (!head_c_ok(c)) return RCF_EUNSUPPORTED;
+    const long long total = (long long)n * h * w_ * (c >> 2);
+    unsigned b = nblk(total, 256); if (b > 16384) b = 16384;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(b), dim3(256), 9 * c * sizeof(float), (hipStream_t)stream, x, w, logit, depth, n, h,
+                       w_, c, min_depth, max_depth);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_head_bwd_logit(const float* ddepth, const float* logit, float* dlogit, long long n_pix, float min_depth,
+                                  float max_depth, void* stream) {
+    if (!ddepth || !logit || !dlogit || n_pix <= 0) return RCF_EINVAL;
+    unsigned b = nblk(n_pix, 256); if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(head_bwd_logit_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, ddepth, logit, dlogit, n_pix, min_depth,
+                       max_depth);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_head_bwd_dgrad(const float* dlogit, const float* w, float* dx, int n, int h, int w_, int c, void* stream) {
+    if (!dlogit || !w || !dx || n <= 0 || h <= 0 || w_ <= 0) return RCF_EINVAL;
+    if (!head_c_ok(c)) return RCF_EUNSUPPORTED;
+    const long long total = (long long)n * h * w_ * (c >> 2);
+    unsigned b = nblk(total, 256); if (b > 16384) b = 16384;
+    hipLaunchKernelGGL(head_bwd_dgrad_kernel, dim3(b), dim3(256), 9 * c * sizeof(float), (hipStream_t)stream, dlogit, w, dx, n, h,
+                       w_, c);
+    return rcf_launch_status();
+}
+
+extern "C" size_t rcf_head_wgrad_workspace_floats(int n, int h, int w_, int c) {
+    (void)n; (void)h; (void)w_;
+    return (size_t)HEAD_WG_BLOCKS * 9 * (size_t)c;
+}
+
+extern "C" int rcf_head_bwd_wgrad(const float* x, const float* dlogit, float* dw, float* workspace, int n, int h, int w_, int c,
+                                  void* stream) {
+    if (!x || !dlogit || !dw || !workspace || n <= 0 || h <= 0 || w_ <= 0) return RCF_EINVAL;
+    if (!head_c_ok(c)) return RCF_EUNSUPPORTED;
+    const int ppb = 256 / (c >> 2);
+    long long nb = ((long long)n * h * w_ + ppb - 1) / ppb;
+    if (nb > HEAD_WG_BLOCKS) nb = HEAD_WG_BLOCKS;
+    hipLaunchKernelGGL(head_bwd_wgrad_kernel, dim3((unsigned)nb), dim3(256), (size_t)ppb * 9 * c * sizeof(float),
+                       (hipStream_t)stream, x, dlogit, workspace, n, h, w_, c);
+    int rc = rcf_launch_status();
+    if (rc != RCF_OK) return rc;
+    hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(9 * c), dim3(64), 0, (hipStream_t)stream, workspace, dw, (int)nb, c);
+    return rcf_launch_status();
+}
+
+extern "C" size_t rcf_loss_workspace_floats(long long n_pix) {
+    (void)n_pix;
+    return (size_t)LOSS_BLOCKS * 4;
+}
+
+extern "C" int rcf_l1_loss_fwd(const float* depth, const float* gt, const float* lidar, float* workspace, double* sums,
+                               long long n_pix, void* stream) {
+    if (!depth || !gt || !lidar || !workspace || !sums || n_pix <= 0) return RCF_EINVAL;
+    long long nb = (n_pix + 255) / 256;
+    if (nb > LOSS_BLOCKS) nb = LOSS_BLOCKS;
+    hipLaunchKernelGGL(l1_loss_partial_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, depth, gt, lidar, workspace,
+                       n_pix);
+    int rc = rcf_launch_status();
+    if (rc != RCF_OK) return rc;
+    hipLaunchKernelGGL(l1_loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, (int)nb, sums);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_l1_loss_value(const double* sums, float w_lidar, float* loss, void* stream) {
+    if (!sums || !loss) return RCF_EINVAL;
+    hipLaunchKernelGGL(l1_loss_value_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, w_lidar, loss);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_l1_loss_bwd(const float* depth, const float* gt, const float* lidar, const double* sums, const float* upstream,
+                               float w_lidar, float* ddepth, long long n_pix, void* stream) {
+    if (!depth || !gt || !lidar || !sums || !ddepth || n_pix <= 0) return RCF_EINVAL;
+    unsigned b = nblk(n_pix, 256); if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(l1_loss_bwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, depth, gt, lidar, sums, upstream, w_lidar,
+                       ddepth, n_pix);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step <= 0) return RCF_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    unsigned b = nblk(n, 256); if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(adam_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                       step_size, inv_bc2_sqrt);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, void* stream) {
+    if (!in || !out || n <= 0 || c <= 0 || h <= 0 || w <= 0) return RCF_EINVAL;
+    const long long total = (long long)n * c * h * w;
+    unsigned b = nblk(total, 256); if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, in, out, n, c, (long long)h * w);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, void* stream) {
+    if (!in || !out || n <= 0 || c <= 0 || h <= 0 || w <= 0) return RCF_EINVAL;
+    const long long total = (long long)n * c * h * w;
+    unsigned b = nblk(total, 256); if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, in, out, n, c, (long long)h * w);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_radar_scatter(const float* crops, const float* points, int k, int h, int w, int wc, int strict_reference,
+                                 float* depth, float* response, void* stream) {
+    if (!crops || !points || !depth || !response || k <= 0 || h <= 0 || w <= 0 || wc <= 0 || (wc & 1)) return RCF_EINVAL;
+    const long long total = (long long)h * w;
+    unsigned b = nblk(total, 256); if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(radar_scatter_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, crops, points, k, h, w, h, wc,
+                       strict_reference, depth, response);
+    return rcf_launch_status();
+}
+
+extern "C" const char* rcf_version(void) { return "rcf_hip 0.1.0 (gfx950, fp32 mfma_f32_32x32x2)"; }
+
+extern "C" int rcf_device_ok(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
+    const char* arch = prop.gcnArchName;
+    return (arch[0] == 'g' && arch[1] == 'f' && arch[2] == 'x' && arch[3] == '9' && arch[4] == '5' && arch[5] == '0') ? 1 : 0;
+}

@@ -1,0 +1,330 @@
+'''
+Execution engine for the FusionNet hot path: runs FusionNetEncoder.forward (src/networks.py:840-1005),
+MultiScaleDecoder.forward (src/networks.py:1557-1657) and the depth map of FusionNetModel.forward
+(src/fusionnet_model.py:160-165) as a sequence of HIP kernel launches on the caller's stream, and records a
+tape of backward closures that replaces autograd for this path (loss.backward(), src/fusionnet_main.py:398).
+
+Why a tape and not torch.autograd per op: the engine controls which tensors exist (the upsampled and the
+concatenated decoder tensors never do), in what order gradients are produced (so gradient buckets can be
+all-reduced while the encoder's backward is still running) and where every gradient accumulates (dgrad kernels
+accumulate in place; no generic add kernels).  Torch owns memory and the stream only.
+
+Layout: activations (N, H, W, C) fp32 contiguous.  BN layers keep the raw conv output z and the per-channel
+coefficients; the activation is materialised once (round 1; folding it into the consumer's operand load is the
+next step -- DESIGN.md section 6).
+'''
+
+import torch
+
+from . import ops
+from ._lib import RCF_ACT_LEAKY_RELU, RCF_ACT_NONE, RCF_GATHER_DIRECT, RCF_GATHER_NEAREST
+
+BN_EPS = 1e-5       # torch.nn.BatchNorm2d default (src/net_utils.py:82)
+BN_MOMENTUM = 0.1
+
+
+class Act(object):
+    '''An activation tensor and (during backward) its gradient accumulator.'''
+    __slots__ = ('t', 'g', 'needs_grad')
+
+    def __init__(self, t, needs_grad=True):
+        self.t = t
+        self.g = None
+        self.needs_grad = needs_grad
+
+
+class Engine(object):
+    def __init__(self, encoder, decoder, min_predict_depth, max_predict_depth):
+        self.encoder = encoder
+        self.decoder = decoder
+        self.dmin = float(min_predict_depth)
+        self.dmax = float(max_predict_depth)
+        self.grad_of = None        # callable: parameter -> gradient tensor to write (set by the model)
+        self.on_param_grad = None  # callable(parameter): called once the parameter's gradient is enqueued
+        self.tape = None
+        self.training = True
+        self.kernel_log = None     # optional list collecting (layer, kernel_id) for profiling
+        self.prof = None           # optional KernelTimer: brackets conv launches with events on the launch stream
+
+    # ------------------------------------------------------------------ helpers
+    def _new(self, shape, ref):
+        return torch.empty(shape, dtype=torch.float32, device=ref.device)
+
+    def _wgrad_done(self, *params):
+        if self.on_param_grad is not None:
+            for p in params:
+                self.on_param_grad(p)
+
+    def _conv(self, layer, x, x2=None, up_hw=None, want_stats=False):
+        '''conv (+ folded nearest-upsample of x to up_hw, + folded channel concat with x2) -> raw output z.'''
+        n, h, w, c1 = x.t.shape
+        c2 = 0 if x2 is None else x2.t.shape[3]
+        h_in, w_in, gather = h, w, RCF_GATHER_DIRECT
+        if up_hw is not None and (int(up_hw[0]), int(up_hw[1])) != (h, w):
+            h_in, w_in, gather = int(up_hw[0]), int(up_hw[1]), RCF_GATHER_NEAREST
+        if x2 is not None and tuple(x2.t.shape[1:3]) != (h_in, w_in):
+            raise ValueError('skip connection and upsampled tensor disagree in size')
+        weight = layer.conv.weight
+        desc = ops.make_fwd_desc(n, h_in, w_in, c1, c2, weight.shape[0], layer.kernel_size, layer.stride, h, w, gather)
+        info = ops.conv_query(desc)
+        packed = self._new((info.packed_weight_floats,), x.t)
+        ops.conv_pack(desc, weight.detach(), packed)
+        z = self._new((n, desc.h_out, desc.w_out, desc.c_out), x.t)
+        partials = self._new((info.n_partials, 2, desc.c_out), x.t) if want_stats else None
+        if self.prof is not None:
+            self.prof.begin(info.kernel_id, ops.algorithmic_flops(desc))
+        ops.conv_fwd(desc, x.t, None if x2 is None else x2.t, packed, z, partials)
+        if self.prof is not None:
+            self.prof.end()
+        if self.kernel_log is not None:
+            self.kernel_log.append((desc.ksize, desc.stride, desc.c1 + desc.c2, desc.c_out, desc.h_out, desc.w_out,
+                                    info.kernel_id))
+        return z, desc, info, partials
+
+    def _conv_backward(self, layer, desc, info, x, x2, dz):
+        '''dW (written once into the parameter's gradient) and dX / dX2 (accumulated into the producers' .g).'''
+        weight = layer.conv.weight
+        dw = self.grad_of(weight)
+        ws = self._new((max(1, info.wgrad_workspace_floats),), dz)
+        if self.prof is not None:
+            self.prof.begin(info.wgrad_kernel_id, ops.algorithmic_flops(desc))
+        ops.conv_wgrad(desc, x.t, None if x2 is None else x2.t, dz, dw, ws)
+        if self.prof is not None:
+            self.prof.end()
+        self._wgrad_done(weight)
+        for src, off, cnt in ((x, 0, desc.c1), (x2, desc.c1, desc.c2)):
+            if src is None or not src.needs_grad:
+                continue
+            if src is x and desc.gather1 == RCF_GATHER_NEAREST:
+                dd = ops.make_dgrad_desc(desc, off, cnt, False)
+                tmp = self._new((desc.n, desc.h_in, desc.w_in, cnt), dz)
+                self._run_dgrad(dd, weight, dz, tmp)
+                acc = src.g is not None
+                if not acc:
+                    src.g = torch.empty_like(src.t)
+                ops.upsample_nearest_bwd(tmp, src.g, acc)
+            else:
+                acc = src.g is not None
+                if not acc:
+                    src.g = torch.empty_like(src.t)
+                dd = ops.make_dgrad_desc(desc, off, cnt, acc)
+                self._run_dgrad(dd, weight, dz, src.g)
+
+    def _run_dgrad(self, dd, weight, dz, out):
+        info = ops.conv_query(dd)
+        packed = self._new((info.packed_weight_floats,), dz)
+        ops.conv_pack(dd, weight.detach(), packed)
+        if self.prof is not None:
+            self.prof.begin(info.kernel_id, ops.algorithmic_flops(dd))
+        ops.conv_fwd(dd, dz, None, packed, out, None)
+        if self.prof is not None:
+            self.prof.end()
+
+    def _bn_coef(self, layer, partials, info, z):
+        bn = layer.batch_norm
+        c = z.shape[3]
+        coef = self._new((4, c), z)
+        count = z.shape[0] * z.shape[1] * z.shape[2]
+        ops.bn_finalize(partials, info.n_partials if partials is not None else 0, c, count, bn.weight.detach(),
+                        bn.bias.detach(), bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, self.training, coef)
+        return coef
+
+    # ------------------------------------------------------------------ layer ops
+    def conv_bn_act(self, layer, x, x2=None, up_hw=None, res=None):
+        '''
+        net_utils.Conv2d.forward (src/net_utils.py:84-91) with BN + leaky_relu (+ the residual tail of
+        ResNetBlock.forward when res is given: lrelu(lrelu(BN(conv)) + res), src/net_utils.py:311-323).
+        '''
+        if not layer.use_batch_norm or layer.activation_func != 'leaky_relu':
+            raise ValueError('conv_bn_act expects a BatchNorm + leaky_relu Conv2d block')
+        z, desc, info, partials = self._conv(layer, x, x2, up_hw, want_stats=self.training)
+        coef = self._bn_coef(layer, partials, info, z)
+        n_pix = z.shape[0] * z.shape[1] * z.shape[2]
+        c = z.shape[3]
+        out = Act(torch.empty_like(z))
+        ops.bn_act_fwd(z, coef, None if res is None else res.t, out.t, n_pix, c, RCF_ACT_LEAKY_RELU)
+        if self.tape is not None:
+            bn = layer.batch_norm
+            batch_stats = self.training
+
+            def backward():
+                dout = out.g
+                nb = ops.ew_blocks(n_pix, c)
+                bpart = self._new((nb, 2, c), z)
+                has_res = res is not None
+                ops.bn_act_bwd_reduce(dout, z, coef, out.t, bpart, n_pix, c, RCF_ACT_LEAKY_RELU, has_res)
+                bcoef = self._new((2, c), z)
+                ops.bn_bwd_finalize(bpart, nb, 2 * c, c, n_pix, bcoef, self.grad_of(bn.weight), self.grad_of(bn.bias))
+                if not batch_stats:
+                    bcoef.zero_()   # eval-mode BN is affine: no batch-statistic terms in dz
+                self._wgrad_done(bn.weight, bn.bias)
+                dz = torch.empty_like(z)
+                dres, dres_acc = None, False
+                if has_res and res.needs_grad:
+                    dres_acc = res.g is not None
+                    if not dres_acc:
+                        res.g = torch.empty_like(res.t)
+                    dres = res.g
+                ops.bn_act_bwd_apply(dout, z, coef, out.t, bcoef, dz, dres, dres_acc, n_pix, c, RCF_ACT_LEAKY_RELU, has_res)
+                out.g = None
+                self._conv_backward(layer, desc, info, x, x2, dz)
+
+            self.tape.append(backward)
+        return out
+
+    def conv_plain(self, layer, x):
+        '''Conv2d without BN and activation (ResNetBlock.projection, src/net_utils.py:300-307).'''
+        if layer.use_batch_norm or layer.activation_func is not None:
+            raise ValueError('conv_plain expects a bare conv')
+        z, desc, info, _ = self._conv(layer, x)
+        out = Act(z)
+        if self.tape is not None:
+            def backward():
+                dz = out.g
+                out.g = None
+                self._conv_backward(layer, desc, info, x, None, dz)
+            self.tape.append(backward)
+        return out
+
+    def fuse(self, layer_w, layer_p, dep, img):
+        '''conv_weight * conv_project + image (src/networks.py:863-866): sigmoid(BN(W1 d)) * BN(W2 d) + img.'''
+        zw, dw_, iw, pw = self._conv(layer_w, dep, want_stats=self.training)
+        zp, dp_, ip, pp = self._conv(layer_p, dep, want_stats=self.training)
+        coef_w = self._bn_coef(layer_w, pw, iw, zw)
+        coef_p = self._bn_coef(layer_p, pp, ip, zp)
+        n_pix = zw.shape[0] * zw.shape[1] * zw.shape[2]
+        c = zw.shape[3]
+        out = Act(torch.empty_like(zw))
+        ops.fuse_fwd(zw, coef_w, zp, coef_p, img.t, out.t, n_pix, c)
+        if self.tape is not None:
+            bnw, bnp = layer_w.batch_norm, layer_p.batch_norm
+            batch_stats = self.training
+
+            def backward():
+                dout = out.g
+                nb = ops.ew_blocks(n_pix, c)
+                bpart = self._new((nb, 4, c), zw)
+                ops.fuse_bwd_reduce(dout, zw, coef_w, zp, coef_p, bpart, n_pix, c)
+                bcw = self._new((2, c), zw)
+                bcp = self._new((2, c), zw)
+                ops.bn_bwd_finalize(bpart, nb, 4 * c, c, n_pix, bcw, self.grad_of(bnw.weight), self.grad_of(bnw.bias))
+                ops.bn_bwd_finalize(bpart.view(-1)[2 * c:], nb, 4 * c, c, n_pix, bcp, self.grad_of(bnp.weight),
+                                    self.grad_of(bnp.bias))
+                if not batch_stats:
+                    bcw.zero_()
+                    bcp.zero_()
+                self._wgrad_done(bnw.weight, bnw.bias, bnp.weight, bnp.bias)
+                dzw = torch.empty_like(zw)
+                dzp = torch.empty_like(zp)
+                dimg, dimg_acc = None, False
+                if img.needs_grad:
+                    dimg_acc = img.g is not None
+                    if not dimg_acc:
+                        img.g = torch.empty_like(img.t)
+                    dimg = img.g
+                ops.fuse_bwd_apply(dout, zw, coef_w, zp, coef_p, bcw, bcp, dzw, dzp, dimg, dimg_acc, n_pix, c)
+                out.g = None
+                self._conv_backward(layer_w, dw_, iw, dep, None, dzw)
+                self._conv_backward(layer_p, dp_, ip, dep, None, dzp)
+
+            self.tape.append(backward)
+        return out
+
+    def max_pool(self, x):
+        '''torch.nn.MaxPool2d(3, 2, 1) (src/networks.py:392-395).'''
+        n, h, w, c = x.t.shape
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        out = Act(self._new((n, ho, wo, c), x.t))
+        idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.t.device)
+        ops.maxpool_fwd(x.t, out.t, idx)
+        if self.tape is not None:
+            def backward():
+                acc = x.g is not None
+                if not acc:
+                    x.g = torch.empty_like(x.t)
+                ops.maxpool_bwd(out.g, idx, x.g, acc)
+                out.g = None
+            self.tape.append(backward)
+        return out
+
+    def resnet_block(self, block, x):
+        '''ResNetBlock.forward (src/net_utils.py:309-323).'''
+        c1 = self.conv_bn_act(block.conv1, x)
+        shortcut = self.conv_plain(block.projection, x) if block.uses_projection else x
+        return self.conv_bn_act(block.conv2, c1, res=shortcut)
+
+    def decoder_block(self, block, x, skip=None, shape=None):
+        '''DecoderBlock.forward (src/net_utils.py:535-569), deconv_type 'up'.'''
+        if skip is not None:
+            shape = skip.t.shape[1:3]
+        elif shape is None:
+            shape = (2 * x.t.shape[1], 2 * x.t.shape[2])
+        deconv = self.conv_bn_act(block.deconv.conv, x, up_hw=shape)
+        if block.skip_channels > 0:
+            return self.conv_bn_act(block.conv, deconv, x2=skip)
+        return self.conv_bn_act(block.conv, deconv)
+
+    def head(self, layer, x):
+        '''output0 (src/networks.py:1548-1555, :1654) + d = min/(sigmoid(o)+min/max) (src/fusionnet_model.py:162-165).'''
+        n, h, w, c = x.t.shape
+        weight = layer.conv.weight
+        logit = self._new((n, h, w), x.t)
+        depth = Act(self._new((n, h, w), x.t))
+        ops.head_fwd(x.t, weight.detach(), logit, depth.t, self.dmin, self.dmax)
+        if self.tape is not None:
+            def backward():
+                dlogit = torch.empty_like(logit)
+                ops.head_bwd_logit(depth.g, logit, dlogit, self.dmin, self.dmax)
+                depth.g = None
+                ops.head_bwd_wgrad(x.t, dlogit, self.grad_of(weight))
+                self._wgrad_done(weight)
+                if x.needs_grad:
+                    if x.g is not None:
+                        raise RuntimeError('head input has another consumer')
+                    x.g = torch.empty_like(x.t)
+                    ops.head_bwd_dgrad(dlogit, weight.detach(), x.g)
+            self.tape.append(backward)
+        return depth
+
+    # ------------------------------------------------------------------ the network
+    def forward(self, image_nhwc, depth_nhwc, training, record):
+        '''
+        image_nhwc (N,H,W,3), depth_nhwc (N,H,W,2) -> depth (N,H,W) as an Act.  record=True keeps the tape for
+        backward(); record=False is the no_grad / eval path of validate()/run() (src/fusionnet_main.py:517, :814).
+        '''
+        enc, dec = self.encoder, self.decoder
+        self.training = bool(training)
+        self.tape = [] if record else None
+        img = self.conv_bn_act(enc.conv1_image, Act(image_nhwc, needs_grad=False))
+        dep = self.conv_bn_act(enc.conv1_depth, Act(depth_nhwc, needs_grad=False))
+        layers = [self.fuse(enc.conv1_weight, enc.conv1_project, dep, img)]
+        img = self.max_pool(img)
+        dep = self.max_pool(dep)
+        for lvl in range(2, enc.network_depth + 1):
+            for blk_i, blk_d in zip(getattr(enc, 'blocks%d_image' % lvl), getattr(enc, 'blocks%d_depth' % lvl)):
+                img = self.resnet_block(blk_i, img)
+                dep = self.resnet_block(blk_d, dep)
+            layers.append(self.fuse(getattr(enc, 'conv%d_weight' % lvl), getattr(enc, 'conv%d_project' % lvl), dep, img))
+        latent, skips = layers[-1], layers[:-1]
+
+        # MultiScaleDecoder.forward, n_resolution == 1 (src/networks.py:1571-1657)
+        x = latent
+        n = len(skips) - 1
+        names = dec.block_names
+        for name in names[:-1]:
+            x = self.decoder_block(getattr(dec, name), x, skip=skips[n])
+            n -= 1
+        if n == 0:
+            x = self.decoder_block(dec.deconv0, x, skip=skips[0])
+        else:
+            x = self.decoder_block(dec.deconv0, x, shape=image_nhwc.shape[1:3])
+        out = self.head(dec.output0, x)
+        tape, self.tape = self.tape, None
+        return out, tape
+
+    @staticmethod
+    def backward(out, tape, ddepth):
+        '''Run the recorded tape in reverse.  ddepth: (N,H,W) gradient of the loss w.r.t. the output depth.'''
+        out.g = ddepth
+        while tape:
+            tape.pop()()

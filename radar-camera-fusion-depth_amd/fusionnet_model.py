@@ -1,0 +1,418 @@
+'''
+FusionNetModel -- drop-in for the reference's src/fusionnet_model.py:7-587 on MI355X.
+
+Same constructor arguments, same methods (forward, compute_loss, parameters, train, eval, to, save_model,
+restore_model, data_parallel, log_summary), same checkpoint dictionary and state_dict names, so the reference's
+training loop (src/fusionnet_main.py:180-200, :369-399, :428-451) runs unchanged:
+
+    output_depth = model.forward(image=image, input_depth=input_depth)
+    loss, loss_info = model.compute_loss(...)
+    optimizer.zero_grad(); loss.backward(); optimizer.step()
+
+forward() and compute_loss() return torch tensors that participate in autograd, but everything between the
+inputs and the loss runs on the hand-written HIP kernels of librcf_hip.so through engine.py; loss.backward()
+replays the engine's tape and leaves each parameter's .grad as a view into one flat gradient arena (which is
+what the bucketed RCCL all-reduce and the fused Adam operate on).  There is no CPU path: a missing library or a
+CPU tensor raises.
+'''
+
+import torch
+
+from . import _lib, networks, ops
+from .engine import Engine
+
+
+class _FusionNetFunction(torch.autograd.Function):
+    '''Bridges the engine's tape into torch.autograd: one node for the whole encoder-decoder.'''
+
+    @staticmethod
+    def forward(ctx, model, image, input_depth, anchor):
+        out, tape = model._run_engine(image, input_depth, record=True)
+        ctx.model = model
+        ctx.out = out
+        ctx.tape = tape
+        return out.t.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        model, out, tape = ctx.model, ctx.out, ctx.tape
+        if tape is None:
+            raise RuntimeError('FusionNetModel: backward through the same forward twice')
+        ctx.tape = None
+        n, _, h, w = grad_output.shape
+        ddepth = grad_output.contiguous().view(n, h, w)
+        model._backward(out, tape, ddepth)
+        return None, None, None, None
+
+
+class _MaskedL1Function(torch.autograd.Function):
+    '''compute_loss with loss_func='l1' (src/fusionnet_model.py:209-253) on the HIP loss kernels.'''
+
+    @staticmethod
+    def forward(ctx, output_depth, ground_truth, lidar_map, w_lidar, model):
+        d = output_depth.contiguous()
+        gt = ground_truth.contiguous()
+        lidar = lidar_map.contiguous()
+        sums = torch.empty(4, dtype=torch.float64, device=d.device)
+        ops.l1_loss_fwd(d, gt, lidar, sums)
+        if model is not None:
+            model._all_reduce_loss_sums(sums)
+        loss = torch.empty(3, dtype=torch.float32, device=d.device)
+        ops.l1_loss_value(sums, float(w_lidar), loss)
+        ctx.save_for_backward(d, gt, lidar, sums)
+        ctx.w_lidar = float(w_lidar)
+        ctx.mark_non_differentiable(loss)
+        return loss[0].clone(), loss
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_terms):
+        d, gt, lidar, sums = ctx.saved_tensors
+        dd = torch.empty_like(d)
+        up = grad_loss.contiguous().view(1).to(torch.float32)
+        ops.l1_loss_bwd(d, gt, lidar, sums, up, ctx.w_lidar, dd)
+        return dd, None, None, None, None
+
+
+class FusionNetModel(object):
+    '''
+    Image radar fusion (see the reference docstring, src/fusionnet_model.py:8-44, for the argument meanings).
+    '''
+
+    def __init__(self,
+                 input_channels_image,
+                 input_channels_depth,
+                 encoder_type,
+                 n_filters_encoder_image,
+                 n_filters_encoder_depth,
+                 fusion_type,
+                 decoder_type,
+                 n_resolution_decoder,
+                 n_filters_decoder,
+                 deconv_type,
+                 activation_func,
+                 weight_initializer,
+                 min_predict_depth,
+                 max_predict_depth,
+                 device=torch.device('cuda')):
+
+        self.encoder_type = encoder_type
+        self.min_predict_depth = min_predict_depth
+        self.max_predict_depth = max_predict_depth
+        self.device = torch.device(device)
+
+        # src/fusionnet_model.py:68-82
+        if fusion_type in ('add', 'weight', 'weight_and_project'):
+            n_filters_encoder = n_filters_encoder_image
+            latent_channels = n_filters_encoder[-1]
+        elif fusion_type == 'concat':
+            n_filters_encoder = [i + z for i, z in zip(n_filters_encoder_image, n_filters_encoder_depth)]
+            latent_channels = n_filters_encoder[-1]
+        else:
+            raise ValueError('Unsupported fusion type: {}'.format(fusion_type))
+
+        # src/fusionnet_model.py:84-115
+        if 'fusionnet18' in encoder_type or 'resnet18' in encoder_type:
+            n_layer = 18
+        elif 'fusionnet34' in encoder_type or 'resnet34' in encoder_type:
+            n_layer = 34
+        else:
+            raise ValueError('Unsupported encoder type: {}'.format(encoder_type))
+
+        if 'fusionnet18' in encoder_type or 'fusionnet34' in encoder_type:
+            self.encoder = networks.FusionNetEncoder(
+                n_layer=n_layer,
+                input_channels_image=input_channels_image,
+                input_channels_depth=input_channels_depth,
+                n_filters_encoder_image=n_filters_encoder_image,
+                n_filters_encoder_depth=n_filters_encoder_depth,
+                weight_initializer=weight_initializer,
+                activation_func=activation_func,
+                use_batch_norm='batch_norm' in encoder_type,
+                fusion_type=fusion_type)
+        else:
+            # the reference's image-only ResNetEncoder (:103-113) is not on the FusionNet hot path
+            raise ValueError('Unsupported encoder type on the HIP path: {}'.format(encoder_type))
+
+        n_skips = list(n_filters_encoder[:-1])
+        n_skips = n_skips[::-1] + [0]                                            # :118-119
+
+        if 'multiscale' in decoder_type:
+            self.decoder = networks.MultiScaleDecoder(
+                input_channels=latent_channels,
+                output_channels=1,
+                n_resolution=n_resolution_decoder,
+                n_filters=n_filters_decoder,
+                n_skips=n_skips,
+                weight_initializer=weight_initializer,
+                activation_func=activation_func,
+                output_func='linear',
+                use_batch_norm='batch_norm' in decoder_type,
+                deconv_type=deconv_type)
+        else:
+            raise ValueError('Unsuported decoder type: {}'.format(decoder_type))
+
+        if not ('batch_norm' in encoder_type and 'batch_norm' in decoder_type):
+            raise ValueError('HIP path implements the shipped batch_norm encoder/decoder only')
+
+        self._is_data_parallel = False
+        self._dp = None
+        self._training = True
+        self._anchor = None
+        self._engine = Engine(self.encoder, self.decoder, min_predict_depth, max_predict_depth)
+        self._engine.grad_of = self._grad_of
+        self._param_arena = None
+        self._grad_arena = None
+
+        # Move to device
+        self.to(self.device)
+
+    # ------------------------------------------------------------------ parameter / gradient arenas
+    def _forward_order_params(self):
+        '''Parameters in the order the engine's forward touches them (used ones only).'''
+        enc, dec = self.encoder, self.decoder
+        order = []
+
+        def conv_block(layer):
+            order.append(layer.conv.weight)
+            if layer.use_batch_norm:
+                order.extend([layer.batch_norm.weight, layer.batch_norm.bias])
+
+        def res_block(b):
+            conv_block(b.conv1)
+            if b.uses_projection:
+                conv_block(b.projection)
+            conv_block(b.conv2)
+
+        conv_block(enc.conv1_image); conv_block(enc.conv1_depth)
+        conv_block(enc.conv1_weight); conv_block(enc.conv1_project)
+        for lvl in range(2, enc.network_depth + 1):
+            for bi, bd in zip(getattr(enc, 'blocks%d_image' % lvl), getattr(enc, 'blocks%d_depth' % lvl)):
+                res_block(bi); res_block(bd)
+            conv_block(getattr(enc, 'conv%d_weight' % lvl)); conv_block(getattr(enc, 'conv%d_project' % lvl))
+        for name in dec.block_names:
+            blk = getattr(dec, name)
+            conv_block(blk.deconv.conv); conv_block(blk.conv)
+        conv_block(dec.output0)
+        return order
+
+    def _build_arenas(self):
+        '''
+        One flat fp32 arena for all parameters and one for their gradients.  Layout = reverse forward order
+        (the order gradients become final during backward: decoder first), then the parameters the network never
+        uses (ResNetBlock.projection of shape-preserving blocks: they get no gradient).
+        '''
+        used = self._forward_order_params()[::-1]
+        used_ids = set(id(p) for p in used)
+        unused = [p for p in self.parameters() if id(p) not in used_ids]
+        ordered = used + unused
+        device = self.device
+        total = sum(p.numel() for p in ordered)
+        arena = torch.empty(total, dtype=torch.float32, device=device)
+        garena = torch.zeros(total, dtype=torch.float32, device=device)
+        self._grad_views = {}
+        self._param_offset = {}
+        off = 0
+        with torch.no_grad():
+            for p in ordered:
+                n = p.numel()
+                view = arena[off:off + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                self._grad_views[id(p)] = garena[off:off + n].view(p.shape)
+                self._param_offset[id(p)] = off
+                p._rcf_arena = (arena, garena, off)
+                off += n
+        self._param_arena, self._grad_arena = arena, garena
+        self._used_params = used
+        self._n_used = sum(p.numel() for p in used)
+        # BatchNorm num_batches_tracked: views of one int64 arena, bumped with a single add per training forward
+        bns = [m for mod in (self.encoder, self.decoder) for m in mod.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        self._nbt = torch.zeros(len(bns), dtype=torch.int64, device=device)
+        for i, bn in enumerate(bns):
+            self._nbt[i] = bn.num_batches_tracked.to(device)
+            bn._buffers['num_batches_tracked'] = self._nbt[i]
+        self._anchor = torch.zeros((), dtype=torch.float32, device=device, requires_grad=True)
+        if self._dp is not None:
+            self._dp.rebuild(self)
+
+    def _grad_of(self, p):
+        return self._grad_views[id(p)]
+
+    # ------------------------------------------------------------------ engine entry points
+    def _run_engine(self, image, input_depth, record):
+        if not image.is_cuda:
+            raise _lib.RcfError('FusionNetModel.forward needs CUDA(HIP) tensors: the hot path is HIP-only '
+                                '(got %s)' % image.device)
+        _lib.load()
+        if image.dtype != torch.float32 or input_depth.dtype != torch.float32:
+            raise _lib.RcfError('FusionNetModel.forward is fp32')
+        x_img = ops.nchw_to_nhwc(image.contiguous())
+        x_dep = ops.nchw_to_nhwc(input_depth.contiguous())
+        training = self._training
+        out, tape = self._engine.forward(x_img, x_dep, training=training, record=record)
+        if training:
+            self._nbt += 1
+        return out, tape
+
+    def _backward(self, out, tape, ddepth):
+        used = self._used_params
+        accumulate = any(p.grad is not None for p in used)
+        prev = self._grad_arena[:self._n_used].clone() if accumulate else None
+        if self._dp is not None:
+            self._dp.begin_backward()
+        self._engine.on_param_grad = self._dp.on_param_grad if self._dp is not None else None
+        Engine.backward(out, tape, ddepth)
+        if self._dp is not None:
+            self._dp.finish_backward()
+        if prev is not None:
+            self._grad_arena[:self._n_used].add_(prev)
+        for p in used:
+            p.grad = self._grad_views[id(p)]
+
+    def _all_reduce_loss_sums(self, sums):
+        if self._dp is not None:
+            self._dp.all_reduce_sums(sums)
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, image, input_depth, return_multiscale=False):
+        '''
+        Forwards the inputs through the network (src/fusionnet_model.py:140-170)
+
+        Arg(s):
+            image : torch.Tensor[float32]
+                N x 3 x H x W image
+            input_depth : torch.Tensor[float32]
+                N x 2 x H x W input depth (cat([depth, response]), src/fusionnet_main.py:366)
+            return_multiscale : bool
+                if set, then return multiple outputs
+        Returns:
+            torch.Tensor[float32] : N x 1 x H x W output dense depth
+        '''
+        if torch.is_grad_enabled():
+            output = _FusionNetFunction.apply(self, image, input_depth, self._anchor)
+        else:
+            out, _ = self._run_engine(image, input_depth, record=False)
+            output = out.t.unsqueeze(1)
+        if return_multiscale:
+            return [output]
+        return output
+
+    def compute_loss(self,
+                     image,
+                     output_depth,
+                     ground_truth,
+                     lidar_map,
+                     loss_func,
+                     w_smoothness,
+                     loss_smoothness_kernel_size,
+                     validity_map_loss_smoothness,
+                     w_lidar_loss):
+        '''
+        Computes loss function (src/fusionnet_model.py:172-302); returns (loss, loss_info).
+        The HIP path implements the shipped configuration: loss_func 'l1', w_smoothness 0
+        (bash/train_fusionnet_nuscenes.sh:43-45).
+        '''
+        if isinstance(output_depth, list):
+            if len(output_depth) != 1:
+                raise ValueError('HIP path supports a single output resolution')
+            output_depth = output_depth[0]
+        if loss_func != 'l1':
+            if loss_func in ('l2', 'smoothl1'):
+                raise ValueError('Loss not implemented on the HIP path: {}'.format(loss_func))
+            raise ValueError('No such loss: {}'.format(loss_func))
+        if w_smoothness > 0.0:
+            raise ValueError('Smoothness loss is not implemented on the HIP path (shipped w_smoothness is 0.0)')
+        if w_lidar_loss > 0.0:
+            lidar = lidar_map
+        else:
+            lidar = torch.zeros_like(ground_truth)   # no lidar term and no ground-truth masking (:214-221)
+        loss, terms = _MaskedL1Function.apply(output_depth, ground_truth, lidar, float(max(w_lidar_loss, 0.0)), self)
+        loss_info = {
+            'loss': loss,
+            'loss_supervised': terms[1],
+            'loss_smoothness': 0.0,
+            'loss_lidar': terms[2] if w_lidar_loss > 0.0 else 0.0,
+        }
+        return loss, loss_info
+
+    def parameters(self):
+        '''Returns the list of parameters in the model (src/fusionnet_model.py:304-316)'''
+        return list(self.encoder.parameters()) + list(self.decoder.parameters())
+
+    def train(self):
+        '''Sets model to training mode (batch statistics, running stats updated)'''
+        self.encoder.train()
+        self.decoder.train()
+        self._training = True
+
+    def eval(self):
+        '''Sets model to evaluation mode (running statistics)'''
+        self.encoder.eval()
+        self.decoder.eval()
+        self._training = False
+
+    def to(self, device):
+        '''Moves model to specified device and (re)builds the flat parameter/gradient arenas'''
+        self.device = torch.device(device)
+        self.encoder.to(self.device)
+        self.decoder.to(self.device)
+        self._build_arenas()
+
+    def _state_dicts(self):
+        enc, dec = self.encoder.state_dict(), self.decoder.state_dict()
+        if self._is_data_parallel:
+            # the reference saves after data_parallel(), so its keys carry 'module.' 
+            enc = {'module.' + k: v for k, v in enc.items()}
+            dec = {'module.' + k: v for k, v in dec.items()}
+        return enc, dec
+
+    def save_model(self, checkpoint_path, step, optimizer):
+        '''Save weights of the model to checkpoint path (src/fusionnet_model.py:347-368); same dictionary keys.'''
+        enc, dec = self._state_dicts()
+        checkpoint = {
+            'train_step': step,
+            'optimizer_state_dict': optimizer.state_dict(),
+            'encoder_state_dict': {k: v.detach().clone() for k, v in enc.items()},
+            'decoder_state_dict': {k: v.detach().clone() for k, v in dec.items()},
+        }
+        torch.save(checkpoint, checkpoint_path)
+
+    def restore_model(self, checkpoint_path, optimizer=None):
+        '''Restore weights of the model (src/fusionnet_model.py:370-393); accepts keys with or without 'module.'.'''
+        checkpoint = torch.load(checkpoint_path, map_location=self.device)
+
+        def strip(sd):
+            return {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in sd.items()}
+
+        self.encoder.load_state_dict(strip(checkpoint['encoder_state_dict']))
+        self.decoder.load_state_dict(strip(checkpoint['decoder_state_dict']))
+        if optimizer is not None:
+            optimizer.load_state_dict(checkpoint['optimizer_state_dict'])
+        return checkpoint['train_step'], optimizer
+
+    def data_parallel(self):
+        '''
+        Allows multi-gpu split along batch (src/fusionnet_model.py:395-401).  The reference wraps encoder and
+        decoder in single-process nn.DataParallel; here each GPU has its own process (torch.distributed over
+        RCCL/xGMI) and this call arms the bucketed gradient all-reduce that overlaps with backward.  With one
+        process it only switches the checkpoint key prefix, like the reference.
+        '''
+        self._is_data_parallel = True
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from .parallel import GradientBuckets
+            self._dp = GradientBuckets(self)
+
+    def log_summary(self, summary_writer, tag, step, image=None, input_depth=None, input_response=None,
+                    output_depth=None, ground_truth=None, scalars={}, n_display=4):
+        '''
+        Logs summary (src/fusionnet_model.py:403-587).  Scalars are written when the writer exposes add_scalar;
+        the image grids need torchvision/matplotlib which this image lacks, so they are skipped.
+        '''
+        if summary_writer is None or not hasattr(summary_writer, 'add_scalar'):
+            return
+        with torch.no_grad():
+            for name, value in scalars.items():
+                summary_writer.add_scalar(tag + '_' + name, float(value), global_step=step)
+            if output_depth is not None and hasattr(summary_writer, 'add_histogram'):
+                summary_writer.add_histogram(tag + '_output_depth_distro', output_depth.detach().cpu(), global_step=step)

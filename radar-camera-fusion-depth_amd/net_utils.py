@@ -1,0 +1,110 @@
+'''
+Host-side mirror of the reference's block classes (src/net_utils.py): same constructor arguments, same
+sub-module and parameter names, hence the same state_dict keys -- so the reference's checkpoints load and
+torch.optim.Adam / state_dict work unchanged.
+
+These modules are PARAMETER CONTAINERS.  They do not compute: the forward/backward of the whole network
+runs in engine.py on hand-written HIP kernels (csrc/).  Calling a block's forward() directly raises.
+'''
+
+import torch
+
+LEAKY_SLOPE = 0.20
+
+
+def activation_func(activation_fn):
+    '''
+    src/net_utils.py:4-23.  Returns the activation NAME the engine understands (the reference returns a
+    torch module); raises ValueError for unsupported names exactly like the reference.
+    '''
+    if 'linear' in activation_fn:
+        return None
+    elif 'leaky_relu' in activation_fn:
+        return 'leaky_relu'
+    elif 'sigmoid' in activation_fn:
+        return 'sigmoid'
+    elif 'relu' in activation_fn or 'elu' in activation_fn:
+        raise ValueError('Unsupported activation function on the HIP path: {}'.format(activation_fn))
+    else:
+        raise ValueError('Unsupported activation function: {}'.format(activation_fn))
+
+
+class _NoForward(torch.nn.Module):
+    def forward(self, *args, **kwargs):
+        raise RuntimeError(
+            type(self).__name__ + ' is a parameter container; run the network through FusionNetModel.forward '
+            '(HIP engine). There is no per-block or CPU forward.')
+
+
+class Conv2d(_NoForward):
+    '''src/net_utils.py:29-91: conv(bias=False, padding=k//2) + optional BatchNorm2d + optional activation.'''
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1,
+                 weight_initializer='kaiming_uniform', activation_func='leaky_relu', use_batch_norm=False):
+        super(Conv2d, self).__init__()
+        self.use_batch_norm = use_batch_norm
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.conv = torch.nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                                    padding=kernel_size // 2, bias=False)
+        # src/net_utils.py:72-77 ('kaiming_uniform' keeps torch.nn.Conv2d's default initialisation)
+        if weight_initializer == 'kaiming_normal':
+            torch.nn.init.kaiming_normal_(self.conv.weight)
+        elif weight_initializer == 'xavier_normal':
+            torch.nn.init.xavier_normal_(self.conv.weight)
+        elif weight_initializer == 'xavier_uniform':
+            torch.nn.init.xavier_uniform_(self.conv.weight)
+        self.activation_func = activation_func   # None | 'leaky_relu' | 'sigmoid'
+        if self.use_batch_norm:
+            self.batch_norm = torch.nn.BatchNorm2d(out_channels)
+
+
+class UpConv2d(_NoForward):
+    '''src/net_utils.py:156-198: nearest interpolate to `shape` + Conv2d 3x3.'''
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, weight_initializer='kaiming_uniform',
+                 activation_func='leaky_relu', use_batch_norm=False):
+        super(UpConv2d, self).__init__()
+        self.conv = Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=1,
+                           weight_initializer=weight_initializer, activation_func=activation_func,
+                           use_batch_norm=use_batch_norm)
+
+
+class ResNetBlock(_NoForward):
+    '''src/net_utils.py:253-323.  `projection` (1x1, no BN, no activation) is always allocated (:300-307) and only
+    used when the block changes shape (:317-320) -- 10 of them never receive gradients in the published net.'''
+
+    def __init__(self, in_channels, out_channels, stride=1, weight_initializer='kaiming_uniform',
+                 activation_func='leaky_relu', use_batch_norm=False):
+        super(ResNetBlock, self).__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.stride = stride
+        self.activation_func = activation_func
+        self.conv1 = Conv2d(in_channels, out_channels, 3, stride, weight_initializer, activation_func, use_batch_norm)
+        self.conv2 = Conv2d(out_channels, out_channels, 3, 1, weight_initializer, activation_func, use_batch_norm)
+        self.projection = Conv2d(in_channels, out_channels, 1, stride, weight_initializer, None, False)
+
+    @property
+    def uses_projection(self):
+        return self.stride != 1 or self.in_channels != self.out_channels
+
+
+class DecoderBlock(_NoForward):
+    '''src/net_utils.py:473-569 with deconv_type 'up' (the only one the reference can run).'''
+
+    def __init__(self, in_channels, skip_channels, out_channels, weight_initializer='kaiming_uniform',
+                 activation_func='leaky_relu', use_batch_norm=False, deconv_type='up'):
+        super(DecoderBlock, self).__init__()
+        self.skip_channels = skip_channels
+        self.deconv_type = deconv_type
+        if deconv_type == 'up':
+            self.deconv = UpConv2d(in_channels, out_channels, 3, weight_initializer, activation_func, use_batch_norm)
+        else:
+            # src/net_utils.py:94-153: TransposeConv2d cannot run at 900x1600 (odd sizes) and crashes for
+            # non-default initialisers in the reference itself; the shipped entry points hard-code 'up'.
+            raise ValueError('Unsupported deconv type on the HIP path: {}'.format(deconv_type))
+        self.conv = Conv2d(skip_channels + out_channels, out_channels, 3, 1, weight_initializer, activation_func,
+                           use_batch_norm)

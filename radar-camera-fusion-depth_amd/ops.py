@@ -1,0 +1,264 @@
+'''
+Tensor-level wrappers over the C ABI (include/rcf_hip.h).  torch is used only to own device memory and the
+stream; every computation below is a hand-written HIP kernel in librcf_hip.so.  All activations are fp32 NHWC
+contiguous torch tensors of shape (N, H, W, C); weights are OIHW like torch.nn.Conv2d.weight.
+'''
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ConvDesc, ConvInfo, RCF_ACT_LEAKY_RELU, RCF_ACT_NONE, RCF_GATHER_DIRECT, RCF_GATHER_NEAREST,
+                   RCF_GATHER_ZERO_INSERT, RCF_W_DGRAD, RCF_W_FORWARD, check)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.RcfError('rcf ops need CUDA(HIP) tensors; got a %s tensor -- there is no CPU path' % t.device)
+    if not t.is_contiguous():
+        raise _lib.RcfError('rcf ops need contiguous tensors')
+    return t.data_ptr()
+
+
+def _f32(t):
+    if t is not None and t.dtype != torch.float32:
+        raise _lib.RcfError('rcf ops are fp32; got %s' % t.dtype)
+    return _p(t)
+
+
+def conv_out_hw(h, w, ksize, stride, pad):
+    return (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+
+
+def make_fwd_desc(n, h_in, w_in, c1, c2, c_out, ksize, stride, h_src1=None, w_src1=None, gather=RCF_GATHER_DIRECT):
+    '''Descriptor of the reference's Conv2d (padding = ksize // 2, src/net_utils.py:61) on [src1 | src2].'''
+    pad = ksize // 2
+    h_out, w_out = conv_out_hw(h_in, w_in, ksize, stride, pad)
+    return ConvDesc(n=n, h_in=h_in, w_in=w_in, c1=c1, c2=c2,
+                    h_src1=h_in if h_src1 is None else h_src1, w_src1=w_in if w_src1 is None else w_src1,
+                    gather1=gather, h_out=h_out, w_out=w_out, c_out=c_out, ksize=ksize, stride=stride, pad=pad,
+                    w_mode=RCF_W_FORWARD, w_o=c_out, w_i=c1 + c2, w_i_off=0, accumulate=0)
+
+
+def make_dgrad_desc(fwd, i_off, i_cnt, accumulate):
+    '''
+    The input gradient of the conv `fwd` (on its LOGICAL input, i.e. at the upsampled resolution when the
+    forward gathered), for the input-channel slice [i_off, i_off + i_cnt): itself a stride-1 convolution of dZ
+    with flipped taps and pad ksize-1-pad; a stride-2 forward makes dZ zero-dilated (a transposed convolution).
+    '''
+    k = fwd.ksize
+    return ConvDesc(n=fwd.n, h_in=fwd.h_in, w_in=fwd.w_in, c1=fwd.c_out, c2=0,
+                    h_src1=fwd.h_out, w_src1=fwd.w_out,
+                    gather1=RCF_GATHER_ZERO_INSERT if fwd.stride == 2 else RCF_GATHER_DIRECT,
+                    h_out=fwd.h_in, w_out=fwd.w_in, c_out=i_cnt, ksize=k, stride=1, pad=k - 1 - fwd.pad,
+                    w_mode=RCF_W_DGRAD, w_o=fwd.w_o, w_i=fwd.w_i, w_i_off=i_off, accumulate=1 if accumulate else 0)
+
+
+def algorithmic_flops(desc):
+    """2*MACs of the convolution a descriptor stands for, counted on REAL channels and on the forward conv's
+    output grid (a stride-2 input gradient counts the forward conv's MACs, not the zero-dilated ones)."""
+    k2 = desc.ksize * desc.ksize
+    if desc.w_mode == RCF_W_DGRAD:
+        return 2.0 * desc.n * desc.h_src1 * desc.w_src1 * desc.c1 * k2 * desc.c_out
+    return 2.0 * desc.n * desc.h_out * desc.w_out * desc.c_out * k2 * (desc.c1 + desc.c2)
+
+
+class KernelTimer(object):
+    """Brackets kernel launches with events on the stream they are launched on (torch's current stream is the
+    stream handed to the C ABI) and accumulates (launches, algorithmic flops, ms) per kernel id."""
+
+    def __init__(self, only_ids=None):
+        self.only = None if only_ids is None else set(only_ids)
+        self.pending = []
+        self.cur = None
+
+    def begin(self, kid, flops):
+        if self.only is not None and kid not in self.only:
+            self.cur = None
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.cur = (kid, flops, ev)
+
+    def end(self):
+        if self.cur is None:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.pending.append(self.cur + (ev,))
+        self.cur = None
+
+    def collect(self):
+        """Call after a synchronize.  Returns {kernel id: [launches, flops, ms]}."""
+        out = {}
+        for kid, flops, e0, e1 in self.pending:
+            r = out.setdefault(kid, [0, 0.0, 0.0])
+            r[0] += 1
+            r[1] += flops
+            r[2] += e0.elapsed_time(e1)
+        self.pending = []
+        return out
+
+
+def conv_query(desc):
+    info = ConvInfo()
+    check(_lib.load().rcf_conv2d_query(ctypes.byref(desc), ctypes.byref(info)), 'rcf_conv2d_query')
+    return info
+
+
+def conv_pack(desc, w_oihw, packed):
+    check(_lib.load().rcf_conv2d_pack_weights(ctypes.byref(desc), _f32(w_oihw), _f32(packed), _stream()),
+          'rcf_conv2d_pack_weights')
+
+
+def conv_fwd(desc, in1, in2, packed, out, stat_partials=None):
+    check(_lib.load().rcf_conv2d_fwd(ctypes.byref(desc), _f32(in1), _f32(in2), _f32(packed), _f32(out),
+                                     _f32(stat_partials), _stream()), 'rcf_conv2d_fwd')
+
+
+def conv_wgrad(desc, in1, in2, dz, dw, workspace):
+    check(_lib.load().rcf_conv2d_wgrad(ctypes.byref(desc), _f32(in1), _f32(in2), _f32(dz), _f32(dw), _f32(workspace),
+                                       _stream()), 'rcf_conv2d_wgrad')
+
+
+def bn_finalize(partials, n_partials, c, count, gamma, beta, running_mean, running_var, momentum, eps, training, coef):
+    check(_lib.load().rcf_bn_finalize(_f32(partials), n_partials, c, float(count), _f32(gamma), _f32(beta),
+                                      _f32(running_mean), _f32(running_var), momentum, eps, 1 if training else 0,
+                                      _f32(coef), _stream()), 'rcf_bn_finalize')
+
+
+def bn_act_fwd(z, coef, res, out, n_pix, c, act):
+    check(_lib.load().rcf_bn_act_fwd(_f32(z), _f32(coef), _f32(res), _f32(out), n_pix, c, act, _stream()), 'rcf_bn_act_fwd')
+
+
+def fuse_fwd(zw, coef_w, zp, coef_p, img, out, n_pix, c):
+    check(_lib.load().rcf_fuse_fwd(_f32(zw), _f32(coef_w), _f32(zp), _f32(coef_p), _f32(img), _f32(out), n_pix, c,
+                                   _stream()), 'rcf_fuse_fwd')
+
+
+def ew_blocks(n_pix, c):
+    nb = _lib.load().rcf_ew_blocks(n_pix, c)
+    if nb <= 0:
+        raise _lib.RcfError('rcf_ew_blocks: unsupported channel count %d' % c)
+    return nb
+
+
+def bn_act_bwd_reduce(dout, z, coef, out, partials, n_pix, c, act, has_res):
+    check(_lib.load().rcf_bn_act_bwd_reduce(_f32(dout), _f32(z), _f32(coef), _f32(out), _f32(partials), n_pix, c, act,
+                                            1 if has_res else 0, _stream()), 'rcf_bn_act_bwd_reduce')
+
+
+def bn_bwd_finalize(partials, n_blocks, stride, c, count, bcoef, dgamma, dbeta):
+    check(_lib.load().rcf_bn_bwd_finalize(_f32(partials), n_blocks, stride, c, float(count), _f32(bcoef), _f32(dgamma),
+                                          _f32(dbeta), _stream()), 'rcf_bn_bwd_finalize')
+
+
+def bn_act_bwd_apply(dout, z, coef, out, bcoef, dz, dres, dres_accumulate, n_pix, c, act, has_res):
+    check(_lib.load().rcf_bn_act_bwd_apply(_f32(dout), _f32(z), _f32(coef), _f32(out), _f32(bcoef), _f32(dz), _f32(dres),
+                                           1 if dres_accumulate else 0, n_pix, c, act, 1 if has_res else 0, _stream()),
+          'rcf_bn_act_bwd_apply')
+
+
+def fuse_bwd_reduce(dout, zw, coef_w, zp, coef_p, partials, n_pix, c):
+    check(_lib.load().rcf_fuse_bwd_reduce(_f32(dout), _f32(zw), _f32(coef_w), _f32(zp), _f32(coef_p), _f32(partials),
+                                          n_pix, c, _stream()), 'rcf_fuse_bwd_reduce')
+
+
+def fuse_bwd_apply(dout, zw, coef_w, zp, coef_p, bcoef_w, bcoef_p, dzw, dzp, dimg, dimg_accumulate, n_pix, c):
+    check(_lib.load().rcf_fuse_bwd_apply(_f32(dout), _f32(zw), _f32(coef_w), _f32(zp), _f32(coef_p), _f32(bcoef_w),
+                                         _f32(bcoef_p), _f32(dzw), _f32(dzp), _f32(dimg), 1 if dimg_accumulate else 0,
+                                         n_pix, c, _stream()), 'rcf_fuse_bwd_apply')
+
+
+def maxpool_fwd(x, out, idx):
+    n, h, w, c = x.shape
+    check(_lib.load().rcf_maxpool3x3s2_fwd(_f32(x), _f32(out), _p(idx), n, h, w, c, _stream()), 'rcf_maxpool3x3s2_fwd')
+
+
+def maxpool_bwd(dout, idx, din, accumulate):
+    n, h, w, c = din.shape
+    check(_lib.load().rcf_maxpool3x3s2_bwd(_f32(dout), _p(idx), _f32(din), 1 if accumulate else 0, n, h, w, c, _stream()),
+          'rcf_maxpool3x3s2_bwd')
+
+
+def upsample_nearest_bwd(dup, dsrc, accumulate):
+    n, hu, wu, c = dup.shape
+    _, hs, ws, _ = dsrc.shape
+    check(_lib.load().rcf_upsample_nearest_bwd(_f32(dup), _f32(dsrc), 1 if accumulate else 0, n, hu, wu, hs, ws, c,
+                                               _stream()), 'rcf_upsample_nearest_bwd')
+
+
+def head_fwd(x, w, logit, depth, dmin, dmax):
+    n, h, ww, c = x.shape
+    check(_lib.load().rcf_head_fwd(_f32(x), _f32(w), _f32(logit), _f32(depth), n, h, ww, c, dmin, dmax, _stream()),
+          'rcf_head_fwd')
+
+
+def head_bwd_logit(ddepth, logit, dlogit, dmin, dmax):
+    check(_lib.load().rcf_head_bwd_logit(_f32(ddepth), _f32(logit), _f32(dlogit), logit.numel(), dmin, dmax, _stream()),
+          'rcf_head_bwd_logit')
+
+
+def head_bwd_dgrad(dlogit, w, dx):
+    n, h, ww, c = dx.shape
+    check(_lib.load().rcf_head_bwd_dgrad(_f32(dlogit), _f32(w), _f32(dx), n, h, ww, c, _stream()), 'rcf_head_bwd_dgrad')
+
+
+def head_bwd_wgrad(x, dlogit, dw):
+    n, h, ww, c = x.shape
+    nws = _lib.load().rcf_head_wgrad_workspace_floats(n, h, ww, c)
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+    check(_lib.load().rcf_head_bwd_wgrad(_f32(x), _f32(dlogit), _f32(dw), _f32(ws), n, h, ww, c, _stream()),
+          'rcf_head_bwd_wgrad')
+
+
+def l1_loss_fwd(depth, gt, lidar, sums):
+    n = depth.numel()
+    ws = torch.empty(_lib.load().rcf_loss_workspace_floats(n), dtype=torch.float32, device=depth.device)
+    if sums.dtype != torch.float64:
+        raise _lib.RcfError('l1_loss sums must be float64[4]')
+    check(_lib.load().rcf_l1_loss_fwd(_f32(depth), _f32(gt), _f32(lidar), _f32(ws), _p(sums), n, _stream()), 'rcf_l1_loss_fwd')
+
+
+def l1_loss_value(sums, w_lidar, loss):
+    check(_lib.load().rcf_l1_loss_value(_p(sums), w_lidar, _f32(loss), _stream()), 'rcf_l1_loss_value')
+
+
+def l1_loss_bwd(depth, gt, lidar, sums, upstream, w_lidar, ddepth):
+    check(_lib.load().rcf_l1_loss_bwd(_f32(depth), _f32(gt), _f32(lidar), _p(sums), _f32(upstream), w_lidar, _f32(ddepth),
+                                      depth.numel(), _stream()), 'rcf_l1_loss_bwd')
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    check(_lib.load().rcf_adam_step(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), lr, beta1, beta2, eps, weight_decay,
+                                    step, _stream()), 'rcf_adam_step')
+
+
+def nchw_to_nhwc(x):
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    check(_lib.load().rcf_nchw_to_nhwc(_f32(x), _f32(out), n, c, h, w, _stream()), 'rcf_nchw_to_nhwc')
+    return out
+
+
+def nhwc_to_nchw(x):
+    n, h, w, c = x.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.load().rcf_nhwc_to_nchw(_f32(x), _f32(out), n, c, h, w, _stream()), 'rcf_nhwc_to_nchw')
+    return out
+
+
+def radar_scatter(crops, points, width, strict_reference=True):
+    k, h, wc = crops.shape
+    depth = torch.empty((h, width), dtype=torch.float32, device=crops.device)
+    resp = torch.empty((h, width), dtype=torch.float32, device=crops.device)
+    check(_lib.load().rcf_radar_scatter(_f32(crops), _f32(points), k, h, width, wc, 1 if strict_reference else 0,
+                                        _f32(depth), _f32(resp), _stream()), 'rcf_radar_scatter')
+    return depth, resp

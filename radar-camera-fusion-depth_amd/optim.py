@@ -1,0 +1,115 @@
+'''
+FusedAdam: torch.optim.Adam semantics (the reference's optimizer, src/fusionnet_main.py:307-312) executed as ONE
+HIP kernel launch over the model's flat parameter arena (rcf_adam_step) instead of ~270 per-tensor update chains.
+Same param_group keys and per-parameter state names ('step', 'exp_avg', 'exp_avg_sq') as torch.optim.Adam, so
+optimizer state dicts interchange with the reference's checkpoints.
+'''
+
+import torch
+
+from . import ops
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        if lr < 0.0 or eps < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or weight_decay < 0.0:
+            raise ValueError('Invalid Adam hyper-parameter')
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                        foreach=None, capturable=False, differentiable=False, fused=None,
+                        decoupled_weight_decay=False)
+        super(FusedAdam, self).__init__(params, defaults)
+        self._moment_arenas = {}   # id(param arena) -> (exp_avg arena, exp_avg_sq arena)
+
+    def _init_state(self, p):
+        state = self.state[p]
+        if len(state) != 0:
+            return state
+        arena = getattr(p, '_rcf_arena', None)
+        state['step'] = torch.tensor(0.0, dtype=torch.float32)
+        if arena is not None:
+            parena, _, off = arena
+            key = id(parena)
+            if key not in self._moment_arenas:
+                self._moment_arenas[key] = (torch.zeros_like(parena), torch.zeros_like(parena))
+            m, v = self._moment_arenas[key]
+            state['exp_avg'] = m[off:off + p.numel()].view(p.shape)
+            state['exp_avg_sq'] = v[off:off + p.numel()].view(p.shape)
+        else:
+            state['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return state
+
+    def load_state_dict(self, state_dict):
+        super(FusedAdam, self).load_state_dict(state_dict)
+        # re-home the loaded moments into the flat arenas so the single-launch path stays valid
+        for group in self.param_groups:
+            for p in group['params']:
+                st = self.state.get(p)
+                arena = getattr(p, '_rcf_arena', None)
+                if not st or arena is None:
+                    continue
+                parena, _, off = arena
+                key = id(parena)
+                if key not in self._moment_arenas:
+                    self._moment_arenas[key] = (torch.zeros_like(parena), torch.zeros_like(parena))
+                m, v = self._moment_arenas[key]
+                for name, ar in (('exp_avg', m), ('exp_avg_sq', v)):
+                    view = ar[off:off + p.numel()].view(p.shape)
+                    view.copy_(st[name])
+                    st[name] = view
+                st['step'] = torch.as_tensor(float(st['step']), dtype=torch.float32)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            params = [p for p in group['params'] if p.grad is not None]
+            if not params:
+                continue
+            if group.get('amsgrad') or group.get('maximize'):
+                raise ValueError('FusedAdam: amsgrad / maximize are not implemented')
+            beta1, beta2 = group['betas']
+            states = [self._init_state(p) for p in params]
+            for st in states:
+                st['step'] += 1
+            if not self._flat_step(group, params, states, beta1, beta2):
+                for p, st in zip(params, states):
+                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    if not p.data.is_contiguous() or not st['exp_avg'].is_contiguous():
+                        raise RuntimeError('FusedAdam needs contiguous parameters')
+                    ops.adam_step(p.data.view(-1), g.view(-1), st['exp_avg'].view(-1), st['exp_avg_sq'].view(-1),
+                                  group['lr'], beta1, beta2, group['eps'], group['weight_decay'], int(st['step']))
+        return loss
+
+    def _flat_step(self, group, params, states, beta1, beta2):
+        '''One launch over [lo, hi) of the arena when the parameters with gradients tile it exactly.'''
+        first = getattr(params[0], '_rcf_arena', None)
+        if first is None:
+            return False
+        parena, garena, _ = first
+        step0 = int(states[0]['step'])
+        lo, hi, total = None, None, 0
+        for p, st in zip(params, states):
+            a = getattr(p, '_rcf_arena', None)
+            if a is None or a[0] is not parena or int(st['step']) != step0:
+                return False
+            off, n = a[2], p.numel()
+            if p.grad.data_ptr() != garena.data_ptr() + 4 * off:
+                return False
+            if p.data.data_ptr() != parena.data_ptr() + 4 * off:
+                return False
+            m, v = self._moment_arenas.get(id(parena), (None, None))
+            if m is None or st['exp_avg'].data_ptr() != m.data_ptr() + 4 * off:
+                return False
+            lo = off if lo is None else min(lo, off)
+            hi = off + n if hi is None else max(hi, off + n)
+            total += n
+        if hi - lo != total:
+            return False
+        m, v = self._moment_arenas[id(parena)]
+        ops.adam_step(parena[lo:hi], garena[lo:hi], m[lo:hi], v[lo:hi], group['lr'], beta1, beta2, group['eps'],
+                      group['weight_decay'], step0)
+        return True

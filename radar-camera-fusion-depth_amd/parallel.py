@@ -1,0 +1,92 @@
+'''
+Data parallelism for the FusionNet training step: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference only has single-process torch.nn.DataParallel (src/fusionnet_model.py:395-401), which gathers the
+whole batch's outputs on GPU 0, computes ONE masked-mean loss there (src/fusionnet_main.py:385) and reduce-adds
+the replicas' gradients.  The equivalent here:
+  * every rank computes the local loss sums and valid-pixel counts; the 4 scalars are all-reduced BEFORE backward,
+    so each rank's gradient is already normalised by the GLOBAL counts;
+  * parameter gradients are all-reduced with SUM (no 1/world factor) in a few contiguous buckets of the flat
+    gradient arena.  The arena is laid out in the order gradients become final (decoder first), so a bucket is
+    launched on RCCL's stream as soon as the tape has produced its last gradient, overlapping the rest of backward.
+  * BatchNorm statistics stay per replica, as in nn.DataParallel; parameters that never get a gradient
+    (10 unused projections) sit outside every bucket.
+'''
+
+import torch
+import torch.distributed as dist
+
+
+class GradientBuckets(object):
+    def __init__(self, model, n_buckets=6, group=None):
+        self.n_buckets = n_buckets
+        self.group = group
+        self.handles = []
+        self.rebuild(model)
+
+    def rebuild(self, model):
+        used = model._used_params
+        total = model._n_used
+        target = max(1, (total + self.n_buckets - 1) // self.n_buckets)
+        self.garena = model._grad_arena
+        self.bounds = []          # (lo, hi) element ranges of the gradient arena
+        self.bucket_of = {}
+        self.members = []
+        lo, off, cur = 0, 0, []
+        for p in used:
+            cur.append(p)
+            off += p.numel()
+            if off - lo >= target:
+                self._close(lo, off, cur)
+                lo, cur = off, []
+        if cur:
+            self._close(lo, off, cur)
+        assert off == total
+
+    def _close(self, lo, hi, params):
+        b = len(self.bounds)
+        self.bounds.append((lo, hi))
+        self.members.append(len(params))
+        for p in params:
+            self.bucket_of[id(p)] = b
+
+    def begin_backward(self):
+        self.remaining = list(self.members)
+        self.handles = []
+
+    def on_param_grad(self, p):
+        b = self.bucket_of.get(id(p))
+        if b is None:
+            return
+        self.remaining[b] -= 1
+        if self.remaining[b] == 0:
+            lo, hi = self.bounds[b]
+            self.handles.append(dist.all_reduce(self.garena[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish_backward(self):
+        if any(r != 0 for r in self.remaining):
+            raise RuntimeError('gradient buckets incomplete after backward: %s' % self.remaining)
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+
+    def all_reduce_sums(self, sums):
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+
+
+def init_from_env(backend=None):
+    '''Rendezvous from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run); returns (rank, world, local_rank).'''
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank

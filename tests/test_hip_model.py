@@ -1,0 +1,262 @@
+'''
+GPU end-to-end parity of the drop-in FusionNetModel (HIP engine) against
+  (a) the committed golden vectors captured from the real reference (tests/golden/T0..T3), and
+  (b) the CPU oracle on fresh seeded inputs, including the full 900x1600 resolution of BASELINE.json.
+Bar: 1e-3 relative (north_star, fp32); most checks sit one to two orders below it.
+'''
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BAR = 1e-3
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _named(model, what):
+    out = []
+    for prefix, mod in (('encoder.', model.encoder), ('decoder.', model.decoder)):
+        it = mod.named_parameters() if what == 'p' else mod.named_buffers()
+        out += [(prefix + k, v) for k, v in it if not k.endswith('num_batches_tracked')]
+    return out
+
+
+@pytest.fixture(scope='module')
+def env():
+    import rcf_amd  # noqa: F401
+    from rcf_amd import _lib, synth, train
+    assert torch.cuda.is_available()
+    _lib.load()
+    return synth, train
+
+
+def _build(env, cfg, seed):
+    synth, train = env
+    m = train.build_model(cfg, device='cuda')
+    synth.fill_state_dict_([m.encoder, m.decoder], seed)
+    return m
+
+
+def _gpu_batch(b):
+    return {k: v.cuda() for k, v in b.items()}
+
+
+def _loss(m, b, out):
+    return m.compute_loss(image=b['image'], output_depth=out, ground_truth=b['ground_truth'], lidar_map=b['lidar_map'],
+                          loss_func='l1', w_smoothness=0.0, loss_smoothness_kernel_size=-1,
+                          validity_map_loss_smoothness=None, w_lidar_loss=2.0)
+
+
+def test_t0_tiny_train_step_matches_reference_golden(env, golden_dir):
+    synth, _ = env
+    g = np.load(os.path.join(golden_dir, 'T0_tiny_train.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    m = _build(env, synth.TINY, wseed)
+    b = _gpu_batch(synth.make_batch(n, h, w, k, seed=dseed))
+    m.train()
+    out = m.forward(image=b['image'], input_depth=b['input_depth'])
+    loss, info = _loss(m, b, out)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (n, 1, h, w)
+    assert _rel(out, g['output']) < BAR
+    np.testing.assert_allclose([float(loss), float(info['loss_supervised']), float(info['loss_lidar'])], g['loss'], rtol=BAR)
+    unused = set(g['unused'].tolist())
+    worst = 0.0
+    for key, p in _named(m, 'p'):
+        if key in unused:
+            assert p.grad is None, key
+            continue
+        e = _rel(p.grad, g['grad:' + key])
+        worst = max(worst, e)
+        assert e < 5 * BAR, (key, e)
+    for key, buf in _named(m, 'b'):
+        assert _rel(buf, g['buf:' + key]) < BAR, key
+    print('T0 worst gradient rel err %.2e' % worst)
+
+
+def test_t1_published_config1_matches_reference_golden(env, golden_dir):
+    synth, _ = env
+    g = np.load(os.path.join(golden_dir, 'T1_published_train.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    m = _build(env, synth.PUBLISHED, wseed)
+    b = _gpu_batch(synth.make_batch(n, h, w, k, seed=dseed))
+    m.train()
+    out = m.forward(image=b['image'], input_depth=b['input_depth'])
+    loss, info = _loss(m, b, out)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert _rel(out, g['output']) < BAR
+    mae_mm = float((out.detach().cpu() - torch.from_numpy(g['output'])).abs().mean()) * 1000.0
+    print('T1 output MAE vs reference: %.4f mm' % mae_mm)
+    np.testing.assert_allclose([float(loss), float(info['loss_supervised']), float(info['loss_lidar'])], g['loss'], rtol=BAR)
+    grads = dict(_named(m, 'p'))
+    for key, l2, sm in zip(g['grad_keys'].tolist(), g['grad_l2'].tolist(), g['grad_sum'].tolist()):
+        got = float(grads[key].grad.double().norm())
+        assert abs(got - l2) <= 5 * BAR * l2 + 1e-12, (key, got, l2)
+    for key in g['unused'].tolist():
+        assert grads[key].grad is None
+    bufs = dict(_named(m, 'b'))
+    for key, l2 in zip(g['buf_keys'].tolist(), g['buf_l2'].tolist()):
+        assert abs(float(bufs[key].double().norm()) - l2) <= BAR * l2, key
+
+
+def test_t3_eval_mode_matches_reference_golden(env, golden_dir):
+    synth, _ = env
+    g = np.load(os.path.join(golden_dir, 'T3_eval.npz'))
+    for tag, cfg in (('tiny', synth.TINY), ('published', synth.PUBLISHED)):
+        n, h, w, k, dseed, wseed = [int(v) for v in g[tag + '_meta']]
+        m = _build(env, cfg, wseed)
+        m.eval()
+        b = _gpu_batch(synth.make_batch(n, h, w, k, seed=dseed))
+        before = {k_: v.clone() for k_, v in _named(m, 'b')}
+        with torch.no_grad():
+            out = m.forward(image=b['image'], input_depth=b['input_depth'])
+        torch.cuda.synchronize()
+        assert _rel(out, g[tag + '_output']) < BAR
+        for k_, v in _named(m, 'b'):
+            assert torch.equal(v, before[k_]), 'eval must not touch running statistics'
+
+
+@pytest.mark.parametrize('fused', [True, False], ids=['FusedAdam', 'torch.optim.Adam'])
+def test_t2_three_adam_steps_match_reference_trajectory(env, golden_dir, fused):
+    synth, train = env
+    g = np.load(os.path.join(golden_dir, 'T2_tiny_adam3.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    m = _build(env, synth.TINY, wseed)
+    if fused:
+        opt = train.make_optimizer(m, lr=1e-3)
+    else:   # the reference's own optimizer drives the HIP model unchanged
+        opt = torch.optim.Adam([{'params': m.parameters(), 'weight_decay': 0.0}], lr=1e-3)
+    m.train()
+    for step in range(3):
+        b = _gpu_batch(synth.make_batch(n, h, w, k, seed=dseed + step))
+        loss, _, _ = train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])
+        assert abs(float(loss) - g['losses'][step]) < BAR * g['losses'][step], (step, float(loss))
+    psum = float(sum(p.detach().double().abs().sum() for p in m.parameters()))
+    assert abs(psum - float(g['param_abs_sum'])) < 1e-4 * float(g['param_abs_sum'])
+    bsum = float(sum(v.detach().double().abs().sum() for _, v in _named(m, 'b')))
+    assert abs(bsum - float(g['buffer_abs_sum'])) < BAR * float(g['buffer_abs_sum'])
+
+
+def test_fresh_seed_odd_size_against_oracle(env):
+    synth, _ = env
+    from oracle.fusionnet_oracle import FusionNetOracle
+    m = _build(env, synth.PUBLISHED, 5)
+    o = FusionNetOracle(**synth.PUBLISHED)
+    synth.fill_state_dict_([o.encoder, o.decoder], 5)
+    cb = synth.make_batch(2, 113, 200, 16, seed=9)
+    b = _gpu_batch(cb)
+    m.train(); o.train()
+    out = m.forward(image=b['image'], input_depth=b['input_depth'])
+    loss, _ = _loss(m, b, out)
+    loss.backward()
+    ro = o.forward(cb['image'], cb['input_depth'])
+    rl = o.compute_loss(ro, cb['ground_truth'], cb['lidar_map'], 2.0)[0]
+    rl.backward()
+    torch.cuda.synchronize()
+    assert _rel(out, ro) < BAR
+    assert abs(float(loss) - float(rl)) < BAR * abs(float(rl))
+    ref = dict(_named(o, 'p'))
+    worst = 0.0
+    for key, p in _named(m, 'p'):
+        if ref[key].grad is None:
+            assert p.grad is None
+            continue
+        worst = max(worst, _rel(p.grad, ref[key].grad))
+    print('fresh-seed worst gradient rel err %.2e' % worst)
+    assert worst < 5 * BAR
+
+
+def test_checkpoint_round_trip_and_reference_key_names(env, tmp_path):
+    synth, train = env
+    m = _build(env, synth.TINY, 3)
+    opt = train.make_optimizer(m, lr=1e-3)
+    b = _gpu_batch(synth.make_batch(1, 64, 96, 4, seed=1))
+    m.train()
+    train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])
+    m.data_parallel()      # the reference always calls it before saving (src/fusionnet_main.py:198)
+    path = str(tmp_path / 'model-1.pth')
+    m.save_model(path, 1, opt)
+    ck = torch.load(path, map_location='cpu')
+    assert set(ck.keys()) == {'train_step', 'optimizer_state_dict', 'encoder_state_dict', 'decoder_state_dict'}
+    assert all(k.startswith('module.') for k in ck['encoder_state_dict'])
+    assert 'module.blocks2_image.0.conv1.conv.weight' in ck['encoder_state_dict']
+    assert 'module.deconv0.deconv.conv.conv.weight' in ck['decoder_state_dict']
+    m2 = train.build_model(synth.TINY, device='cuda')
+    opt2 = train.make_optimizer(m2, lr=1e-3)
+    step, _ = m2.restore_model(path, opt2)
+    assert step == 1
+    m.eval(); m2.eval()
+    with torch.no_grad():
+        a = m.forward(b['image'], b['input_depth'])
+        c = m2.forward(b['image'], b['input_depth'])
+    assert torch.equal(a, c)
+    # optimizer state followed: one more identical step gives identical parameters
+    m.train(); m2.train()
+    train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])
+    train.train_step(m2, opt2, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])
+    for (ka, pa), (kb, pb) in zip(_named(m, 'p'), _named(m2, 'p')):
+        assert torch.equal(pa, pb), ka
+
+
+def test_gradient_accumulation_without_zero_grad(env):
+    synth, _ = env
+    m = _build(env, synth.TINY, 4)
+    b = _gpu_batch(synth.make_batch(1, 64, 96, 4, seed=2))
+    m.eval()   # running-stat BN: the two passes are identical, so the accumulated gradient is exactly double
+    grads = []
+    for _ in range(2):
+        out = m.forward(b['image'], b['input_depth'])
+        loss, _ = _loss(m, b, out)
+        loss.backward()
+        grads.append(m.decoder.output0.conv.weight.grad.clone())
+    assert _rel(grads[1], 2 * grads[0]) < 1e-6
+
+
+def test_full_resolution_900x1600_against_oracle(env):
+    '''BASELINE.json's resolution, batch 1, published net: output, loss and every parameter gradient.'''
+    import time
+    synth, _ = env
+    from oracle.fusionnet_oracle import FusionNetOracle
+    m = _build(env, synth.PUBLISHED, 8)
+    cb = synth.make_batch(1, 900, 1600, 64, seed=1234)
+    b = _gpu_batch(cb)
+    m.train()
+    torch.cuda.synchronize(); t0 = time.time()
+    out = m.forward(image=b['image'], input_depth=b['input_depth'])
+    loss, _ = _loss(m, b, out)
+    loss.backward()
+    torch.cuda.synchronize(); t_gpu = time.time() - t0
+    o = FusionNetOracle(**synth.PUBLISHED)
+    synth.fill_state_dict_([o.encoder, o.decoder], 8)
+    o.train()
+    t0 = time.time()
+    ro = o.forward(cb['image'], cb['input_depth'])
+    rl = o.compute_loss(ro, cb['ground_truth'], cb['lidar_map'], 2.0)[0]
+    rl.backward()
+    t_cpu = time.time() - t0
+    e_out = _rel(out, ro)
+    mae_mm = float((out.detach().cpu() - ro.detach()).abs().mean()) * 1000.0
+    ref = dict(_named(o, 'p'))
+    worst, worst_key = 0.0, None
+    for key, p in _named(m, 'p'):
+        if ref[key].grad is None:
+            continue
+        e = _rel(p.grad, ref[key].grad)
+        if e > worst:
+            worst, worst_key = e, key
+    print('900x1600: out rel %.2e, MAE %.4f mm, loss %.6f vs %.6f, worst grad rel %.2e (%s); first-call gpu %.2fs, cpu oracle %.1fs'
+          % (e_out, mae_mm, float(loss), float(rl), worst, worst_key, t_gpu, t_cpu))
+    assert e_out < BAR
+    assert abs(float(loss) - float(rl)) < BAR * abs(float(rl))
+    assert worst < 5 * BAR

@@ -1,0 +1,371 @@
+'''
+GPU parity tests, kernel by kernel, THROUGH THE C ABI (rcf_amd.ops -> librcf_hip.so) against stock fp32
+PyTorch CPU ops on the same seeded inputs.  Tolerance: 2e-4 of the reference tensor's max-abs (fp32 summation
+order is the only difference: the MFMA is an exact fmaf chain); north_star's bar is 1e-3.
+'''
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-4
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import rcf_amd  # noqa: F401
+    from rcf_amd import _lib, ops as _ops
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    _lib.load()
+    assert _lib.load().rcf_device_ok() == 1, 'librcf_hip.so: no gfx950 device'
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.detach().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+# (ksize, stride, c1, c2, cout, n, h, w, up_from)
+CONV_CASES = [
+    (3, 1, 16, 0, 32, 2, 20, 37, None),
+    (3, 1, 64, 0, 64, 1, 33, 64, None),
+    (3, 1, 64, 32, 64, 2, 17, 40, None),        # decoder concat 64+32 -> 64 (deconv1.conv)
+    (3, 1, 32, 0, 32, 1, 40, 100, None),        # w=100 picks the 16x16 tile
+    (3, 1, 8, 8, 8, 2, 35, 51, None),           # tiny net concat, CK=8 path
+    (3, 1, 4, 0, 4, 2, 70, 102, None),          # tiny net deconv0
+    (3, 1, 256, 0, 128, 1, 29, 50, (15, 25)),   # UpConv 15x25 -> 29x50 (non-2x nearest)
+    (3, 1, 64, 0, 32, 1, 70, 102, (35, 51)),    # UpConv exact 2x
+    (3, 1, 128, 128, 128, 1, 15, 26, None),     # 256 -> 128 concat
+    (3, 2, 32, 0, 64, 2, 45, 80, None),         # stride 2 (blocks3.0.conv1)
+    (3, 2, 8, 0, 16, 2, 35, 51, None),
+    (3, 2, 128, 0, 256, 1, 29, 50, None),
+    (1, 1, 16, 0, 32, 2, 35, 51, None),         # fusion 1x1
+    (1, 1, 128, 0, 256, 1, 15, 25, None),
+    (1, 2, 32, 0, 64, 2, 45, 80, None),         # projection 1x1 stride 2
+    (1, 2, 8, 0, 16, 1, 35, 51, None),
+    (7, 2, 3, 0, 32, 2, 70, 102, None),         # image stem
+    (7, 2, 2, 0, 16, 2, 70, 102, None),         # depth stem
+    (7, 2, 2, 0, 4, 1, 64, 96, None),           # tiny depth stem
+]
+
+
+def _conv_case(case, seed):
+    k, s, c1, c2, co, n, h, w, up = case
+    hs, ws = (h, w) if up is None else up
+    x1 = rnd(n, c1, hs, ws, seed=seed)
+    x2 = rnd(n, c2, h, w, seed=seed + 1) if c2 else None
+    wt = rnd(co, c1 + c2, k, k, seed=seed + 2, scale=1.0 / np.sqrt((c1 + c2) * k * k))
+    return x1, x2, wt
+
+
+def _ref_conv(case, x1, x2, wt):
+    k, s, c1, c2, co, n, h, w, up = case
+    xin = x1 if up is None else F.interpolate(x1, size=(h, w))
+    if x2 is not None:
+        xin = torch.cat([xin, x2], 1)
+    return F.conv2d(xin, wt, stride=s, padding=k // 2)
+
+
+def _desc(ops, case):
+    k, s, c1, c2, co, n, h, w, up = case
+    hs, ws = (h, w) if up is None else up
+    gather = 0 if up is None else 1
+    return ops.make_fwd_desc(n, h, w, c1, c2, co, k, s, hs, ws, gather)
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv_forward_and_bn_statistics(ops, case):
+    x1, x2, wt = _conv_case(case, 10)
+    ref = _ref_conv(case, x1, x2, wt)
+    d = _desc(ops, case)
+    info = ops.conv_query(d)
+    packed = torch.empty(info.packed_weight_floats, device='cuda')
+    ops.conv_pack(d, dev(wt), packed)
+    out = torch.full((d.n, d.h_out, d.w_out, d.c_out), float('nan'), device='cuda')
+    partials = torch.full((info.n_partials, 2, d.c_out), float('nan'), device='cuda')
+    ops.conv_fwd(d, nhwc(x1), None if x2 is None else nhwc(x2), packed, out, partials)
+    torch.cuda.synchronize()
+    got = nchw(out)
+    assert got.shape == ref.shape
+    assert rel(got, ref) < TOL
+    s = partials.double().sum(0).cpu()
+    assert rel(s[0], ref.double().sum((0, 2, 3))) < 1e-3 or float((s[0] - ref.double().sum((0, 2, 3))).abs().max()) < 1e-2
+    assert rel(s[1], (ref.double() ** 2).sum((0, 2, 3))) < TOL
+
+
+@pytest.mark.parametrize('case', [c for c in CONV_CASES if c[0] != 7], ids=[str(c) for c in CONV_CASES if c[0] != 7])
+def test_conv_input_gradient(ops, case):
+    k, s, c1, c2, co, n, h, w, up = case
+    x1, x2, wt = _conv_case(case, 20)
+    x1.requires_grad_(True)
+    if x2 is not None:
+        x2.requires_grad_(True)
+    ref = _ref_conv(case, x1, x2, wt)
+    dz = rnd(*ref.shape, seed=33)
+    (ref * dz).sum().backward()
+    d = _desc(ops, case)
+    dzg = nhwc(dz)
+    for src, off, cnt in ((x1, 0, c1), (x2, c1, c2)):
+        if src is None:
+            continue
+        for accumulate in (False, True):
+            dd = ops.make_dgrad_desc(d, off, cnt, accumulate and not (src is x1 and up is not None))
+            info = ops.conv_query(dd)
+            packed = torch.empty(info.packed_weight_floats, device='cuda')
+            ops.conv_pack(dd, dev(wt), packed)
+            base = rnd(n, cnt, h, w, seed=5) if accumulate else torch.zeros(n, cnt, h, w)
+            if src is x1 and up is not None:
+                tmp = torch.full((n, h, w, cnt), float('nan'), device='cuda')
+                ops.conv_fwd(dd, dzg, None, packed, tmp, None)
+                base = rnd(n, cnt, up[0], up[1], seed=5) if accumulate else torch.zeros(n, cnt, up[0], up[1])
+                dst = nhwc(base) if accumulate else torch.full((n, up[0], up[1], cnt), float('nan'), device='cuda')
+                ops.upsample_nearest_bwd(tmp, dst, accumulate)
+            else:
+                dst = nhwc(base) if accumulate else torch.full((n, h, w, cnt), float('nan'), device='cuda')
+                ops.conv_fwd(dd, dzg, None, packed, dst, None)
+            torch.cuda.synchronize()
+            want = src.grad + base
+            assert rel(nchw(dst), want) < TOL, (off, accumulate)
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv_weight_gradient(ops, case):
+    x1, x2, wt = _conv_case(case, 30)
+    wt.requires_grad_(True)
+    ref = _ref_conv(case, x1, x2, wt)
+    dz = rnd(*ref.shape, seed=44)
+    (ref * dz).sum().backward()
+    d = _desc(ops, case)
+    info = ops.conv_query(d)
+    ws = torch.empty(max(1, info.wgrad_workspace_floats), device='cuda')
+    dw = torch.full(tuple(wt.shape), float('nan'), device='cuda')
+    ops.conv_wgrad(d, nhwc(x1), None if x2 is None else nhwc(x2), nhwc(dz), dw, ws)
+    torch.cuda.synchronize()
+    assert rel(dw.cpu(), wt.grad) < TOL
+
+
+@pytest.mark.parametrize('c,n,h,w,has_res', [(32, 2, 19, 23, False), (64, 1, 30, 17, True), (4, 2, 35, 51, True),
+                                             (256, 2, 8, 13, False), (16, 3, 9, 9, True)])
+def test_batchnorm_leakyrelu_residual_forward_backward(ops, c, n, h, w, has_res):
+    z = rnd(n, c, h, w, seed=1, scale=2.0) + 0.3
+    res = rnd(n, c, h, w, seed=2) if has_res else None
+    gamma = rnd(c, seed=3) * 0.5 + 1.0
+    beta = rnd(c, seed=4) * 0.1
+    rm0, rv0 = rnd(c, seed=5) * 0.1, rnd(c, seed=6) * 0.25 + 1.0
+    dout = rnd(n, c, h, w, seed=7)
+
+    zz = z.clone().requires_grad_(True)
+    g, b = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if has_res else None
+    rm, rv = rm0.clone(), rv0.clone()
+    y = F.leaky_relu(F.batch_norm(zz, rm, rv, g, b, True, 0.1, 1e-5), 0.2)
+    if has_res:
+        y = F.leaky_relu(y + rr, 0.2)
+    (y * dout).sum().backward()
+
+    n_pix = n * h * w
+    zg = nhwc(z)
+    # statistics partials as the conv epilogue would produce them (one partial row)
+    part = torch.stack([zg.view(-1, c).double().sum(0), (zg.view(-1, c).double() ** 2).sum(0)]).float().view(1, 2, c).contiguous()
+    coef = torch.empty(4, c, device='cuda')
+    rmg, rvg = dev(rm0.clone()), dev(rv0.clone())
+    ops.bn_finalize(part, 1, c, n_pix, dev(gamma), dev(beta), rmg, rvg, 0.1, 1e-5, True, coef)
+    out = torch.empty_like(zg)
+    resg = nhwc(res) if has_res else None
+    ops.bn_act_fwd(zg, coef, resg, out, n_pix, c, 1)
+    torch.cuda.synchronize()
+    assert rel(nchw(out), y.detach()) < TOL
+    assert rel(rmg.cpu(), rm) < 1e-5 and rel(rvg.cpu(), rv) < 1e-5
+
+    nb = ops.ew_blocks(n_pix, c)
+    bpart = torch.empty(nb, 2, c, device='cuda')
+    doutg = nhwc(dout)
+    ops.bn_act_bwd_reduce(doutg, zg, coef, out, bpart, n_pix, c, 1, has_res)
+    bcoef = torch.empty(2, c, device='cuda')
+    dgamma, dbeta = torch.empty(c, device='cuda'), torch.empty(c, device='cuda')
+    ops.bn_bwd_finalize(bpart, nb, 2 * c, c, n_pix, bcoef, dgamma, dbeta)
+    dz = torch.empty_like(zg)
+    dres = nhwc(torch.ones(n, c, h, w)) if has_res else None
+    ops.bn_act_bwd_apply(doutg, zg, coef, out, bcoef, dz, dres, True, n_pix, c, 1, has_res)
+    torch.cuda.synchronize()
+    assert rel(nchw(dz), zz.grad) < TOL
+    assert rel(dgamma.cpu(), g.grad) < TOL and rel(dbeta.cpu(), b.grad) < TOL
+    if has_res:
+        assert rel(nchw(dres), rr.grad + 1.0) < TOL
+
+    # eval mode: coefficients from the running statistics
+    coef_e = torch.empty(4, c, device='cuda')
+    ops.bn_finalize(None, 0, c, n_pix, dev(gamma), dev(beta), dev(rm0.clone()), dev(rv0.clone()), 0.1, 1e-5, False, coef_e)
+    out_e = torch.empty_like(zg)
+    ops.bn_act_fwd(zg, coef_e, None, out_e, n_pix, c, 0)
+    want = F.batch_norm(z, rm0.clone(), rv0.clone(), gamma, beta, False, 0.1, 1e-5)
+    assert rel(nchw(out_e), want) < TOL
+
+
+@pytest.mark.parametrize('c,n,h,w', [(32, 2, 17, 21), (8, 2, 35, 51), (256, 1, 15, 25)])
+def test_weight_and_project_fusion_forward_backward(ops, c, n, h, w):
+    zw, zp, img, dout = (rnd(n, c, h, w, seed=s, scale=sc) for s, sc in ((1, 2.0), (2, 1.5), (3, 1.0), (4, 1.0)))
+    gw, bw, gp, bp = rnd(c, seed=5) * 0.5 + 1, rnd(c, seed=6) * 0.1, rnd(c, seed=7) * 0.5 + 1, rnd(c, seed=8) * 0.1
+    leaves = [t.clone().requires_grad_(True) for t in (zw, zp, img, gw, bw, gp, bp)]
+    a, b, i_, g1, b1, g2, b2 = leaves
+    run = lambda z, g, bb: F.batch_norm(z, torch.zeros(c), torch.ones(c), g, bb, True, 0.1, 1e-5)
+    y = torch.sigmoid(run(a, g1, b1)) * run(b, g2, b2) + i_
+    (y * dout).sum().backward()
+
+    n_pix = n * h * w
+    zwg, zpg, imgg, doutg = nhwc(zw), nhwc(zp), nhwc(img), nhwc(dout)
+
+    def coef_of(zg, g, bb):
+        part = torch.stack([zg.view(-1, c).double().sum(0), (zg.view(-1, c).double() ** 2).sum(0)]).float().view(1, 2, c).contiguous()
+        coef = torch.empty(4, c, device='cuda')
+        ops.bn_finalize(part, 1, c, n_pix, dev(g), dev(bb), torch.zeros(c, device='cuda'), torch.ones(c, device='cuda'),
+                        0.1, 1e-5, True, coef)
+        return coef
+    cw, cp = coef_of(zwg, gw, bw), coef_of(zpg, gp, bp)
+    out = torch.empty_like(zwg)
+    ops.fuse_fwd(zwg, cw, zpg, cp, imgg, out, n_pix, c)
+    torch.cuda.synchronize()
+    assert rel(nchw(out), y.detach()) < TOL
+
+    nb = ops.ew_blocks(n_pix, c)
+    bpart = torch.empty(nb, 4, c, device='cuda')
+    ops.fuse_bwd_reduce(doutg, zwg, cw, zpg, cp, bpart, n_pix, c)
+    bcw, bcp = torch.empty(2, c, device='cuda'), torch.empty(2, c, device='cuda')
+    dgw, dbw, dgp, dbp = (torch.empty(c, device='cuda') for _ in range(4))
+    ops.bn_bwd_finalize(bpart, nb, 4 * c, c, n_pix, bcw, dgw, dbw)
+    ops.bn_bwd_finalize(bpart.view(-1)[2 * c:], nb, 4 * c, c, n_pix, bcp, dgp, dbp)
+    dzw, dzp = torch.empty_like(zwg), torch.empty_like(zpg)
+    dimg = torch.empty_like(imgg)
+    ops.fuse_bwd_apply(doutg, zwg, cw, zpg, cp, bcw, bcp, dzw, dzp, dimg, False, n_pix, c)
+    torch.cuda.synchronize()
+    assert rel(nchw(dzw), a.grad) < 5e-4 and rel(nchw(dzp), b.grad) < TOL and rel(nchw(dimg), i_.grad) < 1e-6
+    assert rel(dgw.cpu(), g1.grad) < 5e-4 and rel(dbw.cpu(), b1.grad) < 5e-4
+    assert rel(dgp.cpu(), g2.grad) < TOL and rel(dbp.cpu(), b2.grad) < TOL
+
+
+@pytest.mark.parametrize('c,n,h,w', [(32, 2, 35, 51), (16, 1, 450 // 10, 80), (4, 2, 7, 9), (8, 1, 1, 5)])
+def test_maxpool_forward_backward(ops, c, n, h, w):
+    x = rnd(n, c, h, w, seed=1).requires_grad_(True)
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = rnd(*y.shape, seed=2)
+    (y * dy).sum().backward()
+    out = torch.empty(n, y.shape[2], y.shape[3], c, device='cuda')
+    idx = torch.empty(n, y.shape[2], y.shape[3], c, dtype=torch.uint8, device='cuda')
+    ops.maxpool_fwd(nhwc(x.detach()), out, idx)
+    din = nhwc(torch.ones(n, c, h, w))
+    ops.maxpool_bwd(nhwc(dy), idx, din, True)
+    torch.cuda.synchronize()
+    assert torch.equal(nchw(out), y.detach())
+    assert rel(nchw(din), x.grad + 1.0) < 1e-6
+
+
+@pytest.mark.parametrize('hs,ws,hu,wu', [(15, 25, 29, 50), (35, 51, 70, 102), (57, 100, 113, 200), (3, 4, 3, 4), (2, 3, 7, 11)])
+def test_nearest_upsample_backward(ops, hs, ws, hu, wu):
+    n, c = 2, 8
+    x = rnd(n, c, hs, ws, seed=1).requires_grad_(True)
+    y = F.interpolate(x, size=(hu, wu))
+    dy = rnd(n, c, hu, wu, seed=2)
+    (y * dy).sum().backward()
+    dsrc = torch.full((n, hs, ws, c), float('nan'), device='cuda')
+    ops.upsample_nearest_bwd(nhwc(dy), dsrc, False)
+    torch.cuda.synchronize()
+    assert rel(nchw(dsrc), x.grad) < 1e-6
+
+
+@pytest.mark.parametrize('c,n,h,w', [(32, 2, 33, 47), (4, 2, 70, 102), (8, 1, 5, 3)])
+def test_output_head_forward_backward(ops, c, n, h, w):
+    x = rnd(n, c, h, w, seed=1).requires_grad_(True)
+    wt = (rnd(1, c, 3, 3, seed=2) * 0.3).requires_grad_(True)
+    o = F.conv2d(x, wt, padding=1)
+    d = 1.0 / (torch.sigmoid(o) + 1.0 / 100.0)
+    dd = rnd(n, 1, h, w, seed=3)
+    (d * dd).sum().backward()
+    xg = nhwc(x.detach())
+    logit, depth = torch.empty(n, h, w, device='cuda'), torch.empty(n, h, w, device='cuda')
+    ops.head_fwd(xg, dev(wt.detach()), logit, depth, 1.0, 100.0)
+    dlogit = torch.empty_like(logit)
+    ops.head_bwd_logit(dev(dd.view(n, h, w).contiguous()), logit, dlogit, 1.0, 100.0)
+    dx = torch.empty_like(xg)
+    ops.head_bwd_dgrad(dlogit, dev(wt.detach()), dx)
+    dw = torch.empty(1, c, 3, 3, device='cuda')
+    ops.head_bwd_wgrad(xg, dlogit, dw)
+    torch.cuda.synchronize()
+    assert rel(logit.cpu(), o.detach().view(n, h, w)) < TOL
+    assert rel(depth.cpu(), d.detach().view(n, h, w)) < TOL
+    assert rel(nchw(dx), x.grad) < TOL
+    assert rel(dw.cpu(), wt.grad) < TOL
+
+
+def test_masked_l1_loss_forward_backward(ops):
+    from oracle.fusionnet_oracle import FusionNetOracle
+    n, h, w = 2, 37, 53
+    g = torch.Generator().manual_seed(3)
+    d = (torch.rand(n, 1, h, w, generator=g) * 60 + 1).requires_grad_(True)
+    gt = torch.rand(n, 1, h, w, generator=g) * 80 * (torch.rand(n, 1, h, w, generator=g) < 0.3)
+    lidar = torch.rand(n, 1, h, w, generator=g) * 80 * (torch.rand(n, 1, h, w, generator=g) < 0.05)
+    o = FusionNetOracle.__new__(FusionNetOracle)
+    loss, ls, ll = FusionNetOracle.compute_loss(o, d, gt, lidar, 2.0)
+    loss.backward()
+    sums = torch.empty(4, dtype=torch.float64, device='cuda')
+    dg, gtg, lg = dev(d.detach()), dev(gt), dev(lidar)
+    ops.l1_loss_fwd(dg, gtg, lg, sums)
+    val = torch.empty(3, device='cuda')
+    ops.l1_loss_value(sums, 2.0, val)
+    dd = torch.empty_like(dg)
+    ops.l1_loss_bwd(dg, gtg, lg, sums, None, 2.0, dd)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(val.cpu().numpy(), [float(loss), float(ls), float(ll)], rtol=1e-5)
+    assert rel(dd.cpu(), d.grad) < 1e-5
+
+
+def test_adam_matches_torch_optim(ops):
+    p0, steps = rnd(10007, seed=1), 4
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([{'params': [ref], 'weight_decay': 0.01}], lr=1e-2)
+    p, m, v = dev(p0.clone()), torch.zeros(10007, device='cuda'), torch.zeros(10007, device='cuda')
+    for s in range(1, steps + 1):
+        g = rnd(10007, seed=10 + s)
+        ref.grad = g.clone()
+        opt.step()
+        ops.adam_step(p, dev(g), m, v, 1e-2, 0.9, 0.999, 1e-8, 0.01, s)
+    torch.cuda.synchronize()
+    assert rel(p.cpu(), ref.detach()) < 1e-5
+
+
+def test_layout_round_trip(ops):
+    x = rnd(2, 3, 11, 7, seed=1)
+    y = ops.nchw_to_nhwc(dev(x))
+    assert torch.equal(y.cpu(), x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.nhwc_to_nchw(y).cpu(), x)
+
+
+def test_unsupported_shapes_return_errors(ops):
+    from rcf_amd import _lib
+    with pytest.raises(_lib.RcfError):
+        ops.conv_query(ops.make_fwd_desc(1, 8, 8, 16, 0, 1, 3, 1))       # c_out == 1 belongs to the head kernel
+    with pytest.raises(_lib.RcfError):
+        ops.conv_query(ops.make_fwd_desc(1, 8, 8, 16, 0, 16, 5, 1))      # 5x5 does not exist in FusionNet
+    with pytest.raises(_lib.RcfError):
+        ops.bn_act_fwd(torch.zeros(4, device='cuda'), torch.zeros(16, device='cuda'), None, torch.zeros(4, device='cuda'), 1, 6, 1)
+    with pytest.raises(_lib.RcfError):
+        ops.conv_fwd(ops.make_fwd_desc(1, 8, 8, 16, 0, 16, 3, 1), torch.zeros(4), None, torch.zeros(4), torch.zeros(4))  # CPU tensors

@@ -1,0 +1,188 @@
+'''
+CPU tests (no GPU): the C-ABI library loads and exports every symbol include/rcf_hip.h declares, the host mirror of
+the reference's API (names, state_dict keys, error behaviour), the optimizer's state format, and the data-parallel
+gradient buckets over a 2-rank gloo group.  No HIP compute is invoked here.
+'''
+
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    import __graft_entry__ as entry
+    entry.build()
+    import rcf_amd
+    return rcf_amd
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    from rcf_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'rcf_hip.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = set(re.findall(r'\b(rcf_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 30
+    assert declared == set(_lib._SIGNATURES.keys()), declared ^ set(_lib._SIGNATURES.keys())
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b'gfx950' in lib.rcf_version()
+
+
+def test_product_path_has_no_cpu_fallback(pkg):
+    from rcf_amd import _lib, ops, synth, train
+    m = train.build_model(synth.TINY, device='cpu')
+    with pytest.raises(_lib.RcfError):
+        m.forward(torch.zeros(1, 3, 64, 96), torch.zeros(1, 2, 64, 96))
+    with pytest.raises(_lib.RcfError):
+        ops.nchw_to_nhwc(torch.zeros(1, 3, 4, 4))
+    with pytest.raises(RuntimeError):
+        m.encoder.conv1_image(torch.zeros(1, 3, 8, 8))      # blocks are parameter containers
+    # nothing under the package imports the oracle
+    for root, _, files in os.walk(os.path.join(ROOT, 'radar-camera-fusion-depth_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                assert 'oracle' not in open(os.path.join(root, f)).read().replace('the oracle', '').replace('CPU oracle', ''), f
+
+
+def test_state_dict_names_and_shapes_match_reference(pkg):
+    from rcf_amd import synth, train
+    from oracle.fusionnet_oracle import FusionNetOracle
+    for cfg in (synth.TINY, synth.PUBLISHED):
+        m = train.build_model(cfg, device='cpu')
+        o = FusionNetOracle(**cfg)       # key-for-key identical to the reference (tests/golden/make_golden.py asserts it)
+        for mine, ref in ((m.encoder, o.encoder), (m.decoder, o.decoder)):
+            a, b = mine.state_dict(), ref.state_dict()
+            assert list(a.keys()) == list(b.keys())
+            for k in a:
+                assert tuple(a[k].shape) == tuple(b[k].shape), k
+    m = train.build_model(synth.PUBLISHED, device='cpu')
+    assert sum(p.numel() for p in m.parameters()) == 14413568
+    assert m._n_used == 14142208
+    assert len(m.parameters()) - len(m._used_params) == 10     # unused projections
+    unused = [k for k, p in list(m.encoder.named_parameters()) if id(p) not in set(id(q) for q in m._used_params)]
+    assert all(k.endswith('.1.projection.conv.weight') for k in unused)
+
+
+def test_parameters_are_views_of_one_arena_in_backward_order(pkg):
+    from rcf_amd import synth, train
+    m = train.build_model(synth.TINY, device='cpu')
+    base = m._param_arena.data_ptr()
+    off = 0
+    for p in m._used_params:
+        assert p.data_ptr() == base + 4 * off
+        assert m._grad_of(p).data_ptr() == m._grad_arena.data_ptr() + 4 * off
+        off += p.numel()
+    assert off == m._n_used
+    assert m._used_params[0] is m.decoder.output0.conv.weight          # first gradient to become final
+    assert m._used_params[-1] is m.encoder.conv1_image.conv.weight     # last
+    # load_state_dict writes through the views
+    sd = m.encoder.state_dict()
+    sd['conv1_image.conv.weight'] = torch.full_like(sd['conv1_image.conv.weight'], 0.5)
+    m.encoder.load_state_dict(sd)
+    assert float(m._param_arena[m._param_offset[id(m.encoder.conv1_image.conv.weight)]]) == 0.5
+
+
+def test_error_behaviour_mirrors_reference(pkg):
+    from rcf_amd.fusionnet_model import FusionNetModel
+    from rcf_amd import net_utils
+    base = dict(input_channels_image=3, input_channels_depth=2, encoder_type=['fusionnet18', 'batch_norm'],
+                n_filters_encoder_image=[8, 16, 32, 32, 32, 32], n_filters_encoder_depth=[4, 8, 16, 16, 16, 16],
+                fusion_type='weight_and_project', decoder_type=['multiscale', 'batch_norm'], n_resolution_decoder=1,
+                n_filters_decoder=[32, 32, 16, 8, 8, 4], deconv_type='up', activation_func='leaky_relu',
+                weight_initializer='kaiming_uniform', min_predict_depth=1.0, max_predict_depth=100.0, device='cpu')
+    for key, bad in (('fusion_type', 'bogus'), ('encoder_type', ['vgg11']), ('decoder_type', ['unet']),
+                     ('activation_func', 'swish'), ('deconv_type', 'transpose')):
+        kw = dict(base); kw[key] = bad
+        with pytest.raises(ValueError):           # src/fusionnet_model.py:82, :90, :115, :135; src/net_utils.py:23
+            FusionNetModel(**kw)
+    with pytest.raises(ValueError):
+        net_utils.activation_func('tanh')
+    m = FusionNetModel(**base)
+    with pytest.raises(ValueError):               # src/fusionnet_model.py:275
+        m.compute_loss(None, torch.zeros(1, 1, 4, 4), torch.zeros(1, 1, 4, 4), torch.zeros(1, 1, 4, 4), 'huber', 0.0, -1, None, 2.0)
+
+
+def test_fused_adam_state_dict_is_torch_adam_compatible(pkg):
+    from rcf_amd import synth, train
+    m = train.build_model(synth.TINY, device='cpu')
+    fused = train.make_optimizer(m, lr=1e-3, weight_decay=0.0)
+    ref = torch.optim.Adam([{'params': m.parameters(), 'weight_decay': 0.0}], lr=1e-3)
+    a, b = fused.state_dict(), ref.state_dict()
+    assert a['param_groups'][0].keys() == b['param_groups'][0].keys()
+    assert a['param_groups'][0]['params'] == b['param_groups'][0]['params']
+    # a torch.optim.Adam state (after one CPU step) loads into FusedAdam and lands in the flat moment arenas
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    ref.step()
+    fused.load_state_dict(ref.state_dict())
+    p0 = m.decoder.output0.conv.weight
+    st = fused.state[p0]
+    assert float(st['step']) == 1.0
+    marena = fused._moment_arenas[id(m._param_arena)][0]
+    assert st['exp_avg'].data_ptr() == marena.data_ptr() + 4 * m._param_offset[id(p0)]
+    assert torch.allclose(st['exp_avg'], ref.state[p0]['exp_avg'])
+
+
+def test_synthetic_inputs_are_deterministic(pkg):
+    from rcf_amd import synth
+    a = synth.make_batch(2, 64, 96, 8, seed=5)
+    b = synth.make_batch(2, 64, 96, 8, seed=5)
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    assert 0.2 < float((a['ground_truth'] > 0).float().mean()) < 0.4
+    assert float(a['input_depth'][:, 1].max()) <= 64.0 and float(a['input_depth'][:, 1][a['input_depth'][:, 1] > 0].min()) >= 32.0
+
+
+def _dp_worker(rank, world, port, tmpdir):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import rcf_amd  # noqa: F401
+    from rcf_amd import synth, train
+    from rcf_amd.parallel import GradientBuckets
+    m = train.build_model(synth.TINY, device='cpu')
+    m.data_parallel()
+    assert isinstance(m._dp, GradientBuckets) and len(m._dp.bounds) >= 2
+    # simulate a backward: every rank fills its gradient arena with rank-dependent values, then the tape
+    # reports parameters in completion order
+    g = torch.Generator().manual_seed(100 + rank)
+    local = torch.rand(m._grad_arena.numel(), generator=g)
+    m._grad_arena.copy_(local)
+    m._dp.begin_backward()
+    launched_before_end = 0
+    for i, p in enumerate(m._used_params):
+        m._dp.on_param_grad(p)
+        if i < len(m._used_params) - 1:
+            launched_before_end = len(m._dp.handles)
+    m._dp.finish_backward()
+    sums = torch.tensor([1.0 + rank, 10.0, 2.0, 5.0 + rank], dtype=torch.float64)
+    m._all_reduce_loss_sums(sums)
+    torch.save({'local': local, 'reduced': m._grad_arena.clone(), 'n_used': m._n_used, 'sums': sums,
+                'early': launched_before_end, 'n_buckets': len(m._dp.bounds)}, os.path.join(tmpdir, 'r%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_all_reduce_two_ranks_gloo(pkg, tmp_path):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), 'r0.pt'))
+    r1 = torch.load(os.path.join(str(tmp_path), 'r1.pt'))
+    n = r0['n_used']
+    want = r0['local'] + r1['local']
+    for r in (r0, r1):
+        assert torch.allclose(r['reduced'][:n], want[:n])                     # SUM over ranks, no 1/world factor
+        assert torch.equal(r['reduced'][n:], r['local'][n:])                  # unused parameters are never reduced
+        assert r['sums'].tolist() == [3.0, 20.0, 4.0, 11.0]                   # global loss sums / valid counts
+        assert r['early'] >= r['n_buckets'] - 1                               # buckets launch before backward ends
