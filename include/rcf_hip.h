@@ -79,10 +79,10 @@ int rcf_conv2d_pack_weights(const rcf_conv_desc* d, const float* w_oihw, float* 
 /* torch.nn.Conv2d.forward, bias=False (src/net_utils.py:85); with gather1=NEAREST also the F.interpolate of
  * UpConv2d.forward (src/net_utils.py:195-198); with c2>0 also the torch.cat of DecoderBlock.forward
  * (src/net_utils.py:564-569).  With w_mode=DGRAD it is the input gradient autograd computes for that conv.
- * stat_partials (nullable): per-workgroup sum and sum-of-squares of the outputs per channel, consumed by
+ * stat_partials (nullable, fp64): per-workgroup sum and sum-of-squares of the outputs per channel, consumed by
  * rcf_bn_finalize -- the batch statistics of torch.nn.BatchNorm2d (src/net_utils.py:82,86). */
 int rcf_conv2d_fwd(const rcf_conv_desc* d, const float* in1, const float* in2, const float* packed,
-                   float* out, float* stat_partials, void* stream);
+                   float* out, double* stat_partials, void* stream);
 
 /* Weight gradient of the conv described by the FORWARD descriptor d: dw[o][i][ky][kx] (OIHW, same layout as
  * the parameter) = sum over pixels of in[...] * dz[...].  Replaces autograd's conv weight backward behind
@@ -95,7 +95,7 @@ int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const float* in2,
  * training != 0: batch statistics, and running_mean/var are updated with `momentum` (unbiased variance),
  * exactly torch.nn.BatchNorm2d(eps=1e-5, momentum=0.1) in train mode (src/net_utils.py:82).
  * training == 0: coefficients from the running statistics (eval mode); partials is ignored. */
-int rcf_bn_finalize(const float* partials, int n_partials, int c, double count,
+int rcf_bn_finalize(const double* partials, int n_partials, int c, double count,
                     const float* gamma, const float* beta, float* running_mean, float* running_var,
                     float momentum, float eps, int training, float* coef, void* stream);
 
@@ -109,13 +109,14 @@ int rcf_fuse_fwd(const float* zw, const float* coef_w, const float* zp, const fl
                  const float* img, float* out, long long n_pix, int c, void* stream);
 
 /* Backward of rcf_bn_act_fwd, two passes around a per-channel reduction (BatchNorm2d backward).
- * reduce: partials[n_blocks][2][c] = (sum g, sum g*xhat), g = dout * act'(.) (* lrelu'(out) when has_res).
+ * reduce: partials[n_blocks][2][c] (fp64: these sums cancel heavily, and PyTorch's CPU BatchNorm accumulates float
+ * tensors in double) = (sum g, sum g*xhat), g = dout * act'(.) (* lrelu'(out) when has_res).
  * n_blocks for a given (n_pix, c) comes from rcf_ew_blocks. */
 int rcf_ew_blocks(long long n_pix, int c);
 int rcf_bn_act_bwd_reduce(const float* dout, const float* z, const float* coef, const float* out,
-                          float* partials, long long n_pix, int c, int act, int has_res, void* stream);
+                          double* partials, long long n_pix, int c, int act, int has_res, void* stream);
 /* bcoef[2][c] = (sum g / M, sum g*xhat / M); dgamma[c], dbeta[c] (accumulate == 0: overwrite). */
-int rcf_bn_bwd_finalize(const float* partials, int n_blocks, int partial_stride, int c, double count,
+int rcf_bn_bwd_finalize(const double* partials, int n_blocks, int partial_stride, int c, double count,
                         float* bcoef, float* dgamma, float* dbeta, void* stream);
 /* dz = scale * (g - bcoef0 - xhat*bcoef1); dres (nullable) = dout*lrelu'(out), accumulated when dres_accumulate. */
 int rcf_bn_act_bwd_apply(const float* dout, const float* z, const float* coef, const float* out,
@@ -124,7 +125,7 @@ int rcf_bn_act_bwd_apply(const float* dout, const float* z, const float* coef, c
 
 /* Backward of rcf_fuse_fwd. partials[n_blocks][4][c]: (sum gw, sum gw*xhat_w, sum gp, sum gp*xhat_p). */
 int rcf_fuse_bwd_reduce(const float* dout, const float* zw, const float* coef_w, const float* zp,
-                        const float* coef_p, float* partials, long long n_pix, int c, void* stream);
+                        const float* coef_p, double* partials, long long n_pix, int c, void* stream);
 int rcf_fuse_bwd_apply(const float* dout, const float* zw, const float* coef_w, const float* zp,
                        const float* coef_p, const float* bcoef_w, const float* bcoef_p,
                        float* dzw, float* dzp, float* dimg, int dimg_accumulate,

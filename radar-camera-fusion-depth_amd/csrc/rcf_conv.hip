@@ -28,7 +28,7 @@ struct ConvArgs {
     const float* in2;
     const float* wp;
     float* out;
-    float* stats;
+    double* stats;
     const float* dz;   // wgrad only
     float* ws;         // wgrad only
     int n, h_in, w_in, c1, c2, h1, w1, gather1;
@@ -222,11 +222,14 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
     }
     if (a.stats != nullptr) {
         __syncthreads();   // LDS is free again
-        float* red = smem; // [4 waves][BN][2]
+        // in-lane fp32 sums cover <= 32 values; everything across lanes / waves / workgroups is fp64
+        // (PyTorch's CPU BatchNorm accumulates float tensors in double as well)
+        double* red = reinterpret_cast<double*>(smem); // [4 waves][BN][2]
 #pragma unroll
         for (int ni = 0; ni < C::NT; ++ni) {
-            const float t1 = s1[ni] + __shfl_xor(s1[ni], 32);
-            const float t2 = s2[ni] + __shfl_xor(s2[ni], 32);
+            const double d1 = (double)s1[ni], d2 = (double)s2[ni];
+            const double t1 = d1 + __shfl_xor(d1, 32);
+            const double t2 = d2 + __shfl_xor(d2, 32);
             if (lh == 0) {
                 red[(wave * C::BN + ni * 32 + li) * 2 + 0] = t1;
                 red[(wave * C::BN + ni * 32 + li) * 2 + 1] = t2;
@@ -236,7 +239,7 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
         if (tid < C::BN) {
             const int co = n0 + tid;
             if (co < a.c_out) {
-                float t1 = 0.f, t2 = 0.f;
+                double t1 = 0.0, t2 = 0.0;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     t1 += red[(w * C::BN + tid) * 2 + 0];
@@ -404,11 +407,11 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
             ci += c1;
         }
     }
-    float s = 0.f;
+    double s = 0.0;   // the per-workgroup partials cancel heavily for BN-followed convs: sum them in fp64
     const size_t stride = (size_t)ktot * cop;
-    for (int sl = 0; sl < nslot; ++sl) s += ws[sl * stride + idx];
+    for (int sl = 0; sl < nslot; ++sl) s += (double)ws[sl * stride + idx];
     const int kw = (kind == 1) ? 7 : ksx;
-    dw[(((size_t)co * (c1 + c2) + ci) * ksy_total + ky) * kw + kx] = s;
+    dw[(((size_t)co * (c1 + c2) + ci) * ksy_total + ky) * kw + kx] = (float)s;
 }
 
 // OIHW -> [n-tile][chunk][tap][BN][CK].  kind 0 generic, 1 stem (k = kx*4 + c, tap = ky).
@@ -681,7 +684,7 @@ extern "C" int rcf_conv2d_pack_weights(const rcf_conv_desc* d, const float* w_oi
 }
 
 extern "C" int rcf_conv2d_fwd(const rcf_conv_desc* d, const float* in1, const float* in2, const float* packed, float* out,
-                              float* stat_partials, void* stream) {
+                              double* stat_partials, void* stream) {
     if (!in1 || !packed || !out) return RCF_EINVAL;
     Sel s;
     int rc = select_cfg(d, &s);

@@ -95,8 +95,8 @@ __global__ void __launch_bounds__(256) fuse_fwd_kernel(const float* __restrict__
 // ---------------------------------------------------------------- block reduction of NS per-channel sums
 // Each thread holds s[NS][4] for its channel group; result row layout: partial[blk][NS][c].
 template <int NS>
-__device__ __forceinline__ void block_reduce_store(const float (&s)[NS][4], float* __restrict__ partial_row, int c,
-                                                   int cg, int pl, float* sm) {
+__device__ __forceinline__ void block_reduce_store(const double (&s)[NS][4], double* __restrict__ partial_row, int c,
+                                                   int cg, int pl, double* sm) {
     const int c4n = c >> 2;
     const int ppb = 256 / c4n;
     __syncthreads();
@@ -106,7 +106,7 @@ __device__ __forceinline__ void block_reduce_store(const float (&s)[NS][4], floa
         for (int j = 0; j < 4; ++j) sm[(pl * NS + q) * c + cg * 4 + j] = s[q][j];
     __syncthreads();
     for (int e = threadIdx.x; e < NS * c; e += 256) {
-        float t = 0.f;
+        double t = 0.0;
         for (int r = 0; r < ppb; ++r) t += sm[r * NS * c + e];
         partial_row[e] = t;
     }
@@ -114,15 +114,17 @@ __device__ __forceinline__ void block_reduce_store(const float (&s)[NS][4], floa
 
 __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ z,
                                                                 const float* __restrict__ coef, const float* __restrict__ out,
-                                                                float* __restrict__ partials, long long n_pix, int c, int act,
+                                                                double* __restrict__ partials, long long n_pix, int c, int act,
                                                                 int has_res) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+    extern __shared__ __attribute__((aligned(16))) double sm[];
     const int c4n = c >> 2;
     const int cg = threadIdx.x % c4n;
     const int pl = threadIdx.x / c4n;
     const int ppb = 256 / c4n;
     const Coef4 k = load_coef(coef, c, cg);
-    float s[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // fp64 accumulation: these sums cancel almost completely in-network (the upstream BatchNorm already made
+    // the gradient mean-free); PyTorch's CPU BatchNorm also accumulates float tensors in double.
+    double s[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
     for (long long p = (long long)blockIdx.x * ppb + pl; p < n_pix; p += (long long)gridDim.x * ppb) {
         const size_t i = (size_t)p * c + cg * 4;
         f32x4 g = ld4(dout, i);
@@ -137,8 +139,8 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(const float* __r
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (act == RCF_ACT_LEAKY_RELU) g[j] *= rcf_lrelu_grad(y[j]);
-            s[0][j] += g[j];
-            s[1][j] += g[j] * xh[j];
+            s[0][j] += (double)g[j];
+            s[1][j] += (double)g[j] * (double)xh[j];
         }
     }
     block_reduce_store<2>(s, partials + (size_t)blockIdx.x * 2 * c, c, cg, pl, sm);
@@ -185,20 +187,20 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const float* __re
 
 __global__ void __launch_bounds__(256) fuse_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ zw,
                                                               const float* __restrict__ coef_w, const float* __restrict__ zp,
-                                                              const float* __restrict__ coef_p, float* __restrict__ partials,
+                                                              const float* __restrict__ coef_p, double* __restrict__ partials,
                                                               long long n_pix, int c) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+    extern __shared__ __attribute__((aligned(16))) double sm[];
     const int c4n = c >> 2;
     const int cg = threadIdx.x % c4n;
     const int pl = threadIdx.x / c4n;
     const int ppb = 256 / c4n;
     const Coef4 kw = load_coef(coef_w, c, cg);
     const Coef4 kp = load_coef(coef_p, c, cg);
-    float s[4][4];
+    double s[4][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s[q][j] = 0.f;
+        for (int j = 0; j < 4; ++j) s[q][j] = 0.0;
     for (long long p = (long long)blockIdx.x * ppb + pl; p < n_pix; p += (long long)gridDim.x * ppb) {
         const size_t i = (size_t)p * c + cg * 4;
         const f32x4 g = ld4(dout, i);
@@ -213,10 +215,10 @@ __global__ void __launch_bounds__(256) fuse_bwd_reduce_kernel(const float* __res
             const float sg = 1.f / (1.f + expf(-yw[j]));
             const float gw = g[j] * yp[j] * sg * (1.f - sg);
             const float gp = g[j] * sg;
-            s[0][j] += gw;
-            s[1][j] += gw * xw[j];
-            s[2][j] += gp;
-            s[3][j] += gp * xp[j];
+            s[0][j] += (double)gw;
+            s[1][j] += (double)gw * (double)xw[j];
+            s[2][j] += (double)gp;
+            s[3][j] += (double)gp * (double)xp[j];
         }
     }
     block_reduce_store<4>(s, partials + (size_t)blockIdx.x * 4 * c, c, cg, pl, sm);
@@ -279,7 +281,7 @@ __device__ __forceinline__ double block_sum_double(double v, double* smd) {
     return t;
 }
 
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ partials, int n_partials, int c,
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restrict__ partials, int n_partials, int c,
                                                           double count, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var, float momentum, float eps,
@@ -290,8 +292,8 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
     if (training) {
         double s1 = 0.0, s2 = 0.0;
         for (int r = threadIdx.x; r < n_partials; r += blockDim.x) {
-            s1 += (double)partials[((size_t)r * 2 + 0) * c + ch];
-            s2 += (double)partials[((size_t)r * 2 + 1) * c + ch];
+            s1 += partials[((size_t)r * 2 + 0) * c + ch];
+            s2 += partials[((size_t)r * 2 + 1) * c + ch];
         }
         s1 = block_sum_double(s1, smd);
         s2 = block_sum_double(s2, smd);
@@ -317,14 +319,14 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
     }
 }
 
-__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __restrict__ partials, int n_blocks, int stride,
+__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double* __restrict__ partials, int n_blocks, int stride,
                                                              int c, double count, float* __restrict__ bcoef,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int ch = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
     for (int r = threadIdx.x; r < n_blocks; r += 64) {
-        s1 += (double)partials[(size_t)r * stride + ch];
-        s2 += (double)partials[(size_t)r * stride + c + ch];
+        s1 += partials[(size_t)r * stride + ch];
+        s2 += partials[(size_t)r * stride + c + ch];
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -346,7 +348,7 @@ extern "C" int rcf_ew_blocks(long long n_pix, int c) {
     return ew_blocks(n_pix, c);
 }
 
-extern "C" int rcf_bn_finalize(const float* partials, int n_partials, int c, double count, const float* gamma,
+extern "C" int rcf_bn_finalize(const double* partials, int n_partials, int c, double count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                int training, float* coef, void* stream) {
     if (c <= 0 || !gamma || !beta || !running_mean || !running_var || !coef) return RCF_EINVAL;
@@ -374,17 +376,17 @@ extern "C" int rcf_fuse_fwd(const float* zw, const float* coef_w, const float* z
     return rcf_launch_status();
 }
 
-extern "C" int rcf_bn_act_bwd_reduce(const float* dout, const float* z, const float* coef, const float* out, float* partials,
+extern "C" int rcf_bn_act_bwd_reduce(const float* dout, const float* z, const float* coef, const float* out, double* partials,
                                      long long n_pix, int c, int act, int has_res, void* stream) {
     if (!dout || !z || !coef || !partials || n_pix <= 0 || (has_res && !out)) return RCF_EINVAL;
     if (!c4_ok(c)) return RCF_EUNSUPPORTED;
     const int ppb = 256 / (c >> 2);
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), (size_t)ppb * 2 * c * sizeof(float),
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), (size_t)ppb * 2 * c * sizeof(double),
                        (hipStream_t)stream, dout, z, coef, out, partials, n_pix, c, act, has_res);
     return rcf_launch_status();
 }
 
-extern "C" int rcf_bn_bwd_finalize(const float* partials, int n_blocks, int partial_stride, int c, double count, float* bcoef,
+extern "C" int rcf_bn_bwd_finalize(const double* partials, int n_blocks, int partial_stride, int c, double count, float* bcoef,
                                    float* dgamma, float* dbeta, void* stream) {
     if (!partials || n_blocks <= 0 || c <= 0 || partial_stride < 2 * c || count <= 0.0 || !bcoef || !dgamma || !dbeta)
         return RCF_EINVAL;
@@ -404,11 +406,11 @@ extern "C" int rcf_bn_act_bwd_apply(const float* dout, const float* z, const flo
 }
 
 extern "C" int rcf_fuse_bwd_reduce(const float* dout, const float* zw, const float* coef_w, const float* zp,
-                                   const float* coef_p, float* partials, long long n_pix, int c, void* stream) {
+                                   const float* coef_p, double* partials, long long n_pix, int c, void* stream) {
     if (!dout || !zw || !coef_w || !zp || !coef_p || !partials || n_pix <= 0) return RCF_EINVAL;
     if (!c4_ok(c)) return RCF_EUNSUPPORTED;
     const int ppb = 256 / (c >> 2);
-    hipLaunchKernelGGL(fuse_bwd_reduce_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), (size_t)ppb * 4 * c * sizeof(float),
+    hipLaunchKernelGGL(fuse_bwd_reduce_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), (size_t)ppb * 4 * c * sizeof(double),
                        (hipStream_t)stream, dout, zw, coef_w, zp, coef_p, partials, n_pix, c);
     return rcf_launch_status();
 }

@@ -70,7 +70,7 @@ class Engine(object):
         packed = self._new((info.packed_weight_floats,), x.t)
         ops.conv_pack(desc, weight.detach(), packed)
         z = self._new((n, desc.h_out, desc.w_out, desc.c_out), x.t)
-        partials = self._new((info.n_partials, 2, desc.c_out), x.t) if want_stats else None
+        partials = torch.empty((info.n_partials, 2, desc.c_out), dtype=torch.float64, device=x.t.device) if want_stats else None
         if self.prof is not None:
             self.prof.begin(info.kernel_id, ops.algorithmic_flops(desc))
         ops.conv_fwd(desc, x.t, None if x2 is None else x2.t, packed, z, partials)
@@ -150,7 +150,7 @@ class Engine(object):
             def backward():
                 dout = out.g
                 nb = ops.ew_blocks(n_pix, c)
-                bpart = self._new((nb, 2, c), z)
+                bpart = torch.empty((nb, 2, c), dtype=torch.float64, device=z.device)
                 has_res = res is not None
                 ops.bn_act_bwd_reduce(dout, z, coef, out.t, bpart, n_pix, c, RCF_ACT_LEAKY_RELU, has_res)
                 bcoef = self._new((2, c), z)
@@ -203,7 +203,7 @@ class Engine(object):
             def backward():
                 dout = out.g
                 nb = ops.ew_blocks(n_pix, c)
-                bpart = self._new((nb, 4, c), zw)
+                bpart = torch.empty((nb, 4, c), dtype=torch.float64, device=zw.device)
                 ops.fuse_bwd_reduce(dout, zw, coef_w, zp, coef_p, bpart, n_pix, c)
                 bcw = self._new((2, c), zw)
                 bcp = self._new((2, c), zw)

@@ -27,6 +27,12 @@ def _p(t):
     return t.data_ptr()
 
 
+def _f64(t):
+    if t is not None and t.dtype != torch.float64:
+        raise _lib.RcfError('this rcf buffer is fp64; got %s' % t.dtype)
+    return _p(t)
+
+
 def _f32(t):
     if t is not None and t.dtype != torch.float32:
         raise _lib.RcfError('rcf ops are fp32; got %s' % t.dtype)
@@ -120,7 +126,7 @@ def conv_pack(desc, w_oihw, packed):
 
 def conv_fwd(desc, in1, in2, packed, out, stat_partials=None):
     check(_lib.load().rcf_conv2d_fwd(ctypes.byref(desc), _f32(in1), _f32(in2), _f32(packed), _f32(out),
-                                     _f32(stat_partials), _stream()), 'rcf_conv2d_fwd')
+                                     _f64(stat_partials), _stream()), 'rcf_conv2d_fwd')
 
 
 def conv_wgrad(desc, in1, in2, dz, dw, workspace):
@@ -129,7 +135,7 @@ def conv_wgrad(desc, in1, in2, dz, dw, workspace):
 
 
 def bn_finalize(partials, n_partials, c, count, gamma, beta, running_mean, running_var, momentum, eps, training, coef):
-    check(_lib.load().rcf_bn_finalize(_f32(partials), n_partials, c, float(count), _f32(gamma), _f32(beta),
+    check(_lib.load().rcf_bn_finalize(_f64(partials), n_partials, c, float(count), _f32(gamma), _f32(beta),
                                       _f32(running_mean), _f32(running_var), momentum, eps, 1 if training else 0,
                                       _f32(coef), _stream()), 'rcf_bn_finalize')
 
@@ -151,12 +157,12 @@ def ew_blocks(n_pix, c):
 
 
 def bn_act_bwd_reduce(dout, z, coef, out, partials, n_pix, c, act, has_res):
-    check(_lib.load().rcf_bn_act_bwd_reduce(_f32(dout), _f32(z), _f32(coef), _f32(out), _f32(partials), n_pix, c, act,
+    check(_lib.load().rcf_bn_act_bwd_reduce(_f32(dout), _f32(z), _f32(coef), _f32(out), _f64(partials), n_pix, c, act,
                                             1 if has_res else 0, _stream()), 'rcf_bn_act_bwd_reduce')
 
 
 def bn_bwd_finalize(partials, n_blocks, stride, c, count, bcoef, dgamma, dbeta):
-    check(_lib.load().rcf_bn_bwd_finalize(_f32(partials), n_blocks, stride, c, float(count), _f32(bcoef), _f32(dgamma),
+    check(_lib.load().rcf_bn_bwd_finalize(_f64(partials), n_blocks, stride, c, float(count), _f32(bcoef), _f32(dgamma),
                                           _f32(dbeta), _stream()), 'rcf_bn_bwd_finalize')
 
 
@@ -167,7 +173,7 @@ def bn_act_bwd_apply(dout, z, coef, out, bcoef, dz, dres, dres_accumulate, n_pix
 
 
 def fuse_bwd_reduce(dout, zw, coef_w, zp, coef_p, partials, n_pix, c):
-    check(_lib.load().rcf_fuse_bwd_reduce(_f32(dout), _f32(zw), _f32(coef_w), _f32(zp), _f32(coef_p), _f32(partials),
+    check(_lib.load().rcf_fuse_bwd_reduce(_f32(dout), _f32(zw), _f32(coef_w), _f32(zp), _f32(coef_p), _f64(partials),
                                           n_pix, c, _stream()), 'rcf_fuse_bwd_reduce')
 
 

@@ -102,13 +102,13 @@ def test_conv_forward_and_bn_statistics(ops, case):
     packed = torch.empty(info.packed_weight_floats, device='cuda')
     ops.conv_pack(d, dev(wt), packed)
     out = torch.full((d.n, d.h_out, d.w_out, d.c_out), float('nan'), device='cuda')
-    partials = torch.full((info.n_partials, 2, d.c_out), float('nan'), device='cuda')
+    partials = torch.full((info.n_partials, 2, d.c_out), float('nan'), device='cuda', dtype=torch.float64)
     ops.conv_fwd(d, nhwc(x1), None if x2 is None else nhwc(x2), packed, out, partials)
     torch.cuda.synchronize()
     got = nchw(out)
     assert got.shape == ref.shape
     assert rel(got, ref) < TOL
-    s = partials.double().sum(0).cpu()
+    s = partials.sum(0).cpu()
     assert rel(s[0], ref.double().sum((0, 2, 3))) < 1e-3 or float((s[0] - ref.double().sum((0, 2, 3))).abs().max()) < 1e-2
     assert rel(s[1], (ref.double() ** 2).sum((0, 2, 3))) < TOL
 
@@ -186,7 +186,7 @@ def test_batchnorm_leakyrelu_residual_forward_backward(ops, c, n, h, w, has_res)
     n_pix = n * h * w
     zg = nhwc(z)
     # statistics partials as the conv epilogue would produce them (one partial row)
-    part = torch.stack([zg.view(-1, c).double().sum(0), (zg.view(-1, c).double() ** 2).sum(0)]).float().view(1, 2, c).contiguous()
+    part = torch.stack([zg.view(-1, c).double().sum(0), (zg.view(-1, c).double() ** 2).sum(0)]).view(1, 2, c).contiguous()
     coef = torch.empty(4, c, device='cuda')
     rmg, rvg = dev(rm0.clone()), dev(rv0.clone())
     ops.bn_finalize(part, 1, c, n_pix, dev(gamma), dev(beta), rmg, rvg, 0.1, 1e-5, True, coef)
@@ -198,7 +198,7 @@ def test_batchnorm_leakyrelu_residual_forward_backward(ops, c, n, h, w, has_res)
     assert rel(rmg.cpu(), rm) < 1e-5 and rel(rvg.cpu(), rv) < 1e-5
 
     nb = ops.ew_blocks(n_pix, c)
-    bpart = torch.empty(nb, 2, c, device='cuda')
+    bpart = torch.empty(nb, 2, c, device='cuda', dtype=torch.float64)
     doutg = nhwc(dout)
     ops.bn_act_bwd_reduce(doutg, zg, coef, out, bpart, n_pix, c, 1, has_res)
     bcoef = torch.empty(2, c, device='cuda')
@@ -236,7 +236,7 @@ def test_weight_and_project_fusion_forward_backward(ops, c, n, h, w):
     zwg, zpg, imgg, doutg = nhwc(zw), nhwc(zp), nhwc(img), nhwc(dout)
 
     def coef_of(zg, g, bb):
-        part = torch.stack([zg.view(-1, c).double().sum(0), (zg.view(-1, c).double() ** 2).sum(0)]).float().view(1, 2, c).contiguous()
+        part = torch.stack([zg.view(-1, c).double().sum(0), (zg.view(-1, c).double() ** 2).sum(0)]).view(1, 2, c).contiguous()
         coef = torch.empty(4, c, device='cuda')
         ops.bn_finalize(part, 1, c, n_pix, dev(g), dev(bb), torch.zeros(c, device='cuda'), torch.ones(c, device='cuda'),
                         0.1, 1e-5, True, coef)
@@ -248,7 +248,7 @@ def test_weight_and_project_fusion_forward_backward(ops, c, n, h, w):
     assert rel(nchw(out), y.detach()) < TOL
 
     nb = ops.ew_blocks(n_pix, c)
-    bpart = torch.empty(nb, 4, c, device='cuda')
+    bpart = torch.empty(nb, 4, c, device='cuda', dtype=torch.float64)
     ops.fuse_bwd_reduce(doutg, zwg, cw, zpg, cp, bpart, n_pix, c)
     bcw, bcp = torch.empty(2, c, device='cuda'), torch.empty(2, c, device='cuda')
     dgw, dbw, dgp, dbp = (torch.empty(c, device='cuda') for _ in range(4))
