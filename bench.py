@@ -53,8 +53,8 @@ def cpu_baseline(height, width, points):
     import torch
     from rcf_amd import synth
     from oracle.fusionnet_oracle import FusionNetOracle
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    # torch's default intra-op thread count (= physical cores): setting it to the logical-CPU count
+    # (256 on the 2 x EPYC 9575F box) oversubscribes oneDNN and is ~25x slower
     model = FusionNetOracle(**synth.PUBLISHED)
     synth.fill_state_dict_([model.encoder, model.decoder], 1234)
     opt = torch.optim.Adam([{'params': model.parameters(), 'weight_decay': 0.0}], lr=1e-3)
