@@ -169,8 +169,10 @@ def main():
         if args.kernel_table:
             rows = [{'kernel_id': kid, 'launches': c, 'gflop': f / 1e9, 'ms': m, 'tflops': f / (m * 1e-3) / 1e12 if m > 0 else 0}
                     for kid, (c, f, m) in sorted(table.items())]
+            layers = [{'kernel_id': k[0], 'layer': k[1], 'launches': c, 'gflop': f / 1e9, 'ms': m,
+                       'tflops': f / (m * 1e-3) / 1e12 if m > 0 else 0} for k, (c, f, m) in sorted(timer.layers.items(), key=lambda kv: -kv[1][2])]
             with open(args.kernel_table, 'w') as fh:
-                json.dump({'steps': args.steps, 'ms_per_step': 1000.0 * dt / args.steps, 'kernels': rows}, fh, indent=1)
+                json.dump({'steps': args.steps, 'ms_per_step': 1000.0 * dt / args.steps, 'kernels': rows, 'layers': layers}, fh, indent=1)
         if world == 1 and not args.no_cpu_baseline:
             rec['cpu_baseline'] = cpu_baseline(args.height, args.width, args.points)
         print(json.dumps(rec), flush=True)

@@ -32,6 +32,13 @@ extern "C" {
 #define RCF_GATHER_DIRECT 0     /* source 1 is read as is */
 #define RCF_GATHER_NEAREST 1    /* source 1 is nearest-upsampled to (h_in,w_in): F.interpolate(x,size), src/net_utils.py:196 */
 #define RCF_GATHER_ZERO_INSERT 2 /* source 1 is zero-dilated by 2 (transposed conv: dgrad of a stride-2 conv) */
+#define RCF_GATHER_STRIDED2 3   /* logical pixel (y,x) is physical pixel (2y+in_off_y, 2x+in_off_x) of source 1: one phase of a tensor */
+
+/* Phase decomposition (rcf_phase_weights): a 3x3 conv on an exactly-2x nearest-upsampled tensor is four 2x2 convs
+ * on the source (4/9 of the MACs); the input gradient of a 3x3 stride-2 conv is four 2x2 convs on dZ. */
+#define RCF_PHASE_UP2X_FWD 0   /* Wp[a][b][o][i][t][u] = sum of the 3x3 taps that land on source tap (t,u) for output phase (a,b) */
+#define RCF_PHASE_UP2X_DGRAD 1 /* the same, channel-transposed and tap-flipped: maps dZ phase (a,b) to dX */
+#define RCF_PHASE_S2_DGRAD 2   /* W[o][i][ky][kx] selected per input-pixel phase (a,b) of a stride-2 conv, channel-transposed */
 
 #define RCF_W_FORWARD 0 /* weight tensor is used as stored: out channel O, in channel I */
 #define RCF_W_DGRAD 1   /* flipped taps and swapped roles: this conv maps dZ (O channels) to dX (a slice of I) */
@@ -49,13 +56,19 @@ typedef struct rcf_conv_desc {
     int h_src1, w_src1; /* physical extent of source 1 (== h_in,w_in for RCF_GATHER_DIRECT) */
     int gather1;        /* RCF_GATHER_* */
     int h_out, w_out, c_out;
-    int ksize;          /* 1, 3 or 7 */
+    int ksize;          /* 1, 2 (phase convs), 3 or 7 */
     int stride;         /* 1 or 2 */
-    int pad;            /* ksize/2 for the reference's Conv2d (src/net_utils.py:61); ksize-1-pad for its dgrad */
+    int pad;            /* top pad; ksize/2 for the reference's Conv2d (src/net_utils.py:61); ksize-1-pad for its dgrad */
+    int pad_x;          /* left pad (== pad except for the 2x2 phase convs) */
     int w_mode;         /* RCF_W_FORWARD / RCF_W_DGRAD */
     int w_o, w_i;       /* dims of the OIHW weight tensor this conv is packed from */
     int w_i_off;        /* RCF_W_DGRAD: first input channel of the dX slice produced (c_out channels) */
     int accumulate;     /* out += result instead of out = result */
+    /* phase addressing: output pixel (oy,ox) lives at (oy*out_stride+out_off_y, ox*out_stride+out_off_x) of a tensor with
+     * out_h_phys x out_w_phys pixels (out_stride 1, offsets 0, phys == h_out,w_out for an ordinary conv); rcf_conv2d_wgrad
+     * reads dZ through the same map.  in_off_*: RCF_GATHER_STRIDED2 only. */
+    int out_stride, out_off_y, out_off_x, out_h_phys, out_w_phys;
+    int in_off_y, in_off_x;
 } rcf_conv_desc;
 
 typedef struct rcf_conv_info {
@@ -89,6 +102,13 @@ int rcf_conv2d_fwd(const rcf_conv_desc* d, const float* in1, const float* in2, c
  * loss.backward() (src/fusionnet_main.py:398). */
 int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const float* in2, const float* dz,
                      float* dw_oihw, float* workspace, void* stream);
+
+/* Phase weights.  w: the layer's OIHW 3x3 weight [o][i][3][3]; out: [4 phases (a*2+b)][O'][I'][2][2] with
+ * (O',I') = (o,i) for RCF_PHASE_UP2X_FWD and (i,o) for the two DGRAD modes.  Each phase block is then packed with
+ * rcf_conv2d_pack_weights (ksize 2, RCF_W_FORWARD).  rcf_phase_wgrad_fold maps the four 2x2 phase weight gradients
+ * of an up-2x conv back to the 3x3 gradient: dw[o][i][ky][kx] = sum_{a,b} dwp[a][b][o][i][t(a,ky)][u(b,kx)]. */
+int rcf_phase_weights(const float* w_oihw, float* out, int o, int i, int mode, void* stream);
+int rcf_phase_wgrad_fold(const float* dwp, float* dw_oihw, int o, int i, void* stream);
 
 /* BatchNorm2d batch statistics -> affine coefficients.  partials: [n_partials][2][c] from rcf_conv2d_fwd.
  * coef: [4][c] = scale (gamma*invstd), shift (beta-mean*scale), mean, invstd.

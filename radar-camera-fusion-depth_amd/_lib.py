@@ -10,7 +10,8 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_lon
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librcf_hip.so')
 
-RCF_GATHER_DIRECT, RCF_GATHER_NEAREST, RCF_GATHER_ZERO_INSERT = 0, 1, 2
+RCF_GATHER_DIRECT, RCF_GATHER_NEAREST, RCF_GATHER_ZERO_INSERT, RCF_GATHER_STRIDED2 = 0, 1, 2, 3
+RCF_PHASE_UP2X_FWD, RCF_PHASE_UP2X_DGRAD, RCF_PHASE_S2_DGRAD = 0, 1, 2
 RCF_W_FORWARD, RCF_W_DGRAD = 0, 1
 RCF_ACT_NONE, RCF_ACT_LEAKY_RELU = 0, 1
 
@@ -18,7 +19,8 @@ RCF_ACT_NONE, RCF_ACT_LEAKY_RELU = 0, 1
 class ConvDesc(Structure):
     _fields_ = [(n, c_int) for n in (
         'n', 'h_in', 'w_in', 'c1', 'c2', 'h_src1', 'w_src1', 'gather1', 'h_out', 'w_out', 'c_out',
-        'ksize', 'stride', 'pad', 'w_mode', 'w_o', 'w_i', 'w_i_off', 'accumulate')]
+        'ksize', 'stride', 'pad', 'pad_x', 'w_mode', 'w_o', 'w_i', 'w_i_off', 'accumulate',
+        'out_stride', 'out_off_y', 'out_off_x', 'out_h_phys', 'out_w_phys', 'in_off_y', 'in_off_x')]
 
 
 class ConvInfo(Structure):
@@ -34,6 +36,8 @@ _SIGNATURES = {
     'rcf_conv2d_pack_weights': (c_int, [POINTER(ConvDesc), _P, _P, _P]),
     'rcf_conv2d_fwd': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     'rcf_conv2d_wgrad': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    'rcf_phase_weights': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'rcf_phase_wgrad_fold': (c_int, [_P, _P, c_int, c_int, _P]),
     'rcf_bn_finalize': (c_int, [_P, c_int, c_int, c_double, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P]),
     'rcf_bn_act_fwd': (c_int, [_P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
     'rcf_fuse_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, _P]),

@@ -20,6 +20,7 @@
 //    sum of squares BatchNorm needs (in-lane adds -> one cross-half shuffle -> LDS across the 4 waves ->
 //    one partial row per workgroup; no atomics, deterministic).
 #include "rcf_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -30,9 +31,12 @@ struct ConvArgs {
     float* out;
     double* stats;
     const float* dz;   // wgrad only
+    const float* zero; // wgrad DMA path: >= 16 bytes of zeros in global memory (source of padded lanes)
     float* ws;         // wgrad only
     int n, h_in, w_in, c1, c2, h1, w1, gather1;
-    int h_out, w_out, c_out, pad, stride, gstep, accumulate;
+    int h_out, w_out, c_out, pad, pad_x, stride, gstep, accumulate;
+    int os, ooy, oox, ohp, owp;   // output (and wgrad dZ) phase addressing
+    int ioy, iox;                 // RCF_GATHER_STRIDED2 input offsets
     float sy, sx;
     int tiles_x, tiles_y, ntiles;
     int nchunk1, nchunk2;
@@ -57,52 +61,90 @@ struct FwdCfg {
     static constexpr int MINW = MINW_;
 };
 
-// Stage one chunk of the input halo tile into LDS.  Halo pixel (hy,hx) <-> logical input pixel
-// (iy0 + hy*gstep, ix0 + hx*gstep); out-of-image pixels and channels >= csrc are zero (the conv's zero padding).
+// Halo staging, split in three so the HBM/L2 latency hides under the MFMAs of the previous chunk:
+//   halo_setup  once per (tile, source): each thread's NA halo elements -> global pixel index (or -1 for zero padding /
+//               zero-insert holes / outside the tile); all the gather math (nearest upsample, zero dilation) lives here
+//   halo_load   per chunk: NA independent 16-B loads into registers (no LDS, no waits)
+//   halo_store  per chunk: registers -> LDS
+// Halo pixel (hy,hx) <-> logical input pixel (iy0 + hy*gstep, ix0 + hx*gstep).  Thread t owns channel group t % C4 of
+// pixels t / C4 + i * (256 / C4).
 template <int CST, int STRP, int HXP, int HYP>
-__device__ __forceinline__ void stage_halo(float* __restrict__ As, const float* __restrict__ src, int csrc, int cb,
-                                           int hs, int ws, int gmode, int img, int iy0, int ix0, int gstep,
-                                           int h_in, int w_in, float sy, float sx, int tid) {
-    constexpr int C4 = CST / 4;
-    constexpr int NV = HXP * HYP * C4;
-    const bool vec = (csrc & 3) == 0;
-    for (int idx = tid; idx < NV; idx += 256) {
-        const int p = idx / C4;
-        const int c4 = idx - p * C4;
-        const int hy = p / HXP;
-        const int hx = p - hy * HXP;
-        const int ly = iy0 + hy * gstep;
-        const int lx = ix0 + hx * gstep;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int c = cb + c4 * 4;
-        if (ly >= 0 && ly < h_in && lx >= 0 && lx < w_in && c < csrc) {
-            int py = ly, px = lx;
-            bool ok = true;
-            if (gmode == RCF_GATHER_NEAREST) {
-                // PyTorch nearest: src = min(floor(dst * (float)in/out), in-1)  (UpSampleKernel nearest_idx)
-                py = min((int)floorf((float)ly * sy), hs - 1);
-                px = min((int)floorf((float)lx * sx), ws - 1);
-            } else if (gmode == RCF_GATHER_ZERO_INSERT) {
-                ok = ((ly | lx) & 1) == 0;
-                py = ly >> 1;
-                px = lx >> 1;
-                ok = ok && py < hs && px < ws;
+struct Halo {
+    static constexpr int C4 = CST / 4;
+    static constexpr int PPI = 256 / C4;                       // halo pixels covered per iteration
+    static constexpr int NA = (HXP * HYP + PPI - 1) / PPI;
+    int pix[NA];                                               // element index of the pixel in the source, / csrc; -1: zero
+
+    __device__ __forceinline__ void setup(int hs, int ws, int gmode, int img, int iy0, int ix0, int gstep, int h_in, int w_in,
+                                          float sy, float sx, int tid, int ioy = 0, int iox = 0) {
+        const int p0 = tid / C4;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int p = p0 + i * PPI;
+            const int hy = p / HXP;
+            const int hx = p - hy * HXP;
+            const int ly = iy0 + hy * gstep;
+            const int lx = ix0 + hx * gstep;
+            int v = -1;
+            if (p < HXP * HYP && ly >= 0 && ly < h_in && lx >= 0 && lx < w_in) {
+                int py = ly, px = lx;
+                bool ok = true;
+                if (gmode == RCF_GATHER_NEAREST) {
+                    // PyTorch nearest: src = min(floor(dst * (float)in/out), in-1)
+                    py = min((int)floorf((float)ly * sy), hs - 1);
+                    px = min((int)floorf((float)lx * sx), ws - 1);
+                } else if (gmode == RCF_GATHER_ZERO_INSERT) {
+                    ok = ((ly | lx) & 1) == 0;
+                    py = ly >> 1;
+                    px = lx >> 1;
+                    ok = ok && py < hs && px < ws;
+                } else if (gmode == RCF_GATHER_STRIDED2) {
+                    py = 2 * ly + ioy;
+                    px = 2 * lx + iox;
+                    ok = py < hs && px < ws;
+                }
+                if (ok) v = (img * hs + py) * ws + px;
             }
-            if (ok) {
-                const float* g = src + (((size_t)img * hs + py) * ws + px) * csrc + c;
-                if (vec) {
-                    v = *reinterpret_cast<const f32x4*>(g);
-                } else {
+            pix[i] = v;
+        }
+    }
+
+    __device__ __forceinline__ void load(f32x4 (&r)[NA], const float* __restrict__ src, int csrc, int cb, int tid) const {
+        const int c = cb + (tid % C4) * 4;
+        const bool cok = c < csrc;
+        if ((csrc & 3) == 0) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (cok && pix[i] >= 0) v = *reinterpret_cast<const f32x4*>(src + (size_t)pix[i] * csrc + c);
+                r[i] = v;
+            }
+        } else {   // stems (3 / 2 input channels): scalar loads
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (cok && pix[i] >= 0) {
+                    const float* g = src + (size_t)pix[i] * csrc + c;
                     v[0] = g[0];
                     if (c + 1 < csrc) v[1] = g[1];
                     if (c + 2 < csrc) v[2] = g[2];
                     if (c + 3 < csrc) v[3] = g[3];
                 }
+                r[i] = v;
             }
         }
-        *reinterpret_cast<f32x4*>(As + p * STRP + c4 * 4) = v;
     }
-}
+
+    __device__ __forceinline__ void store(const f32x4 (&r)[NA], float* __restrict__ As, int tid) const {
+        const int p0 = tid / C4;
+        const int c4 = tid % C4;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int p = p0 + i * PPI;
+            if (p < HXP * HYP) *reinterpret_cast<f32x4*>(As + p * STRP + c4 * 4) = r[i];
+        }
+    }
+};
 
 template <class C>
 __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
@@ -115,16 +157,6 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
     const int li = lane & 31;
     const int lh = lane >> 5;
 
-    int t = blockIdx.x;
-    const int tx = t % a.tiles_x;
-    t /= a.tiles_x;
-    const int ty = t % a.tiles_y;
-    const int img = t / a.tiles_y;
-    const int oy0 = ty * C::TH;
-    const int ox0 = tx * C::PX;
-    const int iy0 = oy0 * a.stride - a.pad;
-    const int ix0 = ox0 * a.stride - a.pad;
-
     int abase[C::MT];
 #pragma unroll
     for (int mi = 0; mi < C::MT; ++mi) {
@@ -135,41 +167,71 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
     const int bbase = li * C::STRB + 4 * lh;
 
     f32x16 acc[C::MT][C::NT];
-#pragma unroll
-    for (int mi = 0; mi < C::MT; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < C::NT; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const int nchunk = a.nchunk1 + a.nchunk2;
     constexpr int WCHUNK = C::T * C::BN * C::CK;
     const float* wp = a.wp + (size_t)blockIdx.y * nchunk * WCHUNK;
+    const int n0 = blockIdx.y * C::BN;
 
-    for (int q = 0; q < nchunk; ++q) {
+    using H = Halo<C::CST, C::STRP, C::HXP, C::HYP>;
+    constexpr int K4 = C::CK / 4;
+    constexpr int NVB = C::T * C::BN * K4;
+    constexpr int NB = (NVB + 255) / 256;
+    H halo;
+    f32x4 ra[H::NA];
+    f32x4 rb[NB];
+
+    // Work items are (tile, chunk) pairs; the workgroup is persistent over tiles (grid-stride) and the loads of item i+1
+    // are issued before the MFMAs of item i, also across a tile boundary.
+    auto load_item = [&](int tile, int q) {
         const bool first = q < a.nchunk1;
-        const float* src = first ? a.in1 : a.in2;
-        const int csrc = first ? a.c1 : a.c2;
-        const int cb = (first ? q : q - a.nchunk1) * C::CST;
-        const int hs = first ? a.h1 : a.h_in;
-        const int ws = first ? a.w1 : a.w_in;
-        const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
+        if (q == 0 || q == a.nchunk1) {
+            int t = tile;
+            const int tx = t % a.tiles_x;
+            t /= a.tiles_x;
+            const int ty = t % a.tiles_y;
+            const int img = t / a.tiles_y;
+            const int iy0 = ty * C::TH * a.stride - a.pad;
+            const int ix0 = tx * C::PX * a.stride - a.pad_x;
+            if (q == 0)
+                halo.setup(a.h1, a.w1, a.gather1, img, iy0, ix0, a.gstep, a.h_in, a.w_in, a.sy, a.sx, tid, a.ioy, a.iox);
+            else
+                halo.setup(a.h_in, a.w_in, RCF_GATHER_DIRECT, img, iy0, ix0, a.gstep, a.h_in, a.w_in, 1.f, 1.f, tid);
+        }
+        halo.load(ra, first ? a.in1 : a.in2, first ? a.c1 : a.c2, (first ? q : q - a.nchunk1) * C::CST, tid);
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + (size_t)q * WCHUNK);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + i * 256;
+            if (NVB % 256 == 0 || idx < NVB) rb[i] = wsrc[idx];
+        }
+    };
 
-        __syncthreads();   // everyone is done reading the previous chunk
-        stage_halo<C::CST, C::STRP, C::HXP, C::HYP>(As, src, csrc, cb, hs, ws, gmode, img, iy0, ix0, a.gstep,
-                                                    a.h_in, a.w_in, a.sy, a.sx, tid);
-        {
-            constexpr int K4 = C::CK / 4;
-            constexpr int NVB = C::T * C::BN * K4;
-            const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + (size_t)q * WCHUNK);
-            for (int idx = tid; idx < NVB; idx += 256) {
-                const int row = idx / K4;
-                const int k4 = idx - row * K4;
-                *reinterpret_cast<f32x4*>(Bs + row * C::STRB + k4 * 4) = wsrc[idx];
-            }
+    int tile = blockIdx.x;
+    int q = 0;
+    if (tile < a.ntiles) load_item(tile, 0);
+    while (tile < a.ntiles) {
+        __syncthreads();   // everyone is done reading the previous item from LDS
+        halo.store(ra, As, tid);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + i * 256;
+            if (NVB % 256 == 0 || idx < NVB)
+                *reinterpret_cast<f32x4*>(Bs + (idx / K4) * C::STRB + (idx % K4) * 4) = rb[i];
         }
         __syncthreads();
+        int ntile = tile, nq = q + 1;
+        if (nq == nchunk) { nq = 0; ntile = tile + gridDim.x; }
+        if (ntile < a.ntiles) load_item(ntile, nq);   // in flight while the MFMAs below run
 
+        if (q == 0) {
+#pragma unroll
+            for (int mi = 0; mi < C::MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        }
 #pragma unroll
         for (int tap = 0; tap < C::T; ++tap) {
             const int toff = ((tap / C::KSX) * C::HXP + (tap % C::KSX)) * C::STRP;
@@ -191,64 +253,75 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][kq], bv[ni][kq], acc[mi][ni], 0, 0, 0);
             }
         }
-    }
 
-    // ---- epilogue: store (+accumulate) and BN statistics ----
-    const int n0 = blockIdx.y * C::BN;
-    float s1[C::NT], s2[C::NT];
+        if (q == nchunk - 1) {
+            // ---- epilogue of this tile: store (+accumulate) and BN statistics ----
+            int t = tile;
+            const int tx = t % a.tiles_x;
+            t /= a.tiles_x;
+            const int ty = t % a.tiles_y;
+            const int img = t / a.tiles_y;
+            const int oy0 = ty * C::TH;
+            const int ox0 = tx * C::PX;
+            float s1[C::NT], s2[C::NT];
 #pragma unroll
-    for (int ni = 0; ni < C::NT; ++ni) { s1[ni] = 0.f; s2[ni] = 0.f; }
+            for (int ni = 0; ni < C::NT; ++ni) { s1[ni] = 0.f; s2[ni] = 0.f; }
 #pragma unroll
-    for (int mi = 0; mi < C::MT; ++mi) {
+            for (int mi = 0; mi < C::MT; ++mi) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rcf_mfma_row(r, lh);
-            const int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
-            const int ox = ox0 + row % C::PX;
-            const bool pix_ok = oy < a.h_out && ox < a.w_out;
-            const size_t pbase = (((size_t)img * a.h_out + oy) * a.w_out + ox) * a.c_out;
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rcf_mfma_row(r, lh);
+                    const int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
+                    const int ox = ox0 + row % C::PX;
+                    const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+                    const bool pix_ok = oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
+                    const size_t pbase = (((size_t)img * a.ohp + py) * a.owp + px) * a.c_out;
 #pragma unroll
-            for (int ni = 0; ni < C::NT; ++ni) {
-                const int co = n0 + ni * 32 + li;
-                if (pix_ok && co < a.c_out) {
-                    float v = acc[mi][ni][r];
-                    if (a.accumulate) v += a.out[pbase + co];
-                    a.out[pbase + co] = v;
-                    s1[ni] += v;
-                    s2[ni] += v * v;
+                    for (int ni = 0; ni < C::NT; ++ni) {
+                        const int co = n0 + ni * 32 + li;
+                        if (pix_ok && co < a.c_out) {
+                            float v = acc[mi][ni][r];
+                            if (a.accumulate) v += a.out[pbase + co];
+                            a.out[pbase + co] = v;
+                            s1[ni] += v;
+                            s2[ni] += v * v;
+                        }
+                    }
+                }
+            }
+            if (a.stats != nullptr) {
+                __syncthreads();   // the MFMA loop is done with LDS
+                // in-lane fp32 sums cover <= 32 values; everything across lanes / waves / workgroups is fp64
+                // (PyTorch's CPU BatchNorm accumulates float tensors in double as well)
+                double* red = reinterpret_cast<double*>(smem);   // [4 waves][BN][2]
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni) {
+                    const double d1 = (double)s1[ni], d2 = (double)s2[ni];
+                    const double t1 = d1 + __shfl_xor(d1, 32);
+                    const double t2 = d2 + __shfl_xor(d2, 32);
+                    if (lh == 0) {
+                        red[(wave * C::BN + ni * 32 + li) * 2 + 0] = t1;
+                        red[(wave * C::BN + ni * 32 + li) * 2 + 1] = t2;
+                    }
+                }
+                __syncthreads();
+                if (tid < C::BN) {
+                    const int co = n0 + tid;
+                    if (co < a.c_out) {
+                        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            t1 += red[(w * C::BN + tid) * 2 + 0];
+                            t2 += red[(w * C::BN + tid) * 2 + 1];
+                        }
+                        a.stats[((size_t)tile * 2 + 0) * a.c_out + co] = t1;
+                        a.stats[((size_t)tile * 2 + 1) * a.c_out + co] = t2;
+                    }
                 }
             }
         }
-    }
-    if (a.stats != nullptr) {
-        __syncthreads();   // LDS is free again
-        // in-lane fp32 sums cover <= 32 values; everything across lanes / waves / workgroups is fp64
-        // (PyTorch's CPU BatchNorm accumulates float tensors in double as well)
-        double* red = reinterpret_cast<double*>(smem); // [4 waves][BN][2]
-#pragma unroll
-        for (int ni = 0; ni < C::NT; ++ni) {
-            const double d1 = (double)s1[ni], d2 = (double)s2[ni];
-            const double t1 = d1 + __shfl_xor(d1, 32);
-            const double t2 = d2 + __shfl_xor(d2, 32);
-            if (lh == 0) {
-                red[(wave * C::BN + ni * 32 + li) * 2 + 0] = t1;
-                red[(wave * C::BN + ni * 32 + li) * 2 + 1] = t2;
-            }
-        }
-        __syncthreads();
-        if (tid < C::BN) {
-            const int co = n0 + tid;
-            if (co < a.c_out) {
-                double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    t1 += red[(w * C::BN + tid) * 2 + 0];
-                    t2 += red[(w * C::BN + tid) * 2 + 1];
-                }
-                a.stats[((size_t)blockIdx.x * 2 + 0) * a.c_out + co] = t1;
-                a.stats[((size_t)blockIdx.x * 2 + 1) * a.c_out + co] = t2;
-            }
-        }
+        tile = ntile;
+        q = nq;
     }
 }
 
@@ -259,8 +332,9 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
 // A workgroup walks many spatial tiles (persistent over gridDim.x splits) for one (k-chunk, 32-co group);
 // wave w reduces the tile rows of slice w, the 4 slices are summed through LDS at the end, and one partial
 // [T*32][32] per workgroup goes to the workspace (reduced deterministically by wgrad_reduce_kernel).
-template <int KSY_, int KSX_, int XEXTRA_, int LSTEP_, int CST_, int STRP_, int PX_, int TH_, int MINW_>
+template <int KSY_, int KSX_, int XEXTRA_, int LSTEP_, int CST_, int STRP_, int PX_, int TH_, int MINW_, int PREFETCH_ = (MINW_ == 1)>
 struct WgCfg {
+    static constexpr bool PREFETCH = PREFETCH_ != 0;   // stage tile t+1 through registers during the MFMAs of tile t
     static constexpr int KSY = KSY_, KSX = KSX_, T = KSY_ * KSX_;
     static constexpr int LSTEP = LSTEP_;
     static constexpr int CST = CST_, STRP = STRP_;
@@ -303,7 +377,14 @@ __global__ void __launch_bounds__(256, C::MINW) conv_wgrad_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tap][r] = 0.f;
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    using H = Halo<C::CST, C::STRP, C::HXP, C::HYP>;
+    constexpr int ND = (C::TP * 8) / 256;     // dZ tile: TP pixels x 8 float4
+    H halo;
+    f32x4 ra[H::NA];
+    f32x4 rd[ND];
+    const int dc = co0 + (tid & 7) * 4;
+
+    auto load_tile = [&](int tile) {
         int t = tile;
         const int tx = t % a.tiles_x;
         t /= a.tiles_x;
@@ -311,36 +392,59 @@ __global__ void __launch_bounds__(256, C::MINW) conv_wgrad_kernel(ConvArgs a) {
         const int img = t / a.tiles_y;
         const int oy0 = ty * C::TH;
         const int ox0 = tx * C::PX;
-
-        __syncthreads();
-        stage_halo<C::CST, C::STRP, C::HXP, C::HYP>(As, src, csrc, cb, hs, ws, gmode, img, oy0 * a.stride - a.pad,
-                                                    ox0 * a.stride - a.pad, a.gstep, a.h_in, a.w_in, a.sy, a.sx, tid);
-        for (int idx = tid; idx < C::TP * 8; idx += 256) {
-            const int p = idx >> 3;
-            const int c4 = idx & 7;
+        halo.setup(hs, ws, gmode, img, oy0 * a.stride - a.pad, ox0 * a.stride - a.pad_x, a.gstep, a.h_in, a.w_in, a.sy, a.sx, tid,
+                   a.ioy, a.iox);
+        halo.load(ra, src, csrc, cb, tid);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int p = (tid >> 3) + i * 32;
             const int oy = oy0 + p / C::PX;
             const int ox = ox0 + p % C::PX;
-            const int co = co0 + c4 * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (oy < a.h_out && ox < a.w_out && co < a.c_out)
-                v = *reinterpret_cast<const f32x4*>(a.dz + (((size_t)img * a.h_out + oy) * a.w_out + ox) * a.c_out + co);
-            *reinterpret_cast<f32x4*>(Ds + p * 32 + c4 * 4) = v;
+            const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+            if (oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp && dc < a.c_out)
+                v = *reinterpret_cast<const f32x4*>(a.dz + (((size_t)img * a.ohp + py) * a.owp + px) * a.c_out + dc);
+            rd[i] = v;
+        }
+    };
+
+    if (C::PREFETCH && (int)blockIdx.x < a.ntiles) load_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        if (!C::PREFETCH) load_tile(tile);   // two workgroups per CU cover each other's staging instead
+        __syncthreads();
+        halo.store(ra, As, tid);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int p = (tid >> 3) + i * 32;
+            *reinterpret_cast<f32x4*>(Ds + p * 32 + (tid & 7) * 4) = rd[i];
         }
         __syncthreads();
+        if (C::PREFETCH && tile + (int)gridDim.x < a.ntiles) load_tile(tile + gridDim.x);   // in flight while the MFMAs below run
 
-#pragma unroll
-        for (int r = 0; r < C::RS; ++r) {
-            const int trow = wave * C::RS + r;
-#pragma unroll 2
-            for (int tc = 0; tc < C::PX; tc += 2) {
-                const int pc = tc + lh;
-                const float b = Ds[(trow * C::PX + pc) * 32 + li];
+        // MFMA loop over this wave's RS tile rows x PX/2 pixel pairs; operands of iteration it+1 are read from LDS while
+        // the T MFMAs of iteration it issue (one wave per SIMD: nothing else would cover the LDS latency)
+        {
+            constexpr int NIT = C::RS * (C::PX / 2);
+            float av[2][C::T], bv[2];
+            auto fetch = [&](int it, int slot) {
+                const int trow = wave * C::RS + it / (C::PX / 2);
+                const int pc = 2 * (it % (C::PX / 2)) + lh;
+                bv[slot] = Ds[(trow * C::PX + pc) * 32 + li];
                 const int hb = (trow * C::LSTEP * C::HXP + pc * C::LSTEP) * C::STRP + li;
 #pragma unroll
-                for (int tap = 0; tap < C::T; ++tap) {
-                    const float av = As[hb + ((tap / C::KSX) * C::HXP + (tap % C::KSX)) * C::STRP];
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[tap], 0, 0, 0);
-                }
+                for (int tap = 0; tap < C::T; ++tap)
+                    av[slot][tap] = As[hb + ((tap / C::KSX) * C::HXP + (tap % C::KSX)) * C::STRP];
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int cur = it & 1;
+                if (it + 1 < NIT) fetch(it + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);   // keep the next operands' reads ahead of this iteration's MFMAs
+#pragma unroll
+                for (int tap = 0; tap < C::T; ++tap)
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][tap], bv[cur], acc[tap], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -364,6 +468,135 @@ __global__ void __launch_bounds__(256, C::MINW) conv_wgrad_kernel(ConvArgs a) {
         }
     }
     if (wave == 0) {
+        float* wsp = a.ws + (size_t)blockIdx.x * a.ktot * a.cop;
+#pragma unroll
+        for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = (q * C::T + tap) * 32 + rcf_mfma_row(r, lh);
+                wsp[(size_t)k * a.cop + co0 + li] = acc[tap][r];
+            }
+    }
+}
+
+// Weight gradient, LDS-DMA variant (all non-stem layers): the halo tile [pixel][32 ch] and the dZ tile [pixel][32 co] are
+// unpadded, so each wave-level global_load_lds_dwordx4 moves 8 whole pixels (1 KiB) straight from HBM/L2 into LDS with
+// per-lane source addresses (padding / out-of-image lanes read a zero page).  No staging registers and no ds_write pass:
+// the kernel fits two workgroups per CU, which cover each other's DMA latency and address arithmetic.
+template <class C>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using H = Halo<C::CST, C::STRP, C::HXP, C::HYP>;
+    static_assert(C::CST == 32 && C::STRP == 32, "DMA path needs the unpadded [pixel][32] tile");
+    constexpr int A_DMA_FLOATS = H::NA * H::PPI * 32;   // every lane of every instruction lands somewhere
+    constexpr int ND = (C::TP * 8) / 256;
+    float* As = smem;
+    float* Ds = smem + A_DMA_FLOATS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+
+    const int q = blockIdx.y;
+    const int co0 = blockIdx.z * 32;
+    const bool first = q < a.nchunk1;
+    const float* src = first ? a.in1 : a.in2;
+    const int csrc = first ? a.c1 : a.c2;
+    const int cb = (first ? q : q - a.nchunk1) * 32;
+    const int hs = first ? a.h1 : a.h_in;
+    const int ws = first ? a.w1 : a.w_in;
+    const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
+    const int cch = cb + (tid & 7) * 4;
+    const bool cok = cch < csrc;
+    const int dc = co0 + (tid & 7) * 4;
+    const bool dok = dc < a.c_out;
+
+    f32x16 acc[C::T];
+#pragma unroll
+    for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tap][r] = 0.f;
+
+    H halo;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % a.tiles_x;
+        t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        const int img = t / a.tiles_y;
+        const int oy0 = ty * C::TH;
+        const int ox0 = tx * C::PX;
+        halo.setup(hs, ws, gmode, img, oy0 * a.stride - a.pad, ox0 * a.stride - a.pad_x, a.gstep, a.h_in, a.w_in, a.sy, a.sx, tid,
+                   a.ioy, a.iox);
+        __syncthreads();   // the previous tile's MFMAs are done with LDS
+#pragma unroll
+        for (int i = 0; i < H::NA; ++i) {
+            const float* g = (cok && halo.pix[i] >= 0) ? src + (size_t)halo.pix[i] * csrc + cch : a.zero;
+            float* dst = As + (i * H::PPI + wave * 8) * 32;   // wave-uniform; lane l lands 16*l bytes further
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int p = (tid >> 3) + i * 32;
+            const int oy = oy0 + p / C::PX;
+            const int ox = ox0 + p % C::PX;
+            const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+            const bool ok = dok && oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
+            const float* g = ok ? a.dz + (((size_t)img * a.ohp + py) * a.owp + px) * a.c_out + dc : a.zero;
+            float* dst = Ds + (i * 32 + wave * 8) * 32;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+        __syncthreads();   // hipcc drains the DMA (vmcnt(0)) before this barrier
+
+        {
+            constexpr int NIT = C::RS * (C::PX / 2);
+            float av[2][C::T], bv[2];
+            auto fetch = [&](int it, int slot) {
+                const int trow = (tid >> 6) * C::RS + it / (C::PX / 2);
+                const int pc = 2 * (it % (C::PX / 2)) + lh;
+                bv[slot] = Ds[(trow * C::PX + pc) * 32 + li];
+                const int hb = (trow * C::LSTEP * C::HXP + pc * C::LSTEP) * C::STRP + li;
+#pragma unroll
+                for (int tap = 0; tap < C::T; ++tap)
+                    av[slot][tap] = As[hb + ((tap / C::KSX) * C::HXP + (tap % C::KSX)) * C::STRP];
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int cur = it & 1;
+                if (it + 1 < NIT) fetch(it + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tap = 0; tap < C::T; ++tap)
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][tap], bv[cur], acc[tap], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // sum the 4 waves' accumulators through LDS (wave 3 -> 2 -> 1 -> 0 chain keeps it deterministic)
+    float* red = smem;
+    const int wv = tid >> 6;
+    for (int s = 3; s >= 1; --s) {
+        __syncthreads();
+        if (wv == s) {
+#pragma unroll
+            for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(tap * 16 + r) * 64 + lane] = acc[tap][r];
+        }
+        __syncthreads();
+        if (wv == s - 1) {
+#pragma unroll
+            for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tap][r] += red[(tap * 16 + r) * 64 + lane];
+        }
+    }
+    if (wv == 0) {
         float* wsp = a.ws + (size_t)blockIdx.x * a.ktot * a.cop;
 #pragma unroll
         for (int tap = 0; tap < C::T; ++tap)
@@ -458,24 +691,88 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     dst[idx] = v;
 }
 
+// Phase weights (see include/rcf_hip.h).  Up-2x: output row 2y+a reads source rows {y-1,y} (a=0) / {y,y+1} (a=1); 3x3 tap ky
+// lands on source tap t: a=0 -> (0,1,1), a=1 -> (0,0,1).  Stride-2 dgrad: input row 2y+a receives dZ rows y (tap 0) and y+1
+// (tap 1): a=0 -> ky (1, none), a=1 -> ky (2, 0).
+__device__ __forceinline__ int up2x_tap(int a, int k) { return a == 0 ? (k == 0 ? 0 : 1) : (k == 2 ? 1 : 0); }
+__device__ __forceinline__ int s2_tap_k(int a, int t) { return a == 0 ? (t == 0 ? 1 : -1) : (t == 0 ? 2 : 0); }
+
+__global__ void phase_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I, int mode) {
+    const int total = 4 * O * I * 4;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int t = idx;
+    const int u = t & 1; t >>= 1;
+    const int tt = t & 1; t >>= 1;
+    const int OP = (mode == RCF_PHASE_UP2X_FWD) ? O : I;   // out channels of the phase conv
+    const int IP = (mode == RCF_PHASE_UP2X_FWD) ? I : O;
+    const int ip = t % IP; t /= IP;
+    const int op = t % OP; t /= OP;
+    const int b = t & 1, a = t >> 1;
+    float v = 0.f;
+    if (mode == RCF_PHASE_UP2X_FWD) {
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx)
+                if (up2x_tap(a, ky) == tt && up2x_tap(b, kx) == u) v += w[((op * I + ip) * 3 + ky) * 3 + kx];
+    } else if (mode == RCF_PHASE_UP2X_DGRAD) {   // Wd[n=i][c=o][t'][u'] = Wp[o][i][1-t'][1-u']
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx)
+                if (up2x_tap(a, ky) == 1 - tt && up2x_tap(b, kx) == 1 - u) v += w[((ip * I + op) * 3 + ky) * 3 + kx];
+    } else {   // RCF_PHASE_S2_DGRAD: Wd[n=i][c=o][t][u] = W[o][i][ky(a,t)][kx(b,u)]
+        const int ky = s2_tap_k(a, tt), kx = s2_tap_k(b, u);
+        if (ky >= 0 && kx >= 0) v = w[((ip * I + op) * 3 + ky) * 3 + kx];
+    }
+    out[idx] = v;
+}
+
+__global__ void phase_wgrad_fold_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int O, int I) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= O * I * 9) return;
+    const int kx = idx % 3, ky = (idx / 3) % 3;
+    const int oi = idx / 9;
+    float v = 0.f;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+            v += dwp[(((size_t)(a * 2 + b) * O * I + oi) * 2 + up2x_tap(a, ky)) * 2 + up2x_tap(b, kx)];
+    dw[idx] = v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // configuration tables
-enum Kind { K3S1 = 0, K3S2 = 1, K1 = 2, K7S2 = 3 };
+enum Kind { K3S1 = 0, K3S2 = 1, K1 = 2, K7S2 = 3, K2S1 = 4 };
 
 struct Sel {
     int kind, ck, nt, px;
     int th, bn, t, cst;
 };
 
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
 template <class C>
 int launch_fwd(const ConvArgs& a, int ntile_n, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            C::LDS_BYTES);
-        attr_done = true;
+    static int resident = 0;   // workgroups that fit on the device at once
+    if (resident == 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C::LDS_BYTES);
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_fwd_kernel<C>, 256, C::LDS_BYTES) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        resident = per_cu * num_cus();
     }
-    dim3 grid(a.ntiles, ntile_n, 1);
+    // persistent over tiles: one resident wave of workgroups, split between the n-tiles
+    int gx = resident / ntile_n;
+    if (gx < 1) gx = 1;
+    if (gx > a.ntiles) gx = a.ntiles;
+    dim3 grid(gx, ntile_n, 1);
     hipLaunchKernelGGL((conv_fwd_kernel<C>), grid, dim3(256), C::LDS_BYTES, st, a);
     return rcf_launch_status();
 }
@@ -484,12 +781,29 @@ template <class C>
 int launch_wgrad(const ConvArgs& a, int nsplit, int nchunk, int ncog, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            C::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C::LDS_BYTES);
         attr_done = true;
     }
     dim3 grid(nsplit, nchunk, ncog);
     hipLaunchKernelGGL((conv_wgrad_kernel<C>), grid, dim3(256), C::LDS_BYTES, st, a);
+    return rcf_launch_status();
+}
+
+template <class C>
+int launch_wgrad_dma(const ConvArgs& a, int nsplit, int nchunk, int ncog, hipStream_t st) {
+    using H = Halo<C::CST, C::STRP, C::HXP, C::HYP>;
+    constexpr int red_floats = C::T * 16 * 64;
+    constexpr int tile_floats = H::NA * H::PPI * 32 + C::TP * 32;
+    constexpr int lds_bytes = (tile_floats > red_floats ? tile_floats : red_floats) * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  lds_bytes);
+        attr_done = true;
+    }
+    dim3 grid(nsplit, nchunk, ncog);
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<C>), grid, dim3(256), lds_bytes, st, a);
     return rcf_launch_status();
 }
 
@@ -514,16 +828,22 @@ using F1_16_1_32 = FwdCfg<1, 1, 0, 1, 16, 16, 20, 1, 32, 2>;
 using F1_16_2_32 = FwdCfg<1, 1, 0, 1, 16, 16, 20, 2, 32, 2>;
 using F1_16_1_16 = FwdCfg<1, 1, 0, 1, 16, 16, 20, 1, 16, 2>;
 using F1_16_2_16 = FwdCfg<1, 1, 0, 1, 16, 16, 20, 2, 16, 2>;
+using F2_32_1_32 = FwdCfg<2, 2, 0, 1, 32, 32, 36, 1, 32, 2>;
+using F2_32_2_32 = FwdCfg<2, 2, 0, 1, 32, 32, 36, 2, 32, 2>;
+using F2_32_1_16 = FwdCfg<2, 2, 0, 1, 32, 32, 36, 1, 16, 2>;
+using F2_32_2_16 = FwdCfg<2, 2, 0, 1, 32, 32, 36, 2, 16, 2>;
 using F7_32 = FwdCfg<7, 1, 7, 2, 32, 4, 4, 1, 32, 2>;
 using F7_16 = FwdCfg<7, 1, 7, 2, 32, 4, 4, 1, 16, 2>;
 
 //               KSY KSX XE LS CST STRP PX TH MINW
-using W3S1_32 = WgCfg<3, 3, 0, 1, 32, 32, 32, 8, 2>;
-using W3S1_16 = WgCfg<3, 3, 0, 1, 32, 32, 16, 16, 2>;
+using W3S1_32 = WgCfg<3, 3, 0, 1, 32, 32, 32, 8, 1>;
+using W3S1_16 = WgCfg<3, 3, 0, 1, 32, 32, 16, 16, 1>;
 using W3S2_32 = WgCfg<3, 3, 0, 2, 32, 32, 32, 4, 1>;
 using W3S2_16 = WgCfg<3, 3, 0, 2, 32, 32, 16, 8, 1>;
 using W1_32 = WgCfg<1, 1, 0, 1, 32, 32, 32, 8, 2>;
 using W1_16 = WgCfg<1, 1, 0, 1, 32, 32, 16, 16, 2>;
+using W2_32 = WgCfg<2, 2, 0, 1, 32, 32, 32, 8, 1>;
+using W2_16 = WgCfg<2, 2, 0, 1, 32, 32, 16, 16, 1>;
 using W7_32 = WgCfg<7, 1, 7, 2, 4, 4, 32, 8, 2>;
 using W7_16 = WgCfg<7, 1, 7, 2, 4, 4, 16, 16, 2>;
 
@@ -539,13 +859,19 @@ bool valid_desc(const rcf_conv_desc* d) {
     if (d->n <= 0 || d->h_in <= 0 || d->w_in <= 0 || d->c1 <= 0 || d->c2 < 0 || d->h_out <= 0 || d->w_out <= 0 ||
         d->c_out <= 0)
         return false;
-    if (d->ksize != 1 && d->ksize != 3 && d->ksize != 7) return false;
+    if (d->ksize != 1 && d->ksize != 2 && d->ksize != 3 && d->ksize != 7) return false;
     if (d->stride != 1 && d->stride != 2) return false;
-    if (d->gather1 < 0 || d->gather1 > 2) return false;
+    if (d->gather1 < 0 || d->gather1 > 3) return false;
+    if (d->out_stride != 1 && d->out_stride != 2) return false;
+    if (d->out_h_phys <= 0 || d->out_w_phys <= 0) return false;
     if (d->gather1 == RCF_GATHER_DIRECT && (d->h_src1 != d->h_in || d->w_src1 != d->w_in)) return false;
     if (d->h_src1 <= 0 || d->w_src1 <= 0) return false;
-    if ((d->h_in + 2 * d->pad - d->ksize) / d->stride + 1 != d->h_out) return false;
-    if ((d->w_in + 2 * d->pad - d->ksize) / d->stride + 1 != d->w_out) return false;
+    if (d->ksize != 2) {   // 2x2 phase convs pad asymmetrically: their output grid is given, not derived
+        if ((d->h_in + 2 * d->pad - d->ksize) / d->stride + 1 != d->h_out) return false;
+        if ((d->w_in + 2 * d->pad_x - d->ksize) / d->stride + 1 != d->w_out) return false;
+    } else if (d->stride != 1 || d->w_mode != RCF_W_FORWARD) {
+        return false;
+    }
     if (d->w_mode == RCF_W_FORWARD) {
         if (d->w_o != d->c_out || d->w_i != d->c1 + d->c2) return false;
     } else if (d->w_mode == RCF_W_DGRAD) {
@@ -565,6 +891,8 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
         if (d->stride != 2 || d->c2 != 0 || d->c1 > 4 || d->gather1 != RCF_GATHER_DIRECT || d->w_mode != RCF_W_FORWARD)
             return RCF_EUNSUPPORTED;
         s->kind = K7S2; s->ck = 32; s->cst = 4; s->nt = 1; s->t = 7;
+    } else if (d->ksize == 2) {
+        s->kind = K2S1; s->t = 4; s->ck = 32; s->cst = 32;
     } else if (d->ksize == 3) {
         s->t = 9;
         if (d->stride == 2) { s->kind = K3S2; s->ck = 8; }
@@ -591,9 +919,11 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
 void fill_args(const rcf_conv_desc* d, const Sel& s, ConvArgs* a) {
     a->n = d->n; a->h_in = d->h_in; a->w_in = d->w_in; a->c1 = d->c1; a->c2 = d->c2;
     a->h1 = d->h_src1; a->w1 = d->w_src1; a->gather1 = d->gather1;
-    a->h_out = d->h_out; a->w_out = d->w_out; a->c_out = d->c_out; a->pad = d->pad; a->stride = d->stride;
+    a->h_out = d->h_out; a->w_out = d->w_out; a->c_out = d->c_out; a->pad = d->pad; a->pad_x = d->pad_x; a->stride = d->stride;
     a->gstep = d->ksize == 1 ? d->stride : 1;
     a->accumulate = d->accumulate;
+    a->os = d->out_stride; a->ooy = d->out_off_y; a->oox = d->out_off_x; a->ohp = d->out_h_phys; a->owp = d->out_w_phys;
+    a->ioy = d->in_off_y; a->iox = d->in_off_x;
     a->sy = (float)d->h_src1 / (float)d->h_in;
     a->sx = (float)d->w_src1 / (float)d->w_in;
     a->tiles_x = ceil_div(d->w_out, s.px);
@@ -612,6 +942,8 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
     if (d->ksize == 7) {
         if (d->stride != 2 || d->c2 != 0 || d->c1 > 4 || d->gather1 != RCF_GATHER_DIRECT) return RCF_EUNSUPPORTED;
         w->kind = K7S2; w->t = 7; w->cst = 4;
+    } else if (d->ksize == 2) {
+        w->kind = K2S1; w->t = 4; w->cst = 32;
     } else if (d->ksize == 3) {
         w->kind = d->stride == 2 ? K3S2 : K3S1; w->t = 9; w->cst = 32;
     } else {
@@ -631,7 +963,7 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
     w->nchunk2 = d->c2 > 0 ? ceil_div(d->c2, 32) : 0;
     w->ncog = ceil_div(d->c_out, 32);
     const int combos = (w->nchunk1 + w->nchunk2) * w->ncog;
-    int ns = ceil_div(768, combos);
+    int ns = 512 / combos;   // <= one resident wave at 2 workgroups/CU (two at 1/CU); never a nearly empty extra wave
     if (ns > w->ntiles) ns = w->ntiles;
     if (ns < 1) ns = 1;
     w->nsplit = ns;
@@ -641,6 +973,20 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
 }
 
 }   // namespace
+
+extern "C" int rcf_phase_weights(const float* w_oihw, float* out, int o, int i, int mode, void* stream) {
+    if (!w_oihw || !out || o <= 0 || i <= 0 || mode < 0 || mode > 2) return RCF_EINVAL;
+    const int total = 16 * o * i;
+    hipLaunchKernelGGL(phase_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, out, o, i, mode);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_phase_wgrad_fold(const float* dwp, float* dw_oihw, int o, int i, void* stream) {
+    if (!dwp || !dw_oihw || o <= 0 || i <= 0) return RCF_EINVAL;
+    const int total = 9 * o * i;
+    hipLaunchKernelGGL(phase_wgrad_fold_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, dwp, dw_oihw, o, i);
+    return rcf_launch_status();
+}
 
 extern "C" int rcf_conv2d_query(const rcf_conv_desc* d, rcf_conv_info* info) {
     if (!info) return RCF_EINVAL;
@@ -658,7 +1004,7 @@ extern "C" int rcf_conv2d_query(const rcf_conv_desc* d, rcf_conv_info* info) {
     if (d->w_mode == RCF_W_FORWARD) {
         WSel w;
         if (select_wgrad(d, &w) == RCF_OK) {
-            info->wgrad_workspace_floats = (size_t)w.nsplit * w.ktot * w.cop;
+            info->wgrad_workspace_floats = (size_t)w.nsplit * w.ktot * w.cop + 64;   // + a zero page for the DMA path
             info->wgrad_kernel_id = 10000 + w.kind * 1000 + (w.px == 16 ? 100 : 0);
         }
     }
@@ -717,6 +1063,9 @@ extern "C" int rcf_conv2d_fwd(const rcf_conv_desc* d, const float* in1, const fl
             return p16 ? launch_fwd<F1_16_2_16>(a, nn, st) : launch_fwd<F1_16_2_32>(a, nn, st);
         case K7S2:
             return p16 ? launch_fwd<F7_16>(a, nn, st) : launch_fwd<F7_32>(a, nn, st);
+        case K2S1:
+            if (s.nt == 1) return p16 ? launch_fwd<F2_32_1_16>(a, nn, st) : launch_fwd<F2_32_1_32>(a, nn, st);
+            return p16 ? launch_fwd<F2_32_2_16>(a, nn, st) : launch_fwd<F2_32_2_32>(a, nn, st);
     }
     return RCF_EUNSUPPORTED;
 }
@@ -731,9 +1080,11 @@ extern "C" int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const 
     ConvArgs a;
     a.n = d->n; a.h_in = d->h_in; a.w_in = d->w_in; a.c1 = d->c1; a.c2 = d->c2;
     a.h1 = d->h_src1; a.w1 = d->w_src1; a.gather1 = d->gather1;
-    a.h_out = d->h_out; a.w_out = d->w_out; a.c_out = d->c_out; a.pad = d->pad; a.stride = d->stride;
+    a.h_out = d->h_out; a.w_out = d->w_out; a.c_out = d->c_out; a.pad = d->pad; a.pad_x = d->pad_x; a.stride = d->stride;
     a.gstep = d->ksize == 1 ? d->stride : 1;
     a.accumulate = 0;
+    a.os = d->out_stride; a.ooy = d->out_off_y; a.oox = d->out_off_x; a.ohp = d->out_h_phys; a.owp = d->out_w_phys;
+    a.ioy = d->in_off_y; a.iox = d->in_off_x;
     a.sy = (float)d->h_src1 / (float)d->h_in;
     a.sx = (float)d->w_src1 / (float)d->w_in;
     a.tiles_x = w.tiles_x; a.tiles_y = w.tiles_y; a.ntiles = w.ntiles;
@@ -743,10 +1094,27 @@ extern "C" int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const 
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = w.nchunk1 + w.nchunk2;
     const int p16 = w.px == 16;
+    float* zero = workspace + (size_t)w.nsplit * w.ktot * w.cop;
+    a.zero = zero;
+    const bool dma = w.kind != K7S2 && (d->c1 % 4 == 0) && (d->c2 % 4 == 0) && getenv("RCF_WGRAD_NO_DMA") == nullptr;
+    if (dma && hipMemsetAsync(zero, 0, 64 * sizeof(float), st) != hipSuccess) return rcf_launch_status();
     switch (w.kind) {
-        case K3S1: rc = p16 ? launch_wgrad<W3S1_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad<W3S1_32>(a, w.nsplit, nchunk, w.ncog, st); break;
-        case K3S2: rc = p16 ? launch_wgrad<W3S2_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad<W3S2_32>(a, w.nsplit, nchunk, w.ncog, st); break;
-        case K1: rc = p16 ? launch_wgrad<W1_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad<W1_32>(a, w.nsplit, nchunk, w.ncog, st); break;
+        case K3S1:
+            if (dma) rc = p16 ? launch_wgrad_dma<W3S1_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad_dma<W3S1_32>(a, w.nsplit, nchunk, w.ncog, st);
+            else rc = p16 ? launch_wgrad<W3S1_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad<W3S1_32>(a, w.nsplit, nchunk, w.ncog, st);
+            break;
+        case K3S2:
+            if (dma) rc = p16 ? launch_wgrad_dma<W3S2_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad_dma<W3S2_32>(a, w.nsplit, nchunk, w.ncog, st);
+            else rc = p16 ? launch_wgrad<W3S2_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad<W3S2_32>(a, w.nsplit, nchunk, w.ncog, st);
+            break;
+        case K1:
+            if (dma) rc = p16 ? launch_wgrad_dma<W1_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad_dma<W1_32>(a, w.nsplit, nchunk, w.ncog, st);
+            else rc = p16 ? launch_wgrad<W1_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad<W1_32>(a, w.nsplit, nchunk, w.ncog, st);
+            break;
+        case K2S1:
+            if (dma) rc = p16 ? launch_wgrad_dma<W2_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad_dma<W2_32>(a, w.nsplit, nchunk, w.ncog, st);
+            else rc = p16 ? launch_wgrad<W2_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad<W2_32>(a, w.nsplit, nchunk, w.ncog, st);
+            break;
         case K7S2: rc = p16 ? launch_wgrad<W7_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad<W7_32>(a, w.nsplit, nchunk, w.ncog, st); break;
         default: return RCF_EUNSUPPORTED;
     }

@@ -17,7 +17,8 @@ next step -- DESIGN.md section 6).
 import torch
 
 from . import ops
-from ._lib import RCF_ACT_LEAKY_RELU, RCF_ACT_NONE, RCF_GATHER_DIRECT, RCF_GATHER_NEAREST
+from ._lib import (RCF_ACT_LEAKY_RELU, RCF_ACT_NONE, RCF_GATHER_DIRECT, RCF_GATHER_NEAREST, RCF_PHASE_S2_DGRAD,
+                   RCF_PHASE_UP2X_DGRAD, RCF_PHASE_UP2X_FWD)
 
 BN_EPS = 1e-5       # torch.nn.BatchNorm2d default (src/net_utils.py:82)
 BN_MOMENTUM = 0.1
@@ -45,6 +46,7 @@ class Engine(object):
         self.training = True
         self.kernel_log = None     # optional list collecting (layer, kernel_id) for profiling
         self.prof = None           # optional KernelTimer: brackets conv launches with events on the launch stream
+        self.use_phase_convs = True  # exact-2x UpConv and stride-2 dgrad as 2x2 phase convs (False: 9-tap / zero-insert forms)
 
     # ------------------------------------------------------------------ helpers
     def _new(self, shape, ref):
@@ -65,6 +67,9 @@ class Engine(object):
         if x2 is not None and tuple(x2.t.shape[1:3]) != (h_in, w_in):
             raise ValueError('skip connection and upsampled tensor disagree in size')
         weight = layer.conv.weight
+        if (self.use_phase_convs and gather == RCF_GATHER_NEAREST and x2 is None and layer.kernel_size == 3
+                and layer.stride == 1 and (h_in, w_in) == (2 * h, 2 * w) and c1 % 4 == 0):
+            return self._conv_up2x(layer, x, want_stats)
         desc = ops.make_fwd_desc(n, h_in, w_in, c1, c2, weight.shape[0], layer.kernel_size, layer.stride, h, w, gather)
         info = ops.conv_query(desc)
         packed = self._new((info.packed_weight_floats,), x.t)
@@ -72,22 +77,86 @@ class Engine(object):
         z = self._new((n, desc.h_out, desc.w_out, desc.c_out), x.t)
         partials = torch.empty((info.n_partials, 2, desc.c_out), dtype=torch.float64, device=x.t.device) if want_stats else None
         if self.prof is not None:
-            self.prof.begin(info.kernel_id, ops.algorithmic_flops(desc))
+            self.prof.begin(info.kernel_id, ops.algorithmic_flops(desc), desc)
         ops.conv_fwd(desc, x.t, None if x2 is None else x2.t, packed, z, partials)
         if self.prof is not None:
             self.prof.end()
-        if self.kernel_log is not None:
+        if self.kernel_log is not None and desc is not None:
             self.kernel_log.append((desc.ksize, desc.stride, desc.c1 + desc.c2, desc.c_out, desc.h_out, desc.w_out,
                                     info.kernel_id))
         return z, desc, info, partials
 
+    def _run_packed(self, desc, w_oihw, in1, out, partials=None):
+        info = ops.conv_query(desc)
+        packed = self._new((info.packed_weight_floats,), in1)
+        ops.conv_pack(desc, w_oihw, packed)
+        if self.prof is not None:
+            self.prof.begin(info.kernel_id, ops.algorithmic_flops(desc), desc)
+        ops.conv_fwd(desc, in1, None, packed, out, partials)
+        if self.prof is not None:
+            self.prof.end()
+        return info
+
+    def _conv_up2x(self, layer, x, want_stats):
+        '''
+        conv3x3(F.interpolate(x, 2x nearest)) as four 2x2 phase convolutions on x (4/9 of the MACs; the weights of the
+        taps that hit the same source pixel are pre-summed, so results differ from the 9-tap form by fp32 round-off only).
+        '''
+        n, h, w, c1 = x.t.shape
+        weight = layer.conv.weight
+        co = weight.shape[0]
+        wp = ops.phase_weights(weight.detach(), RCF_PHASE_UP2X_FWD)
+        z = self._new((n, 2 * h, 2 * w, co), x.t)
+        descs, partials, n_part = [], None, 0
+        for ph in range(4):
+            d = ops.make_up2x_fwd_desc(n, h, w, c1, co, ph >> 1, ph & 1)
+            if ph == 0:
+                n_part = ops.conv_query(d).n_partials
+                if want_stats:
+                    partials = torch.empty((4 * n_part, 2, co), dtype=torch.float64, device=x.t.device)
+            self._run_packed(d, wp[ph], x.t, z, None if partials is None else partials[ph * n_part:(ph + 1) * n_part])
+            descs.append(d)
+
+        class _Info(object):
+            pass
+        info = _Info()
+        info.n_partials = 4 * n_part
+        info.up2x = descs
+        return z, None, info, partials
+
+    def _conv_up2x_backward(self, layer, info, x, dz):
+        n, h, w, c1 = x.t.shape
+        weight = layer.conv.weight
+        co = weight.shape[0]
+        dwp = self._new((4, co, c1, 2, 2), dz)
+        for ph, d in enumerate(info.up2x):
+            qi = ops.conv_query(d)
+            ws = self._new((max(1, qi.wgrad_workspace_floats),), dz)
+            if self.prof is not None:
+                self.prof.begin(qi.wgrad_kernel_id, ops.algorithmic_flops(d), d)
+            ops.conv_wgrad(d, x.t, None, dz, dwp[ph], ws)
+            if self.prof is not None:
+                self.prof.end()
+        ops.phase_wgrad_fold(dwp, self.grad_of(weight))
+        self._wgrad_done(weight)
+        if x.needs_grad:
+            wd = ops.phase_weights(weight.detach(), RCF_PHASE_UP2X_DGRAD)
+            acc = x.g is not None
+            if not acc:
+                x.g = torch.empty_like(x.t)
+            for ph in range(4):
+                dd = ops.make_up2x_dgrad_desc(n, h, w, c1, co, ph >> 1, ph & 1, acc or ph > 0)
+                self._run_packed(dd, wd[ph], dz, x.g)
+
     def _conv_backward(self, layer, desc, info, x, x2, dz):
         '''dW (written once into the parameter's gradient) and dX / dX2 (accumulated into the producers' .g).'''
+        if desc is None:
+            return self._conv_up2x_backward(layer, info, x, dz)
         weight = layer.conv.weight
         dw = self.grad_of(weight)
         ws = self._new((max(1, info.wgrad_workspace_floats),), dz)
         if self.prof is not None:
-            self.prof.begin(info.wgrad_kernel_id, ops.algorithmic_flops(desc))
+            self.prof.begin(info.wgrad_kernel_id, ops.algorithmic_flops(desc), desc)
         ops.conv_wgrad(desc, x.t, None if x2 is None else x2.t, dz, dw, ws)
         if self.prof is not None:
             self.prof.end()
@@ -103,6 +172,14 @@ class Engine(object):
                 if not acc:
                     src.g = torch.empty_like(src.t)
                 ops.upsample_nearest_bwd(tmp, src.g, acc)
+            elif self.use_phase_convs and desc.stride == 2 and desc.ksize == 3 and x2 is None and desc.c1 % 4 == 0:
+                # transposed convolution in 4 phases (16 of the 36 zero-dilated taps are real)
+                acc = src.g is not None
+                if not acc:
+                    src.g = torch.empty_like(src.t)
+                wd = ops.phase_weights(weight.detach(), RCF_PHASE_S2_DGRAD)
+                for ph in range(4):
+                    self._run_packed(ops.make_s2_dgrad_desc(desc, ph >> 1, ph & 1, acc), wd[ph], dz, src.g)
             else:
                 acc = src.g is not None
                 if not acc:
@@ -115,7 +192,7 @@ class Engine(object):
         packed = self._new((info.packed_weight_floats,), dz)
         ops.conv_pack(dd, weight.detach(), packed)
         if self.prof is not None:
-            self.prof.begin(info.kernel_id, ops.algorithmic_flops(dd))
+            self.prof.begin(info.kernel_id, ops.algorithmic_flops(dd), dd)
         ops.conv_fwd(dd, dz, None, packed, out, None)
         if self.prof is not None:
             self.prof.end()

@@ -10,7 +10,8 @@ import torch
 
 from . import _lib
 from ._lib import (ConvDesc, ConvInfo, RCF_ACT_LEAKY_RELU, RCF_ACT_NONE, RCF_GATHER_DIRECT, RCF_GATHER_NEAREST,
-                   RCF_GATHER_ZERO_INSERT, RCF_W_DGRAD, RCF_W_FORWARD, check)
+                   RCF_GATHER_STRIDED2, RCF_GATHER_ZERO_INSERT, RCF_PHASE_S2_DGRAD, RCF_PHASE_UP2X_DGRAD, RCF_PHASE_UP2X_FWD,
+                   RCF_W_DGRAD, RCF_W_FORWARD, check)
 
 
 def _stream():
@@ -49,8 +50,9 @@ def make_fwd_desc(n, h_in, w_in, c1, c2, c_out, ksize, stride, h_src1=None, w_sr
     h_out, w_out = conv_out_hw(h_in, w_in, ksize, stride, pad)
     return ConvDesc(n=n, h_in=h_in, w_in=w_in, c1=c1, c2=c2,
                     h_src1=h_in if h_src1 is None else h_src1, w_src1=w_in if w_src1 is None else w_src1,
-                    gather1=gather, h_out=h_out, w_out=w_out, c_out=c_out, ksize=ksize, stride=stride, pad=pad,
-                    w_mode=RCF_W_FORWARD, w_o=c_out, w_i=c1 + c2, w_i_off=0, accumulate=0)
+                    gather1=gather, h_out=h_out, w_out=w_out, c_out=c_out, ksize=ksize, stride=stride, pad=pad, pad_x=pad,
+                    w_mode=RCF_W_FORWARD, w_o=c_out, w_i=c1 + c2, w_i_off=0, accumulate=0,
+                    out_stride=1, out_off_y=0, out_off_x=0, out_h_phys=h_out, out_w_phys=w_out, in_off_y=0, in_off_x=0)
 
 
 def make_dgrad_desc(fwd, i_off, i_cnt, accumulate):
@@ -63,14 +65,57 @@ def make_dgrad_desc(fwd, i_off, i_cnt, accumulate):
     return ConvDesc(n=fwd.n, h_in=fwd.h_in, w_in=fwd.w_in, c1=fwd.c_out, c2=0,
                     h_src1=fwd.h_out, w_src1=fwd.w_out,
                     gather1=RCF_GATHER_ZERO_INSERT if fwd.stride == 2 else RCF_GATHER_DIRECT,
-                    h_out=fwd.h_in, w_out=fwd.w_in, c_out=i_cnt, ksize=k, stride=1, pad=k - 1 - fwd.pad,
-                    w_mode=RCF_W_DGRAD, w_o=fwd.w_o, w_i=fwd.w_i, w_i_off=i_off, accumulate=1 if accumulate else 0)
+                    h_out=fwd.h_in, w_out=fwd.w_in, c_out=i_cnt, ksize=k, stride=1, pad=k - 1 - fwd.pad, pad_x=k - 1 - fwd.pad,
+                    w_mode=RCF_W_DGRAD, w_o=fwd.w_o, w_i=fwd.w_i, w_i_off=i_off, accumulate=1 if accumulate else 0,
+                    out_stride=1, out_off_y=0, out_off_x=0, out_h_phys=fwd.h_in, out_w_phys=fwd.w_in, in_off_y=0, in_off_x=0)
+
+
+# ---- 2x2 phase convolutions (include/rcf_hip.h, RCF_PHASE_*) -------------------------------------------------------
+def make_up2x_fwd_desc(n, hs, ws, c_in, c_out, a, b):
+    """Phase (a,b) of conv3x3(nearest-upsample-2x(x)): a 2x2 conv on x writing output pixels (2y+a, 2x+b)."""
+    return ConvDesc(n=n, h_in=hs, w_in=ws, c1=c_in, c2=0, h_src1=hs, w_src1=ws, gather1=RCF_GATHER_DIRECT,
+                    h_out=hs, w_out=ws, c_out=c_out, ksize=2, stride=1, pad=1 - a, pad_x=1 - b,
+                    w_mode=RCF_W_FORWARD, w_o=c_out, w_i=c_in, w_i_off=0, accumulate=0,
+                    out_stride=2, out_off_y=a, out_off_x=b, out_h_phys=2 * hs, out_w_phys=2 * ws, in_off_y=0, in_off_x=0)
+
+
+def make_up2x_dgrad_desc(n, hs, ws, c_in, c_out, a, b, accumulate):
+    """dX += 2x2 conv of phase (a,b) of dZ (read strided) with the transposed, flipped phase weights."""
+    return ConvDesc(n=n, h_in=hs, w_in=ws, c1=c_out, c2=0, h_src1=2 * hs, w_src1=2 * ws, gather1=RCF_GATHER_STRIDED2,
+                    h_out=hs, w_out=ws, c_out=c_in, ksize=2, stride=1, pad=a, pad_x=b,
+                    w_mode=RCF_W_FORWARD, w_o=c_in, w_i=c_out, w_i_off=0, accumulate=1 if accumulate else 0,
+                    out_stride=1, out_off_y=0, out_off_x=0, out_h_phys=hs, out_w_phys=ws, in_off_y=a, in_off_x=b)
+
+
+def make_s2_dgrad_desc(fwd, a, b, accumulate):
+    """Input gradient of a 3x3 stride-2 conv for input pixels (2y+a, 2x+b): a 2x2 conv on dZ (a transposed conv, 4 phases)."""
+    hy = (fwd.h_in - a + 1) // 2
+    wx = (fwd.w_in - b + 1) // 2
+    return ConvDesc(n=fwd.n, h_in=fwd.h_out, w_in=fwd.w_out, c1=fwd.c_out, c2=0, h_src1=fwd.h_out, w_src1=fwd.w_out,
+                    gather1=RCF_GATHER_DIRECT, h_out=hy, w_out=wx, c_out=fwd.c1, ksize=2, stride=1, pad=0, pad_x=0,
+                    w_mode=RCF_W_FORWARD, w_o=fwd.c1, w_i=fwd.c_out, w_i_off=0, accumulate=1 if accumulate else 0,
+                    out_stride=2, out_off_y=a, out_off_x=b, out_h_phys=fwd.h_in, out_w_phys=fwd.w_in, in_off_y=0, in_off_x=0)
+
+
+def phase_weights(w_oihw, mode):
+    """[4][O'][I'][2][2] phase weights of a 3x3 OIHW weight (RCF_PHASE_*)."""
+    o, i = w_oihw.shape[0], w_oihw.shape[1]
+    out = torch.empty((4, o, i, 2, 2) if mode == RCF_PHASE_UP2X_FWD else (4, i, o, 2, 2), dtype=torch.float32, device=w_oihw.device)
+    check(_lib.load().rcf_phase_weights(_f32(w_oihw), _f32(out), o, i, mode, _stream()), 'rcf_phase_weights')
+    return out
+
+
+def phase_wgrad_fold(dwp, dw_oihw):
+    o, i = dw_oihw.shape[0], dw_oihw.shape[1]
+    check(_lib.load().rcf_phase_wgrad_fold(_f32(dwp), _f32(dw_oihw), o, i, _stream()), 'rcf_phase_wgrad_fold')
 
 
 def algorithmic_flops(desc):
     """2*MACs of the convolution a descriptor stands for, counted on REAL channels and on the forward conv's
     output grid (a stride-2 input gradient counts the forward conv's MACs, not the zero-dilated ones)."""
     k2 = desc.ksize * desc.ksize
+    if desc.ksize == 2:     # a phase conv: count what it executes (its 4 phases together do 4/9 resp. 16/36 of the 3x3 MACs)
+        return 2.0 * desc.n * desc.h_out * desc.w_out * desc.c_out * k2 * desc.c1
     if desc.w_mode == RCF_W_DGRAD:
         return 2.0 * desc.n * desc.h_src1 * desc.w_src1 * desc.c1 * k2 * desc.c_out
     return 2.0 * desc.n * desc.h_out * desc.w_out * desc.c_out * k2 * (desc.c1 + desc.c2)
@@ -85,13 +130,18 @@ class KernelTimer(object):
         self.pending = []
         self.cur = None
 
-    def begin(self, kid, flops):
+    def begin(self, kid, flops, desc=None):
         if self.only is not None and kid not in self.only:
             self.cur = None
             return
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
-        self.cur = (kid, flops, ev)
+        tag = None
+        if desc is not None:
+            tag = '%s k%d s%d %d+%d->%d @%dx%d g%d' % ('dgrad' if desc.w_mode == RCF_W_DGRAD else ('wgrad' if kid >= 10000 else 'fwd'),
+                                                      desc.ksize, desc.stride, desc.c1, desc.c2, desc.c_out, desc.h_out, desc.w_out,
+                                                      desc.gather1)
+        self.cur = (kid, flops, ev, tag)
 
     def end(self):
         if self.cur is None:
@@ -104,11 +154,18 @@ class KernelTimer(object):
     def collect(self):
         """Call after a synchronize.  Returns {kernel id: [launches, flops, ms]}."""
         out = {}
-        for kid, flops, e0, e1 in self.pending:
+        self.layers = {}
+        for kid, flops, e0, tag, e1 in self.pending:
+            ms = e0.elapsed_time(e1)
             r = out.setdefault(kid, [0, 0.0, 0.0])
             r[0] += 1
             r[1] += flops
-            r[2] += e0.elapsed_time(e1)
+            r[2] += ms
+            if tag is not None:
+                q = self.layers.setdefault((kid, tag), [0, 0.0, 0.0])
+                q[0] += 1
+                q[1] += flops
+                q[2] += ms
         self.pending = []
         return out
 

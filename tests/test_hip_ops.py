@@ -369,3 +369,77 @@ def test_unsupported_shapes_return_errors(ops):
         ops.bn_act_fwd(torch.zeros(4, device='cuda'), torch.zeros(16, device='cuda'), None, torch.zeros(4, device='cuda'), 1, 6, 1)
     with pytest.raises(_lib.RcfError):
         ops.conv_fwd(ops.make_fwd_desc(1, 8, 8, 16, 0, 16, 3, 1), torch.zeros(4), None, torch.zeros(4), torch.zeros(4))  # CPU tensors
+
+
+@pytest.mark.parametrize('cin,cout,n,hs,ws', [(64, 32, 1, 35, 51), (64, 64, 2, 12, 20), (8, 4, 2, 35, 51), (32, 32, 1, 9, 33)])
+def test_up2x_conv_as_four_phase_convs(ops, cin, cout, n, hs, ws):
+    '''conv3x3(F.interpolate(x, exactly 2x)) == four 2x2 phase convs on x: forward (+BN statistics), dX, dW.'''
+    from rcf_amd._lib import RCF_PHASE_UP2X_DGRAD, RCF_PHASE_UP2X_FWD
+    x = rnd(n, cin, hs, ws, seed=1).requires_grad_(True)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=1.0 / np.sqrt(cin * 9)).requires_grad_(True)
+    ref = F.conv2d(F.interpolate(x, size=(2 * hs, 2 * ws)), wt, padding=1)
+    dz = rnd(*ref.shape, seed=3)
+    (ref * dz).sum().backward()
+    xg, dzg, wg = nhwc(x.detach()), nhwc(dz), dev(wt.detach())
+
+    wp = ops.phase_weights(wg, RCF_PHASE_UP2X_FWD)
+    z = torch.full((n, 2 * hs, 2 * ws, cout), float('nan'), device='cuda')
+    descs, parts = [], []
+    for ph in range(4):
+        d = ops.make_up2x_fwd_desc(n, hs, ws, cin, cout, ph >> 1, ph & 1)
+        info = ops.conv_query(d)
+        packed = torch.empty(info.packed_weight_floats, device='cuda')
+        ops.conv_pack(d, wp[ph], packed)
+        part = torch.full((info.n_partials, 2, cout), float('nan'), device='cuda', dtype=torch.float64)
+        ops.conv_fwd(d, xg, None, packed, z, part)
+        descs.append(d); parts.append(part)
+    torch.cuda.synchronize()
+    assert rel(nchw(z), ref.detach()) < TOL
+    s = torch.cat(parts).sum(0).cpu()
+    assert rel(s[1], (ref.detach().double() ** 2).sum((0, 2, 3))) < TOL
+
+    dwp = torch.full((4, cout, cin, 2, 2), float('nan'), device='cuda')
+    for ph, d in enumerate(descs):
+        info = ops.conv_query(d)
+        ws_ = torch.empty(max(1, info.wgrad_workspace_floats), device='cuda')
+        ops.conv_wgrad(d, xg, None, dzg, dwp[ph], ws_)
+    dw = torch.full((cout, cin, 3, 3), float('nan'), device='cuda')
+    ops.phase_wgrad_fold(dwp, dw)
+    torch.cuda.synchronize()
+    assert rel(dw.cpu(), wt.grad) < TOL
+
+    wd = ops.phase_weights(wg, RCF_PHASE_UP2X_DGRAD)
+    base = rnd(n, cin, hs, ws, seed=9)
+    dx = nhwc(base)
+    for ph in range(4):
+        dd = ops.make_up2x_dgrad_desc(n, hs, ws, cin, cout, ph >> 1, ph & 1, True)
+        info = ops.conv_query(dd)
+        packed = torch.empty(info.packed_weight_floats, device='cuda')
+        ops.conv_pack(dd, wd[ph], packed)
+        ops.conv_fwd(dd, dzg, None, packed, dx, None)
+    torch.cuda.synchronize()
+    assert rel(nchw(dx), x.grad + base) < TOL
+
+
+@pytest.mark.parametrize('cin,cout,n,h,w', [(32, 64, 2, 45, 80), (8, 16, 2, 35, 51), (128, 256, 1, 29, 50), (64, 128, 1, 8, 6)])
+def test_stride2_input_gradient_as_four_phase_convs(ops, cin, cout, n, h, w):
+    '''The transposed convolution (dX of a 3x3 stride-2 conv) in 4 phases, odd and even extents.'''
+    from rcf_amd._lib import RCF_PHASE_S2_DGRAD
+    x = rnd(n, cin, h, w, seed=1).requires_grad_(True)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=1.0 / np.sqrt(cin * 9))
+    ref = F.conv2d(x, wt, stride=2, padding=1)
+    dz = rnd(*ref.shape, seed=3)
+    (ref * dz).sum().backward()
+    fwd = ops.make_fwd_desc(n, h, w, cin, 0, cout, 3, 2)
+    wd = ops.phase_weights(dev(wt), RCF_PHASE_S2_DGRAD)
+    for accumulate in (False, True):
+        base = rnd(n, cin, h, w, seed=7) if accumulate else torch.zeros(n, cin, h, w)
+        dx = nhwc(base) if accumulate else torch.full((n, h, w, cin), float('nan'), device='cuda')
+        for ph in range(4):
+            dd = ops.make_s2_dgrad_desc(fwd, ph >> 1, ph & 1, accumulate)
+            info = ops.conv_query(dd)
+            packed = torch.empty(info.packed_weight_floats, device='cuda')
+            ops.conv_pack(dd, wd[ph], packed)
+            ops.conv_fwd(dd, nhwc(dz), None, packed, dx, None)
+        torch.cuda.synchronize()
+        assert rel(nchw(dx), x.grad + base) < TOL, accumulate
