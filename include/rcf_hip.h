@@ -69,6 +69,10 @@ typedef struct rcf_conv_desc {
      * reads dZ through the same map.  in_off_*: RCF_GATHER_STRIDED2 only. */
     int out_stride, out_off_y, out_off_x, out_h_phys, out_w_phys;
     int in_off_y, in_off_x;
+    /* phase_sum != 0 (ksize 2, RCF_GATHER_STRIDED2): out = sum over the four input phases (a,b) of the 2x2 conv of phase
+     * (a,b) with pad (a,b) -- the whole input gradient of an up-2x conv in ONE launch.  `packed` then holds the four
+     * phases' packed weights back to back (each rcf_conv_info.packed_weight_floats long). */
+    int phase_sum;
 } rcf_conv_desc;
 
 typedef struct rcf_conv_info {

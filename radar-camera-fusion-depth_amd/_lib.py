@@ -20,7 +20,7 @@ class ConvDesc(Structure):
     _fields_ = [(n, c_int) for n in (
         'n', 'h_in', 'w_in', 'c1', 'c2', 'h_src1', 'w_src1', 'gather1', 'h_out', 'w_out', 'c_out',
         'ksize', 'stride', 'pad', 'pad_x', 'w_mode', 'w_o', 'w_i', 'w_i_off', 'accumulate',
-        'out_stride', 'out_off_y', 'out_off_x', 'out_h_phys', 'out_w_phys', 'in_off_y', 'in_off_x')]
+        'out_stride', 'out_off_y', 'out_off_x', 'out_h_phys', 'out_w_phys', 'in_off_y', 'in_off_x', 'phase_sum')]
 
 
 class ConvInfo(Structure):

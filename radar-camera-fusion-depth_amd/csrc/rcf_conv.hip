@@ -37,6 +37,8 @@ struct ConvArgs {
     int h_out, w_out, c_out, pad, pad_x, stride, gstep, accumulate;
     int os, ooy, oox, ohp, owp;   // output (and wgrad dZ) phase addressing
     int ioy, iox;                 // RCF_GATHER_STRIDED2 input offsets
+    int phase_sum;                // sum the four input phases (up-2x dgrad) inside one launch
+    int wp_phase_stride;          // floats between the phases' packed weights
     float sy, sx;
     int tiles_x, tiles_y, ntiles;
     int nchunk1, nchunk2;
@@ -183,7 +185,10 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
 
     // Work items are (tile, chunk) pairs; the workgroup is persistent over tiles (grid-stride) and the loads of item i+1
     // are issued before the MFMAs of item i, also across a tile boundary.
-    auto load_item = [&](int tile, int q) {
+    const int nitem = a.phase_sum ? 4 * nchunk : nchunk;   // work items per tile
+    auto load_item = [&](int tile, int item) {
+        const int ph = a.phase_sum ? item / nchunk : 0;
+        const int q = a.phase_sum ? item - ph * nchunk : item;
         const bool first = q < a.nchunk1;
         if (q == 0 || q == a.nchunk1) {
             int t = tile;
@@ -191,21 +196,29 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
             t /= a.tiles_x;
             const int ty = t % a.tiles_y;
             const int img = t / a.tiles_y;
-            const int iy0 = ty * C::TH * a.stride - a.pad;
-            const int ix0 = tx * C::PX * a.stride - a.pad_x;
+            const int pa = a.phase_sum ? (ph >> 1) : a.pad, pb = a.phase_sum ? (ph & 1) : a.pad_x;
+            const int iy0 = ty * C::TH * a.stride - pa;
+            const int ix0 = tx * C::PX * a.stride - pb;
             if (q == 0)
-                halo.setup(a.h1, a.w1, a.gather1, img, iy0, ix0, a.gstep, a.h_in, a.w_in, a.sy, a.sx, tid, a.ioy, a.iox);
+                halo.setup(a.h1, a.w1, a.gather1, img, iy0, ix0, a.gstep, a.h_in, a.w_in, a.sy, a.sx, tid,
+                           a.phase_sum ? (ph >> 1) : a.ioy, a.phase_sum ? (ph & 1) : a.iox);
             else
                 halo.setup(a.h_in, a.w_in, RCF_GATHER_DIRECT, img, iy0, ix0, a.gstep, a.h_in, a.w_in, 1.f, 1.f, tid);
         }
         halo.load(ra, first ? a.in1 : a.in2, first ? a.c1 : a.c2, (first ? q : q - a.nchunk1) * C::CST, tid);
-        const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + (size_t)q * WCHUNK);
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + (size_t)ph * a.wp_phase_stride + (size_t)q * WCHUNK);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int idx = tid + i * 256;
             if (NVB % 256 == 0 || idx < NVB) rb[i] = wsrc[idx];
         }
     };
+
+    // BatchNorm statistics of this workgroup's output channels, accumulated over all its tiles (fp64; in-lane fp32 sums
+    // cover <= 32 values per tile) and written as ONE partial row per workgroup at the end.
+    double st1[C::NT], st2[C::NT];
+#pragma unroll
+    for (int ni = 0; ni < C::NT; ++ni) { st1[ni] = 0.0; st2[ni] = 0.0; }
 
     int tile = blockIdx.x;
     int q = 0;
@@ -221,7 +234,7 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
         }
         __syncthreads();
         int ntile = tile, nq = q + 1;
-        if (nq == nchunk) { nq = 0; ntile = tile + gridDim.x; }
+        if (nq == nitem) { nq = 0; ntile = tile + gridDim.x; }
         if (ntile < a.ntiles) load_item(ntile, nq);   // in flight while the MFMAs below run
 
         if (q == 0) {
@@ -254,7 +267,7 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
             }
         }
 
-        if (q == nchunk - 1) {
+        if (q == nitem - 1) {
             // ---- epilogue of this tile: store (+accumulate) and BN statistics ----
             int t = tile;
             const int tx = t % a.tiles_x;
@@ -290,38 +303,40 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
                 }
             }
             if (a.stats != nullptr) {
-                __syncthreads();   // the MFMA loop is done with LDS
-                // in-lane fp32 sums cover <= 32 values; everything across lanes / waves / workgroups is fp64
-                // (PyTorch's CPU BatchNorm accumulates float tensors in double as well)
-                double* red = reinterpret_cast<double*>(smem);   // [4 waves][BN][2]
 #pragma unroll
-                for (int ni = 0; ni < C::NT; ++ni) {
-                    const double d1 = (double)s1[ni], d2 = (double)s2[ni];
-                    const double t1 = d1 + __shfl_xor(d1, 32);
-                    const double t2 = d2 + __shfl_xor(d2, 32);
-                    if (lh == 0) {
-                        red[(wave * C::BN + ni * 32 + li) * 2 + 0] = t1;
-                        red[(wave * C::BN + ni * 32 + li) * 2 + 1] = t2;
-                    }
-                }
-                __syncthreads();
-                if (tid < C::BN) {
-                    const int co = n0 + tid;
-                    if (co < a.c_out) {
-                        double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) {
-                            t1 += red[(w * C::BN + tid) * 2 + 0];
-                            t2 += red[(w * C::BN + tid) * 2 + 1];
-                        }
-                        a.stats[((size_t)tile * 2 + 0) * a.c_out + co] = t1;
-                        a.stats[((size_t)tile * 2 + 1) * a.c_out + co] = t2;
-                    }
-                }
+                for (int ni = 0; ni < C::NT; ++ni) { st1[ni] += (double)s1[ni]; st2[ni] += (double)s2[ni]; }
             }
         }
         tile = ntile;
         q = nq;
+    }
+
+    if (a.stats != nullptr) {
+        __syncthreads();   // LDS is free
+        double* red = reinterpret_cast<double*>(smem);   // [4 waves][BN][2]
+#pragma unroll
+        for (int ni = 0; ni < C::NT; ++ni) {
+            const double t1 = st1[ni] + __shfl_xor(st1[ni], 32);
+            const double t2 = st2[ni] + __shfl_xor(st2[ni], 32);
+            if (lh == 0) {
+                red[(wave * C::BN + ni * 32 + li) * 2 + 0] = t1;
+                red[(wave * C::BN + ni * 32 + li) * 2 + 1] = t2;
+            }
+        }
+        __syncthreads();
+        if (tid < C::BN) {
+            const int co = n0 + tid;
+            if (co < a.c_out) {
+                double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    t1 += red[(w * C::BN + tid) * 2 + 0];
+                    t2 += red[(w * C::BN + tid) * 2 + 1];
+                }
+                a.stats[((size_t)blockIdx.x * 2 + 0) * a.c_out + co] = t1;
+                a.stats[((size_t)blockIdx.x * 2 + 1) * a.c_out + co] = t2;
+            }
+        }
     }
 }
 
@@ -610,10 +625,22 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(ConvArgs a) {
 
 // workspace [nslot][ktot][cop] -> dW in OIHW.  One thread per (k, co), co fastest (coalesced reads).
 // kind: 0 generic (k = (q*T+tap)*32 + channel-in-chunk), 1 stem (k = tap(ky)*32 + kx*4 + c).
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslot, int ktot, int cop,
-                                    int c_out, int c1, int c2, int nchunk1, int T, int ksx, int kind) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= ktot * cop) return;
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslot, int ktot,
+                                                           int cop, int c_out, int c1, int c2, int nchunk1, int T, int ksx, int kind) {
+    __shared__ double sm[4][64];
+    const int lane_o = threadIdx.x & 63;     // 64 consecutive (k, co) outputs per block: coalesced 256-B reads per slot
+    const int lane_s = threadIdx.x >> 6;     // 4 slot lanes
+    const int idx = blockIdx.x * 64 + lane_o;
+    const bool live = idx < ktot * cop;
+    double s = 0.0;   // the per-workgroup partials cancel heavily for BN-followed convs: sum them in fp64
+    if (live) {
+        const size_t stride = (size_t)ktot * cop;
+        for (int sl = lane_s; sl < nslot; sl += 4) s += (double)ws[sl * stride + idx];
+    }
+    sm[lane_s][lane_o] = s;
+    __syncthreads();
+    if (lane_s != 0 || !live) return;
+    s = sm[0][lane_o] + sm[1][lane_o] + sm[2][lane_o] + sm[3][lane_o];
     const int co = idx % cop;
     const int k = idx / cop;
     if (co >= c_out) return;
@@ -640,9 +667,6 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
             ci += c1;
         }
     }
-    double s = 0.0;   // the per-workgroup partials cancel heavily for BN-followed convs: sum them in fp64
-    const size_t stride = (size_t)ktot * cop;
-    for (int sl = 0; sl < nslot; ++sl) s += (double)ws[sl * stride + idx];
     const int kw = (kind == 1) ? 7 : ksx;
     dw[(((size_t)co * (c1 + c2) + ci) * ksy_total + ky) * kw + kx] = (float)s;
 }
@@ -757,8 +781,10 @@ int num_cus() {
     return n;
 }
 
+// Persistent grid: one resident wave of workgroups (occupancy API), split between the n-tiles.  Also the number of
+// BN-statistics partial rows the kernel writes, so rcf_conv2d_query reports the same number.
 template <class C>
-int launch_fwd(const ConvArgs& a, int ntile_n, hipStream_t st) {
+int fwd_grid_x(int ntiles, int ntile_n) {
     static int resident = 0;   // workgroups that fit on the device at once
     if (resident == 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -768,10 +794,15 @@ int launch_fwd(const ConvArgs& a, int ntile_n, hipStream_t st) {
             per_cu = 1;
         resident = per_cu * num_cus();
     }
-    // persistent over tiles: one resident wave of workgroups, split between the n-tiles
     int gx = resident / ntile_n;
     if (gx < 1) gx = 1;
-    if (gx > a.ntiles) gx = a.ntiles;
+    if (gx > ntiles) gx = ntiles;
+    return gx;
+}
+
+template <class C>
+int launch_fwd(const ConvArgs& a, int ntile_n, hipStream_t st) {
+    const int gx = fwd_grid_x<C>(a.ntiles, ntile_n);
     dim3 grid(gx, ntile_n, 1);
     hipLaunchKernelGGL((conv_fwd_kernel<C>), grid, dim3(256), C::LDS_BYTES, st, a);
     return rcf_launch_status();
@@ -849,6 +880,9 @@ using W7_16 = WgCfg<7, 1, 7, 2, 4, 4, 16, 16, 2>;
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+template <class T>
+struct Tag { using type = T; };
+
 // tile utilisation of a PX x TH tiling of a w x h image
 double tile_eff(int w, int h, int px, int th) {
     return ((double)w / (ceil_div(w, px) * px)) * ((double)h / (ceil_div(h, th) * th));
@@ -872,6 +906,7 @@ bool valid_desc(const rcf_conv_desc* d) {
     } else if (d->stride != 1 || d->w_mode != RCF_W_FORWARD) {
         return false;
     }
+    if (d->phase_sum && (d->ksize != 2 || d->gather1 != RCF_GATHER_STRIDED2 || d->c2 != 0)) return false;
     if (d->w_mode == RCF_W_FORWARD) {
         if (d->w_o != d->c_out || d->w_i != d->c1 + d->c2) return false;
     } else if (d->w_mode == RCF_W_DGRAD) {
@@ -924,6 +959,7 @@ void fill_args(const rcf_conv_desc* d, const Sel& s, ConvArgs* a) {
     a->accumulate = d->accumulate;
     a->os = d->out_stride; a->ooy = d->out_off_y; a->oox = d->out_off_x; a->ohp = d->out_h_phys; a->owp = d->out_w_phys;
     a->ioy = d->in_off_y; a->iox = d->in_off_x;
+    a->phase_sum = d->phase_sum; a->wp_phase_stride = 0;
     a->sy = (float)d->h_src1 / (float)d->h_in;
     a->sx = (float)d->w_src1 / (float)d->w_in;
     a->tiles_x = ceil_div(d->w_out, s.px);
@@ -931,6 +967,36 @@ void fill_args(const rcf_conv_desc* d, const Sel& s, ConvArgs* a) {
     a->ntiles = d->n * a->tiles_x * a->tiles_y;
     a->nchunk1 = ceil_div(d->c1, s.cst);
     a->nchunk2 = d->c2 > 0 ? ceil_div(d->c2, s.cst) : 0;
+}
+
+template <class F>
+int dispatch_fwd(const Sel& s, F&& f) {
+    const bool p16 = s.px == 16;
+    switch (s.kind) {
+        case K3S1:
+            if (s.ck == 16) {
+                if (s.nt == 1) return p16 ? f(Tag<F3S1_16_1_16>{}) : f(Tag<F3S1_16_1_32>{});
+                return p16 ? f(Tag<F3S1_16_2_16>{}) : f(Tag<F3S1_16_2_32>{});
+            }
+            if (s.nt == 1) return p16 ? f(Tag<F3S1_8_1_16>{}) : f(Tag<F3S1_8_1_32>{});
+            return p16 ? f(Tag<F3S1_8_2_16>{}) : f(Tag<F3S1_8_2_32>{});
+        case K3S2:
+            if (s.nt == 1) return p16 ? f(Tag<F3S2_8_1_16>{}) : f(Tag<F3S2_8_1_32>{});
+            return p16 ? f(Tag<F3S2_8_2_16>{}) : f(Tag<F3S2_8_2_32>{});
+        case K1:
+            if (s.ck == 32) {
+                if (s.nt == 1) return p16 ? f(Tag<F1_32_1_16>{}) : f(Tag<F1_32_1_32>{});
+                return p16 ? f(Tag<F1_32_2_16>{}) : f(Tag<F1_32_2_32>{});
+            }
+            if (s.nt == 1) return p16 ? f(Tag<F1_16_1_16>{}) : f(Tag<F1_16_1_32>{});
+            return p16 ? f(Tag<F1_16_2_16>{}) : f(Tag<F1_16_2_32>{});
+        case K7S2:
+            return p16 ? f(Tag<F7_16>{}) : f(Tag<F7_32>{});
+        case K2S1:
+            if (s.nt == 1) return p16 ? f(Tag<F2_32_1_16>{}) : f(Tag<F2_32_1_32>{});
+            return p16 ? f(Tag<F2_32_2_16>{}) : f(Tag<F2_32_2_32>{});
+    }
+    return RCF_EUNSUPPORTED;
 }
 
 // wgrad tiling for the forward descriptor
@@ -997,7 +1063,8 @@ extern "C" int rcf_conv2d_query(const rcf_conv_desc* d, rcf_conv_info* info) {
     fill_args(d, s, &a);
     const int ntile_n = ceil_div(d->c_out, s.bn);
     info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * s.ck;
-    info->n_partials = a.ntiles;
+    info->n_partials = dispatch_fwd(s, [&](auto tag) { return fwd_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
+    if (info->n_partials <= 0) return RCF_EUNSUPPORTED;
     info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : 0);
     info->wgrad_workspace_floats = 0;
     info->wgrad_kernel_id = 0;
@@ -1041,33 +1108,8 @@ extern "C" int rcf_conv2d_fwd(const rcf_conv_desc* d, const float* in1, const fl
     a.in1 = in1; a.in2 = in2; a.wp = packed; a.out = out; a.stats = stat_partials; a.dz = nullptr; a.ws = nullptr;
     a.ktot = 0; a.cop = 0;
     const int nn = ceil_div(d->c_out, s.bn);
-    hipStream_t st = (hipStream_t)stream;
-    const int p16 = s.px == 16;
-    switch (s.kind) {
-        case K3S1:
-            if (s.ck == 16) {
-                if (s.nt == 1) return p16 ? launch_fwd<F3S1_16_1_16>(a, nn, st) : launch_fwd<F3S1_16_1_32>(a, nn, st);
-                return p16 ? launch_fwd<F3S1_16_2_16>(a, nn, st) : launch_fwd<F3S1_16_2_32>(a, nn, st);
-            }
-            if (s.nt == 1) return p16 ? launch_fwd<F3S1_8_1_16>(a, nn, st) : launch_fwd<F3S1_8_1_32>(a, nn, st);
-            return p16 ? launch_fwd<F3S1_8_2_16>(a, nn, st) : launch_fwd<F3S1_8_2_32>(a, nn, st);
-        case K3S2:
-            if (s.nt == 1) return p16 ? launch_fwd<F3S2_8_1_16>(a, nn, st) : launch_fwd<F3S2_8_1_32>(a, nn, st);
-            return p16 ? launch_fwd<F3S2_8_2_16>(a, nn, st) : launch_fwd<F3S2_8_2_32>(a, nn, st);
-        case K1:
-            if (s.ck == 32) {
-                if (s.nt == 1) return p16 ? launch_fwd<F1_32_1_16>(a, nn, st) : launch_fwd<F1_32_1_32>(a, nn, st);
-                return p16 ? launch_fwd<F1_32_2_16>(a, nn, st) : launch_fwd<F1_32_2_32>(a, nn, st);
-            }
-            if (s.nt == 1) return p16 ? launch_fwd<F1_16_1_16>(a, nn, st) : launch_fwd<F1_16_1_32>(a, nn, st);
-            return p16 ? launch_fwd<F1_16_2_16>(a, nn, st) : launch_fwd<F1_16_2_32>(a, nn, st);
-        case K7S2:
-            return p16 ? launch_fwd<F7_16>(a, nn, st) : launch_fwd<F7_32>(a, nn, st);
-        case K2S1:
-            if (s.nt == 1) return p16 ? launch_fwd<F2_32_1_16>(a, nn, st) : launch_fwd<F2_32_1_32>(a, nn, st);
-            return p16 ? launch_fwd<F2_32_2_16>(a, nn, st) : launch_fwd<F2_32_2_32>(a, nn, st);
-    }
-    return RCF_EUNSUPPORTED;
+    a.wp_phase_stride = (int)((size_t)nn * (a.nchunk1 + a.nchunk2) * s.t * s.bn * s.ck);
+    return dispatch_fwd(s, [&](auto tag) { return launch_fwd<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
 }
 
 extern "C" int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const float* in2, const float* dz,
@@ -1085,6 +1127,7 @@ extern "C" int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const 
     a.accumulate = 0;
     a.os = d->out_stride; a.ooy = d->out_off_y; a.oox = d->out_off_x; a.ohp = d->out_h_phys; a.owp = d->out_w_phys;
     a.ioy = d->in_off_y; a.iox = d->in_off_x;
+    a.phase_sum = 0; a.wp_phase_stride = 0;
     a.sy = (float)d->h_src1 / (float)d->h_in;
     a.sx = (float)d->w_src1 / (float)d->w_in;
     a.tiles_x = w.tiles_x; a.tiles_y = w.tiles_y; a.ntiles = w.ntiles;
@@ -1121,7 +1164,7 @@ extern "C" int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const 
     if (rc != RCF_OK) return rc;
     const int total = w.ktot * w.cop;
     const int ksx = w.kind == K7S2 ? 1 : d->ksize;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, dw_oihw, w.nsplit, w.ktot,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, workspace, dw_oihw, w.nsplit, w.ktot,
                        w.cop, d->c_out, d->c1, d->c2, w.nchunk1, w.t, ksx, w.kind == K7S2 ? 1 : 0);
     return rcf_launch_status();
 }

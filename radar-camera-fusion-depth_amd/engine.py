@@ -144,9 +144,16 @@ class Engine(object):
             acc = x.g is not None
             if not acc:
                 x.g = torch.empty_like(x.t)
+            dd = ops.make_up2x_dgrad_desc(n, h, w, c1, co, 0, 0, acc, phase_sum=True)
+            qi = ops.conv_query(dd)
+            packed = self._new((4 * qi.packed_weight_floats,), dz)
             for ph in range(4):
-                dd = ops.make_up2x_dgrad_desc(n, h, w, c1, co, ph >> 1, ph & 1, acc or ph > 0)
-                self._run_packed(dd, wd[ph], dz, x.g)
+                ops.conv_pack(dd, wd[ph], packed[ph * qi.packed_weight_floats:(ph + 1) * qi.packed_weight_floats])
+            if self.prof is not None:
+                self.prof.begin(qi.kernel_id, ops.algorithmic_flops(dd), dd)
+            ops.conv_fwd(dd, dz, None, packed, x.g, None)
+            if self.prof is not None:
+                self.prof.end()
 
     def _conv_backward(self, layer, desc, info, x, x2, dz):
         '''dW (written once into the parameter's gradient) and dX / dX2 (accumulated into the producers' .g).'''

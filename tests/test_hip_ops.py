@@ -420,6 +420,18 @@ def test_up2x_conv_as_four_phase_convs(ops, cin, cout, n, hs, ws):
     torch.cuda.synchronize()
     assert rel(nchw(dx), x.grad + base) < TOL
 
+    # the same input gradient with the four phases summed inside ONE launch
+    for accumulate in (False, True):
+        dd = ops.make_up2x_dgrad_desc(n, hs, ws, cin, cout, 0, 0, accumulate, phase_sum=True)
+        info = ops.conv_query(dd)
+        packed = torch.empty(4 * info.packed_weight_floats, device='cuda')
+        for ph in range(4):
+            ops.conv_pack(dd, wd[ph], packed[ph * info.packed_weight_floats:(ph + 1) * info.packed_weight_floats])
+        dx1 = nhwc(base) if accumulate else torch.full((n, hs, ws, cin), float('nan'), device='cuda')
+        ops.conv_fwd(dd, dzg, None, packed, dx1, None)
+        torch.cuda.synchronize()
+        assert rel(nchw(dx1), x.grad + (base if accumulate else 0)) < TOL, accumulate
+
 
 @pytest.mark.parametrize('cin,cout,n,h,w', [(32, 64, 2, 45, 80), (8, 16, 2, 35, 51), (128, 256, 1, 29, 50), (64, 128, 1, 8, 6)])
 def test_stride2_input_gradient_as_four_phase_convs(ops, cin, cout, n, h, w):
