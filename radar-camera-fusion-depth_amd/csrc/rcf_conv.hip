@@ -37,6 +37,8 @@ struct ConvArgs {
     int h_out, w_out, c_out, pad, pad_x, stride, gstep, accumulate;
     int os, ooy, oox, ohp, owp;   // output (and wgrad dZ) phase addressing
     int ioy, iox;                 // RCF_GATHER_STRIDED2 input offsets
+    int vt, hp, nimg;             // virtual tall image: rows = n*(h+1) with a zero separator row after each image
+    float inv_hp;
     int phase_sum;                // sum the four input phases (up-2x dgrad) inside one launch
     int wp_phase_stride;          // floats between the phases' packed weights
     float sy, sx;
@@ -77,8 +79,11 @@ struct Halo {
     static constexpr int NA = (HXP * HYP + PPI - 1) / PPI;
     int pix[NA];                                               // element index of the pixel in the source, / csrc; -1: zero
 
+    // vt != 0: rows are VIRTUAL rows of the batch stacked vertically with one zero row after each image (hp = h + 1);
+    // that separator is exactly the zero padding of a stride-1 3x3 conv, so tiles may straddle images.
     __device__ __forceinline__ void setup(int hs, int ws, int gmode, int img, int iy0, int ix0, int gstep, int h_in, int w_in,
-                                          float sy, float sx, int tid, int ioy = 0, int iox = 0) {
+                                          float sy, float sx, int tid, int ioy = 0, int iox = 0, int vt = 0, int hp = 1,
+                                          float inv_hp = 1.f, int nimg = 1) {
         const int p0 = tid / C4;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -88,7 +93,13 @@ struct Halo {
             const int ly = iy0 + hy * gstep;
             const int lx = ix0 + hx * gstep;
             int v = -1;
-            if (p < HXP * HYP && ly >= 0 && ly < h_in && lx >= 0 && lx < w_in) {
+            if (vt) {
+                if (p < HXP * HYP && ly >= 0 && lx >= 0 && lx < w_in) {
+                    const int im = (int)(((float)ly + 0.5f) * inv_hp);   // exact: ly < 2^20, |frac - k| >= 0.5/hp
+                    const int y = ly - im * hp;
+                    if (im < nimg && y < h_in) v = (im * hs + y) * ws + lx;
+                }
+            } else if (p < HXP * HYP && ly >= 0 && ly < h_in && lx >= 0 && lx < w_in) {
                 int py = ly, px = lx;
                 bool ok = true;
                 if (gmode == RCF_GATHER_NEAREST) {
@@ -195,15 +206,16 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
             const int tx = t % a.tiles_x;
             t /= a.tiles_x;
             const int ty = t % a.tiles_y;
-            const int img = t / a.tiles_y;
+            const int img = t / a.tiles_y;   // 0 in virtual-tall mode (tiles_y covers all images)
             const int pa = a.phase_sum ? (ph >> 1) : a.pad, pb = a.phase_sum ? (ph & 1) : a.pad_x;
             const int iy0 = ty * C::TH * a.stride - pa;
             const int ix0 = tx * C::PX * a.stride - pb;
             if (q == 0)
                 halo.setup(a.h1, a.w1, a.gather1, img, iy0, ix0, a.gstep, a.h_in, a.w_in, a.sy, a.sx, tid,
-                           a.phase_sum ? (ph >> 1) : a.ioy, a.phase_sum ? (ph & 1) : a.iox);
+                           a.phase_sum ? (ph >> 1) : a.ioy, a.phase_sum ? (ph & 1) : a.iox, a.vt, a.hp, a.inv_hp, a.nimg);
             else
-                halo.setup(a.h_in, a.w_in, RCF_GATHER_DIRECT, img, iy0, ix0, a.gstep, a.h_in, a.w_in, 1.f, 1.f, tid);
+                halo.setup(a.h_in, a.w_in, RCF_GATHER_DIRECT, img, iy0, ix0, a.gstep, a.h_in, a.w_in, 1.f, 1.f, tid, 0, 0, a.vt, a.hp,
+                           a.inv_hp, a.nimg);
         }
         halo.load(ra, first ? a.in1 : a.in2, first ? a.c1 : a.c2, (first ? q : q - a.nchunk1) * C::CST, tid);
         const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + (size_t)ph * a.wp_phase_stride + (size_t)q * WCHUNK);
@@ -214,8 +226,8 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
         }
     };
 
-    // BatchNorm statistics of this workgroup's output channels, accumulated over all its tiles (fp64; in-lane fp32 sums
-    // cover <= 32 values per tile) and written as ONE partial row per workgroup at the end.
+    // BatchNorm statistics of this workgroup's output channels, accumulated in fp64 over all its tiles (PyTorch's CPU
+    // BatchNorm accumulates float tensors in double too) and written as ONE partial row per workgroup at the end.
     double st1[C::NT], st2[C::NT];
 #pragma unroll
     for (int ni = 0; ni < C::NT; ++ni) { st1[ni] = 0.0; st2[ni] = 0.0; }
@@ -276,19 +288,23 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
             const int img = t / a.tiles_y;
             const int oy0 = ty * C::TH;
             const int ox0 = tx * C::PX;
-            float s1[C::NT], s2[C::NT];
-#pragma unroll
-            for (int ni = 0; ni < C::NT; ++ni) { s1[ni] = 0.f; s2[ni] = 0.f; }
+            const bool want_stats = a.stats != nullptr;
 #pragma unroll
             for (int mi = 0; mi < C::MT; ++mi) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rcf_mfma_row(r, lh);
-                    const int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
+                    int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
                     const int ox = ox0 + row % C::PX;
+                    int im = img;
+                    if (a.vt) {   // virtual row -> (image, row); separator rows produce no output
+                        im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                        oy -= im * a.hp;
+                        if (im >= a.nimg) oy = a.h_out;
+                    }
                     const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
                     const bool pix_ok = oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
-                    const size_t pbase = (((size_t)img * a.ohp + py) * a.owp + px) * a.c_out;
+                    const size_t pbase = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
 #pragma unroll
                     for (int ni = 0; ni < C::NT; ++ni) {
                         const int co = n0 + ni * 32 + li;
@@ -296,15 +312,14 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
                             float v = acc[mi][ni][r];
                             if (a.accumulate) v += a.out[pbase + co];
                             a.out[pbase + co] = v;
-                            s1[ni] += v;
-                            s2[ni] += v * v;
+                            if (want_stats) {   // fp64 per value: E[x^2]-mean^2 must not depend on how tiles group the sum
+                                const double dv = (double)v;
+                                st1[ni] += dv;
+                                st2[ni] += dv * dv;
+                            }
                         }
                     }
                 }
-            }
-            if (a.stats != nullptr) {
-#pragma unroll
-                for (int ni = 0; ni < C::NT; ++ni) { st1[ni] += (double)s1[ni]; st2[ni] += (double)s2[ni]; }
             }
         }
         tile = ntile;
@@ -543,7 +558,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(ConvArgs a) {
         const int oy0 = ty * C::TH;
         const int ox0 = tx * C::PX;
         halo.setup(hs, ws, gmode, img, oy0 * a.stride - a.pad, ox0 * a.stride - a.pad_x, a.gstep, a.h_in, a.w_in, a.sy, a.sx, tid,
-                   a.ioy, a.iox);
+                   a.ioy, a.iox, a.vt, a.hp, a.inv_hp, a.nimg);
         __syncthreads();   // the previous tile's MFMAs are done with LDS
 #pragma unroll
         for (int i = 0; i < H::NA; ++i) {
@@ -555,11 +570,17 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const int p = (tid >> 3) + i * 32;
-            const int oy = oy0 + p / C::PX;
+            int oy = oy0 + p / C::PX;
             const int ox = ox0 + p % C::PX;
+            int im = img;
+            if (a.vt) {
+                im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                oy -= im * a.hp;
+                if (im >= a.nimg) oy = a.h_out;
+            }
             const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
             const bool ok = dok && oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
-            const float* g = ok ? a.dz + (((size_t)img * a.ohp + py) * a.owp + px) * a.c_out + dc : a.zero;
+            const float* g = ok ? a.dz + (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out + dc : a.zero;
             float* dst = Ds + (i * 32 + wave * 8) * 32;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -768,6 +789,7 @@ enum Kind { K3S1 = 0, K3S2 = 1, K1 = 2, K7S2 = 3, K2S1 = 4 };
 struct Sel {
     int kind, ck, nt, px;
     int th, bn, t, cst;
+    int vt;   // virtual tall image tiling
 };
 
 int num_cus() {
@@ -843,6 +865,8 @@ using F3S1_16_1_32 = FwdCfg<3, 3, 0, 1, 16, 16, 20, 1, 32, 2>;
 using F3S1_16_2_32 = FwdCfg<3, 3, 0, 1, 16, 16, 20, 2, 32, 2>;
 using F3S1_16_1_16 = FwdCfg<3, 3, 0, 1, 16, 16, 20, 1, 16, 2>;
 using F3S1_16_2_16 = FwdCfg<3, 3, 0, 1, 16, 16, 20, 2, 16, 2>;
+using F3S1_16_1_8 = FwdCfg<3, 3, 0, 1, 16, 16, 20, 1, 8, 2>;
+using F3S1_16_2_8 = FwdCfg<3, 3, 0, 1, 16, 16, 20, 2, 8, 2>;
 using F3S1_8_1_32 = FwdCfg<3, 3, 0, 1, 8, 8, 12, 1, 32, 2>;
 using F3S1_8_2_32 = FwdCfg<3, 3, 0, 1, 8, 8, 12, 2, 32, 2>;
 using F3S1_8_1_16 = FwdCfg<3, 3, 0, 1, 8, 8, 12, 1, 16, 2>;
@@ -869,6 +893,7 @@ using F7_16 = FwdCfg<7, 1, 7, 2, 32, 4, 4, 1, 16, 2>;
 //               KSY KSX XE LS CST STRP PX TH MINW
 using W3S1_32 = WgCfg<3, 3, 0, 1, 32, 32, 32, 8, 1>;
 using W3S1_16 = WgCfg<3, 3, 0, 1, 32, 32, 16, 16, 1>;
+using W3S1_8 = WgCfg<3, 3, 0, 1, 32, 32, 8, 32, 1>;
 using W3S2_32 = WgCfg<3, 3, 0, 2, 32, 32, 32, 4, 1>;
 using W3S2_16 = WgCfg<3, 3, 0, 2, 32, 32, 16, 8, 1>;
 using W1_32 = WgCfg<1, 1, 0, 1, 32, 32, 32, 8, 2>;
@@ -886,6 +911,17 @@ struct Tag { using type = T; };
 // tile utilisation of a PX x TH tiling of a w x h image
 double tile_eff(int w, int h, int px, int th) {
     return ((double)w / (ceil_div(w, px) * px)) * ((double)h / (ceil_div(h, th) * th));
+}
+
+// utilisation when the n images are stacked with one separator row each (rows n*(h+1))
+double tile_eff_vt(int w, int h, int n, int px, int th) {
+    return ((double)w / (ceil_div(w, px) * px)) * ((double)n * h / (ceil_div(n * (h + 1), th) * th));
+}
+
+// stride-1 3x3 conv with pad 1 on directly addressed sources: the separator row is the conv's own zero padding
+bool vt_allowed(const rcf_conv_desc* d) {
+    return d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->pad_x == 1 && d->gather1 == RCF_GATHER_DIRECT &&
+           d->out_stride == 1 && d->h_in == d->h_out && d->n > 1 && getenv("RCF_NO_VT") == nullptr;
 }
 
 bool valid_desc(const rcf_conv_desc* d) {
@@ -942,10 +978,20 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
         // scalar staging path handles it, but concat boundaries must stay 4-aligned
         if (d->c2 != 0) return RCF_EUNSUPPORTED;
     }
-    // tile shape: 32x8 or 16x16 output pixels, whichever wastes less at the image edges
-    const double e32 = tile_eff(d->w_out, d->h_out, 32, 8);
-    const double e16 = tile_eff(d->w_out, d->h_out, 16, 16);
-    s->px = e16 > e32 + 1e-9 ? 16 : 32;
+    // tile shape: 32x8 or 16x16 output pixels (8x32 too for the stride-1 3x3 kernels with >= 16 channels), whichever
+    // wastes least at the image edges; stride-1 3x3 convs may also tile the batch as one tall virtual image
+    s->vt = 0;
+    double best = -1.0;
+    const bool vt_ok = vt_allowed(d);
+    const int pxs[3] = {32, 16, 8};
+    for (int i = 0; i < 3; ++i) {
+        const int px = pxs[i], th = 256 / px;
+        if (px == 8 && !(s->kind == K3S1 && s->ck == 16)) continue;
+        for (int vt = 0; vt <= (vt_ok ? 1 : 0); ++vt) {
+            const double e = vt ? tile_eff_vt(d->w_out, d->h_out, d->n, px, th) : tile_eff(d->w_out, d->h_out, px, th);
+            if (e > best + 1e-9) { best = e; s->px = px; s->vt = vt; }
+        }
+    }
     s->th = 256 / s->px;
     s->bn = 32 * s->nt;
     return RCF_OK;
@@ -963,8 +1009,14 @@ void fill_args(const rcf_conv_desc* d, const Sel& s, ConvArgs* a) {
     a->sy = (float)d->h_src1 / (float)d->h_in;
     a->sx = (float)d->w_src1 / (float)d->w_in;
     a->tiles_x = ceil_div(d->w_out, s.px);
-    a->tiles_y = ceil_div(d->h_out, s.th);
-    a->ntiles = d->n * a->tiles_x * a->tiles_y;
+    a->vt = s.vt; a->hp = d->h_out + 1; a->nimg = d->n; a->inv_hp = 1.0f / (float)(d->h_out + 1);
+    if (s.vt) {
+        a->tiles_y = ceil_div(d->n * (d->h_out + 1), s.th);
+        a->ntiles = a->tiles_x * a->tiles_y;
+    } else {
+        a->tiles_y = ceil_div(d->h_out, s.th);
+        a->ntiles = d->n * a->tiles_x * a->tiles_y;
+    }
     a->nchunk1 = ceil_div(d->c1, s.cst);
     a->nchunk2 = d->c2 > 0 ? ceil_div(d->c2, s.cst) : 0;
 }
@@ -975,6 +1027,7 @@ int dispatch_fwd(const Sel& s, F&& f) {
     switch (s.kind) {
         case K3S1:
             if (s.ck == 16) {
+                if (s.px == 8) return s.nt == 1 ? f(Tag<F3S1_16_1_8>{}) : f(Tag<F3S1_16_2_8>{});
                 if (s.nt == 1) return p16 ? f(Tag<F3S1_16_1_16>{}) : f(Tag<F3S1_16_1_32>{});
                 return p16 ? f(Tag<F3S1_16_2_16>{}) : f(Tag<F3S1_16_2_32>{});
             }
@@ -1000,7 +1053,7 @@ int dispatch_fwd(const Sel& s, F&& f) {
 }
 
 // wgrad tiling for the forward descriptor
-struct WSel { int kind, px, th, t, cst, nchunk1, nchunk2, ncog, nsplit, ktot, cop, tiles_x, tiles_y, ntiles; };
+struct WSel { int kind, px, th, t, cst, nchunk1, nchunk2, ncog, nsplit, ktot, cop, tiles_x, tiles_y, ntiles, vt; };
 
 int select_wgrad(const rcf_conv_desc* d, WSel* w) {
     if (!valid_desc(d) || d->w_mode != RCF_W_FORWARD) return RCF_EINVAL;
@@ -1018,13 +1071,26 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
     if ((d->c1 % 4 != 0 || d->c2 % 4 != 0) && w->kind != K7S2 && d->c2 != 0) return RCF_EUNSUPPORTED;
     const int th32 = (w->kind == K3S2) ? 4 : 8;
     const int th16 = (w->kind == K3S2) ? 8 : 16;
-    const double e32 = tile_eff(d->w_out, d->h_out, 32, th32);
-    const double e16 = tile_eff(d->w_out, d->h_out, 16, th16);
-    w->px = e16 > e32 + 1e-9 ? 16 : 32;
-    w->th = w->px == 32 ? th32 : th16;
+    const bool dma_ok = w->kind != K7S2 && (d->c1 % 4 == 0) && (d->c2 % 4 == 0);
+    const bool vt_ok = dma_ok && vt_allowed(d);
+    w->vt = 0;
+    double best = -1.0;
+    const int pxs[3] = {32, 16, 8}, ths[3] = {th32, th16, 32};
+    for (int i = 0; i < 3; ++i) {
+        if (pxs[i] == 8 && !(w->kind == K3S1 && dma_ok)) continue;
+        for (int vt = 0; vt <= (vt_ok ? 1 : 0); ++vt) {
+            const double e = vt ? tile_eff_vt(d->w_out, d->h_out, d->n, pxs[i], ths[i]) : tile_eff(d->w_out, d->h_out, pxs[i], ths[i]);
+            if (e > best + 1e-9) { best = e; w->px = pxs[i]; w->th = ths[i]; w->vt = vt; }
+        }
+    }
     w->tiles_x = ceil_div(d->w_out, w->px);
-    w->tiles_y = ceil_div(d->h_out, w->th);
-    w->ntiles = d->n * w->tiles_x * w->tiles_y;
+    if (w->vt) {
+        w->tiles_y = ceil_div(d->n * (d->h_out + 1), w->th);
+        w->ntiles = w->tiles_x * w->tiles_y;
+    } else {
+        w->tiles_y = ceil_div(d->h_out, w->th);
+        w->ntiles = d->n * w->tiles_x * w->tiles_y;
+    }
     w->nchunk1 = (w->kind == K7S2) ? 1 : ceil_div(d->c1, 32);
     w->nchunk2 = d->c2 > 0 ? ceil_div(d->c2, 32) : 0;
     w->ncog = ceil_div(d->c_out, 32);
@@ -1065,14 +1131,14 @@ extern "C" int rcf_conv2d_query(const rcf_conv_desc* d, rcf_conv_info* info) {
     info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * s.ck;
     info->n_partials = dispatch_fwd(s, [&](auto tag) { return fwd_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
     if (info->n_partials <= 0) return RCF_EUNSUPPORTED;
-    info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : 0);
+    info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0);
     info->wgrad_workspace_floats = 0;
     info->wgrad_kernel_id = 0;
     if (d->w_mode == RCF_W_FORWARD) {
         WSel w;
         if (select_wgrad(d, &w) == RCF_OK) {
             info->wgrad_workspace_floats = (size_t)w.nsplit * w.ktot * w.cop + 64;   // + a zero page for the DMA path
-            info->wgrad_kernel_id = 10000 + w.kind * 1000 + (w.px == 16 ? 100 : 0);
+            info->wgrad_kernel_id = 10000 + w.kind * 1000 + (w.px == 16 ? 100 : (w.px == 8 ? 200 : 0)) + (w.vt ? 400 : 0);
         }
     }
     return RCF_OK;
@@ -1128,6 +1194,7 @@ extern "C" int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const 
     a.os = d->out_stride; a.ooy = d->out_off_y; a.oox = d->out_off_x; a.ohp = d->out_h_phys; a.owp = d->out_w_phys;
     a.ioy = d->in_off_y; a.iox = d->in_off_x;
     a.phase_sum = 0; a.wp_phase_stride = 0;
+    a.vt = w.vt; a.hp = d->h_out + 1; a.nimg = d->n; a.inv_hp = 1.0f / (float)(d->h_out + 1);
     a.sy = (float)d->h_src1 / (float)d->h_in;
     a.sx = (float)d->w_src1 / (float)d->w_in;
     a.tiles_x = w.tiles_x; a.tiles_y = w.tiles_y; a.ntiles = w.ntiles;
@@ -1139,11 +1206,12 @@ extern "C" int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const 
     const int p16 = w.px == 16;
     float* zero = workspace + (size_t)w.nsplit * w.ktot * w.cop;
     a.zero = zero;
-    const bool dma = w.kind != K7S2 && (d->c1 % 4 == 0) && (d->c2 % 4 == 0) && getenv("RCF_WGRAD_NO_DMA") == nullptr;
+    const bool dma = w.kind != K7S2 && (d->c1 % 4 == 0) && (d->c2 % 4 == 0);
     if (dma && hipMemsetAsync(zero, 0, 64 * sizeof(float), st) != hipSuccess) return rcf_launch_status();
     switch (w.kind) {
         case K3S1:
-            if (dma) rc = p16 ? launch_wgrad_dma<W3S1_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad_dma<W3S1_32>(a, w.nsplit, nchunk, w.ncog, st);
+            if (dma && w.px == 8) rc = launch_wgrad_dma<W3S1_8>(a, w.nsplit, nchunk, w.ncog, st);
+            else if (dma) rc = p16 ? launch_wgrad_dma<W3S1_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad_dma<W3S1_32>(a, w.nsplit, nchunk, w.ncog, st);
             else rc = p16 ? launch_wgrad<W3S1_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad<W3S1_32>(a, w.nsplit, nchunk, w.ncog, st);
             break;
         case K3S2:

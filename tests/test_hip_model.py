@@ -58,10 +58,10 @@ def _check_gradients_against_fp64(hip_grads, g32, g64, tag):
     """
     FusionNet's fp32 gradients are chaotic (LeakyReLU-sign / max-pool-argmax flips move some parameter gradients by
     1e-2 between ANY two fp32 implementations, e.g. PyTorch CPU fp32 vs fp64), so the bar is relative: the HIP path
-    must be about as close to the fp64 truth as the fp32 CPU reference is.  The worst tensor must match the CPU's
-    worst; the median may be up to 10x the CPU's because the flip count scales with forward round-off, and an MFMA
-    fmaf chain over K = 9*Cin (sequential) rounds ~2x more than oneDNN's blocked sums (tools/diag_net.py shows the
-    first divergence is a single-pixel 1e-3 jump at the last decoder layer: one LeakyReLU sign flip).
+    must be about as close to the fp64 truth as the fp32 CPU reference is (median within 3x, worst tensor within 5x).
+    Reaching that needed fp64 accumulation of every BatchNorm sum (forward statistics per value, backward reductions):
+    BN backward relies on dz being exactly mean-free, and 1e-5 of jitter in mean/invstd turns into 1e-3 errors in the
+    next layer's nearly-cancelling sum of g (tools/diag_net.py, tools/diag_vt.py).
     """
     e_hip, e_cpu = [], []
     for k, ref in g64.items():
@@ -73,7 +73,7 @@ def _check_gradients_against_fp64(hip_grads, g32, g64, tag):
     e_hip, e_cpu = np.array(e_hip), np.array(e_cpu)
     print('%s gradients vs fp64: HIP median %.2e max %.2e | CPU-fp32 median %.2e max %.2e'
           % (tag, np.median(e_hip), e_hip.max(), np.median(e_cpu), e_cpu.max()))
-    assert np.median(e_hip) <= 10.0 * np.median(e_cpu) + 2e-5
+    assert np.median(e_hip) <= 3.0 * np.median(e_cpu) + 2e-5
     assert e_hip.max() <= 5.0 * e_cpu.max() + 2e-4
 
 
