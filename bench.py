@@ -38,7 +38,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=8, help='per-GPU batch (BASELINE.json configs[1]: 8)')
     ap.add_argument('--height', type=int, default=900)
     ap.add_argument('--width', type=int, default=1600)
@@ -126,8 +126,8 @@ def main():
     fam = {}
     for kid, (cnt, flops, ms) in table.items():
         f = (10 + (kid - 10000) // 1000) if kid >= 10000 else kid // 1000
-        r = fam.setdefault(f, [0, 0.0, 0.0])
-        r[0] += cnt; r[1] += flops; r[2] += ms
+        r = fam.setdefault(f, [0, 0.0, 0.0, 0.0])
+        r[0] += cnt; r[1] += flops; r[2] += ms; r[3] += getattr(timer, 'bytes', {}).get(kid, 0.0)
     dom = max(fam, key=lambda f: fam[f][2]) if fam else None
 
     if rank == 0:
@@ -151,14 +151,24 @@ def main():
                        'step': 'forward + masked L1 + backward + Adam, train-mode BatchNorm', 'final_loss': round(final_loss, 5)},
         }
         if dom is not None:
-            cnt, flops, ms = fam[dom]
+            cnt, flops, ms, abytes = fam[dom]
             achieved = flops / (ms * 1e-3) / 1e12
+            traffic, traffic_src = None, None
+            pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_bench.json')
+            if os.path.exists(pmc_path):   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+                try:
+                    pmc = json.load(open(pmc_path)).get(KERNEL_NAMES.get(dom, ''), {})
+                    traffic = round(pmc['hbm_bytes_per_launch'] / 1e9, 4)
+                    traffic_src = 'profiles/r01_pmc_bench.json (GB per launch, FETCH_SIZE x2 + WRITE_SIZE)'
+                except Exception:
+                    traffic = None
             conv_ms = sum(r[2] for r in fam.values())
             conv_flops = sum(r[1] for r in fam.values())
             rec['roofline'] = {
                 'bound': 'mfma', 'kernel': KERNEL_NAMES.get(dom, str(dom)),
                 'achieved': round(achieved, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                'frac': round(achieved / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+                'algorithmic_gbytes_per_launch': round(abytes / cnt / 1e9, 4),
                 'launches_per_step': cnt // args.steps, 'avg_launch_ms': round(ms / cnt, 4),
                 'algorithmic_gflop_per_launch': round(flops / cnt / 1e9, 3),
                 'share_of_step_time': round(ms / (1000.0 * dt), 4),

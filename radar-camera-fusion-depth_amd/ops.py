@@ -123,6 +123,19 @@ def algorithmic_flops(desc):
     return 2.0 * desc.n * desc.h_out * desc.w_out * desc.c_out * k2 * (desc.c1 + desc.c2)
 
 
+def algorithmic_bytes(desc):
+    """HBM bytes a conv launch must move at minimum: every input element read once, every output written once
+    (read-modify-write when it accumulates); weights are negligible."""
+    n = desc.n
+    if desc.gather1 == RCF_GATHER_STRIDED2 and not desc.phase_sum:
+        in1 = desc.h_in * desc.w_in * desc.c1            # one phase of the source
+    else:
+        in1 = desc.h_src1 * desc.w_src1 * desc.c1
+    in2 = desc.h_in * desc.w_in * desc.c2
+    out = desc.h_out * desc.w_out * desc.c_out
+    return 4.0 * n * (in1 + in2 + out * (2 if desc.accumulate else 1))
+
+
 class KernelTimer(object):
     """Brackets kernel launches with events on the stream they are launched on (torch's current stream is the
     stream handed to the C ABI) and accumulates (launches, algorithmic flops, ms) per kernel id."""
@@ -139,7 +152,9 @@ class KernelTimer(object):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         tag = None
+        self.bytes = getattr(self, 'bytes', {})
         if desc is not None:
+            self.bytes[kid] = self.bytes.get(kid, 0.0) + (algorithmic_bytes(desc) if kid < 10000 else 0.0)
             tag = '%s k%d s%d %d+%d->%d @%dx%d g%d' % ('dgrad' if desc.w_mode == RCF_W_DGRAD else ('wgrad' if kid >= 10000 else 'fwd'),
                                                       desc.ksize, desc.stride, desc.c1, desc.c2, desc.c_out, desc.h_out, desc.w_out,
                                                       desc.gather1)

@@ -91,6 +91,21 @@ def fill_state_dict_(modules, seed):
                 t.copy_(torch.from_numpy(v.astype(np.float32)))
 
 
+def make_scatter_case(k, h, w, wc, seed, small_z):
+    '''
+    Seeded inputs for the radar point -> grid scatter (src/radarnet_main.py:563-589): K sparse sigmoid response crops
+    (H x wc) and K points (x in padded-canvas coordinates, y, z).  small_z draws z from [0.2, K+3) so that int(z) collides
+    with point indices and the reference's in-place replacement chain changes the answer.
+    '''
+    rs = np.random.RandomState(seed)
+    pad = wc // 2
+    crops = rs.rand(k, h, wc).astype(np.float32)
+    crops *= (rs.rand(k, h, wc) < 0.35)
+    pts = np.stack([rs.uniform(pad, w + pad, k), rs.uniform(0, h, k),
+                    rs.uniform(0.2, (k + 3) if small_z else 80.0, k)], -1).astype(np.float32)
+    return crops, pts
+
+
 PUBLISHED = dict(
     input_channels_image=3, input_channels_depth=2,
     n_filters_encoder_image=[32, 64, 128, 256, 256, 256],

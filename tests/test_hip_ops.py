@@ -455,3 +455,24 @@ def test_stride2_input_gradient_as_four_phase_convs(ops, cin, cout, n, h, w):
             ops.conv_fwd(dd, nhwc(dz), None, packed, dx, None)
         torch.cuda.synchronize()
         assert rel(nchw(dx), x.grad + base) < TOL, accumulate
+
+
+def test_radar_scatter_matches_reference_golden_and_oracle(ops, golden_dir):
+    '''Bit-exact (integer/index work): golden vectors from the real radarnet_main.forward, then larger seeded cases vs the oracle.'''
+    import os
+    from rcf_amd import synth
+    from oracle.radar_scatter_oracle import radar_scatter
+    g = np.load(os.path.join(golden_dir, 'T4_radar_scatter.npz'))
+    for ci in range(int(g['n_cases'])):
+        k, h, w, wc, seed, small_z = [int(v) for v in g['meta%d' % ci]]
+        crops, pts = synth.make_scatter_case(k, h, w, wc, seed, bool(small_z))
+        depth, resp = ops.radar_scatter(torch.from_numpy(crops).cuda(), torch.from_numpy(pts).cuda(), w, True)
+        torch.cuda.synchronize()
+        assert np.array_equal(depth.cpu().numpy(), g['depth%d' % ci]), ci
+        assert np.array_equal(resp.cpu().numpy(), g['resp%d' % ci]), ci
+    for (k, h, w, wc, seed, small_z) in ((64, 225, 400, 72, 11, True), (96, 90, 1600, 288, 12, False), (1, 7, 9, 4, 13, True)):
+        crops, pts = synth.make_scatter_case(k, h, w, wc, seed, small_z)
+        for strict in (True, False):
+            depth, resp = ops.radar_scatter(torch.from_numpy(crops).cuda(), torch.from_numpy(pts).cuda(), w, strict)
+            od, orr = radar_scatter(crops, pts, w, strict_reference=strict)
+            assert np.array_equal(depth.cpu().numpy(), od) and np.array_equal(resp.cpu().numpy(), orr), (k, h, w, strict)

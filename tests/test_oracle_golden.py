@@ -122,3 +122,13 @@ def test_outlier_removal_matches_definition():
             if float(vals.min()) < v - 1.5:
                 ref[0, 0, y, x] = 0.0
     assert torch.equal(clean, ref)
+
+
+def test_t4_radar_scatter_oracle_matches_reference_golden(golden_dir):
+    from oracle.radar_scatter_oracle import radar_scatter
+    g = np.load(os.path.join(golden_dir, 'T4_radar_scatter.npz'))
+    for ci in range(int(g['n_cases'])):
+        k, h, w, wc, seed, small_z = [int(v) for v in g['meta%d' % ci]]
+        crops, pts = synth.make_scatter_case(k, h, w, wc, seed, bool(small_z))
+        depth, resp = radar_scatter(crops, pts, w, strict_reference=True)
+        assert np.array_equal(depth, g['depth%d' % ci]) and np.array_equal(resp, g['resp%d' % ci])
