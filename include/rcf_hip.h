@@ -192,6 +192,13 @@ int rcf_l1_loss_value(const double* sums, float w_lidar, float* loss, void* stre
 int rcf_l1_loss_bwd(const float* depth, const float* gt, const float* lidar, const double* sums,
                     const float* upstream, float w_lidar, float* ddepth, long long n_pix, void* stream);
 
+/* OutlierRemoval.remove_outliers (src/net_utils.py:591-638; called on the ground truth every training step,
+ * src/fusionnet_main.py:377-378): a valid point (depth > 0) is zeroed when some valid point in its k x k window is more
+ * than `threshold` metres closer.  depth, out: [N][H][W] (single channel).  scratch: one float (device), used for the
+ * global maximum the reference fills invalid pixels with (10 * max(depth)); kernel_size odd, <= 15. */
+int rcf_outlier_removal(const float* depth, float* out, float* scratch, int n, int h, int w, int kernel_size,
+                        float threshold, void* stream);
+
 /* torch.optim.Adam step (src/fusionnet_main.py:307-312, :399) over one flat parameter arena.
  * step is the 1-based step count; weight_decay is the L2 form Adam uses (added to the gradient). */
 int rcf_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,

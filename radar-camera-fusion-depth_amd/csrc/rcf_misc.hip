@@ -328,6 +328,44 @@ __global__ void __launch_bounds__(256) l1_loss_bwd_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------- OutlierRemoval (7x7 min filter on sparse depth)
+__global__ void __launch_bounds__(256) max_reduce_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out_bits) {
+    float m = 0.f;   // depth maps are >= 0: max(depth) >= 0 and non-negative floats order like their bit patterns
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, x[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));
+}
+
+__global__ void __launch_bounds__(256) outlier_removal_kernel(const float* __restrict__ depth, float* __restrict__ out,
+                                                              const float* __restrict__ gmax, int h, int w, int k, float threshold) {
+    extern __shared__ float tile[];   // (8 + k - 1) x (32 + k - 1) max-filled depth
+    const int r = k / 2;
+    const int tw = 32 + 2 * r, th = 8 + 2 * r;
+    const float max_value = 10.f * gmax[0];
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 8;
+    const float* img = depth + (size_t)blockIdx.z * h * w;
+    for (int i = threadIdx.x; i < tw * th; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        const int y = y0 + ty - r, x = x0 + tx - r;
+        float v = max_value;                                   // constant padding with max_value (:617-621)
+        if (y >= 0 && y < h && x >= 0 && x < w) {
+            const float d = img[(size_t)y * w + x];
+            v = d > 0.f ? d : (d <= 0.f ? max_value : d);      // validity_map <= 0 -> max_value (:603-613)
+        }
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= w || y >= h) return;
+    float mn = tile[ly * tw + lx];
+    for (int dy = 0; dy < k; ++dy)
+        for (int dx = 0; dx < k; ++dx) mn = fminf(mn, tile[(ly + dy) * tw + lx + dx]);
+    const float d = img[(size_t)y * w + x];
+    out[(size_t)blockIdx.z * h * w + (size_t)y * w + x] = (mn < d - threshold) ? d * 0.f : d;   // depth * validity_map_clean
+}
+
 // ---------------------------------------------------------------- Adam over one flat arena
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
@@ -532,6 +570,24 @@ extern "C" int rcf_l1_loss_bwd(const float* depth, const float* gt, const float*
     unsigned b = nblk(n_pix, 256); if (b > 8192) b = 8192;
     hipLaunchKernelGGL(l1_loss_bwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, depth, gt, lidar, sums, upstream, w_lidar,
                        ddepth, n_pix);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_outlier_removal(const float* depth, float* out, float* scratch, int n, int h, int w, int kernel_size,
+                                   float threshold, void* stream) {
+    if (!depth || !out || !scratch || n <= 0 || h <= 0 || w <= 0) return RCF_EINVAL;
+    if (kernel_size < 1 || kernel_size > 15 || (kernel_size & 1) == 0) return RCF_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(scratch, 0, sizeof(float), st) != hipSuccess) return rcf_launch_status();
+    const long long total = (long long)n * h * w;
+    unsigned b = nblk(total, 256); if (b > 2048) b = 2048;
+    hipLaunchKernelGGL(max_reduce_kernel, dim3(b), dim3(256), 0, st, depth, total, reinterpret_cast<unsigned*>(scratch));
+    int rc = rcf_launch_status();
+    if (rc != RCF_OK) return rc;
+    const int r = kernel_size / 2;
+    const size_t lds = (size_t)(32 + 2 * r) * (8 + 2 * r) * sizeof(float);
+    hipLaunchKernelGGL(outlier_removal_kernel, dim3((w + 31) / 32, (h + 7) / 8, n), dim3(256), lds, st, depth, out, scratch, h, w,
+                       kernel_size, threshold);
     return rcf_launch_status();
 }
 

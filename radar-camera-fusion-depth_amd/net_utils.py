@@ -108,3 +108,19 @@ class DecoderBlock(_NoForward):
             raise ValueError('Unsupported deconv type on the HIP path: {}'.format(deconv_type))
         self.conv = Conv2d(skip_channels + out_channels, out_channels, 3, 1, weight_initializer, activation_func,
                            use_batch_norm)
+
+
+class OutlierRemoval(object):
+    '''
+    Class to perform outlier removal based on depth difference in local neighborhood (src/net_utils.py:575-638); same
+    constructor and method as the reference, computed by rcf_outlier_removal (one global-max pass + one LDS-tiled
+    min-filter pass; no host synchronisation).
+    '''
+
+    def __init__(self, kernel_size=7, threshold=1.5):
+        self.kernel_size = kernel_size
+        self.threshold = threshold
+
+    def remove_outliers(self, depth):
+        from . import ops
+        return ops.outlier_removal(depth, self.kernel_size, self.threshold)

@@ -316,6 +316,18 @@ def l1_loss_bwd(depth, gt, lidar, sums, upstream, w_lidar, ddepth):
                                       depth.numel(), _stream()), 'rcf_l1_loss_bwd')
 
 
+def outlier_removal(depth, kernel_size=7, threshold=1.5):
+    """OutlierRemoval.remove_outliers (src/net_utils.py:591-638) on an N x 1 x H x W (or N x H x W) sparse depth map."""
+    shape = depth.shape
+    n, h, w = shape[0], shape[-2], shape[-1]
+    d = depth.contiguous()
+    out = torch.empty_like(d)
+    scratch = torch.empty(1, dtype=torch.float32, device=d.device)
+    check(_lib.load().rcf_outlier_removal(_f32(d), _f32(out), _f32(scratch), n, h, w, kernel_size, threshold, _stream()),
+          'rcf_outlier_removal')
+    return out
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     check(_lib.load().rcf_adam_step(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), lr, beta1, beta2, eps, weight_decay,
                                     step, _stream()), 'rcf_adam_step')

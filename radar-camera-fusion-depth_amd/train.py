@@ -34,8 +34,11 @@ def make_optimizer(model, lr=1e-3, weight_decay=0.0):
     return FusedAdam([{'params': model.parameters(), 'weight_decay': weight_decay}], lr=lr)
 
 
-def train_step(model, optimizer, image, input_depth, ground_truth, lidar_map, w_lidar_loss=2.0):
+def train_step(model, optimizer, image, input_depth, ground_truth, lidar_map, w_lidar_loss=2.0, outlier_removal=None):
+    '''outlier_removal: a net_utils.OutlierRemoval applied to the ground truth first (src/fusionnet_main.py:377-378).'''
     output_depth = model.forward(image=image, input_depth=input_depth)
+    if outlier_removal is not None:
+        ground_truth = outlier_removal.remove_outliers(ground_truth)
     loss, loss_info = model.compute_loss(
         image=image, output_depth=output_depth, ground_truth=ground_truth, lidar_map=lidar_map,
         loss_func='l1', w_smoothness=0.0, loss_smoothness_kernel_size=-1,

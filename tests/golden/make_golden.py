@@ -237,6 +237,17 @@ def main():
     t3['published_meta'] = np.array([1, 224, 384, 32, 301, 21])
     np.savez_compressed(os.path.join(gold, 'T3_eval.npz'), **t3)
 
+    # ---------------- OutlierRemoval: oracle restatement == the reference class (src/net_utils.py:575-638) ----------------
+    import net_utils as ref_net_utils
+    from oracle.fusionnet_oracle import remove_outliers
+    for seed, (hh, ww), ks, thr in ((1, (37, 53), 7, 1.5), (2, (64, 96), 7, 1.5), (3, (20, 31), 5, 0.5)):
+        gt = synth.make_batch(2, hh, ww, 4, seed=seed)['ground_truth']
+        a = ref_net_utils.OutlierRemoval(ks, thr).remove_outliers(gt)
+        b = remove_outliers(gt, ks, thr)
+        assert torch.equal(a, b), 'OutlierRemoval oracle differs from the reference'
+        assert int((a != gt).sum()) > 0, 'test input must contain outliers'
+    print('[OutlierRemoval] oracle == reference (bit-exact, 3 cases)')
+
     n_par = sum(p.numel() for _, p in named_params(ref))
     n_used = sum(p.numel() for k, p in named_params(ref) if k in keys)
     print('published net: %d parameters, %d receive gradients, %d unused tensors'

@@ -476,3 +476,17 @@ def test_radar_scatter_matches_reference_golden_and_oracle(ops, golden_dir):
             depth, resp = ops.radar_scatter(torch.from_numpy(crops).cuda(), torch.from_numpy(pts).cuda(), w, strict)
             od, orr = radar_scatter(crops, pts, w, strict_reference=strict)
             assert np.array_equal(depth.cpu().numpy(), od) and np.array_equal(resp.cpu().numpy(), orr), (k, h, w, strict)
+
+
+@pytest.mark.parametrize('n,h,w,ks,thr', [(2, 37, 53, 7, 1.5), (1, 900 // 4, 1600 // 4, 7, 1.5), (3, 20, 31, 5, 0.5), (1, 9, 70, 3, 2.0)])
+def test_outlier_removal_bit_exact(ops, n, h, w, ks, thr):
+    '''Comparisons and copies only: bit-exact against the oracle (itself pinned to the reference class by make_golden.py).'''
+    from rcf_amd import synth
+    from rcf_amd.net_utils import OutlierRemoval
+    from oracle.fusionnet_oracle import remove_outliers
+    gt = synth.make_batch(n, h, w, 4, seed=5)['ground_truth']
+    want = remove_outliers(gt, ks, thr)
+    got = OutlierRemoval(ks, thr).remove_outliers(gt.cuda())
+    torch.cuda.synchronize()
+    assert got.shape == gt.shape and torch.equal(got.cpu(), want)
+    assert int((want != gt).sum()) > 0
