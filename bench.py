@@ -83,7 +83,8 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path is HIP-only')
-    dev = torch.device('cuda', local_rank if world > 1 else 0)
+    # RCF_BENCH_SINGLE_DEVICE=1 (tests on a 1-GPU box, gloo backend): every rank shares cuda:0
+    dev = torch.device('cuda', local_rank if (world > 1 and not os.environ.get('RCF_BENCH_SINGLE_DEVICE')) else 0)
     torch.cuda.set_device(dev)
 
     torch.manual_seed(1234)                       # identical initial weights on every rank

@@ -83,9 +83,9 @@ def init_from_env(backend=None):
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('RCF_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank)   # one process per GPU; RCCL over xGMI
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -273,3 +273,75 @@ def test_full_resolution_900x1600_against_oracle(env):
     assert e_out < BAR and _rel(out, o64) < BAR
     assert abs(float(loss) - l32) < BAR * abs(l32)
     _check_gradients_against_fp64({k: p.grad for k, p in _named(m, 'p')}, g32, g64, '900x1600')
+
+
+def _dp_gpu_worker(rank, world, port, tmpdir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)   # gloo moves CUDA tensors; both ranks share cuda:0
+    import rcf_amd  # noqa: F401
+    from rcf_amd import synth, train
+    torch.manual_seed(7)
+    m = train.build_model(synth.TINY, device='cuda')
+    synth.fill_state_dict_([m.encoder, m.decoder], 31)
+    m.data_parallel()
+    assert m._dp is not None
+    opt = train.make_optimizer(m, lr=1e-3)
+    b = {k: v.cuda() for k, v in synth.make_batch(2, 64, 96, 6, seed=500 + rank).items()}
+    m.train()
+    out = m.forward(b['image'], b['input_depth'])
+    loss, info = m.compute_loss(b['image'], out, b['ground_truth'], b['lidar_map'], 'l1', 0.0, -1, None, 2.0)
+    opt.zero_grad(); loss.backward()
+    g = m._grad_arena[:m._n_used].clone()
+    opt.step()
+    torch.cuda.synchronize()
+    torch.save({'loss': float(loss), 'grad': g.cpu(), 'param': m._param_arena.detach().cpu().clone()}, os.path.join(tmpdir, 'dp%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_two_ranks_on_one_gpu(env, tmp_path):
+    '''
+    The DP training step end to end (bucketed SUM all-reduce launched from the tape, loss normalised by the GLOBAL valid
+    counts) with 2 ranks sharing cuda:0 over gloo, against a single-process emulation of what nn.DataParallel computes:
+    per-replica BatchNorm statistics, ONE masked mean over the gathered batch (src/fusionnet_main.py:385), summed gradients.
+    '''
+    import torch.multiprocessing as mp
+    synth, train = env
+    port = 29700 + (os.getpid() % 1000)
+    mp.spawn(_dp_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), 'dp%d.pt' % k)) for k in range(2)]
+    assert r[0]['loss'] == r[1]['loss']                                  # the global masked mean, identical on both ranks
+    assert torch.equal(r[0]['grad'], r[1]['grad']) and torch.equal(r[0]['param'], r[1]['param'])
+
+    # emulation: each replica forward with its own BN statistics, loss = global masked mean, gradients summed
+    from rcf_amd import ops
+    m = _build(env, synth.TINY, 31)
+    m.train()
+    batches = [_gpu_batch(synth.make_batch(2, 64, 96, 6, seed=500 + k)) for k in range(2)]
+    sums = []
+    for b in batches:
+        with torch.no_grad():
+            out = m.forward(b['image'], b['input_depth'])
+        s = torch.empty(4, dtype=torch.float64, device='cuda')
+        ops.l1_loss_fwd(out.contiguous(), b['ground_truth'], b['lidar_map'], s)
+        sums.append(s)
+    # undo the running-stat updates of the two probing forwards: rebuild and replay with gradients
+    m = _build(env, synth.TINY, 31)
+    m.train()
+    tot = sums[0] + sums[1]
+    want_loss = float(tot[0] / tot[1] + 2.0 * tot[2] / tot[3])
+    grad = torch.zeros(m._n_used, device='cuda')
+    for b in batches:
+        out = m.forward(b['image'], b['input_depth'])
+        dd = torch.empty_like(out)
+        ops.l1_loss_bwd(out.detach().contiguous(), b['ground_truth'], b['lidar_map'], tot, None, 2.0, dd)
+        for p in m.parameters():
+            p.grad = None
+        out.backward(dd)
+        grad += m._grad_arena[:m._n_used]
+    assert abs(r[0]['loss'] - want_loss) < 1e-5 * abs(want_loss)
+    assert _rel(r[0]['grad'], grad) < 1e-4
