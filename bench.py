@@ -28,8 +28,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
+SPLIT_PRODUCTS = 6              # bf16 partial products executed per fp32 multiply-add in the split kernels
 KERNEL_NAMES = {
     0: 'conv_fwd_kernel 3x3 s1', 1: 'conv_fwd_kernel 3x3 s2', 2: 'conv_fwd_kernel 1x1', 3: 'conv_fwd_kernel 7x7 s2 stem',
+    5: 'conv_split_kernel 3x3 s1 (fp32 via bf16x3 split)', 9: 'conv_split_kernel 2x2 phases (fp32 via bf16x3 split)',
     10: 'conv_wgrad_kernel 3x3 s1', 11: 'conv_wgrad_kernel 3x3 s2', 12: 'conv_wgrad_kernel 1x1', 13: 'conv_wgrad_kernel 7x7 s2 stem',
 }
 
@@ -156,7 +159,11 @@ def main():
         }
         if dom is not None:
             cnt, flops, ms, abytes = fam[dom]
-            achieved = flops / (ms * 1e-3) / 1e12
+            algorithmic = flops / (ms * 1e-3) / 1e12
+            is_split = dom in (5, 9, 15, 19)
+            # split kernels are bound by the bf16 matrix pipe: price them on the bf16 FLOPs they execute (6 per fp32 MAC)
+            achieved = algorithmic * (SPLIT_PRODUCTS if is_split else 1)
+            peak = BF16_MFMA_PEAK_TFLOPS if is_split else F32_MFMA_PEAK_TFLOPS
             traffic, traffic_src = None, None
             pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_bench.json')
             if os.path.exists(pmc_path):   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
@@ -170,8 +177,9 @@ def main():
             conv_flops = sum(r[1] for r in fam.values())
             rec['roofline'] = {
                 'bound': 'mfma', 'kernel': KERNEL_NAMES.get(dom, str(dom)),
-                'achieved': round(achieved, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+                'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': round(achieved / peak, 4), 'algorithmic_fp32_tflops': round(algorithmic, 2),
+                'pipe': 'bf16 MFMA, 6 exact partial products per fp32 multiply, fp32 accumulate' if is_split else 'f32 MFMA', 'traffic': traffic, 'traffic_source': traffic_src,
                 'algorithmic_gbytes_per_launch': round(abytes / cnt / 1e9, 4),
                 'launches_per_step': cnt // args.steps, 'avg_launch_ms': round(ms / cnt, 4),
                 'algorithmic_gflop_per_launch': round(flops / cnt / 1e9, 3),

@@ -355,6 +355,339 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// fp32 convolution on the bf16 matrix pipe ("split" kernel, 3x3 stride 1, forward and input gradient).
+// Every fp32 operand x is split EXACTLY into three bf16 planes by truncation (x = p0 + p1 + p2: 3 x 8 significant bits =
+// fp32's 24), and a*b is accumulated as the six partial products with i + j <= 2 on v_mfma_f32_32x32x16_bf16 (fp32
+// accumulate).  The dropped terms are <= 2^-24 |ab|, below the accumulator's own rounding: measured error equals the exact
+// f32 MFMA's (tools/probe/split_bf16_probe.hip: 1.0e-7 * sum|ab| at K = 2304 for both, 9 products == 6 products bitwise).
+// 6 MFMAs x 32 cycles per 16-deep step against 8 x 64 cycles on the f32 MFMA: 2.7x the matrix rate.
+//  * 8 waves (2 per SIMD), tile PX x TH (32x16 or 16x32) x BN; LDS holds the three planes of the halo tile
+//    ([plane][pixel][16 bf16 + 8 pad]: conflict-free 16-B reads) and of the weight panel ([plane][tap][BN][16 bf16],
+//    halves XOR-swizzled by (co >> 3) & 1), 143 KB for BN = 64.
+//  * activations are split while staged (and/sub, ~5.5 VALU per element); weights are pre-split by the pack kernel.
+//  * persistent + register-prefetched like conv_fwd_kernel; same epilogue (store, +=, fp64 BN statistics).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int KS_, int NT_, int PX_>
+struct SplitCfg {
+    static constexpr int KSY = KS_, KSX = KS_, T = KS_ * KS_, LSTEP = 1, CK = 16, CST = 16;
+    static constexpr int NT = NT_, BN = 32 * NT_;
+    static constexpr int PX = PX_, PY = 32 / PX_, MT = 2, NW = 8, TH = PY * MT * NW;
+    static constexpr int HXP = PX + KS_ - 1, HYP = TH + KS_ - 1, NPIX = HXP * HYP;
+    static constexpr int APS = 24;                         // bf16 per halo pixel in LDS (16 + 8 pad) = 48 B
+    static constexpr int A_PLANE_BYTES = NPIX * APS * 2;
+    static constexpr int A_BYTES = ((3 * A_PLANE_BYTES + 15) / 16) * 16;
+    static constexpr int B_PLANE_BYTES = T * BN * 32;      // 16 bf16 per row
+    static constexpr int B_BYTES = 3 * B_PLANE_BYTES;
+    static constexpr int LDS_BYTES = A_BYTES + B_BYTES;
+    static constexpr int WCHUNK_BYTES = B_BYTES;           // one chunk of pre-split packed weights
+};
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <class C>
+__global__ void __launch_bounds__(512, 2) conv_split_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* As = smem_b;
+    unsigned char* Bs = smem_b + C::A_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+
+    int abase[C::MT];   // byte offset of this lane's 16-B operand slice inside one A plane (tap offset added later)
+#pragma unroll
+    for (int mi = 0; mi < C::MT; ++mi) {
+        const int tr = (wave * C::MT + mi) * C::PY + li / C::PX;
+        const int tc = li % C::PX;
+        abase[mi] = (tr * C::HXP + tc) * (C::APS * 2) + lh * 16;
+    }
+    const int bbase = li * 32 + ((lh ^ ((li >> 3) & 1)) * 16);   // row co = ni*32 + li; (ni*32) keeps (co>>3)&1 == (li>>3)&1
+
+    f32x16 acc[C::MT][C::NT];
+    const int nchunk = a.nchunk1 + a.nchunk2;
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.wp) + (size_t)blockIdx.y * nchunk * C::WCHUNK_BYTES;
+    const int n0 = blockIdx.y * C::BN;
+
+    // A staging: thread t owns channel quad t % 4 of halo pixels t / 4 + i * 128
+    constexpr int NA = (C::NPIX + 127) / 128;
+    constexpr int NVB = C::WCHUNK_BYTES / 16;
+    constexpr int NB = (NVB + 511) / 512;
+    int pix[NA];
+    f32x4 ra[NA];
+    u32x4 rb[NB];
+
+    auto setup = [&](int tile, bool first, int ph) {
+        int t = tile;
+        const int tx = t % a.tiles_x;
+        t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        const int img = t / a.tiles_y;
+        const int pa = a.phase_sum ? (ph >> 1) : a.pad, pb = a.phase_sum ? (ph & 1) : a.pad_x;
+        const int ioy = a.phase_sum ? (ph >> 1) : a.ioy, iox = a.phase_sum ? (ph & 1) : a.iox;
+        const int iy0 = ty * C::TH - pa;
+        const int ix0 = tx * C::PX - pb;
+        const int hs = first ? a.h1 : a.h_in, ws = first ? a.w1 : a.w_in;
+        const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int p = (tid >> 2) + i * 128;
+            const int hy = p / C::HXP;
+            const int hx = p - hy * C::HXP;
+            const int ly = iy0 + hy, lx = ix0 + hx;
+            int v = -1;
+            if (p < C::NPIX && ly >= 0 && lx >= 0 && lx < a.w_in) {
+                if (a.vt) {
+                    const int im = (int)(((float)ly + 0.5f) * a.inv_hp);
+                    const int y = ly - im * a.hp;
+                    if (im < a.nimg && y < a.h_in) v = (im * hs + y) * ws + lx;
+                } else if (ly < a.h_in) {
+                    int py = ly, px = lx;
+                    bool ok = true;
+                    if (gmode == RCF_GATHER_NEAREST) {
+                        py = min((int)floorf((float)ly * a.sy), hs - 1);
+                        px = min((int)floorf((float)lx * a.sx), ws - 1);
+                    } else if (gmode == RCF_GATHER_STRIDED2) {
+                        py = 2 * ly + ioy;
+                        px = 2 * lx + iox;
+                        ok = py < hs && px < ws;
+                    } else if (gmode == RCF_GATHER_ZERO_INSERT) {
+                        ok = ((ly | lx) & 1) == 0;
+                        py = ly >> 1;
+                        px = lx >> 1;
+                        ok = ok && py < hs && px < ws;
+                    }
+                    if (ok) v = (img * hs + py) * ws + px;
+                }
+            }
+            pix[i] = v;
+        }
+    };
+    const int nitem = a.phase_sum ? 4 * nchunk : nchunk;
+    auto load_item = [&](int tile, int item) {
+        const int ph = a.phase_sum ? item / nchunk : 0;
+        const int q = a.phase_sum ? item - ph * nchunk : item;
+        const bool first = q < a.nchunk1;
+        if (q == 0 || q == a.nchunk1) setup(tile, first, ph);
+        const float* src = first ? a.in1 : a.in2;
+        const int csrc = first ? a.c1 : a.c2;
+        const int cch = (first ? q : q - a.nchunk1) * 16 + (tid & 3) * 4;
+        const bool cok = cch < csrc;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (cok && pix[i] >= 0) v = *reinterpret_cast<const f32x4*>(src + (size_t)pix[i] * csrc + cch);
+            ra[i] = v;
+        }
+        const u32x4* wsrc = reinterpret_cast<const u32x4*>(wp + (size_t)ph * a.wp_phase_stride * 4 + (size_t)q * C::WCHUNK_BYTES);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + i * 512;
+            if (NVB % 512 == 0 || idx < NVB) rb[i] = wsrc[idx];
+        }
+    };
+    auto store_item = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int p = (tid >> 2) + i * 128;
+            if (p < C::NPIX) {
+                // exact 3-way truncation split: plane k keeps the next 8 significant bits
+                unsigned x0[4], x1[4], x2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = ra[i][e];
+                    x0[e] = __float_as_uint(x) & 0xffff0000u;
+                    const float r1 = x - __uint_as_float(x0[e]);
+                    x1[e] = __float_as_uint(r1) & 0xffff0000u;
+                    const float r2 = r1 - __uint_as_float(x1[e]);
+                    x2[e] = __float_as_uint(r2);
+                }
+                unsigned char* dst = As + p * (C::APS * 2) + (tid & 3) * 8;
+                u32x2 w0 = {(x0[0] >> 16) | x0[1], (x0[2] >> 16) | x0[3]};
+                u32x2 w1 = {(x1[0] >> 16) | x1[1], (x1[2] >> 16) | x1[3]};
+                u32x2 w2 = {(x2[0] >> 16) | (x2[1] & 0xffff0000u), (x2[2] >> 16) | (x2[3] & 0xffff0000u)};
+                *reinterpret_cast<u32x2*>(dst) = w0;
+                *reinterpret_cast<u32x2*>(dst + C::A_PLANE_BYTES) = w1;
+                *reinterpret_cast<u32x2*>(dst + 2 * C::A_PLANE_BYTES) = w2;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + i * 512;
+            if (NVB % 512 == 0 || idx < NVB) *reinterpret_cast<u32x4*>(Bs + (size_t)idx * 16) = rb[i];
+        }
+    };
+
+    double st1[C::NT], st2[C::NT];
+#pragma unroll
+    for (int ni = 0; ni < C::NT; ++ni) { st1[ni] = 0.0; st2[ni] = 0.0; }
+
+    int tile = blockIdx.x;
+    int q = 0;
+    if (tile < a.ntiles) load_item(tile, 0);
+    while (tile < a.ntiles) {
+        __syncthreads();
+        store_item();
+        __syncthreads();
+        int ntile = tile, nq = q + 1;
+        if (nq == nitem) { nq = 0; ntile = tile + gridDim.x; }
+        if (ntile < a.ntiles) load_item(ntile, nq);
+
+        if (q == 0) {
+#pragma unroll
+            for (int mi = 0; mi < C::MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        }
+#pragma unroll
+        for (int tap = 0; tap < C::T; ++tap) {
+            const int toff = ((tap / C::KSX) * C::HXP + (tap % C::KSX)) * (C::APS * 2);
+            bf16x8 av[3][C::MT], bv[3][C::NT];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int mi = 0; mi < C::MT; ++mi)
+                    av[pl][mi] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + pl * C::A_PLANE_BYTES + abase[mi] + toff));
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni)
+                    bv[pl][ni] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + pl * C::B_PLANE_BYTES + (tap * C::BN + ni * 32) * 32 + bbase));
+            }
+            // six partial products, smallest first: (2,0) (1,1) (0,2) (1,0) (0,1) (0,0)
+#pragma unroll
+            for (int mi = 0; mi < C::MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni) {
+                    f32x16 c = acc[mi][ni];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2][mi], bv[0][ni], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][mi], bv[1][ni], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][mi], bv[2][ni], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][mi], bv[0][ni], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][mi], bv[1][ni], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][mi], bv[0][ni], c, 0, 0, 0);
+                    acc[mi][ni] = c;
+                }
+        }
+
+        if (q == nitem - 1) {
+            int t = tile;
+            const int tx = t % a.tiles_x;
+            t /= a.tiles_x;
+            const int ty = t % a.tiles_y;
+            const int img = t / a.tiles_y;
+            const int oy0 = ty * C::TH;
+            const int ox0 = tx * C::PX;
+            const bool want_stats = a.stats != nullptr;
+#pragma unroll
+            for (int mi = 0; mi < C::MT; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rcf_mfma_row(r, lh);
+                    int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
+                    const int ox = ox0 + row % C::PX;
+                    int im = img;
+                    if (a.vt) {
+                        im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                        oy -= im * a.hp;
+                        if (im >= a.nimg) oy = a.h_out;
+                    }
+                    const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+                    const bool pix_ok = oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
+                    const size_t pbase = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
+#pragma unroll
+                    for (int ni = 0; ni < C::NT; ++ni) {
+                        const int co = n0 + ni * 32 + li;
+                        if (pix_ok && co < a.c_out) {
+                            float v = acc[mi][ni][r];
+                            if (a.accumulate) v += a.out[pbase + co];
+                            a.out[pbase + co] = v;
+                            if (want_stats) {
+                                const double dv = (double)v;
+                                st1[ni] += dv;
+                                st2[ni] += dv * dv;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        tile = ntile;
+        q = nq;
+    }
+
+    if (a.stats != nullptr) {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem_b);   // [8 waves][BN][2]
+#pragma unroll
+        for (int ni = 0; ni < C::NT; ++ni) {
+            const double t1 = st1[ni] + __shfl_xor(st1[ni], 32);
+            const double t2 = st2[ni] + __shfl_xor(st2[ni], 32);
+            if (lh == 0) {
+                red[(wave * C::BN + ni * 32 + li) * 2 + 0] = t1;
+                red[(wave * C::BN + ni * 32 + li) * 2 + 1] = t2;
+            }
+        }
+        __syncthreads();
+        if (tid < C::BN) {
+            const int co = n0 + tid;
+            if (co < a.c_out) {
+                double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < C::NW; ++w) {
+                    t1 += red[(w * C::BN + tid) * 2 + 0];
+                    t2 += red[(w * C::BN + tid) * 2 + 1];
+                }
+                a.stats[((size_t)blockIdx.x * 2 + 0) * a.c_out + co] = t1;
+                a.stats[((size_t)blockIdx.x * 2 + 1) * a.c_out + co] = t2;
+            }
+        }
+    }
+}
+
+// OIHW fp32 -> pre-split bf16 planes [n-tile][chunk][plane][tap][BN][16], halves swapped when (co >> 3) & 1.
+__global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, size_t total_rows16, int w_o,
+                                          int w_i, int mode, int i_off, int c_out, int c1, int c2, int nchunk1, int nchunk, int BN,
+                                          int ks) {
+    // one thread per (n-tile, chunk, tap, co, k) element; writes its three planes
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_rows16) return;
+    size_t t = idx;
+    const int k = t % 16; t /= 16;
+    const int T = ks * ks;
+    const int j = t % BN; t /= BN;
+    const int tap = t % T; t /= T;
+    const int q = t % nchunk;
+    const int nt = t / nchunk;
+    const int co = nt * BN + j;
+    const int ky = tap / ks, kx = tap % ks;
+    int cin = -1;
+    if (q < nchunk1) { const int c = q * 16 + k; if (c < c1) cin = c; }
+    else { const int c = (q - nchunk1) * 16 + k; if (c < c2) cin = c1 + c; }
+    float v = 0.f;
+    if (cin >= 0 && co < c_out) {
+        if (mode == RCF_W_FORWARD) v = w[(((size_t)co * w_i + cin) * ks + ky) * ks + kx];
+        else v = w[(((size_t)cin * w_i + (i_off + co)) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
+    }
+    const unsigned x0 = __float_as_uint(v) & 0xffff0000u;
+    const float r1 = v - __uint_as_float(x0);
+    const unsigned x1 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(x1);
+    const unsigned x2 = __float_as_uint(r2);
+    const size_t chunk_elems = (size_t)3 * T * BN * 16;
+    const size_t plane_elems = (size_t)T * BN * 16;
+    const int kk = ((k >> 3) ^ ((j >> 3) & 1)) * 8 + (k & 7);   // XOR-swizzle the 16-B halves: conflict-free ds_read_b128
+    const size_t base = ((size_t)nt * nchunk + q) * chunk_elems + ((size_t)tap * BN + j) * 16 + kk;
+    dst[base] = (unsigned short)(x0 >> 16);
+    dst[base + plane_elems] = (unsigned short)(x1 >> 16);
+    dst[base + 2 * plane_elems] = (unsigned short)(x2 >> 16);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Weight gradient.  GEMM view: dW[k][co] = sum_pixels A[pixel][k] * dZ[pixel][co]; MFMA rows i = 32
 // consecutive k of one tap (32 input channels of one halo pixel, contiguous in the LDS halo tile),
@@ -790,6 +1123,7 @@ struct Sel {
     int kind, ck, nt, px;
     int th, bn, t, cst;
     int vt;   // virtual tall image tiling
+    int split;   // fp32 on the bf16 matrix pipe (conv_split_kernel)
 };
 
 int num_cus() {
@@ -827,6 +1161,30 @@ int launch_fwd(const ConvArgs& a, int ntile_n, hipStream_t st) {
     const int gx = fwd_grid_x<C>(a.ntiles, ntile_n);
     dim3 grid(gx, ntile_n, 1);
     hipLaunchKernelGGL((conv_fwd_kernel<C>), grid, dim3(256), C::LDS_BYTES, st, a);
+    return rcf_launch_status();
+}
+
+template <class C>
+int split_grid_x(int ntiles, int ntile_n) {
+    static int resident = 0;
+    if (resident == 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C::LDS_BYTES);
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_split_kernel<C>, 512, C::LDS_BYTES) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        resident = per_cu * num_cus();
+    }
+    int gx = resident / ntile_n;
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    return gx;
+}
+
+template <class C>
+int launch_split(const ConvArgs& a, int ntile_n, hipStream_t st) {
+    const int gx = split_grid_x<C>(a.ntiles, ntile_n);
+    hipLaunchKernelGGL((conv_split_kernel<C>), dim3(gx, ntile_n, 1), dim3(512), C::LDS_BYTES, st, a);
     return rcf_launch_status();
 }
 
@@ -888,6 +1246,14 @@ using F2_32_2_32 = FwdCfg<2, 2, 0, 1, 32, 32, 36, 2, 32, 2>;
 using F2_32_1_16 = FwdCfg<2, 2, 0, 1, 32, 32, 36, 1, 16, 2>;
 using F2_32_2_16 = FwdCfg<2, 2, 0, 1, 32, 32, 36, 2, 16, 2>;
 using F7_32 = FwdCfg<7, 1, 7, 2, 32, 4, 4, 1, 32, 2>;
+using S3_1_32 = SplitCfg<3, 1, 32>;
+using S3_2_32 = SplitCfg<3, 2, 32>;
+using S3_1_16 = SplitCfg<3, 1, 16>;
+using S3_2_16 = SplitCfg<3, 2, 16>;
+using S2_1_32 = SplitCfg<2, 1, 32>;
+using S2_2_32 = SplitCfg<2, 2, 32>;
+using S2_1_16 = SplitCfg<2, 1, 16>;
+using S2_2_16 = SplitCfg<2, 2, 16>;
 using F7_16 = FwdCfg<7, 1, 7, 2, 32, 4, 4, 1, 16, 2>;
 
 //               KSY KSX XE LS CST STRP PX TH MINW
@@ -916,6 +1282,13 @@ double tile_eff(int w, int h, int px, int th) {
 // utilisation when the n images are stacked with one separator row each (rows n*(h+1))
 double tile_eff_vt(int w, int h, int n, int px, int th) {
     return ((double)w / (ceil_div(w, px) * px)) * ((double)n * h / (ceil_div(n * (h + 1), th) * th));
+}
+
+// The split-bf16 kernels (fp32 arithmetic on the bf16 matrix pipe) are the default wherever they exist;
+// RCF_CONV_SPLIT=0 selects the exact-f32-MFMA kernels instead (both are parity-tested).
+bool split_enabled() {
+    const char* e = getenv("RCF_CONV_SPLIT");
+    return e == nullptr || e[0] != '0';
 }
 
 // stride-1 3x3 conv with pad 1 on directly addressed sources: the separator row is the conv's own zero padding
@@ -981,18 +1354,25 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     // tile shape: 32x8 or 16x16 output pixels (8x32 too for the stride-1 3x3 kernels with >= 16 channels), whichever
     // wastes least at the image edges; stride-1 3x3 convs may also tile the batch as one tall virtual image
     s->vt = 0;
+    s->split = 0;
+    if (((s->kind == K3S1 && s->ck == 16) || (s->kind == K2S1 && cmax >= 16)) && (d->c1 % 4 == 0) && (d->c2 % 4 == 0) &&
+        split_enabled()) {
+        s->split = 1;
+        s->ck = 16;
+        s->cst = 16;
+    }
     double best = -1.0;
     const bool vt_ok = vt_allowed(d);
     const int pxs[3] = {32, 16, 8};
     for (int i = 0; i < 3; ++i) {
-        const int px = pxs[i], th = 256 / px;
-        if (px == 8 && !(s->kind == K3S1 && s->ck == 16)) continue;
+        const int px = pxs[i], th = (s->split ? 512 : 256) / px;
+        if (px == 8 && (s->split || !(s->kind == K3S1 && s->ck == 16))) continue;
         for (int vt = 0; vt <= (vt_ok ? 1 : 0); ++vt) {
             const double e = vt ? tile_eff_vt(d->w_out, d->h_out, d->n, px, th) : tile_eff(d->w_out, d->h_out, px, th);
             if (e > best + 1e-9) { best = e; s->px = px; s->vt = vt; }
         }
     }
-    s->th = 256 / s->px;
+    s->th = (s->split ? 512 : 256) / s->px;
     s->bn = 32 * s->nt;
     return RCF_OK;
 }
@@ -1050,6 +1430,16 @@ int dispatch_fwd(const Sel& s, F&& f) {
             return p16 ? f(Tag<F2_32_2_16>{}) : f(Tag<F2_32_2_32>{});
     }
     return RCF_EUNSUPPORTED;
+}
+
+template <class F>
+int dispatch_split(const Sel& s, F&& f) {
+    if (s.kind == K2S1) {
+        if (s.nt == 1) return s.px == 16 ? f(Tag<S2_1_16>{}) : f(Tag<S2_1_32>{});
+        return s.px == 16 ? f(Tag<S2_2_16>{}) : f(Tag<S2_2_32>{});
+    }
+    if (s.nt == 1) return s.px == 16 ? f(Tag<S3_1_16>{}) : f(Tag<S3_1_32>{});
+    return s.px == 16 ? f(Tag<S3_2_16>{}) : f(Tag<S3_2_32>{});
 }
 
 // wgrad tiling for the forward descriptor
@@ -1129,9 +1519,11 @@ extern "C" int rcf_conv2d_query(const rcf_conv_desc* d, rcf_conv_info* info) {
     fill_args(d, s, &a);
     const int ntile_n = ceil_div(d->c_out, s.bn);
     info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * s.ck;
-    info->n_partials = dispatch_fwd(s, [&](auto tag) { return fwd_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
+    if (s.split) info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * 24;   // three bf16 planes
+    info->n_partials = s.split ? dispatch_split(s, [&](auto tag) { return split_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); })
+                               : dispatch_fwd(s, [&](auto tag) { return fwd_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
     if (info->n_partials <= 0) return RCF_EUNSUPPORTED;
-    info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0);
+    info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0);
     info->wgrad_workspace_floats = 0;
     info->wgrad_kernel_id = 0;
     if (d->w_mode == RCF_W_FORWARD) {
@@ -1154,6 +1546,13 @@ extern "C" int rcf_conv2d_pack_weights(const rcf_conv_desc* d, const float* w_oi
     const int ntile_n = ceil_div(d->c_out, s.bn);
     const int nchunk = a.nchunk1 + a.nchunk2;
     const size_t total = (size_t)ntile_n * nchunk * s.t * s.bn * s.ck;
+    if (s.split) {
+        const size_t rows16 = (size_t)ntile_n * nchunk * s.t * s.bn * 16;
+        hipLaunchKernelGGL(pack_weights_split_kernel, dim3((unsigned)((rows16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                           reinterpret_cast<unsigned short*>(packed), rows16, d->w_o, d->w_i, d->w_mode, d->w_i_off, d->c_out, d->c1,
+                           d->c2, a.nchunk1, nchunk, s.bn, d->ksize);
+        return rcf_launch_status();
+    }
     const int ksx = s.kind == K7S2 ? 1 : d->ksize;
     const unsigned blocks = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, total, d->w_o,
@@ -1174,7 +1573,8 @@ extern "C" int rcf_conv2d_fwd(const rcf_conv_desc* d, const float* in1, const fl
     a.in1 = in1; a.in2 = in2; a.wp = packed; a.out = out; a.stats = stat_partials; a.dz = nullptr; a.ws = nullptr;
     a.ktot = 0; a.cop = 0;
     const int nn = ceil_div(d->c_out, s.bn);
-    a.wp_phase_stride = (int)((size_t)nn * (a.nchunk1 + a.nchunk2) * s.t * s.bn * s.ck);
+    a.wp_phase_stride = (int)((size_t)nn * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.split ? 24 : s.ck));
+    if (s.split) return dispatch_split(s, [&](auto tag) { return launch_split<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
     return dispatch_fwd(s, [&](auto tag) { return launch_fwd<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
 }
 

@@ -490,3 +490,48 @@ def test_outlier_removal_bit_exact(ops, n, h, w, ks, thr):
     torch.cuda.synchronize()
     assert got.shape == gt.shape and torch.equal(got.cpu(), want)
     assert int((want != gt).sum()) > 0
+
+
+SPLIT_CASES = [c for c in CONV_CASES if c[0] == 3 and c[1] == 1 and c[8] is None and max(c[2], c[3]) > 8]
+
+
+@pytest.mark.parametrize('case', SPLIT_CASES, ids=[str(c) for c in SPLIT_CASES])
+def test_split_bf16_conv_is_fp32_accurate(ops, case, monkeypatch):
+    '''
+    The default 3x3 stride-1 forward / input-gradient convolution runs on the bf16 matrix pipe (exact 3-way operand split,
+    6 partial products, fp32 accumulate); RCF_CONV_SPLIT=0 selects the exact-f32-MFMA kernel.  The split kernel must be as
+    close to an fp64 reference as the f32-MFMA kernel is.
+    '''
+    k, s, c1, c2, co, n, h, w, up = case
+    x1, x2, wt = _conv_case(case, 10)
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    ref64 = F.conv2d(xin.double(), wt.double(), padding=1)
+    dz = rnd(*ref64.shape, seed=33)
+    errs = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('RCF_CONV_SPLIT', mode)
+        d = _desc(ops, case)
+        info = ops.conv_query(d)
+        assert (info.kernel_id >= 5000) == (mode == '1')
+        packed = torch.empty(info.packed_weight_floats, device='cuda')
+        ops.conv_pack(d, dev(wt), packed)
+        out = torch.full((d.n, d.h_out, d.w_out, d.c_out), float('nan'), device='cuda')
+        partials = torch.full((info.n_partials, 2, d.c_out), float('nan'), device='cuda', dtype=torch.float64)
+        ops.conv_fwd(d, nhwc(x1), None if x2 is None else nhwc(x2), packed, out, partials)
+        torch.cuda.synchronize()
+        errs['fwd' + mode] = float((nchw(out).double() - ref64).abs().max() / ref64.abs().max())
+        s2 = partials.sum(0).cpu()
+        assert rel(s2[1], (ref64 ** 2).sum((0, 2, 3))) < 1e-5
+        # input gradient of source 1 through the same kernel
+        dd = ops.make_dgrad_desc(d, 0, c1, False)
+        di = ops.conv_query(dd)
+        pd = torch.empty(di.packed_weight_floats, device='cuda')
+        ops.conv_pack(dd, dev(wt), pd)
+        dx = torch.full((n, h, w, c1), float('nan'), device='cuda')
+        ops.conv_fwd(dd, nhwc(dz), None, pd, dx, None)
+        torch.cuda.synchronize()
+        want = torch.nn.grad.conv2d_input(xin.shape, wt.double(), dz.double(), padding=1)[:, :c1]
+        errs['dx' + mode] = float((nchw(dx).double() - want).abs().max() / want.abs().max())
+    print('split vs f32-mfma error against fp64:', {k_: '%.2e' % v for k_, v in errs.items()})
+    assert errs['fwd1'] < 2.0 * errs['fwd0'] + 1e-7 and errs['dx1'] < 2.0 * errs['dx0'] + 1e-7
+    assert errs['fwd1'] < 1e-5 and errs['dx1'] < 1e-5
