@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librcf_hip.so')
+LIB_PATH = os.environ.get('RCF_HIP_LIB') or os.path.join(_HERE, 'librcf_hip.so')   # RCF_HIP_LIB: an explicitly chosen build of the same library
 
 RCF_GATHER_DIRECT, RCF_GATHER_NEAREST, RCF_GATHER_ZERO_INSERT, RCF_GATHER_STRIDED2 = 0, 1, 2, 3
 RCF_PHASE_UP2X_FWD, RCF_PHASE_UP2X_DGRAD, RCF_PHASE_S2_DGRAD = 0, 1, 2

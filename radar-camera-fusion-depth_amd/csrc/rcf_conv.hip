@@ -20,6 +20,7 @@
 //    sum of squares BatchNorm needs (in-lane adds -> one cross-half shuffle -> LDS across the 4 waves ->
 //    one partial row per workgroup; no atomics, deterministic).
 #include "rcf_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -78,6 +79,7 @@ struct Halo {
     static constexpr int PPI = 256 / C4;                       // halo pixels covered per iteration
     static constexpr int NA = (HXP * HYP + PPI - 1) / PPI;
     int pix[NA];                                               // element index of the pixel in the source, / csrc; -1: zero
+    unsigned okm;                                              // bit i: the load of pix[i] is real data (NA <= 32)
 
     // vt != 0: rows are VIRTUAL rows of the batch stacked vertically with one zero row after each image (hp = h + 1);
     // that separator is exactly the zero padding of a stride-1 3x3 conv, so tiles may straddle images.
@@ -122,15 +124,19 @@ struct Halo {
         }
     }
 
-    __device__ __forceinline__ void load(f32x4 (&r)[NA], const float* __restrict__ src, int csrc, int cb, int tid) const {
+    // Loads are branch-free: a clamped (always valid) address, and the value is replaced by zero only when it is written to
+    // LDS -- a branch or a select right behind each load makes the compiler wait for it before issuing the next.
+    __device__ __forceinline__ void load(f32x4 (&r)[NA], const float* __restrict__ src, int csrc, int cb, int tid) {
         const int c = cb + (tid % C4) * 4;
         const bool cok = c < csrc;
+        okm = 0xffffffffu;
         if ((csrc & 3) == 0) {
+            const int cld = cok ? c : 0;
+            okm = 0u;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (cok && pix[i] >= 0) v = *reinterpret_cast<const f32x4*>(src + (size_t)pix[i] * csrc + c);
-                r[i] = v;
+                if (cok && pix[i] >= 0) okm |= 1u << i;
+                r[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(pix[i] < 0 ? 0 : pix[i]) * csrc + cld);
             }
         } else {   // stems (3 / 2 input channels): scalar loads
 #pragma unroll
@@ -154,7 +160,8 @@ struct Halo {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int p = p0 + i * PPI;
-            if (p < HXP * HYP) *reinterpret_cast<f32x4*>(As + p * STRP + c4 * 4) = r[i];
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (p < HXP * HYP) *reinterpret_cast<f32x4*>(As + p * STRP + c4 * 4) = ((okm >> i) & 1u) ? r[i] : z;
         }
     }
 };
@@ -292,33 +299,54 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
             for (int mi = 0; mi < C::MT; ++mi) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rcf_mfma_row(r, lh);
-                    int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
-                    const int ox = ox0 + row % C::PX;
-                    int im = img;
-                    if (a.vt) {   // virtual row -> (image, row); separator rows produce no output
-                        im = (int)(((float)oy + 0.5f) * a.inv_hp);
-                        oy -= im * a.hp;
-                        if (im >= a.nimg) oy = a.h_out;
-                    }
-                    const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
-                    const bool pix_ok = oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
-                    const size_t pbase = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
+                for (int r0 = 0; r0 < 16; r0 += 4) {
+                    size_t pbase[4];
+                    bool pok[4];
 #pragma unroll
-                    for (int ni = 0; ni < C::NT; ++ni) {
-                        const int co = n0 + ni * 32 + li;
-                        if (pix_ok && co < a.c_out) {
-                            float v = acc[mi][ni][r];
-                            if (a.accumulate) v += a.out[pbase + co];
-                            a.out[pbase + co] = v;
-                            if (want_stats) {   // fp64 per value: E[x^2]-mean^2 must not depend on how tiles group the sum
-                                const double dv = (double)v;
-                                st1[ni] += dv;
-                                st2[ni] += dv * dv;
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = rcf_mfma_row(r0 + j, lh);
+                        int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
+                        const int ox = ox0 + row % C::PX;
+                        int im = img;
+                        if (a.vt) {   // virtual row -> (image, row); separator rows produce no output
+                            im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                            oy -= im * a.hp;
+                            if (im >= a.nimg) oy = a.h_out;
+                        }
+                        const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+                        pok[j] = oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
+                        pbase[j] = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
+                    }
+                    float old[4][C::NT];
+                    if (a.accumulate) {   // all old values of the group in flight together (clamped address, used only where valid)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int ni = 0; ni < C::NT; ++ni) {
+                                const int co = n0 + ni * 32 + li;
+                                old[j][ni] = a.out[(pok[j] && co < a.c_out) ? pbase[j] + co : 0];
+                            }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int ni = 0; ni < C::NT; ++ni) old[j][ni] = 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int ni = 0; ni < C::NT; ++ni) {
+                            const int co = n0 + ni * 32 + li;
+                            if (pok[j] && co < a.c_out) {
+                                const float v = acc[mi][ni][r0 + j] + old[j][ni];
+                                a.out[pbase[j] + co] = v;
+                                if (want_stats) {   // fp64 per value: E[x^2]-mean^2 must not depend on how tiles group the sum
+                                    const double dv = (double)v;
+                                    st1[ni] += dv;
+                                    st2[ni] += dv * dv;
+                                }
                             }
                         }
-                    }
                 }
             }
         }
@@ -372,25 +400,32 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// Work decomposition: a 256-thread workgroup owns a 32x8 / 16x16 output tile x BN output channels; two workgroups are resident per
+// CU (<= 80 KB LDS, <= 256 VGPRs each), so one converts/stages while the other feeds the matrix pipe.  Per 16-channel chunk the
+// fp32 halo tile is loaded once (registers), split, and written to LDS as three bf16 planes [pixel][16 ch] whose 16-B halves are
+// XOR-swizzled by bit 3 of the pixel index (conflict-free ds_read_b128 without padding).  The pre-split packed weights arrive one
+// KERNEL ROW (KSX taps) at a time into a double-buffered LDS piece, so only the A tile needs the two-barrier hand-over.
 template <int KS_, int NT_, int PX_>
 struct SplitCfg {
     static constexpr int KSY = KS_, KSX = KS_, T = KS_ * KS_, LSTEP = 1, CK = 16, CST = 16;
     static constexpr int NT = NT_, BN = 32 * NT_;
-    static constexpr int PX = PX_, PY = 32 / PX_, MT = 2, NW = 8, TH = PY * MT * NW;
+    static constexpr int PX = PX_, PY = 32 / PX_, MT = 2, NW = 4, TH = PY * MT * NW;
     static constexpr int HXP = PX + KS_ - 1, HYP = TH + KS_ - 1, NPIX = HXP * HYP;
-    static constexpr int APS = 24;                         // bf16 per halo pixel in LDS (16 + 8 pad) = 48 B
-    static constexpr int A_PLANE_BYTES = NPIX * APS * 2;
-    static constexpr int A_BYTES = ((3 * A_PLANE_BYTES + 15) / 16) * 16;
-    static constexpr int B_PLANE_BYTES = T * BN * 32;      // 16 bf16 per row
-    static constexpr int B_BYTES = 3 * B_PLANE_BYTES;
-    static constexpr int LDS_BYTES = A_BYTES + B_BYTES;
-    static constexpr int WCHUNK_BYTES = B_BYTES;           // one chunk of pre-split packed weights
+    static constexpr int A_PLANE_BYTES = NPIX * 32;        // 16 bf16 per halo pixel
+    static constexpr int A_BYTES = 3 * A_PLANE_BYTES;
+    static constexpr int B_PLANE_BYTES = KSX * BN * 32;    // one kernel row: 16 bf16 per (tap, co)
+    static constexpr int B_PIECE_BYTES = 3 * B_PLANE_BYTES;
+    static constexpr int LDS_BYTES = A_BYTES + 2 * B_PIECE_BYTES;
+    static constexpr int WCHUNK_BYTES = KSY * B_PIECE_BYTES;   // one chunk of pre-split packed weights
 };
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+// s_waitcnt vmcnt(0) (expcnt/lgkmcnt untouched): LDS-DMA completion is tracked by vmcnt only, and the compiler does not know
+// that a later ds_read depends on it -- the wait before the publishing barrier has to be explicit.
+__device__ __forceinline__ void rcf_wait_dma() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 template <class C>
-__global__ void __launch_bounds__(512, 2) conv_split_kernel(ConvArgs a) {
+__global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char* As = smem_b;
     unsigned char* Bs = smem_b + C::A_BYTES;
@@ -400,12 +435,12 @@ __global__ void __launch_bounds__(512, 2) conv_split_kernel(ConvArgs a) {
     const int li = lane & 31;
     const int lh = lane >> 5;
 
-    int abase[C::MT];   // byte offset of this lane's 16-B operand slice inside one A plane (tap offset added later)
+    int apix[C::MT];   // halo pixel of this lane's output pixel at tap (0, 0)
 #pragma unroll
     for (int mi = 0; mi < C::MT; ++mi) {
         const int tr = (wave * C::MT + mi) * C::PY + li / C::PX;
         const int tc = li % C::PX;
-        abase[mi] = (tr * C::HXP + tc) * (C::APS * 2) + lh * 16;
+        apix[mi] = tr * C::HXP + tc;
     }
     const int bbase = li * 32 + ((lh ^ ((li >> 3) & 1)) * 16);   // row co = ni*32 + li; (ni*32) keeps (co>>3)&1 == (li>>3)&1
 
@@ -414,13 +449,11 @@ __global__ void __launch_bounds__(512, 2) conv_split_kernel(ConvArgs a) {
     const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.wp) + (size_t)blockIdx.y * nchunk * C::WCHUNK_BYTES;
     const int n0 = blockIdx.y * C::BN;
 
-    // A staging: thread t owns channel quad t % 4 of halo pixels t / 4 + i * 128
-    constexpr int NA = (C::NPIX + 127) / 128;
-    constexpr int NVB = C::WCHUNK_BYTES / 16;
-    constexpr int NB = (NVB + 511) / 512;
+    // A staging: thread t owns channel quad t % 4 of halo pixels t / 4 + i * 64
+    constexpr int NA = (C::NPIX + 63) / 64;
     int pix[NA];
     f32x4 ra[NA];
-    u32x4 rb[NB];
+    unsigned okm = 0u;   // bit i: ra[i] holds real data (else the clamped load is replaced by zero at store time)
 
     auto setup = [&](int tile, bool first, int ph) {
         int t = tile;
@@ -436,7 +469,7 @@ __global__ void __launch_bounds__(512, 2) conv_split_kernel(ConvArgs a) {
         const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int p = (tid >> 2) + i * 128;
+            const int p = (tid >> 2) + i * 64;
             const int hy = p / C::HXP;
             const int hx = p - hy * C::HXP;
             const int ly = iy0 + hy, lx = ix0 + hx;
@@ -468,8 +501,10 @@ __global__ void __launch_bounds__(512, 2) conv_split_kernel(ConvArgs a) {
             pix[i] = v;
         }
     };
-    const int nitem = a.phase_sum ? 4 * nchunk : nchunk;
-    auto load_item = [&](int tile, int item) {
+    const int nitem = a.phase_sum ? 4 * nchunk : nchunk;   // A tiles per output tile
+    // fp32 halo tile of one item -> registers.  Loads are unconditional from a clamped (always valid) address and zero-selected at
+    // store time: a branch or a select behind each load makes the compiler wait for it before issuing the next.
+    auto load_a = [&](int tile, int item) {
         const int ph = a.phase_sum ? item / nchunk : 0;
         const int q = a.phase_sum ? item - ph * nchunk : item;
         const bool first = q < a.nchunk1;
@@ -478,36 +513,32 @@ __global__ void __launch_bounds__(512, 2) conv_split_kernel(ConvArgs a) {
         const int csrc = first ? a.c1 : a.c2;
         const int cch = (first ? q : q - a.nchunk1) * 16 + (tid & 3) * 4;
         const bool cok = cch < csrc;
+        const int cld = cok ? cch : 0;
+        okm = 0u;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (cok && pix[i] >= 0) v = *reinterpret_cast<const f32x4*>(src + (size_t)pix[i] * csrc + cch);
-            ra[i] = v;
-        }
-        const u32x4* wsrc = reinterpret_cast<const u32x4*>(wp + (size_t)ph * a.wp_phase_stride * 4 + (size_t)q * C::WCHUNK_BYTES);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int idx = tid + i * 512;
-            if (NVB % 512 == 0 || idx < NVB) rb[i] = wsrc[idx];
+            if (cok && pix[i] >= 0) okm |= 1u << i;
+            ra[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(pix[i] < 0 ? 0 : pix[i]) * csrc + cld);
         }
     };
-    auto store_item = [&]() {
+    auto store_a = [&]() {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int p = (tid >> 2) + i * 128;
+            const int p = (tid >> 2) + i * 64;
             if (p < C::NPIX) {
                 // exact 3-way truncation split: plane k keeps the next 8 significant bits
                 unsigned x0[4], x1[4], x2[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float x = ra[i][e];
+                    const float x = ((okm >> i) & 1u) ? ra[i][e] : 0.f;
                     x0[e] = __float_as_uint(x) & 0xffff0000u;
                     const float r1 = x - __uint_as_float(x0[e]);
                     x1[e] = __float_as_uint(r1) & 0xffff0000u;
                     const float r2 = r1 - __uint_as_float(x1[e]);
                     x2[e] = __float_as_uint(r2);
                 }
-                unsigned char* dst = As + p * (C::APS * 2) + (tid & 3) * 8;
+                const int cq = tid & 3;
+                unsigned char* dst = As + p * 32 + (((cq >> 1) ^ ((p >> 3) & 1)) * 16) + (cq & 1) * 8;
                 u32x2 w0 = {(x0[0] >> 16) | x0[1], (x0[2] >> 16) | x0[3]};
                 u32x2 w1 = {(x1[0] >> 16) | x1[1], (x1[2] >> 16) | x1[3]};
                 u32x2 w2 = {(x2[0] >> 16) | (x2[1] & 0xffff0000u), (x2[2] >> 16) | (x2[3] & 0xffff0000u)};
@@ -516,10 +547,25 @@ __global__ void __launch_bounds__(512, 2) conv_split_kernel(ConvArgs a) {
                 *reinterpret_cast<u32x2*>(dst + 2 * C::A_PLANE_BYTES) = w2;
             }
         }
+    };
+    // one kernel row of pre-split weights: straight copy global -> LDS piece `buf` by LDS-DMA (each wave instruction moves 1 KiB to a
+    // wave-uniform LDS base + 16 B x lane; no staging registers, no ds_write).  hipcc drains vmcnt before the next barrier.
+    auto chunk_base = [&](int item) -> const unsigned char* {
+        const int ph = a.phase_sum ? item / nchunk : 0;
+        const int q = a.phase_sum ? item - ph * nchunk : item;
+        return wp + (size_t)ph * a.wp_phase_stride * 4 + (size_t)q * C::WCHUNK_BYTES;
+    };
+    auto copy_b = [&](const unsigned char* cbase, int ky, int buf) {
+        constexpr int NKB = C::B_PIECE_BYTES / 1024;
+        static_assert(C::B_PIECE_BYTES % 1024 == 0, "weight piece must be whole KiB");
+        const int w = __builtin_amdgcn_readfirstlane(wave);
+        const unsigned char* wsrc = cbase + (size_t)ky * C::B_PIECE_BYTES + lane * 16;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int idx = tid + i * 512;
-            if (NVB % 512 == 0 || idx < NVB) *reinterpret_cast<u32x4*>(Bs + (size_t)idx * 16) = rb[i];
+        for (int i = 0; i < (NKB + 3) / 4; ++i) {
+            int kb = i * 4 + w;
+            if ((i + 1) * 4 > NKB) kb = kb < NKB ? kb : NKB - 1;   // ragged tail: a duplicate copy of the last KiB is harmless
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 1024),
+                                             (__attribute__((address_space(3))) void*)(Bs + buf * C::B_PIECE_BYTES + kb * 1024), 16, 0, 0);
         }
     };
 
@@ -527,17 +573,46 @@ __global__ void __launch_bounds__(512, 2) conv_split_kernel(ConvArgs a) {
 #pragma unroll
     for (int ni = 0; ni < C::NT; ++ni) { st1[ni] = 0.0; st2[ni] = 0.0; }
 
+    // Phases: one kernel row (KSX taps) per barrier interval.  During a row's MFMAs the next row's weight piece arrives by DMA in
+    // the other LDS slot and (one row before the chunk ends) the next A tile is loaded into registers; the A tile itself is handed
+    // over between two barriers at the end of the chunk.  The second resident workgroup of the CU fills the matrix pipe meanwhile.
     int tile = blockIdx.x;
     int q = 0;
-    if (tile < a.ntiles) load_item(tile, 0);
+    int pb = 0;   // LDS slot of the weight piece the current kernel row reads
+    bf16x8 av[2][3][C::MT], bv[2][3][C::NT];
+    auto fetch_a = [&](int ky, int kx, int slot) {
+#pragma unroll
+        for (int mi = 0; mi < C::MT; ++mi) {
+            int ap = apix[mi];
+            asm volatile("" : "+v"(ap));   // recompute the swizzled address per tap: hoisted, the 2 x T addresses cost 18 VGPRs
+            const int p = ap + ky * C::HXP + kx;
+            const int ao = p * 32 + ((lh ^ ((p >> 3) & 1)) * 16);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) av[slot][pl][mi] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + pl * C::A_PLANE_BYTES + ao));
+        }
+    };
+    auto fetch_b = [&](int kx, int slot, int bslot) {
+        const unsigned char* Bp = Bs + bslot * C::B_PIECE_BYTES;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int ni = 0; ni < C::NT; ++ni)
+                bv[slot][pl][ni] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bp + pl * C::B_PLANE_BYTES + (kx * C::BN + ni * 32) * 32 + bbase));
+    };
+    const unsigned char* cb_cur = wp;   // packed weights of the current chunk
+    if (tile < a.ntiles) {
+        load_a(tile, 0);
+        copy_b(cb_cur, 0, 0);
+        store_a();
+    }
+    rcf_wait_dma();
+    __syncthreads();
+    if (tile < a.ntiles) fetch_a(0, 0, 0);
     while (tile < a.ntiles) {
-        __syncthreads();
-        store_item();
-        __syncthreads();
         int ntile = tile, nq = q + 1;
         if (nq == nitem) { nq = 0; ntile = tile + gridDim.x; }
-        if (ntile < a.ntiles) load_item(ntile, nq);
-
+        const bool more = ntile < a.ntiles;
+        const unsigned char* cb_next = more ? chunk_base(nq) : wp;
         if (q == 0) {
 #pragma unroll
             for (int mi = 0; mi < C::MT; ++mi)
@@ -547,83 +622,139 @@ __global__ void __launch_bounds__(512, 2) conv_split_kernel(ConvArgs a) {
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
         }
 #pragma unroll
-        for (int tap = 0; tap < C::T; ++tap) {
-            const int toff = ((tap / C::KSX) * C::HXP + (tap % C::KSX)) * (C::APS * 2);
-            bf16x8 av[3][C::MT], bv[3][C::NT];
+        for (int ky = 0; ky < C::KSY; ++ky) {
+            const bool last_row = ky == C::KSY - 1;
+            // every row starts in register set 0: its A operands were fetched before the barrier that published its weights
+            fetch_b(0, 0, pb);
+            if (!last_row) copy_b(cb_cur, ky + 1, pb ^ 1);   // nobody reads that slot during this row
+            else if (more) copy_b(cb_next, 0, pb ^ 1);
+            if (ky == (C::KSY >= 2 ? C::KSY - 2 : 0) && more) load_a(ntile, nq);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int kx = 0; kx < C::KSX; ++kx) {
+                const int cur = kx & 1;
+                // The 6 x MT x NT MFMAs of this tap in product-major, accumulator-round-robin order (dependent MFMAs stay MT x NT
+                // apart), with the next tap's LDS reads issued ONE AT A TIME between them: issued as a block, the reads stall the
+                // wave's MFMA issue for as long as the LDS queue takes them, and the partner wave on the SIMD tends to be doing
+                // the same.  sched_barrier pins the hand-written order.
+                constexpr int MN = C::MT * C::NT, NMF = 6 * MN, NRD = 3 * (C::MT + C::NT);
+                const bool has_next = kx + 1 < C::KSX;
+                int nr = 0;
+                int ao_next[C::MT];
 #pragma unroll
-                for (int mi = 0; mi < C::MT; ++mi)
-                    av[pl][mi] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + pl * C::A_PLANE_BYTES + abase[mi] + toff));
+                for (int j = 0; j < NMF; ++j) {
+                    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
+                    const int pj = j / MN, mi = (j % MN) / C::NT, ni = j % C::NT;
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][PA[pj]][mi], bv[cur][PB[pj]][ni], acc[mi][ni], 0, 0, 0);
+                    if (has_next) {
 #pragma unroll
-                for (int ni = 0; ni < C::NT; ++ni)
-                    bv[pl][ni] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + pl * C::B_PLANE_BYTES + (tap * C::BN + ni * 32) * 32 + bbase));
-            }
-            // six partial products, smallest first: (2,0) (1,1) (0,2) (1,0) (0,1) (0,0)
-#pragma unroll
-            for (int mi = 0; mi < C::MT; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < C::NT; ++ni) {
-                    f32x16 c = acc[mi][ni];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2][mi], bv[0][ni], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][mi], bv[1][ni], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][mi], bv[2][ni], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][mi], bv[0][ni], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][mi], bv[1][ni], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][mi], bv[0][ni], c, 0, 0, 0);
-                    acc[mi][ni] = c;
-                }
-        }
-
-        if (q == nitem - 1) {
-            int t = tile;
-            const int tx = t % a.tiles_x;
-            t /= a.tiles_x;
-            const int ty = t % a.tiles_y;
-            const int img = t / a.tiles_y;
-            const int oy0 = ty * C::TH;
-            const int ox0 = tx * C::PX;
-            const bool want_stats = a.stats != nullptr;
-#pragma unroll
-            for (int mi = 0; mi < C::MT; ++mi) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rcf_mfma_row(r, lh);
-                    int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
-                    const int ox = ox0 + row % C::PX;
-                    int im = img;
-                    if (a.vt) {
-                        im = (int)(((float)oy + 0.5f) * a.inv_hp);
-                        oy -= im * a.hp;
-                        if (im >= a.nimg) oy = a.h_out;
-                    }
-                    const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
-                    const bool pix_ok = oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
-                    const size_t pbase = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
-#pragma unroll
-                    for (int ni = 0; ni < C::NT; ++ni) {
-                        const int co = n0 + ni * 32 + li;
-                        if (pix_ok && co < a.c_out) {
-                            float v = acc[mi][ni][r];
-                            if (a.accumulate) v += a.out[pbase + co];
-                            a.out[pbase + co] = v;
-                            if (want_stats) {
-                                const double dv = (double)v;
-                                st1[ni] += dv;
-                                st2[ni] += dv * dv;
+                        for (int rep = 0; rep < 2; ++rep) {
+                            if (nr < NRD && (nr + 1) * NMF <= (j + 1) * NRD) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (nr < 3 * C::MT) {
+                                    const int rmi = nr / 3, pl = nr % 3;
+                                    if (pl == 0) {
+                                        int ap = apix[rmi];
+                                        asm volatile("" : "+v"(ap));
+                                        const int p = ap + ky * C::HXP + kx + 1;
+                                        ao_next[rmi] = p * 32 + ((lh ^ ((p >> 3) & 1)) * 16);
+                                    }
+                                    av[cur ^ 1][pl][rmi] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + pl * C::A_PLANE_BYTES + ao_next[rmi]));
+                                } else {
+                                    const int rb = nr - 3 * C::MT, pl = rb / C::NT, rni = rb % C::NT;
+                                    bv[cur ^ 1][pl][rni] = as_bf16x8(*reinterpret_cast<const u32x4*>(
+                                        Bs + pb * C::B_PIECE_BYTES + pl * C::B_PLANE_BYTES + ((kx + 1) * C::BN + rni * 32) * 32 + bbase));
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                ++nr;
                             }
                         }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (last_row) {
+                if (q == nitem - 1) {
+                    int t = tile;
+                    const int tx = t % a.tiles_x;
+                    t /= a.tiles_x;
+                    const int ty = t % a.tiles_y;
+                    const int img = t / a.tiles_y;
+                    const int oy0 = ty * C::TH;
+                    const int ox0 = tx * C::PX;
+                    const bool want_stats = a.stats != nullptr;
+#pragma unroll
+                    for (int mi = 0; mi < C::MT; ++mi) {
+#pragma unroll
+                        for (int r0 = 0; r0 < 16; r0 += 4) {
+                            size_t pbase[4];
+                            bool pok[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int row = rcf_mfma_row(r0 + j, lh);
+                                int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
+                                const int ox = ox0 + row % C::PX;
+                                int im = img;
+                                if (a.vt) {   // virtual row -> (image, row); separator rows produce no output
+                                    im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                                    oy -= im * a.hp;
+                                    if (im >= a.nimg) oy = a.h_out;
+                                }
+                                const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+                                pok[j] = oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
+                                pbase[j] = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
+                            }
+                            float old[4][C::NT];
+                            if (a.accumulate) {   // all old values of the group in flight together (clamped address, used only where valid)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int ni = 0; ni < C::NT; ++ni) {
+                                        const int co = n0 + ni * 32 + li;
+                                        old[j][ni] = a.out[(pok[j] && co < a.c_out) ? pbase[j] + co : 0];
+                                    }
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int ni = 0; ni < C::NT; ++ni) old[j][ni] = 0.f;
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int ni = 0; ni < C::NT; ++ni) {
+                                    const int co = n0 + ni * 32 + li;
+                                    if (pok[j] && co < a.c_out) {
+                                        const float v = acc[mi][ni][r0 + j] + old[j][ni];
+                                        a.out[pbase[j] + co] = v;
+                                        if (want_stats) {   // fp64 per value: E[x^2]-mean^2 must not depend on how tiles group the sum
+                                            const double dv = (double)v;
+                                            st1[ni] += dv;
+                                            st2[ni] += dv * dv;
+                                        }
+                                    }
+                                }
+                        }
+                    }
+                }
+                __syncthreads();   // every wave is done reading the A tile
+                if (more) store_a();
+            } else {
+                fetch_a(ky + 1, 0, 0);   // next row's first A operands: the tile does not change inside a chunk
+            }
+            rcf_wait_dma();   // the next weight piece has landed
+            __syncthreads();
+            if (last_row && more) fetch_a(0, 0, 0);
+            pb ^= 1;
         }
         tile = ntile;
         q = nq;
+        cb_cur = cb_next;
     }
 
     if (a.stats != nullptr) {
         __syncthreads();
-        double* red = reinterpret_cast<double*>(smem_b);   // [8 waves][BN][2]
+        double* red = reinterpret_cast<double*>(smem_b);   // [4 waves][BN][2]
 #pragma unroll
         for (int ni = 0; ni < C::NT; ++ni) {
             const double t1 = st1[ni] + __shfl_xor(st1[ni], 32);
@@ -650,7 +781,7 @@ __global__ void __launch_bounds__(512, 2) conv_split_kernel(ConvArgs a) {
     }
 }
 
-// OIHW fp32 -> pre-split bf16 planes [n-tile][chunk][plane][tap][BN][16], halves swapped when (co >> 3) & 1.
+// OIHW fp32 -> pre-split bf16 planes [n-tile][chunk][kernel row][plane][kx][BN][16], halves swapped when (co >> 3) & 1.
 __global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, size_t total_rows16, int w_o,
                                           int w_i, int mode, int i_off, int c_out, int c1, int c2, int nchunk1, int nchunk, int BN,
                                           int ks) {
@@ -680,9 +811,10 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned 
     const float r2 = r1 - __uint_as_float(x1);
     const unsigned x2 = __float_as_uint(r2);
     const size_t chunk_elems = (size_t)3 * T * BN * 16;
-    const size_t plane_elems = (size_t)T * BN * 16;
+    const size_t plane_elems = (size_t)ks * BN * 16;
+    const size_t piece_elems = 3 * plane_elems;
     const int kk = ((k >> 3) ^ ((j >> 3) & 1)) * 8 + (k & 7);   // XOR-swizzle the 16-B halves: conflict-free ds_read_b128
-    const size_t base = ((size_t)nt * nchunk + q) * chunk_elems + ((size_t)tap * BN + j) * 16 + kk;
+    const size_t base = ((size_t)nt * nchunk + q) * chunk_elems + (size_t)ky * piece_elems + ((size_t)kx * BN + j) * 16 + kk;
     dst[base] = (unsigned short)(x0 >> 16);
     dst[base + plane_elems] = (unsigned short)(x1 >> 16);
     dst[base + 2 * plane_elems] = (unsigned short)(x2 >> 16);
@@ -918,7 +1050,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(ConvArgs a) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
-        __syncthreads();   // hipcc drains the DMA (vmcnt(0)) before this barrier
+        rcf_wait_dma();
+        __syncthreads();
 
         {
             constexpr int NIT = C::RS * (C::PX / 2);
@@ -1171,7 +1304,7 @@ int split_grid_x(int ntiles, int ntile_n) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   C::LDS_BYTES);
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_split_kernel<C>, 512, C::LDS_BYTES) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_split_kernel<C>, 256, C::LDS_BYTES) != hipSuccess || per_cu < 1)
             per_cu = 1;
         resident = per_cu * num_cus();
     }
@@ -1184,7 +1317,7 @@ int split_grid_x(int ntiles, int ntile_n) {
 template <class C>
 int launch_split(const ConvArgs& a, int ntile_n, hipStream_t st) {
     const int gx = split_grid_x<C>(a.ntiles, ntile_n);
-    hipLaunchKernelGGL((conv_split_kernel<C>), dim3(gx, ntile_n, 1), dim3(512), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_split_kernel<C>), dim3(gx, ntile_n, 1), dim3(256), C::LDS_BYTES, st, a);
     return rcf_launch_status();
 }
 
@@ -1365,14 +1498,14 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     const bool vt_ok = vt_allowed(d);
     const int pxs[3] = {32, 16, 8};
     for (int i = 0; i < 3; ++i) {
-        const int px = pxs[i], th = (s->split ? 512 : 256) / px;
+        const int px = pxs[i], th = 256 / px;
         if (px == 8 && (s->split || !(s->kind == K3S1 && s->ck == 16))) continue;
         for (int vt = 0; vt <= (vt_ok ? 1 : 0); ++vt) {
             const double e = vt ? tile_eff_vt(d->w_out, d->h_out, d->n, px, th) : tile_eff(d->w_out, d->h_out, px, th);
             if (e > best + 1e-9) { best = e; s->px = px; s->vt = vt; }
         }
     }
-    s->th = (s->split ? 512 : 256) / s->px;
+    s->th = 256 / s->px;
     s->bn = 32 * s->nt;
     return RCF_OK;
 }
