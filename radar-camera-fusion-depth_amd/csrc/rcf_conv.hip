@@ -1110,6 +1110,335 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient on the bf16 matrix pipe (3x3 stride 1; same exact 3-way split and six partial products as conv_split_kernel).
+// The reduction index of dW[ci][tap][co] = sum_pixels x[p + tap][ci] * dz[p][co] is the PIXEL, and v_mfma_f32_32x32x16_bf16 wants
+// 8 consecutive reduction elements per lane: both operands are therefore staged CHANNEL-MAJOR in LDS, [plane][channel][row][x]
+// bf16, so that 8 consecutive pixels of one channel are one ds_read_b128.  A tile is 16 x 8 output pixels; one MFMA step is one
+// tile row (lane half h takes pixels 8h..8h+7).  The kx = 1 operand is built from the aligned 16 B + the next 4 B with
+// v_alignbit; kx = 2 is the same five dwords offset by one register.
+// One workgroup per CU (4 waves, one per SIMD, up to 512 VGPRs): wave (wi, wj, wk) owns the 32 ci x 32 co x 9 tap accumulators
+// (144 VGPRs) of ci-block wi and co-block wj and reduces the tile rows wk, wk + KSPLIT, ...  The next step's 21 LDS reads and this
+// step's 36 v_alignbit are issued one at a time between the 54 MFMAs of a step (hand order, pinned with sched_barrier).
+// LDS rows are permuted (row = (ch % 4) * (N / 4) + ch / 4) so that the transposing ds_write_b128 of adjacent lanes (adjacent
+// channel quads) land on adjacent rows: with a row pitch of 16 B mod 128 B both the writes and the reads are conflict-free.
+template <int WCI_, int WCO_>
+struct WsCfg {
+    static constexpr int KS = 3, T = 9;
+    static constexpr int WCI = WCI_, WCO = WCO_, KSPLIT = 4 / (WCI_ * WCO_);
+    static constexpr int NCI = 32 * WCI_, NCO = 32 * WCO_;
+    static constexpr int PX = 16, TH = 8, HXP = PX + KS - 1, HYP = TH + KS - 1;
+    static constexpr int XROW = 48, DROW = 32;     // bytes per tile row of one channel: 24 px (18 used) / 16 px
+    static constexpr int SX = 528, SD = 272;       // bytes per channel and plane, == 16 (mod 128)
+    static constexpr int XPL = NCI * SX, DPL = NCO * SD;
+    static constexpr int X_BYTES = 3 * XPL, D_BYTES = 3 * DPL;
+    static constexpr int RED_BYTES = (KSPLIT > 1) ? WCI * WCO * T * 16 * 64 * 4 : 0;
+    static constexpr int LDS_BYTES = (X_BYTES + D_BYTES) > RED_BYTES ? (X_BYTES + D_BYTES) : RED_BYTES;
+    static constexpr int CQX = 8 * WCI, CQD = 8 * WCO;
+    static constexpr int NXU = HYP * 3 * CQX, NDU = TH * 2 * CQD;     // 8-pixel x 4-channel staging units
+    static constexpr int RX = (NXU + 255) / 256, RD = (NDU + 255) / 256;
+    static constexpr int NS = TH / KSPLIT;         // MFMA steps (tile rows) per wave and tile
+    static_assert(HYP * XROW <= SX && TH * DROW <= SD, "tile rows must fit the channel pitch");
+};
+
+template <class C>
+__global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* Xs = smem_b;
+    unsigned char* Ds = smem_b + C::X_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int wi = wave % C::WCI, wj = (wave / C::WCI) % C::WCO, wk = wave / (C::WCI * C::WCO);
+
+    const int Q = blockIdx.y;
+    const bool first = Q < a.nchunk1;
+    const float* src = first ? a.in1 : a.in2;
+    const int csrc = first ? a.c1 : a.c2;
+    const int cb = (first ? Q : Q - a.nchunk1) * C::NCI;   // first channel of this chunk inside its source
+    const int hs = first ? a.h1 : a.h_in;
+    const int ws = first ? a.w1 : a.w_in;
+    const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
+    const int co0 = blockIdx.z * C::NCO;
+
+    f32x16 acc[C::T];
+#pragma unroll
+    for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tap][r] = 0.f;
+
+    // ---- staging: fp32 [pixel][channel] in HBM -> registers (next tile, during this tile's MFMAs) -> bf16 planes in LDS
+    f32x4 rx[C::RX][8], rd[C::RD][8];
+    unsigned mx[C::RX], md[C::RD];   // bit j: pixel j of the unit is real data (loads are branch-free from a clamped address)
+    auto load_tile = [&](int tile) {
+        int t = tile;
+        const int tx = t % a.tiles_x;
+        t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        const int img = t / a.tiles_y;
+        const int oy0 = ty * C::TH, ox0 = tx * C::PX;
+        const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad_x;
+#pragma unroll
+        for (int i = 0; i < C::RX; ++i) {
+            const int u = tid + 256 * i;
+            const int cq = u % C::CQX, g = (u / C::CQX) % 3, hy = u / (3 * C::CQX);
+            const int ch = cb + cq * 4;
+            const bool cok = u < C::NXU && ch < csrc;
+            const int ly = iy0 + hy;
+            bool rowok;
+            int rowbase;
+            if (a.vt) {
+                const int im = (int)(((float)ly + 0.5f) * a.inv_hp);
+                const int y = ly - im * a.hp;
+                rowok = ly >= 0 && im < a.nimg && y < a.h_in;
+                rowbase = (im * hs + y) * ws;
+            } else {
+                rowok = ly >= 0 && ly < a.h_in;
+                const int py = gmode == RCF_GATHER_NEAREST ? min((int)floorf((float)ly * a.sy), hs - 1) : ly;
+                rowbase = (img * hs + py) * ws;
+            }
+            const float* base = src + (cok ? ch : 0);
+            unsigned m = 0u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int hx = 8 * g + j;
+                const int lx = ix0 + hx;
+                const bool ok = cok && rowok && hx < C::HXP && lx >= 0 && lx < a.w_in;
+                const int px = gmode == RCF_GATHER_NEAREST ? min((int)floorf((float)lx * a.sx), ws - 1) : lx;
+                if (ok) m |= 1u << j;
+                rx[i][j] = *reinterpret_cast<const f32x4*>(base + (size_t)(ok ? rowbase + px : 0) * csrc);
+            }
+            mx[i] = m;
+        }
+#pragma unroll
+        for (int i = 0; i < C::RD; ++i) {
+            const int u = tid + 256 * i;
+            const int cq = u % C::CQD, g = (u / C::CQD) % 2, r = u / (2 * C::CQD);
+            const int dc = co0 + cq * 4;
+            const bool dok = u < C::NDU && dc < a.c_out;
+            int oy = oy0 + r;
+            int im = img;
+            if (a.vt) {
+                im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                oy -= im * a.hp;
+                if (im >= a.nimg) oy = a.h_out;
+            }
+            const bool rowok = oy < a.h_out;
+            const int rowbase = (im * a.h_out + oy) * a.w_out;
+            const float* base = a.dz + (dok ? dc : 0);
+            unsigned m = 0u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ox = ox0 + 8 * g + j;
+                const bool ok = dok && rowok && ox < a.w_out;
+                if (ok) m |= 1u << j;
+                rd[i][j] = *reinterpret_cast<const f32x4*>(base + (size_t)(ok ? rowbase + ox : 0) * a.c_out);
+            }
+            md[i] = m;
+        }
+    };
+    // 8 pixels of one channel -> three 16-B bf16 vectors (exact truncation split), written to the channel's LDS row
+    auto split8 = [&](const f32x4 (&v)[8], unsigned m, int e, unsigned char* dst, int plane_bytes) {
+        u32x4 w0, w1, w2;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            unsigned x0[2], x1[2], x2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float x = ((m >> (2 * d + h)) & 1u) ? v[2 * d + h][e] : 0.f;
+                x0[h] = __float_as_uint(x) & 0xffff0000u;
+                const float r1 = x - __uint_as_float(x0[h]);
+                x1[h] = __float_as_uint(r1) & 0xffff0000u;
+                const float r2 = r1 - __uint_as_float(x1[h]);
+                x2[h] = __float_as_uint(r2);
+            }
+            w0[d] = (x0[0] >> 16) | x0[1];
+            w1[d] = (x1[0] >> 16) | x1[1];
+            w2[d] = (x2[0] >> 16) | (x2[1] & 0xffff0000u);
+        }
+        *reinterpret_cast<u32x4*>(dst) = w0;
+        *reinterpret_cast<u32x4*>(dst + plane_bytes) = w1;
+        *reinterpret_cast<u32x4*>(dst + 2 * plane_bytes) = w2;
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < C::RX; ++i) {
+            const int u = tid + 256 * i;
+            if (C::NXU % 256 == 0 || u < C::NXU) {
+                const int cq = u % C::CQX, g = (u / C::CQX) % 3, hy = u / (3 * C::CQX);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    split8(rx[i], mx[i], e, Xs + (e * C::CQX + cq) * C::SX + hy * C::XROW + g * 16, C::XPL);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::RD; ++i) {
+            const int u = tid + 256 * i;
+            if (C::NDU % 256 == 0 || u < C::NDU) {
+                const int cq = u % C::CQD, g = (u / C::CQD) % 2, r = u / (2 * C::CQD);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    split8(rd[i], md[i], e, Ds + (e * C::CQD + cq) * C::SD + r * C::DROW + g * 16, C::DPL);
+            }
+        }
+    };
+
+    // ---- MFMA operands of one step: raw x rows (3 planes x 3 kernel rows x 5 dwords) and dz (3 planes x 4 dwords)
+    const unsigned char* xb = Xs + (wi * 32 + li) * C::SX + lh * 16 + wk * C::XROW;
+    const unsigned char* db = Ds + (wj * 32 + li) * C::SD + lh * 16 + wk * C::DROW;
+    // x rows live in a ring of register slots: with KSPLIT == 1 consecutive steps share two of their three halo rows, so only
+    // ONE new row is read per step (4 slots); otherwise two sets of three rows.  (256 architectural VGPRs hold the staging
+    // registers, the operands and the addresses; the 144 accumulators live in AGPRs.)
+    constexpr int ROLL = C::KSPLIT == 1;
+    constexpr int NSLOT = ROLL ? 4 : 6;
+    constexpr int NEWROWS = ROLL ? 1 : 3;           // halo rows fetched per step
+    constexpr int NRD = NEWROWS * 6 + 3;            // LDS reads per step: (b128 + b32) x 3 planes per row, + 3 dz
+    u32x4 xlo[NSLOT][3];     // [row slot][plane]  pixels 8h .. 8h+7
+    unsigned xhi[NSLOT][3];  //                    pixels 8h+8, 8h+9
+    u32x4 dzv[2][3];         // [set][plane]
+    u32x4 xs1[3][3];         // kx = 1 operands of the current step
+
+    int tile = blockIdx.x;
+    if (tile < a.ntiles) load_tile(tile);
+    while (tile < a.ntiles) {
+        __syncthreads();   // the previous tile's MFMAs are done with LDS
+        store_tile();
+        __syncthreads();
+        const int ntile = tile + gridDim.x;
+        if (ntile < a.ntiles) load_tile(ntile);
+
+        // prologue of the tile: operands of this wave's first row
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                xlo[ky][pl] = *reinterpret_cast<const u32x4*>(xb + pl * C::XPL + ky * C::XROW);
+                xhi[ky][pl] = *reinterpret_cast<const unsigned*>(xb + pl * C::XPL + ky * C::XROW + 16);
+            }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dzv[0][pl] = *reinterpret_cast<const u32x4*>(db + pl * C::DPL);
+        __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            const bool has_next = s + 1 < C::NS;
+            const int rn = (s + 1) * C::KSPLIT;   // next row of this wave (relative to wk)
+            constexpr int NMF = 54;
+#pragma unroll
+            for (int j = 0; j < NMF; ++j) {
+                // order: all kx = 0 taps, then kx = 2, then kx = 1 (whose operands are being built meanwhile); inside a group the
+                // six partial products run smallest first and the three kernel rows alternate
+                constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+                constexpr int KXO[3] = {0, 2, 1};
+                const int kx = KXO[j / 18], pj = (j % 18) / 3, ky = j % 3;
+                const int tap = ky * 3 + kx;
+                const int sl = ROLL ? (s + ky) % 4 : cur * 3 + ky;
+                u32x4 av;
+                if (kx == 0) av = xlo[sl][PA[pj]];
+                else if (kx == 1) av = xs1[ky][PA[pj]];
+                else {
+                    const u32x4 lo = xlo[sl][PA[pj]];
+                    av[0] = lo[1]; av[1] = lo[2]; av[2] = lo[3]; av[3] = xhi[sl][PA[pj]];
+                }
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av), as_bf16x8(dzv[cur][PB[pj]]), acc[tap], 0, 0, 0);
+                // one kx = 1 operand (4 v_alignbit) behind each of the first 9 even MFMAs
+                if (j < 18 && (j & 1) == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int sky = (j / 2) / 3, spl = (j / 2) % 3;
+                    const int ssl = ROLL ? (s + sky) % 4 : cur * 3 + sky;
+                    const u32x4 lo = xlo[ssl][spl];
+                    const unsigned hi = xhi[ssl][spl];
+                    xs1[sky][spl][0] = __builtin_amdgcn_alignbit(lo[1], lo[0], 16);
+                    xs1[sky][spl][1] = __builtin_amdgcn_alignbit(lo[2], lo[1], 16);
+                    xs1[sky][spl][2] = __builtin_amdgcn_alignbit(lo[3], lo[2], 16);
+                    xs1[sky][spl][3] = __builtin_amdgcn_alignbit(hi, lo[3], 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // the next step's LDS reads, one at a time, spread evenly over the MFMAs that do not touch their target slot:
+                // with the ring, the new row replaces this step's ky = 0 row, which the kx = 0 / kx = 2 / kx = 1 groups all read,
+                // so it must wait for the last group's ky = 0 MFMAs -- dz and (non-ring) rows go to the other set and may go early
+                const int n0 = (j * NRD) / NMF, n1 = ((j + 1) * NRD) / NMF;
+                if (has_next && n1 > n0 && !ROLL) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int nr = n0;
+                    if (nr < 18) {
+                        const int rky = (nr / 2) / 3, rpl = (nr / 2) % 3;
+                        const unsigned char* g = xb + rpl * C::XPL + (rn + rky) * C::XROW;
+                        if ((nr & 1) == 0) xlo[nxt * 3 + rky][rpl] = *reinterpret_cast<const u32x4*>(g);
+                        else xhi[nxt * 3 + rky][rpl] = *reinterpret_cast<const unsigned*>(g + 16);
+                    } else {
+                        const int rpl = nr - 18;
+                        dzv[nxt][rpl] = *reinterpret_cast<const u32x4*>(db + rpl * C::DPL + rn * C::DROW);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (has_next && ROLL) {
+                    // ring: slot (s + 3) % 4 is free during the whole step (it held row s - 1): 6 row reads + 3 dz reads, one
+                    // behind every sixth MFMA
+                    if (j % 6 == 5) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int nr = j / 6;
+                        const int nsl = (s + 3) % 4;
+                        if (nr < 6) {
+                            const int rpl = nr / 2;
+                            const unsigned char* g = xb + rpl * C::XPL + (rn + 2) * C::XROW;
+                            if ((nr & 1) == 0) xlo[nsl][rpl] = *reinterpret_cast<const u32x4*>(g);
+                            else xhi[nsl][rpl] = *reinterpret_cast<const unsigned*>(g + 16);
+                        } else {
+                            const int rpl = nr - 6;
+                            dzv[nxt][rpl] = *reinterpret_cast<const u32x4*>(db + rpl * C::DPL + rn * C::DROW);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tile = ntile;
+    }
+
+    // ---- sum the KSPLIT row slices of each (wi, wj) block through LDS (fixed order), then one partial per workgroup
+    if (C::KSPLIT > 1) {
+        float* red = reinterpret_cast<float*>(smem_b) + (wi + C::WCI * wj) * (C::T * 16 * 64);
+        for (int s = C::KSPLIT - 1; s >= 1; --s) {
+            __syncthreads();
+            if (wk == s) {
+#pragma unroll
+                for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(tap * 16 + r) * 64 + lane] = acc[tap][r];
+            }
+            __syncthreads();
+            if (wk == s - 1) {
+#pragma unroll
+                for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tap][r] += red[(tap * 16 + r) * 64 + lane];
+            }
+        }
+    }
+    if (wk == 0) {
+        float* wsp = a.ws + (size_t)blockIdx.x * a.ktot * a.cop;
+        const int q32_0 = first ? 0 : (a.c1 + 31) / 32;   // 32-channel chunk index of this source's first chunk in k
+        const int rdz = wj * 32 + li;
+        const int co = co0 + (rdz % C::CQD) * 4 + rdz / C::CQD;
+#pragma unroll
+        for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rxr = wi * 32 + rcf_mfma_row(r, lh);
+                const int ch = cb + (rxr % C::CQX) * 4 + rxr / C::CQX;   // channel inside its source
+                if ((ch & ~31) < csrc && co < a.cop) {
+                    const int k = ((q32_0 + (ch >> 5)) * C::T + tap) * 32 + (ch & 31);
+                    wsp[(size_t)k * a.cop + co] = acc[tap][r];
+                }
+            }
+    }
+}
+
 // workspace [nslot][ktot][cop] -> dW in OIHW.  One thread per (k, co), co fastest (coalesced reads).
 // kind: 0 generic (k = (q*T+tap)*32 + channel-in-chunk), 1 stem (k = tap(ky)*32 + kx*4 + c).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslot, int ktot,
@@ -1331,6 +1660,18 @@ int launch_wgrad(const ConvArgs& a, int nsplit, int nchunk, int ncog, hipStream_
     }
     dim3 grid(nsplit, nchunk, ncog);
     hipLaunchKernelGGL((conv_wgrad_kernel<C>), grid, dim3(256), C::LDS_BYTES, st, a);
+    return rcf_launch_status();
+}
+
+template <class C>
+int launch_wgrad_split(const ConvArgs& a, int nsplit, int gy, int gz, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C::LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_split_kernel<C>), dim3(nsplit, gy, gz), dim3(256), C::LDS_BYTES, st, a);
     return rcf_launch_status();
 }
 
@@ -1576,7 +1917,7 @@ int dispatch_split(const Sel& s, F&& f) {
 }
 
 // wgrad tiling for the forward descriptor
-struct WSel { int kind, px, th, t, cst, nchunk1, nchunk2, ncog, nsplit, ktot, cop, tiles_x, tiles_y, ntiles, vt; };
+struct WSel { int kind, px, th, t, cst, nchunk1, nchunk2, ncog, nsplit, ktot, cop, tiles_x, tiles_y, ntiles, vt, split, wci, wco, gy, gz; };
 
 int select_wgrad(const rcf_conv_desc* d, WSel* w) {
     if (!valid_desc(d) || d->w_mode != RCF_W_FORWARD) return RCF_EINVAL;
@@ -1597,9 +1938,14 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
     const bool dma_ok = w->kind != K7S2 && (d->c1 % 4 == 0) && (d->c2 % 4 == 0);
     const bool vt_ok = dma_ok && vt_allowed(d);
     w->vt = 0;
+    // 3x3 stride-1 layers run on the bf16 matrix pipe (conv_wgrad_split_kernel): 16x8 tiles, 32/64-channel blocks per workgroup
+    w->split = (w->kind == K3S1 && dma_ok && split_enabled() && d->out_stride == 1 && d->out_h_phys == d->h_out &&
+                d->out_w_phys == d->w_out && (d->gather1 == RCF_GATHER_DIRECT || d->gather1 == RCF_GATHER_NEAREST)) ? 1 : 0;
+    w->wci = w->wco = 1; w->gy = w->gz = 0;
     double best = -1.0;
-    const int pxs[3] = {32, 16, 8}, ths[3] = {th32, th16, 32};
+    const int pxs[3] = {32, 16, 8}, ths[3] = {th32, w->split ? 8 : th16, 32};
     for (int i = 0; i < 3; ++i) {
+        if (w->split && pxs[i] != 16) continue;
         if (pxs[i] == 8 && !(w->kind == K3S1 && dma_ok)) continue;
         for (int vt = 0; vt <= (vt_ok ? 1 : 0); ++vt) {
             const double e = vt ? tile_eff_vt(d->w_out, d->h_out, d->n, pxs[i], ths[i]) : tile_eff(d->w_out, d->h_out, pxs[i], ths[i]);
@@ -1624,6 +1970,16 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
     w->nsplit = ns;
     w->ktot = (w->nchunk1 + w->nchunk2) * w->t * 32;
     w->cop = w->ncog * 32;
+    if (w->split) {
+        w->wco = d->c_out > 32 ? 2 : 1;
+        w->wci = (w->wco == 2 && d->c1 % 64 == 0 && d->c2 % 64 == 0) ? 2 : 1;
+        w->gy = ceil_div(d->c1, 32 * w->wci) + (d->c2 > 0 ? ceil_div(d->c2, 32 * w->wci) : 0);
+        w->gz = ceil_div(d->c_out, 32 * w->wco);
+        int nsp = num_cus() / (w->gy * w->gz);   // one workgroup per CU
+        if (nsp > w->ntiles) nsp = w->ntiles;
+        if (nsp < 1) nsp = 1;
+        w->nsplit = nsp;
+    }
     return RCF_OK;
 }
 
@@ -1663,7 +2019,8 @@ extern "C" int rcf_conv2d_query(const rcf_conv_desc* d, rcf_conv_info* info) {
         WSel w;
         if (select_wgrad(d, &w) == RCF_OK) {
             info->wgrad_workspace_floats = (size_t)w.nsplit * w.ktot * w.cop + 64;   // + a zero page for the DMA path
-            info->wgrad_kernel_id = 10000 + w.kind * 1000 + (w.px == 16 ? 100 : (w.px == 8 ? 200 : 0)) + (w.vt ? 400 : 0);
+            info->wgrad_kernel_id = 10000 + w.kind * 1000 + (w.px == 16 ? 100 : (w.px == 8 ? 200 : 0)) + (w.vt ? 400 : 0) +
+                                    (w.split ? 5000 + w.wci * 10 + w.wco : 0);
         }
     }
     return RCF_OK;
@@ -1741,6 +2098,13 @@ extern "C" int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const 
     a.zero = zero;
     const bool dma = w.kind != K7S2 && (d->c1 % 4 == 0) && (d->c2 % 4 == 0);
     if (dma && hipMemsetAsync(zero, 0, 64 * sizeof(float), st) != hipSuccess) return rcf_launch_status();
+    if (w.split) {
+        a.nchunk1 = ceil_div(d->c1, 32 * w.wci);
+        a.nchunk2 = d->c2 > 0 ? ceil_div(d->c2, 32 * w.wci) : 0;
+        if (w.wci == 2) rc = launch_wgrad_split<WsCfg<2, 2>>(a, w.nsplit, w.gy, w.gz, st);
+        else if (w.wco == 2) rc = launch_wgrad_split<WsCfg<1, 2>>(a, w.nsplit, w.gy, w.gz, st);
+        else rc = launch_wgrad_split<WsCfg<1, 1>>(a, w.nsplit, w.gy, w.gz, st);
+    } else
     switch (w.kind) {
         case K3S1:
             if (dma && w.px == 8) rc = launch_wgrad_dma<W3S1_8>(a, w.nsplit, nchunk, w.ncog, st);
