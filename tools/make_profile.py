@@ -1,0 +1,112 @@
+'''Turn one round's rocprofv3 outputs into the committed files under profiles/.
+
+  python tools/make_profile.py <kernel-trace dir or .db> <pmc dir> <bench json line file> [round tag]
+
+<kernel-trace>: output of `rocprofv3 --kernel-trace --stats -d DIR -o r -- python3 bench.py --no-cpu-baseline` (rocpd .db)
+<pmc dir>     : one sub-directory per `rocprofv3 --pmc X --output-format csv -d DIR/X -o b -- python3 bench.py --steps 1 --warmup 1
+                --no-cpu-baseline` pass (FETCH_SIZE, WRITE_SIZE, "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE")
+Writes profiles/<tag>_bench_kernel_stats.csv, <tag>_pmc_bench.json, <tag>_summary.md, <tag>_bench_line.json.
+'''
+import collections, csv, glob, json, os, re, sqlite3, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+trace, pmc_dir, line_file = sys.argv[1:4]
+tag = sys.argv[4] if len(sys.argv) > 4 else 'r01'
+prof = os.path.join(ROOT, 'profiles')
+
+FAMILIES = [   # (bench.py KERNEL_NAMES entry, kernel-name prefix)
+    ('conv_split_kernel 3x3 s1 (fp32 via bf16x3 split)', 'conv_split_kernel<SplitCfg<3,'),
+    ('conv_split_kernel 2x2 phases (fp32 via bf16x3 split)', 'conv_split_kernel<SplitCfg<2,'),
+    ('conv_wgrad_split_kernel 3x3 s1 (fp32 via bf16x3 split)', 'conv_wgrad_split_kernel<'),
+    ('conv_fwd_kernel 3x3 s1', 'conv_fwd_kernel<FwdCfg<3, 3, 0, 1'),
+]
+
+
+def clean(n):
+    n = re.sub(r'\(anonymous namespace\)::|void ', '', n)
+    return re.sub(r'\(ConvArgs\)|\(.*', '', n).strip()
+
+
+# ---- kernel trace
+db = trace if trace.endswith('.db') else sorted(glob.glob(os.path.join(trace, '**', '*.db'), recursive=True))[0]
+cur = sqlite3.connect(db).cursor()
+rows = list(cur.execute('select name, start, end from kernels order by start'))
+agg = collections.defaultdict(lambda: [0, 0.0])
+for n, s, e in rows:
+    a = agg[clean(n)]
+    a[0] += 1
+    a[1] += (e - s) / 1e3
+line = json.loads([l for l in open(line_file) if l.startswith('{')][-1])
+nstep = line['steps'] + line['warmup']
+tot = sum(v[1] for v in agg.values())
+with open(os.path.join(prof, tag + '_bench_kernel_stats.csv'), 'w') as f:
+    w = csv.writer(f)
+    w.writerow(['Name', 'Calls', 'TotalDurationUs', 'AverageUs', 'Percentage'])
+    for n, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        w.writerow([n, cnt, '%.1f' % us, '%.2f' % (us / cnt), '%.2f' % (100 * us / tot)])
+
+# ---- PMC passes
+pm = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+for f in glob.glob(os.path.join(pmc_dir, '**', '*counter_collection.csv'), recursive=True):
+    rr = list(csv.DictReader(open(f)))
+    ids = sorted(set(int(r['Dispatch_Id']) for r in rr))
+    cut = ids[len(ids) // 2]   # second half of the dispatches = the timed step after one warm-up step
+    for r in rr:
+        if int(r['Dispatch_Id']) < cut:
+            continue
+        a = pm[clean(r['Kernel_Name'])][r['Counter_Name']]
+        a[0] += 1
+        a[1] += float(r['Counter_Value'])
+kernels = {}
+for n, cs in pm.items():
+    e = {'launches': max(v[0] for v in cs.values())}
+    for cn, (k, s) in cs.items():
+        e[cn] = s
+    if 'FETCH_SIZE' in e and 'WRITE_SIZE' in e:
+        e['hbm_bytes_per_launch'] = (2.0 * e['FETCH_SIZE'] + e['WRITE_SIZE']) * 1024.0 / e['launches']
+    kernels[n] = e
+out = {'kernels': kernels,
+       'corrections': 'FETCH_SIZE and WRITE_SIZE are KiB; FETCH_SIZE doubled (gfx950 counts 128-B requests of 16-B/lane coalesced reads as '
+                      '64 B, MI355X_MICROARCH.md HBM section); MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)',
+       'source': 'rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE} -- python3 bench.py --steps 1 --warmup 1 '
+                 '--no-cpu-baseline (separate passes, second half of the dispatches)'}
+fam_rows = []
+for key, prefix in FAMILIES:
+    ks = [k for k in kernels if k.startswith(prefix)]
+    if not ks:
+        continue
+    n = sum(kernels[k]['launches'] for k in ks)
+    e = {'launches': n}
+    if all('hbm_bytes_per_launch' in kernels[k] for k in ks):
+        e['hbm_bytes_per_launch'] = sum(kernels[k]['hbm_bytes_per_launch'] * kernels[k]['launches'] for k in ks) / n
+    if all('SQ_VALU_MFMA_BUSY_CYCLES' in kernels[k] and 'GRBM_GUI_ACTIVE' in kernels[k] for k in ks):
+        busy = sum(kernels[k]['SQ_VALU_MFMA_BUSY_CYCLES'] for k in ks)
+        act = sum(kernels[k]['GRBM_GUI_ACTIVE'] for k in ks)
+        e['mfma_busy_fraction'] = busy / (act / 8.0 * 1024.0)
+    out[key] = e
+    fam_rows.append((key, e))
+json.dump(out, open(os.path.join(prof, tag + '_pmc_bench.json'), 'w'), indent=1, sort_keys=True)
+json.dump(line, open(os.path.join(prof, tag + '_bench_line.json'), 'w'), indent=1)
+
+# ---- summary
+with open(os.path.join(prof, tag + '_summary.md'), 'w') as f:
+    f.write('# Round 1 profile (state of the tree at the commit that carries this file)\n\n')
+    f.write('`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps %d --warmup %d --no-cpu-baseline` on MI355X (gfx950):\n'
+            % (line['steps'], line['warmup']))
+    f.write('FusionNet fp32 training, batch 8, 900x1600; %d steps in the trace.\n' % nstep)
+    f.write('Total kernel time %.1f ms = %.1f ms/step (bench wall clock without the profiler: see %s_bench_line.json).\n\n'
+            % (tot / 1e3, tot / 1e3 / nstep, tag))
+    rl = line.get('roofline', {})
+    f.write('Dominant kernel family for `roofline`: `%s`: %.4f ms per launch from events inside bench.py, %.1f algorithmic fp32 TFLOP/s.\n\n'
+            % (rl.get('kernel'), rl.get('avg_launch_ms', 0), rl.get('algorithmic_fp32_tflops', rl.get('achieved', 0))))
+    f.write('PMC passes (`%s_pmc_bench.json`):\n\n| family | launches | MFMA-busy fraction | HBM GB per launch (FETCH x2 + WRITE) |\n|---|---|---|---|\n' % tag)
+    for key, e in fam_rows:
+        f.write('| %s | %d | %s | %s |\n' % (key, e['launches'], '%.3f' % e['mfma_busy_fraction'] if 'mfma_busy_fraction' in e else '-',
+                                             '%.4f' % (e['hbm_bytes_per_launch'] / 1e9) if 'hbm_bytes_per_launch' in e else '-'))
+    f.write('\nEarlier profiles of the round (58.1 and 81.6 samples/s states) are in git history of this directory.\n\n')
+    f.write('| % | ms/step | calls/step | avg us | kernel |\n|---|---|---|---|---|\n')
+    for n, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:48]:
+        f.write('| %.2f | %.2f | %.1f | %.1f | `%s` |\n' % (100 * us / tot, us / 1e3 / nstep, cnt / nstep, us / cnt, n[:90]))
+print('wrote', tag, 'files; total %.1f ms/step over %d steps' % (tot / 1e3 / nstep, nstep))
+for key, e in fam_rows:
+    print(key, e)
