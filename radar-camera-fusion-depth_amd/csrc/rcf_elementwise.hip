@@ -14,6 +14,7 @@
 namespace {
 
 constexpr int EW_MAX_BLOCKS = 2048;
+constexpr int EW_U = 4;   // pixels per loop trip (independent loads in flight per thread)
 
 __host__ __device__ inline bool c4_ok(int c) {
     if (c < 4 || (c & 3)) return false;
@@ -54,19 +55,37 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
     const int pl = threadIdx.x / c4n;
     const int ppb = 256 / c4n;
     const Coef4 k = load_coef(coef, c, cg);
-    for (long long p = (long long)blockIdx.x * ppb + pl; p < n_pix; p += (long long)gridDim.x * ppb) {
-        const size_t i = (size_t)p * c + cg * 4;
-        f32x4 y = ld4(z, i) * k.scale + k.shift;
+    // EW_U pixels per trip: all their loads are issued before the first use (one 16-B load in flight per thread caps the stream at
+    // ~4.4 TB/s: 2048 threads/CU x 16 B against ~2 us of HBM latency)
+    const long long stride = (long long)gridDim.x * ppb;
+    auto one = [&](f32x4 zz, f32x4 r, size_t i) {
+        f32x4 y = zz * k.scale + k.shift;
         if (act == RCF_ACT_LEAKY_RELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = rcf_lrelu(y[j]);
         }
         if (res != nullptr) {
-            const f32x4 r = ld4(res, i);
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = rcf_lrelu(y[j] + r[j]);
         }
         st4(out, i, y);
+    };
+    long long p = (long long)blockIdx.x * ppb + pl;
+    for (; p + (EW_U - 1) * stride < n_pix; p += EW_U * stride) {
+        f32x4 zz[EW_U], rr[EW_U];
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) {
+            const size_t i = (size_t)(p + u * stride) * c + cg * 4;
+            zz[u] = ld4(z, i);
+            rr[u] = res != nullptr ? ld4(res, i) : zz[u];
+        }
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) one(zz[u], rr[u], (size_t)(p + u * stride) * c + cg * 4);
+    }
+    for (; p < n_pix; p += stride) {
+        const size_t i = (size_t)p * c + cg * 4;
+        const f32x4 zz = ld4(z, i);
+        one(zz, res != nullptr ? ld4(res, i) : zz, i);
     }
 }
 
@@ -125,12 +144,9 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(const float* __r
     // fp64 accumulation: these sums cancel almost completely in-network (the upstream BatchNorm already made
     // the gradient mean-free); PyTorch's CPU BatchNorm also accumulates float tensors in double.
     double s[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-    for (long long p = (long long)blockIdx.x * ppb + pl; p < n_pix; p += (long long)gridDim.x * ppb) {
-        const size_t i = (size_t)p * c + cg * 4;
-        f32x4 g = ld4(dout, i);
-        const f32x4 zz = ld4(z, i);
+    const long long stride = (long long)gridDim.x * ppb;
+    auto one = [&](f32x4 g, f32x4 zz, f32x4 o) {
         if (has_res) {
-            const f32x4 o = ld4(out, i);
 #pragma unroll
             for (int j = 0; j < 4; ++j) g[j] *= rcf_lrelu_grad(o[j]);
         }
@@ -142,6 +158,24 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(const float* __r
             s[0][j] += (double)g[j];
             s[1][j] += (double)g[j] * (double)xh[j];
         }
+    };
+    long long p = (long long)blockIdx.x * ppb + pl;
+    for (; p + (EW_U - 1) * stride < n_pix; p += EW_U * stride) {   // same pixel order per thread as the one-at-a-time loop
+        f32x4 g[EW_U], zz[EW_U], o[EW_U];
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) {
+            const size_t i = (size_t)(p + u * stride) * c + cg * 4;
+            g[u] = ld4(dout, i);
+            zz[u] = ld4(z, i);
+            o[u] = has_res ? ld4(out, i) : zz[u];
+        }
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) one(g[u], zz[u], o[u]);
+    }
+    for (; p < n_pix; p += stride) {
+        const size_t i = (size_t)p * c + cg * 4;
+        const f32x4 zz = ld4(z, i);
+        one(ld4(dout, i), zz, has_res ? ld4(out, i) : zz);
     }
     block_reduce_store<2>(s, partials + (size_t)blockIdx.x * 2 * c, c, cg, pl, sm);
 }
@@ -158,17 +192,15 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const float* __re
     const Coef4 k = load_coef(coef, c, cg);
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(bcoef + cg * 4);
     const f32x4 b1 = *reinterpret_cast<const f32x4*>(bcoef + c + cg * 4);
-    for (long long p = (long long)blockIdx.x * ppb + pl; p < n_pix; p += (long long)gridDim.x * ppb) {
-        const size_t i = (size_t)p * c + cg * 4;
-        f32x4 g = ld4(dout, i);
-        const f32x4 zz = ld4(z, i);
+    const long long stride = (long long)gridDim.x * ppb;
+    const bool want_dres = has_res && dres != nullptr;
+    auto one = [&](f32x4 g, f32x4 zz, f32x4 o, f32x4 dold, size_t i) {
         if (has_res) {
-            const f32x4 o = ld4(out, i);
 #pragma unroll
             for (int j = 0; j < 4; ++j) g[j] *= rcf_lrelu_grad(o[j]);
             if (dres != nullptr) {
                 f32x4 d = g;
-                if (dres_accumulate) d += ld4(dres, i);
+                if (dres_accumulate) d += dold;
                 st4(dres, i, d);
             }
         }
@@ -182,6 +214,25 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const float* __re
             r[j] = k.scale[j] * (gj - b0[j] - xh[j] * b1[j]);
         }
         st4(dz, i, r);
+    };
+    long long p = (long long)blockIdx.x * ppb + pl;
+    for (; p + (EW_U - 1) * stride < n_pix; p += EW_U * stride) {
+        f32x4 g[EW_U], zz[EW_U], o[EW_U], dold[EW_U];
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) {
+            const size_t i = (size_t)(p + u * stride) * c + cg * 4;
+            g[u] = ld4(dout, i);
+            zz[u] = ld4(z, i);
+            o[u] = has_res ? ld4(out, i) : zz[u];
+            dold[u] = (want_dres && dres_accumulate) ? ld4(dres, i) : zz[u];
+        }
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) one(g[u], zz[u], o[u], dold[u], (size_t)(p + u * stride) * c + cg * 4);
+    }
+    for (; p < n_pix; p += stride) {
+        const size_t i = (size_t)p * c + cg * 4;
+        const f32x4 zz = ld4(z, i);
+        one(ld4(dout, i), zz, has_res ? ld4(out, i) : zz, (want_dres && dres_accumulate) ? ld4(dres, i) : zz, i);
     }
 }
 
@@ -319,20 +370,30 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restri
     }
 }
 
-__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double* __restrict__ partials, int n_blocks, int stride,
-                                                             int c, double count, float* __restrict__ bcoef,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double* __restrict__ partials, int n_blocks, int stride,
+                                                              int c, double count, float* __restrict__ bcoef,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double smd[8];
     const int ch = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int r = threadIdx.x; r < n_blocks; r += 64) {
+    // column reads (one channel of every partial row): 4 rows per trip so that 8 loads are in flight per thread
+    int r = threadIdx.x;
+    for (; r + 768 < n_blocks; r += 1024) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = partials[(size_t)(r + 256 * u) * stride + ch];
+            b[u] = partials[(size_t)(r + 256 * u) * stride + c + ch];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s1 += a[u]; s2 += b[u]; }
+    }
+    for (; r < n_blocks; r += 256) {
         s1 += partials[(size_t)r * stride + ch];
         s2 += partials[(size_t)r * stride + c + ch];
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        s1 += __shfl_xor(s1, off);
-        s2 += __shfl_xor(s2, off);
-    }
+    s1 = block_sum_double(s1, smd);
+    s2 = block_sum_double(s2, smd);
     if (threadIdx.x == 0) {
         bcoef[ch] = (float)(s1 / count);
         bcoef[c + ch] = (float)(s2 / count);
@@ -390,7 +451,7 @@ extern "C" int rcf_bn_bwd_finalize(const double* partials, int n_blocks, int par
                                    float* dgamma, float* dbeta, void* stream) {
     if (!partials || n_blocks <= 0 || c <= 0 || partial_stride < 2 * c || count <= 0.0 || !bcoef || !dgamma || !dbeta)
         return RCF_EINVAL;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(64), 0, (hipStream_t)stream, partials, n_blocks, partial_stride, c,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, partials, n_blocks, partial_stride, c,
                        count, bcoef, dgamma, dbeta);
     return rcf_launch_status();
 }

@@ -202,6 +202,178 @@ __global__ void __launch_bounds__(256) head_bwd_dgrad_kernel(const float* __rest
     }
 }
 
+// ---- tile versions of the three head kernels (C <= 64): a block owns an 8 x 32 pixel tile (no per-element divisions), every
+// activation element is read exactly once, and what the 3x3 stencil shares between neighbours goes through LDS.
+constexpr int HT_H = 8, HT_W = 32, HT_HX = HT_W + 2, HT_HY = HT_H + 2, HT_NP = HT_HX * HT_HY;
+
+template <int CTRL>
+__device__ __forceinline__ float head_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the C4N adjacent lanes that hold one pixel's channel quads (every lane ends up with the total)
+template <int C4N>
+__device__ __forceinline__ float head_lane_sum(float v) {
+    if (C4N >= 2) v += head_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+    if (C4N >= 4) v += head_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+    if (C4N >= 8) v += head_dpp<0x141>(v);   // row_half_mirror
+    if (C4N >= 16) v += head_dpp<0x140>(v);  // row_mirror
+    return v;
+}
+
+__device__ __forceinline__ void head_tile_origin(int tile, int h, int w, int* img, int* oy0, int* ox0) {
+    const int tiles_x = (w + HT_W - 1) / HT_W, tiles_y = (h + HT_H - 1) / HT_H;
+    const int tx = tile % tiles_x;
+    const int t2 = tile / tiles_x;
+    *img = t2 / tiles_y;
+    *oy0 = (t2 % tiles_y) * HT_H;
+    *ox0 = tx * HT_W;
+}
+
+// forward: per halo pixel the nine per-tap dot products T[pixel][tap] = <x[pixel], w[tap]> (x read once, cross-lane sum by DPP),
+// then logit[q] = sum_tap T[q + tap offset][tap] from LDS.
+template <int C4N>
+__global__ void __launch_bounds__(256) head_fwd_tile_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                            float* __restrict__ logit, float* __restrict__ depth, int n, int h, int w,
+                                                            float dmin, float dmax) {
+    constexpr int C = 4 * C4N;
+    __shared__ __attribute__((aligned(16))) float wl[9 * C];
+    __shared__ float T[HT_NP * 9];
+    for (int i = threadIdx.x; i < 9 * C; i += 256) wl[(i % 9) * C + i / 9] = wgt[i];   // OIHW [1][c][3][3] -> [tap][c]
+    int img, oy0, ox0;
+    head_tile_origin(blockIdx.x, h, w, &img, &oy0, &ox0);
+    __syncthreads();
+    const int cg = threadIdx.x % C4N;
+    f32x4 k[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) k[t] = *reinterpret_cast<const f32x4*>(wl + t * C + cg * 4);
+    constexpr int NIT = (HT_NP * C4N + 255) / 256;
+#pragma unroll 4
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + 256 * it;
+        const int hp = i / C4N;
+        const int hy = hp / HT_HX, hx = hp - hy * HT_HX;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        const bool ok = hp < HT_NP && iy >= 0 && iy < h && ix >= 0 && ix < w;
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)img * h + (ok ? iy : 0)) * w + (ok ? ix : 0)) * C + cg * 4);
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float s = head_lane_sum<C4N>(v[0] * k[t][0] + v[1] * k[t][1] + v[2] * k[t][2] + v[3] * k[t][3]);
+            if (hp < HT_NP && cg == t % C4N) T[hp * 9 + t] = s;
+        }
+    }
+    __syncthreads();
+    const int ty = threadIdx.x / HT_W, tx = threadIdx.x % HT_W;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy < h && ox < w) {
+        float s = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) s += T[((ty + ky) * HT_HX + tx + kx) * 9 + ky * 3 + kx];
+        const size_t p = ((size_t)img * h + oy) * w + ox;
+        logit[p] = s;
+        depth[p] = dmin / (1.f / (1.f + expf(-s)) + dmin / dmax);
+    }
+}
+
+// input gradient: dx[p] = sum_tap dl[p - (ky-1, kx-1)] w[tap]; the dl halo tile sits in LDS, the weights in registers
+template <int C4N>
+__global__ void __launch_bounds__(256) head_bwd_dgrad_tile_kernel(const float* __restrict__ dl, const float* __restrict__ wgt,
+                                                                  float* __restrict__ dx, int n, int h, int w) {
+    constexpr int C = 4 * C4N;
+    __shared__ __attribute__((aligned(16))) float wl[9 * C];
+    __shared__ float D[HT_NP];
+    for (int i = threadIdx.x; i < 9 * C; i += 256) wl[(i % 9) * C + i / 9] = wgt[i];
+    int img, oy0, ox0;
+    head_tile_origin(blockIdx.x, h, w, &img, &oy0, &ox0);
+    for (int hp = threadIdx.x; hp < HT_NP; hp += 256) {
+        const int hy = hp / HT_HX, hx = hp - hy * HT_HX;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        D[hp] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? dl[((size_t)img * h + iy) * w + ix] : 0.f;
+    }
+    __syncthreads();
+    const int cg = threadIdx.x % C4N;
+    f32x4 k[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) k[t] = *reinterpret_cast<const f32x4*>(wl + t * C + cg * 4);
+#pragma unroll
+    for (int it = 0; it < C4N; ++it) {
+        const int pix = (threadIdx.x + 256 * it) / C4N;
+        const int ty = pix / HT_W, tx = pix % HT_W;
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) s += D[(ty + 2 - ky) * HT_HX + tx + 2 - kx] * k[ky * 3 + kx];
+        if (oy < h && ox < w) *reinterpret_cast<f32x4*>(dx + (((size_t)img * h + oy) * w + ox) * C + cg * 4) = s;
+    }
+}
+
+// weight gradient: persistent blocks over tiles; acc[tap] += dl[p - offset] * x[p] with the dl halo tile in LDS
+template <int C4N>
+__global__ void __launch_bounds__(256) head_bwd_wgrad_tile_kernel(const float* __restrict__ x, const float* __restrict__ dl,
+                                                                  float* __restrict__ ws, int n, int h, int w) {
+    constexpr int C = 4 * C4N;
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [256 / C4N][9][C] for the final reduction; D aliases its start
+    float* D = sm;
+    const int cg = threadIdx.x % C4N;
+    float acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = 0.f;
+    const int tiles_x = (w + HT_W - 1) / HT_W, tiles_y = (h + HT_H - 1) / HT_H;
+    const int ntiles = n * tiles_x * tiles_y;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int img, oy0, ox0;
+        head_tile_origin(tile, h, w, &img, &oy0, &ox0);
+        f32x4 v[C4N];
+#pragma unroll
+        for (int it = 0; it < C4N; ++it) {   // this tile's activations: issued before the barrier that waits for the dl tile
+            const int pix = (threadIdx.x + 256 * it) / C4N;
+            const int oy = oy0 + pix / HT_W, ox = ox0 + pix % HT_W;
+            const bool ok = oy < h && ox < w;
+            v[it] = *reinterpret_cast<const f32x4*>(x + (((size_t)img * h + (ok ? oy : 0)) * w + (ok ? ox : 0)) * C + cg * 4);
+            if (!ok) v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();   // previous tile's D readers are done
+        for (int hp = threadIdx.x; hp < HT_NP; hp += 256) {
+            const int hy = hp / HT_HX, hx = hp - hy * HT_HX;
+            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+            D[hp] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? dl[((size_t)img * h + iy) * w + ix] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < C4N; ++it) {
+            const int pix = (threadIdx.x + 256 * it) / C4N;
+            const int ty = pix / HT_W, tx = pix % HT_W;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float d = D[(ty + 2 - ky) * HT_HX + tx + 2 - kx];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ky * 3 + kx][j] += d * v[it][j];
+                }
+        }
+    }
+    __syncthreads();
+    const int pl = threadIdx.x / C4N;
+    constexpr int PPB = 256 / C4N;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm[(pl * 9 + t) * C + cg * 4 + j] = acc[t][j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 9 * C; e += 256) {
+        float s = 0.f;
+        for (int r = 0; r < PPB; ++r) s += sm[r * 9 * C + e];
+        ws[(size_t)blockIdx.x * 9 * C + e] = s;
+    }
+}
+
 constexpr int HEAD_WG_BLOCKS = 1024;
 
 __global__ void __launch_bounds__(256) head_bwd_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dl,
@@ -494,6 +666,21 @@ extern "C" int rcf_head_fwd(const float* x, const float* w, float* logit, float*
                             float min_depth, float max_depth, void* stream) {
     if (!x || !w || !logit || !depth || n <= 0 || h <= 0 || w_ <= 0) return RCF_EINVAL;
     if (!head_c_ok(c)) return RCF_EUNSUPPORTED;
+    const int c4n = c >> 2;
+    if (c4n <= 16) {
+        const unsigned nt = (unsigned)n * ((h + HT_H - 1) / HT_H) * ((w_ + HT_W - 1) / HT_W);
+        hipStream_t st = (hipStream_t)stream;
+#define RCF_HEAD_FWD(N) hipLaunchKernelGGL(head_fwd_tile_kernel<N>, dim3(nt), dim3(256), 0, st, x, w, logit, depth, n, h, w_, min_depth, max_depth)
+        switch (c4n) {
+            case 1: RCF_HEAD_FWD(1); break;
+            case 2: RCF_HEAD_FWD(2); break;
+            case 4: RCF_HEAD_FWD(4); break;
+            case 8: RCF_HEAD_FWD(8); break;
+            default: RCF_HEAD_FWD(16); break;
+        }
+#undef RCF_HEAD_FWD
+        return rcf_launch_status();
+    }
     const long long total = (long long)n * h * w_ * (c >> 2);
     unsigned b = nblk(total, 256); if (b > 16384) b = 16384;
     hipLaunchKernelGGL(head_fwd_kernel, dim3(b), dim3(256), 9 * c * sizeof(float), (hipStream_t)stream, x, w, logit, depth, n, h,
@@ -513,6 +700,21 @@ extern "C" int rcf_head_bwd_logit(const float* ddepth, const float* logit, float
 extern "C" int rcf_head_bwd_dgrad(const float* dlogit, const float* w, float* dx, int n, int h, int w_, int c, void* stream) {
     if (!dlogit || !w || !dx || n <= 0 || h <= 0 || w_ <= 0) return RCF_EINVAL;
     if (!head_c_ok(c)) return RCF_EUNSUPPORTED;
+    const int c4n = c >> 2;
+    if (c4n <= 16) {
+        const unsigned nt = (unsigned)n * ((h + HT_H - 1) / HT_H) * ((w_ + HT_W - 1) / HT_W);
+        hipStream_t st = (hipStream_t)stream;
+#define RCF_HEAD_DG(N) hipLaunchKernelGGL(head_bwd_dgrad_tile_kernel<N>, dim3(nt), dim3(256), 0, st, dlogit, w, dx, n, h, w_)
+        switch (c4n) {
+            case 1: RCF_HEAD_DG(1); break;
+            case 2: RCF_HEAD_DG(2); break;
+            case 4: RCF_HEAD_DG(4); break;
+            case 8: RCF_HEAD_DG(8); break;
+            default: RCF_HEAD_DG(16); break;
+        }
+#undef RCF_HEAD_DG
+        return rcf_launch_status();
+    }
     const long long total = (long long)n * h * w_ * (c >> 2);
     unsigned b = nblk(total, 256); if (b > 16384) b = 16384;
     hipLaunchKernelGGL(head_bwd_dgrad_kernel, dim3(b), dim3(256), 9 * c * sizeof(float), (hipStream_t)stream, dlogit, w, dx, n, h,
@@ -532,6 +734,23 @@ extern "C" int rcf_head_bwd_wgrad(const float* x, const float* dlogit, float* dw
     const int ppb = 256 / (c >> 2);
     long long nb = ((long long)n * h * w_ + ppb - 1) / ppb;
     if (nb > HEAD_WG_BLOCKS) nb = HEAD_WG_BLOCKS;
+    const int c4n = c >> 2;
+    if (c4n <= 16) {
+        const long long nt = (long long)n * ((h + HT_H - 1) / HT_H) * ((w_ + HT_W - 1) / HT_W);
+        if (nb > nt) nb = nt;
+        size_t lds = (size_t)ppb * 9 * c * sizeof(float);
+        if (lds < HT_NP * sizeof(float)) lds = HT_NP * sizeof(float);
+        hipStream_t st = (hipStream_t)stream;
+#define RCF_HEAD_WG(N) hipLaunchKernelGGL(head_bwd_wgrad_tile_kernel<N>, dim3((unsigned)nb), dim3(256), lds, st, x, dlogit, workspace, n, h, w_)
+        switch (c4n) {
+            case 1: RCF_HEAD_WG(1); break;
+            case 2: RCF_HEAD_WG(2); break;
+            case 4: RCF_HEAD_WG(4); break;
+            case 8: RCF_HEAD_WG(8); break;
+            default: RCF_HEAD_WG(16); break;
+        }
+#undef RCF_HEAD_WG
+    } else
     hipLaunchKernelGGL(head_bwd_wgrad_kernel, dim3((unsigned)nb), dim3(256), (size_t)ppb * 9 * c * sizeof(float),
                        (hipStream_t)stream, x, dlogit, workspace, n, h, w_, c);
     int rc = rcf_launch_status();
