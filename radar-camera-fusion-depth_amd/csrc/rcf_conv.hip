@@ -1171,7 +1171,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
 
     // ---- staging: fp32 [pixel][channel] in HBM -> registers (next tile, during this tile's MFMAs) -> bf16 planes in LDS
     f32x4 rx[C::RX][8], rd[C::RD][8];
-    unsigned mx[C::RX], md[C::RD];   // bit j: pixel j of the unit is real data (loads are branch-free from a clamped address)
+    // loads are branch-free: padding / out-of-image / out-of-range-channel elements read a zero page (a.zero), so the values need
+    // no masking afterwards
     auto load_tile = [&](int tile) {
         int t = tile;
         const int tx = t % a.tiles_x;
@@ -1185,39 +1186,34 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             const int u = tid + 256 * i;
             const int cq = u % C::CQX, g = (u / C::CQX) % 3, hy = u / (3 * C::CQX);
             const int ch = cb + cq * 4;
-            const bool cok = u < C::NXU && ch < csrc;
             const int ly = iy0 + hy;
-            bool rowok;
+            bool rowok = u < C::NXU && ch < csrc;
             int rowbase;
             if (a.vt) {
                 const int im = (int)(((float)ly + 0.5f) * a.inv_hp);
                 const int y = ly - im * a.hp;
-                rowok = ly >= 0 && im < a.nimg && y < a.h_in;
+                rowok = rowok && ly >= 0 && im < a.nimg && y < a.h_in;
                 rowbase = (im * hs + y) * ws;
             } else {
-                rowok = ly >= 0 && ly < a.h_in;
+                rowok = rowok && ly >= 0 && ly < a.h_in;
                 const int py = gmode == RCF_GATHER_NEAREST ? min((int)floorf((float)ly * a.sy), hs - 1) : ly;
                 rowbase = (img * hs + py) * ws;
             }
-            const float* base = src + (cok ? ch : 0);
-            unsigned m = 0u;
+            const float* rowptr = src + (size_t)(rowok ? rowbase : 0) * csrc + (rowok ? ch : 0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int hx = 8 * g + j;
                 const int lx = ix0 + hx;
-                const bool ok = cok && rowok && hx < C::HXP && lx >= 0 && lx < a.w_in;
+                const bool ok = rowok && hx < C::HXP && lx >= 0 && lx < a.w_in;
                 const int px = gmode == RCF_GATHER_NEAREST ? min((int)floorf((float)lx * a.sx), ws - 1) : lx;
-                if (ok) m |= 1u << j;
-                rx[i][j] = *reinterpret_cast<const f32x4*>(base + (size_t)(ok ? rowbase + px : 0) * csrc);
+                rx[i][j] = *reinterpret_cast<const f32x4*>(ok ? rowptr + px * csrc : a.zero);
             }
-            mx[i] = m;
         }
 #pragma unroll
         for (int i = 0; i < C::RD; ++i) {
             const int u = tid + 256 * i;
             const int cq = u % C::CQD, g = (u / C::CQD) % 2, r = u / (2 * C::CQD);
             const int dc = co0 + cq * 4;
-            const bool dok = u < C::NDU && dc < a.c_out;
             int oy = oy0 + r;
             int im = img;
             if (a.vt) {
@@ -1225,38 +1221,33 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 oy -= im * a.hp;
                 if (im >= a.nimg) oy = a.h_out;
             }
-            const bool rowok = oy < a.h_out;
-            const int rowbase = (im * a.h_out + oy) * a.w_out;
-            const float* base = a.dz + (dok ? dc : 0);
-            unsigned m = 0u;
+            const bool rowok = u < C::NDU && dc < a.c_out && oy < a.h_out;
+            const float* rowptr = a.dz + (size_t)(rowok ? (im * a.h_out + oy) * a.w_out : 0) * a.c_out + (rowok ? dc : 0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int ox = ox0 + 8 * g + j;
-                const bool ok = dok && rowok && ox < a.w_out;
-                if (ok) m |= 1u << j;
-                rd[i][j] = *reinterpret_cast<const f32x4*>(base + (size_t)(ok ? rowbase + ox : 0) * a.c_out);
+                rd[i][j] = *reinterpret_cast<const f32x4*>((rowok && ox < a.w_out) ? rowptr + ox * a.c_out : a.zero);
             }
-            md[i] = m;
         }
     };
     // 8 pixels of one channel -> three 16-B bf16 vectors (exact truncation split), written to the channel's LDS row
-    auto split8 = [&](const f32x4 (&v)[8], unsigned m, int e, unsigned char* dst, int plane_bytes) {
+    auto split8 = [&](const f32x4 (&v)[8], int e, unsigned char* dst, int plane_bytes) {
         u32x4 w0, w1, w2;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             unsigned x0[2], x1[2], x2[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const float x = ((m >> (2 * d + h)) & 1u) ? v[2 * d + h][e] : 0.f;
+                const float x = v[2 * d + h][e];
                 x0[h] = __float_as_uint(x) & 0xffff0000u;
                 const float r1 = x - __uint_as_float(x0[h]);
                 x1[h] = __float_as_uint(r1) & 0xffff0000u;
                 const float r2 = r1 - __uint_as_float(x1[h]);
                 x2[h] = __float_as_uint(r2);
             }
-            w0[d] = (x0[0] >> 16) | x0[1];
-            w1[d] = (x1[0] >> 16) | x1[1];
-            w2[d] = (x2[0] >> 16) | (x2[1] & 0xffff0000u);
+            w0[d] = __builtin_amdgcn_perm(x0[1], x0[0], 0x07060302u);   // high halves of the pixel pair
+            w1[d] = __builtin_amdgcn_perm(x1[1], x1[0], 0x07060302u);
+            w2[d] = __builtin_amdgcn_perm(x2[1], x2[0], 0x07060302u);
         }
         *reinterpret_cast<u32x4*>(dst) = w0;
         *reinterpret_cast<u32x4*>(dst + plane_bytes) = w1;
@@ -1270,7 +1261,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 const int cq = u % C::CQX, g = (u / C::CQX) % 3, hy = u / (3 * C::CQX);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    split8(rx[i], mx[i], e, Xs + (e * C::CQX + cq) * C::SX + hy * C::XROW + g * 16, C::XPL);
+                    split8(rx[i], e, Xs + (e * C::CQX + cq) * C::SX + hy * C::XROW + g * 16, C::XPL);
             }
         }
 #pragma unroll
@@ -1280,7 +1271,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 const int cq = u % C::CQD, g = (u / C::CQD) % 2, r = u / (2 * C::CQD);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    split8(rd[i], md[i], e, Ds + (e * C::CQD + cq) * C::SD + r * C::DROW + g * 16, C::DPL);
+                    split8(rd[i], e, Ds + (e * C::CQD + cq) * C::SD + r * C::DROW + g * 16, C::DPL);
             }
         }
     };
@@ -1304,10 +1295,18 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
     if (tile < a.ntiles) load_tile(tile);
     while (tile < a.ntiles) {
         __syncthreads();   // the previous tile's MFMAs are done with LDS
+#if RCF_EXP != 2 && (RCF_EXP < 3)
         store_tile();
+#endif
         __syncthreads();
         const int ntile = tile + gridDim.x;
+#if RCF_EXP != 2 && (RCF_EXP < 3)
         if (ntile < a.ntiles) load_tile(ntile);
+#endif
+#if RCF_EXP == 1
+        tile = ntile;
+        continue;
+#endif
 
         // prologue of the tile: operands of this wave's first row
 #pragma unroll
