@@ -1295,18 +1295,10 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
     if (tile < a.ntiles) load_tile(tile);
     while (tile < a.ntiles) {
         __syncthreads();   // the previous tile's MFMAs are done with LDS
-#if RCF_EXP != 2 && (RCF_EXP < 3)
         store_tile();
-#endif
         __syncthreads();
         const int ntile = tile + gridDim.x;
-#if RCF_EXP != 2 && (RCF_EXP < 3)
         if (ntile < a.ntiles) load_tile(ntile);
-#endif
-#if RCF_EXP == 1
-        tile = ntile;
-        continue;
-#endif
 
         // prologue of the tile: operands of this wave's first row
 #pragma unroll
