@@ -1122,9 +1122,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(ConvArgs a) {
 // step's 36 v_alignbit are issued one at a time between the 54 MFMAs of a step (hand order, pinned with sched_barrier).
 // LDS rows are permuted (row = (ch % 4) * (N / 4) + ch / 4) so that the transposing ds_write_b128 of adjacent lanes (adjacent
 // channel quads) land on adjacent rows: with a row pitch of 16 B mod 128 B both the writes and the reads are conflict-free.
-template <int WCI_, int WCO_>
+template <int WCI_, int WCO_, int KS_ = 3>
 struct WsCfg {
-    static constexpr int KS = 3, T = 9;
+    static constexpr int KS = KS_, T = KS_ * KS_;
     static constexpr int WCI = WCI_, WCO = WCO_, KSPLIT = 4 / (WCI_ * WCO_);
     static constexpr int NCI = 32 * WCI_, NCO = 32 * WCO_;
     static constexpr int PX = 16, TH = 8, HXP = PX + KS - 1, HYP = TH + KS - 1;
@@ -1221,12 +1221,14 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 oy -= im * a.hp;
                 if (im >= a.nimg) oy = a.h_out;
             }
-            const bool rowok = u < C::NDU && dc < a.c_out && oy < a.h_out;
-            const float* rowptr = a.dz + (size_t)(rowok ? (im * a.h_out + oy) * a.w_out : 0) * a.c_out + (rowok ? dc : 0);
+            const int py = oy * a.os + a.ooy;   // strided output rows/columns of the phase convolutions
+            const bool rowok = u < C::NDU && dc < a.c_out && oy < a.h_out && py < a.ohp;
+            const float* rowptr = a.dz + (size_t)(rowok ? (im * a.ohp + py) * a.owp : 0) * a.c_out + (rowok ? dc : 0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int ox = ox0 + 8 * g + j;
-                rd[i][j] = *reinterpret_cast<const f32x4*>((rowok && ox < a.w_out) ? rowptr + ox * a.c_out : a.zero);
+                const int px = ox * a.os + a.oox;
+                rd[i][j] = *reinterpret_cast<const f32x4*>((rowok && ox < a.w_out && px < a.owp) ? rowptr + px * a.c_out : a.zero);
             }
         }
     };
@@ -1282,14 +1284,16 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
     // x rows live in a ring of register slots: with KSPLIT == 1 consecutive steps share two of their three halo rows, so only
     // ONE new row is read per step (4 slots); otherwise two sets of three rows.  (256 architectural VGPRs hold the staging
     // registers, the operands and the addresses; the 144 accumulators live in AGPRs.)
+    constexpr int KS = C::KS;
     constexpr int ROLL = C::KSPLIT == 1;
-    constexpr int NSLOT = ROLL ? 4 : 6;
-    constexpr int NEWROWS = ROLL ? 1 : 3;           // halo rows fetched per step
+    constexpr int NSLOT = ROLL ? KS + 1 : 2 * KS;
+    constexpr int NEWROWS = ROLL ? 1 : KS;          // halo rows fetched per step
     constexpr int NRD = NEWROWS * 6 + 3;            // LDS reads per step: (b128 + b32) x 3 planes per row, + 3 dz
+    constexpr int NMF = 6 * C::T;                   // MFMAs per step
     u32x4 xlo[NSLOT][3];     // [row slot][plane]  pixels 8h .. 8h+7
     unsigned xhi[NSLOT][3];  //                    pixels 8h+8, 8h+9
     u32x4 dzv[2][3];         // [set][plane]
-    u32x4 xs1[3][3];         // kx = 1 operands of the current step
+    u32x4 xs1[KS][3];        // kx = 1 operands of the current step
 
     int tile = blockIdx.x;
     if (tile < a.ntiles) load_tile(tile);
@@ -1302,7 +1306,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
 
         // prologue of the tile: operands of this wave's first row
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
                 xlo[ky][pl] = *reinterpret_cast<const u32x4*>(xb + pl * C::XPL + ky * C::XROW);
@@ -1317,16 +1321,15 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             const int cur = s & 1, nxt = cur ^ 1;
             const bool has_next = s + 1 < C::NS;
             const int rn = (s + 1) * C::KSPLIT;   // next row of this wave (relative to wk)
-            constexpr int NMF = 54;
 #pragma unroll
             for (int j = 0; j < NMF; ++j) {
-                // order: all kx = 0 taps, then kx = 2, then kx = 1 (whose operands are being built meanwhile); inside a group the
-                // six partial products run smallest first and the three kernel rows alternate
+                // order: all kx = 0 taps, (kx = 2,) then kx = 1, whose operands are being built meanwhile; inside a group the six
+                // partial products run smallest first and the kernel rows alternate
                 constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-                constexpr int KXO[3] = {0, 2, 1};
-                const int kx = KXO[j / 18], pj = (j % 18) / 3, ky = j % 3;
-                const int tap = ky * 3 + kx;
-                const int sl = ROLL ? (s + ky) % 4 : cur * 3 + ky;
+                constexpr int KXO[3] = {0, KS == 3 ? 2 : 1, 1};
+                const int kx = KXO[j / (6 * KS)], pj = (j % (6 * KS)) / KS, ky = j % KS;
+                const int tap = ky * KS + kx;
+                const int sl = ROLL ? (s + ky) % (KS + 1) : cur * KS + ky;
                 u32x4 av;
                 if (kx == 0) av = xlo[sl][PA[pj]];
                 else if (kx == 1) av = xs1[ky][PA[pj]];
@@ -1335,11 +1338,11 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                     av[0] = lo[1]; av[1] = lo[2]; av[2] = lo[3]; av[3] = xhi[sl][PA[pj]];
                 }
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av), as_bf16x8(dzv[cur][PB[pj]]), acc[tap], 0, 0, 0);
-                // one kx = 1 operand (4 v_alignbit) behind each of the first 9 even MFMAs
-                if (j < 18 && (j & 1) == 0) {
+                // one kx = 1 operand (4 v_alignbit) behind each of the first 3 KS even MFMAs (all inside the kx = 0 group)
+                if (j < 6 * KS && (j & 1) == 0) {
                     __builtin_amdgcn_sched_barrier(0);
                     const int sky = (j / 2) / 3, spl = (j / 2) % 3;
-                    const int ssl = ROLL ? (s + sky) % 4 : cur * 3 + sky;
+                    const int ssl = ROLL ? (s + sky) % (KS + 1) : cur * KS + sky;
                     const u32x4 lo = xlo[ssl][spl];
                     const unsigned hi = xhi[ssl][spl];
                     xs1[sky][spl][0] = __builtin_amdgcn_alignbit(lo[1], lo[0], 16);
@@ -1348,42 +1351,24 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                     xs1[sky][spl][3] = __builtin_amdgcn_alignbit(hi, lo[3], 16);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                // the next step's LDS reads, one at a time, spread evenly over the MFMAs that do not touch their target slot:
-                // with the ring, the new row replaces this step's ky = 0 row, which the kx = 0 / kx = 2 / kx = 1 groups all read,
-                // so it must wait for the last group's ky = 0 MFMAs -- dz and (non-ring) rows go to the other set and may go early
+                // the next step's LDS reads, one at a time, spread evenly over the step.  Ring (KSPLIT == 1): only the new halo
+                // row, into the slot that held row s - 1 and is free during the whole step; otherwise KS rows into the other set.
                 const int n0 = (j * NRD) / NMF, n1 = ((j + 1) * NRD) / NMF;
-                if (has_next && n1 > n0 && !ROLL) {
+                if (has_next && n1 > n0) {
                     __builtin_amdgcn_sched_barrier(0);
                     const int nr = n0;
-                    if (nr < 18) {
-                        const int rky = (nr / 2) / 3, rpl = (nr / 2) % 3;
+                    if (nr < NEWROWS * 6) {
+                        const int rrow = (nr / 2) / 3, rpl = (nr / 2) % 3;
+                        const int rky = ROLL ? KS - 1 : rrow;
+                        const int nsl = ROLL ? (s + KS) % (KS + 1) : nxt * KS + rrow;
                         const unsigned char* g = xb + rpl * C::XPL + (rn + rky) * C::XROW;
-                        if ((nr & 1) == 0) xlo[nxt * 3 + rky][rpl] = *reinterpret_cast<const u32x4*>(g);
-                        else xhi[nxt * 3 + rky][rpl] = *reinterpret_cast<const unsigned*>(g + 16);
+                        if ((nr & 1) == 0) xlo[nsl][rpl] = *reinterpret_cast<const u32x4*>(g);
+                        else xhi[nsl][rpl] = *reinterpret_cast<const unsigned*>(g + 16);
                     } else {
-                        const int rpl = nr - 18;
+                        const int rpl = nr - NEWROWS * 6;
                         dzv[nxt][rpl] = *reinterpret_cast<const u32x4*>(db + rpl * C::DPL + rn * C::DROW);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                }
-                if (has_next && ROLL) {
-                    // ring: slot (s + 3) % 4 is free during the whole step (it held row s - 1): 6 row reads + 3 dz reads, one
-                    // behind every sixth MFMA
-                    if (j % 6 == 5) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        const int nr = j / 6;
-                        const int nsl = (s + 3) % 4;
-                        if (nr < 6) {
-                            const int rpl = nr / 2;
-                            const unsigned char* g = xb + rpl * C::XPL + (rn + 2) * C::XROW;
-                            if ((nr & 1) == 0) xlo[nsl][rpl] = *reinterpret_cast<const u32x4*>(g);
-                            else xhi[nsl][rpl] = *reinterpret_cast<const unsigned*>(g + 16);
-                        } else {
-                            const int rpl = nr - 6;
-                            dzv[nxt][rpl] = *reinterpret_cast<const u32x4*>(db + rpl * C::DPL + rn * C::DROW);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1930,8 +1915,10 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
     const bool vt_ok = dma_ok && vt_allowed(d);
     w->vt = 0;
     // 3x3 stride-1 layers run on the bf16 matrix pipe (conv_wgrad_split_kernel): 16x8 tiles, 32/64-channel blocks per workgroup
-    w->split = (w->kind == K3S1 && dma_ok && split_enabled() && d->out_stride == 1 && d->out_h_phys == d->h_out &&
-                d->out_w_phys == d->w_out && (d->gather1 == RCF_GATHER_DIRECT || d->gather1 == RCF_GATHER_NEAREST)) ? 1 : 0;
+    w->split = (dma_ok && split_enabled() &&
+                ((w->kind == K3S1 && d->out_stride == 1 && d->out_h_phys == d->h_out && d->out_w_phys == d->w_out &&
+                  (d->gather1 == RCF_GATHER_DIRECT || d->gather1 == RCF_GATHER_NEAREST)) ||
+                 (w->kind == K2S1 && d->gather1 == RCF_GATHER_DIRECT))) ? 1 : 0;
     w->wci = w->wco = 1; w->gy = w->gz = 0;
     double best = -1.0;
     const int pxs[3] = {32, 16, 8}, ths[3] = {th32, w->split ? 8 : th16, 32};
@@ -2092,7 +2079,11 @@ extern "C" int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const 
     if (w.split) {
         a.nchunk1 = ceil_div(d->c1, 32 * w.wci);
         a.nchunk2 = d->c2 > 0 ? ceil_div(d->c2, 32 * w.wci) : 0;
-        if (w.wci == 2) rc = launch_wgrad_split<WsCfg<2, 2>>(a, w.nsplit, w.gy, w.gz, st);
+        if (w.kind == K2S1) {
+            if (w.wci == 2) rc = launch_wgrad_split<WsCfg<2, 2, 2>>(a, w.nsplit, w.gy, w.gz, st);
+            else if (w.wco == 2) rc = launch_wgrad_split<WsCfg<1, 2, 2>>(a, w.nsplit, w.gy, w.gz, st);
+            else rc = launch_wgrad_split<WsCfg<1, 1, 2>>(a, w.nsplit, w.gy, w.gz, st);
+        } else if (w.wci == 2) rc = launch_wgrad_split<WsCfg<2, 2>>(a, w.nsplit, w.gy, w.gz, st);
         else if (w.wco == 2) rc = launch_wgrad_split<WsCfg<1, 2>>(a, w.nsplit, w.gy, w.gz, st);
         else rc = launch_wgrad_split<WsCfg<1, 1>>(a, w.nsplit, w.gy, w.gz, st);
     } else
