@@ -1122,14 +1122,16 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(ConvArgs a) {
 // step's 36 v_alignbit are issued one at a time between the 54 MFMAs of a step (hand order, pinned with sched_barrier).
 // LDS rows are permuted (row = (ch % 4) * (N / 4) + ch / 4) so that the transposing ds_write_b128 of adjacent lanes (adjacent
 // channel quads) land on adjacent rows: with a row pitch of 16 B mod 128 B both the writes and the reads are conflict-free.
-template <int WCI_, int WCO_, int KS_ = 3>
+constexpr int ws_pitch(int bytes) { return ((bytes - 16 + 127) / 128) * 128 + 16; }   // >= bytes and == 16 (mod 128)
+
+template <int WCI_, int WCO_, int KS_ = 3, int TH_ = 8>
 struct WsCfg {
     static constexpr int KS = KS_, T = KS_ * KS_;
     static constexpr int WCI = WCI_, WCO = WCO_, KSPLIT = 4 / (WCI_ * WCO_);
     static constexpr int NCI = 32 * WCI_, NCO = 32 * WCO_;
-    static constexpr int PX = 16, TH = 8, HXP = PX + KS - 1, HYP = TH + KS - 1;
+    static constexpr int PX = 16, TH = TH_, HXP = PX + KS - 1, HYP = TH + KS - 1;
     static constexpr int XROW = 48, DROW = 32;     // bytes per tile row of one channel: 24 px (18 used) / 16 px
-    static constexpr int SX = 528, SD = 272;       // bytes per channel and plane, == 16 (mod 128)
+    static constexpr int SX = ws_pitch(HYP * XROW), SD = ws_pitch(TH * DROW);   // bytes per channel and plane
     static constexpr int XPL = NCI * SX, DPL = NCO * SD;
     static constexpr int X_BYTES = 3 * XPL, D_BYTES = 3 * DPL;
     static constexpr int RED_BYTES = (KSPLIT > 1) ? WCI * WCO * T * 16 * 64 * 4 : 0;
@@ -1138,7 +1140,7 @@ struct WsCfg {
     static constexpr int NXU = HYP * 3 * CQX, NDU = TH * 2 * CQD;     // 8-pixel x 4-channel staging units
     static constexpr int RX = (NXU + 255) / 256, RD = (NDU + 255) / 256;
     static constexpr int NS = TH / KSPLIT;         // MFMA steps (tile rows) per wave and tile
-    static_assert(HYP * XROW <= SX && TH * DROW <= SD, "tile rows must fit the channel pitch");
+    static_assert(HYP * XROW <= SX && TH * DROW <= SD && LDS_BYTES <= 160 * 1024, "tile rows must fit the channel pitch / LDS");
 };
 
 template <class C>
@@ -1920,8 +1922,13 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
                   (d->gather1 == RCF_GATHER_DIRECT || d->gather1 == RCF_GATHER_NEAREST)) ||
                  (w->kind == K2S1 && d->gather1 == RCF_GATHER_DIRECT))) ? 1 : 0;
     w->wci = w->wco = 1; w->gy = w->gz = 0;
+    if (w->split) {   // channels per workgroup: 64 x 64, 32 x 64, 64 x 32 or 32 x 32 (the last with 16-row tiles)
+        w->wco = d->c_out > 32 ? 2 : 1;
+        w->wci = (d->c1 % 64 == 0 && d->c2 % 64 == 0) ? 2 : 1;
+    }
+    const int th_split = (w->wci == 1 && w->wco == 1) ? 16 : 8;
     double best = -1.0;
-    const int pxs[3] = {32, 16, 8}, ths[3] = {th32, w->split ? 8 : th16, 32};
+    const int pxs[3] = {32, 16, 8}, ths[3] = {th32, w->split ? th_split : th16, 32};
     for (int i = 0; i < 3; ++i) {
         if (w->split && pxs[i] != 16) continue;
         if (pxs[i] == 8 && !(w->kind == K3S1 && dma_ok)) continue;
@@ -1949,8 +1956,6 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
     w->ktot = (w->nchunk1 + w->nchunk2) * w->t * 32;
     w->cop = w->ncog * 32;
     if (w->split) {
-        w->wco = d->c_out > 32 ? 2 : 1;
-        w->wci = (w->wco == 2 && d->c1 % 64 == 0 && d->c2 % 64 == 0) ? 2 : 1;
         w->gy = ceil_div(d->c1, 32 * w->wci) + (d->c2 > 0 ? ceil_div(d->c2, 32 * w->wci) : 0);
         w->gz = ceil_div(d->c_out, 32 * w->wco);
         int nsp = num_cus() / (w->gy * w->gz);   // one workgroup per CU
@@ -2079,13 +2084,16 @@ extern "C" int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const 
     if (w.split) {
         a.nchunk1 = ceil_div(d->c1, 32 * w.wci);
         a.nchunk2 = d->c2 > 0 ? ceil_div(d->c2, 32 * w.wci) : 0;
+        const int cfg = w.wci * 10 + w.wco;
         if (w.kind == K2S1) {
-            if (w.wci == 2) rc = launch_wgrad_split<WsCfg<2, 2, 2>>(a, w.nsplit, w.gy, w.gz, st);
-            else if (w.wco == 2) rc = launch_wgrad_split<WsCfg<1, 2, 2>>(a, w.nsplit, w.gy, w.gz, st);
-            else rc = launch_wgrad_split<WsCfg<1, 1, 2>>(a, w.nsplit, w.gy, w.gz, st);
-        } else if (w.wci == 2) rc = launch_wgrad_split<WsCfg<2, 2>>(a, w.nsplit, w.gy, w.gz, st);
-        else if (w.wco == 2) rc = launch_wgrad_split<WsCfg<1, 2>>(a, w.nsplit, w.gy, w.gz, st);
-        else rc = launch_wgrad_split<WsCfg<1, 1>>(a, w.nsplit, w.gy, w.gz, st);
+            if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2, 2>>(a, w.nsplit, w.gy, w.gz, st);
+            else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2, 2>>(a, w.nsplit, w.gy, w.gz, st);
+            else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 2>>(a, w.nsplit, w.gy, w.gz, st);
+            else rc = launch_wgrad_split<WsCfg<1, 1, 2, 16>>(a, w.nsplit, w.gy, w.gz, st);
+        } else if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2>>(a, w.nsplit, w.gy, w.gz, st);
+        else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2>>(a, w.nsplit, w.gy, w.gz, st);
+        else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1>>(a, w.nsplit, w.gy, w.gz, st);
+        else rc = launch_wgrad_split<WsCfg<1, 1, 3, 16>>(a, w.nsplit, w.gy, w.gz, st);
     } else
     switch (w.kind) {
         case K3S1:
