@@ -409,7 +409,7 @@ template <int KS_, int NT_, int PX_>
 struct SplitCfg {
     static constexpr int KSY = KS_, KSX = KS_, T = KS_ * KS_, LSTEP = 1, CK = 16, CST = 16;
     static constexpr int NT = NT_, BN = 32 * NT_;
-    static constexpr int PX = PX_, PY = 32 / PX_, MT = 2, NW = 4, TH = PY * MT * NW;
+    static constexpr int PX = PX_, PY = 32 / PX_, MT = (NT_ == 1 && KS_ == 3) ? 4 : 2, NW = 4, TH = PY * MT * NW;   // 3x3 32-co layers: 512-pixel tiles
     static constexpr int HXP = PX + KS_ - 1, HYP = TH + KS_ - 1, NPIX = HXP * HYP;
     static constexpr int A_PLANE_BYTES = NPIX * 32;        // 16 bf16 per halo pixel
     static constexpr int A_BYTES = 3 * A_PLANE_BYTES;
@@ -1817,14 +1817,14 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     const bool vt_ok = vt_allowed(d);
     const int pxs[3] = {32, 16, 8};
     for (int i = 0; i < 3; ++i) {
-        const int px = pxs[i], th = 256 / px;
+        const int px = pxs[i], th = ((s->split && s->nt == 1 && s->kind == K3S1) ? 512 : 256) / px;
         if (px == 8 && (s->split || !(s->kind == K3S1 && s->ck == 16))) continue;
         for (int vt = 0; vt <= (vt_ok ? 1 : 0); ++vt) {
             const double e = vt ? tile_eff_vt(d->w_out, d->h_out, d->n, px, th) : tile_eff(d->w_out, d->h_out, px, th);
             if (e > best + 1e-9) { best = e; s->px = px; s->vt = vt; }
         }
     }
-    s->th = 256 / s->px;
+    s->th = ((s->split && s->nt == 1 && s->kind == K3S1) ? 512 : 256) / s->px;
     s->bn = 32 * s->nt;
     return RCF_OK;
 }
