@@ -405,11 +405,11 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // fp32 halo tile is loaded once (registers), split, and written to LDS as three bf16 planes [pixel][16 ch] whose 16-B halves are
 // XOR-swizzled by bit 3 of the pixel index (conflict-free ds_read_b128 without padding).  The pre-split packed weights arrive one
 // KERNEL ROW (KSX taps) at a time into a double-buffered LDS piece, so only the A tile needs the two-barrier hand-over.
-template <int KS_, int NT_, int PX_>
+template <int KS_, int NT_, int PX_, int MT_ = 0>
 struct SplitCfg {
     static constexpr int KSY = KS_, KSX = KS_, T = KS_ * KS_, LSTEP = 1, CK = 16, CST = 16;
     static constexpr int NT = NT_, BN = 32 * NT_;
-    static constexpr int PX = PX_, PY = 32 / PX_, MT = (NT_ == 1 && KS_ == 3) ? 4 : 2, NW = 4, TH = PY * MT * NW;   // 3x3 32-co layers: 512-pixel tiles
+    static constexpr int PX = PX_, PY = 32 / PX_, MT = MT_ ? MT_ : ((NT_ == 1 && KS_ == 3) ? 4 : 2), NW = 4, TH = PY * MT * NW;   // 3x3 32-co layers: 512-pixel tiles
     static constexpr int HXP = PX + KS_ - 1, HYP = TH + KS_ - 1, NPIX = HXP * HYP;
     static constexpr int A_PLANE_BYTES = NPIX * 32;        // 16 bf16 per halo pixel
     static constexpr int A_BYTES = 3 * A_PLANE_BYTES;
@@ -1564,6 +1564,7 @@ struct Sel {
     int th, bn, t, cst;
     int vt;   // virtual tall image tiling
     int split;   // fp32 on the bf16 matrix pipe (conv_split_kernel)
+    int small;   // split 3x3 layer too small to fill the chip with 64-co workgroups: 256-pixel x 32-co workgroups instead
 };
 
 int num_cus() {
@@ -1702,6 +1703,8 @@ using S3_1_32 = SplitCfg<3, 1, 32>;
 using S3_2_32 = SplitCfg<3, 2, 32>;
 using S3_1_16 = SplitCfg<3, 1, 16>;
 using S3_2_16 = SplitCfg<3, 2, 16>;
+using S3_1_32s = SplitCfg<3, 1, 32, 2>;   // 256-pixel x 32-co workgroups: more of them for the small layers
+using S3_1_16s = SplitCfg<3, 1, 16, 2>;
 using S2_1_32 = SplitCfg<2, 1, 32>;
 using S2_2_32 = SplitCfg<2, 2, 32>;
 using S2_1_16 = SplitCfg<2, 1, 16>;
@@ -1807,24 +1810,28 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     // wastes least at the image edges; stride-1 3x3 convs may also tile the batch as one tall virtual image
     s->vt = 0;
     s->split = 0;
+    s->small = 0;
     if (((s->kind == K3S1 && s->ck == 16) || (s->kind == K2S1 && cmax >= 16)) && (d->c1 % 4 == 0) && (d->c2 % 4 == 0) &&
         split_enabled()) {
         s->split = 1;
         s->ck = 16;
         s->cst = 16;
+        // fewer 256-pixel x 64-co workgroups than CUs: halve the workgroup (BN = 32) to double their number
+        const long long wgs = (((long long)d->n * d->h_out * d->w_out + 255) / 256) * ceil_div(d->c_out, 64);
+        if (s->kind == K3S1 && s->nt == 2 && wgs < num_cus()) { s->small = 1; s->nt = 1; }
     }
     double best = -1.0;
     const bool vt_ok = vt_allowed(d);
     const int pxs[3] = {32, 16, 8};
     for (int i = 0; i < 3; ++i) {
-        const int px = pxs[i], th = ((s->split && s->nt == 1 && s->kind == K3S1) ? 512 : 256) / px;
+        const int px = pxs[i], th = ((s->split && s->nt == 1 && s->kind == K3S1 && !s->small) ? 512 : 256) / px;
         if (px == 8 && (s->split || !(s->kind == K3S1 && s->ck == 16))) continue;
         for (int vt = 0; vt <= (vt_ok ? 1 : 0); ++vt) {
             const double e = vt ? tile_eff_vt(d->w_out, d->h_out, d->n, px, th) : tile_eff(d->w_out, d->h_out, px, th);
             if (e > best + 1e-9) { best = e; s->px = px; s->vt = vt; }
         }
     }
-    s->th = ((s->split && s->nt == 1 && s->kind == K3S1) ? 512 : 256) / s->px;
+    s->th = ((s->split && s->nt == 1 && s->kind == K3S1 && !s->small) ? 512 : 256) / s->px;
     s->bn = 32 * s->nt;
     return RCF_OK;
 }
@@ -1890,6 +1897,7 @@ int dispatch_split(const Sel& s, F&& f) {
         if (s.nt == 1) return s.px == 16 ? f(Tag<S2_1_16>{}) : f(Tag<S2_1_32>{});
         return s.px == 16 ? f(Tag<S2_2_16>{}) : f(Tag<S2_2_32>{});
     }
+    if (s.nt == 1 && s.small) return s.px == 16 ? f(Tag<S3_1_16s>{}) : f(Tag<S3_1_32s>{});
     if (s.nt == 1) return s.px == 16 ? f(Tag<S3_1_16>{}) : f(Tag<S3_1_32>{});
     return s.px == 16 ? f(Tag<S3_2_16>{}) : f(Tag<S3_2_32>{});
 }
@@ -1995,7 +2003,7 @@ extern "C" int rcf_conv2d_query(const rcf_conv_desc* d, rcf_conv_info* info) {
     info->n_partials = s.split ? dispatch_split(s, [&](auto tag) { return split_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); })
                                : dispatch_fwd(s, [&](auto tag) { return fwd_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
     if (info->n_partials <= 0) return RCF_EUNSUPPORTED;
-    info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0);
+    info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0) + (s.small ? 5 : 0);
     info->wgrad_workspace_floats = 0;
     info->wgrad_kernel_id = 0;
     if (d->w_mode == RCF_W_FORWARD) {
