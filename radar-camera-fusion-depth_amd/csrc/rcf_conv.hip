@@ -2085,10 +2085,16 @@ extern "C" int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const 
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = w.nchunk1 + w.nchunk2;
     const int p16 = w.px == 16;
-    float* zero = workspace + (size_t)w.nsplit * w.ktot * w.cop;
-    a.zero = zero;
+    // padding / out-of-image lanes of the DMA and split kernels read this page; allocated and cleared once per process
+    static float* zero_page = nullptr;
+    if (zero_page == nullptr) {
+        if (hipMalloc(reinterpret_cast<void**>(&zero_page), 256) != hipSuccess || hipMemset(zero_page, 0, 256) != hipSuccess) {
+            zero_page = nullptr;
+            return rcf_launch_status();
+        }
+    }
+    a.zero = zero_page;
     const bool dma = w.kind != K7S2 && (d->c1 % 4 == 0) && (d->c2 % 4 == 0);
-    if (dma && hipMemsetAsync(zero, 0, 64 * sizeof(float), st) != hipSuccess) return rcf_launch_status();
     if (w.split) {
         a.nchunk1 = ceil_div(d->c1, 32 * w.wci);
         a.nchunk2 = d->c2 > 0 ? ceil_div(d->c2, 32 * w.wci) : 0;
