@@ -147,6 +147,16 @@ int rcf_bn_act_bwd_apply(const float* dout, const float* z, const float* coef, c
                          const float* bcoef, float* dz, float* dres, int dres_accumulate,
                          long long n_pix, int c, int act, int has_res, void* stream);
 
+/* BatchNorm + LeakyReLU backward of the layer that feeds the output head (MultiScaleDecoder deconv0.conv -> output0,
+ * src/networks.py:1548-1555, :1649-1654), fused with rcf_head_bwd_dgrad: dout is recomputed from dlogit (N,H,W) and the head
+ * weight in both passes, so the C-channel gradient of the head's input is never materialised.  c <= 64.  partials
+ * [rcf_head_bn_blocks][2][c] feed rcf_bn_bwd_finalize like those of rcf_bn_act_bwd_reduce. */
+int rcf_head_bn_blocks(int n, int h, int w, int c);
+int rcf_head_bn_bwd_reduce(const float* dlogit, const float* w_head, const float* z, const float* coef, double* partials,
+                           int n, int h, int w, int c, void* stream);
+int rcf_head_bn_bwd_apply(const float* dlogit, const float* w_head, const float* z, const float* coef, const float* bcoef,
+                          float* dz, int n, int h, int w, int c, void* stream);
+
 /* Backward of rcf_fuse_fwd. partials[n_blocks][4][c]: (sum gw, sum gw*xhat_w, sum gp, sum gp*xhat_p). */
 int rcf_fuse_bwd_reduce(const float* dout, const float* zw, const float* coef_w, const float* zp,
                         const float* coef_p, double* partials, long long n_pix, int c, void* stream);

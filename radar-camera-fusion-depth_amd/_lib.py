@@ -45,6 +45,9 @@ _SIGNATURES = {
     'rcf_bn_act_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P]),
     'rcf_bn_bwd_finalize': (c_int, [_P, c_int, c_int, c_int, c_double, _P, _P, _P, _P]),
     'rcf_bn_act_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_longlong, c_int, c_int, c_int, _P]),
+    'rcf_head_bn_blocks': (c_int, [c_int, c_int, c_int, c_int]),
+    'rcf_head_bn_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'rcf_head_bn_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'rcf_fuse_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, _P]),
     'rcf_fuse_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_longlong, c_int, _P]),
     'rcf_maxpool3x3s2_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -252,6 +252,123 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const float* __re
     }
 }
 
+// ---- BatchNorm backward of the layer that feeds the 3x3 C->1 output head, fused with the head's input gradient:
+// dout[p][c] = sum_tap dlogit[p - (ky-1, kx-1)] * w_head[tap][c] is recomputed from the dlogit halo tile in LDS in both passes, so
+// the full-resolution C-channel gradient tensor is never written or read (saves one write and two reads of it per step).
+constexpr int HB_H = 8, HB_W = 32, HB_HX = HB_W + 2, HB_HY = HB_H + 2, HB_NP = HB_HX * HB_HY;
+
+template <int C4N>
+struct HeadBnTile {
+    static constexpr int C = 4 * C4N;
+    f32x4 k[9];
+    int cg;
+    __device__ __forceinline__ void init(const float* __restrict__ w_head, float* wl) {
+        for (int i = threadIdx.x; i < 9 * C; i += 256) wl[(i % 9) * C + i / 9] = w_head[i];   // OIHW [1][c][3][3] -> [tap][c]
+        __syncthreads();
+        cg = threadIdx.x % C4N;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) k[t] = *reinterpret_cast<const f32x4*>(wl + t * C + cg * 4);
+    }
+    static __device__ __forceinline__ void origin(int tile, int h, int w, int* img, int* oy0, int* ox0) {
+        const int tiles_x = (w + HB_W - 1) / HB_W, tiles_y = (h + HB_H - 1) / HB_H;
+        const int t2 = tile / tiles_x;
+        *img = t2 / tiles_y;
+        *oy0 = (t2 % tiles_y) * HB_H;
+        *ox0 = (tile % tiles_x) * HB_W;
+    }
+    static __device__ __forceinline__ void load_halo(float* D, const float* __restrict__ dl, int img, int oy0, int ox0, int h, int w) {
+        for (int hp = threadIdx.x; hp < HB_NP; hp += 256) {
+            const int hy = hp / HB_HX, hx = hp - hy * HB_HX;
+            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+            D[hp] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? dl[((size_t)img * h + iy) * w + ix] : 0.f;
+        }
+    }
+    __device__ __forceinline__ f32x4 dout(const float* D, int ty, int tx) const {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) s += D[(ty + 2 - ky) * HB_HX + tx + 2 - kx] * k[ky * 3 + kx];
+        return s;
+    }
+};
+
+template <int C4N>
+__global__ void __launch_bounds__(256) head_bn_bwd_reduce_kernel(const float* __restrict__ dlogit, const float* __restrict__ w_head,
+                                                                 const float* __restrict__ z, const float* __restrict__ coef,
+                                                                 double* __restrict__ partials, int n, int h, int w) {
+    constexpr int C = 4 * C4N;
+    extern __shared__ __attribute__((aligned(16))) double smd[];   // [256 / C4N][2][C] doubles for the final reduction
+    __shared__ __attribute__((aligned(16))) float wl[9 * C];
+    __shared__ float D[HB_NP];
+    HeadBnTile<C4N> hb;
+    hb.init(w_head, wl);
+    const Coef4 kc = load_coef(coef, C, hb.cg);
+    double s[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    const int ntiles = n * ((h + HB_H - 1) / HB_H) * ((w + HB_W - 1) / HB_W);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int img, oy0, ox0;
+        HeadBnTile<C4N>::origin(tile, h, w, &img, &oy0, &ox0);
+        __syncthreads();
+        HeadBnTile<C4N>::load_halo(D, dlogit, img, oy0, ox0, h, w);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < C4N; ++it) {
+            const int pix = (threadIdx.x + 256 * it) / C4N;
+            const int ty = pix / HB_W, tx = pix % HB_W;
+            const int oy = oy0 + ty, ox = ox0 + tx;
+            if (oy < h && ox < w) {
+                const f32x4 zz = ld4(z, (((size_t)img * h + oy) * w + ox) * C + hb.cg * 4);
+                const f32x4 g0 = hb.dout(D, ty, tx);
+                const f32x4 y = zz * kc.scale + kc.shift;
+                const f32x4 xh = (zz - kc.mean) * kc.invstd;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float g = g0[j] * rcf_lrelu_grad(y[j]);
+                    s[0][j] += (double)g;
+                    s[1][j] += (double)g * (double)xh[j];
+                }
+            }
+        }
+    }
+    block_reduce_store<2>(s, partials + (size_t)blockIdx.x * 2 * C, C, hb.cg, threadIdx.x / C4N, smd);
+}
+
+template <int C4N>
+__global__ void __launch_bounds__(256) head_bn_bwd_apply_kernel(const float* __restrict__ dlogit, const float* __restrict__ w_head,
+                                                                const float* __restrict__ z, const float* __restrict__ coef,
+                                                                const float* __restrict__ bcoef, float* __restrict__ dz, int n, int h,
+                                                                int w) {
+    constexpr int C = 4 * C4N;
+    __shared__ __attribute__((aligned(16))) float wl[9 * C];
+    __shared__ float D[HB_NP];
+    HeadBnTile<C4N> hb;
+    int img, oy0, ox0;
+    HeadBnTile<C4N>::origin(blockIdx.x, h, w, &img, &oy0, &ox0);
+    HeadBnTile<C4N>::load_halo(D, dlogit, img, oy0, ox0, h, w);
+    hb.init(w_head, wl);   // contains the barrier that also publishes D
+    const Coef4 kc = load_coef(coef, C, hb.cg);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bcoef + hb.cg * 4);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bcoef + C + hb.cg * 4);
+#pragma unroll
+    for (int it = 0; it < C4N; ++it) {
+        const int pix = (threadIdx.x + 256 * it) / C4N;
+        const int ty = pix / HB_W, tx = pix % HB_W;
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        if (oy < h && ox < w) {
+            const size_t i = (((size_t)img * h + oy) * w + ox) * C + hb.cg * 4;
+            const f32x4 zz = ld4(z, i);
+            const f32x4 g0 = hb.dout(D, ty, tx);
+            const f32x4 y = zz * kc.scale + kc.shift;
+            const f32x4 xh = (zz - kc.mean) * kc.invstd;
+            f32x4 r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = kc.scale[j] * (g0[j] * rcf_lrelu_grad(y[j]) - b0[j] - xh[j] * b1[j]);
+            st4(dz, i, r);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) fuse_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ zw,
                                                               const float* __restrict__ coef_w, const float* __restrict__ zp,
                                                               const float* __restrict__ coef_p, double* __restrict__ partials,
@@ -499,5 +616,49 @@ extern "C" int rcf_fuse_bwd_apply(const float* dout, const float* zw, const floa
     if (!c4_ok(c)) return RCF_EUNSUPPORTED;
     hipLaunchKernelGGL(fuse_bwd_apply_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, dout, zw, coef_w, zp,
                        coef_p, bcoef_w, bcoef_p, dzw, dzp, dimg, dimg_accumulate, n_pix, c);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_head_bn_blocks(int n, int h, int w, int c) {
+    if (n <= 0 || h <= 0 || w <= 0 || !c4_ok(c) || (c >> 2) > 16) return RCF_EINVAL;
+    const long long nt = (long long)n * ((h + HB_H - 1) / HB_H) * ((w + HB_W - 1) / HB_W);
+    return (int)(nt < EW_MAX_BLOCKS ? nt : EW_MAX_BLOCKS);
+}
+
+extern "C" int rcf_head_bn_bwd_reduce(const float* dlogit, const float* w_head, const float* z, const float* coef, double* partials,
+                                      int n, int h, int w, int c, void* stream) {
+    if (!dlogit || !w_head || !z || !coef || !partials) return RCF_EINVAL;
+    const int nb = rcf_head_bn_blocks(n, h, w, c);
+    if (nb <= 0) return RCF_EUNSUPPORTED;
+    const int c4n = c >> 2;
+    const size_t lds = (size_t)(256 / c4n) * 2 * c * sizeof(double);
+    hipStream_t st = (hipStream_t)stream;
+#define RCF_HBR(N) hipLaunchKernelGGL(head_bn_bwd_reduce_kernel<N>, dim3(nb), dim3(256), lds, st, dlogit, w_head, z, coef, partials, n, h, w)
+    switch (c4n) {
+        case 1: RCF_HBR(1); break;
+        case 2: RCF_HBR(2); break;
+        case 4: RCF_HBR(4); break;
+        case 8: RCF_HBR(8); break;
+        default: RCF_HBR(16); break;
+    }
+#undef RCF_HBR
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_head_bn_bwd_apply(const float* dlogit, const float* w_head, const float* z, const float* coef, const float* bcoef,
+                                     float* dz, int n, int h, int w, int c, void* stream) {
+    if (!dlogit || !w_head || !z || !coef || !bcoef || !dz) return RCF_EINVAL;
+    if (rcf_head_bn_blocks(n, h, w, c) <= 0) return RCF_EUNSUPPORTED;
+    const unsigned nt = (unsigned)n * ((h + HB_H - 1) / HB_H) * ((w + HB_W - 1) / HB_W);
+    hipStream_t st = (hipStream_t)stream;
+#define RCF_HBA(N) hipLaunchKernelGGL(head_bn_bwd_apply_kernel<N>, dim3(nt), dim3(256), 0, st, dlogit, w_head, z, coef, bcoef, dz, n, h, w)
+    switch (c >> 2) {
+        case 1: RCF_HBA(1); break;
+        case 2: RCF_HBA(2); break;
+        case 4: RCF_HBA(4); break;
+        case 8: RCF_HBA(8); break;
+        default: RCF_HBA(16); break;
+    }
+#undef RCF_HBA
     return rcf_launch_status();
 }

@@ -26,12 +26,14 @@ BN_MOMENTUM = 0.1
 
 class Act(object):
     '''An activation tensor and (during backward) its gradient accumulator.'''
-    __slots__ = ('t', 'g', 'needs_grad')
+    __slots__ = ('t', 'g', 'needs_grad', 'head_fusable', 'g_head')
 
     def __init__(self, t, needs_grad=True):
         self.t = t
         self.g = None
         self.needs_grad = needs_grad
+        self.head_fusable = False   # produced by a plain conv+BN+lrelu block: its BN backward can absorb the head's dgrad
+        self.g_head = None          # (dlogit, head weight): the gradient in un-materialised form
 
 
 class Engine(object):
@@ -226,12 +228,29 @@ class Engine(object):
         n_pix = z.shape[0] * z.shape[1] * z.shape[2]
         c = z.shape[3]
         out = Act(torch.empty_like(z))
+        out.head_fusable = res is None
         ops.bn_act_fwd(z, coef, None if res is None else res.t, out.t, n_pix, c, RCF_ACT_LEAKY_RELU)
         if self.tape is not None:
             bn = layer.batch_norm
             batch_stats = self.training
 
             def backward():
+                if out.g is None and out.g_head is not None:
+                    # the only consumer was the output head: its input gradient is recomputed inside both BN-backward passes
+                    dlogit, w_head = out.g_head
+                    out.g_head = None
+                    nb = ops.head_bn_blocks(z.shape[0], z.shape[1], z.shape[2], c)
+                    bpart = torch.empty((nb, 2, c), dtype=torch.float64, device=z.device)
+                    ops.head_bn_bwd_reduce(dlogit, w_head, z, coef, bpart)
+                    bcoef = self._new((2, c), z)
+                    ops.bn_bwd_finalize(bpart, nb, 2 * c, c, n_pix, bcoef, self.grad_of(bn.weight), self.grad_of(bn.bias))
+                    if not batch_stats:
+                        bcoef.zero_()
+                    self._wgrad_done(bn.weight, bn.bias)
+                    dz = torch.empty_like(z)
+                    ops.head_bn_bwd_apply(dlogit, w_head, z, coef, bcoef, dz)
+                    self._conv_backward(layer, desc, info, x, x2, dz)
+                    return
                 dout = out.g
                 nb = ops.ew_blocks(n_pix, c)
                 bpart = torch.empty((nb, 2, c), dtype=torch.float64, device=z.device)
@@ -365,8 +384,11 @@ class Engine(object):
                 if x.needs_grad:
                     if x.g is not None:
                         raise RuntimeError('head input has another consumer')
-                    x.g = torch.empty_like(x.t)
-                    ops.head_bwd_dgrad(dlogit, weight.detach(), x.g)
+                    if x.head_fusable and ops.head_bn_blocks(n, h, w, c) > 0:
+                        x.g_head = (dlogit, weight.detach())   # consumed by the producer's BatchNorm backward
+                    else:
+                        x.g = torch.empty_like(x.t)
+                        ops.head_bwd_dgrad(dlogit, weight.detach(), x.g)
             self.tape.append(backward)
         return depth
 

@@ -240,6 +240,23 @@ def bn_bwd_finalize(partials, n_blocks, stride, c, count, bcoef, dgamma, dbeta):
                                           _f32(dbeta), _stream()), 'rcf_bn_bwd_finalize')
 
 
+def head_bn_blocks(n, h, w, c):
+    """Partial rows of head_bn_bwd_reduce, or <= 0 when the fused path does not cover the shape."""
+    return _lib.load().rcf_head_bn_blocks(n, h, w, c)
+
+
+def head_bn_bwd_reduce(dlogit, w_head, z, coef, partials):
+    n, h, w, c = z.shape
+    check(_lib.load().rcf_head_bn_bwd_reduce(_f32(dlogit), _f32(w_head), _f32(z), _f32(coef), _f64(partials), n, h, w, c, _stream()),
+          'rcf_head_bn_bwd_reduce')
+
+
+def head_bn_bwd_apply(dlogit, w_head, z, coef, bcoef, dz):
+    n, h, w, c = z.shape
+    check(_lib.load().rcf_head_bn_bwd_apply(_f32(dlogit), _f32(w_head), _f32(z), _f32(coef), _f32(bcoef), _f32(dz), n, h, w, c,
+                                            _stream()), 'rcf_head_bn_bwd_apply')
+
+
 def bn_act_bwd_apply(dout, z, coef, out, bcoef, dz, dres, dres_accumulate, n_pix, c, act, has_res):
     check(_lib.load().rcf_bn_act_bwd_apply(_f32(dout), _f32(z), _f32(coef), _f32(out), _f32(bcoef), _f32(dz), _f32(dres),
                                            1 if dres_accumulate else 0, n_pix, c, act, 1 if has_res else 0, _stream()),

@@ -535,3 +535,45 @@ def test_split_bf16_conv_is_fp32_accurate(ops, case, monkeypatch):
     print('split vs f32-mfma error against fp64:', {k_: '%.2e' % v for k_, v in errs.items()})
     assert errs['fwd1'] < 2.0 * errs['fwd0'] + 1e-7 and errs['dx1'] < 2.0 * errs['dx0'] + 1e-7
     assert errs['fwd1'] < 1e-5 and errs['dx1'] < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('c', [4, 32])
+def test_head_dgrad_fused_into_bn_backward(ops, c):
+    '''rcf_head_bn_bwd_reduce / _apply == rcf_head_bwd_dgrad followed by rcf_bn_act_bwd_reduce / _apply (same sums, same dz).'''
+    import torch
+    torch.manual_seed(7)
+    dev = 'cuda'
+    n, h, w = 2, 21, 45
+    z = torch.randn(n, h, w, c, device=dev)
+    dlogit = torch.randn(n, h, w, device=dev)
+    w_head = torch.randn(1, c, 3, 3, device=dev) * 0.2
+    coef = torch.stack([torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.1, torch.randn(c, device=dev) * 0.1,
+                        torch.rand(c, device=dev) + 0.5]).contiguous()
+    n_pix = n * h * w
+    # unfused reference path (both HIP): materialise dout, then the generic BN backward
+    dout = torch.empty_like(z)
+    ops.head_bwd_dgrad(dlogit, w_head, dout)
+    nb = ops.ew_blocks(n_pix, c)
+    part = torch.empty(nb, 2, c, dtype=torch.float64, device=dev)
+    out = torch.empty_like(z)
+    ops.bn_act_fwd(z, coef, None, out, n_pix, c, 1)
+    ops.bn_act_bwd_reduce(dout, z, coef, out, part, n_pix, c, 1, False)
+    bcoef = torch.empty(2, c, device=dev)
+    dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    ops.bn_bwd_finalize(part, nb, 2 * c, c, n_pix, bcoef, dg, db)
+    dz = torch.empty_like(z)
+    ops.bn_act_bwd_apply(dout, z, coef, out, bcoef, dz, None, False, n_pix, c, 1, False)
+    # fused path
+    nb2 = ops.head_bn_blocks(n, h, w, c)
+    assert nb2 > 0
+    part2 = torch.empty(nb2, 2, c, dtype=torch.float64, device=dev)
+    ops.head_bn_bwd_reduce(dlogit, w_head, z, coef, part2)
+    bcoef2 = torch.empty(2, c, device=dev)
+    dg2, db2 = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    ops.bn_bwd_finalize(part2, nb2, 2 * c, c, n_pix, bcoef2, dg2, db2)
+    dz2 = torch.empty_like(z)
+    ops.head_bn_bwd_apply(dlogit, w_head, z, coef, bcoef2, dz2)
+    np.testing.assert_allclose(dg2.cpu().numpy(), dg.cpu().numpy(), rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(db2.cpu().numpy(), db.cpu().numpy(), rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(dz2.cpu().numpy(), dz.cpu().numpy(), rtol=2e-5, atol=2e-6)
