@@ -180,6 +180,10 @@ int rcf_upsample_nearest_bwd(const float* dup, float* dsrc, int dsrc_accumulate,
  * w: [1][C][3][3] OIHW.  logit and depth: [N][H][W]. */
 int rcf_head_fwd(const float* x, const float* w, float* logit, float* depth,
                  int n, int h, int w_, int c, float min_depth, float max_depth, void* stream);
+/* Same with the previous block's BatchNorm + LeakyReLU applied on load: z is that block's RAW conv output and coef its
+ * rcf_bn_finalize coefficients, so its activation tensor never has to be written (c <= 64). */
+int rcf_head_fwd_bn(const float* z, const float* coef, const float* w, float* logit, float* depth, int n, int h, int w_, int c,
+                    float min_depth, float max_depth, void* stream);
 /* dlogit = ddepth * d(depth)/d(logit). */
 int rcf_head_bwd_logit(const float* ddepth, const float* logit, float* dlogit, long long n_pix,
                        float min_depth, float max_depth, void* stream);
@@ -187,6 +191,8 @@ int rcf_head_bwd_dgrad(const float* dlogit, const float* w, float* dx, int n, in
 size_t rcf_head_wgrad_workspace_floats(int n, int h, int w_, int c);
 int rcf_head_bwd_wgrad(const float* x, const float* dlogit, float* dw, float* workspace,
                        int n, int h, int w_, int c, void* stream);
+int rcf_head_bwd_wgrad_bn(const float* z, const float* coef, const float* dlogit, float* dw, float* workspace, int n, int h,
+                          int w_, int c, void* stream);
 
 /* Masked L1 of FusionNetModel.compute_loss, loss_func='l1' (src/fusionnet_model.py:209-253;
  * src/fusionnet_losses.py:19-32): ground truth is zeroed where lidar > 0, then

@@ -54,10 +54,12 @@ _SIGNATURES = {
     'rcf_maxpool3x3s2_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'rcf_upsample_nearest_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'rcf_head_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
+    'rcf_head_fwd_bn': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
     'rcf_head_bwd_logit': (c_int, [_P, _P, _P, c_longlong, c_float, c_float, _P]),
     'rcf_head_bwd_dgrad': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'rcf_head_wgrad_workspace_floats': (c_size_t, [c_int, c_int, c_int, c_int]),
     'rcf_head_bwd_wgrad': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'rcf_head_bwd_wgrad_bn': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'rcf_loss_workspace_floats': (c_size_t, [c_longlong]),
     'rcf_l1_loss_fwd': (c_int, [_P, _P, _P, _P, _P, c_longlong, _P]),
     'rcf_l1_loss_value': (c_int, [_P, c_float, _P, _P]),

@@ -232,9 +232,9 @@ __device__ __forceinline__ void head_tile_origin(int tile, int h, int w, int* im
 // forward: per halo pixel the nine per-tap dot products T[pixel][tap] = <x[pixel], w[tap]> (x read once, cross-lane sum by DPP),
 // then logit[q] = sum_tap T[q + tap offset][tap] from LDS.
 template <int C4N>
-__global__ void __launch_bounds__(256) head_fwd_tile_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
-                                                            float* __restrict__ logit, float* __restrict__ depth, int n, int h, int w,
-                                                            float dmin, float dmax) {
+__global__ void __launch_bounds__(256) head_fwd_tile_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                            const float* __restrict__ wgt, float* __restrict__ logit,
+                                                            float* __restrict__ depth, int n, int h, int w, float dmin, float dmax) {
     constexpr int C = 4 * C4N;
     __shared__ __attribute__((aligned(16))) float wl[9 * C];
     __shared__ float T[HT_NP * 9];
@@ -246,6 +246,13 @@ __global__ void __launch_bounds__(256) head_fwd_tile_kernel(const float* __restr
     f32x4 k[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) k[t] = *reinterpret_cast<const f32x4*>(wl + t * C + cg * 4);
+    // coef != nullptr: x is the raw conv output z of the previous block and y = lrelu(z * scale + shift) is applied on load
+    // (that block's activation tensor is then never written)
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (coef != nullptr) {
+        sc = *reinterpret_cast<const f32x4*>(coef + cg * 4);
+        sh = *reinterpret_cast<const f32x4*>(coef + C + cg * 4);
+    }
     constexpr int NIT = (HT_NP * C4N + 255) / 256;
 #pragma unroll 4
     for (int it = 0; it < NIT; ++it) {
@@ -255,6 +262,10 @@ __global__ void __launch_bounds__(256) head_fwd_tile_kernel(const float* __restr
         const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
         const bool ok = hp < HT_NP && iy >= 0 && iy < h && ix >= 0 && ix < w;
         f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)img * h + (ok ? iy : 0)) * w + (ok ? ix : 0)) * C + cg * 4);
+        if (coef != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = rcf_lrelu(v[j] * sc[j] + sh[j]);
+        }
         if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -313,8 +324,9 @@ __global__ void __launch_bounds__(256) head_bwd_dgrad_tile_kernel(const float* _
 
 // weight gradient: persistent blocks over tiles; acc[tap] += dl[p - offset] * x[p] with the dl halo tile in LDS
 template <int C4N>
-__global__ void __launch_bounds__(256) head_bwd_wgrad_tile_kernel(const float* __restrict__ x, const float* __restrict__ dl,
-                                                                  float* __restrict__ ws, int n, int h, int w) {
+__global__ void __launch_bounds__(256) head_bwd_wgrad_tile_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                                  const float* __restrict__ dl, float* __restrict__ ws, int n, int h,
+                                                                  int w) {
     constexpr int C = 4 * C4N;
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [256 / C4N][9][C] for the final reduction; D aliases its start
     float* D = sm;
@@ -326,6 +338,11 @@ __global__ void __launch_bounds__(256) head_bwd_wgrad_tile_kernel(const float* _
         for (int j = 0; j < 4; ++j) acc[t][j] = 0.f;
     const int tiles_x = (w + HT_W - 1) / HT_W, tiles_y = (h + HT_H - 1) / HT_H;
     const int ntiles = n * tiles_x * tiles_y;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (coef != nullptr) {   // x is the previous block's raw conv output: apply its BatchNorm + lrelu on load
+        sc = *reinterpret_cast<const f32x4*>(coef + cg * 4);
+        sh = *reinterpret_cast<const f32x4*>(coef + C + cg * 4);
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int img, oy0, ox0;
         head_tile_origin(tile, h, w, &img, &oy0, &ox0);
@@ -336,6 +353,10 @@ __global__ void __launch_bounds__(256) head_bwd_wgrad_tile_kernel(const float* _
             const int oy = oy0 + pix / HT_W, ox = ox0 + pix % HT_W;
             const bool ok = oy < h && ox < w;
             v[it] = *reinterpret_cast<const f32x4*>(x + (((size_t)img * h + (ok ? oy : 0)) * w + (ok ? ox : 0)) * C + cg * 4);
+            if (coef != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[it][j] = rcf_lrelu(v[it][j] * sc[j] + sh[j]);
+            }
             if (!ok) v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();   // previous tile's D readers are done
@@ -662,15 +683,29 @@ static bool head_c_ok(int c) {
     return (c4 & (c4 - 1)) == 0 && c4 <= 64;
 }
 
+static int head_fwd_impl(const float* x, const float* coef, const float* w, float* logit, float* depth, int n, int h, int w_, int c,
+                         float min_depth, float max_depth, void* stream);
+
 extern "C" int rcf_head_fwd(const float* x, const float* w, float* logit, float* depth, int n, int h, int w_, int c,
                             float min_depth, float max_depth, void* stream) {
+    return head_fwd_impl(x, nullptr, w, logit, depth, n, h, w_, c, min_depth, max_depth, stream);
+}
+
+extern "C" int rcf_head_fwd_bn(const float* z, const float* coef, const float* w, float* logit, float* depth, int n, int h, int w_,
+                               int c, float min_depth, float max_depth, void* stream) {
+    if (!coef || (c >> 2) > 16) return coef ? RCF_EUNSUPPORTED : RCF_EINVAL;
+    return head_fwd_impl(z, coef, w, logit, depth, n, h, w_, c, min_depth, max_depth, stream);
+}
+
+static int head_fwd_impl(const float* x, const float* coef, const float* w, float* logit, float* depth, int n, int h, int w_, int c,
+                         float min_depth, float max_depth, void* stream) {
     if (!x || !w || !logit || !depth || n <= 0 || h <= 0 || w_ <= 0) return RCF_EINVAL;
     if (!head_c_ok(c)) return RCF_EUNSUPPORTED;
     const int c4n = c >> 2;
     if (c4n <= 16) {
         const unsigned nt = (unsigned)n * ((h + HT_H - 1) / HT_H) * ((w_ + HT_W - 1) / HT_W);
         hipStream_t st = (hipStream_t)stream;
-#define RCF_HEAD_FWD(N) hipLaunchKernelGGL(head_fwd_tile_kernel<N>, dim3(nt), dim3(256), 0, st, x, w, logit, depth, n, h, w_, min_depth, max_depth)
+#define RCF_HEAD_FWD(N) hipLaunchKernelGGL(head_fwd_tile_kernel<N>, dim3(nt), dim3(256), 0, st, x, coef, w, logit, depth, n, h, w_, min_depth, max_depth)
         switch (c4n) {
             case 1: RCF_HEAD_FWD(1); break;
             case 2: RCF_HEAD_FWD(2); break;
@@ -727,8 +762,22 @@ extern "C" size_t rcf_head_wgrad_workspace_floats(int n, int h, int w_, int c) {
     return (size_t)HEAD_WG_BLOCKS * 9 * (size_t)c;
 }
 
+static int head_bwd_wgrad_impl(const float* x, const float* coef, const float* dlogit, float* dw, float* workspace, int n, int h,
+                               int w_, int c, void* stream);
+
 extern "C" int rcf_head_bwd_wgrad(const float* x, const float* dlogit, float* dw, float* workspace, int n, int h, int w_, int c,
                                   void* stream) {
+    return head_bwd_wgrad_impl(x, nullptr, dlogit, dw, workspace, n, h, w_, c, stream);
+}
+
+extern "C" int rcf_head_bwd_wgrad_bn(const float* z, const float* coef, const float* dlogit, float* dw, float* workspace, int n,
+                                     int h, int w_, int c, void* stream) {
+    if (!coef || (c >> 2) > 16) return coef ? RCF_EUNSUPPORTED : RCF_EINVAL;
+    return head_bwd_wgrad_impl(z, coef, dlogit, dw, workspace, n, h, w_, c, stream);
+}
+
+static int head_bwd_wgrad_impl(const float* x, const float* coef, const float* dlogit, float* dw, float* workspace, int n, int h,
+                               int w_, int c, void* stream) {
     if (!x || !dlogit || !dw || !workspace || n <= 0 || h <= 0 || w_ <= 0) return RCF_EINVAL;
     if (!head_c_ok(c)) return RCF_EUNSUPPORTED;
     const int ppb = 256 / (c >> 2);
@@ -741,7 +790,7 @@ extern "C" int rcf_head_bwd_wgrad(const float* x, const float* dlogit, float* dw
         size_t lds = (size_t)ppb * 9 * c * sizeof(float);
         if (lds < HT_NP * sizeof(float)) lds = HT_NP * sizeof(float);
         hipStream_t st = (hipStream_t)stream;
-#define RCF_HEAD_WG(N) hipLaunchKernelGGL(head_bwd_wgrad_tile_kernel<N>, dim3((unsigned)nb), dim3(256), lds, st, x, dlogit, workspace, n, h, w_)
+#define RCF_HEAD_WG(N) hipLaunchKernelGGL(head_bwd_wgrad_tile_kernel<N>, dim3((unsigned)nb), dim3(256), lds, st, x, coef, dlogit, workspace, n, h, w_)
         switch (c4n) {
             case 1: RCF_HEAD_WG(1); break;
             case 2: RCF_HEAD_WG(2); break;

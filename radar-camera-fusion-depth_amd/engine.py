@@ -26,7 +26,7 @@ BN_MOMENTUM = 0.1
 
 class Act(object):
     '''An activation tensor and (during backward) its gradient accumulator.'''
-    __slots__ = ('t', 'g', 'needs_grad', 'head_fusable', 'g_head')
+    __slots__ = ('t', 'g', 'needs_grad', 'head_fusable', 'g_head', 'z', 'coef')
 
     def __init__(self, t, needs_grad=True):
         self.t = t
@@ -34,6 +34,8 @@ class Act(object):
         self.needs_grad = needs_grad
         self.head_fusable = False   # produced by a plain conv+BN+lrelu block: its BN backward can absorb the head's dgrad
         self.g_head = None          # (dlogit, head weight): the gradient in un-materialised form
+        self.z = None               # deferred activation: t is None and the consumer applies coef (BN + lrelu) to z on load
+        self.coef = None
 
 
 class Engine(object):
@@ -216,7 +218,7 @@ class Engine(object):
         return coef
 
     # ------------------------------------------------------------------ layer ops
-    def conv_bn_act(self, layer, x, x2=None, up_hw=None, res=None):
+    def conv_bn_act(self, layer, x, x2=None, up_hw=None, res=None, defer_act=False):
         '''
         net_utils.Conv2d.forward (src/net_utils.py:84-91) with BN + leaky_relu (+ the residual tail of
         ResNetBlock.forward when res is given: lrelu(lrelu(BN(conv)) + res), src/net_utils.py:311-323).
@@ -227,9 +229,14 @@ class Engine(object):
         coef = self._bn_coef(layer, partials, info, z)
         n_pix = z.shape[0] * z.shape[1] * z.shape[2]
         c = z.shape[3]
-        out = Act(torch.empty_like(z))
+        if defer_act and res is None and ops.head_bn_blocks(z.shape[0], z.shape[1], z.shape[2], c) > 0:
+            # the only consumer is the output head, which applies BN + lrelu to z as it loads it: the activation is never written
+            out = Act(None)
+            out.z, out.coef = z, coef
+        else:
+            out = Act(torch.empty_like(z))
+            ops.bn_act_fwd(z, coef, None if res is None else res.t, out.t, n_pix, c, RCF_ACT_LEAKY_RELU)
         out.head_fusable = res is None
-        ops.bn_act_fwd(z, coef, None if res is None else res.t, out.t, n_pix, c, RCF_ACT_LEAKY_RELU)
         if self.tape is not None:
             bn = layer.batch_norm
             batch_stats = self.training
@@ -251,6 +258,8 @@ class Engine(object):
                     ops.head_bn_bwd_apply(dlogit, w_head, z, coef, bcoef, dz)
                     self._conv_backward(layer, desc, info, x, x2, dz)
                     return
+                if out.t is None:
+                    raise RuntimeError('deferred activation reached the generic BatchNorm backward')
                 dout = out.g
                 nb = ops.ew_blocks(n_pix, c)
                 bpart = torch.empty((nb, 2, c), dtype=torch.float64, device=z.device)
@@ -304,6 +313,8 @@ class Engine(object):
             batch_stats = self.training
 
             def backward():
+                if out.t is None:
+                    raise RuntimeError('deferred activation reached the generic BatchNorm backward')
                 dout = out.g
                 nb = ops.ew_blocks(n_pix, c)
                 bpart = torch.empty((nb, 4, c), dtype=torch.float64, device=zw.device)
@@ -356,30 +367,32 @@ class Engine(object):
         shortcut = self.conv_plain(block.projection, x) if block.uses_projection else x
         return self.conv_bn_act(block.conv2, c1, res=shortcut)
 
-    def decoder_block(self, block, x, skip=None, shape=None):
-        '''DecoderBlock.forward (src/net_utils.py:535-569), deconv_type 'up'.'''
+    def decoder_block(self, block, x, skip=None, shape=None, defer_act=False):
+        '''DecoderBlock.forward (src/net_utils.py:535-569), deconv_type 'up'.  defer_act: the block's output feeds the head only.'''
         if skip is not None:
             shape = skip.t.shape[1:3]
         elif shape is None:
             shape = (2 * x.t.shape[1], 2 * x.t.shape[2])
         deconv = self.conv_bn_act(block.deconv.conv, x, up_hw=shape)
         if block.skip_channels > 0:
-            return self.conv_bn_act(block.conv, deconv, x2=skip)
-        return self.conv_bn_act(block.conv, deconv)
+            return self.conv_bn_act(block.conv, deconv, x2=skip, defer_act=defer_act)
+        return self.conv_bn_act(block.conv, deconv, defer_act=defer_act)
 
     def head(self, layer, x):
         '''output0 (src/networks.py:1548-1555, :1654) + d = min/(sigmoid(o)+min/max) (src/fusionnet_model.py:162-165).'''
-        n, h, w, c = x.t.shape
+        xin = x.t if x.t is not None else x.z     # deferred activation: raw conv output + coefficients
+        xcoef = None if x.t is not None else x.coef
+        n, h, w, c = xin.shape
         weight = layer.conv.weight
-        logit = self._new((n, h, w), x.t)
-        depth = Act(self._new((n, h, w), x.t))
-        ops.head_fwd(x.t, weight.detach(), logit, depth.t, self.dmin, self.dmax)
+        logit = self._new((n, h, w), xin)
+        depth = Act(self._new((n, h, w), xin))
+        ops.head_fwd(xin, weight.detach(), logit, depth.t, self.dmin, self.dmax, coef=xcoef)
         if self.tape is not None:
             def backward():
                 dlogit = torch.empty_like(logit)
                 ops.head_bwd_logit(depth.g, logit, dlogit, self.dmin, self.dmax)
                 depth.g = None
-                ops.head_bwd_wgrad(x.t, dlogit, self.grad_of(weight))
+                ops.head_bwd_wgrad(xin, dlogit, self.grad_of(weight), coef=xcoef)
                 self._wgrad_done(weight)
                 if x.needs_grad:
                     if x.g is not None:
@@ -387,7 +400,7 @@ class Engine(object):
                     if x.head_fusable and ops.head_bn_blocks(n, h, w, c) > 0:
                         x.g_head = (dlogit, weight.detach())   # consumed by the producer's BatchNorm backward
                     else:
-                        x.g = torch.empty_like(x.t)
+                        x.g = torch.empty_like(xin)
                         ops.head_bwd_dgrad(dlogit, weight.detach(), x.g)
             self.tape.append(backward)
         return depth
@@ -421,9 +434,9 @@ class Engine(object):
             x = self.decoder_block(getattr(dec, name), x, skip=skips[n])
             n -= 1
         if n == 0:
-            x = self.decoder_block(dec.deconv0, x, skip=skips[0])
+            x = self.decoder_block(dec.deconv0, x, skip=skips[0], defer_act=True)
         else:
-            x = self.decoder_block(dec.deconv0, x, shape=image_nhwc.shape[1:3])
+            x = self.decoder_block(dec.deconv0, x, shape=image_nhwc.shape[1:3], defer_act=True)
         out = self.head(dec.output0, x)
         tape, self.tape = self.tape, None
         return out, tape

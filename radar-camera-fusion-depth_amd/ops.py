@@ -292,10 +292,15 @@ def upsample_nearest_bwd(dup, dsrc, accumulate):
                                                _stream()), 'rcf_upsample_nearest_bwd')
 
 
-def head_fwd(x, w, logit, depth, dmin, dmax):
+def head_fwd(x, w, logit, depth, dmin, dmax, coef=None):
+    """coef given: x is the previous block's raw conv output z; its BatchNorm + lrelu is applied on load."""
     n, h, ww, c = x.shape
-    check(_lib.load().rcf_head_fwd(_f32(x), _f32(w), _f32(logit), _f32(depth), n, h, ww, c, dmin, dmax, _stream()),
-          'rcf_head_fwd')
+    if coef is None:
+        check(_lib.load().rcf_head_fwd(_f32(x), _f32(w), _f32(logit), _f32(depth), n, h, ww, c, dmin, dmax, _stream()),
+              'rcf_head_fwd')
+    else:
+        check(_lib.load().rcf_head_fwd_bn(_f32(x), _f32(coef), _f32(w), _f32(logit), _f32(depth), n, h, ww, c, dmin, dmax,
+                                          _stream()), 'rcf_head_fwd_bn')
 
 
 def head_bwd_logit(ddepth, logit, dlogit, dmin, dmax):
@@ -308,12 +313,16 @@ def head_bwd_dgrad(dlogit, w, dx):
     check(_lib.load().rcf_head_bwd_dgrad(_f32(dlogit), _f32(w), _f32(dx), n, h, ww, c, _stream()), 'rcf_head_bwd_dgrad')
 
 
-def head_bwd_wgrad(x, dlogit, dw):
+def head_bwd_wgrad(x, dlogit, dw, coef=None):
     n, h, ww, c = x.shape
     nws = _lib.load().rcf_head_wgrad_workspace_floats(n, h, ww, c)
     ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-    check(_lib.load().rcf_head_bwd_wgrad(_f32(x), _f32(dlogit), _f32(dw), _f32(ws), n, h, ww, c, _stream()),
-          'rcf_head_bwd_wgrad')
+    if coef is None:
+        check(_lib.load().rcf_head_bwd_wgrad(_f32(x), _f32(dlogit), _f32(dw), _f32(ws), n, h, ww, c, _stream()),
+              'rcf_head_bwd_wgrad')
+    else:
+        check(_lib.load().rcf_head_bwd_wgrad_bn(_f32(x), _f32(coef), _f32(dlogit), _f32(dw), _f32(ws), n, h, ww, c, _stream()),
+              'rcf_head_bwd_wgrad_bn')
 
 
 def l1_loss_fwd(depth, gt, lidar, sums):

@@ -577,3 +577,30 @@ def test_head_dgrad_fused_into_bn_backward(ops, c):
     np.testing.assert_allclose(dg2.cpu().numpy(), dg.cpu().numpy(), rtol=2e-5, atol=1e-5)
     np.testing.assert_allclose(db2.cpu().numpy(), db.cpu().numpy(), rtol=2e-5, atol=1e-5)
     np.testing.assert_allclose(dz2.cpu().numpy(), dz.cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('c', [4, 32])
+def test_head_applies_previous_bn_on_load(ops, c):
+    '''rcf_head_fwd_bn / rcf_head_bwd_wgrad_bn on the raw conv output == rcf_bn_act_fwd followed by the plain head kernels.'''
+    import torch
+    torch.manual_seed(11)
+    dev = 'cuda'
+    n, h, w = 2, 19, 37
+    z = torch.randn(n, h, w, c, device=dev)
+    coef = torch.stack([torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.3, torch.zeros(c, device=dev),
+                        torch.ones(c, device=dev)]).contiguous()
+    w_head = torch.randn(1, c, 3, 3, device=dev) * 0.2
+    y = torch.empty_like(z)
+    ops.bn_act_fwd(z, coef, None, y, n * h * w, c, 1)
+    logit, depth = torch.empty(n, h, w, device=dev), torch.empty(n, h, w, device=dev)
+    logit2, depth2 = torch.empty_like(logit), torch.empty_like(depth)
+    ops.head_fwd(y, w_head, logit, depth, 1.0, 100.0)
+    ops.head_fwd(z, w_head, logit2, depth2, 1.0, 100.0, coef=coef)
+    np.testing.assert_allclose(logit2.cpu().numpy(), logit.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(depth2.cpu().numpy(), depth.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    dlogit = torch.randn(n, h, w, device=dev)
+    dw, dw2 = torch.empty_like(w_head), torch.empty_like(w_head)
+    ops.head_bwd_wgrad(y, dlogit, dw)
+    ops.head_bwd_wgrad(z, dlogit, dw2, coef=coef)
+    np.testing.assert_allclose(dw2.cpu().numpy(), dw.cpu().numpy(), rtol=1e-4, atol=1e-4)
