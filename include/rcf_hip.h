@@ -81,6 +81,8 @@ typedef struct rcf_conv_info {
     size_t wgrad_workspace_floats; /* workspace for rcf_conv2d_wgrad on the same (forward) descriptor */
     int kernel_id;               /* which tile configuration was selected (for profiling/logs) */
     int wgrad_kernel_id;         /* same for the weight-gradient kernel of a forward descriptor (0: none) */
+    int bn_on_load;              /* 1: rcf_conv2d_fwd_bn accepts this descriptor (raw conv outputs + BN coefficients as inputs) */
+    int wgrad_bn_on_load;        /* 1: rcf_conv2d_wgrad_bn accepts it */
 } rcf_conv_info;
 
 const char* rcf_version(void);
@@ -100,12 +102,20 @@ int rcf_conv2d_pack_weights(const rcf_conv_desc* d, const float* w_oihw, float* 
  * rcf_bn_finalize -- the batch statistics of torch.nn.BatchNorm2d (src/net_utils.py:82,86). */
 int rcf_conv2d_fwd(const rcf_conv_desc* d, const float* in1, const float* in2, const float* packed,
                    float* out, double* stat_partials, void* stream);
+/* BatchNorm + LeakyReLU of the PRODUCING block applied while the operand is staged ("BN on load"): in1 / in2 are raw conv
+ * outputs z and coef1 / coef2 (nullable, one per source) the rcf_bn_finalize coefficients [4][c] of the block that produced
+ * them; the kernel uses y = lrelu(z * coef[0][c] + coef[1][c]).  That block's activation tensor (net_utils.Conv2d.forward,
+ * src/net_utils.py:84-91) is then never written.  Only where rcf_conv_info.bn_on_load is set; RCF_EUNSUPPORTED otherwise. */
+int rcf_conv2d_fwd_bn(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
+                      const float* packed, float* out, double* stat_partials, void* stream);
 
 /* Weight gradient of the conv described by the FORWARD descriptor d: dw[o][i][ky][kx] (OIHW, same layout as
  * the parameter) = sum over pixels of in[...] * dz[...].  Replaces autograd's conv weight backward behind
  * loss.backward() (src/fusionnet_main.py:398). */
 int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const float* in2, const float* dz,
                      float* dw_oihw, float* workspace, void* stream);
+int rcf_conv2d_wgrad_bn(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
+                        const float* dz, float* dw_oihw, float* workspace, void* stream);
 
 /* Phase weights.  w: the layer's OIHW 3x3 weight [o][i][3][3]; out: [4 phases (a*2+b)][O'][I'][2][2] with
  * (O',I') = (o,i) for RCF_PHASE_UP2X_FWD and (i,o) for the two DGRAD modes.  Each phase block is then packed with

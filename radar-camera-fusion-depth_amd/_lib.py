@@ -25,7 +25,8 @@ class ConvDesc(Structure):
 
 class ConvInfo(Structure):
     _fields_ = [('packed_weight_floats', c_size_t), ('n_partials', c_int),
-                ('wgrad_workspace_floats', c_size_t), ('kernel_id', c_int), ('wgrad_kernel_id', c_int)]
+                ('wgrad_workspace_floats', c_size_t), ('kernel_id', c_int), ('wgrad_kernel_id', c_int),
+                ('bn_on_load', c_int), ('wgrad_bn_on_load', c_int)]
 
 
 _P = c_void_p
@@ -35,7 +36,9 @@ _SIGNATURES = {
     'rcf_conv2d_query': (c_int, [POINTER(ConvDesc), POINTER(ConvInfo)]),
     'rcf_conv2d_pack_weights': (c_int, [POINTER(ConvDesc), _P, _P, _P]),
     'rcf_conv2d_fwd': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    'rcf_conv2d_fwd_bn': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'rcf_conv2d_wgrad': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    'rcf_conv2d_wgrad_bn': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'rcf_phase_weights': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'rcf_phase_wgrad_fold': (c_int, [_P, _P, c_int, c_int, _P]),
     'rcf_bn_finalize': (c_int, [_P, c_int, c_int, c_double, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P]),

@@ -28,6 +28,8 @@ namespace {
 struct ConvArgs {
     const float* in1;
     const float* in2;
+    const float* coef1;   // split kernels: in1 / in2 are RAW conv outputs of a BatchNorm + LeakyReLU block whose activation was
+    const float* coef2;   // never written; y = lrelu(z * coef[0][c] + coef[1][c]) is applied as the operand is staged (else null)
     const float* wp;
     float* out;
     double* stats;
@@ -415,8 +417,11 @@ struct SplitCfg {
     static constexpr int A_BYTES = 3 * A_PLANE_BYTES;
     static constexpr int B_PLANE_BYTES = KSX * BN * 32;    // one kernel row: 16 bf16 per (tap, co)
     static constexpr int B_PIECE_BYTES = 3 * B_PLANE_BYTES;
-    static constexpr int LDS_BYTES = A_BYTES + 2 * B_PIECE_BYTES;
+    static constexpr int COEF_MAX_C = 512;                 // input channels (both sources) of the BN-on-load table
+    static constexpr int COEF_BYTES = 2 * COEF_MAX_C * 4;
+    static constexpr int LDS_BYTES = A_BYTES + 2 * B_PIECE_BYTES + COEF_BYTES;
     static constexpr int WCHUNK_BYTES = KSY * B_PIECE_BYTES;   // one chunk of pre-split packed weights
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 };
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
@@ -429,11 +434,25 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char* As = smem_b;
     unsigned char* Bs = smem_b + C::A_BYTES;
+    float* coef_lds = reinterpret_cast<float*>(smem_b + C::A_BYTES + 2 * C::B_PIECE_BYTES);   // [2][c1 + c2]: scale, shift
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int li = lane & 31;
     const int lh = lane >> 5;
+    if (a.coef1 != nullptr || a.coef2 != nullptr) {   // BN-on-load table: identity (1, 0) for a source without coefficients
+        const int ctot = a.c1 + a.c2;
+        for (int i = tid; i < ctot; i += 256) {
+            const bool s1 = i < a.c1;
+            const float* cf = s1 ? a.coef1 : a.coef2;
+            const int cs = s1 ? a.c1 : a.c2, ci = s1 ? i : i - a.c1;
+            coef_lds[i] = cf ? cf[ci] : 1.f;
+            coef_lds[ctot + i] = cf ? cf[cs + ci] : 0.f;
+        }
+        // published by the first __syncthreads() of the kernel, which precedes every store_a that reads it... the prologue's
+        // store_a comes first: make it explicit
+        __syncthreads();
+    }
 
     int apix[C::MT];   // halo pixel of this lane's output pixel at tap (0, 0)
 #pragma unroll
@@ -454,6 +473,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
     int pix[NA];
     f32x4 ra[NA];
     unsigned okm = 0u;   // bit i: ra[i] holds real data (else the clamped load is replaced by zero at store time)
+    int tch = 0;         // first channel (in c1 + c2 numbering) of the staged quad, and whether its source is BN-on-load
+    bool ttf = false;
 
     auto setup = [&](int tile, bool first, int ph) {
         int t = tile;
@@ -514,6 +535,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
         const int cch = (first ? q : q - a.nchunk1) * 16 + (tid & 3) * 4;
         const bool cok = cch < csrc;
         const int cld = cok ? cch : 0;
+        tch = (first ? 0 : a.c1) + cld;
+        ttf = (first ? a.coef1 : a.coef2) != nullptr;
         okm = 0u;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -522,6 +545,11 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
         }
     };
     auto store_a = [&]() {
+        f32x4 tsc = {1.f, 1.f, 1.f, 1.f}, tsh = {0.f, 0.f, 0.f, 0.f};
+        if (ttf) {
+            tsc = *reinterpret_cast<const f32x4*>(coef_lds + tch);
+            tsh = *reinterpret_cast<const f32x4*>(coef_lds + a.c1 + a.c2 + tch);
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int p = (tid >> 2) + i * 64;
@@ -530,7 +558,9 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                 unsigned x0[4], x1[4], x2[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float x = ((okm >> i) & 1u) ? ra[i][e] : 0.f;
+                    float xv = ra[i][e];
+                    if (ttf) xv = rcf_lrelu(xv * tsc[e] + tsh[e]);   // the producer's BatchNorm + LeakyReLU, applied on load
+                    const float x = ((okm >> i) & 1u) ? xv : 0.f;
                     x0[e] = __float_as_uint(x) & 0xffff0000u;
                     const float r1 = x - __uint_as_float(x0[e]);
                     x1[e] = __float_as_uint(r1) & 0xffff0000u;
@@ -1135,7 +1165,8 @@ struct WsCfg {
     static constexpr int XPL = NCI * SX, DPL = NCO * SD;
     static constexpr int X_BYTES = 3 * XPL, D_BYTES = 3 * DPL;
     static constexpr int RED_BYTES = (KSPLIT > 1) ? WCI * WCO * T * 16 * 64 * 4 : 0;
-    static constexpr int LDS_BYTES = (X_BYTES + D_BYTES) > RED_BYTES ? (X_BYTES + D_BYTES) : RED_BYTES;
+    static constexpr int COEF_BYTES = 2 * NCI * 4;   // BN-on-load table of this workgroup's input channels: scale, shift
+    static constexpr int LDS_BYTES = ((X_BYTES + D_BYTES) > RED_BYTES ? (X_BYTES + D_BYTES) : RED_BYTES) + COEF_BYTES;
     static constexpr int CQX = 8 * WCI, CQD = 8 * WCO;
     static constexpr int NXU = HYP * 3 * CQX, NDU = TH * 2 * CQD;     // 8-pixel x 4-channel staging units
     static constexpr int RX = (NXU + 255) / 256, RD = (NDU + 255) / 256;
@@ -1172,6 +1203,17 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
         for (int r = 0; r < 16; ++r) acc[tap][r] = 0.f;
 
     // ---- staging: fp32 [pixel][channel] in HBM -> registers (next tile, during this tile's MFMAs) -> bf16 planes in LDS
+    // BN-on-load (x is a raw conv output, y = lrelu(z * scale + shift) applied while staging): coefficient table in LDS
+    const float* cfx = first ? a.coef1 : a.coef2;
+    float* coef_lds = reinterpret_cast<float*>(smem_b + C::LDS_BYTES - C::COEF_BYTES);
+    if (cfx != nullptr) {
+        for (int i = tid; i < C::NCI; i += 256) {
+            const bool okc = cb + i < csrc;
+            coef_lds[i] = okc ? cfx[cb + i] : 1.f;
+            coef_lds[C::NCI + i] = okc ? cfx[csrc + cb + i] : 0.f;
+        }
+    }
+    unsigned mx[C::RX];   // BN-on-load only: bit j = pixel j of the unit is real data (padding must stay 0 after the transform)
     f32x4 rx[C::RX][8], rd[C::RD][8];
     // loads are branch-free: padding / out-of-image / out-of-range-channel elements read a zero page (a.zero), so the values need
     // no masking afterwards
@@ -1202,6 +1244,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 rowbase = (img * hs + py) * ws;
             }
             const float* rowptr = src + (size_t)(rowok ? rowbase : 0) * csrc + (rowok ? ch : 0);
+            unsigned m = 0u;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int hx = 8 * g + j;
@@ -1209,7 +1252,9 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 const bool ok = rowok && hx < C::HXP && lx >= 0 && lx < a.w_in;
                 const int px = gmode == RCF_GATHER_NEAREST ? min((int)floorf((float)lx * a.sx), ws - 1) : lx;
                 rx[i][j] = *reinterpret_cast<const f32x4*>(ok ? rowptr + px * csrc : a.zero);
+                if (cfx != nullptr) m |= ok ? (1u << j) : 0u;
             }
+            mx[i] = m;
         }
 #pragma unroll
         for (int i = 0; i < C::RD; ++i) {
@@ -1263,6 +1308,15 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             const int u = tid + 256 * i;
             if (C::NXU % 256 == 0 || u < C::NXU) {
                 const int cq = u % C::CQX, g = (u / C::CQX) % 3, hy = u / (3 * C::CQX);
+                if (cfx != nullptr) {   // the producer's BatchNorm + LeakyReLU on the 8 x 4 values; padding stays zero
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(coef_lds + cq * 4);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(coef_lds + C::NCI + cq * 4);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            rx[i][j][e] = ((mx[i] >> j) & 1u) ? rcf_lrelu(rx[i][j][e] * sc[e] + sh[e]) : 0.f;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     split8(rx[i], e, Xs + (e * C::CQX + cq) * C::SX + hy * C::XROW + g * 16, C::XPL);
@@ -1837,6 +1891,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
 }
 
 void fill_args(const rcf_conv_desc* d, const Sel& s, ConvArgs* a) {
+    a->coef1 = nullptr; a->coef2 = nullptr;
     a->n = d->n; a->h_in = d->h_in; a->w_in = d->w_in; a->c1 = d->c1; a->c2 = d->c2;
     a->h1 = d->h_src1; a->w1 = d->w_src1; a->gather1 = d->gather1;
     a->h_out = d->h_out; a->w_out = d->w_out; a->c_out = d->c_out; a->pad = d->pad; a->pad_x = d->pad_x; a->stride = d->stride;
@@ -2006,10 +2061,13 @@ extern "C" int rcf_conv2d_query(const rcf_conv_desc* d, rcf_conv_info* info) {
     info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0) + (s.small ? 5 : 0);
     info->wgrad_workspace_floats = 0;
     info->wgrad_kernel_id = 0;
+    info->bn_on_load = (s.split && d->w_mode == RCF_W_FORWARD && d->c1 + d->c2 <= 512) ? 1 : 0;
+    info->wgrad_bn_on_load = 0;
     if (d->w_mode == RCF_W_FORWARD) {
         WSel w;
         if (select_wgrad(d, &w) == RCF_OK) {
             info->wgrad_workspace_floats = (size_t)w.nsplit * w.ktot * w.cop + 64;   // + a zero page for the DMA path
+            info->wgrad_bn_on_load = w.split ? 1 : 0;
             info->wgrad_kernel_id = 10000 + w.kind * 1000 + (w.px == 16 ? 100 : (w.px == 8 ? 200 : 0)) + (w.vt ? 400 : 0) +
                                     (w.split ? 5000 + w.wci * 10 + w.wco : 0);
         }
@@ -2042,15 +2100,31 @@ extern "C" int rcf_conv2d_pack_weights(const rcf_conv_desc* d, const float* w_oi
     return rcf_launch_status();
 }
 
+static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
+                           const float* packed, float* out, double* stat_partials, void* stream);
+
 extern "C" int rcf_conv2d_fwd(const rcf_conv_desc* d, const float* in1, const float* in2, const float* packed, float* out,
                               double* stat_partials, void* stream) {
+    return conv2d_fwd_impl(d, in1, nullptr, in2, nullptr, packed, out, stat_partials, stream);
+}
+
+extern "C" int rcf_conv2d_fwd_bn(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
+                                 const float* packed, float* out, double* stat_partials, void* stream) {
+    return conv2d_fwd_impl(d, in1, coef1, in2, coef2, packed, out, stat_partials, stream);
+}
+
+static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
+                           const float* packed, float* out, double* stat_partials, void* stream) {
     if (!in1 || !packed || !out) return RCF_EINVAL;
     Sel s;
     int rc = select_cfg(d, &s);
     if (rc != RCF_OK) return rc;
     if (d->c2 > 0 && !in2) return RCF_EINVAL;
+    if ((coef1 || coef2) && (!s.split || d->w_mode != RCF_W_FORWARD || d->c1 + d->c2 > 512 || (coef2 && d->c2 == 0)))
+        return RCF_EUNSUPPORTED;   // BN-on-load exists in the split kernels only (rcf_conv_info.bn_on_load)
     ConvArgs a;
     fill_args(d, s, &a);
+    a.coef1 = coef1; a.coef2 = coef2;
     a.in1 = in1; a.in2 = in2; a.wp = packed; a.out = out; a.stats = stat_partials; a.dz = nullptr; a.ws = nullptr;
     a.ktot = 0; a.cop = 0;
     const int nn = ceil_div(d->c_out, s.bn);
@@ -2059,14 +2133,29 @@ extern "C" int rcf_conv2d_fwd(const rcf_conv_desc* d, const float* in1, const fl
     return dispatch_fwd(s, [&](auto tag) { return launch_fwd<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
 }
 
+static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
+                             const float* dz, float* dw_oihw, float* workspace, void* stream);
+
 extern "C" int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const float* in2, const float* dz,
                                 float* dw_oihw, float* workspace, void* stream) {
+    return conv2d_wgrad_impl(d, in1, nullptr, in2, nullptr, dz, dw_oihw, workspace, stream);
+}
+
+extern "C" int rcf_conv2d_wgrad_bn(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2,
+                                   const float* coef2, const float* dz, float* dw_oihw, float* workspace, void* stream) {
+    return conv2d_wgrad_impl(d, in1, coef1, in2, coef2, dz, dw_oihw, workspace, stream);
+}
+
+static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
+                             const float* dz, float* dw_oihw, float* workspace, void* stream) {
     if (!in1 || !dz || !dw_oihw || !workspace) return RCF_EINVAL;
     WSel w;
     int rc = select_wgrad(d, &w);
     if (rc != RCF_OK) return rc;
     if (d->c2 > 0 && !in2) return RCF_EINVAL;
+    if ((coef1 || coef2) && (!w.split || (coef2 && d->c2 == 0))) return RCF_EUNSUPPORTED;
     ConvArgs a;
+    a.coef1 = coef1; a.coef2 = coef2;
     a.n = d->n; a.h_in = d->h_in; a.w_in = d->w_in; a.c1 = d->c1; a.c2 = d->c2;
     a.h1 = d->h_src1; a.w1 = d->w_src1; a.gather1 = d->gather1;
     a.h_out = d->h_out; a.w_out = d->w_out; a.c_out = d->c_out; a.pad = d->pad; a.pad_x = d->pad_x; a.stride = d->stride;

@@ -10,8 +10,9 @@ all-reduced while the encoder's backward is still running) and where every gradi
 accumulate in place; no generic add kernels).  Torch owns memory and the stream only.
 
 Layout: activations (N, H, W, C) fp32 contiguous.  BN layers keep the raw conv output z and the per-channel
-coefficients; the activation is materialised once (round 1; folding it into the consumer's operand load is the
-next step -- DESIGN.md section 6).
+coefficients.  The activation of a plain conv+BN+lrelu block can be DEFERRED: consumers that apply BatchNorm + lrelu
+while they load z (the output head; with Engine.bn_on_load also the split conv / wgrad kernels) take (z, coef) and
+the tensor is never written; any other consumer materialises it once, on demand (Engine._mat).
 '''
 
 import torch
@@ -51,10 +52,35 @@ class Engine(object):
         self.kernel_log = None     # optional list collecting (layer, kernel_id) for profiling
         self.prof = None           # optional KernelTimer: brackets conv launches with events on the launch stream
         self.use_phase_convs = True  # exact-2x UpConv and stride-2 dgrad as 2x2 phase convs (False: 9-tap / zero-insert forms)
+        # BatchNorm + lrelu applied by the consuming split conv / wgrad kernels as they load z (rcf_conv2d_fwd_bn): saves the
+        # bn_act_fwd pass (-2.4 ms/step) but costs the matrix kernels more in their staging path (+3.6 ms measured): off.  The
+        # output head, an HBM-bound kernel with idle VALU, always consumes its input this way.
+        self.bn_on_load = False
 
     # ------------------------------------------------------------------ helpers
     def _new(self, shape, ref):
         return torch.empty(shape, dtype=torch.float32, device=ref.device)
+
+    def _mat(self, x):
+        '''The activation tensor of x; a deferred one (raw conv output + BN coefficients) is materialised once, on demand.'''
+        if x.t is None:
+            z = x.z
+            x.t = torch.empty_like(z)
+            ops.bn_act_fwd(z, x.coef, None, x.t, z.shape[0] * z.shape[1] * z.shape[2], z.shape[3], RCF_ACT_LEAKY_RELU)
+        return x.t
+
+    @staticmethod
+    def _src(x, on_load_ok):
+        '''(tensor, coef) to hand to a conv kernel: the raw output + coefficients when the kernel applies BN on load.'''
+        if x is None:
+            return None, None
+        if x.t is None and on_load_ok:
+            return x.z, x.coef
+        return None, None   # caller materialises
+
+    @staticmethod
+    def _shape(x):
+        return (x.t if x.t is not None else x.z).shape
 
     def _wgrad_done(self, *params):
         if self.on_param_grad is not None:
@@ -63,12 +89,12 @@ class Engine(object):
 
     def _conv(self, layer, x, x2=None, up_hw=None, want_stats=False):
         '''conv (+ folded nearest-upsample of x to up_hw, + folded channel concat with x2) -> raw output z.'''
-        n, h, w, c1 = x.t.shape
-        c2 = 0 if x2 is None else x2.t.shape[3]
+        n, h, w, c1 = self._shape(x)
+        c2 = 0 if x2 is None else self._shape(x2)[3]
         h_in, w_in, gather = h, w, RCF_GATHER_DIRECT
         if up_hw is not None and (int(up_hw[0]), int(up_hw[1])) != (h, w):
             h_in, w_in, gather = int(up_hw[0]), int(up_hw[1]), RCF_GATHER_NEAREST
-        if x2 is not None and tuple(x2.t.shape[1:3]) != (h_in, w_in):
+        if x2 is not None and tuple(self._shape(x2)[1:3]) != (h_in, w_in):
             raise ValueError('skip connection and upsampled tensor disagree in size')
         weight = layer.conv.weight
         if (self.use_phase_convs and gather == RCF_GATHER_NEAREST and x2 is None and layer.kernel_size == 3
@@ -76,13 +102,19 @@ class Engine(object):
             return self._conv_up2x(layer, x, want_stats)
         desc = ops.make_fwd_desc(n, h_in, w_in, c1, c2, weight.shape[0], layer.kernel_size, layer.stride, h, w, gather)
         info = ops.conv_query(desc)
-        packed = self._new((info.packed_weight_floats,), x.t)
+        t1, k1 = self._src(x, info.bn_on_load)
+        t2, k2 = self._src(x2, info.bn_on_load)
+        if t1 is None:
+            t1 = self._mat(x)
+        if x2 is not None and t2 is None:
+            t2 = self._mat(x2)
+        packed = self._new((info.packed_weight_floats,), t1)
         ops.conv_pack(desc, weight.detach(), packed)
-        z = self._new((n, desc.h_out, desc.w_out, desc.c_out), x.t)
-        partials = torch.empty((info.n_partials, 2, desc.c_out), dtype=torch.float64, device=x.t.device) if want_stats else None
+        z = self._new((n, desc.h_out, desc.w_out, desc.c_out), t1)
+        partials = torch.empty((info.n_partials, 2, desc.c_out), dtype=torch.float64, device=t1.device) if want_stats else None
         if self.prof is not None:
             self.prof.begin(info.kernel_id, ops.algorithmic_flops(desc), desc)
-        ops.conv_fwd(desc, x.t, None if x2 is None else x2.t, packed, z, partials)
+        ops.conv_fwd(desc, t1, t2, packed, z, partials, coef1=k1, coef2=k2)
         if self.prof is not None:
             self.prof.end()
         if self.kernel_log is not None and desc is not None:
@@ -90,13 +122,13 @@ class Engine(object):
                                     info.kernel_id))
         return z, desc, info, partials
 
-    def _run_packed(self, desc, w_oihw, in1, out, partials=None):
+    def _run_packed(self, desc, w_oihw, in1, out, partials=None, coef1=None):
         info = ops.conv_query(desc)
         packed = self._new((info.packed_weight_floats,), in1)
         ops.conv_pack(desc, w_oihw, packed)
         if self.prof is not None:
             self.prof.begin(info.kernel_id, ops.algorithmic_flops(desc), desc)
-        ops.conv_fwd(desc, in1, None, packed, out, partials)
+        ops.conv_fwd(desc, in1, None, packed, out, partials, coef1=coef1)
         if self.prof is not None:
             self.prof.end()
         return info
@@ -106,19 +138,24 @@ class Engine(object):
         conv3x3(F.interpolate(x, 2x nearest)) as four 2x2 phase convolutions on x (4/9 of the MACs; the weights of the
         taps that hit the same source pixel are pre-summed, so results differ from the 9-tap form by fp32 round-off only).
         '''
-        n, h, w, c1 = x.t.shape
+        n, h, w, c1 = self._shape(x)
         weight = layer.conv.weight
         co = weight.shape[0]
         wp = ops.phase_weights(weight.detach(), RCF_PHASE_UP2X_FWD)
-        z = self._new((n, 2 * h, 2 * w, co), x.t)
         descs, partials, n_part = [], None, 0
+        t1 = k1 = z = None
         for ph in range(4):
             d = ops.make_up2x_fwd_desc(n, h, w, c1, co, ph >> 1, ph & 1)
             if ph == 0:
-                n_part = ops.conv_query(d).n_partials
+                qi = ops.conv_query(d)
+                n_part = qi.n_partials
+                t1, k1 = self._src(x, qi.bn_on_load)
+                if t1 is None:
+                    t1 = self._mat(x)
+                z = self._new((n, 2 * h, 2 * w, co), t1)
                 if want_stats:
-                    partials = torch.empty((4 * n_part, 2, co), dtype=torch.float64, device=x.t.device)
-            self._run_packed(d, wp[ph], x.t, z, None if partials is None else partials[ph * n_part:(ph + 1) * n_part])
+                    partials = torch.empty((4 * n_part, 2, co), dtype=torch.float64, device=t1.device)
+            self._run_packed(d, wp[ph], t1, z, None if partials is None else partials[ph * n_part:(ph + 1) * n_part], coef1=k1)
             descs.append(d)
 
         class _Info(object):
@@ -129,16 +166,19 @@ class Engine(object):
         return z, None, info, partials
 
     def _conv_up2x_backward(self, layer, info, x, dz):
-        n, h, w, c1 = x.t.shape
+        n, h, w, c1 = self._shape(x)
         weight = layer.conv.weight
         co = weight.shape[0]
         dwp = self._new((4, co, c1, 2, 2), dz)
         for ph, d in enumerate(info.up2x):
             qi = ops.conv_query(d)
             ws = self._new((max(1, qi.wgrad_workspace_floats),), dz)
+            t1, k1 = self._src(x, qi.wgrad_bn_on_load)
+            if t1 is None:
+                t1 = self._mat(x)
             if self.prof is not None:
                 self.prof.begin(qi.wgrad_kernel_id, ops.algorithmic_flops(d), d)
-            ops.conv_wgrad(d, x.t, None, dz, dwp[ph], ws)
+            ops.conv_wgrad(d, t1, None, dz, dwp[ph], ws, coef1=k1)
             if self.prof is not None:
                 self.prof.end()
         ops.phase_wgrad_fold(dwp, self.grad_of(weight))
@@ -147,7 +187,7 @@ class Engine(object):
             wd = ops.phase_weights(weight.detach(), RCF_PHASE_UP2X_DGRAD)
             acc = x.g is not None
             if not acc:
-                x.g = torch.empty_like(x.t)
+                x.g = self._new(tuple(self._shape(x)), dz)
             dd = ops.make_up2x_dgrad_desc(n, h, w, c1, co, 0, 0, acc, phase_sum=True)
             qi = ops.conv_query(dd)
             packed = self._new((4 * qi.packed_weight_floats,), dz)
@@ -168,7 +208,13 @@ class Engine(object):
         ws = self._new((max(1, info.wgrad_workspace_floats),), dz)
         if self.prof is not None:
             self.prof.begin(info.wgrad_kernel_id, ops.algorithmic_flops(desc), desc)
-        ops.conv_wgrad(desc, x.t, None if x2 is None else x2.t, dz, dw, ws)
+        t1, k1 = self._src(x, info.wgrad_bn_on_load)
+        t2, k2 = self._src(x2, info.wgrad_bn_on_load)
+        if t1 is None:
+            t1 = self._mat(x)
+        if x2 is not None and t2 is None:
+            t2 = self._mat(x2)
+        ops.conv_wgrad(desc, t1, t2, dz, dw, ws, coef1=k1, coef2=k2)
         if self.prof is not None:
             self.prof.end()
         self._wgrad_done(weight)
@@ -181,20 +227,20 @@ class Engine(object):
                 self._run_dgrad(dd, weight, dz, tmp)
                 acc = src.g is not None
                 if not acc:
-                    src.g = torch.empty_like(src.t)
+                    src.g = self._new(tuple(self._shape(src)), dz)
                 ops.upsample_nearest_bwd(tmp, src.g, acc)
             elif self.use_phase_convs and desc.stride == 2 and desc.ksize == 3 and x2 is None and desc.c1 % 4 == 0:
                 # transposed convolution in 4 phases (16 of the 36 zero-dilated taps are real)
                 acc = src.g is not None
                 if not acc:
-                    src.g = torch.empty_like(src.t)
+                    src.g = self._new(tuple(self._shape(src)), dz)
                 wd = ops.phase_weights(weight.detach(), RCF_PHASE_S2_DGRAD)
                 for ph in range(4):
                     self._run_packed(ops.make_s2_dgrad_desc(desc, ph >> 1, ph & 1, acc), wd[ph], dz, src.g)
             else:
                 acc = src.g is not None
                 if not acc:
-                    src.g = torch.empty_like(src.t)
+                    src.g = self._new(tuple(self._shape(src)), dz)
                 dd = ops.make_dgrad_desc(desc, off, cnt, acc)
                 self._run_dgrad(dd, weight, dz, src.g)
 
@@ -218,7 +264,7 @@ class Engine(object):
         return coef
 
     # ------------------------------------------------------------------ layer ops
-    def conv_bn_act(self, layer, x, x2=None, up_hw=None, res=None, defer_act=False):
+    def conv_bn_act(self, layer, x, x2=None, up_hw=None, res=None, feeds_head=False):
         '''
         net_utils.Conv2d.forward (src/net_utils.py:84-91) with BN + leaky_relu (+ the residual tail of
         ResNetBlock.forward when res is given: lrelu(lrelu(BN(conv)) + res), src/net_utils.py:311-323).
@@ -229,13 +275,15 @@ class Engine(object):
         coef = self._bn_coef(layer, partials, info, z)
         n_pix = z.shape[0] * z.shape[1] * z.shape[2]
         c = z.shape[3]
-        if defer_act and res is None and ops.head_bn_blocks(z.shape[0], z.shape[1], z.shape[2], c) > 0:
-            # the only consumer is the output head, which applies BN + lrelu to z as it loads it: the activation is never written
+        if res is None and (self.bn_on_load or (feeds_head and ops.head_bn_blocks(z.shape[0], z.shape[1], z.shape[2], c) > 0)):
+            # deferred activation: consumers that apply BatchNorm + lrelu while they load z (the output head; with
+            # bn_on_load also the split conv / wgrad kernels) never need the tensor; any other consumer materialises it
+            # once through _mat()
             out = Act(None)
             out.z, out.coef = z, coef
         else:
             out = Act(torch.empty_like(z))
-            ops.bn_act_fwd(z, coef, None if res is None else res.t, out.t, n_pix, c, RCF_ACT_LEAKY_RELU)
+            ops.bn_act_fwd(z, coef, None if res is None else self._mat(res), out.t, n_pix, c, RCF_ACT_LEAKY_RELU)
         out.head_fusable = res is None
         if self.tape is not None:
             bn = layer.batch_norm
@@ -258,12 +306,10 @@ class Engine(object):
                     ops.head_bn_bwd_apply(dlogit, w_head, z, coef, bcoef, dz)
                     self._conv_backward(layer, desc, info, x, x2, dz)
                     return
-                if out.t is None:
-                    raise RuntimeError('deferred activation reached the generic BatchNorm backward')
                 dout = out.g
                 nb = ops.ew_blocks(n_pix, c)
                 bpart = torch.empty((nb, 2, c), dtype=torch.float64, device=z.device)
-                has_res = res is not None
+                has_res = res is not None   # out.t is read only then (a deferred activation has no residual)
                 ops.bn_act_bwd_reduce(dout, z, coef, out.t, bpart, n_pix, c, RCF_ACT_LEAKY_RELU, has_res)
                 bcoef = self._new((2, c), z)
                 ops.bn_bwd_finalize(bpart, nb, 2 * c, c, n_pix, bcoef, self.grad_of(bn.weight), self.grad_of(bn.bias))
@@ -307,14 +353,12 @@ class Engine(object):
         n_pix = zw.shape[0] * zw.shape[1] * zw.shape[2]
         c = zw.shape[3]
         out = Act(torch.empty_like(zw))
-        ops.fuse_fwd(zw, coef_w, zp, coef_p, img.t, out.t, n_pix, c)
+        ops.fuse_fwd(zw, coef_w, zp, coef_p, self._mat(img), out.t, n_pix, c)
         if self.tape is not None:
             bnw, bnp = layer_w.batch_norm, layer_p.batch_norm
             batch_stats = self.training
 
             def backward():
-                if out.t is None:
-                    raise RuntimeError('deferred activation reached the generic BatchNorm backward')
                 dout = out.g
                 nb = ops.ew_blocks(n_pix, c)
                 bpart = torch.empty((nb, 4, c), dtype=torch.float64, device=zw.device)
@@ -346,11 +390,12 @@ class Engine(object):
 
     def max_pool(self, x):
         '''torch.nn.MaxPool2d(3, 2, 1) (src/networks.py:392-395).'''
-        n, h, w, c = x.t.shape
+        xt = self._mat(x)
+        n, h, w, c = xt.shape
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-        out = Act(self._new((n, ho, wo, c), x.t))
-        idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.t.device)
-        ops.maxpool_fwd(x.t, out.t, idx)
+        out = Act(self._new((n, ho, wo, c), xt))
+        idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=xt.device)
+        ops.maxpool_fwd(xt, out.t, idx)
         if self.tape is not None:
             def backward():
                 acc = x.g is not None
@@ -367,19 +412,21 @@ class Engine(object):
         shortcut = self.conv_plain(block.projection, x) if block.uses_projection else x
         return self.conv_bn_act(block.conv2, c1, res=shortcut)
 
-    def decoder_block(self, block, x, skip=None, shape=None, defer_act=False):
-        '''DecoderBlock.forward (src/net_utils.py:535-569), deconv_type 'up'.  defer_act: the block's output feeds the head only.'''
+    def decoder_block(self, block, x, skip=None, shape=None, feeds_head=False):
+        '''DecoderBlock.forward (src/net_utils.py:535-569), deconv_type 'up'.'''
         if skip is not None:
-            shape = skip.t.shape[1:3]
+            shape = self._shape(skip)[1:3]
         elif shape is None:
-            shape = (2 * x.t.shape[1], 2 * x.t.shape[2])
+            shape = (2 * self._shape(x)[1], 2 * self._shape(x)[2])
         deconv = self.conv_bn_act(block.deconv.conv, x, up_hw=shape)
         if block.skip_channels > 0:
-            return self.conv_bn_act(block.conv, deconv, x2=skip, defer_act=defer_act)
-        return self.conv_bn_act(block.conv, deconv, defer_act=defer_act)
+            return self.conv_bn_act(block.conv, deconv, x2=skip, feeds_head=feeds_head)
+        return self.conv_bn_act(block.conv, deconv, feeds_head=feeds_head)
 
     def head(self, layer, x):
         '''output0 (src/networks.py:1548-1555, :1654) + d = min/(sigmoid(o)+min/max) (src/fusionnet_model.py:162-165).'''
+        if x.t is None and ops.head_bn_blocks(*x.z.shape) <= 0:
+            self._mat(x)                          # the fused head kernels do not cover this channel count
         xin = x.t if x.t is not None else x.z     # deferred activation: raw conv output + coefficients
         xcoef = None if x.t is not None else x.coef
         n, h, w, c = xin.shape
@@ -397,7 +444,7 @@ class Engine(object):
                 if x.needs_grad:
                     if x.g is not None:
                         raise RuntimeError('head input has another consumer')
-                    if x.head_fusable and ops.head_bn_blocks(n, h, w, c) > 0:
+                    if x.head_fusable and x.t is None:
                         x.g_head = (dlogit, weight.detach())   # consumed by the producer's BatchNorm backward
                     else:
                         x.g = torch.empty_like(xin)
@@ -434,9 +481,9 @@ class Engine(object):
             x = self.decoder_block(getattr(dec, name), x, skip=skips[n])
             n -= 1
         if n == 0:
-            x = self.decoder_block(dec.deconv0, x, skip=skips[0], defer_act=True)
+            x = self.decoder_block(dec.deconv0, x, skip=skips[0], feeds_head=True)
         else:
-            x = self.decoder_block(dec.deconv0, x, shape=image_nhwc.shape[1:3], defer_act=True)
+            x = self.decoder_block(dec.deconv0, x, shape=image_nhwc.shape[1:3], feeds_head=True)
         out = self.head(dec.output0, x)
         tape, self.tape = self.tape, None
         return out, tape

@@ -198,14 +198,23 @@ def conv_pack(desc, w_oihw, packed):
           'rcf_conv2d_pack_weights')
 
 
-def conv_fwd(desc, in1, in2, packed, out, stat_partials=None):
-    check(_lib.load().rcf_conv2d_fwd(ctypes.byref(desc), _f32(in1), _f32(in2), _f32(packed), _f32(out),
-                                     _f64(stat_partials), _stream()), 'rcf_conv2d_fwd')
+def conv_fwd(desc, in1, in2, packed, out, stat_partials=None, coef1=None, coef2=None):
+    """coef1 / coef2: in1 / in2 are raw conv outputs whose BatchNorm + lrelu is applied on load (rcf_conv_info.bn_on_load)."""
+    if coef1 is None and coef2 is None:
+        check(_lib.load().rcf_conv2d_fwd(ctypes.byref(desc), _f32(in1), _f32(in2), _f32(packed), _f32(out),
+                                         _f64(stat_partials), _stream()), 'rcf_conv2d_fwd')
+    else:
+        check(_lib.load().rcf_conv2d_fwd_bn(ctypes.byref(desc), _f32(in1), _f32(coef1), _f32(in2), _f32(coef2), _f32(packed),
+                                            _f32(out), _f64(stat_partials), _stream()), 'rcf_conv2d_fwd_bn')
 
 
-def conv_wgrad(desc, in1, in2, dz, dw, workspace):
-    check(_lib.load().rcf_conv2d_wgrad(ctypes.byref(desc), _f32(in1), _f32(in2), _f32(dz), _f32(dw), _f32(workspace),
-                                       _stream()), 'rcf_conv2d_wgrad')
+def conv_wgrad(desc, in1, in2, dz, dw, workspace, coef1=None, coef2=None):
+    if coef1 is None and coef2 is None:
+        check(_lib.load().rcf_conv2d_wgrad(ctypes.byref(desc), _f32(in1), _f32(in2), _f32(dz), _f32(dw), _f32(workspace),
+                                           _stream()), 'rcf_conv2d_wgrad')
+    else:
+        check(_lib.load().rcf_conv2d_wgrad_bn(ctypes.byref(desc), _f32(in1), _f32(coef1), _f32(in2), _f32(coef2), _f32(dz),
+                                              _f32(dw), _f32(workspace), _stream()), 'rcf_conv2d_wgrad_bn')
 
 
 def bn_finalize(partials, n_partials, c, count, gamma, beta, running_mean, running_var, momentum, eps, training, coef):

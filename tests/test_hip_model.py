@@ -345,3 +345,25 @@ def test_data_parallel_step_two_ranks_on_one_gpu(env, tmp_path):
         grad += m._grad_arena[:m._n_used]
     assert abs(r[0]['loss'] - want_loss) < 1e-5 * abs(want_loss)
     assert _rel(r[0]['grad'], grad) < 1e-4
+
+
+def test_t1_with_bn_on_load_in_the_conv_kernels(env, golden_dir):
+    '''Engine.bn_on_load (the consuming split conv / wgrad kernels apply BatchNorm + lrelu while they load the raw conv output;
+    off by default because it is slower) gives the same published-net training step: output, loss and gradient norms of T1.'''
+    synth, _ = env
+    g = np.load(os.path.join(golden_dir, 'T1_published_train.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    m = _build(env, synth.PUBLISHED, wseed)
+    m._engine.bn_on_load = True
+    b = _gpu_batch(synth.make_batch(n, h, w, k, seed=dseed))
+    m.train()
+    out = m.forward(image=b['image'], input_depth=b['input_depth'])
+    loss, info = _loss(m, b, out)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert _rel(out, g['output']) < BAR
+    np.testing.assert_allclose([float(loss.detach()), float(info['loss_supervised']), float(info['loss_lidar'])], g['loss'], rtol=BAR)
+    grads = dict(_named(m, 'p'))
+    for key, l2 in zip(g['grad_keys'].tolist(), g['grad_l2'].tolist()):
+        got = float(grads[key].grad.double().norm())
+        assert abs(got - l2) <= 2e-3 * max(l2, 1e-6), (key, got, l2)

@@ -604,3 +604,40 @@ def test_head_applies_previous_bn_on_load(ops, c):
     ops.head_bwd_wgrad(y, dlogit, dw)
     ops.head_bwd_wgrad(z, dlogit, dw2, coef=coef)
     np.testing.assert_allclose(dw2.cpu().numpy(), dw.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('two_src', [False, True])
+def test_conv_applies_producer_bn_on_load(ops, two_src):
+    '''rcf_conv2d_fwd_bn / rcf_conv2d_wgrad_bn on raw conv outputs + coefficients == the plain kernels on the materialised
+    activations (split kernels; bit-identical operands, so only the summation order inside the kernel could differ: none does).'''
+    import torch
+    torch.manual_seed(5)
+    dev = 'cuda'
+    n, h, w, c1, c2, co = 2, 37, 53, 32, (16 if two_src else 0), 64
+    z1 = torch.randn(n, h, w, c1, device=dev)
+    z2 = torch.randn(n, h, w, c2, device=dev) if two_src else None
+
+    def coef(c):
+        return torch.stack([torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.3, torch.zeros(c, device=dev),
+                            torch.ones(c, device=dev)]).contiguous()
+    k1 = coef(c1)
+    y1 = torch.empty_like(z1)
+    ops.bn_act_fwd(z1, k1, None, y1, n * h * w, c1, 1)
+    wt = torch.randn(co, c1 + c2, 3, 3, device=dev) * 0.1
+    d = ops.make_fwd_desc(n, h, w, c1, c2, co, 3, 1, h, w, 0)
+    info = ops.conv_query(d)
+    assert info.bn_on_load == 1 and info.wgrad_bn_on_load == 1
+    packed = torch.empty(info.packed_weight_floats, device=dev)
+    ops.conv_pack(d, wt, packed)
+    out_a, out_b = torch.empty(n, h, w, co, device=dev), torch.empty(n, h, w, co, device=dev)
+    # source 2 stays a plain (already materialised) tensor: per-source coefficients
+    ops.conv_fwd(d, y1, z2, packed, out_a, None)
+    ops.conv_fwd(d, z1, z2, packed, out_b, None, coef1=k1)
+    assert torch.equal(out_a, out_b)
+    dz = torch.randn(n, h, w, co, device=dev)
+    dw_a, dw_b = torch.empty_like(wt), torch.empty_like(wt)
+    ws = torch.empty(max(1, info.wgrad_workspace_floats), device=dev)
+    ops.conv_wgrad(d, y1, z2, dz, dw_a, ws)
+    ops.conv_wgrad(d, z1, z2, dz, dw_b, ws, coef1=k1)
+    assert torch.equal(dw_a, dw_b)
