@@ -243,6 +243,36 @@ int rcf_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, vo
 int rcf_radar_scatter(const float* crops, const float* points, int k, int h, int w, int wc,
                       int strict_reference, float* depth, float* response, void* stream);
 
+/* ---- RadarNet stage 1: ops FusionNet does not have --------------------------------------------------------- */
+
+/* torchvision.ops.roi_pool as RadarNetV1Encoder.forward calls it (src/networks.py:1232-1247; torchvision 0.11.3 semantics
+ * restated, see oracle/roi_pool_oracle.py): in (N,H,W,C) NHWC, rois (R,5) = (batch index, x1, y1, x2, y2) in input-image
+ * coordinates scaled by spatial_scale; out (R,PH,PW,out_cstride) written at channel offset out_coff (so the pooled latent can be
+ * placed next to the radar latent without a concat); argmax (R,PH,PW,C) int32 = y*W+x of each maximum, -1 for an empty bin. */
+int rcf_roi_pool_fwd(const float* in, const float* rois, float* out, int* argmax, int n_roi, int n, int h, int w, int c,
+                     int pooled_h, int pooled_w, float spatial_scale, int out_cstride, int out_coff, void* stream);
+/* din (N,H,W,C) += scatter of dout through argmax (rois overlap: atomic adds; zero din first unless accumulating). */
+int rcf_roi_pool_bwd(const float* dout, const int* argmax, const float* rois, float* din, int n_roi, int n, int h, int w, int c,
+                     int pooled_h, int pooled_w, int dout_cstride, int dout_coff, void* stream);
+
+/* net_utils.FullyConnected (src/net_utils.py:201-247): y = act(x W^T + b), x (M,n_in), W (n_out,n_in), M <= 64.
+ * act: 0 linear, 1 LeakyReLU(0.2).  hw > 1: feature f = c*hw + p is stored at NHWC position m*(hw*cstride) + p*cstride + coff + c
+ * (the .view(M, C, -1, W) + torch.cat of src/networks.py:1251-1255 done by addressing); hw <= 1: plain (M,n_out). */
+int rcf_fc_fwd(const float* x, const float* w, const float* bias, float* y, int m_rows, int n_in, int n_out, int act,
+               int hw, int cstride, int coff, void* stream);
+size_t rcf_fc_bwd_workspace_floats(int m_rows, int n_in, int n_out);
+/* dw (n_out,n_in), db (n_out) overwritten; dx (M,n_in) nullable (then workspace may be null too). y / dy use the forward layout. */
+int rcf_fc_bwd(const float* x, const float* w, const float* y, const float* dy, float* dw, float* db, float* dx,
+               float* workspace, int m_rows, int n_in, int n_out, int act, int hw, int cstride, int coff, void* stream);
+
+/* RadarNetModel.compute_loss (src/radarnet_model.py:131-171): sum(valid * BCEWithLogits(logit, target, pos_weight)) / sum(valid).
+ * sums[2] (fp64) = (weighted loss sum, valid count) feeds the backward; loss[1] fp32. */
+size_t rcf_bce_workspace_doubles(void);
+int rcf_bce_loss_fwd(const float* logit, const float* target, const float* valid, double* workspace, double* sums, float* loss,
+                     long long n, float pos_weight, void* stream);
+int rcf_bce_loss_bwd(const float* logit, const float* target, const float* valid, const double* sums, const float* upstream,
+                     float* dlogit, long long n, float pos_weight, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

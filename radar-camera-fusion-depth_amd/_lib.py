@@ -48,6 +48,14 @@ _SIGNATURES = {
     'rcf_bn_act_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P]),
     'rcf_bn_bwd_finalize': (c_int, [_P, c_int, c_int, c_int, c_double, _P, _P, _P, _P]),
     'rcf_bn_act_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_longlong, c_int, c_int, c_int, _P]),
+    'rcf_roi_pool_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
+    'rcf_roi_pool_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'rcf_fc_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'rcf_fc_bwd_workspace_floats': (c_size_t, [c_int, c_int, c_int]),
+    'rcf_fc_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'rcf_bce_workspace_doubles': (c_size_t, []),
+    'rcf_bce_loss_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_float, _P]),
+    'rcf_bce_loss_bwd': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_float, _P]),
     'rcf_head_bn_blocks': (c_int, [c_int, c_int, c_int, c_int]),
     'rcf_head_bn_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'rcf_head_bn_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -1,0 +1,328 @@
+// RadarNet stage-1 device ops that FusionNet does not have, NHWC fp32 on gfx950:
+//   * ROI max pooling of image features around each radar point -- torchvision.ops.roi_pool as called at
+//     src/networks.py:1232-1247 (torchvision 0.11.3 semantics restated: rounded box * spatial_scale, +1 extent,
+//     floor/ceil bin edges, max over the bin, -FLT_MAX start, 0 for an empty bin) -- forward with argmax, backward scatter;
+//   * net_utils.FullyConnected (src/net_utils.py:201-247): Linear + bias + LeakyReLU(0.2), forward and backward, with an
+//     optional feature -> (pixel, channel) placement so the last layer of FullyConnectedEncoder (src/networks.py:1007-1067)
+//     writes straight into the NHWC latent next to the pooled image features (the .view(N, C, -1, W) + torch.cat of
+//     src/networks.py:1251-1255 never exist as separate tensors);
+//   * RadarNetModel.compute_loss (src/radarnet_model.py:131-171): binary_cross_entropy_with_logits with pos_weight,
+//     masked by the validity map, sum / sum(validity).
+// All HBM / latency bound and small next to the encoder and decoder convolutions, which reuse the FusionNet kernels.
+#include <float.h>
+#include "rcf_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- ROI max pooling
+// One thread per (roi, ph, pw, channel quad).  in: (N, H, W, C); rois: (R, 5) = (batch index, x1, y1, x2, y2);
+// out: (R, PH, PW, out_cstride) at channel offset out_coff; argmax: (R, PH, PW, C) int32 = y * W + x of the maximum (-1: empty).
+__global__ void __launch_bounds__(256) roi_pool_fwd_kernel(const float* __restrict__ in, const float* __restrict__ rois,
+                                                           float* __restrict__ out, int* __restrict__ argmax, int n_roi, int h, int w,
+                                                           int c, int ph_n, int pw_n, float scale, int out_cstride, int out_coff) {
+    const int c4n = c >> 2;
+    const long long total = (long long)n_roi * ph_n * pw_n * c4n;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        long long t = g;
+        const int cg = (int)(t % c4n); t /= c4n;
+        const int pw = (int)(t % pw_n); t /= pw_n;
+        const int ph = (int)(t % ph_n);
+        const int r = (int)(t / ph_n);
+        const float* roi = rois + (size_t)r * 5;
+        const int b = (int)roi[0];
+        const int x0 = (int)roundf(roi[1] * scale), y0 = (int)roundf(roi[2] * scale);
+        const int x1 = (int)roundf(roi[3] * scale), y1 = (int)roundf(roi[4] * scale);
+        const int rw = max(x1 - x0 + 1, 1), rh = max(y1 - y0 + 1, 1);
+        const float bh = (float)rh / (float)ph_n, bw = (float)rw / (float)pw_n;
+        int hs = (int)floorf((float)ph * bh), he = (int)ceilf((float)(ph + 1) * bh);
+        int ws = (int)floorf((float)pw * bw), we = (int)ceilf((float)(pw + 1) * bw);
+        hs = min(max(hs + y0, 0), h); he = min(max(he + y0, 0), h);
+        ws = min(max(ws + x0, 0), w); we = min(max(we + x0, 0), w);
+        const bool empty = he <= hs || we <= ws;
+        f32x4 m = empty ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+        int am[4] = {-1, -1, -1, -1};
+        for (int y = hs; y < he; ++y)
+            for (int x = ws; x < we; ++x) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((size_t)b * h + y) * w + x) * c + cg * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (v[j] > m[j]) { m[j] = v[j]; am[j] = y * w + x; }
+            }
+        const size_t o = ((size_t)r * ph_n + ph) * pw_n + pw;
+        *reinterpret_cast<f32x4*>(out + o * out_cstride + out_coff + cg * 4) = m;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) argmax[o * c + cg * 4 + j] = am[j];
+    }
+}
+
+// din (N, H, W, C) must be zeroed by the caller (or hold an earlier contribution): rois overlap, so this is a scatter-add.
+__global__ void __launch_bounds__(256) roi_pool_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ argmax,
+                                                           const float* __restrict__ rois, float* __restrict__ din, int n_roi, int h,
+                                                           int w, int c, int ph_n, int pw_n, int dout_cstride, int dout_coff) {
+    const long long total = (long long)n_roi * ph_n * pw_n * c;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const int ch = (int)(g % c);
+        const long long o = g / c;
+        const int r = (int)(o / ((long long)ph_n * pw_n));
+        const int a = argmax[g];
+        if (a < 0) continue;
+        const int b = (int)rois[(size_t)r * 5];
+        atomicAdd(din + ((size_t)b * h * w + a) * c + ch, dout[o * dout_cstride + dout_coff + ch]);
+    }
+}
+
+// ---------------------------------------------------------------- fully connected + bias + LeakyReLU
+// y[m][f] = lrelu(sum_k x[m][k] * W[f][k] + b[f]), M <= FC_MAX_M rows held as per-thread accumulators, one thread per output
+// feature (W is read exactly once, coalesced over k by the wave).  Output address of (m, f): with hw == 1 plain [m][f]; otherwise
+// feature f = c * hw + p goes to NHWC position m * (hw * cstride) + p * cstride + coff + c.
+constexpr int FC_MAX_M = 64;
+
+__device__ __forceinline__ size_t fc_addr(int m, int f, int n_out, int hw, int cstride, int coff) {
+    if (hw <= 1) return (size_t)m * n_out + f;
+    const int cch = f / hw, p = f - cch * hw;
+    return ((size_t)m * hw + p) * cstride + coff + cch;
+}
+
+template <int MB>
+__global__ void __launch_bounds__(256) fc_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                     const float* __restrict__ bias, float* __restrict__ y, int m_rows, int n_in,
+                                                     int n_out, int act, int hw, int cstride, int coff) {
+    extern __shared__ float xs[];   // [m_rows][n_in]
+    for (int i = threadIdx.x; i < m_rows * n_in; i += 256) xs[i] = x[i];
+    __syncthreads();
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_out) return;
+    float acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = 0.f;
+    const float* wr = wgt + (size_t)f * n_in;
+    for (int k = 0; k < n_in; ++k) {
+        const float wv = wr[k];
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+            if (m < m_rows) acc[m] = fmaf(xs[m * n_in + k], wv, acc[m]);
+    }
+    const float bv = bias[f];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+        if (m < m_rows) {
+            float v = acc[m] + bv;
+            if (act) v = rcf_lrelu(v);
+            y[fc_addr(m, f, n_out, hw, cstride, coff)] = v;
+        }
+}
+
+// Backward: g = dy * lrelu'(y); dW[f][k] = sum_m g[m][f] x[m][k]; db[f] = sum_m g[m][f] (one thread per output feature).
+template <int MB>
+__global__ void __launch_bounds__(256) fc_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                     const float* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db,
+                                                     int m_rows, int n_in, int n_out, int act, int hw, int cstride, int coff) {
+    extern __shared__ float xs[];   // [m_rows][n_in]
+    for (int i = threadIdx.x; i < m_rows * n_in; i += 256) xs[i] = x[i];
+    __syncthreads();
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_out) return;
+    float g[MB];
+    float gs = 0.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        g[m] = 0.f;
+        if (m < m_rows) {
+            const size_t a = fc_addr(m, f, n_out, hw, cstride, coff);
+            g[m] = dy[a] * (act ? rcf_lrelu_grad(y[a]) : 1.f);
+            gs += g[m];
+        }
+    }
+    db[f] = gs;
+    for (int k = 0; k < n_in; ++k) {
+        float dwv = 0.f;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+            if (m < m_rows) dwv = fmaf(g[m], xs[m * n_in + k], dwv);
+        dw[(size_t)f * n_in + k] = dwv;
+    }
+}
+
+// Input gradient dx[m][k] = sum_f g[m][f] W[f][k]: a block takes 256 features, keeps their g in LDS and accumulates its partial
+// [m][k] (thread owns column k = t % n_in... of rows m = t / n_in + j * rows_per_pass); partials are summed by fc_dx_reduce_kernel.
+__global__ void __launch_bounds__(256) fc_dx_partial_kernel(const float* __restrict__ wgt, const float* __restrict__ y,
+                                                            const float* __restrict__ dy, float* __restrict__ part, int m_rows,
+                                                            int n_in, int n_out, int act, int hw, int cstride, int coff) {
+    extern __shared__ float gs[];   // [256 features][m_rows]
+    const int f0 = blockIdx.x * 256;
+    for (int i = threadIdx.x; i < 256 * m_rows; i += 256) {
+        const int fl = i / m_rows, m = i - fl * m_rows;
+        const int f = f0 + fl;
+        float g = 0.f;
+        if (f < n_out) {
+            const size_t a = fc_addr(m, f, n_out, hw, cstride, coff);
+            g = dy[a] * (act ? rcf_lrelu_grad(y[a]) : 1.f);
+        }
+        gs[i] = g;
+    }
+    __syncthreads();
+    const int nf = min(256, n_out - f0);
+    for (int o = threadIdx.x; o < m_rows * n_in; o += 256) {
+        const int m = o / n_in, k = o - m * n_in;
+        float acc = 0.f;
+        for (int fl = 0; fl < nf; ++fl) acc = fmaf(gs[fl * m_rows + m], wgt[(size_t)(f0 + fl) * n_in + k], acc);
+        part[(size_t)blockIdx.x * m_rows * n_in + o] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) fc_dx_reduce_kernel(const float* __restrict__ part, float* __restrict__ dx, int n_part, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int p = 0; p < n_part; ++p) s += (double)part[(size_t)p * n + i];
+    dx[i] = (float)s;
+}
+
+// ---------------------------------------------------------------- masked BCE with logits
+constexpr int BCE_BLOCKS = 1024;
+
+__device__ __forceinline__ float bce_term(float x, float t, float pw) {
+    // torch.binary_cross_entropy_with_logits with pos_weight: (1 - t) x + (1 + (pw - 1) t) (log1p(exp(-|x|)) + max(-x, 0))
+    const float lw = 1.f + (pw - 1.f) * t;
+    return (1.f - t) * x + lw * (log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.f));
+}
+
+__global__ void __launch_bounds__(256) bce_partial_kernel(const float* __restrict__ logit, const float* __restrict__ target,
+                                                          const float* __restrict__ valid, double* __restrict__ part, long long n,
+                                                          float pw) {
+    __shared__ double sm[2][4];
+    double s0 = 0.0, s1 = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = valid[i];
+        s0 += (double)(v * bce_term(logit[i], target[i], pw));
+        s1 += (double)v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); }
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = s0; sm[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2 + 0] = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3];
+        part[blockIdx.x * 2 + 1] = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
+    }
+}
+
+// sums[0] = sum(valid * loss), sums[1] = sum(valid); loss = sums[0] / sums[1]
+__global__ void __launch_bounds__(64) bce_final_kernel(const double* __restrict__ part, int nb, double* __restrict__ sums,
+                                                       float* __restrict__ loss) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 64) { s0 += part[i * 2]; s1 += part[i * 2 + 1]; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); }
+    if (threadIdx.x == 0) {
+        sums[0] = s0;
+        sums[1] = s1;
+        loss[0] = (float)(s0 / s1);
+    }
+}
+
+__global__ void __launch_bounds__(256) bce_bwd_kernel(const float* __restrict__ logit, const float* __restrict__ target,
+                                                      const float* __restrict__ valid, const double* __restrict__ sums,
+                                                      const float* __restrict__ upstream, float* __restrict__ dlogit, long long n,
+                                                      float pw) {
+    const float k = upstream[0] / (float)sums[1];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float x = logit[i], t = target[i];
+        const float lw = 1.f + (pw - 1.f) * t;
+        dlogit[i] = k * valid[i] * ((1.f - t) - lw * (1.f - rcf_sigmoid(x)));
+    }
+}
+
+unsigned grid_for(long long n, unsigned cap) {
+    long long b = (n + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}   // namespace
+
+extern "C" int rcf_roi_pool_fwd(const float* in, const float* rois, float* out, int* argmax, int n_roi, int n, int h, int w, int c,
+                                int pooled_h, int pooled_w, float spatial_scale, int out_cstride, int out_coff, void* stream) {
+    if (!in || !rois || !out || !argmax || n_roi <= 0 || n <= 0 || h <= 0 || w <= 0 || pooled_h <= 0 || pooled_w <= 0) return RCF_EINVAL;
+    if (c < 4 || (c & 3) || out_cstride < out_coff + c || (out_cstride & 3) || (out_coff & 3)) return RCF_EUNSUPPORTED;
+    const long long total = (long long)n_roi * pooled_h * pooled_w * (c >> 2);
+    hipLaunchKernelGGL(roi_pool_fwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, in, rois, out, argmax, n_roi,
+                       h, w, c, pooled_h, pooled_w, spatial_scale, out_cstride, out_coff);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_roi_pool_bwd(const float* dout, const int* argmax, const float* rois, float* din, int n_roi, int n, int h, int w,
+                                int c, int pooled_h, int pooled_w, int dout_cstride, int dout_coff, void* stream) {
+    if (!dout || !argmax || !rois || !din || n_roi <= 0 || n <= 0 || h <= 0 || w <= 0 || pooled_h <= 0 || pooled_w <= 0) return RCF_EINVAL;
+    if (c <= 0 || dout_cstride < dout_coff + c) return RCF_EUNSUPPORTED;
+    const long long total = (long long)n_roi * pooled_h * pooled_w * c;
+    hipLaunchKernelGGL(roi_pool_bwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dout, argmax, rois, din,
+                       n_roi, h, w, c, pooled_h, pooled_w, dout_cstride, dout_coff);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_fc_fwd(const float* x, const float* w, const float* bias, float* y, int m_rows, int n_in, int n_out, int act,
+                          int hw, int cstride, int coff, void* stream) {
+    if (!x || !w || !bias || !y || m_rows <= 0 || n_in <= 0 || n_out <= 0) return RCF_EINVAL;
+    if (m_rows > FC_MAX_M || (size_t)m_rows * n_in * 4 > 48 * 1024 || (hw > 1 && (n_out % hw != 0 || cstride < coff + n_out / hw)))
+        return RCF_EUNSUPPORTED;
+    const unsigned nb = (unsigned)((n_out + 255) / 256);
+    const size_t lds = (size_t)m_rows * n_in * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (m_rows <= 16) hipLaunchKernelGGL(fc_fwd_kernel<16>, dim3(nb), dim3(256), lds, st, x, w, bias, y, m_rows, n_in, n_out, act, hw, cstride, coff);
+    else if (m_rows <= 32) hipLaunchKernelGGL(fc_fwd_kernel<32>, dim3(nb), dim3(256), lds, st, x, w, bias, y, m_rows, n_in, n_out, act, hw, cstride, coff);
+    else hipLaunchKernelGGL(fc_fwd_kernel<64>, dim3(nb), dim3(256), lds, st, x, w, bias, y, m_rows, n_in, n_out, act, hw, cstride, coff);
+    return rcf_launch_status();
+}
+
+extern "C" size_t rcf_fc_bwd_workspace_floats(int m_rows, int n_in, int n_out) {
+    return (size_t)((n_out + 255) / 256) * m_rows * n_in;
+}
+
+extern "C" int rcf_fc_bwd(const float* x, const float* w, const float* y, const float* dy, float* dw, float* db, float* dx,
+                          float* workspace, int m_rows, int n_in, int n_out, int act, int hw, int cstride, int coff, void* stream) {
+    if (!x || !w || !y || !dy || !dw || !db || m_rows <= 0 || n_in <= 0 || n_out <= 0) return RCF_EINVAL;
+    if (dx && !workspace) return RCF_EINVAL;
+    if (m_rows > FC_MAX_M || (size_t)m_rows * n_in * 4 > 48 * 1024 || (hw > 1 && (n_out % hw != 0 || cstride < coff + n_out / hw)))
+        return RCF_EUNSUPPORTED;
+    const unsigned nb = (unsigned)((n_out + 255) / 256);
+    const size_t lds = (size_t)m_rows * n_in * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (m_rows <= 16) hipLaunchKernelGGL(fc_bwd_kernel<16>, dim3(nb), dim3(256), lds, st, x, y, dy, dw, db, m_rows, n_in, n_out, act, hw, cstride, coff);
+    else if (m_rows <= 32) hipLaunchKernelGGL(fc_bwd_kernel<32>, dim3(nb), dim3(256), lds, st, x, y, dy, dw, db, m_rows, n_in, n_out, act, hw, cstride, coff);
+    else hipLaunchKernelGGL(fc_bwd_kernel<64>, dim3(nb), dim3(256), lds, st, x, y, dy, dw, db, m_rows, n_in, n_out, act, hw, cstride, coff);
+    int rc = rcf_launch_status();
+    if (rc != RCF_OK || !dx) return rc;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_dx_partial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  256 * FC_MAX_M * (int)sizeof(float));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(fc_dx_partial_kernel, dim3(nb), dim3(256), (size_t)256 * m_rows * sizeof(float), st, w, y, dy, workspace, m_rows,
+                       n_in, n_out, act, hw, cstride, coff);
+    const int n = m_rows * n_in;
+    hipLaunchKernelGGL(fc_dx_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, workspace, dx, (int)nb, n);
+    return rcf_launch_status();
+}
+
+extern "C" size_t rcf_bce_workspace_doubles(void) { return (size_t)BCE_BLOCKS * 2; }
+
+extern "C" int rcf_bce_loss_fwd(const float* logit, const float* target, const float* valid, double* workspace, double* sums,
+                                float* loss, long long n, float pos_weight, void* stream) {
+    if (!logit || !target || !valid || !workspace || !sums || !loss || n <= 0) return RCF_EINVAL;
+    const unsigned nb = grid_for(n, BCE_BLOCKS);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bce_partial_kernel, dim3(nb), dim3(256), 0, st, logit, target, valid, workspace, n, pos_weight);
+    hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(64), 0, st, workspace, (int)nb, sums, loss);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_bce_loss_bwd(const float* logit, const float* target, const float* valid, const double* sums,
+                                const float* upstream, float* dlogit, long long n, float pos_weight, void* stream) {
+    if (!logit || !target || !valid || !sums || !upstream || !dlogit || n <= 0) return RCF_EINVAL;
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, logit, target, valid, sums, upstream,
+                       dlogit, n, pos_weight);
+    return rcf_launch_status();
+}

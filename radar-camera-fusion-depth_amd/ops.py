@@ -389,3 +389,45 @@ def radar_scatter(crops, points, width, strict_reference=True):
     check(_lib.load().rcf_radar_scatter(_f32(crops), _f32(points), k, h, width, wc, 1 if strict_reference else 0,
                                         _f32(depth), _f32(resp), _stream()), 'rcf_radar_scatter')
     return depth, resp
+
+
+# ---------------------------------------------------------------- RadarNet stage 1
+def roi_pool_fwd(x, rois, out, argmax, pooled_hw, spatial_scale, out_coff=0):
+    """x (N,H,W,C); rois (R,5); out (R,PH,PW,Ctot) written at channel offset out_coff; argmax (R,PH,PW,C) int32."""
+    n, h, w, c = x.shape
+    if argmax.dtype != torch.int32:
+        raise _lib.RcfError('roi_pool argmax must be int32')
+    check(_lib.load().rcf_roi_pool_fwd(_f32(x), _f32(rois), _f32(out), _p(argmax), rois.shape[0], n, h, w, c, pooled_hw[0],
+                                       pooled_hw[1], float(spatial_scale), out.shape[-1], out_coff, _stream()), 'rcf_roi_pool_fwd')
+
+
+def roi_pool_bwd(dout, argmax, rois, din, pooled_hw, dout_coff=0):
+    n, h, w, c = din.shape
+    check(_lib.load().rcf_roi_pool_bwd(_f32(dout), _p(argmax), _f32(rois), _f32(din), rois.shape[0], n, h, w, c, pooled_hw[0],
+                                       pooled_hw[1], dout.shape[-1], dout_coff, _stream()), 'rcf_roi_pool_bwd')
+
+
+def fc_fwd(x, w, b, y, act, hw=1, cstride=0, coff=0):
+    m, n_in = x.shape
+    check(_lib.load().rcf_fc_fwd(_f32(x), _f32(w), _f32(b), _f32(y), m, n_in, w.shape[0], 1 if act else 0, hw, cstride, coff,
+                                 _stream()), 'rcf_fc_fwd')
+
+
+def fc_bwd(x, w, y, dy, dw, db, dx, act, hw=1, cstride=0, coff=0):
+    m, n_in = x.shape
+    ws = None
+    if dx is not None:
+        ws = torch.empty(_lib.load().rcf_fc_bwd_workspace_floats(m, n_in, w.shape[0]), dtype=torch.float32, device=x.device)
+    check(_lib.load().rcf_fc_bwd(_f32(x), _f32(w), _f32(y), _f32(dy), _f32(dw), _f32(db), _f32(dx), _f32(ws), m, n_in, w.shape[0],
+                                 1 if act else 0, hw, cstride, coff, _stream()), 'rcf_fc_bwd')
+
+
+def bce_loss_fwd(logit, target, valid, sums, loss, pos_weight):
+    ws = torch.empty(_lib.load().rcf_bce_workspace_doubles(), dtype=torch.float64, device=logit.device)
+    check(_lib.load().rcf_bce_loss_fwd(_f32(logit), _f32(target), _f32(valid), _p(ws), _p(sums), _f32(loss), logit.numel(),
+                                       float(pos_weight), _stream()), 'rcf_bce_loss_fwd')
+
+
+def bce_loss_bwd(logit, target, valid, sums, upstream, dlogit, pos_weight):
+    check(_lib.load().rcf_bce_loss_bwd(_f32(logit), _f32(target), _f32(valid), _p(sums), _f32(upstream), _f32(dlogit),
+                                       logit.numel(), float(pos_weight), _stream()), 'rcf_bce_loss_bwd')

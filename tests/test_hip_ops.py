@@ -641,3 +641,89 @@ def test_conv_applies_producer_bn_on_load(ops, two_src):
     ops.conv_wgrad(d, y1, z2, dz, dw_a, ws)
     ops.conv_wgrad(d, z1, z2, dz, dw_b, ws, coef1=k1)
     assert torch.equal(dw_a, dw_b)
+
+
+# ---------------------------------------------------------------- RadarNet stage-1 ops
+@pytest.mark.gpu
+def test_roi_pool_forward_backward_matches_restated_torchvision(ops):
+    import torch
+    from oracle.roi_pool_oracle import roi_pool as roi_pool_ref
+    torch.manual_seed(3)
+    dev = 'cuda'
+    n, c, h, w = 2, 8, 23, 40
+    x = torch.randn(n, c, h, w)
+    boxes = [torch.tensor([[3.0, 0.0, 19.0, 22.0], [30.0, 0.0, 46.0, 22.0]]), torch.tensor([[-4.0, 0.0, 12.0, 22.0], [10.5, 2.0, 26.5, 20.0]])]
+    for scale, out_hw in ((1.0, (23, 16)), (0.5, (11, 8)), (0.25, (5, 4))):
+        hs, ws_ = max(1, int(h * scale)), max(1, int(w * scale))
+        xs = torch.nn.functional.interpolate(x, size=(hs, ws_)).clone().requires_grad_(True)
+        ref = roi_pool_ref(xs, boxes, out_hw, scale)
+        gref = torch.randn_like(ref)
+        ref.backward(gref)
+        rois = torch.cat([torch.cat([torch.full((b.shape[0], 1), float(i)), b], 1) for i, b in enumerate(boxes)], 0).to(dev)
+        x_nhwc = xs.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+        ctot, coff = c + 4, 4
+        out = torch.zeros(rois.shape[0], out_hw[0], out_hw[1], ctot, device=dev)
+        am = torch.empty(rois.shape[0], out_hw[0], out_hw[1], c, dtype=torch.int32, device=dev)
+        ops.roi_pool_fwd(x_nhwc, rois, out, am, out_hw, scale, out_coff=coff)
+        got = out[..., coff:].permute(0, 3, 1, 2).cpu()
+        assert torch.equal(got, ref.detach()), scale        # a max: bit-exact
+        assert float(out[..., :coff].abs().max()) == 0.0    # the other channels of the shared buffer are untouched
+        dout = torch.zeros_like(out)
+        dout[..., coff:] = gref.permute(0, 2, 3, 1).to(dev)
+        din = torch.zeros_like(x_nhwc)
+        ops.roi_pool_bwd(dout, am, rois, din, out_hw, dout_coff=coff)
+        np.testing.assert_allclose(din.permute(0, 3, 1, 2).cpu().numpy(), xs.grad.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('m,n_in,n_out,hw', [(4, 3, 32, 1), (24, 128, 2016, 63), (48, 32, 64, 1)])
+def test_fully_connected_forward_backward(ops, m, n_in, n_out, hw):
+    import torch
+    torch.manual_seed(9)
+    dev = 'cuda'
+    x = torch.randn(m, n_in, requires_grad=True)
+    lin = torch.nn.Linear(n_in, n_out)
+    y_ref = torch.nn.functional.leaky_relu(lin(x), 0.2)
+    g = torch.randn_like(y_ref)
+    y_ref.backward(g)
+    c = n_out // hw
+    ctot, coff = (c + 8, 8) if hw > 1 else (0, 0)
+    xd, wd, bd = x.detach().to(dev), lin.weight.detach().to(dev), lin.bias.detach().to(dev)
+    if hw > 1:   # feature f = ch * hw + p  ->  NHWC (m, p, coff + ch)
+        y = torch.zeros(m, hw, ctot, device=dev)
+        dy = torch.zeros(m, hw, ctot, device=dev)
+        dy[..., coff:] = g.view(m, c, hw).permute(0, 2, 1).to(dev)
+    else:
+        y = torch.empty(m, n_out, device=dev)
+        dy = g.to(dev)
+    ops.fc_fwd(xd, wd, bd, y, True, hw, ctot, coff)
+    got = y[..., coff:].permute(0, 2, 1).reshape(m, n_out) if hw > 1 else y
+    np.testing.assert_allclose(got.cpu().numpy(), y_ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+    dw, db, dx = torch.empty_like(wd), torch.empty_like(bd), torch.empty_like(xd)
+    ops.fc_bwd(xd, wd, y, dy, dw, db, dx, True, hw, ctot, coff)
+    np.testing.assert_allclose(dw.cpu().numpy(), lin.weight.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(db.cpu().numpy(), lin.bias.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_masked_bce_with_logits_loss(ops):
+    '''RadarNetModel.compute_loss (src/radarnet_model.py:131-171).'''
+    import torch
+    torch.manual_seed(4)
+    dev = 'cuda'
+    logit = (torch.randn(3, 1, 37, 29) * 4).requires_grad_(True)
+    target = (torch.rand(3, 1, 37, 29) < 0.3).float()
+    valid = (torch.rand(3, 1, 37, 29) < 0.7).float()
+    pw = 2.0
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(logit, target, reduction='none', pos_weight=torch.tensor(pw))
+    ref = torch.sum(valid * ref) / torch.sum(valid)
+    ref.backward()
+    sums = torch.empty(2, dtype=torch.float64, device=dev)
+    loss = torch.empty(1, device=dev)
+    ld, td, vd = logit.detach().to(dev), target.to(dev), valid.to(dev)
+    ops.bce_loss_fwd(ld, td, vd, sums, loss, pw)
+    np.testing.assert_allclose(float(loss), float(ref), rtol=1e-5)
+    dl = torch.empty_like(ld)
+    ops.bce_loss_bwd(ld, td, vd, sums, torch.ones(1, device=dev), dl, pw)
+    np.testing.assert_allclose(dl.cpu().numpy(), logit.grad.numpy(), rtol=1e-4, atol=1e-8)
