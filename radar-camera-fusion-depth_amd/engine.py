@@ -423,8 +423,9 @@ class Engine(object):
             return self.conv_bn_act(block.conv, deconv, x2=skip, feeds_head=feeds_head)
         return self.conv_bn_act(block.conv, deconv, feeds_head=feeds_head)
 
-    def head(self, layer, x):
-        '''output0 (src/networks.py:1548-1555, :1654) + d = min/(sigmoid(o)+min/max) (src/fusionnet_model.py:162-165).'''
+    def head(self, layer, x, logits=False):
+        '''output0 (src/networks.py:1548-1555, :1654) + d = min/(sigmoid(o)+min/max) (src/fusionnet_model.py:162-165).
+        logits=True (RadarNet, src/radarnet_model.py:118-126): the raw 3x3 C->1 output is the result and receives the gradient.'''
         if x.t is None and ops.head_bn_blocks(*x.z.shape) <= 0:
             self._mat(x)                          # the fused head kernels do not cover this channel count
         xin = x.t if x.t is not None else x.z     # deferred activation: raw conv output + coefficients
@@ -434,10 +435,15 @@ class Engine(object):
         logit = self._new((n, h, w), xin)
         depth = Act(self._new((n, h, w), xin))
         ops.head_fwd(xin, weight.detach(), logit, depth.t, self.dmin, self.dmax, coef=xcoef)
+        if logits:
+            depth = Act(logit)
         if self.tape is not None:
             def backward():
-                dlogit = torch.empty_like(logit)
-                ops.head_bwd_logit(depth.g, logit, dlogit, self.dmin, self.dmax)
+                if logits:
+                    dlogit = depth.g
+                else:
+                    dlogit = torch.empty_like(logit)
+                    ops.head_bwd_logit(depth.g, logit, dlogit, self.dmin, self.dmax)
                 depth.g = None
                 ops.head_bwd_wgrad(xin, dlogit, self.grad_of(weight), coef=xcoef)
                 self._wgrad_done(weight)
@@ -472,8 +478,13 @@ class Engine(object):
                 dep = self.resnet_block(blk_d, dep)
             layers.append(self.fuse(getattr(enc, 'conv%d_weight' % lvl), getattr(enc, 'conv%d_project' % lvl), dep, img))
         latent, skips = layers[-1], layers[:-1]
+        out = self.head(dec.output0, self._decode(latent, skips, image_nhwc.shape[1:3]))
+        tape, self.tape = self.tape, None
+        return out, tape
 
-        # MultiScaleDecoder.forward, n_resolution == 1 (src/networks.py:1571-1657)
+    def _decode(self, latent, skips, shape):
+        '''MultiScaleDecoder.forward, n_resolution == 1 (src/networks.py:1571-1657), up to the input of output0.'''
+        dec = self.decoder
         x = latent
         n = len(skips) - 1
         names = dec.block_names
@@ -481,10 +492,92 @@ class Engine(object):
             x = self.decoder_block(getattr(dec, name), x, skip=skips[n])
             n -= 1
         if n == 0:
-            x = self.decoder_block(dec.deconv0, x, skip=skips[0], feeds_head=True)
-        else:
-            x = self.decoder_block(dec.deconv0, x, shape=image_nhwc.shape[1:3], feeds_head=True)
-        out = self.head(dec.output0, x)
+            return self.decoder_block(dec.deconv0, x, skip=skips[0], feeds_head=True)
+        return self.decoder_block(dec.deconv0, x, shape=shape, feeds_head=True)
+
+    # ------------------------------------------------------------------ RadarNet stage 1
+    def roi_pool(self, x, rois, out_hw, scale, out=None, coff=0):
+        '''torchvision.ops.roi_pool (src/networks.py:1232-1247) of activation x around every radar point; written into the
+        channels [coff, coff + C) of `out` when given (the latent shared with the radar branch).'''
+        xt = self._mat(x)
+        n, h, w, c = xt.shape
+        r = rois.shape[0]
+        if out is None:
+            out = Act(self._new((r, out_hw[0], out_hw[1], c), xt))
+        argmax = torch.empty((r, out_hw[0], out_hw[1], c), dtype=torch.int32, device=xt.device)
+        ops.roi_pool_fwd(xt, rois, out.t, argmax, out_hw, scale, out_coff=coff)
+        if self.tape is not None:
+            def backward():
+                if x.needs_grad and out.g is not None:
+                    if x.g is None:
+                        x.g = torch.zeros_like(xt)   # rois overlap: scatter-add; later consumers accumulate on top
+                    ops.roi_pool_bwd(out.g, argmax, rois, x.g, out_hw, dout_coff=coff)
+            self.tape.append(backward)
+        return out
+
+    def fully_connected_encoder(self, enc, points, latent, hw, coff):
+        '''FullyConnectedEncoder.forward (src/networks.py:1065-1067); the last layer writes feature c * hw + p into
+        latent.t[m, p, coff + c] (= the .view(M, C, -1, W) + torch.cat of src/networks.py:1251-1255).'''
+        layers = list(enc.mlp)
+        acts = [points]
+        ctot = latent.t.shape[-1]
+        for i, fc in enumerate(layers):
+            lin = fc.fully_connected
+            act_on = fc.activation_func is not None
+            last = i == len(layers) - 1
+            if last:
+                ops.fc_fwd(acts[-1], lin.weight.detach(), lin.bias.detach(), latent.t, act_on, hw, ctot, coff)
+                acts.append(latent.t)
+            else:
+                y = self._new((points.shape[0], lin.out_features), points)
+                ops.fc_fwd(acts[-1], lin.weight.detach(), lin.bias.detach(), y, act_on)
+                acts.append(y)
+        if self.tape is not None:
+            def backward():
+                dy = latent.g
+                for i in range(len(layers) - 1, -1, -1):
+                    fc = layers[i]
+                    lin = fc.fully_connected
+                    last = i == len(layers) - 1
+                    dx = self._new(tuple(acts[i].shape), acts[i]) if i > 0 else None   # the radar points need no gradient
+                    ops.fc_bwd(acts[i], lin.weight.detach(), acts[i + 1], dy, self.grad_of(lin.weight), self.grad_of(lin.bias), dx,
+                               fc.activation_func is not None, hw if last else 1, ctot if last else 0, coff if last else 0)
+                    self._wgrad_done(lin.weight, lin.bias)
+                    dy = dx
+            self.tape.append(backward)
+
+    def forward_radarnet(self, image_nhwc, points, rois, training, record):
+        '''
+        RadarNetV1Encoder.forward (src/networks.py:1203-1256) + MultiScaleDecoder.forward + output0 -> logits (M,H,W) as an Act;
+        image_nhwc (N,H,W,3), points (M,3), rois (M,5) = (image index, x1, y1, x2, y2).
+        '''
+        enc = self.encoder
+        ei = enc.encoder_image
+        self.training = bool(training)
+        self.tape = [] if record else None
+        shape = (int(enc.input_patch_size_image[0]), int(enc.input_patch_size_image[1]))
+        # ResNetEncoder.forward (src/networks.py:232-268)
+        x = self.conv_bn_act(ei.conv1, Act(image_nhwc, needs_grad=False))
+        layers = [x]
+        x = self.max_pool(x)
+        for lvl in range(2, ei.network_depth + 1):
+            for blk in getattr(ei, 'blocks%d' % lvl):
+                x = self.resnet_block(blk, x)
+            layers.append(x)
+        latent_image, skips_image = layers[-1], layers[:-1]
+        # ROI pooling (src/networks.py:1215-1247)
+        skip_scales = [1 / 2.0, 1 / 4.0, 1 / 8.0, 1 / 16.0, 1 / 32.0, 1 / 64.0, 1 / 128.0]
+        lat_hw = (int(shape[0] // 32.0), int(shape[1] // 32.0))
+        m = rois.shape[0]
+        c_img = self._shape(latent_image)[3]
+        c_dep = enc.n_neuron_latent_depth
+        latent = Act(self._new((m, lat_hw[0], lat_hw[1], c_img + c_dep), image_nhwc))
+        skips = [self.roi_pool(s, rois, (int(shape[0] * skip_scales[i]), int(shape[1] * skip_scales[i])), skip_scales[i])
+                 for i, s in enumerate(skips_image)]
+        # radar point branch -> channels [c_img, c_img + c_dep) of the latent, pooled image latent -> [0, c_img)
+        self.fully_connected_encoder(enc.encoder_depth, points, latent, lat_hw[0] * lat_hw[1], c_img)
+        self.roi_pool(latent_image, rois, lat_hw, 1 / 32.0, out=latent, coff=0)
+        out = self.head(self.decoder.output0, self._decode(latent, skips, shape), logits=True)
         tape, self.tape = self.tape, None
         return out, tape
 

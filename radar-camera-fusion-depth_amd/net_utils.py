@@ -124,3 +124,21 @@ class OutlierRemoval(object):
     def remove_outliers(self, depth):
         from . import ops
         return ops.outlier_removal(depth, self.kernel_size, self.threshold)
+
+
+class FullyConnected(_NoForward):
+    '''src/net_utils.py:201-247: torch.nn.Linear (with bias) + activation; dropout is not on the shipped path.'''
+
+    def __init__(self, in_features, out_features, weight_initializer='kaiming_uniform', activation_func='leaky_relu',
+                 dropout_rate=0.00):
+        super(FullyConnected, self).__init__()
+        if dropout_rate > 0.00:
+            raise ValueError('Dropout is not implemented on the HIP path')
+        self.fully_connected = torch.nn.Linear(in_features, out_features)
+        if weight_initializer == 'kaiming_normal':
+            torch.nn.init.kaiming_normal_(self.fully_connected.weight)
+        elif weight_initializer == 'xavier_normal':
+            torch.nn.init.xavier_normal_(self.fully_connected.weight)
+        elif weight_initializer == 'xavier_uniform':
+            torch.nn.init.xavier_uniform_(self.fully_connected.weight)
+        self.activation_func = activation_func   # None | 'leaky_relu'

@@ -101,3 +101,65 @@ class MultiScaleDecoder(net_utils._NoForward):
             self.block_names.append(name)
             cin = n_filters[idx]
         self.output0 = net_utils.Conv2d(cin, output_channels, 3, 1, weight_initializer, None, False)   # :1548-1555
+
+
+class ResNetEncoder(net_utils._NoForward):
+    '''src/networks.py:8-268 (n_layer 18 / 34): conv1 7x7 s2, max_pool, blocks2..blocks7; same attribute names and state_dict keys.'''
+
+    def __init__(self, n_layer, input_channels=3, n_filters=[32, 64, 128, 256, 256], weight_initializer='kaiming_uniform',
+                 activation_func='leaky_relu', use_batch_norm=False):
+        super(ResNetEncoder, self).__init__()
+        if n_layer == 18:
+            n_blocks = [2, 2, 2, 2]
+        elif n_layer == 34:
+            n_blocks = [3, 4, 6, 3]
+        else:
+            raise ValueError('Only supports 18, 34 layer architecture')           # :40
+        for n in range(len(n_filters) - len(n_blocks) - 1):                        # :42-43
+            n_blocks = n_blocks + [n_blocks[-1]]
+        network_depth = len(n_filters)
+        assert network_depth < 8, 'Does not support network depth of 8 or more'    # :47
+        assert network_depth == len(n_blocks) + 1
+        self.network_depth = network_depth
+        act = net_utils.activation_func(activation_func)
+        f = list(n_filters)
+        self.conv1 = net_utils.Conv2d(input_channels, f[0], 7, 2, weight_initializer, act, use_batch_norm)   # :61
+        for lvl in range(2, 8):
+            if lvl <= network_depth:
+                stride = 1 if lvl == 2 else 2
+                blocks = []
+                for b in range(n_blocks[lvl - 2]):                                  # _make_layer :175-228
+                    blocks.append(net_utils.ResNetBlock(f[lvl - 2] if b == 0 else f[lvl - 1], f[lvl - 1], stride if b == 0 else 1,
+                                                        weight_initializer, act, use_batch_norm))
+                setattr(self, 'blocks%d' % lvl, torch.nn.Sequential(*blocks))
+            elif lvl >= 6:
+                setattr(self, 'blocks%d' % lvl, None)                               # :146, :165
+
+
+class FullyConnectedEncoder(net_utils._NoForward):
+    '''src/networks.py:1007-1067: six FullyConnected layers input -> n_neurons[0..4] -> latent_size, all with the activation.'''
+
+    def __init__(self, input_channels=3, n_neurons=[32, 64, 96, 128, 256], latent_size=29 * 10,
+                 weight_initializer='kaiming_uniform', activation_func='leaky_relu'):
+        super(FullyConnectedEncoder, self).__init__()
+        act = net_utils.activation_func(activation_func)
+        sizes = [input_channels] + list(n_neurons[:5]) + [latent_size]
+        self.mlp = torch.nn.Sequential(*[net_utils.FullyConnected(sizes[i], sizes[i + 1], weight_initializer, act)
+                                         for i in range(6)])
+
+
+class RadarNetV1Encoder(net_utils._NoForward):
+    '''src/networks.py:1151-1256: ResNet-18 image encoder, ROI pooling of its latent and skips around each radar point, and a
+    fully connected encoder of the point whose output is reshaped to the latent's size and concatenated to it.'''
+
+    def __init__(self, input_channels_image=3, input_channels_depth=3, input_patch_size_image=(900, 288),
+                 n_filters_encoder_image=[32, 64, 128, 128, 128], n_neurons_encoder_depth=[32, 64, 128, 128, 128],
+                 latent_size_depth=128 * 29 * 10, weight_initializer='kaiming_uniform', activation_func='leaky_relu',
+                 use_batch_norm=False):
+        super(RadarNetV1Encoder, self).__init__()
+        self.n_neuron_latent_depth = n_neurons_encoder_depth[-1]
+        self.encoder_image = ResNetEncoder(18, input_channels_image, n_filters_encoder_image, weight_initializer, activation_func,
+                                           use_batch_norm)
+        self.encoder_depth = FullyConnectedEncoder(input_channels_depth, n_neurons_encoder_depth, latent_size_depth,
+                                                   weight_initializer, activation_func)
+        self.input_patch_size_image = input_patch_size_image

@@ -62,7 +62,7 @@ def fill_state_dict_(modules, seed):
     Overwrite every tensor of the given torch modules' state dicts, in sorted key order, from
     numpy.random.RandomState(seed).  Keys follow the reference naming (e.g.
     'blocks2_image.0.conv1.conv.weight', '...batch_norm.running_mean'):
-      conv weight          U(-b, b), b = 1/sqrt(fan_in)
+      conv / fully_connected weight   U(-b, b), b = 1/sqrt(fan_in);   fully_connected bias  U(-0.2, 0.2)
       batch_norm.weight    U(0.5, 1.5)     batch_norm.bias  U(-0.1, 0.1)
       running_mean         U(-0.1, 0.1)    running_var      U(0.5, 1.5)
       num_batches_tracked  0
@@ -77,10 +77,12 @@ def fill_state_dict_(modules, seed):
                 t.zero_()
                 continue
             shape = tuple(t.shape)
-            if k.endswith('conv.weight'):
+            if k.endswith('conv.weight') or k.endswith('fully_connected.weight'):
                 fan_in = int(np.prod(shape[1:]))
                 b = 1.0 / np.sqrt(fan_in)
                 v = rs.uniform(-b, b, size=shape)
+            elif k.endswith('fully_connected.bias'):
+                v = rs.uniform(-0.2, 0.2, size=shape)
             elif k.endswith('batch_norm.weight') or k.endswith('running_var'):
                 v = rs.uniform(0.5, 1.5, size=shape)
             elif k.endswith('batch_norm.bias') or k.endswith('running_mean'):
@@ -119,3 +121,44 @@ TINY = dict(
     n_filters_encoder_depth=[4, 8, 16, 16, 16, 16],
     n_filters_decoder=[32, 32, 16, 8, 8, 4])
 '''SURVEY.md 8c fixture T0: same topology, small channels, used at odd spatial sizes.'''
+
+
+def make_radarnet_batch(seed, n=2, k=2, h=64, w=96, patch_w=32):
+    '''
+    Seeded RadarNet stage-1 inputs: image (n,3,h,w) U[0,1); k radar points per image (x in image coordinates at least half a
+    patch from the border, y, z) as an (n*k, 3) tensor; one box per point [x - patch_w/2, 0, x + patch_w/2, h] as
+    src/radarnet_main.py:638-648 builds them; per-point ground-truth and validity maps (n*k, 1, h, patch_w).
+    '''
+    rs = np.random.RandomState(seed)
+    image = rs.rand(n, 3, h, w).astype(np.float32)
+    pad = patch_w // 2
+    pts, boxes = [], []
+    for i in range(n):
+        x = rs.uniform(pad, w - pad, size=k)
+        pts.append(np.stack([x, rs.uniform(0, h, size=k), rs.uniform(1.0, 80.0, size=k)], -1).astype(np.float32))
+        boxes.append(np.stack([x - pad, np.zeros(k), x + pad, np.full(k, h)], -1).astype(np.float32))
+    m = n * k
+    gt = (rs.rand(m, 1, h, patch_w) < 0.2).astype(np.float32)
+    valid = (rs.rand(m, 1, h, patch_w) < 0.8).astype(np.float32)
+    return {
+        'image': torch.from_numpy(image),
+        'point': torch.from_numpy(np.concatenate(pts, 0)),
+        'bounding_boxes': [torch.from_numpy(b) for b in boxes],
+        'ground_truth': torch.from_numpy(gt),
+        'validity_map': torch.from_numpy(valid),
+    }
+
+
+RADARNET_TINY = dict(
+    input_channels_image=3, input_channels_depth=3, input_patch_size_image=(64, 32),
+    encoder_type=['radarnetv1', 'batch_norm'], n_filters_encoder_image=[8, 16, 32, 32, 32],
+    n_neurons_encoder_depth=[8, 16, 32, 32, 32], decoder_type=['multiscale', 'batch_norm'],
+    n_filters_decoder=[32, 16, 8, 8, 4], weight_initializer='kaiming_uniform', activation_func='leaky_relu')
+'''fixture T5: the shipped RadarNet topology (bash/train_radarnet_nuscenes.sh:22-31) with small channel counts.'''
+
+RADARNET_PUBLISHED = dict(
+    input_channels_image=3, input_channels_depth=3, input_patch_size_image=(900, 288),
+    encoder_type=['radarnetv1', 'batch_norm'], n_filters_encoder_image=[32, 64, 128, 128, 128],
+    n_neurons_encoder_depth=[32, 64, 128, 128, 128], decoder_type=['multiscale', 'batch_norm'],
+    n_filters_decoder=[256, 128, 64, 32, 16], weight_initializer='kaiming_uniform', activation_func='leaky_relu')
+'''bash/train_radarnet_nuscenes.sh:19-31'''

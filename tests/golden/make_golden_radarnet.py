@@ -1,0 +1,79 @@
+'''
+Golden fixture T5 for RadarNet stage 1: runs the REAL reference RadarNetModel (imported read-only from
+/root/reference/src, CPU, fp32) on seeded inputs/weights and stores output, loss, gradients and BN buffers.
+
+torchvision is absent from this image, so `torchvision.ops.roi_pool` -- the one call on this path that is not reference code
+(src/networks.py:1232-1247) -- is provided by oracle/roi_pool_oracle.py, the restatement of torchvision 0.11's kernel.  Parity
+is therefore UNPINNED at that boundary and pinned everywhere else (encoder, MLP, decoder, loss are the reference's own code).
+
+    python tests/golden/make_golden_radarnet.py
+'''
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = '/root/reference/src'
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from oracle.roi_pool_oracle import roi_pool
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    tv = _stub('torchvision')
+    tv.ops = _stub('torchvision.ops', roi_pool=roi_pool)
+    tv.utils = _stub('torchvision.utils')
+    tv.transforms = _stub('torchvision.transforms')
+    tv.transforms.functional = _stub('torchvision.transforms.functional')
+    if not hasattr(np, 'infty'):
+        np.infty = np.inf
+    sys.path.insert(0, REF)
+    import radarnet_model  # noqa
+    return radarnet_model
+
+
+def main():
+    torch.manual_seed(0)
+    from rcf_amd import synth
+    ref_mod = import_reference()
+    gold = os.path.dirname(os.path.abspath(__file__))
+    model = ref_mod.RadarNetModel(device=torch.device('cpu'), **synth.RADARNET_TINY)
+    synth.fill_state_dict_([model.encoder, model.decoder], 31)
+    b = synth.make_radarnet_batch(501)
+    image, points, boxes, gt, valid = b['image'], b['point'], b['bounding_boxes'], b['ground_truth'], b['validity_map']
+    model.train()
+    logits = model.forward(image, points, boxes, return_logits=True)
+    loss, _ = model.compute_loss(logits, gt, valid, w_positive_class=2.0)
+    loss.backward()
+    named = [('encoder.' + k, p) for k, p in model.encoder.named_parameters()] + \
+            [('decoder.' + k, p) for k, p in model.decoder.named_parameters()]
+    bufs = [('encoder.' + k, b) for k, b in model.encoder.named_buffers() if not k.endswith('num_batches_tracked')] + \
+           [('decoder.' + k, b) for k, b in model.decoder.named_buffers() if not k.endswith('num_batches_tracked')]
+    unused = sorted(k for k, p in named if p.grad is None)
+    print('T5: logits', tuple(logits.shape), 'loss %.6f' % float(loss), '%d params, %d unused' % (len(named), len(unused)))
+    # eval-mode output with the updated running statistics
+    model.eval()
+    with torch.no_grad():
+        ev = model.forward(image, points, boxes, return_logits=False)
+    np.savez_compressed(
+        os.path.join(gold, 'T5_radarnet_tiny_train.npz'),
+        meta=np.array([501, 31]), logits=logits.detach().numpy(), loss=np.array(float(loss), np.float64),
+        eval_sigmoid=ev.numpy(), unused=np.array(unused),
+        **{'grad:' + k: p.grad.numpy() for k, p in named if p.grad is not None},
+        **{'buf:' + k: b.detach().numpy() for k, b in bufs})
+    print('%-32s %8.1f KB' % ('T5_radarnet_tiny_train.npz', os.path.getsize(os.path.join(gold, 'T5_radarnet_tiny_train.npz')) / 1024.0))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,106 @@
+'''
+GPU parity tests of RadarNetModel through the C ABI against the golden fixture T5, which was produced by the
+real reference (src/radarnet_model.py) with torchvision.ops.roi_pool supplied by oracle/roi_pool_oracle.py (parity unpinned at
+that one boundary, see the fixture's generating script tests/golden/make_golden_radarnet.py).
+'''
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BAR = 1e-3   # relative fp32 tolerance (north_star)
+
+
+@pytest.fixture(scope='module')
+def env():
+    import rcf_amd
+    from rcf_amd import synth, radarnet_model
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return synth, radarnet_model
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _build(env, seed):
+    synth, rm = env
+    m = rm.RadarNetModel(device=torch.device('cuda'), **synth.RADARNET_TINY)
+    synth.fill_state_dict_([m.encoder, m.decoder], seed)
+    return m
+
+
+def _batch(synth, seed):
+    b = synth.make_radarnet_batch(seed)
+    out = {k: (v.cuda() if isinstance(v, torch.Tensor) else [t.cuda() for t in v]) for k, v in b.items()}
+    return out
+
+
+def test_t5_radarnet_tiny_train_step_matches_reference_golden(env):
+    synth, _ = env
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'T5_radarnet_tiny_train.npz'))
+    dseed, wseed = [int(v) for v in g['meta']]
+    m = _build(env, wseed)
+    b = _batch(synth, dseed)
+    m.train()
+    logits = m.forward(b['image'], b['point'], b['bounding_boxes'], return_logits=True)
+    loss, info = m.compute_loss(logits, b['ground_truth'], b['validity_map'], w_positive_class=2.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert tuple(logits.shape) == tuple(g['logits'].shape)
+    assert _rel(logits, g['logits']) < BAR
+    np.testing.assert_allclose(float(loss.detach()), float(g['loss']), rtol=BAR)
+    unused = set(g['unused'].tolist())
+    named = [('encoder.' + k, p) for k, p in m.encoder.named_parameters()] + [('decoder.' + k, p) for k, p in m.decoder.named_parameters()]
+    worst = 0.0
+    for key, p in named:
+        if key in unused:
+            assert p.grad is None, key
+            continue
+        e = _rel(p.grad, g['grad:' + key])
+        worst = max(worst, e)
+        assert e < 5 * BAR, (key, e)
+    bufs = [('encoder.' + k, v) for k, v in m.encoder.named_buffers() if not k.endswith('num_batches_tracked')] + \
+           [('decoder.' + k, v) for k, v in m.decoder.named_buffers() if not k.endswith('num_batches_tracked')]
+    for key, buf in bufs:
+        assert _rel(buf, g['buf:' + key]) < BAR, key
+    print('T5 worst gradient rel err %.2e' % worst)
+    m.eval()
+    with torch.no_grad():
+        ev = m.forward(b['image'], b['point'], b['bounding_boxes'], return_logits=False)
+    assert _rel(ev, g['eval_sigmoid']) < BAR
+
+
+def test_radarnet_checkpoint_and_adam_step(env, tmp_path):
+    '''save_model / restore_model keep the reference's dictionary keys; torch.optim.Adam drives the flat-arena parameters.'''
+    synth, _ = env
+    m = _build(env, 5)
+    opt = torch.optim.Adam([{'params': m.parameters(), 'weight_decay': 0.0}], lr=2e-4)
+    b = _batch(synth, 77)
+    m.train()
+    losses = []
+    for _ in range(3):
+        logits = m.forward(b['image'], b['point'], b['bounding_boxes'])
+        loss, _ = m.compute_loss(logits, b['ground_truth'], b['validity_map'], w_positive_class=2.0)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0]           # the same batch three times: the loss must go down
+    path = str(tmp_path / 'radarnet.pth')
+    m.save_model(path, 3, opt)
+    ck = torch.load(path, map_location='cpu')
+    assert set(ck.keys()) == {'train_step', 'radarnet_optimizer_state_dict', 'radarnet_encoder_state_dict', 'radarnet_decoder_state_dict'}
+    m2 = _build(env, 6)
+    step, _ = m2.restore_model(path)
+    assert step == 3
+    m.eval(); m2.eval()
+    with torch.no_grad():
+        a = m.forward(b['image'], b['point'], b['bounding_boxes'])
+        c = m2.forward(b['image'], b['point'], b['bounding_boxes'])
+    assert torch.equal(a, c)
