@@ -7,8 +7,9 @@ data_parallel), same checkpoint dictionary ('radarnet_encoder_state_dict', ...) 
 the decoder and the output convolution run on the FusionNet kernels through engine.py; ROI pooling, the fully connected radar
 branch and the masked BCE loss are csrc/rcf_radarnet.hip.  There is no CPU path.
 
-Parity note: torchvision.ops.roi_pool is absent from this image and from /root/reference; the HIP kernel follows the restatement
-in oracle/roi_pool_oracle.py (parity unpinned at that boundary, everything else is pinned against the imported reference).
+Parity note: torchvision.ops.roi_pool is absent from this image and from /root/reference; the HIP kernel follows a restatement
+of torchvision 0.11's published kernel that lives with the test infrastructure: parity is unpinned at that
+boundary, everything else is pinned against the imported reference.
 '''
 
 import torch

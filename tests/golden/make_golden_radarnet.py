@@ -74,6 +74,31 @@ def main():
         **{'buf:' + k: b.detach().numpy() for k, b in bufs})
     print('%-32s %8.1f KB' % ('T5_radarnet_tiny_train.npz', os.path.getsize(os.path.join(gold, 'T5_radarnet_tiny_train.npz')) / 1024.0))
 
+    # ---- T6: the shipped channel configuration (bash/train_radarnet_nuscenes.sh:27-31) on a small image / patch (96 x 64):
+    # exercises the >= 16-channel kernels; logits in full, gradients as L2 norms and sums
+    cfg = dict(synth.RADARNET_PUBLISHED)
+    cfg['input_patch_size_image'] = (96, 64)
+    model = ref_mod.RadarNetModel(device=torch.device('cpu'), **cfg)
+    synth.fill_state_dict_([model.encoder, model.decoder], 32)
+    b = synth.make_radarnet_batch(502, n=2, k=3, h=96, w=160, patch_w=64)
+    model.train()
+    logits = model.forward(b['image'], b['point'], b['bounding_boxes'], return_logits=True)
+    loss, _ = model.compute_loss(logits, b['ground_truth'], b['validity_map'], w_positive_class=2.0)
+    loss.backward()
+    named = [('encoder.' + k, p) for k, p in model.encoder.named_parameters()] + \
+            [('decoder.' + k, p) for k, p in model.decoder.named_parameters()]
+    keys = [k for k, p in named if p.grad is not None]
+    grads = dict(named)
+    print('T6: logits', tuple(logits.shape), 'loss %.6f' % float(loss.detach()))
+    np.savez_compressed(
+        os.path.join(gold, 'T6_radarnet_published_channels.npz'),
+        meta=np.array([502, 32, 2, 3, 96, 160, 64]), logits=logits.detach().numpy(), loss=np.array(float(loss.detach()), np.float64),
+        grad_keys=np.array(keys),
+        grad_l2=np.array([float(grads[k].grad.double().norm()) for k in keys]),
+        grad_sum=np.array([float(grads[k].grad.double().sum()) for k in keys]))
+    print('%-32s %8.1f KB' % ('T6_radarnet_published_channels.npz',
+                              os.path.getsize(os.path.join(gold, 'T6_radarnet_published_channels.npz')) / 1024.0))
+
 
 if __name__ == '__main__':
     main()

@@ -104,3 +104,27 @@ def test_radarnet_checkpoint_and_adam_step(env, tmp_path):
         a = m.forward(b['image'], b['point'], b['bounding_boxes'])
         c = m2.forward(b['image'], b['point'], b['bounding_boxes'])
     assert torch.equal(a, c)
+
+
+def test_t6_radarnet_published_channels_matches_reference_golden(env):
+    '''Shipped channel configuration on a small image: logits, loss and per-parameter gradient norms of the reference.'''
+    synth, rm = env
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'T6_radarnet_published_channels.npz'))
+    dseed, wseed, n, k, h, w, pw = [int(v) for v in g['meta']]
+    cfg = dict(synth.RADARNET_PUBLISHED)
+    cfg['input_patch_size_image'] = (h, pw)
+    m = rm.RadarNetModel(device=torch.device('cuda'), **cfg)
+    synth.fill_state_dict_([m.encoder, m.decoder], wseed)
+    b = synth.make_radarnet_batch(dseed, n=n, k=k, h=h, w=w, patch_w=pw)
+    b = {key: (v.cuda() if isinstance(v, torch.Tensor) else [t.cuda() for t in v]) for key, v in b.items()}
+    m.train()
+    logits = m.forward(b['image'], b['point'], b['bounding_boxes'])
+    loss, _ = m.compute_loss(logits, b['ground_truth'], b['validity_map'], w_positive_class=2.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert _rel(logits, g['logits']) < BAR
+    np.testing.assert_allclose(float(loss.detach()), float(g['loss']), rtol=BAR)
+    grads = dict([('encoder.' + kk, p) for kk, p in m.encoder.named_parameters()] + [('decoder.' + kk, p) for kk, p in m.decoder.named_parameters()])
+    for key, l2 in zip(g['grad_keys'].tolist(), g['grad_l2'].tolist()):
+        got = float(grads[key].grad.double().norm())
+        assert abs(got - l2) <= 5 * BAR * l2 + 1e-12, (key, got, l2)
