@@ -46,6 +46,9 @@ def parse():
     ap.add_argument('--height', type=int, default=900)
     ap.add_argument('--width', type=int, default=1600)
     ap.add_argument('--points', type=int, default=64)
+    ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32',
+                    help="arithmetic of the conv kernels: f32 (the metric's configuration) or bf16 operands with fp32 accumulate "
+                         '(BASELINE.json configs 3-5; informational)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--kernel-table', type=str, default='', help='write the per-kernel event table (JSON) here')
     return ap.parse_args()
@@ -92,6 +95,7 @@ def main():
 
     torch.manual_seed(1234)                       # identical initial weights on every rank
     model = train.build_model(synth.PUBLISHED, device=dev)
+    model.compute_dtype = 'bf16' if args.dtype == 'bf16' else 'fp32'
     if world > 1:
         model.data_parallel()
     opt = train.make_optimizer(model, lr=1e-3)
@@ -132,7 +136,8 @@ def main():
     # aggregate kernel ids (kind*1000 + ck*10 + nt [+100 for the 16x16 tile]; wgrad ids are 10000 + ...) by kernel family
     fam = {}
     for kid, (cnt, flops, ms) in table.items():
-        f = (10 + (kid - 10000) // 1000) if kid >= 10000 else kid // 1000
+        kid0 = kid - 20000 if kid >= 20000 else kid        # + 20000: bf16-operand variant of the same kernel family
+        f = (10 + (kid0 - 10000) // 1000) if kid0 >= 10000 else kid0 // 1000
         r = fam.setdefault(f, [0, 0.0, 0.0, 0.0])
         r[0] += cnt; r[1] += flops; r[2] += ms; r[3] += getattr(timer, 'bytes', {}).get(kid, 0.0)
     dom = max(fam, key=lambda f: fam[f][2]) if fam else None
@@ -150,10 +155,11 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': args.dtype,
             'data': 'synthetic',
-            'config': {'workload': 'FusionNet fp32 training, per-GPU batch %d, %dx%d, %d-point radar maps '
-                                   '(BASELINE.json configs[1])' % (args.batch, args.height, args.width, args.points),
+            'config': {'workload': 'FusionNet %s training, per-GPU batch %d, %dx%d, %d-point radar maps (BASELINE.json %s)'
+                                   % ('fp32' if args.dtype == 'f32' else 'bf16-operand', args.batch, args.height, args.width, args.points,
+                                      'configs[1]' if args.dtype == 'f32' else 'configs[3] arithmetic on one GPU'),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
                        'step': 'forward + outlier removal + masked L1 + backward + Adam, train-mode BatchNorm', 'final_loss': round(final_loss, 5)},
         }
@@ -162,7 +168,7 @@ def main():
             algorithmic = flops / (ms * 1e-3) / 1e12
             is_split = dom in (5, 9, 15, 19)
             # split kernels are bound by the bf16 matrix pipe: price them on the bf16 FLOPs they execute (6 per fp32 MAC)
-            achieved = algorithmic * (SPLIT_PRODUCTS if is_split else 1)
+            achieved = algorithmic * ((1 if args.dtype == 'bf16' else SPLIT_PRODUCTS) if is_split else 1)
             peak = BF16_MFMA_PEAK_TFLOPS if is_split else F32_MFMA_PEAK_TFLOPS
             traffic, traffic_src = None, None
             pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_bench.json')
@@ -179,7 +185,7 @@ def main():
                 'bound': 'mfma', 'kernel': KERNEL_NAMES.get(dom, str(dom)),
                 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                 'frac': round(achieved / peak, 4), 'algorithmic_fp32_tflops': round(algorithmic, 2),
-                'pipe': 'bf16 MFMA, 6 exact partial products per fp32 multiply, fp32 accumulate' if is_split else 'f32 MFMA', 'traffic': traffic, 'traffic_source': traffic_src,
+                'pipe': ('bf16 MFMA, bf16 operands, fp32 accumulate' if args.dtype == 'bf16' else 'bf16 MFMA, 6 exact partial products per fp32 multiply, fp32 accumulate') if is_split else 'f32 MFMA', 'traffic': traffic, 'traffic_source': traffic_src,
                 'algorithmic_gbytes_per_launch': round(abytes / cnt / 1e9, 4),
                 'launches_per_step': cnt // args.steps, 'avg_launch_ms': round(ms / cnt, 4),
                 'algorithmic_gflop_per_launch': round(flops / cnt / 1e9, 3),

@@ -49,6 +49,9 @@ extern "C" {
 /* Implicit-GEMM convolution descriptor: out[n,oy,ox,:] = sum_taps W[tap] . in[n, oy*stride-pad+ky, ox*stride-pad+kx, :]
  * where `in` is the channel concatenation [source1 | source2] (torch.cat([deconv, skip], 1), src/net_utils.py:565)
  * and source 1 may be gathered (nearest upsample / zero insert).  */
+#define RCF_PREC_FP32 0
+#define RCF_PREC_BF16 1
+
 typedef struct rcf_conv_desc {
     int n;              /* batch */
     int h_in, w_in;     /* logical input extent seen by the conv */
@@ -73,6 +76,10 @@ typedef struct rcf_conv_desc {
      * (a,b) with pad (a,b) -- the whole input gradient of an up-2x conv in ONE launch.  `packed` then holds the four
      * phases' packed weights back to back (each rcf_conv_info.packed_weight_floats long). */
     int phase_sum;
+    /* RCF_PREC_FP32 (0): fp32 results (the reference's arithmetic; f32 MFMA or the exact 3-plane bf16 split).
+     * RCF_PREC_BF16 (1): operands rounded to bf16 (nearest even), fp32 accumulate, fp32 tensors in HBM -- the "bf16"
+     * configurations of BASELINE.json; honoured by the split kernels, every other kernel keeps computing in fp32. */
+    int precision;
 } rcf_conv_desc;
 
 typedef struct rcf_conv_info {

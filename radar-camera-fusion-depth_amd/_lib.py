@@ -20,7 +20,7 @@ class ConvDesc(Structure):
     _fields_ = [(n, c_int) for n in (
         'n', 'h_in', 'w_in', 'c1', 'c2', 'h_src1', 'w_src1', 'gather1', 'h_out', 'w_out', 'c_out',
         'ksize', 'stride', 'pad', 'pad_x', 'w_mode', 'w_o', 'w_i', 'w_i_off', 'accumulate',
-        'out_stride', 'out_off_y', 'out_off_x', 'out_h_phys', 'out_w_phys', 'in_off_y', 'in_off_x', 'phase_sum')]
+        'out_stride', 'out_off_y', 'out_off_x', 'out_h_phys', 'out_w_phys', 'in_off_y', 'in_off_x', 'phase_sum', 'precision')]
 
 
 class ConvInfo(Structure):
@@ -28,6 +28,8 @@ class ConvInfo(Structure):
                 ('wgrad_workspace_floats', c_size_t), ('kernel_id', c_int), ('wgrad_kernel_id', c_int),
                 ('bn_on_load', c_int), ('wgrad_bn_on_load', c_int)]
 
+
+RCF_PREC_FP32, RCF_PREC_BF16 = 0, 1
 
 _P = c_void_p
 _SIGNATURES = {

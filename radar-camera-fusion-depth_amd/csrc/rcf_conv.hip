@@ -407,16 +407,19 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // fp32 halo tile is loaded once (registers), split, and written to LDS as three bf16 planes [pixel][16 ch] whose 16-B halves are
 // XOR-swizzled by bit 3 of the pixel index (conflict-free ds_read_b128 without padding).  The pre-split packed weights arrive one
 // KERNEL ROW (KSX taps) at a time into a double-buffered LDS piece, so only the A tile needs the two-barrier hand-over.
-template <int KS_, int NT_, int PX_, int MT_ = 0>
+// NPL_ = 3: fp32 results (exact split, six partial products).  NPL_ = 1: rcf_conv_desc.precision == RCF_PREC_BF16 -- operands
+// rounded to bf16 (nearest even), ONE product, fp32 accumulate: the "bf16" configurations of BASELINE.json.
+template <int KS_, int NT_, int PX_, int MT_ = 0, int NPL_ = 3>
 struct SplitCfg {
+    static constexpr int NPL = NPL_, NP = NPL_ == 3 ? 6 : 1;   // operand planes, partial products per MAC
     static constexpr int KSY = KS_, KSX = KS_, T = KS_ * KS_, LSTEP = 1, CK = 16, CST = 16;
     static constexpr int NT = NT_, BN = 32 * NT_;
     static constexpr int PX = PX_, PY = 32 / PX_, MT = MT_ ? MT_ : ((NT_ == 1 && KS_ == 3) ? 4 : 2), NW = 4, TH = PY * MT * NW;   // 3x3 32-co layers: 512-pixel tiles
     static constexpr int HXP = PX + KS_ - 1, HYP = TH + KS_ - 1, NPIX = HXP * HYP;
     static constexpr int A_PLANE_BYTES = NPIX * 32;        // 16 bf16 per halo pixel
-    static constexpr int A_BYTES = 3 * A_PLANE_BYTES;
+    static constexpr int A_BYTES = NPL * A_PLANE_BYTES;
     static constexpr int B_PLANE_BYTES = KSX * BN * 32;    // one kernel row: 16 bf16 per (tap, co)
-    static constexpr int B_PIECE_BYTES = 3 * B_PLANE_BYTES;
+    static constexpr int B_PIECE_BYTES = NPL * B_PLANE_BYTES;
     static constexpr int COEF_MAX_C = 512;                 // input channels (both sources) of the BN-on-load table
     static constexpr int COEF_BYTES = 2 * COEF_MAX_C * 4;
     static constexpr int LDS_BYTES = A_BYTES + 2 * B_PIECE_BYTES + COEF_BYTES;
@@ -425,6 +428,11 @@ struct SplitCfg {
 };
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+// fp32 -> bf16 (round to nearest even), result in the HIGH 16 bits (low bits garbage)
+__device__ __forceinline__ unsigned rcf_bf16_rne(float x) {
+    const unsigned u = __float_as_uint(x);
+    return u + 0x7fffu + ((u >> 16) & 1u);
+}
 // s_waitcnt vmcnt(0) (expcnt/lgkmcnt untouched): LDS-DMA completion is tracked by vmcnt only, and the compiler does not know
 // that a later ds_read depends on it -- the wait before the publishing barrier has to be explicit.
 __device__ __forceinline__ void rcf_wait_dma() { __builtin_amdgcn_s_waitcnt(0x0F70); }
@@ -556,11 +564,13 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
             if (p < C::NPIX) {
                 // exact 3-way truncation split: plane k keeps the next 8 significant bits
                 unsigned x0[4], x1[4], x2[4];
+                float xin[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float xv = ra[i][e];
                     if (ttf) xv = rcf_lrelu(xv * tsc[e] + tsh[e]);   // the producer's BatchNorm + LeakyReLU, applied on load
                     const float x = ((okm >> i) & 1u) ? xv : 0.f;
+                    xin[e] = x;
                     x0[e] = __float_as_uint(x) & 0xffff0000u;
                     const float r1 = x - __uint_as_float(x0[e]);
                     x1[e] = __float_as_uint(r1) & 0xffff0000u;
@@ -569,12 +579,22 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                 }
                 const int cq = tid & 3;
                 unsigned char* dst = As + p * 32 + (((cq >> 1) ^ ((p >> 3) & 1)) * 16) + (cq & 1) * 8;
-                u32x2 w0 = {(x0[0] >> 16) | x0[1], (x0[2] >> 16) | x0[3]};
-                u32x2 w1 = {(x1[0] >> 16) | x1[1], (x1[2] >> 16) | x1[3]};
-                u32x2 w2 = {(x2[0] >> 16) | (x2[1] & 0xffff0000u), (x2[2] >> 16) | (x2[3] & 0xffff0000u)};
-                *reinterpret_cast<u32x2*>(dst) = w0;
-                *reinterpret_cast<u32x2*>(dst + C::A_PLANE_BYTES) = w1;
-                *reinterpret_cast<u32x2*>(dst + 2 * C::A_PLANE_BYTES) = w2;
+                if (C::NPL == 1) {   // bf16 operands: round to nearest even instead of splitting
+                    unsigned r[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        r[e] = rcf_bf16_rne(xin[e]);
+                    }
+                    u32x2 w0 = {(r[0] >> 16) | (r[1] & 0xffff0000u), (r[2] >> 16) | (r[3] & 0xffff0000u)};
+                    *reinterpret_cast<u32x2*>(dst) = w0;
+                } else {
+                    u32x2 w0 = {(x0[0] >> 16) | x0[1], (x0[2] >> 16) | x0[3]};
+                    u32x2 w1 = {(x1[0] >> 16) | x1[1], (x1[2] >> 16) | x1[3]};
+                    u32x2 w2 = {(x2[0] >> 16) | (x2[1] & 0xffff0000u), (x2[2] >> 16) | (x2[3] & 0xffff0000u)};
+                    *reinterpret_cast<u32x2*>(dst) = w0;
+                    *reinterpret_cast<u32x2*>(dst + (C::NPL > 1 ? 1 : 0) * C::A_PLANE_BYTES) = w1;
+                    *reinterpret_cast<u32x2*>(dst + (C::NPL > 2 ? 2 : 0) * C::A_PLANE_BYTES) = w2;
+                }
             }
         }
     };
@@ -609,7 +629,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
     int tile = blockIdx.x;
     int q = 0;
     int pb = 0;   // LDS slot of the weight piece the current kernel row reads
-    bf16x8 av[2][3][C::MT], bv[2][3][C::NT];
+    bf16x8 av[2][C::NPL][C::MT], bv[2][C::NPL][C::NT];
     auto fetch_a = [&](int ky, int kx, int slot) {
 #pragma unroll
         for (int mi = 0; mi < C::MT; ++mi) {
@@ -618,13 +638,13 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
             const int p = ap + ky * C::HXP + kx;
             const int ao = p * 32 + ((lh ^ ((p >> 3) & 1)) * 16);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) av[slot][pl][mi] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + pl * C::A_PLANE_BYTES + ao));
+            for (int pl = 0; pl < C::NPL; ++pl) av[slot][pl][mi] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + pl * C::A_PLANE_BYTES + ao));
         }
     };
     auto fetch_b = [&](int kx, int slot, int bslot) {
         const unsigned char* Bp = Bs + bslot * C::B_PIECE_BYTES;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < C::NPL; ++pl)
 #pragma unroll
             for (int ni = 0; ni < C::NT; ++ni)
                 bv[slot][pl][ni] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bp + pl * C::B_PLANE_BYTES + (kx * C::BN + ni * 32) * 32 + bbase));
@@ -667,7 +687,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                 // apart), with the next tap's LDS reads issued ONE AT A TIME between them: issued as a block, the reads stall the
                 // wave's MFMA issue for as long as the LDS queue takes them, and the partner wave on the SIMD tends to be doing
                 // the same.  sched_barrier pins the hand-written order.
-                constexpr int MN = C::MT * C::NT, NMF = 6 * MN, NRD = 3 * (C::MT + C::NT);
+                constexpr int MN = C::MT * C::NT, NMF = C::NP * MN, NRD = C::NPL * (C::MT + C::NT);
                 const bool has_next = kx + 1 < C::KSX;
                 int nr = 0;
                 int ao_next[C::MT];
@@ -675,14 +695,15 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                 for (int j = 0; j < NMF; ++j) {
                     constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
                     const int pj = j / MN, mi = (j % MN) / C::NT, ni = j % C::NT;
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][PA[pj]][mi], bv[cur][PB[pj]][ni], acc[mi][ni], 0, 0, 0);
+                    const int pa = C::NPL == 3 ? PA[pj] : 0, pbl = C::NPL == 3 ? PB[pj] : 0;
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][pa][mi], bv[cur][pbl][ni], acc[mi][ni], 0, 0, 0);
                     if (has_next) {
 #pragma unroll
-                        for (int rep = 0; rep < 2; ++rep) {
+                        for (int rep = 0; rep < 3; ++rep) {
                             if (nr < NRD && (nr + 1) * NMF <= (j + 1) * NRD) {
                                 __builtin_amdgcn_sched_barrier(0);
-                                if (nr < 3 * C::MT) {
-                                    const int rmi = nr / 3, pl = nr % 3;
+                                if (nr < C::NPL * C::MT) {
+                                    const int rmi = nr / C::NPL, pl = nr % C::NPL;
                                     if (pl == 0) {
                                         int ap = apix[rmi];
                                         asm volatile("" : "+v"(ap));
@@ -691,7 +712,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                     }
                                     av[cur ^ 1][pl][rmi] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + pl * C::A_PLANE_BYTES + ao_next[rmi]));
                                 } else {
-                                    const int rb = nr - 3 * C::MT, pl = rb / C::NT, rni = rb % C::NT;
+                                    const int rb = nr - C::NPL * C::MT, pl = rb / C::NT, rni = rb % C::NT;
                                     bv[cur ^ 1][pl][rni] = as_bf16x8(*reinterpret_cast<const u32x4*>(
                                         Bs + pb * C::B_PIECE_BYTES + pl * C::B_PLANE_BYTES + ((kx + 1) * C::BN + rni * 32) * 32 + bbase));
                                 }
@@ -814,7 +835,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
 // OIHW fp32 -> pre-split bf16 planes [n-tile][chunk][kernel row][plane][kx][BN][16], halves swapped when (co >> 3) & 1.
 __global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, size_t total_rows16, int w_o,
                                           int w_i, int mode, int i_off, int c_out, int c1, int c2, int nchunk1, int nchunk, int BN,
-                                          int ks) {
+                                          int ks, int npl) {
     // one thread per (n-tile, chunk, tap, co, k) element; writes its three planes
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total_rows16) return;
@@ -840,11 +861,16 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned 
     const unsigned x1 = __float_as_uint(r1) & 0xffff0000u;
     const float r2 = r1 - __uint_as_float(x1);
     const unsigned x2 = __float_as_uint(r2);
-    const size_t chunk_elems = (size_t)3 * T * BN * 16;
+    const size_t chunk_elems = (size_t)npl * T * BN * 16;
     const size_t plane_elems = (size_t)ks * BN * 16;
-    const size_t piece_elems = 3 * plane_elems;
+    const size_t piece_elems = npl * plane_elems;
     const int kk = ((k >> 3) ^ ((j >> 3) & 1)) * 8 + (k & 7);   // XOR-swizzle the 16-B halves: conflict-free ds_read_b128
     const size_t base = ((size_t)nt * nchunk + q) * chunk_elems + (size_t)ky * piece_elems + ((size_t)kx * BN + j) * 16 + kk;
+    if (npl == 1) {   // bf16 operands: round to nearest even
+        const unsigned u = __float_as_uint(v);
+        dst[base] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        return;
+    }
     dst[base] = (unsigned short)(x0 >> 16);
     dst[base + plane_elems] = (unsigned short)(x1 >> 16);
     dst[base + 2 * plane_elems] = (unsigned short)(x2 >> 16);
@@ -1154,16 +1180,17 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(ConvArgs a) {
 // channel quads) land on adjacent rows: with a row pitch of 16 B mod 128 B both the writes and the reads are conflict-free.
 constexpr int ws_pitch(int bytes) { return ((bytes - 16 + 127) / 128) * 128 + 16; }   // >= bytes and == 16 (mod 128)
 
-template <int WCI_, int WCO_, int KS_ = 3, int TH_ = 8>
+template <int WCI_, int WCO_, int KS_ = 3, int TH_ = 8, int NPL_ = 3>
 struct WsCfg {
     static constexpr int KS = KS_, T = KS_ * KS_;
+    static constexpr int NPL = NPL_, NP = NPL_ == 3 ? 6 : 1;   // operand planes / partial products (1: bf16 operands, RCF_PREC_BF16)
     static constexpr int WCI = WCI_, WCO = WCO_, KSPLIT = 4 / (WCI_ * WCO_);
     static constexpr int NCI = 32 * WCI_, NCO = 32 * WCO_;
     static constexpr int PX = 16, TH = TH_, HXP = PX + KS - 1, HYP = TH + KS - 1;
     static constexpr int XROW = 48, DROW = 32;     // bytes per tile row of one channel: 24 px (18 used) / 16 px
     static constexpr int SX = ws_pitch(HYP * XROW), SD = ws_pitch(TH * DROW);   // bytes per channel and plane
     static constexpr int XPL = NCI * SX, DPL = NCO * SD;
-    static constexpr int X_BYTES = 3 * XPL, D_BYTES = 3 * DPL;
+    static constexpr int X_BYTES = NPL * XPL, D_BYTES = NPL * DPL;
     static constexpr int RED_BYTES = (KSPLIT > 1) ? WCI * WCO * T * 16 * 64 * 4 : 0;
     static constexpr int COEF_BYTES = 2 * NCI * 4;   // BN-on-load table of this workgroup's input channels: scale, shift
     static constexpr int LDS_BYTES = ((X_BYTES + D_BYTES) > RED_BYTES ? (X_BYTES + D_BYTES) : RED_BYTES) + COEF_BYTES;
@@ -1294,13 +1321,19 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 const float r2 = r1 - __uint_as_float(x1[h]);
                 x2[h] = __float_as_uint(r2);
             }
-            w0[d] = __builtin_amdgcn_perm(x0[1], x0[0], 0x07060302u);   // high halves of the pixel pair
-            w1[d] = __builtin_amdgcn_perm(x1[1], x1[0], 0x07060302u);
-            w2[d] = __builtin_amdgcn_perm(x2[1], x2[0], 0x07060302u);
+            if (C::NPL == 1) {   // bf16 operands: round to nearest even instead of splitting
+                w0[d] = __builtin_amdgcn_perm(rcf_bf16_rne(v[2 * d + 1][e]), rcf_bf16_rne(v[2 * d][e]), 0x07060302u);
+            } else {
+                w0[d] = __builtin_amdgcn_perm(x0[1], x0[0], 0x07060302u);   // high halves of the pixel pair
+                w1[d] = __builtin_amdgcn_perm(x1[1], x1[0], 0x07060302u);
+                w2[d] = __builtin_amdgcn_perm(x2[1], x2[0], 0x07060302u);
+            }
         }
         *reinterpret_cast<u32x4*>(dst) = w0;
-        *reinterpret_cast<u32x4*>(dst + plane_bytes) = w1;
-        *reinterpret_cast<u32x4*>(dst + 2 * plane_bytes) = w2;
+        if (C::NPL == 3) {
+            *reinterpret_cast<u32x4*>(dst + plane_bytes) = w1;
+            *reinterpret_cast<u32x4*>(dst + 2 * plane_bytes) = w2;
+        }
     };
     auto store_tile = [&]() {
 #pragma unroll
@@ -1344,12 +1377,13 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
     constexpr int ROLL = C::KSPLIT == 1;
     constexpr int NSLOT = ROLL ? KS + 1 : 2 * KS;
     constexpr int NEWROWS = ROLL ? 1 : KS;          // halo rows fetched per step
-    constexpr int NRD = NEWROWS * 6 + 3;            // LDS reads per step: (b128 + b32) x 3 planes per row, + 3 dz
-    constexpr int NMF = 6 * C::T;                   // MFMAs per step
-    u32x4 xlo[NSLOT][3];     // [row slot][plane]  pixels 8h .. 8h+7
-    unsigned xhi[NSLOT][3];  //                    pixels 8h+8, 8h+9
-    u32x4 dzv[2][3];         // [set][plane]
-    u32x4 xs1[KS][3];        // kx = 1 operands of the current step
+    constexpr int NPL = C::NPL, NP = C::NP;
+    constexpr int NRD = NEWROWS * 2 * NPL + NPL;    // LDS reads per step: (b128 + b32) x planes per row, + planes of dz
+    constexpr int NMF = NP * C::T;                  // MFMAs per step
+    u32x4 xlo[NSLOT][NPL];     // [row slot][plane]  pixels 8h .. 8h+7
+    unsigned xhi[NSLOT][NPL];  //                    pixels 8h+8, 8h+9
+    u32x4 dzv[2][NPL];         // [set][plane]
+    u32x4 xs1[KS][NPL];        // kx = 1 operands of the current step
 
     int tile = blockIdx.x;
     if (tile < a.ntiles) load_tile(tile);
@@ -1364,12 +1398,12 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NPL; ++pl) {
                 xlo[ky][pl] = *reinterpret_cast<const u32x4*>(xb + pl * C::XPL + ky * C::XROW);
                 xhi[ky][pl] = *reinterpret_cast<const unsigned*>(xb + pl * C::XPL + ky * C::XROW + 16);
             }
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) dzv[0][pl] = *reinterpret_cast<const u32x4*>(db + pl * C::DPL);
+        for (int pl = 0; pl < NPL; ++pl) dzv[0][pl] = *reinterpret_cast<const u32x4*>(db + pl * C::DPL);
         __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
@@ -1383,21 +1417,24 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 // partial products run smallest first and the kernel rows alternate
                 constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
                 constexpr int KXO[3] = {0, KS == 3 ? 2 : 1, 1};
-                const int kx = KXO[j / (6 * KS)], pj = (j % (6 * KS)) / KS, ky = j % KS;
+                const int kx = KXO[j / (NP * KS)], pj = (j % (NP * KS)) / KS, ky = j % KS;
                 const int tap = ky * KS + kx;
                 const int sl = ROLL ? (s + ky) % (KS + 1) : cur * KS + ky;
+                const int pa = NPL == 3 ? PA[pj] : 0, pbl = NPL == 3 ? PB[pj] : 0;
                 u32x4 av;
-                if (kx == 0) av = xlo[sl][PA[pj]];
-                else if (kx == 1) av = xs1[ky][PA[pj]];
+                if (kx == 0) av = xlo[sl][pa];
+                else if (kx == 1) av = xs1[ky][pa];
                 else {
-                    const u32x4 lo = xlo[sl][PA[pj]];
-                    av[0] = lo[1]; av[1] = lo[2]; av[2] = lo[3]; av[3] = xhi[sl][PA[pj]];
+                    const u32x4 lo = xlo[sl][pa];
+                    av[0] = lo[1]; av[1] = lo[2]; av[2] = lo[3]; av[3] = xhi[sl][pa];
                 }
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av), as_bf16x8(dzv[cur][PB[pj]]), acc[tap], 0, 0, 0);
-                // one kx = 1 operand (4 v_alignbit) behind each of the first 3 KS even MFMAs (all inside the kx = 0 group)
-                if (j < 6 * KS && (j & 1) == 0) {
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av), as_bf16x8(dzv[cur][pbl]), acc[tap], 0, 0, 0);
+                // one kx = 1 operand (4 v_alignbit) behind each of the first NPL * KS even (three planes) / consecutive (one plane)
+                // MFMAs: all of them before the kx = 1 group starts
+                constexpr int SHS = NPL == 3 ? 2 : 1;
+                if (j < SHS * NPL * KS && j % SHS == 0) {
                     __builtin_amdgcn_sched_barrier(0);
-                    const int sky = (j / 2) / 3, spl = (j / 2) % 3;
+                    const int sky = (j / SHS) / NPL, spl = (j / SHS) % NPL;
                     const int ssl = ROLL ? (s + sky) % (KS + 1) : cur * KS + sky;
                     const u32x4 lo = xlo[ssl][spl];
                     const unsigned hi = xhi[ssl][spl];
@@ -1410,18 +1447,19 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 // the next step's LDS reads, one at a time, spread evenly over the step.  Ring (KSPLIT == 1): only the new halo
                 // row, into the slot that held row s - 1 and is free during the whole step; otherwise KS rows into the other set.
                 const int n0 = (j * NRD) / NMF, n1 = ((j + 1) * NRD) / NMF;
-                if (has_next && n1 > n0) {
+#pragma unroll
+                for (int nr = n0; nr < n1; ++nr) {
+                    if (!has_next) break;
                     __builtin_amdgcn_sched_barrier(0);
-                    const int nr = n0;
-                    if (nr < NEWROWS * 6) {
-                        const int rrow = (nr / 2) / 3, rpl = (nr / 2) % 3;
+                    if (nr < NEWROWS * 2 * NPL) {
+                        const int rrow = (nr / 2) / NPL, rpl = (nr / 2) % NPL;
                         const int rky = ROLL ? KS - 1 : rrow;
                         const int nsl = ROLL ? (s + KS) % (KS + 1) : nxt * KS + rrow;
                         const unsigned char* g = xb + rpl * C::XPL + (rn + rky) * C::XROW;
                         if ((nr & 1) == 0) xlo[nsl][rpl] = *reinterpret_cast<const u32x4*>(g);
                         else xhi[nsl][rpl] = *reinterpret_cast<const unsigned*>(g + 16);
                     } else {
-                        const int rpl = nr - NEWROWS * 6;
+                        const int rpl = nr - NEWROWS * 2 * NPL;
                         dzv[nxt][rpl] = *reinterpret_cast<const u32x4*>(db + rpl * C::DPL + rn * C::DROW);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1619,6 +1657,7 @@ struct Sel {
     int vt;   // virtual tall image tiling
     int split;   // fp32 on the bf16 matrix pipe (conv_split_kernel)
     int small;   // split 3x3 layer too small to fill the chip with 64-co workgroups: 256-pixel x 32-co workgroups instead
+    int bf16;    // rcf_conv_desc.precision == RCF_PREC_BF16 and a split kernel: one bf16 plane, one product
 };
 
 int num_cus() {
@@ -1757,6 +1796,16 @@ using S3_1_32 = SplitCfg<3, 1, 32>;
 using S3_2_32 = SplitCfg<3, 2, 32>;
 using S3_1_16 = SplitCfg<3, 1, 16>;
 using S3_2_16 = SplitCfg<3, 2, 16>;
+using B3_1_32 = SplitCfg<3, 1, 32, 0, 1>;    // bf16-operand variants (one plane, one product)
+using B3_2_32 = SplitCfg<3, 2, 32, 0, 1>;
+using B3_1_16 = SplitCfg<3, 1, 16, 0, 1>;
+using B3_2_16 = SplitCfg<3, 2, 16, 0, 1>;
+using B2_1_32 = SplitCfg<2, 1, 32, 0, 1>;
+using B2_2_32 = SplitCfg<2, 2, 32, 0, 1>;
+using B2_1_16 = SplitCfg<2, 1, 16, 0, 1>;
+using B2_2_16 = SplitCfg<2, 2, 16, 0, 1>;
+using B3_1_32s = SplitCfg<3, 1, 32, 2, 1>;
+using B3_1_16s = SplitCfg<3, 1, 16, 2, 1>;
 using S3_1_32s = SplitCfg<3, 1, 32, 2>;   // 256-pixel x 32-co workgroups: more of them for the small layers
 using S3_1_16s = SplitCfg<3, 1, 16, 2>;
 using S2_1_32 = SplitCfg<2, 1, 32>;
@@ -1814,6 +1863,7 @@ bool valid_desc(const rcf_conv_desc* d) {
     if (d->ksize != 1 && d->ksize != 2 && d->ksize != 3 && d->ksize != 7) return false;
     if (d->stride != 1 && d->stride != 2) return false;
     if (d->gather1 < 0 || d->gather1 > 3) return false;
+    if (d->precision != RCF_PREC_FP32 && d->precision != RCF_PREC_BF16) return false;
     if (d->out_stride != 1 && d->out_stride != 2) return false;
     if (d->out_h_phys <= 0 || d->out_w_phys <= 0) return false;
     if (d->gather1 == RCF_GATHER_DIRECT && (d->h_src1 != d->h_in || d->w_src1 != d->w_in)) return false;
@@ -1865,6 +1915,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     s->vt = 0;
     s->split = 0;
     s->small = 0;
+    s->bf16 = 0;
     if (((s->kind == K3S1 && s->ck == 16) || (s->kind == K2S1 && cmax >= 16)) && (d->c1 % 4 == 0) && (d->c2 % 4 == 0) &&
         split_enabled()) {
         s->split = 1;
@@ -1873,6 +1924,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
         // fewer 256-pixel x 64-co workgroups than CUs: halve the workgroup (BN = 32) to double their number
         const long long wgs = (((long long)d->n * d->h_out * d->w_out + 255) / 256) * ceil_div(d->c_out, 64);
         if (s->kind == K3S1 && s->nt == 2 && wgs < num_cus()) { s->small = 1; s->nt = 1; }
+        s->bf16 = d->precision == RCF_PREC_BF16 ? 1 : 0;
     }
     double best = -1.0;
     const bool vt_ok = vt_allowed(d);
@@ -1948,6 +2000,15 @@ int dispatch_fwd(const Sel& s, F&& f) {
 
 template <class F>
 int dispatch_split(const Sel& s, F&& f) {
+    if (s.bf16) {
+        if (s.kind == K2S1) {
+            if (s.nt == 1) return s.px == 16 ? f(Tag<B2_1_16>{}) : f(Tag<B2_1_32>{});
+            return s.px == 16 ? f(Tag<B2_2_16>{}) : f(Tag<B2_2_32>{});
+        }
+        if (s.nt == 1 && s.small) return s.px == 16 ? f(Tag<B3_1_16s>{}) : f(Tag<B3_1_32s>{});
+        if (s.nt == 1) return s.px == 16 ? f(Tag<B3_1_16>{}) : f(Tag<B3_1_32>{});
+        return s.px == 16 ? f(Tag<B3_2_16>{}) : f(Tag<B3_2_32>{});
+    }
     if (s.kind == K2S1) {
         if (s.nt == 1) return s.px == 16 ? f(Tag<S2_1_16>{}) : f(Tag<S2_1_32>{});
         return s.px == 16 ? f(Tag<S2_2_16>{}) : f(Tag<S2_2_32>{});
@@ -2054,11 +2115,11 @@ extern "C" int rcf_conv2d_query(const rcf_conv_desc* d, rcf_conv_info* info) {
     fill_args(d, s, &a);
     const int ntile_n = ceil_div(d->c_out, s.bn);
     info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * s.ck;
-    if (s.split) info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * 24;   // three bf16 planes
+    if (s.split) info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.bf16 ? 8 : 24);   // 16 bf16 x planes per row
     info->n_partials = s.split ? dispatch_split(s, [&](auto tag) { return split_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); })
                                : dispatch_fwd(s, [&](auto tag) { return fwd_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
     if (info->n_partials <= 0) return RCF_EUNSUPPORTED;
-    info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0) + (s.small ? 5 : 0);
+    info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0) + (s.small ? 5 : 0) + (s.bf16 ? 20000 : 0);
     info->wgrad_workspace_floats = 0;
     info->wgrad_kernel_id = 0;
     info->bn_on_load = (s.split && d->w_mode == RCF_W_FORWARD && d->c1 + d->c2 <= 512) ? 1 : 0;
@@ -2069,7 +2130,7 @@ extern "C" int rcf_conv2d_query(const rcf_conv_desc* d, rcf_conv_info* info) {
             info->wgrad_workspace_floats = (size_t)w.nsplit * w.ktot * w.cop + 64;   // + a zero page for the DMA path
             info->wgrad_bn_on_load = w.split ? 1 : 0;
             info->wgrad_kernel_id = 10000 + w.kind * 1000 + (w.px == 16 ? 100 : (w.px == 8 ? 200 : 0)) + (w.vt ? 400 : 0) +
-                                    (w.split ? 5000 + w.wci * 10 + w.wco : 0);
+                                    (w.split ? 5000 + w.wci * 10 + w.wco : 0) + ((w.split && d->precision == RCF_PREC_BF16) ? 20000 : 0);
         }
     }
     return RCF_OK;
@@ -2089,7 +2150,7 @@ extern "C" int rcf_conv2d_pack_weights(const rcf_conv_desc* d, const float* w_oi
         const size_t rows16 = (size_t)ntile_n * nchunk * s.t * s.bn * 16;
         hipLaunchKernelGGL(pack_weights_split_kernel, dim3((unsigned)((rows16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw,
                            reinterpret_cast<unsigned short*>(packed), rows16, d->w_o, d->w_i, d->w_mode, d->w_i_off, d->c_out, d->c1,
-                           d->c2, a.nchunk1, nchunk, s.bn, d->ksize);
+                           d->c2, a.nchunk1, nchunk, s.bn, d->ksize, s.bf16 ? 1 : 3);
         return rcf_launch_status();
     }
     const int ksx = s.kind == K7S2 ? 1 : d->ksize;
@@ -2128,7 +2189,7 @@ static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float
     a.in1 = in1; a.in2 = in2; a.wp = packed; a.out = out; a.stats = stat_partials; a.dz = nullptr; a.ws = nullptr;
     a.ktot = 0; a.cop = 0;
     const int nn = ceil_div(d->c_out, s.bn);
-    a.wp_phase_stride = (int)((size_t)nn * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.split ? 24 : s.ck));
+    a.wp_phase_stride = (int)((size_t)nn * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.split ? (s.bf16 ? 8 : 24) : s.ck));
     if (s.split) return dispatch_split(s, [&](auto tag) { return launch_split<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
     return dispatch_fwd(s, [&](auto tag) { return launch_fwd<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
 }
@@ -2188,6 +2249,17 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
         a.nchunk1 = ceil_div(d->c1, 32 * w.wci);
         a.nchunk2 = d->c2 > 0 ? ceil_div(d->c2, 32 * w.wci) : 0;
         const int cfg = w.wci * 10 + w.wco;
+        if (d->precision == RCF_PREC_BF16) {
+            if (w.kind == K2S1) {
+                if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2, 2, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
+                else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2, 2, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
+                else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 2, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
+                else rc = launch_wgrad_split<WsCfg<1, 1, 2, 16, 1>>(a, w.nsplit, w.gy, w.gz, st);
+            } else if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2, 3, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
+            else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2, 3, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
+            else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 3, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
+            else rc = launch_wgrad_split<WsCfg<1, 1, 3, 16, 1>>(a, w.nsplit, w.gy, w.gz, st);
+        } else
         if (w.kind == K2S1) {
             if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2, 2>>(a, w.nsplit, w.gy, w.gz, st);
             else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2, 2>>(a, w.nsplit, w.gy, w.gz, st);

@@ -239,7 +239,21 @@ class FusionNetModel(object):
         return self._grad_views[id(p)]
 
     # ------------------------------------------------------------------ engine entry points
+    # ------------------------------------------------------------------ arithmetic of the convolutions
+    compute_dtype = 'fp32'
+    '''
+    'fp32' (default, the reference's arithmetic) or 'bf16': the split convolution kernels round their operands to bf16 (nearest
+    even) and accumulate in fp32 -- the "bf16" configurations of BASELINE.json; tensors, BatchNorm, loss and optimizer stay fp32.
+    '''
+
     def _run_engine(self, image, input_depth, record):
+        ops.set_precision(self.compute_dtype)
+        try:
+            return self._run_engine_impl(image, input_depth, record)
+        finally:
+            ops.set_precision('fp32')
+
+    def _run_engine_impl(self, image, input_depth, record):
         if not image.is_cuda:
             raise _lib.RcfError('FusionNetModel.forward needs CUDA(HIP) tensors: the hot path is HIP-only '
                                 '(got %s)' % image.device)
@@ -261,7 +275,11 @@ class FusionNetModel(object):
         if self._dp is not None:
             self._dp.begin_backward()
         self._engine.on_param_grad = self._dp.on_param_grad if self._dp is not None else None
-        Engine.backward(out, tape, ddepth)
+        ops.set_precision(self.compute_dtype)
+        try:
+            Engine.backward(out, tape, ddepth)
+        finally:
+            ops.set_precision('fp32')
         if self._dp is not None:
             self._dp.finish_backward()
         if prev is not None:

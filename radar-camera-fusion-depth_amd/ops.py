@@ -44,6 +44,18 @@ def conv_out_hw(h, w, ksize, stride, pad):
     return (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
 
 
+_PRECISION = [0]   # rcf_conv_desc.precision of every descriptor built below (RCF_PREC_FP32 / RCF_PREC_BF16)
+
+
+def set_precision(p):
+    '''0 / 'fp32': fp32 arithmetic (default).  1 / 'bf16': bf16 operands, fp32 accumulate in the split conv kernels.'''
+    _PRECISION[0] = 1 if p in (1, 'bf16') else 0
+
+
+def get_precision():
+    return _PRECISION[0]
+
+
 def make_fwd_desc(n, h_in, w_in, c1, c2, c_out, ksize, stride, h_src1=None, w_src1=None, gather=RCF_GATHER_DIRECT):
     '''Descriptor of the reference's Conv2d (padding = ksize // 2, src/net_utils.py:61) on [src1 | src2].'''
     pad = ksize // 2
@@ -52,7 +64,7 @@ def make_fwd_desc(n, h_in, w_in, c1, c2, c_out, ksize, stride, h_src1=None, w_sr
                     h_src1=h_in if h_src1 is None else h_src1, w_src1=w_in if w_src1 is None else w_src1,
                     gather1=gather, h_out=h_out, w_out=w_out, c_out=c_out, ksize=ksize, stride=stride, pad=pad, pad_x=pad,
                     w_mode=RCF_W_FORWARD, w_o=c_out, w_i=c1 + c2, w_i_off=0, accumulate=0,
-                    out_stride=1, out_off_y=0, out_off_x=0, out_h_phys=h_out, out_w_phys=w_out, in_off_y=0, in_off_x=0, phase_sum=0)
+                    out_stride=1, out_off_y=0, out_off_x=0, out_h_phys=h_out, out_w_phys=w_out, in_off_y=0, in_off_x=0, phase_sum=0, precision=_PRECISION[0])
 
 
 def make_dgrad_desc(fwd, i_off, i_cnt, accumulate):
@@ -67,7 +79,7 @@ def make_dgrad_desc(fwd, i_off, i_cnt, accumulate):
                     gather1=RCF_GATHER_ZERO_INSERT if fwd.stride == 2 else RCF_GATHER_DIRECT,
                     h_out=fwd.h_in, w_out=fwd.w_in, c_out=i_cnt, ksize=k, stride=1, pad=k - 1 - fwd.pad, pad_x=k - 1 - fwd.pad,
                     w_mode=RCF_W_DGRAD, w_o=fwd.w_o, w_i=fwd.w_i, w_i_off=i_off, accumulate=1 if accumulate else 0,
-                    out_stride=1, out_off_y=0, out_off_x=0, out_h_phys=fwd.h_in, out_w_phys=fwd.w_in, in_off_y=0, in_off_x=0, phase_sum=0)
+                    out_stride=1, out_off_y=0, out_off_x=0, out_h_phys=fwd.h_in, out_w_phys=fwd.w_in, in_off_y=0, in_off_x=0, phase_sum=0, precision=_PRECISION[0])
 
 
 # ---- 2x2 phase convolutions (include/rcf_hip.h, RCF_PHASE_*) -------------------------------------------------------
@@ -76,7 +88,7 @@ def make_up2x_fwd_desc(n, hs, ws, c_in, c_out, a, b):
     return ConvDesc(n=n, h_in=hs, w_in=ws, c1=c_in, c2=0, h_src1=hs, w_src1=ws, gather1=RCF_GATHER_DIRECT,
                     h_out=hs, w_out=ws, c_out=c_out, ksize=2, stride=1, pad=1 - a, pad_x=1 - b,
                     w_mode=RCF_W_FORWARD, w_o=c_out, w_i=c_in, w_i_off=0, accumulate=0,
-                    out_stride=2, out_off_y=a, out_off_x=b, out_h_phys=2 * hs, out_w_phys=2 * ws, in_off_y=0, in_off_x=0, phase_sum=0)
+                    out_stride=2, out_off_y=a, out_off_x=b, out_h_phys=2 * hs, out_w_phys=2 * ws, in_off_y=0, in_off_x=0, phase_sum=0, precision=_PRECISION[0])
 
 
 def make_up2x_dgrad_desc(n, hs, ws, c_in, c_out, a, b, accumulate, phase_sum=False):
@@ -86,7 +98,7 @@ def make_up2x_dgrad_desc(n, hs, ws, c_in, c_out, a, b, accumulate, phase_sum=Fal
                     h_out=hs, w_out=ws, c_out=c_in, ksize=2, stride=1, pad=a, pad_x=b,
                     w_mode=RCF_W_FORWARD, w_o=c_in, w_i=c_out, w_i_off=0, accumulate=1 if accumulate else 0,
                     out_stride=1, out_off_y=0, out_off_x=0, out_h_phys=hs, out_w_phys=ws, in_off_y=a, in_off_x=b,
-                    phase_sum=1 if phase_sum else 0)
+                    phase_sum=1 if phase_sum else 0, precision=_PRECISION[0])
 
 
 def make_s2_dgrad_desc(fwd, a, b, accumulate):
@@ -96,7 +108,7 @@ def make_s2_dgrad_desc(fwd, a, b, accumulate):
     return ConvDesc(n=fwd.n, h_in=fwd.h_out, w_in=fwd.w_out, c1=fwd.c_out, c2=0, h_src1=fwd.h_out, w_src1=fwd.w_out,
                     gather1=RCF_GATHER_DIRECT, h_out=hy, w_out=wx, c_out=fwd.c1, ksize=2, stride=1, pad=0, pad_x=0,
                     w_mode=RCF_W_FORWARD, w_o=fwd.c1, w_i=fwd.c_out, w_i_off=0, accumulate=1 if accumulate else 0,
-                    out_stride=2, out_off_y=a, out_off_x=b, out_h_phys=fwd.h_in, out_w_phys=fwd.w_in, in_off_y=0, in_off_x=0, phase_sum=0)
+                    out_stride=2, out_off_y=a, out_off_x=b, out_h_phys=fwd.h_in, out_w_phys=fwd.w_in, in_off_y=0, in_off_x=0, phase_sum=0, precision=_PRECISION[0])
 
 
 def phase_weights(w_oihw, mode):

@@ -173,7 +173,16 @@ class RadarNetModel(object):
     _backward = FusionNetModel._backward
 
     # ------------------------------------------------------------------ engine entry point
+    compute_dtype = 'fp32'   # or 'bf16': see FusionNetModel.compute_dtype
+
     def _run_engine(self, image, point, rois, record):
+        ops.set_precision(self.compute_dtype)
+        try:
+            return self._run_engine_impl(image, point, rois, record)
+        finally:
+            ops.set_precision('fp32')
+
+    def _run_engine_impl(self, image, point, rois, record):
         if not image.is_cuda:
             raise _lib.RcfError('RadarNetModel.forward needs CUDA(HIP) tensors: the hot path is HIP-only (got %s)' % image.device)
         _lib.load()

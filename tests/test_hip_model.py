@@ -367,3 +367,35 @@ def test_t1_with_bn_on_load_in_the_conv_kernels(env, golden_dir):
     for key, l2 in zip(g['grad_keys'].tolist(), g['grad_l2'].tolist()):
         got = float(grads[key].grad.double().norm())
         assert abs(got - l2) <= 2e-3 * max(l2, 1e-6), (key, got, l2)
+
+
+def test_bf16_compute_mode_published_net(env, golden_dir):
+    '''FusionNetModel.compute_dtype = 'bf16' (bf16 operands, fp32 accumulate in the split conv kernels; BASELINE.json configs 3-5):
+    a training step of the published net stays close to the fp32 reference (bf16 has 8 significant bits: a loose bar) and differs
+    from the fp32 path (i.e. the mode is really in use).'''
+    synth, _ = env
+    g = np.load(os.path.join(golden_dir, 'T1_published_train.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    b = _gpu_batch(synth.make_batch(n, h, w, k, seed=dseed))
+    outs = {}
+    for mode in ('fp32', 'bf16'):
+        m = _build(env, synth.PUBLISHED, wseed)
+        m.compute_dtype = mode
+        m.train()
+        out = m.forward(image=b['image'], input_depth=b['input_depth'])
+        loss, info = _loss(m, b, out)
+        loss.backward()
+        torch.cuda.synchronize()
+        outs[mode] = (out.detach(), float(loss.detach()), m)
+    e32, e16 = _rel(outs['fp32'][0], g['output']), _rel(outs['bf16'][0], g['output'])
+    print('output rel err vs reference: fp32 %.2e, bf16 %.2e; loss %.5f / %.5f / ref %.5f' % (e32, e16, outs['fp32'][1], outs['bf16'][1], float(g['loss'][0])))
+    assert e32 < BAR
+    assert 1e-4 < e16 < 5e-2
+    assert abs(outs['bf16'][1] - float(g['loss'][0])) < 2e-2 * abs(float(g['loss'][0]))
+    grads = dict(_named(outs['bf16'][2], 'p'))
+    bad = 0
+    for key, l2 in zip(g['grad_keys'].tolist(), g['grad_l2'].tolist()):
+        got = float(grads[key].grad.double().norm())
+        if abs(got - l2) > 0.25 * l2 + 1e-9:
+            bad += 1
+    assert bad <= len(g['grad_keys']) // 20, bad     # gradient norms within 25 % for (nearly) every parameter

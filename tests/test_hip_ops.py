@@ -727,3 +727,62 @@ def test_masked_bce_with_logits_loss(ops):
     dl = torch.empty_like(ld)
     ops.bce_loss_bwd(ld, td, vd, sums, torch.ones(1, device=dev), dl, pw)
     np.testing.assert_allclose(dl.cpu().numpy(), logit.grad.numpy(), rtol=1e-4, atol=1e-8)
+
+
+# ---------------------------------------------------------------- bf16-operand mode (BASELINE.json "bf16" configurations)
+@pytest.mark.gpu
+@pytest.mark.parametrize('ksize,c1,c2,co,up', [(3, 32, 0, 64, False), (3, 64, 32, 64, False), (3, 64, 0, 32, False), (2, 32, 0, 64, True)])
+def test_bf16_operand_mode_matches_bf16_rounded_reference(ops, ksize, c1, c2, co, up):
+    '''rcf_conv_desc.precision = RCF_PREC_BF16: operands rounded to bf16 (nearest even), fp32 accumulate.  Against torch convs on
+    bf16-rounded fp32 tensors (fp64 accumulate) the only difference is the fp32 accumulation order: tight tolerance.'''
+    import torch
+    torch.manual_seed(21)
+    dev = 'cuda'
+    n, h, w = 2, 29, 45
+    rnd = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    x1 = torch.randn(n, h, w, c1, device=dev)
+    x2 = torch.randn(n, h, w, c2, device=dev) if c2 else None
+    ops.set_precision('bf16')
+    try:
+        if up:   # phase (1, 0) of the exact-2x UpConv: 2x2 conv, strided output
+            wt = torch.randn(co, c1, 2, 2, device=dev) * 0.2
+            d = ops.make_up2x_fwd_desc(n, h, w, c1, co, 1, 0)
+        else:
+            wt = torch.randn(co, c1 + c2, ksize, ksize, device=dev) * 0.1
+            d = ops.make_fwd_desc(n, h, w, c1, c2, co, ksize, 1, h, w, 0)
+        info = ops.conv_query(d)
+        assert info.kernel_id >= 20000, info.kernel_id     # a bf16-operand kernel was selected
+        packed = torch.empty(info.packed_weight_floats, device=dev)
+        ops.conv_pack(d, wt, packed)
+        out = torch.zeros(n, d.out_h_phys, d.out_w_phys, co, device=dev)
+        ops.conv_fwd(d, x1, x2, packed, out, None)
+        xin = torch.cat([x1, x2], 3) if c2 else x1
+        xr, wr = rnd(xin).double().permute(0, 3, 1, 2), rnd(wt).double()
+        if not up:
+            ref = torch.nn.functional.conv2d(xr, wr, padding=ksize // 2)
+            np.testing.assert_allclose(out.permute(0, 3, 1, 2).cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5)
+            # weight gradient: dz and x rounded to bf16
+            dz = torch.randn(n, h, w, co, device=dev)
+            dw = torch.empty_like(wt)
+            ws = torch.empty(max(1, info.wgrad_workspace_floats), device=dev)
+            assert info.wgrad_kernel_id >= 30000
+            ops.conv_wgrad(d, x1, x2, dz, dw, ws)
+            wref = torch.nn.grad.conv2d_weight(xr, wr.shape, rnd(dz).double().permute(0, 3, 1, 2), padding=ksize // 2)
+            np.testing.assert_allclose(dw.cpu().numpy(), wref.cpu().numpy(), rtol=2e-5, atol=2e-4)
+            # input gradient of source 1: dz and W rounded
+            dd = ops.make_dgrad_desc(d, 0, c1, False)
+            di = ops.conv_query(dd)
+            pk = torch.empty(di.packed_weight_floats, device=dev)
+            ops.conv_pack(dd, wt, pk)
+            dx = torch.empty(n, h, w, c1, device=dev)
+            ops.conv_fwd(dd, dz, None, pk, dx, None)
+            xref = torch.nn.grad.conv2d_input(xr.shape, wr, rnd(dz).double().permute(0, 3, 1, 2), padding=ksize // 2)[:, :c1]
+            np.testing.assert_allclose(dx.permute(0, 3, 1, 2).cpu().numpy(), xref.cpu().numpy(), rtol=2e-5, atol=2e-4)
+        else:
+            # phase (a, b) = (1, 0): rows use source rows (y, y+1) (pad 0 on top), columns (x-1, x) (pad 1 on the left)
+            xp = torch.nn.functional.pad(xr, (1, 0, 0, 1))
+            ref = torch.nn.functional.conv2d(xp, wr)
+            got = out[:, 1::2, 0::2, :].permute(0, 3, 1, 2)
+            np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    finally:
+        ops.set_precision('fp32')
