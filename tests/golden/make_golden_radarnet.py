@@ -56,6 +56,24 @@ def main():
     logits = model.forward(image, points, boxes, return_logits=True)
     loss, _ = model.compute_loss(logits, gt, valid, w_positive_class=2.0)
     loss.backward()
+    # ---- pin oracle/radarnet_oracle.py: same weights, same inputs -> identical logits, loss, gradients (stock torch ops both sides)
+    from oracle.radarnet_oracle import RadarNetOracle
+    ora = RadarNetOracle(**synth.RADARNET_TINY)
+    synth.fill_state_dict_([ora.encoder, ora.decoder], 31)
+    assert list(ora.encoder.state_dict().keys()) == list(model.encoder.state_dict().keys())
+    assert list(ora.decoder.state_dict().keys()) == list(model.decoder.state_dict().keys())
+    ora.train()
+    ol = ora.forward(image, points, boxes)
+    oloss = ora.compute_loss(ol, gt, valid, 2.0)
+    oloss.backward()
+    assert float((ol - logits).abs().max()) < 1e-5 * float(logits.abs().max()), 'oracle logits differ from the reference'
+    assert abs(float(oloss) - float(loss)) < 1e-6 * abs(float(loss))
+    for (k, p), (k2, p2) in zip(list(model.encoder.named_parameters()) + list(model.decoder.named_parameters()),
+                                list(ora.encoder.named_parameters()) + list(ora.decoder.named_parameters())):
+        assert k == k2 and (p.grad is None) == (p2.grad is None), k
+        if p.grad is not None:
+            assert float((p.grad - p2.grad).abs().max()) <= 5e-4 * float(p.grad.abs().max()) + 1e-9, k
+    print('[T5] oracle/radarnet_oracle.py == reference (logits, loss, every gradient)')
     named = [('encoder.' + k, p) for k, p in model.encoder.named_parameters()] + \
             [('decoder.' + k, p) for k, p in model.decoder.named_parameters()]
     bufs = [('encoder.' + k, b) for k, b in model.encoder.named_buffers() if not k.endswith('num_batches_tracked')] + \

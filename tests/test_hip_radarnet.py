@@ -128,3 +128,47 @@ def test_t6_radarnet_published_channels_matches_reference_golden(env):
     for key, l2 in zip(g['grad_keys'].tolist(), g['grad_l2'].tolist()):
         got = float(grads[key].grad.double().norm())
         assert abs(got - l2) <= 5 * BAR * l2 + 1e-12, (key, got, l2)
+
+
+@pytest.mark.parametrize('case', ['clipped_boxes', 'odd_image_k5'])
+def test_radarnet_fresh_inputs_match_cpu_oracle(env, case):
+    '''Fresh seeds and awkward geometry against the pinned CPU restatement (oracle/radarnet_oracle.py): boxes that stick out of the
+    image (clipped ROI bins, empty bins -> 0), five overlapping points per image on an odd-sized image.'''
+    from oracle.radarnet_oracle import RadarNetOracle
+    synth, rm = env
+    cfg = dict(synth.RADARNET_TINY)
+    if case == 'clipped_boxes':
+        b = synth.make_radarnet_batch(901, n=2, k=3, h=64, w=96, patch_w=32)
+        b['bounding_boxes'][0][0] = torch.tensor([-20.0, 0.0, 12.0, 64.0])     # left part outside the image
+        b['bounding_boxes'][1][2] = torch.tensor([80.0, 0.0, 112.0, 64.0])      # right part outside
+    else:
+        b = synth.make_radarnet_batch(902, n=2, k=5, h=70, w=119, patch_w=32)
+        cfg['input_patch_size_image'] = (64, 32)
+        for i in range(2):   # boxes of the patch height, as the training crops produce them
+            b['bounding_boxes'][i][:, 1] = 6.0
+            b['bounding_boxes'][i][:, 3] = 70.0
+        b['ground_truth'] = b['ground_truth'][:, :, 6:, :].contiguous()
+        b['validity_map'] = b['validity_map'][:, :, 6:, :].contiguous()
+    ora = RadarNetOracle(**cfg)
+    synth.fill_state_dict_([ora.encoder, ora.decoder], 61)
+    ora.train()
+    ol = ora.forward(b['image'], b['point'], b['bounding_boxes'])
+    oloss = ora.compute_loss(ol, b['ground_truth'], b['validity_map'], 2.0)
+    oloss.backward()
+    m = rm.RadarNetModel(device=torch.device('cuda'), **cfg)
+    synth.fill_state_dict_([m.encoder, m.decoder], 61)
+    bg = {key: (v.cuda() if isinstance(v, torch.Tensor) else [t.cuda() for t in v]) for key, v in b.items()}
+    m.train()
+    logits = m.forward(bg['image'], bg['point'], bg['bounding_boxes'])
+    loss, _ = m.compute_loss(logits, bg['ground_truth'], bg['validity_map'], w_positive_class=2.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert _rel(logits, ol.detach().numpy()) < BAR
+    np.testing.assert_allclose(float(loss.detach()), float(oloss.detach()), rtol=BAR)
+    for (k, p), (k2, p2) in zip(list(m.encoder.named_parameters()) + list(m.decoder.named_parameters()),
+                                list(ora.encoder.named_parameters()) + list(ora.decoder.named_parameters())):
+        assert k == k2
+        if p2.grad is None:
+            assert p.grad is None, k
+        else:
+            assert _rel(p.grad, p2.grad.numpy()) < 5 * BAR, k

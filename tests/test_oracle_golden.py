@@ -132,3 +132,29 @@ def test_t4_radar_scatter_oracle_matches_reference_golden(golden_dir):
         crops, pts = synth.make_scatter_case(k, h, w, wc, seed, bool(small_z))
         depth, resp = radar_scatter(crops, pts, w, strict_reference=True)
         assert np.array_equal(depth, g['depth%d' % ci]) and np.array_equal(resp, g['resp%d' % ci])
+
+
+def test_radarnet_oracle_reproduces_reference_fixture_t5(golden_dir):
+    '''oracle/radarnet_oracle.py against fixture T5 (captured from the real reference, roi_pool restated).'''
+    import rcf_amd  # noqa: F401
+    from rcf_amd import synth
+    from oracle.radarnet_oracle import RadarNetOracle
+    g = np.load(os.path.join(golden_dir, 'T5_radarnet_tiny_train.npz'))
+    dseed, wseed = [int(v) for v in g['meta']]
+    ora = RadarNetOracle(**synth.RADARNET_TINY)
+    synth.fill_state_dict_([ora.encoder, ora.decoder], wseed)
+    b = synth.make_radarnet_batch(dseed)
+    ora.train()
+    logits = ora.forward(b['image'], b['point'], b['bounding_boxes'])
+    loss = ora.compute_loss(logits, b['ground_truth'], b['validity_map'], 2.0)
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().numpy(), g['logits'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(float(loss.detach()), float(g['loss']), rtol=1e-6)
+    named = [('encoder.' + k, p) for k, p in ora.encoder.named_parameters()] + [('decoder.' + k, p) for k, p in ora.decoder.named_parameters()]
+    unused = set(g['unused'].tolist())
+    for k, p in named:
+        if k in unused:
+            assert p.grad is None
+        else:
+            ref = g['grad:' + k]
+            assert float(np.abs(p.grad.numpy() - ref).max()) <= 5e-4 * float(np.abs(ref).max()) + 1e-9, k
