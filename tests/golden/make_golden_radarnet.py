@@ -35,7 +35,13 @@ def import_reference():
     tv.ops = _stub('torchvision.ops', roi_pool=roi_pool)
     tv.utils = _stub('torchvision.utils')
     tv.transforms = _stub('torchvision.transforms')
-    tv.transforms.functional = _stub('torchvision.transforms.functional')
+    def tv_pad(img, padding, padding_mode='constant'):
+        l, t, r, b = padding
+        x = img if img.dim() == 4 else img.unsqueeze(0)
+        return torch.nn.functional.pad(x, (l, r, t, b), mode={'edge': 'replicate', 'constant': 'constant'}[padding_mode]) \
+            .reshape(*img.shape[:-2], img.shape[-2] + t + b, img.shape[-1] + l + r)
+    tv.transforms.functional = _stub('torchvision.transforms.functional', pad=tv_pad)
+    _stub('torch.utils.tensorboard', SummaryWriter=object)
     if not hasattr(np, 'infty'):
         np.infty = np.inf
     sys.path.insert(0, REF)
@@ -91,6 +97,22 @@ def main():
         **{'grad:' + k: p.grad.numpy() for k, p in named if p.grad is not None},
         **{'buf:' + k: b.detach().numpy() for k, b in bufs})
     print('%-32s %8.1f KB' % ('T5_radarnet_tiny_train.npz', os.path.getsize(os.path.join(gold, 'T5_radarnet_tiny_train.npz')) / 1024.0))
+
+    # ---- T7: stage-1 inference glue radarnet_main.forward (src/radarnet_main.py:534-591) with the real model: image + points ->
+    # dense radar depth / response maps
+    import radarnet_main
+    model.eval()
+    rs = np.random.RandomState(77)
+    h7, w7, k7, pw7 = 64, 96, 6, 32
+    img7 = torch.from_numpy(rs.rand(1, 3, h7, w7).astype(np.float32))
+    pts7 = np.stack([rs.uniform(0, w7, k7) + pw7 // 2, rs.uniform(0, h7, k7), rs.uniform(1.0, 9.0, k7)], -1).astype(np.float32)
+    pts7[:, 2] = np.array([0.7, 3.2, 5.9, 2.4, 1.1, 4.6], np.float32)   # small z: the in-place replacement chain fires
+    boxes7 = [torch.from_numpy(np.stack([pts7[:, 0] - pw7 // 2, np.zeros(k7), pts7[:, 0] + pw7 // 2, np.full(k7, h7)], -1).astype(np.float32))]
+    with torch.no_grad():
+        d7, r7 = radarnet_main.forward(model, img7, torch.from_numpy(pts7.copy()), boxes7, device=torch.device('cpu'))
+    print('T7: depth', tuple(d7.shape), 'nonzero response pixels', int((r7 > 0).sum()), 'distinct depths', sorted(set(d7.flatten().tolist()))[:8])
+    np.savez_compressed(os.path.join(gold, 'T7_radarnet_forward_scatter.npz'), image=img7.numpy(), points=pts7,
+                        depth=d7.numpy().astype(np.float32), response=r7.numpy())
 
     # ---- T6: the shipped channel configuration (bash/train_radarnet_nuscenes.sh:27-31) on a small image / patch (96 x 64):
     # exercises the >= 16-channel kernels; logits in full, gradients as L2 norms and sums

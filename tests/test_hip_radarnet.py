@@ -172,3 +172,30 @@ def test_radarnet_fresh_inputs_match_cpu_oracle(env, case):
             assert p.grad is None, k
         else:
             assert _rel(p.grad, p2.grad.numpy()) < 5 * BAR, k
+
+
+def test_t7_stage1_inference_glue_matches_reference_forward(env):
+    '''rcf_amd.pipeline.radarnet_forward == radarnet_main.forward (src/radarnet_main.py:534-591) with the real reference model:
+    padded image -> response crops of all points -> thresholded max / argmax scatter -> int64 depth replacement chain.'''
+    from rcf_amd import pipeline
+    synth, _ = env
+    gdir = os.path.join(os.path.dirname(__file__), 'golden')
+    g5 = np.load(os.path.join(gdir, 'T5_radarnet_tiny_train.npz'))
+    g = np.load(os.path.join(gdir, 'T7_radarnet_forward_scatter.npz'))
+    dseed, wseed = [int(v) for v in g5['meta']]
+    m = _build(env, wseed)
+    b = _batch(synth, dseed)
+    m.train()
+    with torch.no_grad():   # the fixture's model had seen one training forward (BatchNorm running statistics)
+        m.forward(b['image'], b['point'], b['bounding_boxes'])
+    m.eval()
+    pts = torch.from_numpy(g['points']).cuda()
+    pw = 32
+    h = g['image'].shape[-2]
+    boxes = [torch.stack([pts[:, 0] - pw // 2, torch.zeros_like(pts[:, 0]), pts[:, 0] + pw // 2, torch.full_like(pts[:, 0], h)], 1)]
+    depth, resp = pipeline.radarnet_forward(m, torch.from_numpy(g['image']).cuda(), pts, boxes)
+    assert tuple(depth.shape) == tuple(g['depth'].shape)
+    np.testing.assert_allclose(resp.cpu().numpy(), g['response'], rtol=BAR, atol=1e-4)
+    mism = int((depth.cpu().numpy() != g['depth']).sum())
+    assert mism <= max(2, int(0.002 * depth.numel())), mism     # integer depths: equal except where two responses tie within fp32 error
+    assert int((g['response'] > 0).sum()) > 20                  # the fixture does contain predictions
