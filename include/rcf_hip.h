@@ -280,6 +280,20 @@ int rcf_bce_loss_fwd(const float* logit, const float* target, const float* valid
 int rcf_bce_loss_bwd(const float* logit, const float* target, const float* valid, const double* sums, const float* upstream,
                      float* dlogit, long long n, float pos_weight, void* stream);
 
+/* ---- input augmentation: fusionnet_transforms.Transforms.transform, src/fusionnet_transforms.py:46-178 ------- */
+
+/* Per-sample brightness / contrast / saturation (torchvision.transforms.functional.adjust_* restated), float conversion, range
+ * normalisation (norm_mode 0: [0,255], 1: [0,1], 2: [-1,1]) and flips of a batch of RGB images (N,3,H,W).  do_* are N bytes
+ * (nullable: never), f_* N floats, all on the device; the 0..255-vs-0..1 decision of :81-83 is taken on the device. */
+size_t rcf_transform_workspace_bytes(int n);
+int rcf_transform_images(const float* img, float* out, int n, int h, int w, const unsigned char* do_brightness,
+                         const float* f_brightness, const unsigned char* do_contrast, const float* f_contrast,
+                         const unsigned char* do_saturation, const float* f_saturation, const unsigned char* do_hflip,
+                         const unsigned char* do_vflip, int norm_mode, void* workspace, void* stream);
+/* Per-sample horizontal / vertical flips of range maps (N,C,H,W) (src/fusionnet_transforms.py:139-163). */
+int rcf_transform_flip(const float* in, float* out, int n, int c, int h, int w, const unsigned char* do_hflip,
+                       const unsigned char* do_vflip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,9 @@ _SIGNATURES = {
     'rcf_bce_workspace_doubles': (c_size_t, []),
     'rcf_bce_loss_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_float, _P]),
     'rcf_bce_loss_bwd': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_float, _P]),
+    'rcf_transform_workspace_bytes': (c_size_t, [c_int]),
+    'rcf_transform_images': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P]),
+    'rcf_transform_flip': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'rcf_head_bn_blocks': (c_int, [c_int, c_int, c_int, c_int]),
     'rcf_head_bn_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'rcf_head_bn_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

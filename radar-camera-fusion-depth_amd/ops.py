@@ -443,3 +443,28 @@ def bce_loss_fwd(logit, target, valid, sums, loss, pos_weight):
 def bce_loss_bwd(logit, target, valid, sums, upstream, dlogit, pos_weight):
     check(_lib.load().rcf_bce_loss_bwd(_f32(logit), _f32(target), _f32(valid), _p(sums), _f32(upstream), _f32(dlogit),
                                        logit.numel(), float(pos_weight), _stream()), 'rcf_bce_loss_bwd')
+
+
+# ---------------------------------------------------------------- input augmentation
+def transform_images(images, do_b, f_b, do_c, f_c, do_s, f_s, do_hf, do_vf, norm_mode):
+    """images (N,3,H,W) fp32; do_* uint8[N] or None; f_* float32[N]; returns the transformed float images."""
+    n, c, h, w = images.shape
+    if c != 3:
+        raise _lib.RcfError('transform_images expects RGB images')
+    x = images.contiguous()
+    out = torch.empty_like(x)
+    ws = torch.empty(_lib.load().rcf_transform_workspace_bytes(n), dtype=torch.uint8, device=x.device)
+    for t in (do_b, do_c, do_s, do_hf, do_vf):
+        if t is not None and t.dtype != torch.uint8:
+            raise _lib.RcfError('transform decisions must be uint8')
+    check(_lib.load().rcf_transform_images(_f32(x), _f32(out), n, h, w, _p(do_b), _f32(f_b), _p(do_c), _f32(f_c), _p(do_s), _f32(f_s),
+                                           _p(do_hf), _p(do_vf), norm_mode, _p(ws), _stream()), 'rcf_transform_images')
+    return out
+
+
+def transform_flip(maps, do_hf, do_vf):
+    n, c, h, w = maps.shape
+    x = maps.contiguous()
+    out = torch.empty_like(x)
+    check(_lib.load().rcf_transform_flip(_f32(x), _f32(out), n, c, h, w, _p(do_hf), _p(do_vf), _stream()), 'rcf_transform_flip')
+    return out

@@ -786,3 +786,45 @@ def test_bf16_operand_mode_matches_bf16_rounded_reference(ops, ksize, c1, c2, co
             np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5)
     finally:
         ops.set_precision('fp32')
+
+
+# ---------------------------------------------------------------- input augmentation
+@pytest.mark.gpu
+def test_transforms_match_reference_fixture_t8(ops):
+    '''rcf_amd.fusionnet_transforms.Transforms against fixture T8: the real reference Transforms.transform with the decisions it
+    drew (torchvision's adjust_* restated, parity unpinned there).  Flips are exact; the photometric chain may differ by one
+    intensity level on the rare pixel whose blend lands within fp32 round-off of an integer.'''
+    import os
+    import torch
+    from rcf_amd.fusionnet_transforms import Transforms
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'T8_transforms.npz'))
+    cases = [
+        dict(normalized_image_range=[0, 1], random_brightness=[0.8, 1.2], random_contrast=[0.8, 1.2], random_saturation=[0.8, 1.2],
+             random_flip_type=['horizontal']),
+        dict(normalized_image_range=[-1, 1], random_brightness=[0.5, 1.5], random_contrast=[-1], random_saturation=[0.5, 1.5],
+             random_flip_type=['horizontal', 'vertical']),
+        dict(normalized_image_range=[0, 255], random_brightness=[-1], random_contrast=[0.6, 1.4], random_saturation=[-1],
+             random_flip_type=['none']),
+    ]
+    assert int(g['n_cases']) == len(cases)
+    for ci, kw in enumerate(cases):
+        t = Transforms(**kw)
+        dec = {k[len('dec%d_' % ci):]: torch.from_numpy(g[k]).cuda() for k in g.files if k.startswith('dec%d_' % ci)}
+        image = torch.from_numpy(g['image%d' % ci]).cuda()
+        maps = [torch.from_numpy(g['map%d_%d' % (ci, j)]).cuda() for j in range(2)]
+        images_out, maps_out = t.apply([image], maps, dec)
+        for j in range(2):
+            assert torch.equal(maps_out[j].cpu(), torch.from_numpy(g['map_out%d_%d' % (ci, j)])), (ci, j)
+        ref = g['image_out%d' % ci]
+        got = images_out[0].cpu().numpy()
+        level = {1: 1.0 / 255.0, 2: 2.0 / 255.0, 0: 1.0}[t._norm_mode]
+        diff = np.abs(got - ref)
+        assert float(diff.max()) <= level * 1.001 + 1e-6, (ci, float(diff.max()))
+        assert int((diff > 1e-5).sum()) <= max(3, int(0.002 * diff.size)), (ci, int((diff > 1e-5).sum()))
+    # the random path: same API as the reference, decisions drawn on the device
+    t = Transforms(**cases[0])
+    img = torch.from_numpy(g['image0']).cuda()
+    [out], [m0, m1] = t.transform([img], [torch.from_numpy(g['map0_0']).cuda(), torch.from_numpy(g['map0_1']).cuda()], 1.0)
+    assert out.shape == img.shape and float(out.max()) <= 1.0 and float(out.min()) >= 0.0
+    [out2] = Transforms(normalized_image_range=[0, 1]).transform([img])
+    np.testing.assert_allclose(out2.cpu().numpy(), np.floor(g['image0']) / 255.0, rtol=0, atol=1e-7)
