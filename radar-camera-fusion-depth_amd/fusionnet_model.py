@@ -421,6 +421,41 @@ class FusionNetModel(object):
             from .parallel import GradientBuckets
             self._dp = GradientBuckets(self)
 
+    def capture_inference(self, image, input_depth, warmup=2):
+        '''
+        Records one eval-mode forward (running-statistics BatchNorm, no tape) for inputs of this shape into a hipGraph and returns
+        a callable `run(image, input_depth) -> N x 1 x H x W depth`: each call copies the inputs into the graph's static buffers
+        and replays the ~370 kernel launches with one hipGraphLaunch.  The reference's inference loop (src/fusionnet_main.py:
+        708-731, :814) calls model.forward per sample; `run` stands in for that call.  Weight packing is part of the recorded
+        work, so a replay sees the parameters' current values (restore_model after capture is fine); the output tensor is reused
+        by the next replay -- clone it to keep it.
+        '''
+        if self._training:
+            raise _lib.RcfError('capture_inference records the eval-mode forward: call eval() first')
+        if not image.is_cuda:
+            raise _lib.RcfError('capture_inference needs CUDA(HIP) tensors (got %s)' % image.device)
+        static_image, static_depth = image.detach().clone(), input_depth.detach().clone()
+        side = torch.cuda.Stream(device=image.device)
+        side.wait_stream(torch.cuda.current_stream(image.device))
+        with torch.no_grad(), torch.cuda.stream(side):   # lazy one-time state (function attributes, zero page) before recording
+            for _ in range(max(1, warmup)):
+                self.forward(static_image, static_depth)
+        torch.cuda.current_stream(image.device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            static_out = self.forward(static_image, static_depth)
+
+        def run(image, input_depth):
+            if image.shape != static_image.shape or input_depth.shape != static_depth.shape:
+                raise _lib.RcfError('captured for %s / %s, got %s / %s' % (tuple(static_image.shape), tuple(static_depth.shape),
+                                                                          tuple(image.shape), tuple(input_depth.shape)))
+            static_image.copy_(image, non_blocking=True)
+            static_depth.copy_(input_depth, non_blocking=True)
+            graph.replay()
+            return static_out
+        run.graph = graph
+        return run
+
     def log_summary(self, summary_writer, tag, step, image=None, input_depth=None, input_response=None,
                     output_depth=None, ground_truth=None, scalars={}, n_display=4):
         '''

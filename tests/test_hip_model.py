@@ -401,3 +401,34 @@ def test_bf16_compute_mode_published_net(env, golden_dir):
         if abs(got - l2) > 0.25 * l2 + 1e-9:
             bad += 1
     assert bad <= len(g['grad_keys']) // 20, bad     # gradient norms within 25 % for (nearly) every parameter
+
+
+@pytest.mark.gpu
+def test_hipgraph_captured_inference_matches_eager_and_golden(env, golden_dir):
+    '''FusionNetModel.capture_inference (BASELINE.json config 5: hipGraph-captured inference): replays are bit-identical to the
+    eager eval-mode forward, for the captured inputs and for new ones, follow a parameter update, and match the T3 fixture.'''
+    synth, _ = env
+    g = np.load(os.path.join(golden_dir, 'T3_eval.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['published_meta']]
+    m = _build(env, synth.PUBLISHED, wseed)
+    with pytest.raises(Exception):
+        m.capture_inference(torch.zeros(n, 3, h, w, device='cuda'), torch.zeros(n, 2, h, w, device='cuda'))   # still in train mode
+    m.eval()
+    b = _gpu_batch(synth.make_batch(n, h, w, k, seed=dseed))
+    b2 = _gpu_batch(synth.make_batch(n, h, w, k, seed=dseed + 1))
+    run = m.capture_inference(b['image'], b['input_depth'])
+    with torch.no_grad():
+        for bb in (b, b2, b):
+            got = run(bb['image'], bb['input_depth']).clone()
+            ref = m.forward(image=bb['image'], input_depth=bb['input_depth'])
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref)
+        assert _rel(run(b['image'], b['input_depth']), g['published_output']) < BAR
+        # the packed weights are rebuilt inside the graph: a replay sees updated parameters
+        m.decoder.output0.conv.weight.data.mul_(1.5)
+        got = run(b['image'], b['input_depth']).clone()
+        ref = m.forward(image=b['image'], input_depth=b['input_depth'])
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref)
+        with pytest.raises(Exception):
+            run(b['image'][:, :, :-2], b['input_depth'][:, :, :-2])

@@ -43,6 +43,57 @@ void run(const char* name) {
     hipFree(out);
 }
 
+
+// Same loop with the accumulators pinned to AGPRs (as in conv_wgrad_split_kernel) and random operand bits (toggle power).
+template <int NACC, int THREADS, bool RANDOM, bool AGPR>
+__global__ void __launch_bounds__(THREADS, THREADS / 256) k2(float* out, int iters) {
+    f32x16 acc[NACC];
+    for (int j = 0; j < NACC; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    bf16x8 av[3], bv[3];
+    for (int p = 0; p < 3; ++p) {
+        unsigned u[4], w[4];
+        for (int d = 0; d < 4; ++d) {
+            unsigned h = (threadIdx.x * 2654435761u) ^ ((p * 4 + d + 1) * 0x9E3779B9u);
+            h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+            // bf16 pairs with small exponents so nothing overflows: sign/mantissa random, exponent ~ 2^-8..2^0
+            u[d] = RANDOM ? ((h & 0x807f807fu) | 0x3b803b80u) : 0x3f803f80u;
+            w[d] = RANDOM ? (((h * 31u) & 0x807f807fu) | 0x3b803b80u) : 0x3f803f80u;
+        }
+        av[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(u));
+        bv[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(w));
+    }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) {
+            if (AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[j]) : "v"(av[j % 3]), "v"(bv[(j / 3) % 3]));
+            else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[j % 3], bv[(j / 3) % 3], acc[j], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+    for (int j = 0; j < NACC; ++j) for (int r = 0; r < 16; ++r) s += acc[j][r];
+    out[blockIdx.x * THREADS + threadIdx.x] = s;
+}
+
+template <int NACC, int THREADS, bool RANDOM, bool AGPR>
+void run2(const char* name) {
+    float* out; hipMalloc(&out, 256 * THREADS * 4);
+    const int iters = 40000;   // ~6 ms: long enough for the power manager to react
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k2<NACC, THREADS, RANDOM, AGPR>), dim3(256), dim3(THREADS), 0, 0, out, 10);
+    hipDeviceSynchronize();
+    float best = 1e9f, last = 0.f;
+    for (int rep = 0; rep < 20; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k2<NACC, THREADS, RANDOM, AGPR>), dim3(256), dim3(THREADS), 0, 0, out, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best; last = ms;
+    }
+    const double per_simd = (double)iters * NACC * (THREADS / 64) * 256 / 1024.0;
+    printf("%-52s best %6.2f ns, sustained (20th launch) %6.2f ns per MFMA per SIMD\n", name, best * 1e6 / per_simd, last * 1e6 / per_simd);
+    hipFree(out);
+}
+
 int main() {
     run<9, 256, 0>("1 wave/SIMD, 9 acc, no fillers");
     run<9, 256, 2>("1 wave/SIMD, 9 acc, 2 VALU fillers");
@@ -51,5 +102,10 @@ int main() {
     run<4, 512, 0>("2 waves/SIMD, 4 acc, no fillers");
     run<4, 512, 2>("2 waves/SIMD, 4 acc, 2 VALU fillers");
     run<4, 512, 5>("2 waves/SIMD, 4 acc, 5 VALU fillers");
+    run2<9, 256, false, false>("1 wave/SIMD, 9 acc VGPR, constant operands");
+    run2<9, 256, true, false>("1 wave/SIMD, 9 acc VGPR, random operands");
+    run2<9, 256, true, true>("1 wave/SIMD, 9 acc AGPR, random operands");
+    run2<3, 256, true, true>("1 wave/SIMD, 3 acc AGPR, random operands");
+    run2<4, 512, true, false>("2 waves/SIMD, 4 acc VGPR, random operands");
     return 0;
 }
