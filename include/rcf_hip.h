@@ -294,6 +294,32 @@ int rcf_transform_images(const float* img, float* out, int n, int h, int w, cons
 int rcf_transform_flip(const float* in, float* out, int n, int c, int h, int w, const unsigned char* do_hflip,
                        const unsigned char* do_vflip, void* stream);
 
+/* ---- on-disk sample formats finished on the device: src/data_utils.py:167-335, src/datasets.py:19-109 ------------ */
+
+#define RCF_PIXEL_U8 0   /* 8-bit PNG */
+#define RCF_PIXEL_U16 1  /* 16-bit PNG (PIL mode I;16): what save_depth / save_response write */
+#define RCF_PIXEL_I32 2  /* PIL mode I */
+
+/* load_image (src/data_utils.py:167-198) + the crop of datasets.random_crop (src/datasets.py:101-109) for a batch: RGB bytes
+ * (n, src_h, src_w, 3) -> float32 (n, 3, h, w), rows/columns [y0, y0 + h) x [x0, x0 + w) with (y0, x0) = crop_yx[2b], crop_yx[2b+1]
+ * (device ints; NULL: no offset); normalize != 0 divides by 255.0 like load_image(normalize=True). */
+int rcf_decode_image_u8(const unsigned char* src, float* dst, int n, int src_h, int src_w, int h, int w, const int* crop_yx, int normalize,
+                        void* stream);
+/* load_depth / load_depth_with_validity_map / load_response (src/data_utils.py:200-269, :288-318) + crop for a batch of integer
+ * maps (n, src_h, src_w) of type src_type -> float32 (n, 1, h, w): z = float(pixel) / multiplier; clamp_nonpositive != 0 applies
+ * `z[z <= 0] = 0` (the depth loaders; load_response does not); validity (nullable) receives 1.0 where z > 0. */
+int rcf_decode_map(const void* src, int src_type, float* dst, float* validity, int n, int src_h, int src_w, int h, int w,
+                   const int* crop_yx, float multiplier, int clamp_nonpositive, void* stream);
+/* save_depth / save_response (src/data_utils.py:271-286, :320-335): out = np.uint32(z * multiplier), the array PIL then writes. */
+int rcf_encode_map_u32(const float* z, unsigned* out, long long count, float multiplier, void* stream);
+/* points_to_depth_map (setup/setup_dataset_nuscenes_with_denseGT.py:814-840): depth_map[round(y_k), round(x_k)] = depth[k] in point
+ * order (the last point of a pixel wins; np.round = half to even; negative indices wrap once like numpy's).  workspace:
+ * rcf_points_to_depth_map_workspace_bytes(h, w); its last int holds the number of points that fell outside the image (numpy raises
+ * IndexError for those; here they are skipped and counted). */
+size_t rcf_points_to_depth_map_workspace_bytes(int h, int w);
+int rcf_points_to_depth_map(const float* xs, const float* ys, const float* depth, int n_points, float* depth_map, int h, int w,
+                            void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@ RCF_GATHER_DIRECT, RCF_GATHER_NEAREST, RCF_GATHER_ZERO_INSERT, RCF_GATHER_STRIDE
 RCF_PHASE_UP2X_FWD, RCF_PHASE_UP2X_DGRAD, RCF_PHASE_S2_DGRAD = 0, 1, 2
 RCF_W_FORWARD, RCF_W_DGRAD = 0, 1
 RCF_ACT_NONE, RCF_ACT_LEAKY_RELU = 0, 1
+RCF_PIXEL_U8, RCF_PIXEL_U16, RCF_PIXEL_I32 = 0, 1, 2
 
 
 class ConvDesc(Structure):
@@ -61,6 +62,11 @@ _SIGNATURES = {
     'rcf_transform_workspace_bytes': (c_size_t, [c_int]),
     'rcf_transform_images': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P]),
     'rcf_transform_flip': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    'rcf_decode_image_u8': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    'rcf_decode_map': (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, c_int, _P]),
+    'rcf_encode_map_u32': (c_int, [_P, _P, c_longlong, c_float, _P]),
+    'rcf_points_to_depth_map_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'rcf_points_to_depth_map': (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, _P, _P]),
     'rcf_head_bn_blocks': (c_int, [c_int, c_int, c_int, c_int]),
     'rcf_head_bn_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'rcf_head_bn_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

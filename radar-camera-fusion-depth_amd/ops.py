@@ -468,3 +468,78 @@ def transform_flip(maps, do_hf, do_vf):
     out = torch.empty_like(x)
     check(_lib.load().rcf_transform_flip(_f32(x), _f32(out), n, c, h, w, _p(do_hf), _p(do_vf), _stream()), 'rcf_transform_flip')
     return out
+
+
+# ---------------------------------------------------------------- on-disk formats finished on the device
+def _crop_arg(crop_yx, n, src_h, src_w, h, w, device):
+    """crop offsets (n, 2) int32 on the device, bounds-checked on the host BEFORE they are uploaded (numpy / list / CPU tensor)."""
+    if crop_yx is None:
+        if (h, w) != (src_h, src_w):
+            raise _lib.RcfError('a crop needs its (y0, x0) offsets')
+        return None
+    c = torch.as_tensor(crop_yx, dtype=torch.int32)
+    if c.is_cuda:
+        raise _lib.RcfError('crop offsets are drawn on the host (datasets.random_crop): pass a list / numpy / CPU tensor')
+    if tuple(c.shape) != (n, 2):
+        raise _lib.RcfError('crop offsets must have shape (%d, 2)' % n)
+    if n and (int(c.min()) < 0 or int(c[:, 0].max()) + h > src_h or int(c[:, 1].max()) + w > src_w):
+        raise _lib.RcfError('crop window leaves the source image')
+    return c.contiguous().to(device, non_blocking=True)
+
+
+def decode_images(raw, crop_yx=None, shape=None, normalize=False):
+    """raw (N, H, W, 3) uint8 on the device -> (N, 3, h, w) float32: data_utils.load_image(..., data_format='CHW') + random_crop."""
+    if raw.dtype != torch.uint8 or raw.dim() != 4 or raw.shape[3] != 3:
+        raise _lib.RcfError('decode_images expects (N, H, W, 3) uint8')
+    n, src_h, src_w = int(raw.shape[0]), int(raw.shape[1]), int(raw.shape[2])
+    h, w = (src_h, src_w) if shape is None else (int(shape[0]), int(shape[1]))
+    crop = _crop_arg(crop_yx, n, src_h, src_w, h, w, raw.device)
+    out = torch.empty((n, 3, h, w), dtype=torch.float32, device=raw.device)
+    check(_lib.load().rcf_decode_image_u8(_p(raw), _f32(out), n, src_h, src_w, h, w, _p(crop), 1 if normalize else 0, _stream()),
+          'rcf_decode_image_u8')
+    return out
+
+
+_PIXEL_TYPES = {torch.uint8: _lib.RCF_PIXEL_U8, torch.uint16: _lib.RCF_PIXEL_U16, torch.int32: _lib.RCF_PIXEL_I32}
+
+
+def decode_maps(raw, multiplier=256.0, crop_yx=None, shape=None, clamp_nonpositive=True, with_validity=False):
+    """raw (N, H, W) uint8 / uint16 / int32 on the device -> (N, 1, h, w) float32 (data_utils.load_depth / load_response + crop);
+    with_validity also returns load_depth_with_validity_map's second output."""
+    if raw.dtype not in _PIXEL_TYPES or raw.dim() != 3:
+        raise _lib.RcfError('decode_maps expects (N, H, W) uint8 / uint16 / int32, got %s %s' % (raw.dtype, tuple(raw.shape)))
+    n, src_h, src_w = int(raw.shape[0]), int(raw.shape[1]), int(raw.shape[2])
+    h, w = (src_h, src_w) if shape is None else (int(shape[0]), int(shape[1]))
+    crop = _crop_arg(crop_yx, n, src_h, src_w, h, w, raw.device)
+    out = torch.empty((n, 1, h, w), dtype=torch.float32, device=raw.device)
+    valid = torch.empty_like(out) if with_validity else None
+    check(_lib.load().rcf_decode_map(_p(raw), _PIXEL_TYPES[raw.dtype], _f32(out), _f32(valid), n, src_h, src_w, h, w, _p(crop),
+                                     float(multiplier), 1 if clamp_nonpositive else 0, _stream()), 'rcf_decode_map')
+    return (out, valid) if with_validity else out
+
+
+def encode_maps(z, multiplier=256.0):
+    """np.uint32(z * multiplier) of data_utils.save_depth / save_response, as an int32 tensor holding the uint32 bit patterns."""
+    x = z.contiguous()
+    out = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    check(_lib.load().rcf_encode_map_u32(_f32(x), _p(out), x.numel(), float(multiplier), _stream()), 'rcf_encode_map_u32')
+    return out
+
+
+def points_to_depth_map(points, depth, height, width):
+    """points (2, N) = (x, y), depth (N,) on the device -> (H, W) float32 map, the last point of a pixel wins
+    (setup/setup_dataset_nuscenes_with_denseGT.py:814-840).  Raises IndexError for points outside the image, like numpy."""
+    if points.dim() != 2 or points.shape[0] != 2 or depth.dim() != 1 or depth.shape[0] != points.shape[1]:
+        raise _lib.RcfError('points_to_depth_map expects points (2, N) and depth (N,)')
+    # np.round of the reference in the points' own precision (half to even, like torch.round); integers are exact in float32
+    pts = torch.round(points).to(torch.float32).contiguous()
+    d = depth.to(torch.float32).contiguous()
+    n = int(pts.shape[1])
+    out = torch.empty((int(height), int(width)), dtype=torch.float32, device=pts.device)
+    ws = torch.empty(_lib.load().rcf_points_to_depth_map_workspace_bytes(int(height), int(width)), dtype=torch.uint8, device=pts.device)
+    check(_lib.load().rcf_points_to_depth_map(_f32(pts[0]), _f32(pts[1]), _f32(d), n, _f32(out), int(height), int(width), _p(ws),
+                                              _stream()), 'rcf_points_to_depth_map')
+    n_bad = int(ws[-4:].view(torch.int32).item())
+    if n_bad:
+        raise IndexError('%d point(s) fall outside the %d x %d image' % (n_bad, height, width))
+    return out
