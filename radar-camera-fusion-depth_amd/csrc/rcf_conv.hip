@@ -25,6 +25,10 @@
 
 namespace {
 
+// padding / out-of-image / out-of-range-channel lanes of the DMA and split weight-gradient kernels load from here instead of
+// branching: a zero-initialised device global (one copy per device, nothing allocated at run time)
+__device__ __attribute__((aligned(256))) const float rcf_zero_page[64] = {};
+
 struct ConvArgs {
     const float* in1;
     const float* in2;
@@ -34,7 +38,6 @@ struct ConvArgs {
     float* out;
     double* stats;
     const float* dz;   // wgrad only
-    const float* zero; // wgrad DMA path: >= 16 bytes of zeros in global memory (source of padded lanes)
     float* ws;         // wgrad only
     int n, h_in, w_in, c1, c2, h1, w1, gather1;
     int h_out, w_out, c_out, pad, pad_x, stride, gstep, accumulate;
@@ -437,6 +440,15 @@ __device__ __forceinline__ unsigned rcf_bf16_rne(float x) {
 // that a later ds_read depends on it -- the wait before the publishing barrier has to be explicit.
 __device__ __forceinline__ void rcf_wait_dma() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
+#ifdef RCF_PHASE_TIMING   // diagnostics build only (tools/phase_timing.py): where a wave of conv_split_kernel spends its cycles
+__device__ unsigned long long rcf_phase_cycles[8];
+#define RCF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define RCF_TACC(slot, t1, t0) tacc[slot] += (t1) - (t0)
+#else
+#define RCF_T(var)
+#define RCF_TACC(slot, t1, t0)
+#endif
+
 template <class C>
 __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
@@ -650,6 +662,10 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                 bv[slot][pl][ni] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bp + pl * C::B_PLANE_BYTES + (kx * C::BN + ni * 32) * 32 + bbase));
     };
     const unsigned char* cb_cur = wp;   // packed weights of the current chunk
+#ifdef RCF_PHASE_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     if (tile < a.ntiles) {
         load_a(tile, 0);
         copy_b(cb_cur, 0, 0);
@@ -675,11 +691,14 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
         for (int ky = 0; ky < C::KSY; ++ky) {
             const bool last_row = ky == C::KSY - 1;
             // every row starts in register set 0: its A operands were fetched before the barrier that published its weights
+            RCF_T(t_row0);
             fetch_b(0, 0, pb);
             if (!last_row) copy_b(cb_cur, ky + 1, pb ^ 1);   // nobody reads that slot during this row
             else if (more) copy_b(cb_next, 0, pb ^ 1);
             if (ky == (C::KSY >= 2 ? C::KSY - 2 : 0) && more) load_a(ntile, nq);
             __builtin_amdgcn_sched_barrier(0);
+            RCF_T(t_row1);
+            RCF_TACC(0, t_row1, t_row0);   // 0: row prologue (first B reads, DMA / global-load issue)
 #pragma unroll
             for (int kx = 0; kx < C::KSX; ++kx) {
                 const int cur = kx & 1;
@@ -724,6 +743,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            RCF_T(t_row2);
+            RCF_TACC(1, t_row2, t_row1);   // 1: the row's MFMAs + interleaved LDS reads
             if (last_row) {
                 if (q == nitem - 1) {
                     int t = tile;
@@ -788,13 +809,22 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                         }
                     }
                 }
+                RCF_T(t_e0);
+                RCF_TACC(2, t_e0, t_row2);     // 2: output epilogue (last chunk of a tile only)
                 __syncthreads();   // every wave is done reading the A tile
+                RCF_T(t_e1);
+                RCF_TACC(3, t_e1, t_e0);       // 3: barrier "A tile free"
                 if (more) store_a();
+                RCF_T(t_e2);
+                RCF_TACC(4, t_e2, t_e1);       // 4: store_a (wait for the global loads, split, ds_write)
             } else {
                 fetch_a(ky + 1, 0, 0);   // next row's first A operands: the tile does not change inside a chunk
             }
+            RCF_T(t_b0);
             rcf_wait_dma();   // the next weight piece has landed
             __syncthreads();
+            RCF_T(t_b1);
+            RCF_TACC(last_row ? 5 : 6, t_b1, t_b0);   // 5: DMA wait + publishing barrier after store_a; 6: the same between rows
             if (last_row && more) fetch_a(0, 0, 0);
             pb ^= 1;
         }
@@ -803,6 +833,11 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
         cb_cur = cb_next;
     }
 
+#ifdef RCF_PHASE_TIMING
+    tacc[7] = __builtin_amdgcn_s_memtime() - t_begin;   // 7: whole wave
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&rcf_phase_cycles[i], tacc[i]);
+#endif
     if (a.stats != nullptr) {
         __syncthreads();
         double* red = reinterpret_cast<double*>(smem_b);   // [4 waves][BN][2]
@@ -1083,7 +1118,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(ConvArgs a) {
         __syncthreads();   // the previous tile's MFMAs are done with LDS
 #pragma unroll
         for (int i = 0; i < H::NA; ++i) {
-            const float* g = (cok && halo.pix[i] >= 0) ? src + (size_t)halo.pix[i] * csrc + cch : a.zero;
+            const float* g = (cok && halo.pix[i] >= 0) ? src + (size_t)halo.pix[i] * csrc + cch : rcf_zero_page;
             float* dst = As + (i * H::PPI + wave * 8) * 32;   // wave-uniform; lane l lands 16*l bytes further
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -1101,7 +1136,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(ConvArgs a) {
             }
             const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
             const bool ok = dok && oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
-            const float* g = ok ? a.dz + (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out + dc : a.zero;
+            const float* g = ok ? a.dz + (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out + dc : rcf_zero_page;
             float* dst = Ds + (i * 32 + wave * 8) * 32;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -1242,7 +1277,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
     }
     unsigned mx[C::RX];   // BN-on-load only: bit j = pixel j of the unit is real data (padding must stay 0 after the transform)
     f32x4 rx[C::RX][8], rd[C::RD][8];
-    // loads are branch-free: padding / out-of-image / out-of-range-channel elements read a zero page (a.zero), so the values need
+    // loads are branch-free: padding / out-of-image / out-of-range-channel elements read a zero page (rcf_zero_page), so the values need
     // no masking afterwards
     auto load_tile = [&](int tile) {
         int t = tile;
@@ -1278,7 +1313,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 const int lx = ix0 + hx;
                 const bool ok = rowok && hx < C::HXP && lx >= 0 && lx < a.w_in;
                 const int px = gmode == RCF_GATHER_NEAREST ? min((int)floorf((float)lx * a.sx), ws - 1) : lx;
-                rx[i][j] = *reinterpret_cast<const f32x4*>(ok ? rowptr + px * csrc : a.zero);
+                rx[i][j] = *reinterpret_cast<const f32x4*>(ok ? rowptr + px * csrc : rcf_zero_page);
                 if (cfx != nullptr) m |= ok ? (1u << j) : 0u;
             }
             mx[i] = m;
@@ -1302,7 +1337,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             for (int j = 0; j < 8; ++j) {
                 const int ox = ox0 + 8 * g + j;
                 const int px = ox * a.os + a.oox;
-                rd[i][j] = *reinterpret_cast<const f32x4*>((rowok && ox < a.w_out && px < a.owp) ? rowptr + px * a.c_out : a.zero);
+                rd[i][j] = *reinterpret_cast<const f32x4*>((rowok && ox < a.w_out && px < a.owp) ? rowptr + px * a.c_out : rcf_zero_page);
             }
         }
     };
@@ -2235,15 +2270,6 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = w.nchunk1 + w.nchunk2;
     const int p16 = w.px == 16;
-    // padding / out-of-image lanes of the DMA and split kernels read this page; allocated and cleared once per process
-    static float* zero_page = nullptr;
-    if (zero_page == nullptr) {
-        if (hipMalloc(reinterpret_cast<void**>(&zero_page), 256) != hipSuccess || hipMemset(zero_page, 0, 256) != hipSuccess) {
-            zero_page = nullptr;
-            return rcf_launch_status();
-        }
-    }
-    a.zero = zero_page;
     const bool dma = w.kind != K7S2 && (d->c1 % 4 == 0) && (d->c2 % 4 == 0);
     if (w.split) {
         a.nchunk1 = ceil_div(d->c1, 32 * w.wci);
@@ -2298,3 +2324,17 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
                        w.cop, d->c_out, d->c1, d->c2, w.nchunk1, w.t, ksx, w.kind == K7S2 ? 1 : 0);
     return rcf_launch_status();
 }
+
+#ifdef RCF_PHASE_TIMING
+// diagnostics build only: summed s_memtime cycles of all conv_split_kernel waves since the last reset (see RCF_TACC slots)
+extern "C" int rcf_debug_phase_cycles(unsigned long long* out8, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return rcf_launch_status();
+    if (out8 != nullptr && hipMemcpyFromSymbol(out8, HIP_SYMBOL(rcf_phase_cycles), 8 * sizeof(unsigned long long)) != hipSuccess)
+        return rcf_launch_status();
+    if (reset) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(rcf_phase_cycles), z, sizeof(z)) != hipSuccess) return rcf_launch_status();
+    }
+    return RCF_OK;
+}
+#endif
