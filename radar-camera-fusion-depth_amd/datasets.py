@@ -1,6 +1,6 @@
 '''
-FusionNet datasets -- mirror of src/datasets.py:19-109 (random_crop) and :346-527 (FusionNetTrainingDataset,
-FusionNetInferenceDataset): same constructor arguments, same sample tuples (float32 C x H x W numpy arrays), same use of the global
+Datasets -- mirror of src/datasets.py:19-109 (random_crop), :112-343 (RadarNetTrainingDataset, RadarNetInferenceDataset: host
+numpy, as in the reference) and :346-527 (FusionNetTrainingDataset, FusionNetInferenceDataset): same constructor arguments, same sample tuples (float32 C x H x W numpy arrays), same use of the global
 numpy RNG for the crop, so torch.utils.data.DataLoader call sites of the reference (src/fusionnet_main.py:112-123, :145-153,
 :669-677) work unchanged.
 
@@ -9,6 +9,8 @@ offset the reference would have applied; DataLoader stacks those integers, and `
 `[in_.to(device) for in_ in batch_data]`, src/fusionnet_main.py:353-355) uploads 3 + 4 x 2 bytes per pixel instead of 12 + 4 x 4
 and finishes crop + HWC->CHW + float conversion + /256 + zeroing on the GPU, one launch per tensor for the whole batch.
 '''
+import random
+
 import numpy as np
 import torch
 
@@ -144,6 +146,104 @@ class FusionNetInferenceDataset(_Samples):
 
     def __getitem__(self, index):
         return self._fetch(index)
+
+
+def _load_points(path):
+    '''N x 3 radar points (x, y, depth); a file holding one point is 1-D (src/datasets.py:176-180, :326-330)'''
+    points = np.load(path)
+    return points[np.newaxis] if points.ndim == 1 else points
+
+
+class RadarNetTrainingDataset(torch.utils.data.Dataset):
+    '''
+    Dataset for fetching (1) image, edge-padded by half a patch on both sides and cut to the bottom patch_size[0] rows,
+    (2) total_points_sampled radar points with x shifted into the padded frame, (3) their bounding boxes
+    [x - w/2, 0, x + w/2, patch height], (4) the ground-truth crop under each box (src/datasets.py:112-291).
+
+    With probability sample_probability_of_lidar the points are replaced by noisy lidar returns: x and depth of random
+    ground-truth pixels deeper than 1 m, x jittered by N(0, 25), depth by U(0, 0.4), y kept (:194-221).  The global numpy RNG
+    and Python's `random` are consumed in the reference's order.
+
+    Arg(s):
+        image_paths, radar_paths, ground_truth_paths : list[str]
+        patch_size : list[int]
+            height, width of the crop centred at a radar point
+        total_points_sampled : int
+            points per image (drawn with replacement; frames with too few points are repeated 100 x first)
+        sample_probability_of_lidar : float
+    '''
+
+    def __init__(self, image_paths, radar_paths, ground_truth_paths, patch_size, total_points_sampled, sample_probability_of_lidar):
+        self.n_sample = len(image_paths)
+        assert self.n_sample == len(ground_truth_paths)
+        assert self.n_sample == len(radar_paths)
+        self.image_paths, self.radar_paths, self.ground_truth_paths = image_paths, radar_paths, ground_truth_paths
+        self.patch_size = patch_size
+        self.pad_size_x = patch_size[1] // 2
+        self.padding = ((0, 0), (0, 0), (self.pad_size_x, self.pad_size_x))
+        self.data_format = 'CHW'
+        self.total_points_sampled = total_points_sampled
+        self.sample_probability_of_lidar = sample_probability_of_lidar
+
+    def __len__(self):
+        return self.n_sample
+
+    def __getitem__(self, index):
+        k, pad, patch_h = self.total_points_sampled, self.pad_size_x, self.patch_size[0]
+        image = np.pad(data_utils.load_image(self.image_paths[index], normalize=False, data_format=self.data_format),
+                       pad_width=self.padding, mode='edge')
+        points = _load_points(self.radar_paths[index])
+        if points.shape[0] <= k:
+            points = np.repeat(points, 100, axis=0)
+        points = points[np.random.randint(points.shape[0], size=k), :]
+        ground_truth = data_utils.load_depth(self.ground_truth_paths[index], data_format=self.data_format)
+
+        if random.random() < self.sample_probability_of_lidar:
+            gt = ground_truth.squeeze()
+            rows, cols = np.where(gt > 1)
+            picked = random.sample(range(0, len(rows)), k)
+            px, py = cols[picked], rows[picked]
+            noise_x = np.random.normal(0, 25, points.shape[0])
+            noise_z = np.random.uniform(low=0.0, high=0.4, size=points.shape[0])
+            fake = np.copy(points)
+            fake[:, 0] = np.clip(px + noise_x, 0, gt.shape[1])
+            fake[:, 2] = gt[py, px] + noise_z
+            fake[:, 0] = fake[:, 0].astype(int)      # x and y back to whole pixels (y is the radar's own, kept as is)
+            fake[:, 1] = fake[:, 1].astype(int)
+            points = fake
+
+        points[:, 0] = points[:, 0] + pad              # into the padded frame: the point is the centre of its patch
+        boxes = np.stack([points[:, 0] - pad, np.zeros(k, points.dtype), points[:, 0] + pad,
+                          np.full(k, patch_h, points.dtype)], axis=1)
+        ground_truth = np.pad(ground_truth, pad_width=self.padding, mode='constant', constant_values=0)
+        start_y = image.shape[-2] - patch_h
+        crops = np.asarray([ground_truth[:, start_y:, int(x - pad):int(x + pad)] for x in points[:, 0]])
+        image = image[:, start_y:, ...]
+        return image.astype(np.float32), points.astype(np.float32), boxes.astype(np.float32), crops.astype(np.float32)
+
+
+class RadarNetInferenceDataset(torch.utils.data.Dataset):
+    '''Dataset for fetching (1) image (2) all radar points N x 3 (3) ground truth if available (src/datasets.py:294-343)'''
+
+    def __init__(self, image_paths, radar_paths, ground_truth_paths=None):
+        self.n_sample = len(image_paths)
+        assert self.n_sample == len(radar_paths)
+        self.image_paths, self.radar_paths = image_paths, radar_paths
+        self.ground_truth_available = ground_truth_paths is not None and None not in ground_truth_paths
+        if self.ground_truth_available:
+            assert self.n_sample == len(ground_truth_paths)
+        self.ground_truth_paths = ground_truth_paths
+        self.data_format = 'CHW'
+
+    def __len__(self):
+        return self.n_sample
+
+    def __getitem__(self, index):
+        inputs = [data_utils.load_image(self.image_paths[index], normalize=False, data_format=self.data_format),
+                  _load_points(self.radar_paths[index])]
+        if self.ground_truth_available:
+            inputs.append(data_utils.load_depth(self.ground_truth_paths[index], data_format=self.data_format))
+        return [T.astype(np.float32) for T in inputs]
 
 
 def to_device_batch(batch_data, device, shape=None, normalize=False, multiplier=256.0):

@@ -3,7 +3,7 @@ Fixture T9: outputs of the REAL reference loaders / writers / 
 
     python tests/golden/make_golden_formats.py
 
-Writes tests/golden/T9_formats/{image,depth,response,ground_truth,lidar}_{0,1,2}.png with the reference's own save_depth /
+Writes tests/golden/T9_formats/{image,depth,response,ground_truth,lidar}_{0,1,2}.png (+ radar_{0,1,2}.npy) with the reference's own save_depth /
 save_response (image: PIL), and T9_formats.npz with what the reference's load_image / load_depth / load_depth_with_validity_map /
 load_response / random_crop / FusionNetTrainingDataset / FusionNetInferenceDataset return for them (seeds of the global numpy RNG
 stored).  points_to_depth_map lives in a setup script that cannot be imported here (it imports nuscenes-devkit): the function is
@@ -11,6 +11,7 @@ cut out of the parsed file with `ast` and executed as is.
 '''
 import ast
 import os
+import random
 import sys
 import warnings
 
@@ -103,6 +104,31 @@ def main():
         out['infer_ds_2_%d' % j] = t
     ds = ref_ds.FusionNetInferenceDataset(names['image'], names['depth'], names['response'], [None] * 3)
     out['infer_ds_nogt_len'] = np.array([len(ds[0])])
+
+    # RadarNet datasets: radar_{0,1,2}.npy = many points / fewer than sampled / a single 1-D point
+    radar = [np.stack([rs.rand(9) * (W - 1), rs.rand(9) * (H - 1), rs.rand(9) * 60 + 2], 1),
+             np.stack([rs.rand(2) * (W - 1), rs.rand(2) * (H - 1), rs.rand(2) * 60 + 2], 1),
+             np.array([7.3, 5.1, 33.0])]
+    names['radar'] = []
+    for i, r in enumerate(radar):
+        p = os.path.join(DIR, 'radar_%d.npy' % i)
+        np.save(p, r)
+        names['radar'].append(p)
+    for tag, prob in (('radar', 0.0), ('lidar', 1.0), ('mixed', 0.5)):
+        np.random.seed(31)
+        random.seed(32)
+        ds = ref_ds.RadarNetTrainingDataset(names['image'], names['radar'], names['ground_truth'], patch_size=(9, 6),
+                                            total_points_sampled=4, sample_probability_of_lidar=prob)
+        for rep in range(2):
+            for i in range(len(ds)):
+                for j, t in enumerate(ds[i]):
+                    out['radarnet_train_%s_%d_%d_%d' % (tag, rep, i, j)] = t
+        out['radarnet_train_%s_next' % tag] = np.array([np.random.rand(), random.random()])
+    ds = ref_ds.RadarNetInferenceDataset(names['image'], names['radar'], names['ground_truth'])
+    for i in range(3):
+        for j, t in enumerate(ds[i]):
+            out['radarnet_infer_%d_%d' % (i, j)] = t
+    out['radarnet_infer_nogt_len'] = np.array([len(ref_ds.RadarNetInferenceDataset(names['image'], names['radar'])[0])])
 
     # points_to_depth_map
     p2d = reference_points_to_depth_map()

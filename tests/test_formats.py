@@ -159,6 +159,31 @@ def test_random_crop_and_datasets_reproduce_reference_fixture_t9(t9):
         datasets.to_device_batch([torch.zeros(1, 4, 4, 3, dtype=torch.uint8), torch.zeros(1, 2, dtype=torch.int32)], 'cpu')
 
 
+def test_radarnet_datasets_reproduce_reference_fixture_t9(t9, golden_dir):
+    import random
+    g, paths = t9
+    radar = [os.path.join(golden_dir, 'T9_formats', 'radar_%d.npy' % i) for i in range(3)]
+    for tag, prob in (('radar', 0.0), ('lidar', 1.0), ('mixed', 0.5)):
+        np.random.seed(31)
+        random.seed(32)
+        ds = datasets.RadarNetTrainingDataset(paths['image'], radar, paths['ground_truth'], patch_size=(9, 6),
+                                              total_points_sampled=4, sample_probability_of_lidar=prob)
+        for rep in range(2):
+            for i in range(len(ds)):
+                sample = ds[i]
+                assert len(sample) == 4
+                for j, t in enumerate(sample):
+                    assert _same(t, g['radarnet_train_%s_%d_%d_%d' % (tag, rep, i, j)]), (tag, rep, i, j)
+        assert np.array_equal(np.array([np.random.rand(), random.random()]), g['radarnet_train_%s_next' % tag]), 'RNG streams: ' + tag
+    ds = datasets.RadarNetInferenceDataset(paths['image'], radar, paths['ground_truth'])
+    for i in range(3):
+        for j, t in enumerate(ds[i]):
+            assert _same(t, g['radarnet_infer_%d_%d' % (i, j)])
+    assert len(datasets.RadarNetInferenceDataset(paths['image'], radar)[0]) == int(g['radarnet_infer_nogt_len'][0]) == 2
+    with pytest.raises(AssertionError):
+        datasets.RadarNetTrainingDataset(paths['image'], radar[:2], paths['ground_truth'], (9, 6), 4, 0.0)
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 def test_device_decode_encode_match_reference_fixture_t9(t9):
