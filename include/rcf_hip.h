@@ -90,6 +90,7 @@ typedef struct rcf_conv_info {
     int wgrad_kernel_id;         /* same for the weight-gradient kernel of a forward descriptor (0: none) */
     int bn_on_load;              /* 1: rcf_conv2d_fwd_bn accepts this descriptor (raw conv outputs + BN coefficients as inputs) */
     int wgrad_bn_on_load;        /* 1: rcf_conv2d_wgrad_bn accepts it */
+    int fwd_act;                 /* 1: rcf_conv2d_fwd_act accepts it (inference epilogue in the matrix kernel) */
 } rcf_conv_info;
 
 const char* rcf_version(void);
@@ -115,6 +116,16 @@ int rcf_conv2d_fwd(const rcf_conv_desc* d, const float* in1, const float* in2, c
  * src/net_utils.py:84-91) is then never written.  Only where rcf_conv_info.bn_on_load is set; RCF_EUNSUPPORTED otherwise. */
 int rcf_conv2d_fwd_bn(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
                       const float* packed, float* out, double* stat_partials, void* stream);
+
+/* Inference form of net_utils.Conv2d.forward with eval-mode BatchNorm (src/net_utils.py:84-91) and of ResNetBlock's tail
+ * (src/net_utils.py:311-323) in ONE kernel: `packed` holds the weights already multiplied by the BatchNorm scale
+ * gamma / sqrt(running_var + eps) per output channel (rcf_scale_channels, then rcf_conv2d_pack_weights), bias[c_out] is
+ * beta - running_mean * scale, and the kernel stores out = lrelu(conv + bias), or lrelu(lrelu(conv + bias) + res) when res (same
+ * shape as out, nullable) is given.  No z tensor, no BN pass.  Only where rcf_conv_info.fwd_act is set; RCF_EUNSUPPORTED otherwise. */
+int rcf_conv2d_fwd_act(const rcf_conv_desc* d, const float* in1, const float* in2, const float* packed, const float* bias,
+                       const float* res, float* out, void* stream);
+/* out[o][i] = w[o][i] * scale[o]  (o < n_out, i < inner): folds a per-output-channel factor into an OIHW weight tensor. */
+int rcf_scale_channels(const float* w, const float* scale, float* out, int n_out, int inner, void* stream);
 
 /* Weight gradient of the conv described by the FORWARD descriptor d: dw[o][i][ky][kx] (OIHW, same layout as
  * the parameter) = sum over pixels of in[...] * dz[...].  Replaces autograd's conv weight backward behind

@@ -27,7 +27,7 @@ class ConvDesc(Structure):
 class ConvInfo(Structure):
     _fields_ = [('packed_weight_floats', c_size_t), ('n_partials', c_int),
                 ('wgrad_workspace_floats', c_size_t), ('kernel_id', c_int), ('wgrad_kernel_id', c_int),
-                ('bn_on_load', c_int), ('wgrad_bn_on_load', c_int)]
+                ('bn_on_load', c_int), ('wgrad_bn_on_load', c_int), ('fwd_act', c_int)]
 
 
 RCF_PREC_FP32, RCF_PREC_BF16 = 0, 1
@@ -40,6 +40,8 @@ _SIGNATURES = {
     'rcf_conv2d_pack_weights': (c_int, [POINTER(ConvDesc), _P, _P, _P]),
     'rcf_conv2d_fwd': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     'rcf_conv2d_fwd_bn': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    'rcf_conv2d_fwd_act': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    'rcf_scale_channels': (c_int, [_P, _P, _P, c_int, c_int, _P]),
     'rcf_conv2d_wgrad': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     'rcf_conv2d_wgrad_bn': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'rcf_phase_weights': (c_int, [_P, _P, c_int, c_int, c_int, _P]),

@@ -30,6 +30,8 @@ namespace {
 __device__ __attribute__((aligned(256))) const float rcf_zero_page[64] = {};
 
 struct ConvArgs {
+    const float* bias;   // fused inference epilogue (conv_split_kernel<C, true>): out = lrelu(acc + bias[co]), then lrelu(. + res) if res
+    const float* res;
     const float* in1;
     const float* in2;
     const float* coef1;   // split kernels: in1 / in2 are RAW conv outputs of a BatchNorm + LeakyReLU block whose activation was
@@ -449,7 +451,9 @@ __device__ unsigned long long rcf_phase_cycles[8];
 #define RCF_TACC(slot, t1, t0)
 #endif
 
-template <class C>
+// EPI: inference epilogue -- BatchNorm folded into the weights (scale) and a per-channel bias, LeakyReLU, and the residual tail of
+// ResNetBlock (lrelu(y + res)) applied to the accumulators before the only store; no statistics.
+template <class C, bool EPI = false>
 __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char* As = smem_b;
@@ -754,7 +758,15 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                     const int img = t / a.tiles_y;
                     const int oy0 = ty * C::TH;
                     const int ox0 = tx * C::PX;
-                    const bool want_stats = a.stats != nullptr;
+                    const bool want_stats = !EPI && a.stats != nullptr;
+                    float ebias[C::NT];
+                    if (EPI) {
+#pragma unroll
+                        for (int ni = 0; ni < C::NT; ++ni) {
+                            const int co = n0 + ni * 32 + li;
+                            ebias[ni] = a.bias[co < a.c_out ? co : 0];
+                        }
+                    }
 #pragma unroll
                     for (int mi = 0; mi < C::MT; ++mi) {
 #pragma unroll
@@ -777,13 +789,14 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                 pbase[j] = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
                             }
                             float old[4][C::NT];
-                            if (a.accumulate) {   // all old values of the group in flight together (clamped address, used only where valid)
+                            const float* addsrc = EPI ? a.res : a.out;
+                            if (EPI ? a.res != nullptr : a.accumulate != 0) {   // all old values of the group in flight together (clamped address)
 #pragma unroll
                                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                                     for (int ni = 0; ni < C::NT; ++ni) {
                                         const int co = n0 + ni * 32 + li;
-                                        old[j][ni] = a.out[(pok[j] && co < a.c_out) ? pbase[j] + co : 0];
+                                        old[j][ni] = addsrc[(pok[j] && co < a.c_out) ? pbase[j] + co : 0];
                                     }
                             } else {
 #pragma unroll
@@ -797,7 +810,11 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                 for (int ni = 0; ni < C::NT; ++ni) {
                                     const int co = n0 + ni * 32 + li;
                                     if (pok[j] && co < a.c_out) {
-                                        const float v = acc[mi][ni][r0 + j] + old[j][ni];
+                                        float v = acc[mi][ni][r0 + j] + (EPI ? ebias[ni] : old[j][ni]);
+                                        if (EPI) {
+                                            v = rcf_lrelu(v);
+                                            if (a.res != nullptr) v = rcf_lrelu(v + old[j][ni]);
+                                        }
                                         a.out[pbase[j] + co] = v;
                                         if (want_stats) {   // fp64 per value: E[x^2]-mean^2 must not depend on how tiles group the sum
                                             const double dv = (double)v;
@@ -1750,10 +1767,18 @@ int split_grid_x(int ntiles, int ntile_n) {
     return gx;
 }
 
-template <class C>
+template <class C, bool EPI = false>
 int launch_split(const ConvArgs& a, int ntile_n, hipStream_t st) {
     const int gx = split_grid_x<C>(a.ntiles, ntile_n);
-    hipLaunchKernelGGL((conv_split_kernel<C>), dim3(gx, ntile_n, 1), dim3(256), C::LDS_BYTES, st, a);
+    if (EPI) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      C::LDS_BYTES);
+            attr_done = true;
+        }
+    }
+    hipLaunchKernelGGL((conv_split_kernel<C, EPI>), dim3(gx, ntile_n, 1), dim3(256), C::LDS_BYTES, st, a);
     return rcf_launch_status();
 }
 
@@ -1978,7 +2003,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
 }
 
 void fill_args(const rcf_conv_desc* d, const Sel& s, ConvArgs* a) {
-    a->coef1 = nullptr; a->coef2 = nullptr;
+    a->coef1 = nullptr; a->coef2 = nullptr; a->bias = nullptr; a->res = nullptr;
     a->n = d->n; a->h_in = d->h_in; a->w_in = d->w_in; a->c1 = d->c1; a->c2 = d->c2;
     a->h1 = d->h_src1; a->w1 = d->w_src1; a->gather1 = d->gather1;
     a->h_out = d->h_out; a->w_out = d->w_out; a->c_out = d->c_out; a->pad = d->pad; a->pad_x = d->pad_x; a->stride = d->stride;
@@ -2159,6 +2184,7 @@ extern "C" int rcf_conv2d_query(const rcf_conv_desc* d, rcf_conv_info* info) {
     info->wgrad_kernel_id = 0;
     info->bn_on_load = (s.split && d->w_mode == RCF_W_FORWARD && d->c1 + d->c2 <= 512) ? 1 : 0;
     info->wgrad_bn_on_load = 0;
+    info->fwd_act = (s.split && d->w_mode == RCF_W_FORWARD && !d->accumulate) ? 1 : 0;
     if (d->w_mode == RCF_W_FORWARD) {
         WSel w;
         if (select_wgrad(d, &w) == RCF_OK) {
@@ -2229,6 +2255,24 @@ static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float
     return dispatch_fwd(s, [&](auto tag) { return launch_fwd<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
 }
 
+extern "C" int rcf_conv2d_fwd_act(const rcf_conv_desc* d, const float* in1, const float* in2, const float* packed, const float* bias,
+                                  const float* res, float* out, void* stream) {
+    if (!in1 || !packed || !out || !bias) return RCF_EINVAL;
+    Sel s;
+    int rc = select_cfg(d, &s);
+    if (rc != RCF_OK) return rc;
+    if (d->c2 > 0 && !in2) return RCF_EINVAL;
+    if (!s.split || d->w_mode != RCF_W_FORWARD || d->accumulate) return RCF_EUNSUPPORTED;   // rcf_conv_info.fwd_act
+    ConvArgs a;
+    fill_args(d, s, &a);
+    a.bias = bias; a.res = res;
+    a.in1 = in1; a.in2 = in2; a.wp = packed; a.out = out; a.stats = nullptr; a.dz = nullptr; a.ws = nullptr;
+    a.ktot = 0; a.cop = 0;
+    const int nn = ceil_div(d->c_out, s.bn);
+    a.wp_phase_stride = (int)((size_t)nn * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.bf16 ? 8 : 24));
+    return dispatch_split(s, [&](auto tag) { return launch_split<typename decltype(tag)::type, true>(a, nn, (hipStream_t)stream); });
+}
+
 static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
                              const float* dz, float* dw_oihw, float* workspace, void* stream);
 
@@ -2251,6 +2295,7 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
     if (d->c2 > 0 && !in2) return RCF_EINVAL;
     if ((coef1 || coef2) && (!w.split || (coef2 && d->c2 == 0))) return RCF_EUNSUPPORTED;
     ConvArgs a;
+    a.bias = nullptr; a.res = nullptr;
     a.coef1 = coef1; a.coef2 = coef2;
     a.n = d->n; a.h_in = d->h_in; a.w_in = d->w_in; a.c1 = d->c1; a.c2 = d->c2;
     a.h1 = d->h_src1; a.w1 = d->w_src1; a.gather1 = d->gather1;

@@ -908,3 +908,21 @@ extern "C" int rcf_device_ok(void) {
     const char* arch = prop.gcnArchName;
     return (arch[0] == 'g' && arch[1] == 'f' && arch[2] == 'x' && arch[3] == '9' && arch[4] == '5' && arch[5] == '0') ? 1 : 0;
 }
+
+// ---- BatchNorm folding for inference: w[o][...] * scale[o] ---------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) scale_channels_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                            float* __restrict__ out, int n_out, int inner) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)n_out * inner) return;
+    out[i] = w[i] * scale[i / inner];
+}
+}   // namespace
+
+extern "C" int rcf_scale_channels(const float* w, const float* scale, float* out, int n_out, int inner, void* stream) {
+    if (!w || !scale || !out || n_out <= 0 || inner <= 0) return RCF_EINVAL;
+    const long long total = (long long)n_out * inner;
+    hipLaunchKernelGGL(scale_channels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, scale, out,
+                       n_out, inner);
+    return rcf_launch_status();
+}

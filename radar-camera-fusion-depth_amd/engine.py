@@ -56,6 +56,9 @@ class Engine(object):
         # bn_act_fwd pass (-2.4 ms/step) but costs the matrix kernels more in their staging path (+3.6 ms measured): off.  The
         # output head, an HBM-bound kernel with idle VALU, always consumes its input this way.
         self.bn_on_load = False
+        # inference (eval mode, no tape): BatchNorm folded into the conv weights, bias + LeakyReLU (+ residual) in the split kernels'
+        # epilogue (rcf_conv2d_fwd_act): no z tensor and no BN pass for those layers
+        self.fuse_eval = True
 
     # ------------------------------------------------------------------ helpers
     def _new(self, shape, ref):
@@ -87,8 +90,10 @@ class Engine(object):
             for p in params:
                 self.on_param_grad(p)
 
-    def _conv(self, layer, x, x2=None, up_hw=None, want_stats=False):
-        '''conv (+ folded nearest-upsample of x to up_hw, + folded channel concat with x2) -> raw output z.'''
+    def _conv(self, layer, x, x2=None, up_hw=None, want_stats=False, fold=None):
+        '''conv (+ folded nearest-upsample of x to up_hw, + folded channel concat with x2) -> raw output z.
+        fold = (coef, res tensor or None): inference -- BatchNorm scale folded into the weights, bias + LeakyReLU (+ residual) in the
+        kernel's epilogue where it has one (info.fwd_act); the returned tensor is then the ACTIVATION and the 5th result True.'''
         n, h, w, c1 = self._shape(x)
         c2 = 0 if x2 is None else self._shape(x2)[3]
         h_in, w_in, gather = h, w, RCF_GATHER_DIRECT
@@ -99,7 +104,7 @@ class Engine(object):
         weight = layer.conv.weight
         if (self.use_phase_convs and gather == RCF_GATHER_NEAREST and x2 is None and layer.kernel_size == 3
                 and layer.stride == 1 and (h_in, w_in) == (2 * h, 2 * w) and c1 % 4 == 0):
-            return self._conv_up2x(layer, x, want_stats)
+            return self._conv_up2x(layer, x, want_stats, fold)
         desc = ops.make_fwd_desc(n, h_in, w_in, c1, c2, weight.shape[0], layer.kernel_size, layer.stride, h, w, gather)
         info = ops.conv_query(desc)
         t1, k1 = self._src(x, info.bn_on_load)
@@ -109,31 +114,40 @@ class Engine(object):
         if x2 is not None and t2 is None:
             t2 = self._mat(x2)
         packed = self._new((info.packed_weight_floats,), t1)
-        ops.conv_pack(desc, weight.detach(), packed)
+        fused = fold is not None and info.fwd_act and k1 is None and k2 is None
+        ops.conv_pack(desc, ops.scale_channels(weight.detach(), fold[0][0]) if fused else weight.detach(), packed)
         z = self._new((n, desc.h_out, desc.w_out, desc.c_out), t1)
         partials = torch.empty((info.n_partials, 2, desc.c_out), dtype=torch.float64, device=t1.device) if want_stats else None
         if self.prof is not None:
             self.prof.begin(info.kernel_id, ops.algorithmic_flops(desc), desc)
-        ops.conv_fwd(desc, t1, t2, packed, z, partials, coef1=k1, coef2=k2)
+        if fused:
+            ops.conv_fwd_act(desc, t1, t2, packed, fold[0][1], fold[1], z)
+        else:
+            ops.conv_fwd(desc, t1, t2, packed, z, partials, coef1=k1, coef2=k2)
         if self.prof is not None:
             self.prof.end()
         if self.kernel_log is not None and desc is not None:
             self.kernel_log.append((desc.ksize, desc.stride, desc.c1 + desc.c2, desc.c_out, desc.h_out, desc.w_out,
                                     info.kernel_id))
+        if fold is not None:
+            return z, desc, info, partials, fused
         return z, desc, info, partials
 
-    def _run_packed(self, desc, w_oihw, in1, out, partials=None, coef1=None):
+    def _run_packed(self, desc, w_oihw, in1, out, partials=None, coef1=None, bias=None):
         info = ops.conv_query(desc)
         packed = self._new((info.packed_weight_floats,), in1)
         ops.conv_pack(desc, w_oihw, packed)
         if self.prof is not None:
             self.prof.begin(info.kernel_id, ops.algorithmic_flops(desc), desc)
-        ops.conv_fwd(desc, in1, None, packed, out, partials, coef1=coef1)
+        if bias is not None:
+            ops.conv_fwd_act(desc, in1, None, packed, bias, None, out)
+        else:
+            ops.conv_fwd(desc, in1, None, packed, out, partials, coef1=coef1)
         if self.prof is not None:
             self.prof.end()
         return info
 
-    def _conv_up2x(self, layer, x, want_stats):
+    def _conv_up2x(self, layer, x, want_stats, fold=None):
         '''
         conv3x3(F.interpolate(x, 2x nearest)) as four 2x2 phase convolutions on x (4/9 of the MACs; the weights of the
         taps that hit the same source pixel are pre-summed, so results differ from the 9-tap form by fp32 round-off only).
@@ -141,21 +155,25 @@ class Engine(object):
         n, h, w, c1 = self._shape(x)
         weight = layer.conv.weight
         co = weight.shape[0]
-        wp = ops.phase_weights(weight.detach(), RCF_PHASE_UP2X_FWD)
         descs, partials, n_part = [], None, 0
         t1 = k1 = z = None
+        fused = False
         for ph in range(4):
             d = ops.make_up2x_fwd_desc(n, h, w, c1, co, ph >> 1, ph & 1)
             if ph == 0:
                 qi = ops.conv_query(d)
                 n_part = qi.n_partials
-                t1, k1 = self._src(x, qi.bn_on_load)
+                fused = fold is not None and bool(qi.fwd_act) and fold[1] is None
+                wsrc = ops.scale_channels(weight.detach(), fold[0][0]) if fused else weight.detach()
+                wp = ops.phase_weights(wsrc, RCF_PHASE_UP2X_FWD)
+                t1, k1 = self._src(x, qi.bn_on_load and not fused)
                 if t1 is None:
                     t1 = self._mat(x)
                 z = self._new((n, 2 * h, 2 * w, co), t1)
                 if want_stats:
                     partials = torch.empty((4 * n_part, 2, co), dtype=torch.float64, device=t1.device)
-            self._run_packed(d, wp[ph], t1, z, None if partials is None else partials[ph * n_part:(ph + 1) * n_part], coef1=k1)
+            self._run_packed(d, wp[ph], t1, z, None if partials is None else partials[ph * n_part:(ph + 1) * n_part], coef1=k1,
+                             bias=fold[0][1] if fused else None)
             descs.append(d)
 
         class _Info(object):
@@ -163,6 +181,8 @@ class Engine(object):
         info = _Info()
         info.n_partials = 4 * n_part
         info.up2x = descs
+        if fold is not None:
+            return z, None, info, partials, fused
         return z, None, info, partials
 
     def _conv_up2x_backward(self, layer, info, x, dz):
@@ -263,6 +283,14 @@ class Engine(object):
                         bn.bias.detach(), bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, self.training, coef)
         return coef
 
+    def _bn_coef_eval(self, layer, ref):
+        bn = layer.batch_norm
+        c = bn.weight.shape[0]
+        coef = self._new((4, c), ref)
+        ops.bn_finalize(None, 0, c, 1, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS,
+                        False, coef)
+        return coef
+
     # ------------------------------------------------------------------ layer ops
     def conv_bn_act(self, layer, x, x2=None, up_hw=None, res=None, feeds_head=False):
         '''
@@ -271,8 +299,20 @@ class Engine(object):
         '''
         if not layer.use_batch_norm or layer.activation_func != 'leaky_relu':
             raise ValueError('conv_bn_act expects a BatchNorm + leaky_relu Conv2d block')
-        z, desc, info, partials = self._conv(layer, x, x2, up_hw, want_stats=self.training)
-        coef = self._bn_coef(layer, partials, info, z)
+        if self.fuse_eval and not self.training and self.tape is None and not feeds_head:
+            # inference: eval-mode BatchNorm is affine per channel -> scale into the weights, shift + LeakyReLU (+ residual tail) into the
+            # conv kernel's epilogue; layers whose kernel has no such epilogue (f32-MFMA 1x1 / stride-2 / stem) fall through
+            src = x.t if x.t is not None else x.z
+            coef = self._bn_coef_eval(layer, src)
+            z, desc, info, partials, fused = self._conv(layer, x, x2, up_hw, want_stats=False,
+                                                        fold=(coef, None if res is None else self._mat(res)))
+            if fused:
+                out = Act(z)
+                out.head_fusable = False
+                return out
+        else:
+            z, desc, info, partials = self._conv(layer, x, x2, up_hw, want_stats=self.training)
+            coef = self._bn_coef(layer, partials, info, z)
         n_pix = z.shape[0] * z.shape[1] * z.shape[2]
         c = z.shape[3]
         if res is None and (self.bn_on_load or (feeds_head and ops.head_bn_blocks(z.shape[0], z.shape[1], z.shape[2], c) > 0)):

@@ -220,6 +220,21 @@ def conv_fwd(desc, in1, in2, packed, out, stat_partials=None, coef1=None, coef2=
                                             _f32(out), _f64(stat_partials), _stream()), 'rcf_conv2d_fwd_bn')
 
 
+def conv_fwd_act(desc, in1, in2, packed, bias, res, out):
+    """Inference epilogue in the matrix kernel: out = lrelu(conv + bias) (then lrelu(. + res)); rcf_conv_info.fwd_act."""
+    check(_lib.load().rcf_conv2d_fwd_act(ctypes.byref(desc), _f32(in1), _f32(in2), _f32(packed), _f32(bias), _f32(res), _f32(out),
+                                         _stream()), 'rcf_conv2d_fwd_act')
+
+
+def scale_channels(w_oihw, scale):
+    """w[o] * scale[o]: BatchNorm scale folded into a conv weight (inference)."""
+    w = w_oihw.contiguous()
+    out = torch.empty_like(w)
+    check(_lib.load().rcf_scale_channels(_f32(w), _f32(scale), _f32(out), w.shape[0], w.numel() // w.shape[0], _stream()),
+          'rcf_scale_channels')
+    return out
+
+
 def conv_wgrad(desc, in1, in2, dz, dw, workspace, coef1=None, coef2=None):
     if coef1 is None and coef2 is None:
         check(_lib.load().rcf_conv2d_wgrad(ctypes.byref(desc), _f32(in1), _f32(in2), _f32(dz), _f32(dw), _f32(workspace),

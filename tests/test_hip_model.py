@@ -432,3 +432,27 @@ def test_hipgraph_captured_inference_matches_eager_and_golden(env, golden_dir):
         assert torch.equal(got, ref)
         with pytest.raises(Exception):
             run(b['image'][:, :, :-2], b['input_depth'][:, :, :-2])
+
+
+def test_inference_with_folded_batchnorm_matches_unfused_eval_path(env, golden_dir):
+    '''Engine.fuse_eval (BatchNorm folded into the conv weights, bias + LeakyReLU + residual in the conv epilogue) against the
+    unfused eval path (conv -> BN/activation pass) and the T3 fixture; the fused path is really taken (bits differ).'''
+    if os.environ.get('RCF_CONV_SPLIT') == '0':
+        pytest.skip('the inference epilogue lives in the split kernels, which RCF_CONV_SPLIT=0 turns off')
+    synth, _ = env
+    g = np.load(os.path.join(golden_dir, 'T3_eval.npz'))
+    for tag, cfg in (('tiny', synth.TINY), ('published', synth.PUBLISHED)):
+        n, h, w, k, dseed, wseed = [int(v) for v in g[tag + '_meta']]
+        m = _build(env, cfg, wseed)
+        m.eval()
+        b = _gpu_batch(synth.make_batch(n, h, w, k, seed=dseed))
+        outs = {}
+        with torch.no_grad():
+            for fused in (True, False):
+                m._engine.fuse_eval = fused
+                outs[fused] = m.forward(image=b['image'], input_depth=b['input_depth']).clone()
+        torch.cuda.synchronize()
+        assert _rel(outs[True], g[tag + '_output']) < BAR and _rel(outs[False], g[tag + '_output']) < BAR
+        assert _rel(outs[True], outs[False]) < 2e-5
+        if tag == 'published':
+            assert not torch.equal(outs[True], outs[False])

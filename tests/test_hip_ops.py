@@ -646,6 +646,51 @@ def test_conv_applies_producer_bn_on_load(ops, two_src):
     assert torch.equal(dw_a, dw_b)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('with_res', [False, True], ids=['conv+bn+lrelu', 'resnet tail'])
+@pytest.mark.parametrize('shape', [(2, 37, 53, 32, 16, 64), (1, 20, 70, 64, 0, 32), (2, 33, 40, 128, 0, 128)], ids=str)
+def test_inference_epilogue_matches_eval_batchnorm_reference(ops, shape, with_res):
+    '''rcf_scale_channels + rcf_conv2d_fwd_act == lrelu(BN_eval(conv(x))) (and lrelu(. + res)) of torch in fp32: BatchNorm folded into
+    the weights / a bias, activation and residual in the split kernel's epilogue.  Bar 1e-5 relative (folding moves roundings).'''
+    import os
+    import torch
+    import torch.nn.functional as F
+    if os.environ.get('RCF_CONV_SPLIT') == '0':
+        pytest.skip('the inference epilogue lives in the split kernels, which RCF_CONV_SPLIT=0 turns off')
+    torch.manual_seed(11)
+    dev = 'cuda'
+    n, h, w, c1, c2, co = shape
+    x1 = torch.randn(n, c1, h, w)
+    x2 = torch.randn(n, c2, h, w) if c2 else None
+    wt = torch.randn(co, c1 + c2, 3, 3) / np.sqrt(9 * (c1 + c2))
+    gamma, beta = torch.rand(co) + 0.5, torch.randn(co) * 0.2
+    mean, var = torch.randn(co) * 0.3, torch.rand(co) + 0.3
+    res = torch.randn(n, co, h, w) if with_res else None
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    ref = F.leaky_relu(F.batch_norm(F.conv2d(xin.double(), wt.double(), padding=1), mean.double(), var.double(), gamma.double(),
+                                    beta.double(), False, 0.1, 1e-5), 0.2)
+    if with_res:
+        ref = F.leaky_relu(ref + res.double(), 0.2)
+    scale = (gamma / torch.sqrt(var + 1e-5)).to(dev)
+    bias = (beta - mean * gamma / torch.sqrt(var + 1e-5)).to(dev)
+    d = ops.make_fwd_desc(n, h, w, c1, c2, co, 3, 1, h, w, 0)
+    info = ops.conv_query(d)
+    assert info.fwd_act == 1
+    nhwc = lambda t: None if t is None else t.permute(0, 2, 3, 1).contiguous().to(dev)
+    folded = ops.scale_channels(wt.to(dev), scale)
+    assert torch.equal(folded, wt.to(dev) * scale.view(-1, 1, 1, 1))
+    packed = torch.empty(info.packed_weight_floats, device=dev)
+    ops.conv_pack(d, folded, packed)
+    out = torch.empty(n, h, w, co, device=dev)
+    ops.conv_fwd_act(d, nhwc(x1), nhwc(x2), packed, bias, nhwc(res), out)
+    assert rel(out.cpu().permute(0, 3, 1, 2).double(), ref) < 1e-5
+    # descriptors without a split kernel refuse instead of computing something else
+    d1 = ops.make_fwd_desc(n, h, w, c1, 0, co, 1, 1, h, w, 0)
+    assert ops.conv_query(d1).fwd_act == 0
+    with pytest.raises(Exception):
+        ops.conv_fwd_act(d1, nhwc(x1), None, packed, bias, None, out)
+
+
 # ---------------------------------------------------------------- RadarNet stage-1 ops
 @pytest.mark.gpu
 def test_roi_pool_forward_backward_matches_restated_torchvision(ops):
