@@ -130,7 +130,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     table = timer.collect()
     # aggregate kernel ids (kind*1000 + ck*10 + nt [+100 for the 16x16 tile]; wgrad ids are 10000 + ...) by kernel family
