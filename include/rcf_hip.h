@@ -13,7 +13,9 @@
  *     reference's own layout, OIHW contiguous (torch.nn.Conv2d.weight, src/net_utils.py:63).
  *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); it never
  *     synchronises, allocates or frees.  Workspaces are caller-owned; sizes come from *_query.
- *   - stateless and re-entrant.  Return value: 0 = ok; RCF_E* < 0 = invalid argument /
+ *   - stateless and re-entrant for ONE device per process (the deployment model: one process per GPU).  The only process state
+ *     is a cache of per-kernel launch facts (occupancy, dynamic-LDS attribute), filled idempotently on first use.
+ *     Return value: 0 = ok; RCF_E* < 0 = invalid argument /
  *     unsupported shape; > 0 = a hipError_t from a launch.  Nothing throws or aborts.
  */
 #ifndef RCF_HIP_H
