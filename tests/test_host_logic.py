@@ -194,3 +194,17 @@ def test_gradient_buckets_all_reduce_two_ranks_gloo(pkg, tmp_path):
         assert torch.equal(r['reduced'][n:], r['local'][n:])                  # unused parameters are never reduced
         assert r['sums'].tolist() == [3.0, 20.0, 4.0, 11.0]                   # global loss sums / valid counts
         assert r['early'] >= r['n_buckets'] - 1                               # buckets launch before backward ends
+
+
+def test_integration_md_struct_stubs_match_the_binding(pkg):
+    '''The ctypes stub INTEGRATION.md shows a reference maintainer must describe the same rcf_conv_desc / rcf_conv_info as _lib.py
+    (a shorter rcf_conv_info there would let rcf_conv2d_query write past the caller's struct).'''
+    from rcf_amd import _lib
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'INTEGRATION.md')).read()
+    desc = text[text.index('class ConvDesc'):text.index('class ConvInfo')]
+    info = text[text.index('class ConvInfo'):text.index('_lib.rcf_conv2d_query.argtypes')]
+    assert re.findall(r"'(\w+)'", desc) == [n for n, _ in _lib.ConvDesc._fields_]
+    assert re.findall(r"\('(\w+)'", info) == [n for n, _ in _lib.ConvInfo._fields_]
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'rcf_hip.h')).read()
+    hinfo = header[header.index('typedef struct rcf_conv_info {'):header.index('} rcf_conv_info;')]
+    assert re.findall(r'\b(?:int|size_t)\s+(\w+);', hinfo) == [n for n, _ in _lib.ConvInfo._fields_]
