@@ -27,6 +27,7 @@ LAYERS = [
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 flt = sys.argv[2] if len(sys.argv) > 2 else ''
 dev = 'cuda'
+DATA_SCALE = float(os.environ.get('RCF_BENCH_DATA_SCALE', '1'))   # 0: all-zero operands (no toggling in the matrix pipe: power probe)
 print('%-30s %9s | %8s %7s | %8s %7s | %8s %7s' % ('layer', 'GF', 'fwd ms', 'TF/s', 'dgrad ms', 'TF/s', 'wgrad ms', 'TF/s'))
 tot = [0.0, 0.0, 0.0, 0.0]
 for name, k, s, c1, c2, co, h, w, up in LAYERS:
@@ -35,14 +36,14 @@ for name, k, s, c1, c2, co, h, w, up in LAYERS:
     hs, ws = (h, w) if up is None else up
     d = ops.make_fwd_desc(N, h, w, c1, c2, co, k, s, hs, ws, 0 if up is None else 1)
     info = ops.conv_query(d)
-    x1 = torch.randn(N, hs, ws, c1, device=dev)
+    x1 = torch.randn(N, hs, ws, c1, device=dev) * DATA_SCALE
     x2 = torch.randn(N, h, w, c2, device=dev) if c2 else None
-    wt = torch.randn(co, c1 + c2, k, k, device=dev) * 0.05
+    wt = torch.randn(co, c1 + c2, k, k, device=dev) * 0.05 * DATA_SCALE
     packed = torch.empty(info.packed_weight_floats, device=dev)
     ops.conv_pack(d, wt, packed)
     out = torch.empty(N, d.h_out, d.w_out, co, device=dev)
     part = torch.empty(info.n_partials, 2, co, device=dev, dtype=torch.float64)
-    dz = torch.randn_like(out)
+    dz = torch.randn_like(out) * DATA_SCALE
     dw = torch.empty_like(wt)
     wsb = torch.empty(max(1, info.wgrad_workspace_floats), device=dev)
     gf = ops.algorithmic_flops(d) / 1e9
