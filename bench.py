@@ -29,6 +29,9 @@ if ROOT not in sys.path:
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
+# what a loop of nothing but v_mfma_f32_32x32x16_bf16 on random operand bits sustains at the ~1.4 kW board limit
+# (tools/probe/mfma_issue_probe.hip: 17.0 ns per MFMA per SIMD) -- reported next to `frac`, never instead of it
+BF16_MFMA_SUSTAINED_TFLOPS = 1970.0
 SPLIT_PRODUCTS = 6              # bf16 partial products executed per fp32 multiply-add in the split kernels
 KERNEL_NAMES = {
     0: 'conv_fwd_kernel 3x3 s1', 1: 'conv_fwd_kernel 3x3 s2', 2: 'conv_fwd_kernel 1x1', 3: 'conv_fwd_kernel 7x7 s2 stem',
@@ -185,6 +188,7 @@ def main():
                 'bound': 'mfma', 'kernel': KERNEL_NAMES.get(dom, str(dom)),
                 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                 'frac': round(achieved / peak, 4), 'algorithmic_fp32_tflops': round(algorithmic, 2),
+                'frac_of_power_limited_peak': round(achieved / BF16_MFMA_SUSTAINED_TFLOPS, 4) if is_split else None,
                 'pipe': ('bf16 MFMA, bf16 operands, fp32 accumulate' if args.dtype == 'bf16' else 'bf16 MFMA, 6 exact partial products per fp32 multiply, fp32 accumulate') if is_split else 'f32 MFMA', 'traffic': traffic, 'traffic_source': traffic_src,
                 'algorithmic_gbytes_per_launch': round(abytes / cnt / 1e9, 4),
                 'launches_per_step': cnt // args.steps, 'avg_launch_ms': round(ms / cnt, 4),
