@@ -94,6 +94,59 @@ void run2(const char* name) {
     hipFree(out);
 }
 
+// Does the ORDER of operands matter under the power limit?  8 accumulators, pools of 4 random A and 4 random B operands;
+// MODE 0: A and B both change at every MFMA; 1: A changes, B fixed for 4; 2: A fixed for 2 while B alternates (conv_split_kernel's
+// order); 3: A and B both fixed for 4 MFMAs.
+template <int MODE>
+__global__ void __launch_bounds__(256, 1) k3(float* out, int iters) {
+    f32x16 acc[8];
+    for (int j = 0; j < 8; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    bf16x8 av[4], bv[4];
+    for (int p = 0; p < 4; ++p) {
+        unsigned u[4], w[4];
+        for (int d = 0; d < 4; ++d) {
+            unsigned h = (threadIdx.x * 2654435761u) ^ ((p * 4 + d + 1) * 0x9E3779B9u);
+            h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+            u[d] = (h & 0x807f807fu) | 0x3b803b80u;
+            w[d] = ((h * 31u) & 0x807f807fu) | 0x3b803b80u;
+        }
+        av[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(u));
+        bv[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(w));
+    }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int ia, ib;
+            if (MODE == 0) { ia = j % 4; ib = (j + j / 4) % 4; }
+            else if (MODE == 1) { ia = j % 4; ib = (j / 4) % 4; }
+            else if (MODE == 2) { ia = (j / 2) % 4; ib = (j % 2) + 2 * ((j / 8) % 2); }
+            else { ia = (j / 4) % 4; ib = (j / 4 + 1) % 4; }
+            acc[j % 8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ia], bv[ib], acc[j % 8], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+    for (int j = 0; j < 8; ++j) for (int r = 0; r < 16; ++r) s += acc[j][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int MODE>
+void run3(const char* name) {
+    float* out; hipMalloc(&out, 256 * 256 * 4);
+    const int iters = 25000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k3<MODE>), dim3(256), dim3(256), 0, 0, out, 10);
+    hipDeviceSynchronize();
+    float last = 0.f;
+    for (int rep = 0; rep < 15; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k3<MODE>), dim3(256), dim3(256), 0, 0, out, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&last, e0, e1);
+    }
+    printf("%-60s sustained %6.2f ns per MFMA per SIMD\n", name, last * 1e6 / ((double)iters * 16));
+    hipFree(out);
+}
+
 int main() {
     run<9, 256, 0>("1 wave/SIMD, 9 acc, no fillers");
     run<9, 256, 2>("1 wave/SIMD, 9 acc, 2 VALU fillers");
@@ -107,5 +160,9 @@ int main() {
     run2<9, 256, true, true>("1 wave/SIMD, 9 acc AGPR, random operands");
     run2<3, 256, true, true>("1 wave/SIMD, 3 acc AGPR, random operands");
     run2<4, 512, true, false>("2 waves/SIMD, 4 acc VGPR, random operands");
+    run3<0>("operand order: A and B change every MFMA");
+    run3<1>("operand order: A changes, B fixed for 4");
+    run3<2>("operand order: A fixed for 2, B alternates (kernel's order)");
+    run3<3>("operand order: A and B fixed for 4");
     return 0;
 }
