@@ -10,9 +10,10 @@ dev = 'cuda'
 n, h, w, c = 8, 225, 400, 64
 d = ops.make_fwd_desc(n, h, w, c, 0, c, 3, 1, h, w, 0)
 info = ops.conv_query(d)
-x = torch.randn(n, h, w, c, device=dev); wt = torch.randn(c, c, 3, 3, device=dev) * 0.05
+SC = float(os.environ.get('RCF_BENCH_DATA_SCALE', '1'))   # 0: all-zero operands
+x = torch.randn(n, h, w, c, device=dev) * SC; wt = torch.randn(c, c, 3, 3, device=dev) * 0.05 * SC
 packed = torch.empty(info.packed_weight_floats, device=dev); ops.conv_pack(d, wt, packed)
-out = torch.empty(n, h, w, c, device=dev); dz = torch.randn_like(out); dw = torch.empty_like(wt)
+out = torch.empty(n, h, w, c, device=dev); dz = torch.randn_like(out) * SC; dw = torch.empty_like(wt)
 ws = torch.empty(max(1, info.wgrad_workspace_floats), device=dev)
 coef = torch.randn(4, c, device=dev)
 def run():
