@@ -2,6 +2,7 @@
 // measured 45 cycles per MFMA at one wave per SIMD.)  build: hipcc --offload-arch=gfx950 -O3 mfma_issue_probe.hip -o mfma_issue_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -147,7 +148,27 @@ void run3(const char* name) {
     hipFree(out);
 }
 
-int main() {
+// long mode: ./mfma_issue_probe long <0 constant | 1 random> <seconds>   (poll rocm-smi --showpower --showclocks meanwhile)
+template <bool RANDOM>
+void run_long(double secs) {
+    float* out; hipMalloc(&out, 256 * 256 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    double total = 0.0; int n = 0;
+    while (total < secs * 1e3) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k2<9, 256, RANDOM, false>), dim3(256), dim3(256), 0, 0, out, 40000);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        total += ms; ++n;
+    }
+    printf("%s operands: %.2f ns per MFMA per SIMD over %.1f s\n", RANDOM ? "random" : "constant", total / n * 1e6 / (40000.0 * 9), total / 1e3);
+}
+
+int main(int argc, char** argv) {
+    if (argc >= 4 && argv[1][0] == 'l') {
+        if (atoi(argv[2])) run_long<true>(atof(argv[3])); else run_long<false>(atof(argv[3]));
+        return 0;
+    }
     run<9, 256, 0>("1 wave/SIMD, 9 acc, no fillers");
     run<9, 256, 2>("1 wave/SIMD, 9 acc, 2 VALU fillers");
     run<9, 256, 5>("1 wave/SIMD, 9 acc, 5 VALU fillers");
