@@ -568,9 +568,13 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
             ra[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(pix[i] < 0 ? 0 : pix[i]) * csrc + cld);
         }
     };
-    auto store_a = [&]() {
+    // BN selects the BatchNorm-on-load variant at COMPILE time: as one code path the compiler if-converts the (wave-uniform) test and
+    // every plain conversion pays the multiply-add, compare and selects of the other variant (~100 of 330 VALU instructions per chunk;
+    // a VALU wave-instruction costs about a fifth of an MFMA in energy, and these kernels are power-limited)
+    auto store_a_impl = [&](auto bn_tag) __attribute__((always_inline)) {
+        constexpr bool BN = decltype(bn_tag)::value;
         f32x4 tsc = {1.f, 1.f, 1.f, 1.f}, tsh = {0.f, 0.f, 0.f, 0.f};
-        if (ttf) {
+        if (BN) {
             tsc = *reinterpret_cast<const f32x4*>(coef_lds + tch);
             tsh = *reinterpret_cast<const f32x4*>(coef_lds + a.c1 + a.c2 + tch);
         }
@@ -584,7 +588,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float xv = ra[i][e];
-                    if (ttf) xv = rcf_lrelu(xv * tsc[e] + tsh[e]);   // the producer's BatchNorm + LeakyReLU, applied on load
+                    if (BN) xv = rcf_lrelu(xv * tsc[e] + tsh[e]);   // the producer's BatchNorm + LeakyReLU, applied on load
                     const float x = ((okm >> i) & 1u) ? xv : 0.f;
                     xin[e] = x;
                     x0[e] = __float_as_uint(x) & 0xffff0000u;
@@ -613,6 +617,10 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                 }
             }
         }
+    };
+    auto store_a = [&]() __attribute__((always_inline)) {
+        if (ttf) store_a_impl(std::true_type{});
+        else store_a_impl(std::false_type{});
     };
     // one kernel row of pre-split weights: straight copy global -> LDS piece `buf` by LDS-DMA (each wave instruction moves 1 KiB to a
     // wave-uniform LDS base + 16 B x lane; no staging registers, no ds_write).  hipcc drains vmcnt before the next barrier.
@@ -650,7 +658,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
 #pragma unroll
         for (int mi = 0; mi < C::MT; ++mi) {
             int ap = apix[mi];
-            asm volatile("" : "+v"(ap));   // recompute the swizzled address per tap: hoisted, the 2 x T addresses cost 18 VGPRs
+            if (C::MT > 2) asm volatile("" : "+v"(ap));   // recompute the swizzled address per tap: hoisted, the 2 x T addresses cost 18 VGPRs
             const int p = ap + ky * C::HXP + kx;
             const int ao = p * 32 + ((lh ^ ((p >> 3) & 1)) * 16);
 #pragma unroll
@@ -729,7 +737,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                     const int rmi = nr / C::NPL, pl = nr % C::NPL;
                                     if (pl == 0) {
                                         int ap = apix[rmi];
-                                        asm volatile("" : "+v"(ap));
+                                        if (C::MT > 2) asm volatile("" : "+v"(ap));
                                         const int p = ap + ky * C::HXP + kx + 1;
                                         ao_next[rmi] = p * 32 + ((lh ^ ((p >> 3) & 1)) * 16);
                                     }
