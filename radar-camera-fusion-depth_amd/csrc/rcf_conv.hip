@@ -1304,7 +1304,11 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
     f32x4 rx[C::RX][8], rd[C::RD][8];
     // loads are branch-free: padding / out-of-image / out-of-range-channel elements read a zero page (rcf_zero_page), so the values need
     // no masking afterwards
-    auto load_tile = [&](int tile) {
+    // FAST (compile-time): plain layers -- source read as is, one image per tile, unit output stride -- address their pixels with an
+    // add and a compare each; the general path (nearest-upsample gather, virtual tall image, strided phase outputs) costs ~3x the
+    // VALU instructions per load, and a VALU wave-instruction costs about a fifth of an MFMA in energy (these kernels are power-limited)
+    auto load_tile_impl = [&](int tile, auto fast_tag) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_tag)::value;
         int t = tile;
         const int tx = t % a.tiles_x;
         t /= a.tiles_x;
@@ -1320,14 +1324,14 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             const int ly = iy0 + hy;
             bool rowok = u < C::NXU && ch < csrc;
             int rowbase;
-            if (a.vt) {
+            if (!FAST && a.vt) {
                 const int im = (int)(((float)ly + 0.5f) * a.inv_hp);
                 const int y = ly - im * a.hp;
                 rowok = rowok && ly >= 0 && im < a.nimg && y < a.h_in;
                 rowbase = (im * hs + y) * ws;
             } else {
-                rowok = rowok && ly >= 0 && ly < a.h_in;
-                const int py = gmode == RCF_GATHER_NEAREST ? min((int)floorf((float)ly * a.sy), hs - 1) : ly;
+                rowok = rowok && (unsigned)ly < (unsigned)a.h_in;
+                const int py = (!FAST && gmode == RCF_GATHER_NEAREST) ? min((int)floorf((float)ly * a.sy), hs - 1) : ly;
                 rowbase = (img * hs + py) * ws;
             }
             const float* rowptr = src + (size_t)(rowok ? rowbase : 0) * csrc + (rowok ? ch : 0);
@@ -1336,8 +1340,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             for (int j = 0; j < 8; ++j) {
                 const int hx = 8 * g + j;
                 const int lx = ix0 + hx;
-                const bool ok = rowok && hx < C::HXP && lx >= 0 && lx < a.w_in;
-                const int px = gmode == RCF_GATHER_NEAREST ? min((int)floorf((float)lx * a.sx), ws - 1) : lx;
+                const bool ok = rowok && hx < C::HXP && (unsigned)lx < (unsigned)a.w_in;
+                const int px = (!FAST && gmode == RCF_GATHER_NEAREST) ? min((int)floorf((float)lx * a.sx), ws - 1) : lx;
                 rx[i][j] = *reinterpret_cast<const f32x4*>(ok ? rowptr + px * csrc : rcf_zero_page);
                 if (cfx != nullptr) m |= ok ? (1u << j) : 0u;
             }
@@ -1350,21 +1354,26 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             const int dc = co0 + cq * 4;
             int oy = oy0 + r;
             int im = img;
-            if (a.vt) {
+            if (!FAST && a.vt) {
                 im = (int)(((float)oy + 0.5f) * a.inv_hp);
                 oy -= im * a.hp;
                 if (im >= a.nimg) oy = a.h_out;
             }
-            const int py = oy * a.os + a.ooy;   // strided output rows/columns of the phase convolutions
+            const int py = FAST ? oy : oy * a.os + a.ooy;   // strided output rows/columns of the phase convolutions
             const bool rowok = u < C::NDU && dc < a.c_out && oy < a.h_out && py < a.ohp;
             const float* rowptr = a.dz + (size_t)(rowok ? (im * a.ohp + py) * a.owp : 0) * a.c_out + (rowok ? dc : 0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int ox = ox0 + 8 * g + j;
-                const int px = ox * a.os + a.oox;
+                const int px = FAST ? ox : ox * a.os + a.oox;
                 rd[i][j] = *reinterpret_cast<const f32x4*>((rowok && ox < a.w_out && px < a.owp) ? rowptr + px * a.c_out : rcf_zero_page);
             }
         }
+    };
+    const bool plain_tile = gmode == RCF_GATHER_DIRECT && !a.vt && a.os == 1 && a.ooy == 0 && a.oox == 0;
+    auto load_tile = [&](int tile) __attribute__((always_inline)) {
+        if (plain_tile) load_tile_impl(tile, std::true_type{});
+        else load_tile_impl(tile, std::false_type{});
     };
     // 8 pixels of one channel -> three 16-B bf16 vectors (exact truncation split), written to the channel's LDS row
     auto split8 = [&](const f32x4 (&v)[8], int e, unsigned char* dst, int plane_bytes) {
