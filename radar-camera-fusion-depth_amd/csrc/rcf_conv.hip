@@ -779,11 +779,12 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                     for (int mi = 0; mi < C::MT; ++mi) {
 #pragma unroll
                         for (int r0 = 0; r0 < 16; r0 += 4) {
+                            // the four accumulator rows r0 .. r0 + 3 of a lane are four consecutive pixels of ONE tile row (MFMA row =
+                            // j + 8 * (r0 / 4) + 4 * lh, PX a multiple of 4): one address computation per group, then + j pixels
                             size_t pbase[4];
                             bool pok[4];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const int row = rcf_mfma_row(r0 + j, lh);
+                            if (C::MT != 4) {
+                                const int row = rcf_mfma_row(r0, lh);
                                 int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
                                 const int ox = ox0 + row % C::PX;
                                 int im = img;
@@ -793,8 +794,31 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                     if (im >= a.nimg) oy = a.h_out;
                                 }
                                 const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
-                                pok[j] = oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
-                                pbase[j] = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
+                                const bool rowvalid = oy < a.h_out && py < a.ohp;
+                                const size_t base0 = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
+                                const int pstep = a.os * a.c_out;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    pok[j] = rowvalid && ox + j < a.w_out && px + j * a.os < a.owp;
+                                    pbase[j] = base0 + (size_t)(j * pstep);
+                                }
+                            }
+                            if (C::MT == 4) {   // the 512-pixel configuration sits at 256 VGPRs: the per-row form allocates better there
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const int row = rcf_mfma_row(r0 + j, lh);
+                                    int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
+                                    const int ox = ox0 + row % C::PX;
+                                    int im = img;
+                                    if (a.vt) {
+                                        im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                                        oy -= im * a.hp;
+                                        if (im >= a.nimg) oy = a.h_out;
+                                    }
+                                    const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+                                    pok[j] = oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
+                                    pbase[j] = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
+                                }
                             }
                             float old[4][C::NT];
                             const float* addsrc = EPI ? a.res : a.out;
