@@ -7,19 +7,30 @@ bench.py -- FusionNet training throughput on MI355X (BASELINE.json metric).
 
 Workload (BASELINE.json configs[1]): the published FusionNet (bash/train_fusionnet_nuscenes.sh:27-40), fp32,
 per-GPU batch 8, 900x1600, 64-point synthetic radar maps; one step = forward + ground-truth outlier removal +
-masked-L1 loss (w_lidar 2.0) + backward + Adam, training-mode BatchNorm -- the body of the reference's loop (src/fusionnet_main.py:369-399).
-Inputs are resident in HBM before the timed region.  N > 1: one process per GPU, the same per-GPU batch
-(weak scaling), gradients all-reduced over RCCL in buckets that overlap the backward pass.
+masked-L1 loss (w_lidar 2.0) + backward + Adam, training-mode BatchNorm -- the body of the reference's loop
+(src/fusionnet_main.py:369-399).  Inputs are resident in HBM before the timed region.
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live: every launch of the dominant kernel (the 3x3
+N > 1: one process per GPU over RCCL, the same per-GPU batch (weak scaling), gradients all-reduced in buckets that
+overlap the backward pass.  Started WITHOUT a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) the parent starts
+the N ranks itself as child processes -- before it touches the GPU, and it never execs -- and refuses (exit 2) when fewer
+than N devices are visible; it never silently measures fewer GPUs than it was asked for.
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live: every launch of the dominant kernel family (the 3x3
 stride-1 implicit-GEMM convolution, forward + input-gradient launches) is bracketed by events on the launch
-stream inside the timed steps; achieved = algorithmic FLOP / event time.  `cpu_baseline` (N = 1 only) times
-the CPU oracle on the host cores on a bounded sample (one training step at batch 1, 900x1600).
+stream inside the timed steps; achieved = algorithmic FLOP / event time.  `cpu_baseline` (N = 1 only) times the CPU
+oracle on the host cores on a bounded sample (1 warm-up + 3 timed training steps at batch 1, 900x1600, median).
+The loss of the first step is compared with the value the CPU oracle computed for the same seeds
+(tests/golden/bench_expected.json): a wrong step is not timed.
+
+Other legs (the driver's default run is the training metric):  --workload infer  (BASELINE.json configs[4]: eval-mode,
+BatchNorm folded, batch 32, hipGraph-captured);  --workload radarnet  (configs[2]: RadarNet stage 1, 16 images x 4 points).
 '''
 
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,10 +40,13 @@ if ROOT not in sys.path:
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
+HBM_PEAK_GBS = 8000.0
 # what a loop of nothing but v_mfma_f32_32x32x16_bf16 on random operand bits sustains at the ~1.4 kW board limit
 # (tools/probe/mfma_issue_probe.hip: 17.0 ns per MFMA per SIMD) -- reported next to `frac`, never instead of it
 BF16_MFMA_SUSTAINED_TFLOPS = 1970.0
 SPLIT_PRODUCTS = 6              # bf16 partial products executed per fp32 multiply-add in the split kernels
+TRAIN_GFLOP_PER_SAMPLE = 994.8  # forward + dgrad + wgrad of the reference's 9-tap convolutions at 900x1600
+FWD_GFLOP_PER_SAMPLE = 333.09
 KERNEL_NAMES = {
     0: 'conv_fwd_kernel 3x3 s1', 1: 'conv_fwd_kernel 3x3 s2', 2: 'conv_fwd_kernel 1x1', 3: 'conv_fwd_kernel 7x7 s2 stem',
     5: 'conv_split_kernel 3x3 s1 (fp32 via bf16x3 split)', 9: 'conv_split_kernel 2x2 phases (fp32 via bf16x3 split)',
@@ -43,22 +57,72 @@ KERNEL_NAMES = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=8, help='per-GPU batch (BASELINE.json configs[1]: 8)')
+    ap.add_argument('--steps', type=int, default=100, help='timed steps (default: ~7 s of GPU time at batch 8)')
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', choices=('train', 'infer', 'radarnet'), default='train')
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: 8 train, 32 infer, 16 radarnet images)')
     ap.add_argument('--height', type=int, default=900)
     ap.add_argument('--width', type=int, default=1600)
     ap.add_argument('--points', type=int, default=64)
-    ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32',
-                    help="arithmetic of the conv kernels: f32 (the metric's configuration) or bf16 operands with fp32 accumulate "
-                         '(BASELINE.json configs 3-5; informational)')
+    ap.add_argument('--dtype', choices=('f32', 'bf16'), default=None,
+                    help='f32: the reference arithmetic (the metric; default for train).  bf16: bf16 tensors in HBM and bf16 MFMA '
+                         'operands, fp32 accumulate / master weights / BatchNorm statistics (BASELINE.json configs 2-4; default for '
+                         'infer and radarnet)')
+    ap.add_argument('--preheat-s', type=float, default=4.0,
+                    help='untimed steps run for this many seconds after the W warm-up steps, so the timed steps see the clocks '
+                         'of a board at its power limit and not the boost clocks of a cold one')
+    ap.add_argument('--graph', type=int, default=-1, help='train: replay the step from one hipGraph (1) or launch it eagerly (0); '
+                                                          'default: eager')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--kernel-table', type=str, default='', help='write the per-kernel event table (JSON) here')
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------------- launcher
+def spawn_ranks(args):
+    '''`python bench.py --gpus N` without a launcher: start N ranks as children.  Runs before anything touches the GPU in this
+    process (torch.cuda.device_count() does not initialise it on this image) and never execs.'''
+    import socket
+    import torch
+    n_dev = torch.cuda.device_count()
+    if os.environ.get('RCF_BENCH_SINGLE_DEVICE') and n_dev >= 1:   # tests on a 1-GPU box: every rank shares cuda:0 (gloo backend)
+        n_dev = args.gpus
+    if n_dev < args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but only %d device(s) visible; refusing to measure fewer GPUs than asked\n'
+                         % (args.gpus, n_dev))
+        return 2
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(args.gpus), 'LOCAL_WORLD_SIZE': str(args.gpus),
+                    'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'HSA_ENABLE_IPC_MODE_LEGACY': '0',
+                    'RCF_BENCH_SELF_SPAWNED': '1'})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(height, width, points):
-    '''The CPU oracle (stock PyTorch fp32, oneDNN) on the host cores: one training step at batch 1.'''
+    '''The CPU oracle (stock PyTorch fp32, oneDNN) on the host cores: training steps at batch 1, 1 warm-up + 3 timed, median
+    (SURVEY.md 8d asks 2 + 5; bounded here to ~35 s on the GPU box's host so the default run stays within minutes).'''
     import torch
     from rcf_amd import synth
     from oracle.fusionnet_oracle import FusionNetOracle
@@ -69,54 +133,128 @@ def cpu_baseline(height, width, points):
     opt = torch.optim.Adam([{'params': model.parameters(), 'weight_decay': 0.0}], lr=1e-3)
     b = synth.make_batch(1, height, width, points, seed=99)
     model.train()
-    t0 = time.time()
-    out = model.forward(b['image'], b['input_depth'])
-    loss = model.compute_loss(out, b['ground_truth'], b['lidar_map'], 2.0)[0]
-    opt.zero_grad()
-    loss.backward()
-    opt.step()
-    dt = time.time() - t0
+    times = []
+    for i in range(4):
+        t0 = time.time()
+        out = model.forward(b['image'], b['input_depth'])
+        loss = model.compute_loss(out, b['ground_truth'], b['lidar_map'], 2.0)[0]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.time() - t0)
+        if i == 0 and times[0] > 30.0:   # a slow host: keep the run bounded, report the single step and say so
+            break
+    timed = sorted(times[1:]) if len(times) > 1 else times
+    dt = timed[len(timed) // 2]
     return {'value': round(1.0 / dt, 5), 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '1 training step (fwd+loss+bwd+Adam), batch 1, %dx%d, published net, %.1f s' % (height, width, dt)}
+            'cpu': _cpu_model(), 'logical_cpus': os.cpu_count(),
+            'sample': '%s training steps (fwd+loss+bwd+Adam) at batch 1, %dx%d, published net, CPU oracle (stock PyTorch fp32, oneDNN); '
+                      'step times %s s' % ('1 warm-up + median of %d timed' % len(timed) if len(times) > 1 else '1 cold', height, width,
+                                           [round(t, 2) for t in times])}
 
 
-def main():
-    args = parse()
+# ---------------------------------------------------------------------------------------------------------------- helpers
+def _csrc_sha():
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(os.path.join(ROOT, 'radar-camera-fusion-depth_amd', 'csrc'))):
+        h.update(open(os.path.join(ROOT, 'radar-camera-fusion-depth_amd', 'csrc', name), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def _pmc_traffic(kernel_name):
+    '''HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 --pmc passes of this same command
+    (profiles/rNN_pmc_bench.json).  PMC counters cannot be read from inside the process, so this number comes from a profile run;
+    it is reported only when that run profiled the kernels this tree builds (same csrc hash), else null with the reason.'''
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_bench.json')))
+    if not cands:
+        return None, 'no PMC profile committed'
+    path = cands[-1]
+    try:
+        pmc = json.load(open(path))
+        row = pmc.get(kernel_name, {})
+        val = round(row['hbm_bytes_per_launch'] / 1e9, 4)
+    except Exception:
+        return None, '%s has no row for this kernel' % os.path.basename(path)
+    meta = pmc.get('_meta', {})
+    src = 'profiles/%s (GB per launch, FETCH_SIZE x2 + WRITE_SIZE; collected at commit %s)' % (os.path.basename(path),
+                                                                                               meta.get('head', 'of round 1'))
+    if meta.get('csrc_sha') != _csrc_sha():
+        return None, 'stale: ' + src + ' profiled other kernel sources than this tree (was %s GB)' % val
+    return val, src
+
+
+def _expected_first_loss(key):
+    path = os.path.join(ROOT, 'tests', 'golden', 'bench_expected.json')
+    try:
+        return float(json.load(open(path))[key]['first_step_loss'])
+    except Exception:
+        return None
+
+
+# ---------------------------------------------------------------------------------------------------------------- rank body
+def run_rank(args):
     import torch
     import torch.distributed as dist
     import rcf_amd  # noqa: F401
     from rcf_amd import ops, parallel, synth, train
 
     rank, world, local_rank = parallel.init_from_env()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path is HIP-only')
-    # RCF_BENCH_SINGLE_DEVICE=1 (tests on a 1-GPU box, gloo backend): every rank shares cuda:0
-    dev = torch.device('cuda', local_rank if (world > 1 and not os.environ.get('RCF_BENCH_SINGLE_DEVICE')) else 0)
+    single_dev = bool(os.environ.get('RCF_BENCH_SINGLE_DEVICE'))   # tests on a 1-GPU box (gloo backend): every rank shares cuda:0
+    if world > 1 and not single_dev and torch.cuda.device_count() < world:
+        raise SystemExit('--gpus %d but only %d device(s) visible' % (world, torch.cuda.device_count()))
+    dev = torch.device('cuda', local_rank if (world > 1 and not single_dev) else 0)
     torch.cuda.set_device(dev)
+    if args.workload != 'train':
+        if world > 1:
+            raise SystemExit('--workload %s is a single-GPU leg' % args.workload)
+        return run_infer(args, dev) if args.workload == 'infer' else run_radarnet(args, dev)
+    dtype = args.dtype or 'f32'
+    batch = args.batch or 8
 
-    torch.manual_seed(1234)                       # identical initial weights on every rank
     model = train.build_model(synth.PUBLISHED, device=dev)
-    model.compute_dtype = 'bf16' if args.dtype == 'bf16' else 'fp32'
+    synth.fill_state_dict_([model.encoder, model.decoder], 1234)   # seeded U(+-1/sqrt(fan_in)) weights, identical on every rank
+    model.compute_dtype = 'bf16' if dtype == 'bf16' else 'fp32'
     if world > 1:
         model.data_parallel()
     opt = train.make_optimizer(model, lr=1e-3)
     model.train()
-    b = synth.make_batch(args.batch, args.height, args.width, args.points, seed=1234 + rank)
+    b = synth.make_batch(batch, args.height, args.width, args.points, seed=1234 + rank)
     image, input_depth = b['image'].to(dev), b['input_depth'].to(dev)
     gt, lidar = b['ground_truth'].to(dev), b['lidar_map'].to(dev)
 
     from rcf_amd.net_utils import OutlierRemoval
     outlier = OutlierRemoval(kernel_size=7, threshold=1.5)   # bash/train_fusionnet_nuscenes.sh:48-49
 
-    def step():
+    def eager_step():
         return train.train_step(model, opt, image, input_depth, gt, lidar, outlier_removal=outlier)[0]
 
-    for _ in range(args.warmup):
-        step()
+    step = eager_step
+    first_loss = None
+    use_graph = args.graph == 1 and world == 1 and hasattr(model, 'capture_training_step')
+    n_pre = 0
+    for i in range(max(args.warmup, 0)):
+        loss = step()
+        if i == 0:
+            first_loss = float(loss.detach())
+    if use_graph:
+        step = model.capture_training_step(opt, image, input_depth, gt, lidar, outlier_removal=outlier)
+    if args.preheat_s > 0:   # untimed: board at its power limit, clocks settled
+        torch.cuda.synchronize()
+        t_pre = time.time()
+        while time.time() - t_pre < args.preheat_s:
+            loss = step()
+            if first_loss is None:
+                first_loss = float(loss.detach())
+            n_pre += 1
+            torch.cuda.synchronize()
     timer = ops.KernelTimer()
-    model._engine.prof = timer
+    if not use_graph:
+        model._engine.prof = timer
 
     if world > 1:
         dist.barrier()
@@ -129,88 +267,274 @@ def main():
         dist.barrier()
     dt = time.time() - t0
     model._engine.prof = None
+    my_ms = 1000.0 * dt / args.steps
+    final_loss = float(loss.detach())
+    if first_loss is None:
+        first_loss = final_loss if args.steps == 1 else None
+    per_rank_ms = [my_ms]
+    dp_info = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    final_loss = float(loss.detach())
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank_ms = [round(1000.0 * float(g.item()) / args.steps, 3) for g in gathered]
+        dt = max(float(g.item()) for g in gathered)
+        dp_info = measure_overlap(model, step, dev, 1000.0 * dt / args.steps)
 
     table = timer.collect()
+    if use_graph:   # a replayed graph has no per-launch events: time the kernel families on a few eager steps after the timed region
+        model._engine.prof = timer
+        for _ in range(3):
+            eager_step()
+        torch.cuda.synchronize()
+        model._engine.prof = None
+        table = timer.collect()
     # aggregate kernel ids (kind*1000 + ck*10 + nt [+100 for the 16x16 tile]; wgrad ids are 10000 + ...) by kernel family
     fam = {}
     for kid, (cnt, flops, ms) in table.items():
-        kid0 = kid - 20000 if kid >= 20000 else kid        # + 20000: bf16-operand variant of the same kernel family
+        kid0 = kid - 20000 if kid >= 20000 else kid        # + 20000: bf16 variant of the same kernel family
         f = (10 + (kid0 - 10000) // 1000) if kid0 >= 10000 else kid0 // 1000
         r = fam.setdefault(f, [0, 0.0, 0.0, 0.0])
         r[0] += cnt; r[1] += flops; r[2] += ms; r[3] += getattr(timer, 'bytes', {}).get(kid, 0.0)
     dom = max(fam, key=lambda f: fam[f][2]) if fam else None
+    ev_steps = 3 if use_graph else args.steps
 
-    if rank == 0:
-        n_samples = world * args.batch * args.steps
-        rec = {
-            'metric': 'FusionNet train samples/sec at 900x1600',
-            'value': round(n_samples / dt, 4),
-            'unit': 'samples/s',
-            'n_gpus': world,
-            'steps': args.steps,
-            'warmup': args.warmup,
-            'ms_per_step': round(1000.0 * dt / args.steps, 3),
-            'higher_is_better': True,
-            'scaling': 'weak',
-            'vs_baseline': None,
-            'dtype': args.dtype,
-            'data': 'synthetic',
-            'config': {'workload': 'FusionNet %s training, per-GPU batch %d, %dx%d, %d-point radar maps (BASELINE.json %s)'
-                                   % ('fp32' if args.dtype == 'f32' else 'bf16-operand', args.batch, args.height, args.width, args.points,
-                                      'configs[1]' if args.dtype == 'f32' else 'configs[3] arithmetic on one GPU'),
-                       'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
-                       'step': 'forward + outlier removal + masked L1 + backward + Adam, train-mode BatchNorm', 'final_loss': round(final_loss, 5)},
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+    n_samples = world * batch * args.steps
+    is_headline = (args.height, args.width, args.points, batch) == (900, 1600, 64, 8)
+    rec = {
+        'metric': 'FusionNet train samples/sec at 900x1600',
+        'value': round(n_samples / dt, 4),
+        'unit': 'samples/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': round(1000.0 * dt / args.steps, 3),
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': dtype,
+        'data': 'synthetic',
+        'config': {'workload': 'FusionNet %s training, per-GPU batch %d, %dx%d, %d-point radar maps (BASELINE.json %s)'
+                               % ('fp32' if dtype == 'f32' else 'bf16 (bf16 tensors in HBM + bf16 MFMA operands, fp32 accumulate / '
+                                  'master weights / BN statistics)', batch, args.height, args.width, args.points,
+                                  'configs[1]' if dtype == 'f32' else 'configs[3] on %d GPU(s)' % world),
+                   'global_batch': world * batch, 'parallelism': 'dp%d' % world,
+                   'step': 'forward + outlier removal + masked L1 + backward + Adam, train-mode BatchNorm',
+                   'launch': 'one hipGraph replay per step' if use_graph else 'eager launches',
+                   'first_step_loss': None if first_loss is None else round(first_loss, 5), 'final_loss': round(final_loss, 5),
+                   'preheat_steps': n_pre},
+        'rccl_ranks': dist.get_world_size() if world > 1 else 1,
+        'backend': dist.get_backend() if world > 1 else 'none',
+        'per_rank_ms_per_step': per_rank_ms,
+        'algorithmic_tflops': round(TRAIN_GFLOP_PER_SAMPLE * (args.height * args.width / 1.44e6) * n_samples / dt / 1e3, 2),
+    }
+    if dp_info is not None:
+        rec['dp'] = dp_info
+    # the step that is being timed must be the right step: its first loss against the CPU oracle's value for these seeds
+    loss_ok = True
+    if is_headline and first_loss is not None:
+        want = _expected_first_loss('train_b8_900x1600_p64')
+        if want is not None:
+            tol = 1e-3 if dtype == 'f32' else 3e-2
+            relerr = abs(first_loss - want) / abs(want)
+            loss_ok = relerr < tol
+            rec['config']['loss_check'] = {'oracle_first_step_loss': round(want, 5), 'rel_err': float('%.3e' % relerr), 'tol': tol,
+                                           'ok': loss_ok}
+    if dom is not None:
+        cnt, flops, ms, abytes = fam[dom]
+        algorithmic = flops / (ms * 1e-3) / 1e12
+        is_split = dom in (5, 9, 15, 19)
+        # split kernels are bound by the bf16 matrix pipe: price them on the bf16 FLOPs they execute (6 per fp32 MAC)
+        achieved = algorithmic * ((1 if dtype == 'bf16' else SPLIT_PRODUCTS) if is_split else 1)
+        peak = BF16_MFMA_PEAK_TFLOPS if is_split else F32_MFMA_PEAK_TFLOPS
+        traffic, traffic_src = _pmc_traffic(KERNEL_NAMES.get(dom, ''))
+        conv_ms = sum(r[2] for r in fam.values())
+        conv_flops = sum(r[1] for r in fam.values())
+        rec['roofline'] = {
+            'bound': 'mfma', 'kernel': KERNEL_NAMES.get(dom, str(dom)),
+            'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': round(achieved / peak, 4), 'algorithmic_fp32_tflops': round(algorithmic, 2),
+            # the honest fraction: useful (algorithmic) FLOP/s over the peak of the pipe the kernel runs on -- `frac` above prices
+            # the 6 partial products of the exact fp32 split as work, this one does not
+            'useful_frac': round(algorithmic / peak, 4),
+            'useful_frac_of_f32_mfma_peak': round(algorithmic / F32_MFMA_PEAK_TFLOPS, 4),
+            'frac_of_power_limited_peak': round(achieved / BF16_MFMA_SUSTAINED_TFLOPS, 4) if is_split else None,
+            'pipe': ('bf16 MFMA, bf16 operands, fp32 accumulate' if dtype == 'bf16' else 'bf16 MFMA, 6 exact partial products per fp32 multiply, fp32 accumulate') if is_split else 'f32 MFMA',
+            'traffic': traffic, 'traffic_source': traffic_src,
+            'algorithmic_gbytes_per_launch': round(abytes / cnt / 1e9, 4),
+            'launches_per_step': cnt // ev_steps, 'avg_launch_ms': round(ms / cnt, 4),
+            'algorithmic_gflop_per_launch': round(flops / cnt / 1e9, 3),
+            'share_of_step_time': round(ms / ev_steps / (1000.0 * dt / args.steps), 4),
+            'all_conv_kernels': {'achieved': round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
+                                 'share_of_step_time': round(conv_ms / ev_steps / (1000.0 * dt / args.steps), 4),
+                                 'gflop_per_sample': round(conv_flops / (batch * ev_steps) / 1e9, 2)},
         }
-        if dom is not None:
-            cnt, flops, ms, abytes = fam[dom]
-            algorithmic = flops / (ms * 1e-3) / 1e12
-            is_split = dom in (5, 9, 15, 19)
-            # split kernels are bound by the bf16 matrix pipe: price them on the bf16 FLOPs they execute (6 per fp32 MAC)
-            achieved = algorithmic * ((1 if args.dtype == 'bf16' else SPLIT_PRODUCTS) if is_split else 1)
-            peak = BF16_MFMA_PEAK_TFLOPS if is_split else F32_MFMA_PEAK_TFLOPS
-            traffic, traffic_src = None, None
-            pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_bench.json')
-            if os.path.exists(pmc_path):   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-                try:
-                    pmc = json.load(open(pmc_path)).get(KERNEL_NAMES.get(dom, ''), {})
-                    traffic = round(pmc['hbm_bytes_per_launch'] / 1e9, 4)
-                    traffic_src = 'profiles/r01_pmc_bench.json (GB per launch, FETCH_SIZE x2 + WRITE_SIZE)'
-                except Exception:
-                    traffic = None
-            conv_ms = sum(r[2] for r in fam.values())
-            conv_flops = sum(r[1] for r in fam.values())
-            rec['roofline'] = {
-                'bound': 'mfma', 'kernel': KERNEL_NAMES.get(dom, str(dom)),
-                'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': round(achieved / peak, 4), 'algorithmic_fp32_tflops': round(algorithmic, 2),
-                'frac_of_power_limited_peak': round(achieved / BF16_MFMA_SUSTAINED_TFLOPS, 4) if is_split else None,
-                'pipe': ('bf16 MFMA, bf16 operands, fp32 accumulate' if args.dtype == 'bf16' else 'bf16 MFMA, 6 exact partial products per fp32 multiply, fp32 accumulate') if is_split else 'f32 MFMA', 'traffic': traffic, 'traffic_source': traffic_src,
-                'algorithmic_gbytes_per_launch': round(abytes / cnt / 1e9, 4),
-                'launches_per_step': cnt // args.steps, 'avg_launch_ms': round(ms / cnt, 4),
-                'algorithmic_gflop_per_launch': round(flops / cnt / 1e9, 3),
-                'share_of_step_time': round(ms / (1000.0 * dt), 4),
-                'all_conv_kernels': {'achieved': round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
-                                     'share_of_step_time': round(conv_ms / (1000.0 * dt), 4),
-                                     'gflop_per_sample': round(conv_flops / (args.batch * args.steps) / 1e9, 2)},
-            }
-        if args.kernel_table:
-            rows = [{'kernel_id': kid, 'launches': c, 'gflop': f / 1e9, 'ms': m, 'tflops': f / (m * 1e-3) / 1e12 if m > 0 else 0}
-                    for kid, (c, f, m) in sorted(table.items())]
-            layers = [{'kernel_id': k[0], 'layer': k[1], 'launches': c, 'gflop': f / 1e9, 'ms': m,
-                       'tflops': f / (m * 1e-3) / 1e12 if m > 0 else 0} for k, (c, f, m) in sorted(timer.layers.items(), key=lambda kv: -kv[1][2])]
-            with open(args.kernel_table, 'w') as fh:
-                json.dump({'steps': args.steps, 'ms_per_step': 1000.0 * dt / args.steps, 'kernels': rows, 'layers': layers}, fh, indent=1)
-        if world == 1 and not args.no_cpu_baseline:
-            rec['cpu_baseline'] = cpu_baseline(args.height, args.width, args.points)
-        print(json.dumps(rec), flush=True)
+    if args.kernel_table:
+        rows = [{'kernel_id': kid, 'launches': c, 'gflop': f / 1e9, 'ms': m, 'tflops': f / (m * 1e-3) / 1e12 if m > 0 else 0}
+                for kid, (c, f, m) in sorted(table.items())]
+        layers = [{'kernel_id': k[0], 'layer': k[1], 'launches': c, 'gflop': f / 1e9, 'ms': m,
+                   'tflops': f / (m * 1e-3) / 1e12 if m > 0 else 0} for k, (c, f, m) in sorted(timer.layers.items(), key=lambda kv: -kv[1][2])]
+        with open(args.kernel_table, 'w') as fh:
+            json.dump({'steps': ev_steps, 'ms_per_step': 1000.0 * dt / args.steps, 'kernels': rows, 'layers': layers}, fh, indent=1)
+    if world == 1 and not args.no_cpu_baseline:
+        rec['cpu_baseline'] = cpu_baseline(args.height, args.width, args.points)
+    print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if not loss_ok:
+        sys.stderr.write('bench.py: first-step loss %.6f disagrees with the CPU oracle (%s): the timed step is WRONG\n'
+                         % (first_loss, rec['config']['loss_check']))
+        return 3
+    return 0
+
+
+def measure_overlap(model, step, dev, dp_ms):
+    '''After the timed region (untimed): the gradient buckets all-reduced alone, and the step with the exchange switched off, so
+    the exposed communication time and the overlap fraction are numbers and not a design claim.'''
+    import torch
+    import torch.distributed as dist
+    dp = model._dp
+    reps = 5
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.time()
+    for _ in range(reps):
+        hs = [dist.all_reduce(dp.garena[lo:hi], op=dist.ReduceOp.SUM, async_op=True) for lo, hi in dp.bounds]
+        for h in hs:
+            h.wait()
+    torch.cuda.synchronize()
+    comm_ms = 1000.0 * (time.time() - t0) / reps
+    model._dp = None          # no loss-sum all-reduce, no buckets: the compute of one rank alone
+    try:
+        step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.time()
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        alone_ms = 1000.0 * (time.time() - t0) / reps
+    finally:
+        model._dp = dp
+    t = torch.tensor([comm_ms, alone_ms], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    comm_ms, alone_ms = float(t[0]), float(t[1])
+    exposed = max(0.0, dp_ms - alone_ms)
+    return {'gradient_bytes': int(sum(hi - lo for lo, hi in dp.bounds) * 4), 'buckets': len(dp.bounds),
+            'all_reduce_alone_ms': round(comm_ms, 3), 'step_without_exchange_ms': round(alone_ms, 3),
+            'exposed_exchange_ms': round(exposed, 3),
+            'overlap_frac': round(min(1.0, max(0.0, 1.0 - exposed / comm_ms)), 4) if comm_ms > 0 else None}
+
+
+# ---------------------------------------------------------------------------------------------------------------- other legs
+def _time_steps(fn, args, torch):
+    for _ in range(max(args.warmup, 1)):
+        out = fn()
+    n_pre = 0
+    if args.preheat_s > 0:
+        torch.cuda.synchronize()
+        t_pre = time.time()
+        while time.time() - t_pre < args.preheat_s:
+            out = fn()
+            n_pre += 1
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        out = fn()
+    torch.cuda.synchronize()
+    return time.time() - t0, out, n_pre
+
+
+def run_infer(args, dev):
+    '''BASELINE.json configs[4]: FusionNet inference, batch 32, 900x1600, eval-mode BatchNorm folded into the convolutions, one
+    hipGraph replay per batch (FusionNetModel.capture_inference; the reference loop is src/fusionnet_main.py:794-816).'''
+    import torch
+    from rcf_amd import synth, train
+    dtype = args.dtype or 'bf16'
+    batch = args.batch or 32
+    model = train.build_model(synth.PUBLISHED, device=dev)
+    synth.fill_state_dict_([model.encoder, model.decoder], 1234)
+    model.compute_dtype = 'bf16' if dtype == 'bf16' else 'fp32'
+    model.eval()
+    b = synth.make_batch(batch, args.height, args.width, args.points, seed=1234)
+    img, dep = b['image'].to(dev), b['input_depth'].to(dev)
+    with torch.no_grad():
+        use_graph = args.graph != 0
+        fwd = model.capture_inference(img, dep) if use_graph else model.forward
+        dt, out, n_pre = _time_steps(lambda: fwd(img, dep), args, torch)
+    n_samples = batch * args.steps
+    rec = {'metric': 'FusionNet inference samples/sec at 900x1600', 'value': round(n_samples / dt, 3), 'unit': 'samples/s', 'n_gpus': 1,
+           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * dt / args.steps, 3), 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
+           'config': {'workload': 'FusionNet %s inference, batch %d, %dx%d, eval-mode BatchNorm folded, %s (BASELINE.json configs[4])'
+                                  % (dtype, batch, args.height, args.width, 'hipGraph-captured' if use_graph else 'eager'),
+                      'global_batch': batch, 'parallelism': 'dp1', 'preheat_steps': n_pre,
+                      'output_mean_depth': round(float(out.float().mean()), 4)},
+           'algorithmic_tflops': round(FWD_GFLOP_PER_SAMPLE * (args.height * args.width / 1.44e6) * n_samples / dt / 1e3, 2),
+           'peak_memory_gb': round(torch.cuda.max_memory_allocated() / 1e9, 2)}
+    # forward minimum traffic (SURVEY.md 8d): every conv input read once + every conv output written once
+    gbytes = (2.80 if dtype == 'f32' else 1.40) * (args.height * args.width / 1.44e6)
+    ach = gbytes * n_samples / dt
+    rec['roofline'] = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+                       'traffic': None, 'scope': 'whole forward: algorithmic conv input + output bytes per sample (%.2f GB) x samples / time; '
+                                                 'the bf16 layers sit near the MFMA/HBM ridge (SURVEY.md 8d)' % gbytes,
+                       'mfma_frac_of_bf16_peak': round(rec['algorithmic_tflops'] / BF16_MFMA_PEAK_TFLOPS, 4)}
+    print(json.dumps(rec), flush=True)
+    return 0
+
+
+def run_radarnet(args, dev):
+    '''BASELINE.json configs[2]: RadarNet stage-1 training (src/radarnet_main.py:320-403), 16 images x 4 radar points = 64 crops of
+    900x288 from 900x1888 edge-padded images; one step = forward + masked BCE + backward + Adam.'''
+    import torch
+    from rcf_amd import radarnet_model, synth
+    dtype = args.dtype or 'bf16'
+    n_img = args.batch or 16
+    k = 4
+    m = radarnet_model.RadarNetModel(device=dev, **synth.RADARNET_PUBLISHED)
+    m.compute_dtype = 'bf16' if dtype == 'bf16' else 'fp32'
+    synth.fill_state_dict_([m.encoder, m.decoder], 41)
+    b = synth.make_radarnet_batch(7, n=n_img, k=k, h=args.height, w=args.width + 288, patch_w=288)
+    b = {key: (v.to(dev) if isinstance(v, torch.Tensor) else [t.to(dev) for t in v]) for key, v in b.items()}
+    opt = torch.optim.Adam([{'params': m.parameters(), 'weight_decay': 0.0}], lr=2e-4)
+    m.train()
+
+    def step():
+        logits = m.forward(b['image'], b['point'], b['bounding_boxes'])
+        loss, _ = m.compute_loss(logits, b['ground_truth'], b['validity_map'], w_positive_class=2.0)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+    dt, loss, n_pre = _time_steps(step, args, torch)
+    n_samples = n_img * args.steps
+    rec = {'metric': 'RadarNet stage-1 train images/sec at 900x1600', 'value': round(n_samples / dt, 3), 'unit': 'images/s', 'n_gpus': 1,
+           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * dt / args.steps, 3), 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
+           'config': {'workload': 'RadarNet stage-1 %s training, %d images x %d points (crops 900x288 of 900x%d padded images) '
+                                  '(BASELINE.json configs[2])' % (dtype, n_img, k, args.width + 288),
+                      'global_batch': n_img, 'parallelism': 'dp1', 'preheat_steps': n_pre, 'final_loss': round(float(loss.detach()), 5),
+                      'crops_per_s': round(n_samples * k / dt, 1)},
+           # 153.8 GF forward per image at K = 4 (SURVEY.md 8d), x3 for forward + dgrad + wgrad
+           'algorithmic_tflops': round(3 * 153.8 * n_samples / dt / 1e3, 2),
+           'peak_memory_gb': round(torch.cuda.max_memory_allocated() / 1e9, 2)}
+    print(json.dumps(rec), flush=True)
+    return 0
+
+
+def main():
+    args = parse()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return spawn_ranks(args)
+    return run_rank(args)
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

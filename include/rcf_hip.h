@@ -13,8 +13,11 @@
  *     reference's own layout, OIHW contiguous (torch.nn.Conv2d.weight, src/net_utils.py:63).
  *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); it never
  *     synchronises, allocates or frees.  Workspaces are caller-owned; sizes come from *_query.
- *   - stateless and re-entrant for ONE device per process (the deployment model: one process per GPU).  The only process state
- *     is a cache of per-kernel launch facts (occupancy, dynamic-LDS attribute), filled idempotently on first use.
+ *   - stateless and re-entrant for ONE device per process -- a HARD LIMIT, not a default: the deployment model is one process
+ *     per GPU (torch.distributed over RCCL).  The only process state is a cache of per-kernel launch facts (occupancy, CU count,
+ *     dynamic-LDS attribute) and a device-global zero page, filled idempotently on first use FOR THE DEVICE CURRENT AT THAT TIME;
+ *     a second device in the same process would reuse the first one's facts.  Work is enqueued on `stream`, which must belong to
+ *     the device that is current in the calling thread (the Python host makes the tensors' device current around every call).
  *     Return value: 0 = ok; RCF_E* < 0 = invalid argument /
  *     unsupported shape; > 0 = a hipError_t from a launch.  Nothing throws or aborts.
  */
@@ -275,7 +278,8 @@ int rcf_roi_pool_fwd(const float* in, const float* rois, float* out, int* argmax
 int rcf_roi_pool_bwd(const float* dout, const int* argmax, const float* rois, float* din, int n_roi, int n, int h, int w, int c,
                      int pooled_h, int pooled_w, int dout_cstride, int dout_coff, void* stream);
 
-/* net_utils.FullyConnected (src/net_utils.py:201-247): y = act(x W^T + b), x (M,n_in), W (n_out,n_in), M <= 64.
+/* net_utils.FullyConnected (src/net_utils.py:201-247): y = act(x W^T + b), x (M,n_in), W (n_out,n_in), any M >= 1
+ * (rows are processed in blocks of 64 inside the call; dW and db are summed over all rows).
  * act: 0 linear, 1 LeakyReLU(0.2).  hw > 1: feature f = c*hw + p is stored at NHWC position m*(hw*cstride) + p*cstride + coff + c
  * (the .view(M, C, -1, W) + torch.cat of src/networks.py:1251-1255 done by addressing); hw <= 1: plain (M,n_out). */
 int rcf_fc_fwd(const float* x, const float* w, const float* bias, float* y, int m_rows, int n_in, int n_out, int act,

@@ -898,7 +898,7 @@ extern "C" int rcf_radar_scatter(const float* crops, const float* points, int k,
     return rcf_launch_status();
 }
 
-extern "C" const char* rcf_version(void) { return "rcf_hip 0.1.0 (gfx950, fp32 mfma_f32_32x32x2)"; }
+extern "C" const char* rcf_version(void) { return "rcf_hip 0.2.0 (gfx950; fp32 results from v_mfma_f32_32x32x16_bf16 with an exact 3-plane operand split, v_mfma_f32_32x32x2_f32 for 1x1 / stems; bf16 storage mode)"; }
 
 extern "C" int rcf_device_ok(void) {
     int n = 0;

@@ -116,7 +116,8 @@ __global__ void __launch_bounds__(256) fc_fwd_kernel(const float* __restrict__ x
 template <int MB>
 __global__ void __launch_bounds__(256) fc_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                      const float* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db,
-                                                     int m_rows, int n_in, int n_out, int act, int hw, int cstride, int coff) {
+                                                     int m_rows, int n_in, int n_out, int act, int hw, int cstride, int coff,
+                                                     int accumulate) {
     extern __shared__ float xs[];   // [m_rows][n_in]
     for (int i = threadIdx.x; i < m_rows * n_in; i += 256) xs[i] = x[i];
     __syncthreads();
@@ -133,9 +134,9 @@ __global__ void __launch_bounds__(256) fc_bwd_kernel(const float* __restrict__ x
             gs += g[m];
         }
     }
-    db[f] = gs;
+    db[f] = accumulate ? db[f] + gs : gs;
     for (int k = 0; k < n_in; ++k) {
-        float dwv = 0.f;
+        float dwv = accumulate ? dw[(size_t)f * n_in + k] : 0.f;   // later row blocks continue the same fmaf chain
 #pragma unroll
         for (int m = 0; m < MB; ++m)
             if (m < m_rows) dwv = fmaf(g[m], xs[m * n_in + k], dwv);
@@ -262,21 +263,29 @@ extern "C" int rcf_roi_pool_bwd(const float* dout, const int* argmax, const floa
     return rcf_launch_status();
 }
 
+// Rows are processed in blocks of at most FC_MAX_M (the per-thread accumulator count): a frame may carry any number of radar
+// points (pipeline.radarnet_forward runs every point of a frame through one call, like src/radarnet_main.py:534-561).
 extern "C" int rcf_fc_fwd(const float* x, const float* w, const float* bias, float* y, int m_rows, int n_in, int n_out, int act,
                           int hw, int cstride, int coff, void* stream) {
     if (!x || !w || !bias || !y || m_rows <= 0 || n_in <= 0 || n_out <= 0) return RCF_EINVAL;
-    if (m_rows > FC_MAX_M || (size_t)m_rows * n_in * 4 > 48 * 1024 || (hw > 1 && (n_out % hw != 0 || cstride < coff + n_out / hw)))
-        return RCF_EUNSUPPORTED;
+    if ((size_t)FC_MAX_M * n_in * 4 > 48 * 1024 || (hw > 1 && (n_out % hw != 0 || cstride < coff + n_out / hw))) return RCF_EUNSUPPORTED;
     const unsigned nb = (unsigned)((n_out + 255) / 256);
-    const size_t lds = (size_t)m_rows * n_in * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (m_rows <= 16) hipLaunchKernelGGL(fc_fwd_kernel<16>, dim3(nb), dim3(256), lds, st, x, w, bias, y, m_rows, n_in, n_out, act, hw, cstride, coff);
-    else if (m_rows <= 32) hipLaunchKernelGGL(fc_fwd_kernel<32>, dim3(nb), dim3(256), lds, st, x, w, bias, y, m_rows, n_in, n_out, act, hw, cstride, coff);
-    else hipLaunchKernelGGL(fc_fwd_kernel<64>, dim3(nb), dim3(256), lds, st, x, w, bias, y, m_rows, n_in, n_out, act, hw, cstride, coff);
+    const size_t ystride = hw > 1 ? (size_t)hw * cstride : (size_t)n_out;   // floats between consecutive rows of y
+    for (int m0 = 0; m0 < m_rows; m0 += FC_MAX_M) {
+        const int mb = m_rows - m0 < FC_MAX_M ? m_rows - m0 : FC_MAX_M;
+        const size_t lds = (size_t)mb * n_in * sizeof(float);
+        const float* xb = x + (size_t)m0 * n_in;
+        float* yb = y + (size_t)m0 * ystride;
+        if (mb <= 16) hipLaunchKernelGGL(fc_fwd_kernel<16>, dim3(nb), dim3(256), lds, st, xb, w, bias, yb, mb, n_in, n_out, act, hw, cstride, coff);
+        else if (mb <= 32) hipLaunchKernelGGL(fc_fwd_kernel<32>, dim3(nb), dim3(256), lds, st, xb, w, bias, yb, mb, n_in, n_out, act, hw, cstride, coff);
+        else hipLaunchKernelGGL(fc_fwd_kernel<64>, dim3(nb), dim3(256), lds, st, xb, w, bias, yb, mb, n_in, n_out, act, hw, cstride, coff);
+    }
     return rcf_launch_status();
 }
 
 extern "C" size_t rcf_fc_bwd_workspace_floats(int m_rows, int n_in, int n_out) {
+    if (m_rows <= 0 || n_in <= 0 || n_out <= 0) return 0;
     return (size_t)((n_out + 255) / 256) * m_rows * n_in;
 }
 
@@ -284,26 +293,37 @@ extern "C" int rcf_fc_bwd(const float* x, const float* w, const float* y, const 
                           float* workspace, int m_rows, int n_in, int n_out, int act, int hw, int cstride, int coff, void* stream) {
     if (!x || !w || !y || !dy || !dw || !db || m_rows <= 0 || n_in <= 0 || n_out <= 0) return RCF_EINVAL;
     if (dx && !workspace) return RCF_EINVAL;
-    if (m_rows > FC_MAX_M || (size_t)m_rows * n_in * 4 > 48 * 1024 || (hw > 1 && (n_out % hw != 0 || cstride < coff + n_out / hw)))
-        return RCF_EUNSUPPORTED;
+    if ((size_t)FC_MAX_M * n_in * 4 > 48 * 1024 || (hw > 1 && (n_out % hw != 0 || cstride < coff + n_out / hw))) return RCF_EUNSUPPORTED;
     const unsigned nb = (unsigned)((n_out + 255) / 256);
-    const size_t lds = (size_t)m_rows * n_in * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (m_rows <= 16) hipLaunchKernelGGL(fc_bwd_kernel<16>, dim3(nb), dim3(256), lds, st, x, y, dy, dw, db, m_rows, n_in, n_out, act, hw, cstride, coff);
-    else if (m_rows <= 32) hipLaunchKernelGGL(fc_bwd_kernel<32>, dim3(nb), dim3(256), lds, st, x, y, dy, dw, db, m_rows, n_in, n_out, act, hw, cstride, coff);
-    else hipLaunchKernelGGL(fc_bwd_kernel<64>, dim3(nb), dim3(256), lds, st, x, y, dy, dw, db, m_rows, n_in, n_out, act, hw, cstride, coff);
-    int rc = rcf_launch_status();
-    if (rc != RCF_OK || !dx) return rc;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_dx_partial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  256 * FC_MAX_M * (int)sizeof(float));
-        attr_done = true;
+    const size_t ystride = hw > 1 ? (size_t)hw * cstride : (size_t)n_out;
+    if (dx) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_dx_partial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      256 * FC_MAX_M * (int)sizeof(float));
+            attr_done = true;
+        }
     }
-    hipLaunchKernelGGL(fc_dx_partial_kernel, dim3(nb), dim3(256), (size_t)256 * m_rows * sizeof(float), st, w, y, dy, workspace, m_rows,
-                       n_in, n_out, act, hw, cstride, coff);
-    const int n = m_rows * n_in;
-    hipLaunchKernelGGL(fc_dx_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, workspace, dx, (int)nb, n);
+    // dW and db are sums over ALL rows: the first block overwrites, later blocks accumulate; dx rows are independent per block
+    for (int m0 = 0; m0 < m_rows; m0 += FC_MAX_M) {
+        const int mb = m_rows - m0 < FC_MAX_M ? m_rows - m0 : FC_MAX_M;
+        const size_t lds = (size_t)mb * n_in * sizeof(float);
+        const float* xb = x + (size_t)m0 * n_in;
+        const float* yb = y + (size_t)m0 * ystride;
+        const float* dyb = dy + (size_t)m0 * ystride;
+        const int acc = m0 > 0 ? 1 : 0;
+        if (mb <= 16) hipLaunchKernelGGL(fc_bwd_kernel<16>, dim3(nb), dim3(256), lds, st, xb, yb, dyb, dw, db, mb, n_in, n_out, act, hw, cstride, coff, acc);
+        else if (mb <= 32) hipLaunchKernelGGL(fc_bwd_kernel<32>, dim3(nb), dim3(256), lds, st, xb, yb, dyb, dw, db, mb, n_in, n_out, act, hw, cstride, coff, acc);
+        else hipLaunchKernelGGL(fc_bwd_kernel<64>, dim3(nb), dim3(256), lds, st, xb, yb, dyb, dw, db, mb, n_in, n_out, act, hw, cstride, coff, acc);
+        if (dx) {
+            float* wsb = workspace + (size_t)nb * m0 * n_in;
+            hipLaunchKernelGGL(fc_dx_partial_kernel, dim3(nb), dim3(256), (size_t)256 * mb * sizeof(float), st, w, yb, dyb, wsb, mb,
+                               n_in, n_out, act, hw, cstride, coff);
+            const int n = mb * n_in;
+            hipLaunchKernelGGL(fc_dx_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, wsb, dx + (size_t)m0 * n_in, (int)nb, n);
+        }
+    }
     return rcf_launch_status();
 }
 

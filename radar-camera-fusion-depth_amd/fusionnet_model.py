@@ -54,11 +54,12 @@ class _MaskedL1Function(torch.autograd.Function):
         gt = ground_truth.contiguous()
         lidar = lidar_map.contiguous()
         sums = torch.empty(4, dtype=torch.float64, device=d.device)
-        ops.l1_loss_fwd(d, gt, lidar, sums)
-        if model is not None:
-            model._all_reduce_loss_sums(sums)
         loss = torch.empty(3, dtype=torch.float32, device=d.device)
-        ops.l1_loss_value(sums, float(w_lidar), loss)
+        with torch.cuda.device(d.device):
+            ops.l1_loss_fwd(d, gt, lidar, sums)
+            if model is not None:
+                model._all_reduce_loss_sums(sums)
+            ops.l1_loss_value(sums, float(w_lidar), loss)
         ctx.save_for_backward(d, gt, lidar, sums)
         ctx.w_lidar = float(w_lidar)
         ctx.mark_non_differentiable(loss)
@@ -69,7 +70,8 @@ class _MaskedL1Function(torch.autograd.Function):
         d, gt, lidar, sums = ctx.saved_tensors
         dd = torch.empty_like(d)
         up = grad_loss.contiguous().view(1).to(torch.float32)
-        ops.l1_loss_bwd(d, gt, lidar, sums, up, ctx.w_lidar, dd)
+        with torch.cuda.device(d.device):
+            ops.l1_loss_bwd(d, gt, lidar, sums, up, ctx.w_lidar, dd)
         return dd, None, None, None, None
 
 
@@ -247,9 +249,17 @@ class FusionNetModel(object):
     '''
 
     def _run_engine(self, image, input_depth, record):
+        if not image.is_cuda or not self._param_arena.is_cuda:
+            raise _lib.RcfError('FusionNetModel.forward needs CUDA(HIP) tensors and a model on the GPU: the hot path is HIP-only, there is no CPU '
+                                'path (inputs on %s, model on %s)' % (image.device, self._param_arena.device))
+        if image.device != self._param_arena.device:
+            raise _lib.RcfError('inputs live on %s but the model on %s' % (image.device, self._param_arena.device))
         ops.set_precision(self.compute_dtype)
         try:
-            return self._run_engine_impl(image, input_depth, record)
+            # every kernel is enqueued on the CURRENT stream of the CURRENT device: make that the model's device for the whole
+            # call, whatever device the calling thread had selected
+            with torch.cuda.device(self._param_arena.device):
+                return self._run_engine_impl(image, input_depth, record)
         finally:
             ops.set_precision('fp32')
 
@@ -277,7 +287,8 @@ class FusionNetModel(object):
         self._engine.on_param_grad = self._dp.on_param_grad if self._dp is not None else None
         ops.set_precision(self.compute_dtype)
         try:
-            Engine.backward(out, tape, ddepth)
+            with torch.cuda.device(self._grad_arena.device):
+                Engine.backward(out, tape, ddepth)
         finally:
             ops.set_precision('fp32')
         if self._dp is not None:

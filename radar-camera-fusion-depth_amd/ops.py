@@ -15,6 +15,8 @@ from ._lib import (ConvDesc, ConvInfo, RCF_ACT_LEAKY_RELU, RCF_ACT_NONE, RCF_GAT
 
 
 def _stream():
+    # the current stream of the CURRENT device: the model entry points (FusionNetModel / RadarNetModel forward, backward, loss) make
+    # the tensors' device current for the whole call (torch.cuda.device guard); direct users of this module do the same
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -49,7 +49,8 @@ class _MaskedBCEFunction(torch.autograd.Function):
         v = validity_map.contiguous().to(torch.float32)
         sums = torch.empty(2, dtype=torch.float64, device=x.device)
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
-        ops.bce_loss_fwd(x, t, v, sums, loss, float(w_positive_class))
+        with torch.cuda.device(x.device):
+            ops.bce_loss_fwd(x, t, v, sums, loss, float(w_positive_class))
         if model is not None and model._dp is not None:
             # one masked mean over the global batch, like the reference's single-process DataParallel
             model._dp.all_reduce_sums(sums)
@@ -62,7 +63,8 @@ class _MaskedBCEFunction(torch.autograd.Function):
     def backward(ctx, grad_loss):
         x, t, v, sums = ctx.saved_tensors
         dx = torch.empty_like(x)
-        ops.bce_loss_bwd(x, t, v, sums, grad_loss.contiguous().view(1).to(torch.float32), dx, ctx.w)
+        with torch.cuda.device(x.device):
+            ops.bce_loss_bwd(x, t, v, sums, grad_loss.contiguous().view(1).to(torch.float32), dx, ctx.w)
         return dx, None, None, None, None
 
 
@@ -176,9 +178,15 @@ class RadarNetModel(object):
     compute_dtype = 'fp32'   # or 'bf16': see FusionNetModel.compute_dtype
 
     def _run_engine(self, image, point, rois, record):
+        if not image.is_cuda or not self._param_arena.is_cuda:
+            raise _lib.RcfError('RadarNetModel.forward needs CUDA(HIP) tensors and a model on the GPU: the hot path is HIP-only, there is no CPU '
+                                'path (inputs on %s, model on %s)' % (image.device, self._param_arena.device))
+        if image.device != self._param_arena.device:
+            raise _lib.RcfError('inputs live on %s but the model on %s' % (image.device, self._param_arena.device))
         ops.set_precision(self.compute_dtype)
         try:
-            return self._run_engine_impl(image, point, rois, record)
+            with torch.cuda.device(self._param_arena.device):   # kernels go to the current stream of the current device
+                return self._run_engine_impl(image, point, rois, record)
         finally:
             ops.set_precision('fp32')
 

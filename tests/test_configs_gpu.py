@@ -1,0 +1,321 @@
+'''
+Every BASELINE.json configuration at ITS OWN workload, through the C ABI, against the CPU oracle:
+
+  configs[1]  FusionNet fp32 training, batch 8, 900x1600      test_config1_*
+  configs[2]  RadarNet stage-1 bf16 training, 900x288 patches  test_config2_*
+  configs[3]  FusionNet bf16 training at 900x1600              test_config3_*   (one GPU's share of the 8-GPU job; the exchange is
+                                                                                 covered by the 2-rank tests)
+  configs[4]  FusionNet bf16 inference, batch 32, hipGraph     test_config4_*
+
+plus the launcher of bench.py on real ranks.  The oracle is run at the full resolution, forward only where a backward at that
+size would take minutes on the host; the backward at full batch is checked through an exact property of the domain instead:
+with eval-mode BatchNorm every sample is independent, so the batch-8 gradient is the sum of the eight batch-1 gradients and the
+batch-8 output rows are the batch-1 outputs (the batch-1 path is pinned to the oracle in tests/test_hip_model.py).
+
+Bars: 1e-3 relative for fp32 (north_star).  bf16 (bf16 tensors in HBM, bf16 MFMA operands, fp32 accumulate) has no bar in
+north_star; the bars below are what the arithmetic allows (one bf16 rounding, 2^-9, per layer over ~40 layers) and are printed
+next to the measured error.
+'''
+
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BAR = 1e-3
+BF16_OUT_BAR = 6e-2     # max |d - d_ref| / max |d_ref| of the output depth
+BF16_LOSS_BAR = 2e-2
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope='module')
+def env():
+    import rcf_amd  # noqa: F401
+    from rcf_amd import _lib, synth, train
+    assert torch.cuda.is_available()
+    _lib.load()
+    return synth, train
+
+
+def _build(env, seed, dtype='fp32'):
+    synth, train = env
+    m = train.build_model(synth.PUBLISHED, device='cuda')
+    synth.fill_state_dict_([m.encoder, m.decoder], seed)
+    m.compute_dtype = dtype
+    return m
+
+
+def _oracle(env, seed):
+    from oracle.fusionnet_oracle import FusionNetOracle
+    synth, _ = env
+    o = FusionNetOracle(**synth.PUBLISHED)
+    synth.fill_state_dict_([o.encoder, o.decoder], seed)
+    return o
+
+
+def _loss(m, b, out):
+    return m.compute_loss(image=b['image'], output_depth=out, ground_truth=b['ground_truth'], lidar_map=b['lidar_map'],
+                          loss_func='l1', w_smoothness=0.0, loss_smoothness_kernel_size=-1,
+                          validity_map_loss_smoothness=None, w_lidar_loss=2.0)
+
+
+# ------------------------------------------------------------------------------------------------------------ configs[1]
+def test_config1_fp32_batch8_900x1600_train_forward_and_loss_against_oracle(env):
+    '''The workload bench.py times (batch 8, 900x1600, train-mode BatchNorm over the batch): output of samples 0 and 7 and the loss
+    against the CPU oracle run on the same batch of 8, then backward + Adam for finite, non-trivial updates.'''
+    synth, train = env
+    cb = synth.make_batch(8, 900, 1600, 64, seed=1234)
+    m = _build(env, 1234)
+    opt = train.make_optimizer(m, lr=1e-3)
+    b = {k: v.cuda() for k, v in cb.items()}
+    m.train()
+    out = m.forward(image=b['image'], input_depth=b['input_depth'])
+    loss, _ = _loss(m, b, out)
+    p_before = m._param_arena.clone()
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    g = m._grad_arena[:m._n_used]
+    assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+    assert float((m._param_arena - p_before).abs().max()) > 0
+    o = _oracle(env, 1234)
+    o.train()
+    t0 = time.time()
+    with torch.no_grad():
+        ref = o.forward(cb['image'], cb['input_depth'])
+        ref_loss = float(o.compute_loss(ref, cb['ground_truth'], cb['lidar_map'], 2.0)[0])
+    e0, e7 = _rel(out[0], ref[0]), _rel(out[7], ref[7])
+    mae_mm = float((out.detach().cpu() - ref).abs().mean()) * 1000.0
+    print('batch-8 900x1600 fp32: out rel %.2e / %.2e (samples 0 / 7), MAE %.4f mm, loss %.6f vs oracle %.6f (oracle forward %.0f s)'
+          % (e0, e7, mae_mm, float(loss), ref_loss, time.time() - t0))
+    assert e0 < BAR and e7 < BAR
+    assert abs(float(loss) - ref_loss) < BAR * abs(ref_loss)
+    # bench.py's recorded first-step loss (tests/golden/bench_expected.json) is this step with the ground-truth outlier removal in front
+    rec = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_expected.json')))['train_b8_900x1600_p64']
+    from rcf_amd.net_utils import OutlierRemoval
+    m2 = _build(env, 1234)
+    m2.train()
+    with torch.no_grad():
+        out2 = m2.forward(image=b['image'], input_depth=b['input_depth'])
+    b2 = dict(b)
+    b2['ground_truth'] = OutlierRemoval(7, 1.5).remove_outliers(b['ground_truth'])
+    l2, _ = _loss(m2, b2, out2)
+    assert abs(float(l2) - rec['first_step_loss']) < BAR * rec['first_step_loss']
+
+
+def test_config1_fp32_batch8_gradients_are_the_sum_of_batch1_gradients(env):
+    '''Full batch, full resolution, forward AND backward, without a minutes-long CPU backward: with eval-mode BatchNorm the samples
+    are independent, so (i) row i of the batch-8 output is BITWISE the batch-1 output of sample i (tiles that straddle images in
+    the virtual-tall tiling, 64-bit offsets into 30 GB of activations) and (ii) the batch-8 parameter gradient is the sum of
+    the eight batch-1 gradients for the same upstream gradient.'''
+    synth, _ = env
+    cb = synth.make_batch(8, 900, 1600, 64, seed=77)
+    b = {k: v.cuda() for k, v in cb.items()}
+    m = _build(env, 21)
+    m.eval()
+    torch.manual_seed(5)
+    dd = (torch.rand(8, 1, 900, 1600, device='cuda') - 0.5) * 1e-3
+    out8 = m.forward(b['image'], b['input_depth'])
+    for p in m.parameters():
+        p.grad = None
+    out8.backward(dd)
+    g8 = m._grad_arena[:m._n_used].clone()
+    gsum = torch.zeros_like(g8, dtype=torch.float64)
+    for i in range(8):
+        o1 = m.forward(b['image'][i:i + 1].contiguous(), b['input_depth'][i:i + 1].contiguous())
+        if i in (0, 3, 7):
+            assert torch.equal(o1[0], out8.detach()[i]), 'sample %d: batch-8 row differs from the batch-1 output' % i
+        for p in m.parameters():
+            p.grad = None
+        o1.backward(dd[i:i + 1].contiguous())
+        gsum += m._grad_arena[:m._n_used].double()
+    worst = 0.0
+    off = 0
+    for p in m._used_params:
+        n = p.numel()
+        e = _rel(g8[off:off + n], gsum[off:off + n])
+        worst = max(worst, e)
+        off += n
+    print('batch-8 gradient vs sum of batch-1 gradients: worst tensor rel %.2e' % worst)
+    assert worst < 2e-4
+
+
+# ------------------------------------------------------------------------------------------------------------ configs[3]
+def test_config3_bf16_train_step_900x1600_against_fp32_oracle(env):
+    '''bf16 training arithmetic at the benchmark resolution (batch 2 so the batch statistics are over more than one image)
+    against the fp32 CPU oracle, and its gradient against the fp32 HIP gradient.'''
+    synth, train = env
+    cb = synth.make_batch(2, 900, 1600, 64, seed=4321)
+    b = {k: v.cuda() for k, v in cb.items()}
+    res = {}
+    for dtype in ('bf16', 'fp32'):
+        m = _build(env, 9, dtype)
+        m.train()
+        out = m.forward(image=b['image'], input_depth=b['input_depth'])
+        loss, _ = _loss(m, b, out)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[dtype] = (out.detach().cpu(), float(loss), m._grad_arena[:m._n_used].double().cpu())
+    o = _oracle(env, 9)
+    o.train()
+    with torch.no_grad():
+        ref = o.forward(cb['image'], cb['input_depth'])
+        ref_loss = float(o.compute_loss(ref, cb['ground_truth'], cb['lidar_map'], 2.0)[0])
+    e16, e32 = _rel(res['bf16'][0], ref), _rel(res['fp32'][0], ref)
+    mae16 = float((res['bf16'][0] - ref).abs().mean()) * 1000.0
+    cos = float(torch.dot(res['bf16'][2], res['fp32'][2]) / (res['bf16'][2].norm() * res['fp32'][2].norm()))
+    print('900x1600 batch 2: bf16 out rel %.2e (bar %.0e), MAE %.2f mm, loss %.5f vs oracle %.5f; fp32 out rel %.2e; '
+          'gradient cosine bf16 vs fp32 %.4f' % (e16, BF16_OUT_BAR, mae16, res['bf16'][1], ref_loss, e32, cos))
+    assert e32 < BAR and abs(res['fp32'][1] - ref_loss) < BAR * abs(ref_loss)
+    assert e16 < BF16_OUT_BAR and abs(res['bf16'][1] - ref_loss) < BF16_LOSS_BAR * abs(ref_loss)
+    assert cos > 0.9
+
+
+# ------------------------------------------------------------------------------------------------------------ configs[4]
+def test_config4_bf16_batch32_hipgraph_inference_900x1600(env):
+    '''Batch 32 at 900x1600, eval-mode BatchNorm folded, bf16: the hipGraph replay is bitwise the eager forward, a second replay on
+    new inputs too, and a sample of the batch matches the fp32 CPU oracle's eval-mode output within the bf16 bar.'''
+    synth, _ = env
+    cb = synth.make_batch(32, 900, 1600, 64, seed=99)
+    m = _build(env, 3, 'bf16')
+    m.eval()
+    img, dep = cb['image'].cuda(), cb['input_depth'].cuda()
+    with torch.no_grad():
+        eager = m.forward(img, dep).clone()
+        run = m.capture_inference(img, dep)
+        rep = run(img, dep).clone()
+        assert torch.equal(rep, eager)
+        perm = torch.arange(31, -1, -1, device='cuda')
+        rep2 = run(img[perm].contiguous(), dep[perm].contiguous()).clone()
+        assert torch.equal(rep2, eager[perm])          # samples are independent in eval mode: replay on permuted inputs
+    o = _oracle(env, 3)
+    o.eval()
+    with torch.no_grad():
+        ref = o.forward(cb['image'][5:6], cb['input_depth'][5:6])
+    e = _rel(eager[5:6], ref)
+    print('batch-32 bf16 hipGraph inference: sample 5 vs fp32 oracle rel %.2e (bar %.0e), MAE %.2f mm'
+          % (e, BF16_OUT_BAR, float((eager[5:6].cpu() - ref).abs().mean()) * 1000.0))
+    assert e < BF16_OUT_BAR
+
+
+# ------------------------------------------------------------------------------------------------------------ configs[2]
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_config2_radarnet_900x288_patches_against_oracle(env, dtype):
+    '''RadarNet stage 1 at the shipped geometry (900x1888 edge-padded images, 900x288 crops): 4 images x 4 radar points, training
+    step; logits and loss against the CPU restatement (pinned to the reference by fixtures T5/T6), gradients finite; bf16 against
+    the same fp32 oracle at the bf16 bar.'''
+    from oracle.radarnet_oracle import RadarNetOracle
+    from rcf_amd import radarnet_model
+    synth, _ = env
+    cb = synth.make_radarnet_batch(17, n=4, k=4, h=900, w=1888, patch_w=288)
+    m = radarnet_model.RadarNetModel(device=torch.device('cuda'), **synth.RADARNET_PUBLISHED)
+    m.compute_dtype = dtype
+    synth.fill_state_dict_([m.encoder, m.decoder], 41)
+    b = {key: (v.cuda() if isinstance(v, torch.Tensor) else [t.cuda() for t in v]) for key, v in cb.items()}
+    m.train()
+    logits = m.forward(b['image'], b['point'], b['bounding_boxes'])
+    loss, _ = m.compute_loss(logits, b['ground_truth'], b['validity_map'], w_positive_class=2.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    g = m._grad_arena[:m._n_used]
+    assert tuple(logits.shape) == (16, 1, 900, 288)
+    assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+    ora = RadarNetOracle(**synth.RADARNET_PUBLISHED)
+    synth.fill_state_dict_([ora.encoder, ora.decoder], 41)
+    ora.train()
+    with torch.no_grad():
+        ol = ora.forward(cb['image'], cb['point'], cb['bounding_boxes'])
+        oloss = float(ora.compute_loss(ol, cb['ground_truth'], cb['validity_map'], 2.0))
+    e = _rel(logits, ol)
+    print('RadarNet %s 4x4 crops of 900x288: logits rel %.2e, loss %.6f vs oracle %.6f' % (dtype, e, float(loss), oloss))
+    if dtype == 'fp32':
+        assert e < BAR and abs(float(loss) - oloss) < BAR * abs(oloss)
+    else:
+        assert e < BF16_OUT_BAR and abs(float(loss) - oloss) < BF16_LOSS_BAR * abs(oloss)
+
+
+def test_radarnet_frame_with_more_than_64_points(env):
+    '''pipeline.radarnet_forward runs EVERY radar point of a frame through one forward (src/radarnet_main.py:534-561); a frame has
+    up to ~100 of them.  The fully connected encoder works in row blocks of 64: 70 points against the oracle, forward and the
+    gradients of the MLP (whose dW / db sum over all rows).'''
+    from oracle.radarnet_oracle import RadarNetOracle
+    from rcf_amd import radarnet_model
+    synth, _ = env
+    cfg = dict(synth.RADARNET_TINY)
+    cb = synth.make_radarnet_batch(31, n=1, k=70, h=64, w=160, patch_w=32)
+    ora = RadarNetOracle(**cfg)
+    synth.fill_state_dict_([ora.encoder, ora.decoder], 13)
+    ora.train()
+    ol = ora.forward(cb['image'], cb['point'], cb['bounding_boxes'])
+    oloss = ora.compute_loss(ol, cb['ground_truth'], cb['validity_map'], 2.0)
+    oloss.backward()
+    m = radarnet_model.RadarNetModel(device=torch.device('cuda'), **cfg)
+    synth.fill_state_dict_([m.encoder, m.decoder], 13)
+    b = {key: (v.cuda() if isinstance(v, torch.Tensor) else [t.cuda() for t in v]) for key, v in cb.items()}
+    m.train()
+    logits = m.forward(b['image'], b['point'], b['bounding_boxes'])
+    loss, _ = m.compute_loss(logits, b['ground_truth'], b['validity_map'], w_positive_class=2.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert _rel(logits, ol) < BAR
+    assert abs(float(loss) - float(oloss)) < BAR * abs(float(oloss))
+    for (k, p), (k2, p2) in zip(m.encoder.named_parameters(), ora.encoder.named_parameters()):
+        assert k == k2
+        if 'encoder_depth' in k:
+            assert _rel(p.grad, p2.grad) < 5 * BAR, k
+
+
+# ------------------------------------------------------------------------------------------------------------ bench.py on real ranks
+def _run_bench(extra, env_extra=None, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    n = torch.cuda.device_count()
+    r, rec = _run_bench(['--gpus', str(n + 1), '--steps', '1', '--warmup', '0', '--no-cpu-baseline'])
+    assert r.returncode == 2 and rec is None, (r.returncode, r.stdout[-300:], r.stderr[-300:])
+
+
+def test_bench_two_ranks_spawned_by_bench_itself():
+    '''`python bench.py --gpus 2` with no launcher: two child ranks, RCCL when two devices are visible, otherwise (1-GPU box) the
+    two ranks share cuda:0 over gloo -- the same code path: buckets launched from the tape, global-count loss, max-over-ranks time.'''
+    two = torch.cuda.device_count() >= 2
+    extra_env = {} if two else {'RCF_BENCH_SINGLE_DEVICE': '1', 'RCF_DIST_BACKEND': 'gloo'}
+    r, rec = _run_bench(['--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '2', '--height', '224', '--width', '384',
+                         '--points', '32', '--preheat-s', '0', '--no-cpu-baseline'], extra_env)
+    assert r.returncode == 0 and rec is not None, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2 and rec['config']['parallelism'] == 'dp2'
+    assert rec['backend'] == ('nccl' if two else 'gloo')
+    assert len(rec['per_rank_ms_per_step']) == 2 and rec['config']['global_batch'] == 4
+    assert rec['dp']['buckets'] >= 2 and rec['dp']['gradient_bytes'] == 14142208 * 4
+    assert rec['value'] > 0
+
+
+def test_bench_single_gpu_line_carries_the_contract_fields():
+    r, rec = _run_bench(['--steps', '2', '--warmup', '1', '--preheat-s', '0', '--no-cpu-baseline'])
+    assert r.returncode == 0 and rec is not None, (r.returncode, r.stderr[-1500:])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'algorithmic_tflops'):
+        assert key in rec, key
+    assert rec['n_gpus'] == 1 and rec['steps'] == 2 and rec['dtype'] == 'f32'
+    assert rec['config']['loss_check']['ok'] is True          # first step == the CPU oracle's loss for these seeds
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'useful_frac'):
+        assert key in rec['roofline'], key

@@ -208,3 +208,90 @@ def test_integration_md_struct_stubs_match_the_binding(pkg):
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'rcf_hip.h')).read()
     hinfo = header[header.index('typedef struct rcf_conv_info {'):header.index('} rcf_conv_info;')]
     assert re.findall(r'\b(?:int|size_t)\s+(\w+);', hinfo) == [n for n, _ in _lib.ConvInfo._fields_]
+
+
+# ---------------------------------------------------------------------------------------------------- C ABI negative paths
+def test_every_export_rejects_null_arguments_without_launching(pkg):
+    '''Every int-returning export, called with null pointers and zero extents, answers RCF_EINVAL (never a launch, never a crash);
+    runs without a GPU because validation precedes every HIP call.'''
+    import ctypes
+    from rcf_amd import _lib
+    lib = _lib.load()
+    queries = {'rcf_version', 'rcf_device_ok', 'rcf_fc_bwd_workspace_floats', 'rcf_bce_workspace_doubles', 'rcf_transform_workspace_bytes',
+               'rcf_points_to_depth_map_workspace_bytes', 'rcf_head_wgrad_workspace_floats', 'rcf_loss_workspace_floats'}
+    n = 0
+    for name, (restype, argtypes) in _lib._SIGNATURES.items():
+        if name in queries:
+            continue
+        args = [None if (t is _lib._P or 'LP_' in getattr(t, '__name__', '')) else t(0) for t in argtypes]
+        rc = getattr(lib, name)(*args)
+        assert rc == -1, (name, rc)       # RCF_EINVAL
+        n += 1
+    assert n >= 50
+    # size queries answer 0 / a constant for nonsense extents instead of overflowing
+    assert lib.rcf_fc_bwd_workspace_floats(-5, 3, 32) == 0
+    assert lib.rcf_head_wgrad_workspace_floats(0, 0, 0, 0) == 0
+
+
+def test_unsupported_shapes_answer_eunsupported_not_a_launch(pkg):
+    from rcf_amd import _lib, ops
+    lib = _lib.load()
+    fake = 0x10000   # a non-null "device pointer": a rejected call must not dereference it (and there is no device here)
+    import ctypes
+    d = ops.make_fwd_desc(1, 32, 32, 16, 0, 5, 3, 1)          # c_out not a multiple of 4 (c_out == 1 is the head kernel's job)
+    info = _lib.ConvInfo()
+    assert lib.rcf_conv2d_query(ctypes.byref(d), ctypes.byref(info)) == -2
+    assert lib.rcf_conv2d_fwd(ctypes.byref(d), fake, None, fake, fake, None, None) == -2
+    d = ops.make_fwd_desc(1, 32, 32, 16, 6, 32, 3, 1)         # concat boundary not 4-aligned
+    assert lib.rcf_conv2d_query(ctypes.byref(d), ctypes.byref(info)) == -2
+    d = ops.make_fwd_desc(1, 32, 32, 16, 0, 32, 3, 1)
+    d.ksize = 5
+    assert lib.rcf_conv2d_query(ctypes.byref(d), ctypes.byref(info)) == -1
+    assert lib.rcf_roi_pool_fwd(fake, fake, fake, fake, 1, 1, 8, 8, 3, 2, 2, 0.5, 4, 0, None) == -2
+    assert lib.rcf_fc_fwd(fake, fake, fake, fake, 4, 3, 30, 1, 7, 64, 0, None) == -2
+    assert lib.rcf_ew_blocks(1000, 3) <= 0
+    assert lib.rcf_head_bn_blocks(1, 8, 8, 128) <= 0           # fused head path covers c <= 64
+
+
+def test_c_abi_under_address_sanitizer(pkg, tmp_path):
+    '''host-side ASan/UBSan harness over the C ABI (tests/abi/abi_harness.c, plain C99 -> the header is C).'''
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    exe = str(tmp_path / 'abi_harness')
+    subprocess.run(['gcc', '-std=c99', '-g', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-I', os.path.join(ROOT, 'include'),
+                    os.path.join(ROOT, 'tests', 'abi', 'abi_harness.c'), '-ldl', '-o', exe], check=True)
+    from rcf_amd import _lib
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=0:abort_on_error=1')
+    r = subprocess.run([exe, _lib.LIB_PATH], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'all checks passed' in r.stdout
+
+
+# ---------------------------------------------------------------------------------------------------- bench.py launcher
+def test_bench_refuses_to_measure_fewer_gpus_than_asked(pkg):
+    '''`python bench.py --gpus 8` without a launcher starts its own ranks -- and on a box with fewer devices it must refuse
+    (exit 2), never print a dp1 line (round-1 behaviour).  Here there is no device at all.'''
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert 'refusing' in r.stderr and '"metric"' not in r.stdout
+    # under a launcher with a world size that contradicts --gpus it refuses too
+    env.update({'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and '"metric"' not in r.stdout
+
+
+def test_bench_expected_loss_fixture_is_the_oracle_on_the_bench_inputs(pkg):
+    '''tests/golden/bench_expected.json (what bench.py checks its first training step against) is reproduced here for its small case.'''
+    import json
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import make_bench_expected as mk
+    rec = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_expected.json')))
+    assert 'train_b8_900x1600_p64' in rec and rec['train_b8_900x1600_p64']['first_step_loss'] > 0
+    got = mk.first_step_loss(2, 224, 384, 32)
+    assert abs(got - rec['train_b2_224x384_p32']['first_step_loss']) < 1e-5 * abs(got)
