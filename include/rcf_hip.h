@@ -56,6 +56,10 @@ extern "C" {
  * and source 1 may be gathered (nearest upsample / zero insert).  */
 #define RCF_PREC_FP32 0
 #define RCF_PREC_BF16 1
+/* Storage of the NHWC activation / gradient tensors a call reads and writes. */
+#define RCF_STORE_FP32 0 /* fp32 tensors: the reference's configuration */
+#define RCF_STORE_BF16 1 /* bf16 tensors in HBM (BASELINE.json configs 2-4): bf16 storage and MFMA operands, fp32 accumulation; weights,
+                          * BatchNorm statistics / coefficients, loss sums and the optimizer stay fp32.  Requires RCF_PREC_BF16. */
 
 typedef struct rcf_conv_desc {
     int n;              /* batch */
@@ -82,9 +86,12 @@ typedef struct rcf_conv_desc {
      * phases' packed weights back to back (each rcf_conv_info.packed_weight_floats long). */
     int phase_sum;
     /* RCF_PREC_FP32 (0): fp32 results (the reference's arithmetic; f32 MFMA or the exact 3-plane bf16 split).
-     * RCF_PREC_BF16 (1): operands rounded to bf16 (nearest even), fp32 accumulate, fp32 tensors in HBM -- the "bf16"
-     * configurations of BASELINE.json; honoured by the split kernels, every other kernel keeps computing in fp32. */
+     * RCF_PREC_BF16 (1): operands rounded to bf16 (nearest even), fp32 accumulate; honoured by the split kernels, every other
+     * kernel keeps computing in fp32. */
     int precision;
+    /* RCF_STORE_FP32 / RCF_STORE_BF16: element type of in1, in2, out, res and dz (`const void*` below).  The two 7x7 stem
+     * convolutions (c1 <= 4) always read an fp32 input -- the network input is never rounded -- and write `storage`. */
+    int storage;
 } rcf_conv_desc;
 
 typedef struct rcf_conv_info {
@@ -113,32 +120,32 @@ int rcf_conv2d_pack_weights(const rcf_conv_desc* d, const float* w_oihw, float* 
  * (src/net_utils.py:564-569).  With w_mode=DGRAD it is the input gradient autograd computes for that conv.
  * stat_partials (nullable, fp64): per-workgroup sum and sum-of-squares of the outputs per channel, consumed by
  * rcf_bn_finalize -- the batch statistics of torch.nn.BatchNorm2d (src/net_utils.py:82,86). */
-int rcf_conv2d_fwd(const rcf_conv_desc* d, const float* in1, const float* in2, const float* packed,
-                   float* out, double* stat_partials, void* stream);
+int rcf_conv2d_fwd(const rcf_conv_desc* d, const void* in1, const void* in2, const float* packed,
+                   void* out, double* stat_partials, void* stream);
 /* BatchNorm + LeakyReLU of the PRODUCING block applied while the operand is staged ("BN on load"): in1 / in2 are raw conv
  * outputs z and coef1 / coef2 (nullable, one per source) the rcf_bn_finalize coefficients [4][c] of the block that produced
  * them; the kernel uses y = lrelu(z * coef[0][c] + coef[1][c]).  That block's activation tensor (net_utils.Conv2d.forward,
  * src/net_utils.py:84-91) is then never written.  Only where rcf_conv_info.bn_on_load is set; RCF_EUNSUPPORTED otherwise. */
-int rcf_conv2d_fwd_bn(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
-                      const float* packed, float* out, double* stat_partials, void* stream);
+int rcf_conv2d_fwd_bn(const rcf_conv_desc* d, const void* in1, const float* coef1, const void* in2, const float* coef2,
+                      const float* packed, void* out, double* stat_partials, void* stream);
 
 /* Inference form of net_utils.Conv2d.forward with eval-mode BatchNorm (src/net_utils.py:84-91) and of ResNetBlock's tail
  * (src/net_utils.py:311-323) in ONE kernel: `packed` holds the weights already multiplied by the BatchNorm scale
  * gamma / sqrt(running_var + eps) per output channel (rcf_scale_channels, then rcf_conv2d_pack_weights), bias[c_out] is
  * beta - running_mean * scale, and the kernel stores out = lrelu(conv + bias), or lrelu(lrelu(conv + bias) + res) when res (same
  * shape as out, nullable) is given.  No z tensor, no BN pass.  Only where rcf_conv_info.fwd_act is set; RCF_EUNSUPPORTED otherwise. */
-int rcf_conv2d_fwd_act(const rcf_conv_desc* d, const float* in1, const float* in2, const float* packed, const float* bias,
-                       const float* res, float* out, void* stream);
+int rcf_conv2d_fwd_act(const rcf_conv_desc* d, const void* in1, const void* in2, const float* packed, const float* bias,
+                       const void* res, void* out, void* stream);
 /* out[o][i] = w[o][i] * scale[o]  (o < n_out, i < inner): folds a per-output-channel factor into an OIHW weight tensor. */
 int rcf_scale_channels(const float* w, const float* scale, float* out, int n_out, int inner, void* stream);
 
 /* Weight gradient of the conv described by the FORWARD descriptor d: dw[o][i][ky][kx] (OIHW, same layout as
  * the parameter) = sum over pixels of in[...] * dz[...].  Replaces autograd's conv weight backward behind
  * loss.backward() (src/fusionnet_main.py:398). */
-int rcf_conv2d_wgrad(const rcf_conv_desc* d, const float* in1, const float* in2, const float* dz,
+int rcf_conv2d_wgrad(const rcf_conv_desc* d, const void* in1, const void* in2, const void* dz,
                      float* dw_oihw, float* workspace, void* stream);
-int rcf_conv2d_wgrad_bn(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
-                        const float* dz, float* dw_oihw, float* workspace, void* stream);
+int rcf_conv2d_wgrad_bn(const rcf_conv_desc* d, const void* in1, const float* coef1, const void* in2, const float* coef2,
+                        const void* dz, float* dw_oihw, float* workspace, void* stream);
 
 /* Phase weights.  w: the layer's OIHW 3x3 weight [o][i][3][3]; out: [4 phases (a*2+b)][O'][I'][2][2] with
  * (O',I') = (o,i) for RCF_PHASE_UP2X_FWD and (i,o) for the two DGRAD modes.  Each phase block is then packed with
@@ -336,6 +343,61 @@ int rcf_encode_map_u32(const float* z, unsigned* out, long long count, float mul
 size_t rcf_points_to_depth_map_workspace_bytes(int h, int w);
 int rcf_points_to_depth_map(const float* xs, const float* ys, const float* depth, int n_points, float* depth_map, int h, int w,
                             void* workspace, void* stream);
+
+/* ---- bf16 NHWC tensors (BASELINE.json configs 2-4) ----------------------------------------------------------------------------
+ * Every entry point above that reads or writes an NHWC activation / gradient tensor has a twin NAME_b16 with the SAME argument
+ * list in which those tensors hold bf16 elements (2 bytes, round-to-nearest-even on store) instead of fp32; everything else --
+ * weights, BatchNorm partial sums / coefficients, the single-channel logit / depth / dlogit maps, argmax and pool indices,
+ * workspaces, the radar points and the fully connected activations -- keeps the type written in the fp32 declaration.  Arithmetic
+ * is fp32 on the loaded values.  The convolutions take the storage in rcf_conv_desc.storage instead of a twin.
+ * Which arguments are bf16 in the twin:
+ *   rcf_bn_act_fwd_b16 z, res, out | rcf_fuse_fwd_b16 zw, zp, img, out | rcf_bn_act_bwd_reduce_b16 dout, z, out |
+ *   rcf_bn_act_bwd_apply_b16 dout, z, out, dz, dres | rcf_fuse_bwd_reduce_b16 dout, zw, zp | rcf_fuse_bwd_apply_b16 dout, zw, zp,
+ *   dzw, dzp, dimg | rcf_head_bn_bwd_reduce_b16 z | rcf_head_bn_bwd_apply_b16 z, dz | rcf_maxpool3x3s2_fwd_b16 in, out |
+ *   rcf_maxpool3x3s2_bwd_b16 dout, din | rcf_upsample_nearest_bwd_b16 dup, dsrc | rcf_head_fwd_b16 x | rcf_head_fwd_bn_b16 z |
+ *   rcf_head_bwd_dgrad_b16 dx | rcf_head_bwd_wgrad_b16 x | rcf_head_bwd_wgrad_bn_b16 z | rcf_roi_pool_fwd_b16 in, out |
+ *   rcf_roi_pool_bwd_b16 dout (din stays fp32: the scatter uses fp32 atomics; add it into a bf16 gradient with rcf_convert) |
+ *   rcf_fc_fwd_b16 y | rcf_fc_bwd_b16 y, dy. */
+int rcf_bn_act_fwd_b16(const float* z, const float* coef, const float* res, float* out, long long n_pix, int c, int act, void* stream);
+int rcf_fuse_fwd_b16(const float* zw, const float* coef_w, const float* zp, const float* coef_p, const float* img, float* out,
+                     long long n_pix, int c, void* stream);
+int rcf_bn_act_bwd_reduce_b16(const float* dout, const float* z, const float* coef, const float* out, double* partials, long long n_pix,
+                              int c, int act, int has_res, void* stream);
+int rcf_bn_act_bwd_apply_b16(const float* dout, const float* z, const float* coef, const float* out, const float* bcoef, float* dz,
+                             float* dres, int dres_accumulate, long long n_pix, int c, int act, int has_res, void* stream);
+int rcf_fuse_bwd_reduce_b16(const float* dout, const float* zw, const float* coef_w, const float* zp, const float* coef_p,
+                            double* partials, long long n_pix, int c, void* stream);
+int rcf_fuse_bwd_apply_b16(const float* dout, const float* zw, const float* coef_w, const float* zp, const float* coef_p,
+                           const float* bcoef_w, const float* bcoef_p, float* dzw, float* dzp, float* dimg, int dimg_accumulate,
+                           long long n_pix, int c, void* stream);
+int rcf_head_bn_bwd_reduce_b16(const float* dlogit, const float* w_head, const float* z, const float* coef, double* partials, int n,
+                               int h, int w, int c, void* stream);
+int rcf_head_bn_bwd_apply_b16(const float* dlogit, const float* w_head, const float* z, const float* coef, const float* bcoef, float* dz,
+                              int n, int h, int w, int c, void* stream);
+int rcf_maxpool3x3s2_fwd_b16(const float* in, float* out, unsigned char* idx, int n, int h, int w, int c, void* stream);
+int rcf_maxpool3x3s2_bwd_b16(const float* dout, const unsigned char* idx, float* din, int din_accumulate, int n, int h, int w, int c,
+                             void* stream);
+int rcf_upsample_nearest_bwd_b16(const float* dup, float* dsrc, int dsrc_accumulate, int n, int h_up, int w_up, int h_src, int w_src,
+                                 int c, void* stream);
+int rcf_head_fwd_b16(const float* x, const float* w, float* logit, float* depth, int n, int h, int w_, int c, float min_depth,
+                     float max_depth, void* stream);
+int rcf_head_fwd_bn_b16(const float* z, const float* coef, const float* w, float* logit, float* depth, int n, int h, int w_, int c,
+                        float min_depth, float max_depth, void* stream);
+int rcf_head_bwd_dgrad_b16(const float* dlogit, const float* w, float* dx, int n, int h, int w_, int c, void* stream);
+int rcf_head_bwd_wgrad_b16(const float* x, const float* dlogit, float* dw, float* workspace, int n, int h, int w_, int c, void* stream);
+int rcf_head_bwd_wgrad_bn_b16(const float* z, const float* coef, const float* dlogit, float* dw, float* workspace, int n, int h, int w_,
+                              int c, void* stream);
+int rcf_roi_pool_fwd_b16(const float* in, const float* rois, float* out, int* argmax, int n_roi, int n, int h, int w, int c,
+                         int pooled_h, int pooled_w, float spatial_scale, int out_cstride, int out_coff, void* stream);
+int rcf_roi_pool_bwd_b16(const float* dout, const int* argmax, const float* rois, float* din, int n_roi, int n, int h, int w, int c,
+                         int pooled_h, int pooled_w, int dout_cstride, int dout_coff, void* stream);
+int rcf_fc_fwd_b16(const float* x, const float* w, const float* bias, float* y, int m_rows, int n_in, int n_out, int act, int hw,
+                   int cstride, int coff, void* stream);
+int rcf_fc_bwd_b16(const float* x, const float* w, const float* y, const float* dy, float* dw, float* db, float* dx, float* workspace,
+                   int m_rows, int n_in, int n_out, int act, int hw, int cstride, int coff, void* stream);
+/* dst[i] = (accumulate ? dst[i] : 0) + src[i] for n elements, each side RCF_STORE_FP32 or RCF_STORE_BF16 (torch's .to(dtype) of the
+ * reference-side glue; also how an fp32 scatter result joins a bf16 gradient). */
+int rcf_convert(const void* src, int src_storage, void* dst, int dst_storage, long long n, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ class ConvDesc(Structure):
     _fields_ = [(n, c_int) for n in (
         'n', 'h_in', 'w_in', 'c1', 'c2', 'h_src1', 'w_src1', 'gather1', 'h_out', 'w_out', 'c_out',
         'ksize', 'stride', 'pad', 'pad_x', 'w_mode', 'w_o', 'w_i', 'w_i_off', 'accumulate',
-        'out_stride', 'out_off_y', 'out_off_x', 'out_h_phys', 'out_w_phys', 'in_off_y', 'in_off_x', 'phase_sum', 'precision')]
+        'out_stride', 'out_off_y', 'out_off_x', 'out_h_phys', 'out_w_phys', 'in_off_y', 'in_off_x', 'phase_sum', 'precision', 'storage')]
 
 
 class ConvInfo(Structure):
@@ -31,6 +31,7 @@ class ConvInfo(Structure):
 
 
 RCF_PREC_FP32, RCF_PREC_BF16 = 0, 1
+RCF_STORE_FP32, RCF_STORE_BF16 = 0, 1
 
 _P = c_void_p
 _SIGNATURES = {
@@ -94,6 +95,13 @@ _SIGNATURES = {
     'rcf_nhwc_to_nchw': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     'rcf_radar_scatter': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
 }
+B16_TWINS = ('rcf_bn_act_fwd', 'rcf_fuse_fwd', 'rcf_bn_act_bwd_reduce', 'rcf_bn_act_bwd_apply', 'rcf_fuse_bwd_reduce', 'rcf_fuse_bwd_apply',
+             'rcf_head_bn_bwd_reduce', 'rcf_head_bn_bwd_apply', 'rcf_maxpool3x3s2_fwd', 'rcf_maxpool3x3s2_bwd', 'rcf_upsample_nearest_bwd',
+             'rcf_head_fwd', 'rcf_head_fwd_bn', 'rcf_head_bwd_dgrad', 'rcf_head_bwd_wgrad', 'rcf_head_bwd_wgrad_bn', 'rcf_roi_pool_fwd',
+             'rcf_roi_pool_bwd', 'rcf_fc_fwd', 'rcf_fc_bwd')
+for _name in B16_TWINS:   # NAME_b16: same argument list, NHWC activation tensors hold bf16 (include/rcf_hip.h)
+    _SIGNATURES[_name + '_b16'] = _SIGNATURES[_name]
+_SIGNATURES['rcf_convert'] = (c_int, [_P, c_int, _P, c_int, c_longlong, c_int, _P])
 '''Every symbol include/rcf_hip.h declares, with its ctypes signature.'''
 
 _lib = None

@@ -22,3 +22,82 @@ __device__ __forceinline__ float rcf_sigmoid(float v) { return 1.f / (1.f + __ex
 
 // MFMA 32x32x2 f32 C/D fragment: value r of lane l sits at row (r&3)+8*(r>>2)+4*(l>>5), column l&31.
 __device__ __forceinline__ int rcf_mfma_row(int r, int lane_half) { return (r & 3) + 8 * (r >> 2) + 4 * lane_half; }
+
+// ---- storage type of the NHWC activation / gradient tensors -------------------------------------------------------------------
+// StF32: fp32 tensors (the reference's arithmetic).  StB16: bf16 tensors in HBM (BASELINE.json configs 2-4: bf16 storage and MFMA
+// operands, fp32 accumulation, fp32 master weights and BatchNorm statistics).  Kernels are templated on the tag and touch such a
+// tensor only through the helpers below, with ELEMENT indices; the pointer type stays `float*` at every interface (for StB16 it
+// really addresses 2-byte elements).
+struct StF32 { static constexpr bool B16 = false; static constexpr int BYTES = 4; };
+struct StB16 { static constexpr bool B16 = true; static constexpr int BYTES = 2; };
+
+typedef unsigned rcf_u32x2 __attribute__((ext_vector_type(2)));
+
+// fp32 -> bf16 bits, round to nearest even (NaN payloads are not preserved; the hot path never produces them)
+__device__ __forceinline__ unsigned rcf_f2b(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float rcf_b2f(unsigned h) { return __uint_as_float(h << 16); }
+// the value a bf16 tensor will hold for x (fp32 tensors: x itself)
+template <class S>
+__device__ __forceinline__ float rcf_round_st(float x) { return S::B16 ? rcf_b2f(rcf_f2b(x)) : x; }
+
+template <class S>
+__device__ __forceinline__ f32x4 rcf_ld4(const float* p, size_t i) {
+    if constexpr (S::B16) {
+        const rcf_u32x2 w = *reinterpret_cast<const rcf_u32x2*>(reinterpret_cast<const unsigned short*>(p) + i);
+        f32x4 v;
+        v[0] = __uint_as_float(w[0] << 16);
+        v[1] = __uint_as_float(w[0] & 0xffff0000u);
+        v[2] = __uint_as_float(w[1] << 16);
+        v[3] = __uint_as_float(w[1] & 0xffff0000u);
+        return v;
+    } else {
+        return *reinterpret_cast<const f32x4*>(p + i);
+    }
+}
+template <class S>
+__device__ __forceinline__ f32x4 rcf_ld4_nt(const float* p, size_t i) {   // non-temporal: streams larger than the MALL
+    if constexpr (S::B16) {
+        const rcf_u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const rcf_u32x2*>(reinterpret_cast<const unsigned short*>(p) + i));
+        f32x4 v;
+        v[0] = __uint_as_float(w[0] << 16);
+        v[1] = __uint_as_float(w[0] & 0xffff0000u);
+        v[2] = __uint_as_float(w[1] << 16);
+        v[3] = __uint_as_float(w[1] & 0xffff0000u);
+        return v;
+    } else {
+        return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i));
+    }
+}
+template <class S>
+__device__ __forceinline__ void rcf_st4(float* p, size_t i, f32x4 v) {
+    if constexpr (S::B16) {
+        rcf_u32x2 w;
+        w[0] = rcf_f2b(v[0]) | (rcf_f2b(v[1]) << 16);
+        w[1] = rcf_f2b(v[2]) | (rcf_f2b(v[3]) << 16);
+        *reinterpret_cast<rcf_u32x2*>(reinterpret_cast<unsigned short*>(p) + i) = w;
+    } else {
+        *reinterpret_cast<f32x4*>(p + i) = v;
+    }
+}
+template <class S>
+__device__ __forceinline__ float rcf_ld1(const float* p, size_t i) {
+    if constexpr (S::B16) return rcf_b2f(reinterpret_cast<const unsigned short*>(p)[i]);
+    else return p[i];
+}
+template <class S>
+__device__ __forceinline__ void rcf_st1(float* p, size_t i, float v) {
+    if constexpr (S::B16) reinterpret_cast<unsigned short*>(p)[i] = (unsigned short)rcf_f2b(v);
+    else p[i] = v;
+}
+// element offset -> pointer (for address arithmetic that has to stay in bytes, e.g. LDS-DMA sources)
+template <class S>
+__device__ __forceinline__ const float* rcf_at(const float* p, size_t i) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p) + i * S::BYTES);
+}
+template <class S>
+static inline const float* rcf_at_host(const float* p, size_t i) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p) + i * S::BYTES);
+}

@@ -1,0 +1,2499 @@
+// Implicit-GEMM convolution for FusionNet on MI355X (gfx950): forward / input-gradient / weight-gradient.
+//
+// Replaces torch.nn.Conv2d (+ the F.interpolate and torch.cat feeding it) on the reference's hot path
+// (src/net_utils.py:29-91, :156-198, :473-569) and autograd's conv backward behind loss.backward()
+// (src/fusionnet_main.py:398).
+//
+// Design:
+//  * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 -- bit-for-bit an fmaf chain, so results differ
+//    from the CPU reference only by summation order.
+//  * A workgroup (4 waves, one per SIMD) owns a PX x TH tile of output pixels and BN output channels.  Per
+//    chunk of CK input channels it stages the input HALO tile once into LDS ([halo pixel][CK+4], NHWC so each
+//    pixel's channels are one contiguous 16-B-aligned run) and all taps of the weight panel ([tap][BN][CK+4]);
+//    the 3x3 taps are then LDS address offsets, so every input element is fetched from HBM/L2 once per
+//    chunk instead of once per tap.  The nearest-upsample / zero-insert / channel-concat of the decoder are
+//    folded into that staging gather: the upsampled or concatenated tensor is never materialised.
+//  * MFMA operand fetch: lane (i = l&31, h = l>>5) reads ONE ds_read_b128 = 4 consecutive k of row i starting
+//    at k = 4h and feeds 4 consecutive MFMAs with it.  A and B use the same (h, q) -> k map, so the reduction
+//    is merely re-ordered.  The +4 float row pad makes those reads bank-conflict free for stride-1 tiles.
+//  * Epilogue: NHWC store (128 B contiguous per pixel row per 32 channels) and, fused, the per-channel sum and
+//    sum of squares BatchNorm needs (in-lane adds -> one cross-half shuffle -> LDS across the 4 waves ->
+//    one partial row per workgroup; no atomics, deterministic).
+//
+// This file is compiled twice (one translation unit each, so hipcc runs them in parallel): rcf_conv.hip with fp32 NHWC tensors
+// (RCF_CONV_B16 = 0, the public extern "C" entry points) and rcf_conv_b16.hip with bf16 NHWC tensors (RCF_CONV_B16 = 1:
+// rcf_conv_desc.storage == RCF_STORE_BF16, reached through the same entry points).
+#include "rcf_common.h"
+#include <type_traits>
+#include <stdlib.h>
+
+#ifndef RCF_CONV_B16
+#define RCF_CONV_B16 0
+#endif
+
+namespace {
+
+#if RCF_CONV_B16
+using SAct = StB16;   // storage of activations and their gradients in this translation unit
+#else
+using SAct = StF32;
+#endif
+// the two stem convolutions read the fp32 network input whatever the activation storage is (3 / 2 channels staged 4 wide)
+template <class C>
+using SInOf = std::conditional_t<(C::CST == 4), StF32, SAct>;
+
+// padding / out-of-image / out-of-range-channel lanes of the DMA and split weight-gradient kernels load from here instead of
+// branching: a zero-initialised device global (one copy per device, nothing allocated at run time)
+__device__ __attribute__((aligned(256))) const float rcf_zero_page[64] = {};
+
+struct ConvArgs {
+    const float* bias;   // fused inference epilogue (conv_split_kernel<C, true>): out = lrelu(acc + bias[co]), then lrelu(. + res) if res
+    const float* res;
+    const float* in1;
+    const float* in2;
+    const float* coef1;   // split kernels: in1 / in2 are RAW conv outputs of a BatchNorm + LeakyReLU block whose activation was
+    const float* coef2;   // never written; y = lrelu(z * coef[0][c] + coef[1][c]) is applied as the operand is staged (else null)
+    const float* wp;
+    float* out;
+    double* stats;
+    const float* dz;   // wgrad only
+    float* ws;         // wgrad only
+    int n, h_in, w_in, c1, c2, h1, w1, gather1;
+    int h_out, w_out, c_out, pad, pad_x, stride, gstep, accumulate;
+    int os, ooy, oox, ohp, owp;   // output (and wgrad dZ) phase addressing
+    int ioy, iox;                 // RCF_GATHER_STRIDED2 input offsets
+    int vt, hp, nimg;             // virtual tall image: rows = n*(h+1) with a zero separator row after each image
+    float inv_hp;
+    int phase_sum;                // sum the four input phases (up-2x dgrad) inside one launch
+    int wp_phase_stride;          // floats between the phases' packed weights
+    float sy, sx;
+    int tiles_x, tiles_y, ntiles;
+    int nchunk1, nchunk2;
+    int ktot, cop;     // wgrad workspace extents
+};
+
+template <int KSY_, int KSX_, int XEXTRA_, int LSTEP_, int CK_, int CST_, int STRP_, int NT_, int PX_, int MINW_>
+struct FwdCfg {
+    static constexpr int KSY = KSY_, KSX = KSX_, T = KSY_ * KSX_;
+    static constexpr int LSTEP = LSTEP_;   // LDS pixels between neighbouring output pixels
+    static constexpr int CK = CK_;         // reduction run per tap (floats)
+    static constexpr int CST = CST_;       // channels staged per halo pixel and chunk
+    static constexpr int STRP = STRP_;     // LDS floats per halo pixel
+    static constexpr int STRB = CK_ + 4;   // LDS floats per weight row
+    static constexpr int NT = NT_, BN = 32 * NT_;
+    static constexpr int PX = PX_, PY = 32 / PX_, MT = 2, TH = PY * MT * 4;
+    static constexpr int HXP = (PX - 1) * LSTEP + KSX + XEXTRA_;
+    static constexpr int HYP = (TH - 1) * LSTEP + KSY;
+    static constexpr int A_FLOATS = ((HXP * HYP * STRP + 3) / 4) * 4;
+    static constexpr int B_FLOATS = T * BN * STRB;
+    static constexpr int LDS_BYTES = (A_FLOATS + B_FLOATS) * 4;
+    static constexpr int MINW = MINW_;
+};
+
+// Halo staging, split in three so the HBM/L2 latency hides under the MFMAs of the previous chunk:
+//   halo_setup  once per (tile, source): each thread's NA halo elements -> global pixel index (or -1 for zero padding /
+//               zero-insert holes / outside the tile); all the gather math (nearest upsample, zero dilation) lives here
+//   halo_load   per chunk: NA independent 16-B loads into registers (no LDS, no waits)
+//   halo_store  per chunk: registers -> LDS
+// Halo pixel (hy,hx) <-> logical input pixel (iy0 + hy*gstep, ix0 + hx*gstep).  Thread t owns channel group t % C4 of
+// pixels t / C4 + i * (256 / C4).
+template <int CST, int STRP, int HXP, int HYP>
+struct Halo {
+    static constexpr int C4 = CST / 4;
+    static constexpr int PPI = 256 / C4;                       // halo pixels covered per iteration
+    static constexpr int NA = (HXP * HYP + PPI - 1) / PPI;
+    int pix[NA];                                               // element index of the pixel in the source, / csrc; -1: zero
+    unsigned okm;                                              // bit i: the load of pix[i] is real data (NA <= 32)
+
+    // vt != 0: rows are VIRTUAL rows of the batch stacked vertically with one zero row after each image (hp = h + 1);
+    // that separator is exactly the zero padding of a stride-1 3x3 conv, so tiles may straddle images.
+    __device__ __forceinline__ void setup(int hs, int ws, int gmode, int img, int iy0, int ix0, int gstep, int h_in, int w_in,
+                                          float sy, float sx, int tid, int ioy = 0, int iox = 0, int vt = 0, int hp = 1,
+                                          float inv_hp = 1.f, int nimg = 1) {
+        const int p0 = tid / C4;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int p = p0 + i * PPI;
+            const int hy = p / HXP;
+            const int hx = p - hy * HXP;
+            const int ly = iy0 + hy * gstep;
+            const int lx = ix0 + hx * gstep;
+            int v = -1;
+            if (vt) {
+                if (p < HXP * HYP && ly >= 0 && lx >= 0 && lx < w_in) {
+                    const int im = (int)(((float)ly + 0.5f) * inv_hp);   // exact: ly < 2^20, |frac - k| >= 0.5/hp
+                    const int y = ly - im * hp;
+                    if (im < nimg && y < h_in) v = (im * hs + y) * ws + lx;
+                }
+            } else if (p < HXP * HYP && ly >= 0 && ly < h_in && lx >= 0 && lx < w_in) {
+                int py = ly, px = lx;
+                bool ok = true;
+                if (gmode == RCF_GATHER_NEAREST) {
+                    // PyTorch nearest: src = min(floor(dst * (float)in/out), in-1)
+                    py = min((int)floorf((float)ly * sy), hs - 1);
+                    px = min((int)floorf((float)lx * sx), ws - 1);
+                } else if (gmode == RCF_GATHER_ZERO_INSERT) {
+                    ok = ((ly | lx) & 1) == 0;
+                    py = ly >> 1;
+                    px = lx >> 1;
+                    ok = ok && py < hs && px < ws;
+                } else if (gmode == RCF_GATHER_STRIDED2) {
+                    py = 2 * ly + ioy;
+                    px = 2 * lx + iox;
+                    ok = py < hs && px < ws;
+                }
+                if (ok) v = (img * hs + py) * ws + px;
+            }
+            pix[i] = v;
+        }
+    }
+
+    // Loads are branch-free: a clamped (always valid) address, and the value is replaced by zero only when it is written to
+    // LDS -- a branch or a select right behind each load makes the compiler wait for it before issuing the next.
+    template <class S>
+    __device__ __forceinline__ void load(f32x4 (&r)[NA], const float* __restrict__ src, int csrc, int cb, int tid) {
+        const int c = cb + (tid % C4) * 4;
+        const bool cok = c < csrc;
+        okm = 0xffffffffu;
+        if ((csrc & 3) == 0) {
+            const int cld = cok ? c : 0;
+            okm = 0u;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                if (cok && pix[i] >= 0) okm |= 1u << i;
+                r[i] = rcf_ld4<S>(src, (size_t)(pix[i] < 0 ? 0 : pix[i]) * csrc + cld);
+            }
+        } else {   // stems (3 / 2 input channels): scalar loads
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (cok && pix[i] >= 0) {
+                    const size_t g = (size_t)pix[i] * csrc + c;
+                    v[0] = rcf_ld1<S>(src, g);
+                    if (c + 1 < csrc) v[1] = rcf_ld1<S>(src, g + 1);
+                    if (c + 2 < csrc) v[2] = rcf_ld1<S>(src, g + 2);
+                    if (c + 3 < csrc) v[3] = rcf_ld1<S>(src, g + 3);
+                }
+                r[i] = v;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(const f32x4 (&r)[NA], float* __restrict__ As, int tid) const {
+        const int p0 = tid / C4;
+        const int c4 = tid % C4;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int p = p0 + i * PPI;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (p < HXP * HYP) *reinterpret_cast<f32x4*>(As + p * STRP + c4 * 4) = ((okm >> i) & 1u) ? r[i] : z;
+        }
+    }
+};
+
+template <class C, class SI = SInOf<C>, class SO = SAct>
+__global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + C::A_FLOATS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+
+    int abase[C::MT];
+#pragma unroll
+    for (int mi = 0; mi < C::MT; ++mi) {
+        const int tr = (wave * C::MT + mi) * C::PY + li / C::PX;
+        const int tc = li % C::PX;
+        abase[mi] = (tr * C::LSTEP * C::HXP + tc * C::LSTEP) * C::STRP + 4 * lh;
+    }
+    const int bbase = li * C::STRB + 4 * lh;
+
+    f32x16 acc[C::MT][C::NT];
+
+    const int nchunk = a.nchunk1 + a.nchunk2;
+    constexpr int WCHUNK = C::T * C::BN * C::CK;
+    const float* wp = a.wp + (size_t)blockIdx.y * nchunk * WCHUNK;
+    const int n0 = blockIdx.y * C::BN;
+
+    using H = Halo<C::CST, C::STRP, C::HXP, C::HYP>;
+    constexpr int K4 = C::CK / 4;
+    constexpr int NVB = C::T * C::BN * K4;
+    constexpr int NB = (NVB + 255) / 256;
+    H halo;
+    f32x4 ra[H::NA];
+    f32x4 rb[NB];
+
+    // Work items are (tile, chunk) pairs; the workgroup is persistent over tiles (grid-stride) and the loads of item i+1
+    // are issued before the MFMAs of item i, also across a tile boundary.
+    const int nitem = a.phase_sum ? 4 * nchunk : nchunk;   // work items per tile
+    auto load_item = [&](int tile, int item) {
+        const int ph = a.phase_sum ? item / nchunk : 0;
+        const int q = a.phase_sum ? item - ph * nchunk : item;
+        const bool first = q < a.nchunk1;
+        if (q == 0 || q == a.nchunk1) {
+            int t = tile;
+            const int tx = t % a.tiles_x;
+            t /= a.tiles_x;
+            const int ty = t % a.tiles_y;
+            const int img = t / a.tiles_y;   // 0 in virtual-tall mode (tiles_y covers all images)
+            const int pa = a.phase_sum ? (ph >> 1) : a.pad, pb = a.phase_sum ? (ph & 1) : a.pad_x;
+            const int iy0 = ty * C::TH * a.stride - pa;
+            const int ix0 = tx * C::PX * a.stride - pb;
+            if (q == 0)
+                halo.setup(a.h1, a.w1, a.gather1, img, iy0, ix0, a.gstep, a.h_in, a.w_in, a.sy, a.sx, tid,
+                           a.phase_sum ? (ph >> 1) : a.ioy, a.phase_sum ? (ph & 1) : a.iox, a.vt, a.hp, a.inv_hp, a.nimg);
+            else
+                halo.setup(a.h_in, a.w_in, RCF_GATHER_DIRECT, img, iy0, ix0, a.gstep, a.h_in, a.w_in, 1.f, 1.f, tid, 0, 0, a.vt, a.hp,
+                           a.inv_hp, a.nimg);
+        }
+        halo.template load<SI>(ra, first ? a.in1 : a.in2, first ? a.c1 : a.c2, (first ? q : q - a.nchunk1) * C::CST, tid);
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + (size_t)ph * a.wp_phase_stride + (size_t)q * WCHUNK);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + i * 256;
+            if (NVB % 256 == 0 || idx < NVB) rb[i] = wsrc[idx];
+        }
+    };
+
+    // BatchNorm statistics of this workgroup's output channels, accumulated in fp64 over all its tiles (PyTorch's CPU
+    // BatchNorm accumulates float tensors in double too) and written as ONE partial row per workgroup at the end.
+    double st1[C::NT], st2[C::NT];
+#pragma unroll
+    for (int ni = 0; ni < C::NT; ++ni) { st1[ni] = 0.0; st2[ni] = 0.0; }
+
+    int tile = blockIdx.x;
+    int q = 0;
+    if (tile < a.ntiles) load_item(tile, 0);
+    while (tile < a.ntiles) {
+        __syncthreads();   // everyone is done reading the previous item from LDS
+        halo.store(ra, As, tid);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + i * 256;
+            if (NVB % 256 == 0 || idx < NVB)
+                *reinterpret_cast<f32x4*>(Bs + (idx / K4) * C::STRB + (idx % K4) * 4) = rb[i];
+        }
+        __syncthreads();
+        int ntile = tile, nq = q + 1;
+        if (nq == nitem) { nq = 0; ntile = tile + gridDim.x; }
+        if (ntile < a.ntiles) load_item(ntile, nq);   // in flight while the MFMAs below run
+
+        if (q == 0) {
+#pragma unroll
+            for (int mi = 0; mi < C::MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        }
+#pragma unroll
+        for (int tap = 0; tap < C::T; ++tap) {
+            const int toff = ((tap / C::KSX) * C::HXP + (tap % C::KSX)) * C::STRP;
+#pragma unroll
+            for (int s = 0; s < C::CK / 8; ++s) {
+                f32x4 av[C::MT], bv[C::NT];
+#pragma unroll
+                for (int mi = 0; mi < C::MT; ++mi)
+                    av[mi] = *reinterpret_cast<const f32x4*>(As + abase[mi] + toff + s * 8);
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni)
+                    bv[ni] = *reinterpret_cast<const f32x4*>(Bs + bbase + (tap * C::BN + ni * 32) * C::STRB + s * 8);
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                    for (int mi = 0; mi < C::MT; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < C::NT; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][kq], bv[ni][kq], acc[mi][ni], 0, 0, 0);
+            }
+        }
+
+        if (q == nitem - 1) {
+            // ---- epilogue of this tile: store (+accumulate) and BN statistics ----
+            int t = tile;
+            const int tx = t % a.tiles_x;
+            t /= a.tiles_x;
+            const int ty = t % a.tiles_y;
+            const int img = t / a.tiles_y;
+            const int oy0 = ty * C::TH;
+            const int ox0 = tx * C::PX;
+            const bool want_stats = a.stats != nullptr;
+#pragma unroll
+            for (int mi = 0; mi < C::MT; ++mi) {
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += 4) {
+                    size_t pbase[4];
+                    bool pok[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = rcf_mfma_row(r0 + j, lh);
+                        int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
+                        const int ox = ox0 + row % C::PX;
+                        int im = img;
+                        if (a.vt) {   // virtual row -> (image, row); separator rows produce no output
+                            im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                            oy -= im * a.hp;
+                            if (im >= a.nimg) oy = a.h_out;
+                        }
+                        const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+                        pok[j] = oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
+                        pbase[j] = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
+                    }
+                    float old[4][C::NT];
+                    if (a.accumulate) {   // all old values of the group in flight together (clamped address, used only where valid)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int ni = 0; ni < C::NT; ++ni) {
+                                const int co = n0 + ni * 32 + li;
+                                old[j][ni] = rcf_ld1<SO>(a.out, (pok[j] && co < a.c_out) ? pbase[j] + co : 0);
+                            }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int ni = 0; ni < C::NT; ++ni) old[j][ni] = 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int ni = 0; ni < C::NT; ++ni) {
+                            const int co = n0 + ni * 32 + li;
+                            if (pok[j] && co < a.c_out) {
+                                const float v = rcf_round_st<SO>(acc[mi][ni][r0 + j] + old[j][ni]);   // statistics of what is stored
+                                rcf_st1<SO>(a.out, pbase[j] + co, v);
+                                if (want_stats) {   // fp64 per value: E[x^2]-mean^2 must not depend on how tiles group the sum
+                                    const double dv = (double)v;
+                                    st1[ni] += dv;
+                                    st2[ni] += dv * dv;
+                                }
+                            }
+                        }
+                }
+            }
+        }
+        tile = ntile;
+        q = nq;
+    }
+
+    if (a.stats != nullptr) {
+        __syncthreads();   // LDS is free
+        double* red = reinterpret_cast<double*>(smem);   // [4 waves][BN][2]
+#pragma unroll
+        for (int ni = 0; ni < C::NT; ++ni) {
+            const double t1 = st1[ni] + __shfl_xor(st1[ni], 32);
+            const double t2 = st2[ni] + __shfl_xor(st2[ni], 32);
+            if (lh == 0) {
+                red[(wave * C::BN + ni * 32 + li) * 2 + 0] = t1;
+                red[(wave * C::BN + ni * 32 + li) * 2 + 1] = t2;
+            }
+        }
+        __syncthreads();
+        if (tid < C::BN) {
+            const int co = n0 + tid;
+            if (co < a.c_out) {
+                double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    t1 += red[(w * C::BN + tid) * 2 + 0];
+                    t2 += red[(w * C::BN + tid) * 2 + 1];
+                }
+                a.stats[((size_t)blockIdx.x * 2 + 0) * a.c_out + co] = t1;
+                a.stats[((size_t)blockIdx.x * 2 + 1) * a.c_out + co] = t2;
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// fp32 convolution on the bf16 matrix pipe ("split" kernel, 3x3 stride 1, forward and input gradient).
+// Every fp32 operand x is split EXACTLY into three bf16 planes by truncation (x = p0 + p1 + p2: 3 x 8 significant bits =
+// fp32's 24), and a*b is accumulated as the six partial products with i + j <= 2 on v_mfma_f32_32x32x16_bf16 (fp32
+// accumulate).  The dropped terms are <= 2^-24 |ab|, below the accumulator's own rounding: measured error equals the exact
+// f32 MFMA's (tools/probe/split_bf16_probe.hip: 1.0e-7 * sum|ab| at K = 2304 for both, 9 products == 6 products bitwise).
+// 6 MFMAs x 32 cycles per 16-deep step against 8 x 64 cycles on the f32 MFMA: 2.7x the matrix rate.
+//  * 8 waves (2 per SIMD), tile PX x TH (32x16 or 16x32) x BN; LDS holds the three planes of the halo tile
+//    ([plane][pixel][16 bf16 + 8 pad]: conflict-free 16-B reads) and of the weight panel ([plane][tap][BN][16 bf16],
+//    halves XOR-swizzled by (co >> 3) & 1), 143 KB for BN = 64.
+//  * activations are split while staged (and/sub, ~5.5 VALU per element); weights are pre-split by the pack kernel.
+//  * persistent + register-prefetched like conv_fwd_kernel; same epilogue (store, +=, fp64 BN statistics).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// Work decomposition: a 256-thread workgroup owns a 32x8 / 16x16 output tile x BN output channels; two workgroups are resident per
+// CU (<= 80 KB LDS, <= 256 VGPRs each), so one converts/stages while the other feeds the matrix pipe.  Per 16-channel chunk the
+// fp32 halo tile is loaded once (registers), split, and written to LDS as three bf16 planes [pixel][16 ch] whose 16-B halves are
+// XOR-swizzled by bit 3 of the pixel index (conflict-free ds_read_b128 without padding).  The pre-split packed weights arrive one
+// KERNEL ROW (KSX taps) at a time into a double-buffered LDS piece, so only the A tile needs the two-barrier hand-over.
+// NPL_ = 3: fp32 results (exact split, six partial products).  NPL_ = 1: rcf_conv_desc.precision == RCF_PREC_BF16 -- operands
+// rounded to bf16 (nearest even), ONE product, fp32 accumulate: the "bf16" configurations of BASELINE.json.
+template <int KS_, int NT_, int PX_, int MT_ = 0, int NPL_ = 3>
+struct SplitCfg {
+    static constexpr int NPL = NPL_, NP = NPL_ == 3 ? 6 : 1;   // operand planes, partial products per MAC
+    static constexpr int KSY = KS_, KSX = KS_, T = KS_ * KS_, LSTEP = 1, CK = 16, CST = 16;
+    static constexpr int NT = NT_, BN = 32 * NT_;
+    static constexpr int PX = PX_, PY = 32 / PX_, MT = MT_ ? MT_ : ((NT_ == 1 && KS_ == 3) ? 4 : 2), NW = 4, TH = PY * MT * NW;   // 3x3 32-co layers: 512-pixel tiles
+    static constexpr int HXP = PX + KS_ - 1, HYP = TH + KS_ - 1, NPIX = HXP * HYP;
+    static constexpr int A_PLANE_BYTES = NPIX * 32;        // 16 bf16 per halo pixel
+    static constexpr int A_BYTES = NPL * A_PLANE_BYTES;
+    static constexpr int B_PLANE_BYTES = KSX * BN * 32;    // one kernel row: 16 bf16 per (tap, co)
+    static constexpr int B_PIECE_BYTES = NPL * B_PLANE_BYTES;
+    static constexpr int COEF_MAX_C = 512;                 // input channels (both sources) of the BN-on-load table
+    static constexpr int COEF_BYTES = 2 * COEF_MAX_C * 4;
+    static constexpr int LDS_BYTES = A_BYTES + 2 * B_PIECE_BYTES + COEF_BYTES;
+    static constexpr int WCHUNK_BYTES = KSY * B_PIECE_BYTES;   // one chunk of pre-split packed weights
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+};
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+// fp32 -> bf16 (round to nearest even), result in the HIGH 16 bits (low bits garbage)
+__device__ __forceinline__ unsigned rcf_bf16_rne(float x) {
+    const unsigned u = __float_as_uint(x);
+    return u + 0x7fffu + ((u >> 16) & 1u);
+}
+// s_waitcnt vmcnt(0) (expcnt/lgkmcnt untouched): LDS-DMA completion is tracked by vmcnt only, and the compiler does not know
+// that a later ds_read depends on it -- the wait before the publishing barrier has to be explicit.
+__device__ __forceinline__ void rcf_wait_dma() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+#ifdef RCF_PHASE_TIMING   // diagnostics build only (tools/phase_timing.py): where a wave of conv_split_kernel spends its cycles
+__device__ unsigned long long rcf_phase_cycles[8];
+#define RCF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define RCF_TACC(slot, t1, t0) tacc[slot] += (t1) - (t0)
+#else
+#define RCF_T(var)
+#define RCF_TACC(slot, t1, t0)
+#endif
+
+// EPI: inference epilogue -- BatchNorm folded into the weights (scale) and a per-channel bias, LeakyReLU, and the residual tail of
+// ResNetBlock (lrelu(y + res)) applied to the accumulators before the only store; no statistics.
+template <class C, bool EPI = false, class SI = SAct, class SO = SAct>
+__global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
+    static_assert(!SI::B16 || C::NPL == 1, "bf16 tensors go with bf16 operands");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* As = smem_b;
+    unsigned char* Bs = smem_b + C::A_BYTES;
+    float* coef_lds = reinterpret_cast<float*>(smem_b + C::A_BYTES + 2 * C::B_PIECE_BYTES);   // [2][c1 + c2]: scale, shift
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    if (a.coef1 != nullptr || a.coef2 != nullptr) {   // BN-on-load table: identity (1, 0) for a source without coefficients
+        const int ctot = a.c1 + a.c2;
+        for (int i = tid; i < ctot; i += 256) {
+            const bool s1 = i < a.c1;
+            const float* cf = s1 ? a.coef1 : a.coef2;
+            const int cs = s1 ? a.c1 : a.c2, ci = s1 ? i : i - a.c1;
+            coef_lds[i] = cf ? cf[ci] : 1.f;
+            coef_lds[ctot + i] = cf ? cf[cs + ci] : 0.f;
+        }
+        // published by the first __syncthreads() of the kernel, which precedes every store_a that reads it... the prologue's
+        // store_a comes first: make it explicit
+        __syncthreads();
+    }
+
+    int apix[C::MT];   // halo pixel of this lane's output pixel at tap (0, 0)
+#pragma unroll
+    for (int mi = 0; mi < C::MT; ++mi) {
+        const int tr = (wave * C::MT + mi) * C::PY + li / C::PX;
+        const int tc = li % C::PX;
+        apix[mi] = tr * C::HXP + tc;
+    }
+    const int bbase = li * 32 + ((lh ^ ((li >> 3) & 1)) * 16);   // row co = ni*32 + li; (ni*32) keeps (co>>3)&1 == (li>>3)&1
+
+    f32x16 acc[C::MT][C::NT];
+    const int nchunk = a.nchunk1 + a.nchunk2;
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.wp) + (size_t)blockIdx.y * nchunk * C::WCHUNK_BYTES;
+    const int n0 = blockIdx.y * C::BN;
+
+    // A staging: thread t owns channel quad t % 4 of halo pixels t / 4 + i * 64
+    constexpr int NA = (C::NPIX + 63) / 64;
+    int pix[NA];
+    f32x4 ra[NA];
+    unsigned okm = 0u;   // bit i: ra[i] holds real data (else the clamped load is replaced by zero at store time)
+    int tch = 0;         // first channel (in c1 + c2 numbering) of the staged quad, and whether its source is BN-on-load
+    bool ttf = false;
+
+    auto setup = [&](int tile, bool first, int ph) {
+        int t = tile;
+        const int tx = t % a.tiles_x;
+        t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        const int img = t / a.tiles_y;
+        const int pa = a.phase_sum ? (ph >> 1) : a.pad, pb = a.phase_sum ? (ph & 1) : a.pad_x;
+        const int ioy = a.phase_sum ? (ph >> 1) : a.ioy, iox = a.phase_sum ? (ph & 1) : a.iox;
+        const int iy0 = ty * C::TH - pa;
+        const int ix0 = tx * C::PX - pb;
+        const int hs = first ? a.h1 : a.h_in, ws = first ? a.w1 : a.w_in;
+        const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int p = (tid >> 2) + i * 64;
+            const int hy = p / C::HXP;
+            const int hx = p - hy * C::HXP;
+            const int ly = iy0 + hy, lx = ix0 + hx;
+            int v = -1;
+            if (p < C::NPIX && ly >= 0 && lx >= 0 && lx < a.w_in) {
+                if (a.vt) {
+                    const int im = (int)(((float)ly + 0.5f) * a.inv_hp);
+                    const int y = ly - im * a.hp;
+                    if (im < a.nimg && y < a.h_in) v = (im * hs + y) * ws + lx;
+                } else if (ly < a.h_in) {
+                    int py = ly, px = lx;
+                    bool ok = true;
+                    if (gmode == RCF_GATHER_NEAREST) {
+                        py = min((int)floorf((float)ly * a.sy), hs - 1);
+                        px = min((int)floorf((float)lx * a.sx), ws - 1);
+                    } else if (gmode == RCF_GATHER_STRIDED2) {
+                        py = 2 * ly + ioy;
+                        px = 2 * lx + iox;
+                        ok = py < hs && px < ws;
+                    } else if (gmode == RCF_GATHER_ZERO_INSERT) {
+                        ok = ((ly | lx) & 1) == 0;
+                        py = ly >> 1;
+                        px = lx >> 1;
+                        ok = ok && py < hs && px < ws;
+                    }
+                    if (ok) v = (img * hs + py) * ws + px;
+                }
+            }
+            pix[i] = v;
+        }
+    };
+    const int nitem = a.phase_sum ? 4 * nchunk : nchunk;   // A tiles per output tile
+    // fp32 halo tile of one item -> registers.  Loads are unconditional from a clamped (always valid) address and zero-selected at
+    // store time: a branch or a select behind each load makes the compiler wait for it before issuing the next.
+    auto load_a = [&](int tile, int item) {
+        const int ph = a.phase_sum ? item / nchunk : 0;
+        const int q = a.phase_sum ? item - ph * nchunk : item;
+        const bool first = q < a.nchunk1;
+        if (q == 0 || q == a.nchunk1) setup(tile, first, ph);
+        const float* src = first ? a.in1 : a.in2;
+        const int csrc = first ? a.c1 : a.c2;
+        const int cch = (first ? q : q - a.nchunk1) * 16 + (tid & 3) * 4;
+        const bool cok = cch < csrc;
+        const int cld = cok ? cch : 0;
+        tch = (first ? 0 : a.c1) + cld;
+        ttf = (first ? a.coef1 : a.coef2) != nullptr;
+        okm = 0u;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (cok && pix[i] >= 0) okm |= 1u << i;
+            ra[i] = rcf_ld4<SI>(src, (size_t)(pix[i] < 0 ? 0 : pix[i]) * csrc + cld);
+        }
+    };
+    // BN selects the BatchNorm-on-load variant at COMPILE time: as one code path the compiler if-converts the (wave-uniform) test and
+    // every plain conversion pays the multiply-add, compare and selects of the other variant (~100 of 330 VALU instructions per chunk;
+    // a VALU wave-instruction costs about a fifth of an MFMA in energy, and these kernels are power-limited)
+    auto store_a_impl = [&](auto bn_tag) __attribute__((always_inline)) {
+        constexpr bool BN = decltype(bn_tag)::value;
+        f32x4 tsc = {1.f, 1.f, 1.f, 1.f}, tsh = {0.f, 0.f, 0.f, 0.f};
+        if (BN) {
+            tsc = *reinterpret_cast<const f32x4*>(coef_lds + tch);
+            tsh = *reinterpret_cast<const f32x4*>(coef_lds + a.c1 + a.c2 + tch);
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int p = (tid >> 2) + i * 64;
+            if (p < C::NPIX) {
+                // exact 3-way truncation split: plane k keeps the next 8 significant bits
+                unsigned x0[4], x1[4], x2[4];
+                float xin[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float xv = ra[i][e];
+                    if (BN) xv = rcf_lrelu(xv * tsc[e] + tsh[e]);   // the producer's BatchNorm + LeakyReLU, applied on load
+                    const float x = ((okm >> i) & 1u) ? xv : 0.f;
+                    xin[e] = x;
+                    x0[e] = __float_as_uint(x) & 0xffff0000u;
+                    const float r1 = x - __uint_as_float(x0[e]);
+                    x1[e] = __float_as_uint(r1) & 0xffff0000u;
+                    const float r2 = r1 - __uint_as_float(x1[e]);
+                    x2[e] = __float_as_uint(r2);
+                }
+                const int cq = tid & 3;
+                unsigned char* dst = As + p * 32 + (((cq >> 1) ^ ((p >> 3) & 1)) * 16) + (cq & 1) * 8;
+                if (C::NPL == 1) {   // bf16 operands: round to nearest even instead of splitting
+                    unsigned r[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        r[e] = rcf_bf16_rne(xin[e]);
+                    }
+                    u32x2 w0 = {(r[0] >> 16) | (r[1] & 0xffff0000u), (r[2] >> 16) | (r[3] & 0xffff0000u)};
+                    *reinterpret_cast<u32x2*>(dst) = w0;
+                } else {
+                    u32x2 w0 = {(x0[0] >> 16) | x0[1], (x0[2] >> 16) | x0[3]};
+                    u32x2 w1 = {(x1[0] >> 16) | x1[1], (x1[2] >> 16) | x1[3]};
+                    u32x2 w2 = {(x2[0] >> 16) | (x2[1] & 0xffff0000u), (x2[2] >> 16) | (x2[3] & 0xffff0000u)};
+                    *reinterpret_cast<u32x2*>(dst) = w0;
+                    *reinterpret_cast<u32x2*>(dst + (C::NPL > 1 ? 1 : 0) * C::A_PLANE_BYTES) = w1;
+                    *reinterpret_cast<u32x2*>(dst + (C::NPL > 2 ? 2 : 0) * C::A_PLANE_BYTES) = w2;
+                }
+            }
+        }
+    };
+    auto store_a = [&]() __attribute__((always_inline)) {
+        if (ttf) store_a_impl(std::true_type{});
+        else store_a_impl(std::false_type{});
+    };
+    // one kernel row of pre-split weights: straight copy global -> LDS piece `buf` by LDS-DMA (each wave instruction moves 1 KiB to a
+    // wave-uniform LDS base + 16 B x lane; no staging registers, no ds_write).  hipcc drains vmcnt before the next barrier.
+    auto chunk_base = [&](int item) -> const unsigned char* {
+        const int ph = a.phase_sum ? item / nchunk : 0;
+        const int q = a.phase_sum ? item - ph * nchunk : item;
+        return wp + (size_t)ph * a.wp_phase_stride * 4 + (size_t)q * C::WCHUNK_BYTES;
+    };
+    auto copy_b = [&](const unsigned char* cbase, int ky, int buf) {
+        constexpr int NKB = C::B_PIECE_BYTES / 1024;
+        static_assert(C::B_PIECE_BYTES % 1024 == 0, "weight piece must be whole KiB");
+        const int w = __builtin_amdgcn_readfirstlane(wave);
+        const unsigned char* wsrc = cbase + (size_t)ky * C::B_PIECE_BYTES + lane * 16;
+#pragma unroll
+        for (int i = 0; i < (NKB + 3) / 4; ++i) {
+            int kb = i * 4 + w;
+            if ((i + 1) * 4 > NKB) kb = kb < NKB ? kb : NKB - 1;   // ragged tail: a duplicate copy of the last KiB is harmless
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 1024),
+                                             (__attribute__((address_space(3))) void*)(Bs + buf * C::B_PIECE_BYTES + kb * 1024), 16, 0, 0);
+        }
+    };
+
+    double st1[C::NT], st2[C::NT];
+#pragma unroll
+    for (int ni = 0; ni < C::NT; ++ni) { st1[ni] = 0.0; st2[ni] = 0.0; }
+
+    // Phases: one kernel row (KSX taps) per barrier interval.  During a row's MFMAs the next row's weight piece arrives by DMA in
+    // the other LDS slot and (one row before the chunk ends) the next A tile is loaded into registers; the A tile itself is handed
+    // over between two barriers at the end of the chunk.  The second resident workgroup of the CU fills the matrix pipe meanwhile.
+    int tile = blockIdx.x;
+    int q = 0;
+    int pb = 0;   // LDS slot of the weight piece the current kernel row reads
+    bf16x8 av[2][C::NPL][C::MT], bv[2][C::NPL][C::NT];
+    auto fetch_a = [&](int ky, int kx, int slot) {
+#pragma unroll
+        for (int mi = 0; mi < C::MT; ++mi) {
+            int ap = apix[mi];
+            if (C::MT > 2) asm volatile("" : "+v"(ap));   // recompute the swizzled address per tap: hoisted, the 2 x T addresses cost 18 VGPRs
+            const int p = ap + ky * C::HXP + kx;
+            const int ao = p * 32 + ((lh ^ ((p >> 3) & 1)) * 16);
+#pragma unroll
+            for (int pl = 0; pl < C::NPL; ++pl) av[slot][pl][mi] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + pl * C::A_PLANE_BYTES + ao));
+        }
+    };
+    auto fetch_b = [&](int kx, int slot, int bslot) {
+        const unsigned char* Bp = Bs + bslot * C::B_PIECE_BYTES;
+#pragma unroll
+        for (int pl = 0; pl < C::NPL; ++pl)
+#pragma unroll
+            for (int ni = 0; ni < C::NT; ++ni)
+                bv[slot][pl][ni] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bp + pl * C::B_PLANE_BYTES + (kx * C::BN + ni * 32) * 32 + bbase));
+    };
+    const unsigned char* cb_cur = wp;   // packed weights of the current chunk
+#ifdef RCF_PHASE_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
+    if (tile < a.ntiles) {
+        load_a(tile, 0);
+        copy_b(cb_cur, 0, 0);
+        store_a();
+    }
+    rcf_wait_dma();
+    __syncthreads();
+    if (tile < a.ntiles) fetch_a(0, 0, 0);
+    while (tile < a.ntiles) {
+        int ntile = tile, nq = q + 1;
+        if (nq == nitem) { nq = 0; ntile = tile + gridDim.x; }
+        const bool more = ntile < a.ntiles;
+        const unsigned char* cb_next = more ? chunk_base(nq) : wp;
+        if (q == 0) {
+#pragma unroll
+            for (int mi = 0; mi < C::MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        }
+#pragma unroll
+        for (int ky = 0; ky < C::KSY; ++ky) {
+            const bool last_row = ky == C::KSY - 1;
+            // every row starts in register set 0: its A operands were fetched before the barrier that published its weights
+            RCF_T(t_row0);
+            fetch_b(0, 0, pb);
+            if (!last_row) copy_b(cb_cur, ky + 1, pb ^ 1);   // nobody reads that slot during this row
+            else if (more) copy_b(cb_next, 0, pb ^ 1);
+            if (ky == (C::KSY >= 2 ? C::KSY - 2 : 0) && more) load_a(ntile, nq);
+            __builtin_amdgcn_sched_barrier(0);
+            RCF_T(t_row1);
+            RCF_TACC(0, t_row1, t_row0);   // 0: row prologue (first B reads, DMA / global-load issue)
+#pragma unroll
+            for (int kx = 0; kx < C::KSX; ++kx) {
+                const int cur = kx & 1;
+                // The 6 x MT x NT MFMAs of this tap in product-major, accumulator-round-robin order (dependent MFMAs stay MT x NT
+                // apart), with the next tap's LDS reads issued ONE AT A TIME between them: issued as a block, the reads stall the
+                // wave's MFMA issue for as long as the LDS queue takes them, and the partner wave on the SIMD tends to be doing
+                // the same.  sched_barrier pins the hand-written order.
+                constexpr int MN = C::MT * C::NT, NMF = C::NP * MN, NRD = C::NPL * (C::MT + C::NT);
+                const bool has_next = kx + 1 < C::KSX;
+                int nr = 0;
+                int ao_next[C::MT];
+#pragma unroll
+                for (int j = 0; j < NMF; ++j) {
+                    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
+                    const int pj = j / MN, mi = (j % MN) / C::NT, ni = j % C::NT;
+                    const int pa = C::NPL == 3 ? PA[pj] : 0, pbl = C::NPL == 3 ? PB[pj] : 0;
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][pa][mi], bv[cur][pbl][ni], acc[mi][ni], 0, 0, 0);
+                    if (has_next) {
+#pragma unroll
+                        for (int rep = 0; rep < 3; ++rep) {
+                            if (nr < NRD && (nr + 1) * NMF <= (j + 1) * NRD) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (nr < C::NPL * C::MT) {
+                                    const int rmi = nr / C::NPL, pl = nr % C::NPL;
+                                    if (pl == 0) {
+                                        int ap = apix[rmi];
+                                        if (C::MT > 2) asm volatile("" : "+v"(ap));
+                                        const int p = ap + ky * C::HXP + kx + 1;
+                                        ao_next[rmi] = p * 32 + ((lh ^ ((p >> 3) & 1)) * 16);
+                                    }
+                                    av[cur ^ 1][pl][rmi] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + pl * C::A_PLANE_BYTES + ao_next[rmi]));
+                                } else {
+                                    const int rb = nr - C::NPL * C::MT, pl = rb / C::NT, rni = rb % C::NT;
+                                    bv[cur ^ 1][pl][rni] = as_bf16x8(*reinterpret_cast<const u32x4*>(
+                                        Bs + pb * C::B_PIECE_BYTES + pl * C::B_PLANE_BYTES + ((kx + 1) * C::BN + rni * 32) * 32 + bbase));
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                ++nr;
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            RCF_T(t_row2);
+            RCF_TACC(1, t_row2, t_row1);   // 1: the row's MFMAs + interleaved LDS reads
+            if (last_row) {
+                if (q == nitem - 1) {
+                    int t = tile;
+                    const int tx = t % a.tiles_x;
+                    t /= a.tiles_x;
+                    const int ty = t % a.tiles_y;
+                    const int img = t / a.tiles_y;
+                    const int oy0 = ty * C::TH;
+                    const int ox0 = tx * C::PX;
+                    const bool want_stats = !EPI && a.stats != nullptr;
+                    float ebias[C::NT];
+                    if (EPI) {
+#pragma unroll
+                        for (int ni = 0; ni < C::NT; ++ni) {
+                            const int co = n0 + ni * 32 + li;
+                            ebias[ni] = a.bias[co < a.c_out ? co : 0];
+                        }
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < C::MT; ++mi) {
+#pragma unroll
+                        for (int r0 = 0; r0 < 16; r0 += 4) {
+                            // the four accumulator rows r0 .. r0 + 3 of a lane are four consecutive pixels of ONE tile row (MFMA row =
+                            // j + 8 * (r0 / 4) + 4 * lh, PX a multiple of 4): one address computation per group, then + j pixels
+                            size_t pbase[4];
+                            bool pok[4];
+                            if (C::MT != 4) {
+                                const int row = rcf_mfma_row(r0, lh);
+                                int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
+                                const int ox = ox0 + row % C::PX;
+                                int im = img;
+                                if (a.vt) {   // virtual row -> (image, row); separator rows produce no output
+                                    im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                                    oy -= im * a.hp;
+                                    if (im >= a.nimg) oy = a.h_out;
+                                }
+                                const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+                                const bool rowvalid = oy < a.h_out && py < a.ohp;
+                                const size_t base0 = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
+                                const int pstep = a.os * a.c_out;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    pok[j] = rowvalid && ox + j < a.w_out && px + j * a.os < a.owp;
+                                    pbase[j] = base0 + (size_t)(j * pstep);
+                                }
+                            }
+                            if (C::MT == 4) {   // the 512-pixel configuration sits at 256 VGPRs: the per-row form allocates better there
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const int row = rcf_mfma_row(r0 + j, lh);
+                                    int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
+                                    const int ox = ox0 + row % C::PX;
+                                    int im = img;
+                                    if (a.vt) {
+                                        im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                                        oy -= im * a.hp;
+                                        if (im >= a.nimg) oy = a.h_out;
+                                    }
+                                    const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+                                    pok[j] = oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
+                                    pbase[j] = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
+                                }
+                            }
+                            float old[4][C::NT];
+                            const float* addsrc = EPI ? a.res : a.out;
+                            if (EPI ? a.res != nullptr : a.accumulate != 0) {   // all old values of the group in flight together (clamped address)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int ni = 0; ni < C::NT; ++ni) {
+                                        const int co = n0 + ni * 32 + li;
+                                        old[j][ni] = rcf_ld1<SO>(addsrc, (pok[j] && co < a.c_out) ? pbase[j] + co : 0);
+                                    }
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int ni = 0; ni < C::NT; ++ni) old[j][ni] = 0.f;
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int ni = 0; ni < C::NT; ++ni) {
+                                    const int co = n0 + ni * 32 + li;
+                                    if (pok[j] && co < a.c_out) {
+                                        float v = acc[mi][ni][r0 + j] + (EPI ? ebias[ni] : old[j][ni]);
+                                        if (EPI) {
+                                            v = rcf_lrelu(v);
+                                            if (a.res != nullptr) v = rcf_lrelu(v + old[j][ni]);
+                                        }
+                                        v = rcf_round_st<SO>(v);   // BatchNorm statistics of the values the tensor holds
+                                        rcf_st1<SO>(a.out, pbase[j] + co, v);
+                                        if (want_stats) {   // fp64 per value: E[x^2]-mean^2 must not depend on how tiles group the sum
+                                            const double dv = (double)v;
+                                            st1[ni] += dv;
+                                            st2[ni] += dv * dv;
+                                        }
+                                    }
+                                }
+                        }
+                    }
+                }
+                RCF_T(t_e0);
+                RCF_TACC(2, t_e0, t_row2);     // 2: output epilogue (last chunk of a tile only)
+                __syncthreads();   // every wave is done reading the A tile
+                RCF_T(t_e1);
+                RCF_TACC(3, t_e1, t_e0);       // 3: barrier "A tile free"
+                if (more) store_a();
+                RCF_T(t_e2);
+                RCF_TACC(4, t_e2, t_e1);       // 4: store_a (wait for the global loads, split, ds_write)
+            } else {
+                fetch_a(ky + 1, 0, 0);   // next row's first A operands: the tile does not change inside a chunk
+            }
+            RCF_T(t_b0);
+            rcf_wait_dma();   // the next weight piece has landed
+            __syncthreads();
+            RCF_T(t_b1);
+            RCF_TACC(last_row ? 5 : 6, t_b1, t_b0);   // 5: DMA wait + publishing barrier after store_a; 6: the same between rows
+            if (last_row && more) fetch_a(0, 0, 0);
+            pb ^= 1;
+        }
+        tile = ntile;
+        q = nq;
+        cb_cur = cb_next;
+    }
+
+#ifdef RCF_PHASE_TIMING
+    tacc[7] = __builtin_amdgcn_s_memtime() - t_begin;   // 7: whole wave
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&rcf_phase_cycles[i], tacc[i]);
+#endif
+    if (a.stats != nullptr) {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem_b);   // [4 waves][BN][2]
+#pragma unroll
+        for (int ni = 0; ni < C::NT; ++ni) {
+            const double t1 = st1[ni] + __shfl_xor(st1[ni], 32);
+            const double t2 = st2[ni] + __shfl_xor(st2[ni], 32);
+            if (lh == 0) {
+                red[(wave * C::BN + ni * 32 + li) * 2 + 0] = t1;
+                red[(wave * C::BN + ni * 32 + li) * 2 + 1] = t2;
+            }
+        }
+        __syncthreads();
+        if (tid < C::BN) {
+            const int co = n0 + tid;
+            if (co < a.c_out) {
+                double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < C::NW; ++w) {
+                    t1 += red[(w * C::BN + tid) * 2 + 0];
+                    t2 += red[(w * C::BN + tid) * 2 + 1];
+                }
+                a.stats[((size_t)blockIdx.x * 2 + 0) * a.c_out + co] = t1;
+                a.stats[((size_t)blockIdx.x * 2 + 1) * a.c_out + co] = t2;
+            }
+        }
+    }
+}
+
+// OIHW fp32 -> pre-split bf16 planes [n-tile][chunk][kernel row][plane][kx][BN][16], halves swapped when (co >> 3) & 1.
+__global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, size_t total_rows16, int w_o,
+                                          int w_i, int mode, int i_off, int c_out, int c1, int c2, int nchunk1, int nchunk, int BN,
+                                          int ks, int npl) {
+    // one thread per (n-tile, chunk, tap, co, k) element; writes its three planes
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_rows16) return;
+    size_t t = idx;
+    const int k = t % 16; t /= 16;
+    const int T = ks * ks;
+    const int j = t % BN; t /= BN;
+    const int tap = t % T; t /= T;
+    const int q = t % nchunk;
+    const int nt = t / nchunk;
+    const int co = nt * BN + j;
+    const int ky = tap / ks, kx = tap % ks;
+    int cin = -1;
+    if (q < nchunk1) { const int c = q * 16 + k; if (c < c1) cin = c; }
+    else { const int c = (q - nchunk1) * 16 + k; if (c < c2) cin = c1 + c; }
+    float v = 0.f;
+    if (cin >= 0 && co < c_out) {
+        if (mode == RCF_W_FORWARD) v = w[(((size_t)co * w_i + cin) * ks + ky) * ks + kx];
+        else v = w[(((size_t)cin * w_i + (i_off + co)) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
+    }
+    const unsigned x0 = __float_as_uint(v) & 0xffff0000u;
+    const float r1 = v - __uint_as_float(x0);
+    const unsigned x1 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(x1);
+    const unsigned x2 = __float_as_uint(r2);
+    const size_t chunk_elems = (size_t)npl * T * BN * 16;
+    const size_t plane_elems = (size_t)ks * BN * 16;
+    const size_t piece_elems = npl * plane_elems;
+    const int kk = ((k >> 3) ^ ((j >> 3) & 1)) * 8 + (k & 7);   // XOR-swizzle the 16-B halves: conflict-free ds_read_b128
+    const size_t base = ((size_t)nt * nchunk + q) * chunk_elems + (size_t)ky * piece_elems + ((size_t)kx * BN + j) * 16 + kk;
+    if (npl == 1) {   // bf16 operands: round to nearest even
+        const unsigned u = __float_as_uint(v);
+        dst[base] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        return;
+    }
+    dst[base] = (unsigned short)(x0 >> 16);
+    dst[base + plane_elems] = (unsigned short)(x1 >> 16);
+    dst[base + 2 * plane_elems] = (unsigned short)(x2 >> 16);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient.  GEMM view: dW[k][co] = sum_pixels A[pixel][k] * dZ[pixel][co]; MFMA rows i = 32
+// consecutive k of one tap (32 input channels of one halo pixel, contiguous in the LDS halo tile),
+// columns j = 32 output channels, the MFMA's reduction index = pixel (lane half h takes pixel 2t+h).
+// A workgroup walks many spatial tiles (persistent over gridDim.x splits) for one (k-chunk, 32-co group);
+// wave w reduces the tile rows of slice w, the 4 slices are summed through LDS at the end, and one partial
+// [T*32][32] per workgroup goes to the workspace (reduced deterministically by wgrad_reduce_kernel).
+template <int KSY_, int KSX_, int XEXTRA_, int LSTEP_, int CST_, int STRP_, int PX_, int TH_, int MINW_, int PREFETCH_ = (MINW_ == 1)>
+struct WgCfg {
+    static constexpr bool PREFETCH = PREFETCH_ != 0;   // stage tile t+1 through registers during the MFMAs of tile t
+    static constexpr int KSY = KSY_, KSX = KSX_, T = KSY_ * KSX_;
+    static constexpr int LSTEP = LSTEP_;
+    static constexpr int CST = CST_, STRP = STRP_;
+    static constexpr int PX = PX_, TH = TH_, TP = PX_ * TH_;
+    static constexpr int RS = TH_ / 4;   // tile rows per wave
+    static constexpr int HXP = (PX - 1) * LSTEP + KSX + XEXTRA_;
+    static constexpr int HYP = (TH - 1) * LSTEP + KSY;
+    static constexpr int A_FLOATS = ((HXP * HYP * STRP + 3) / 4) * 4;
+    static constexpr int D_FLOATS = TP * 32;
+    static constexpr int RED_FLOATS = T * 16 * 64;   // one wave's accumulators
+    static constexpr int LDS_FLOATS = (A_FLOATS + D_FLOATS) > RED_FLOATS ? (A_FLOATS + D_FLOATS) : RED_FLOATS;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+    static constexpr int MINW = MINW_;
+};
+
+template <class C, class SX = SInOf<C>, class SD = SAct>
+__global__ void __launch_bounds__(256, C::MINW) conv_wgrad_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Ds = smem + C::A_FLOATS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+
+    const int q = blockIdx.y;
+    const int co0 = blockIdx.z * 32;
+    const bool first = q < a.nchunk1;
+    const float* src = first ? a.in1 : a.in2;
+    const int csrc = first ? a.c1 : a.c2;
+    const int cb = (first ? q : q - a.nchunk1) * C::CST;
+    const int hs = first ? a.h1 : a.h_in;
+    const int ws = first ? a.w1 : a.w_in;
+    const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
+
+    f32x16 acc[C::T];
+#pragma unroll
+    for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tap][r] = 0.f;
+
+    using H = Halo<C::CST, C::STRP, C::HXP, C::HYP>;
+    constexpr int ND = (C::TP * 8) / 256;     // dZ tile: TP pixels x 8 float4
+    H halo;
+    f32x4 ra[H::NA];
+    f32x4 rd[ND];
+    const int dc = co0 + (tid & 7) * 4;
+
+    auto load_tile = [&](int tile) {
+        int t = tile;
+        const int tx = t % a.tiles_x;
+        t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        const int img = t / a.tiles_y;
+        const int oy0 = ty * C::TH;
+        const int ox0 = tx * C::PX;
+        halo.setup(hs, ws, gmode, img, oy0 * a.stride - a.pad, ox0 * a.stride - a.pad_x, a.gstep, a.h_in, a.w_in, a.sy, a.sx, tid,
+                   a.ioy, a.iox);
+        halo.template load<SX>(ra, src, csrc, cb, tid);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int p = (tid >> 3) + i * 32;
+            const int oy = oy0 + p / C::PX;
+            const int ox = ox0 + p % C::PX;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+            if (oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp && dc < a.c_out)
+                v = rcf_ld4<SD>(a.dz, (((size_t)img * a.ohp + py) * a.owp + px) * a.c_out + dc);
+            rd[i] = v;
+        }
+    };
+
+    if (C::PREFETCH && (int)blockIdx.x < a.ntiles) load_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        if (!C::PREFETCH) load_tile(tile);   // two workgroups per CU cover each other's staging instead
+        __syncthreads();
+        halo.store(ra, As, tid);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int p = (tid >> 3) + i * 32;
+            *reinterpret_cast<f32x4*>(Ds + p * 32 + (tid & 7) * 4) = rd[i];
+        }
+        __syncthreads();
+        if (C::PREFETCH && tile + (int)gridDim.x < a.ntiles) load_tile(tile + gridDim.x);   // in flight while the MFMAs below run
+
+        // MFMA loop over this wave's RS tile rows x PX/2 pixel pairs; operands of iteration it+1 are read from LDS while
+        // the T MFMAs of iteration it issue (one wave per SIMD: nothing else would cover the LDS latency)
+        {
+            constexpr int NIT = C::RS * (C::PX / 2);
+            float av[2][C::T], bv[2];
+            auto fetch = [&](int it, int slot) {
+                const int trow = wave * C::RS + it / (C::PX / 2);
+                const int pc = 2 * (it % (C::PX / 2)) + lh;
+                bv[slot] = Ds[(trow * C::PX + pc) * 32 + li];
+                const int hb = (trow * C::LSTEP * C::HXP + pc * C::LSTEP) * C::STRP + li;
+#pragma unroll
+                for (int tap = 0; tap < C::T; ++tap)
+                    av[slot][tap] = As[hb + ((tap / C::KSX) * C::HXP + (tap % C::KSX)) * C::STRP];
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int cur = it & 1;
+                if (it + 1 < NIT) fetch(it + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);   // keep the next operands' reads ahead of this iteration's MFMAs
+#pragma unroll
+                for (int tap = 0; tap < C::T; ++tap)
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][tap], bv[cur], acc[tap], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // sum the 4 waves' accumulators through LDS (wave 3 -> 2 -> 1 -> 0 chain keeps it deterministic)
+    float* red = smem;
+    for (int s = 3; s >= 1; --s) {
+        __syncthreads();
+        if (wave == s) {
+#pragma unroll
+            for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(tap * 16 + r) * 64 + lane] = acc[tap][r];
+        }
+        __syncthreads();
+        if (wave == s - 1) {
+#pragma unroll
+            for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tap][r] += red[(tap * 16 + r) * 64 + lane];
+        }
+    }
+    if (wave == 0) {
+        float* wsp = a.ws + (size_t)blockIdx.x * a.ktot * a.cop;
+#pragma unroll
+        for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = (q * C::T + tap) * 32 + rcf_mfma_row(r, lh);
+                wsp[(size_t)k * a.cop + co0 + li] = acc[tap][r];
+            }
+    }
+}
+
+// Weight gradient, LDS-DMA variant (all non-stem layers): the halo tile [pixel][32 ch] and the dZ tile [pixel][32 co] are
+// unpadded, so each wave-level global_load_lds_dwordx4 moves 8 whole pixels (1 KiB) straight from HBM/L2 into LDS with
+// per-lane source addresses (padding / out-of-image lanes read a zero page).  No staging registers and no ds_write pass:
+// the kernel fits two workgroups per CU, which cover each other's DMA latency and address arithmetic.
+template <class C>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using H = Halo<C::CST, C::STRP, C::HXP, C::HYP>;
+    static_assert(C::CST == 32 && C::STRP == 32, "DMA path needs the unpadded [pixel][32] tile");
+    constexpr int A_DMA_FLOATS = H::NA * H::PPI * 32;   // every lane of every instruction lands somewhere
+    constexpr int ND = (C::TP * 8) / 256;
+    float* As = smem;
+    float* Ds = smem + A_DMA_FLOATS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+
+    const int q = blockIdx.y;
+    const int co0 = blockIdx.z * 32;
+    const bool first = q < a.nchunk1;
+    const float* src = first ? a.in1 : a.in2;
+    const int csrc = first ? a.c1 : a.c2;
+    const int cb = (first ? q : q - a.nchunk1) * 32;
+    const int hs = first ? a.h1 : a.h_in;
+    const int ws = first ? a.w1 : a.w_in;
+    const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
+    const int cch = cb + (tid & 7) * 4;
+    const bool cok = cch < csrc;
+    const int dc = co0 + (tid & 7) * 4;
+    const bool dok = dc < a.c_out;
+
+    f32x16 acc[C::T];
+#pragma unroll
+    for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tap][r] = 0.f;
+
+    H halo;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % a.tiles_x;
+        t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        const int img = t / a.tiles_y;
+        const int oy0 = ty * C::TH;
+        const int ox0 = tx * C::PX;
+        halo.setup(hs, ws, gmode, img, oy0 * a.stride - a.pad, ox0 * a.stride - a.pad_x, a.gstep, a.h_in, a.w_in, a.sy, a.sx, tid,
+                   a.ioy, a.iox, a.vt, a.hp, a.inv_hp, a.nimg);
+        __syncthreads();   // the previous tile's MFMAs are done with LDS
+#pragma unroll
+        for (int i = 0; i < H::NA; ++i) {
+            const float* g = (cok && halo.pix[i] >= 0) ? src + (size_t)halo.pix[i] * csrc + cch : rcf_zero_page;
+            float* dst = As + (i * H::PPI + wave * 8) * 32;   // wave-uniform; lane l lands 16*l bytes further
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int p = (tid >> 3) + i * 32;
+            int oy = oy0 + p / C::PX;
+            const int ox = ox0 + p % C::PX;
+            int im = img;
+            if (a.vt) {
+                im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                oy -= im * a.hp;
+                if (im >= a.nimg) oy = a.h_out;
+            }
+            const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+            const bool ok = dok && oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
+            const float* g = ok ? a.dz + (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out + dc : rcf_zero_page;
+            float* dst = Ds + (i * 32 + wave * 8) * 32;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+        rcf_wait_dma();
+        __syncthreads();
+
+        {
+            constexpr int NIT = C::RS * (C::PX / 2);
+            float av[2][C::T], bv[2];
+            auto fetch = [&](int it, int slot) {
+                const int trow = (tid >> 6) * C::RS + it / (C::PX / 2);
+                const int pc = 2 * (it % (C::PX / 2)) + lh;
+                bv[slot] = Ds[(trow * C::PX + pc) * 32 + li];
+                const int hb = (trow * C::LSTEP * C::HXP + pc * C::LSTEP) * C::STRP + li;
+#pragma unroll
+                for (int tap = 0; tap < C::T; ++tap)
+                    av[slot][tap] = As[hb + ((tap / C::KSX) * C::HXP + (tap % C::KSX)) * C::STRP];
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int cur = it & 1;
+                if (it + 1 < NIT) fetch(it + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tap = 0; tap < C::T; ++tap)
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][tap], bv[cur], acc[tap], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // sum the 4 waves' accumulators through LDS (wave 3 -> 2 -> 1 -> 0 chain keeps it deterministic)
+    float* red = smem;
+    const int wv = tid >> 6;
+    for (int s = 3; s >= 1; --s) {
+        __syncthreads();
+        if (wv == s) {
+#pragma unroll
+            for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(tap * 16 + r) * 64 + lane] = acc[tap][r];
+        }
+        __syncthreads();
+        if (wv == s - 1) {
+#pragma unroll
+            for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tap][r] += red[(tap * 16 + r) * 64 + lane];
+        }
+    }
+    if (wv == 0) {
+        float* wsp = a.ws + (size_t)blockIdx.x * a.ktot * a.cop;
+#pragma unroll
+        for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = (q * C::T + tap) * 32 + rcf_mfma_row(r, lh);
+                wsp[(size_t)k * a.cop + co0 + li] = acc[tap][r];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient on the bf16 matrix pipe (3x3 stride 1; same exact 3-way split and six partial products as conv_split_kernel).
+// The reduction index of dW[ci][tap][co] = sum_pixels x[p + tap][ci] * dz[p][co] is the PIXEL, and v_mfma_f32_32x32x16_bf16 wants
+// 8 consecutive reduction elements per lane: both operands are therefore staged CHANNEL-MAJOR in LDS, [plane][channel][row][x]
+// bf16, so that 8 consecutive pixels of one channel are one ds_read_b128.  A tile is 16 x 8 output pixels; one MFMA step is one
+// tile row (lane half h takes pixels 8h..8h+7).  The kx = 1 operand is built from the aligned 16 B + the next 4 B with
+// v_alignbit; kx = 2 is the same five dwords offset by one register.
+// One workgroup per CU (4 waves, one per SIMD, up to 512 VGPRs): wave (wi, wj, wk) owns the 32 ci x 32 co x 9 tap accumulators
+// (144 VGPRs) of ci-block wi and co-block wj and reduces the tile rows wk, wk + KSPLIT, ...  The next step's 21 LDS reads and this
+// step's 36 v_alignbit are issued one at a time between the 54 MFMAs of a step (hand order, pinned with sched_barrier).
+// LDS rows are permuted (row = (ch % 4) * (N / 4) + ch / 4) so that the transposing ds_write_b128 of adjacent lanes (adjacent
+// channel quads) land on adjacent rows: with a row pitch of 16 B mod 128 B both the writes and the reads are conflict-free.
+constexpr int ws_pitch(int bytes) { return ((bytes - 16 + 127) / 128) * 128 + 16; }   // >= bytes and == 16 (mod 128)
+
+template <int WCI_, int WCO_, int KS_ = 3, int TH_ = 8, int NPL_ = 3>
+struct WsCfg {
+    static constexpr int KS = KS_, T = KS_ * KS_;
+    static constexpr int NPL = NPL_, NP = NPL_ == 3 ? 6 : 1;   // operand planes / partial products (1: bf16 operands, RCF_PREC_BF16)
+    static constexpr int WCI = WCI_, WCO = WCO_, KSPLIT = 4 / (WCI_ * WCO_);
+    static constexpr int NCI = 32 * WCI_, NCO = 32 * WCO_;
+    static constexpr int PX = 16, TH = TH_, HXP = PX + KS - 1, HYP = TH + KS - 1;
+    static constexpr int XROW = 48, DROW = 32;     // bytes per tile row of one channel: 24 px (18 used) / 16 px
+    static constexpr int SX = ws_pitch(HYP * XROW), SD = ws_pitch(TH * DROW);   // bytes per channel and plane
+    static constexpr int XPL = NCI * SX, DPL = NCO * SD;
+    static constexpr int X_BYTES = NPL * XPL, D_BYTES = NPL * DPL;
+    static constexpr int RED_BYTES = (KSPLIT > 1) ? WCI * WCO * T * 16 * 64 * 4 : 0;
+    static constexpr int COEF_BYTES = 2 * NCI * 4;   // BN-on-load table of this workgroup's input channels: scale, shift
+    static constexpr int LDS_BYTES = ((X_BYTES + D_BYTES) > RED_BYTES ? (X_BYTES + D_BYTES) : RED_BYTES) + COEF_BYTES;
+    static constexpr int CQX = 8 * WCI, CQD = 8 * WCO;
+    static constexpr int NXU = HYP * 3 * CQX, NDU = TH * 2 * CQD;     // 8-pixel x 4-channel staging units
+    static constexpr int RX = (NXU + 255) / 256, RD = (NDU + 255) / 256;
+    static constexpr int NS = TH / KSPLIT;         // MFMA steps (tile rows) per wave and tile
+    static_assert(HYP * XROW <= SX && TH * DROW <= SD && LDS_BYTES <= 160 * 1024, "tile rows must fit the channel pitch / LDS");
+};
+
+template <class C, class SX = SAct, class SD = SAct>
+__global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
+    static_assert(!SX::B16 || C::NPL == 1, "bf16 tensors go with bf16 operands");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* Xs = smem_b;
+    unsigned char* Ds = smem_b + C::X_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int wi = wave % C::WCI, wj = (wave / C::WCI) % C::WCO, wk = wave / (C::WCI * C::WCO);
+
+    const int Q = blockIdx.y;
+    const bool first = Q < a.nchunk1;
+    const float* src = first ? a.in1 : a.in2;
+    const int csrc = first ? a.c1 : a.c2;
+    const int cb = (first ? Q : Q - a.nchunk1) * C::NCI;   // first channel of this chunk inside its source
+    const int hs = first ? a.h1 : a.h_in;
+    const int ws = first ? a.w1 : a.w_in;
+    const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
+    const int co0 = blockIdx.z * C::NCO;
+
+    f32x16 acc[C::T];
+#pragma unroll
+    for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tap][r] = 0.f;
+
+    // ---- staging: fp32 [pixel][channel] in HBM -> registers (next tile, during this tile's MFMAs) -> bf16 planes in LDS
+    // BN-on-load (x is a raw conv output, y = lrelu(z * scale + shift) applied while staging): coefficient table in LDS
+    const float* cfx = first ? a.coef1 : a.coef2;
+    float* coef_lds = reinterpret_cast<float*>(smem_b + C::LDS_BYTES - C::COEF_BYTES);
+    if (cfx != nullptr) {
+        for (int i = tid; i < C::NCI; i += 256) {
+            const bool okc = cb + i < csrc;
+            coef_lds[i] = okc ? cfx[cb + i] : 1.f;
+            coef_lds[C::NCI + i] = okc ? cfx[csrc + cb + i] : 0.f;
+        }
+    }
+    unsigned mx[C::RX];   // BN-on-load only: bit j = pixel j of the unit is real data (padding must stay 0 after the transform)
+    f32x4 rx[C::RX][8], rd[C::RD][8];
+    // loads are branch-free: padding / out-of-image / out-of-range-channel elements read a zero page (rcf_zero_page), so the values need
+    // no masking afterwards
+    // FAST (compile-time): plain layers -- source read as is, one image per tile, unit output stride -- address their pixels with an
+    // add and a compare each; the general path (nearest-upsample gather, virtual tall image, strided phase outputs) costs ~3x the
+    // VALU instructions per load, and a VALU wave-instruction costs about a fifth of an MFMA in energy (these kernels are power-limited)
+    auto load_tile_impl = [&](int tile, auto fast_tag) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        int t = tile;
+        const int tx = t % a.tiles_x;
+        t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        const int img = t / a.tiles_y;
+        const int oy0 = ty * C::TH, ox0 = tx * C::PX;
+        const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad_x;
+#pragma unroll
+        for (int i = 0; i < C::RX; ++i) {
+            const int u = tid + 256 * i;
+            const int cq = u % C::CQX, g = (u / C::CQX) % 3, hy = u / (3 * C::CQX);
+            const int ch = cb + cq * 4;
+            const int ly = iy0 + hy;
+            bool rowok = u < C::NXU && ch < csrc;
+            int rowbase;
+            if (!FAST && a.vt) {
+                const int im = (int)(((float)ly + 0.5f) * a.inv_hp);
+                const int y = ly - im * a.hp;
+                rowok = rowok && ly >= 0 && im < a.nimg && y < a.h_in;
+                rowbase = (im * hs + y) * ws;
+            } else {
+                rowok = rowok && (unsigned)ly < (unsigned)a.h_in;
+                const int py = (!FAST && gmode == RCF_GATHER_NEAREST) ? min((int)floorf((float)ly * a.sy), hs - 1) : ly;
+                rowbase = (img * hs + py) * ws;
+            }
+            const float* rowptr = rcf_at<SX>(src, (size_t)(rowok ? rowbase : 0) * csrc + (rowok ? ch : 0));
+            unsigned m = 0u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int hx = 8 * g + j;
+                const int lx = ix0 + hx;
+                const bool ok = rowok && hx < C::HXP && (unsigned)lx < (unsigned)a.w_in;
+                const int px = (!FAST && gmode == RCF_GATHER_NEAREST) ? min((int)floorf((float)lx * a.sx), ws - 1) : lx;
+                rx[i][j] = rcf_ld4<SX>(ok ? rcf_at<SX>(rowptr, px * csrc) : rcf_zero_page, 0);
+                if (cfx != nullptr) m |= ok ? (1u << j) : 0u;
+            }
+            mx[i] = m;
+        }
+#pragma unroll
+        for (int i = 0; i < C::RD; ++i) {
+            const int u = tid + 256 * i;
+            const int cq = u % C::CQD, g = (u / C::CQD) % 2, r = u / (2 * C::CQD);
+            const int dc = co0 + cq * 4;
+            int oy = oy0 + r;
+            int im = img;
+            if (!FAST && a.vt) {
+                im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                oy -= im * a.hp;
+                if (im >= a.nimg) oy = a.h_out;
+            }
+            const int py = FAST ? oy : oy * a.os + a.ooy;   // strided output rows/columns of the phase convolutions
+            const bool rowok = u < C::NDU && dc < a.c_out && oy < a.h_out && py < a.ohp;
+            const float* rowptr = rcf_at<SD>(a.dz, (size_t)(rowok ? (im * a.ohp + py) * a.owp : 0) * a.c_out + (rowok ? dc : 0));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ox = ox0 + 8 * g + j;
+                const int px = FAST ? ox : ox * a.os + a.oox;
+                rd[i][j] = rcf_ld4<SD>((rowok && ox < a.w_out && px < a.owp) ? rcf_at<SD>(rowptr, px * a.c_out) : rcf_zero_page, 0);
+            }
+        }
+    };
+    const bool plain_tile = gmode == RCF_GATHER_DIRECT && !a.vt && a.os == 1 && a.ooy == 0 && a.oox == 0;
+    auto load_tile = [&](int tile) __attribute__((always_inline)) {
+        if (plain_tile) load_tile_impl(tile, std::true_type{});
+        else load_tile_impl(tile, std::false_type{});
+    };
+    // 8 pixels of one channel -> three 16-B bf16 vectors (exact truncation split), written to the channel's LDS row
+    auto split8 = [&](const f32x4 (&v)[8], int e, unsigned char* dst, int plane_bytes) {
+        u32x4 w0, w1, w2;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            unsigned x0[2], x1[2], x2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float x = v[2 * d + h][e];
+                x0[h] = __float_as_uint(x) & 0xffff0000u;
+                const float r1 = x - __uint_as_float(x0[h]);
+                x1[h] = __float_as_uint(r1) & 0xffff0000u;
+                const float r2 = r1 - __uint_as_float(x1[h]);
+                x2[h] = __float_as_uint(r2);
+            }
+            if (C::NPL == 1) {   // bf16 operands: round to nearest even instead of splitting
+                w0[d] = __builtin_amdgcn_perm(rcf_bf16_rne(v[2 * d + 1][e]), rcf_bf16_rne(v[2 * d][e]), 0x07060302u);
+            } else {
+                w0[d] = __builtin_amdgcn_perm(x0[1], x0[0], 0x07060302u);   // high halves of the pixel pair
+                w1[d] = __builtin_amdgcn_perm(x1[1], x1[0], 0x07060302u);
+                w2[d] = __builtin_amdgcn_perm(x2[1], x2[0], 0x07060302u);
+            }
+        }
+        *reinterpret_cast<u32x4*>(dst) = w0;
+        if (C::NPL == 3) {
+            *reinterpret_cast<u32x4*>(dst + plane_bytes) = w1;
+            *reinterpret_cast<u32x4*>(dst + 2 * plane_bytes) = w2;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < C::RX; ++i) {
+            const int u = tid + 256 * i;
+            if (C::NXU % 256 == 0 || u < C::NXU) {
+                const int cq = u % C::CQX, g = (u / C::CQX) % 3, hy = u / (3 * C::CQX);
+                if (cfx != nullptr) {   // the producer's BatchNorm + LeakyReLU on the 8 x 4 values; padding stays zero
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(coef_lds + cq * 4);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(coef_lds + C::NCI + cq * 4);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            rx[i][j][e] = ((mx[i] >> j) & 1u) ? rcf_lrelu(rx[i][j][e] * sc[e] + sh[e]) : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    split8(rx[i], e, Xs + (e * C::CQX + cq) * C::SX + hy * C::XROW + g * 16, C::XPL);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::RD; ++i) {
+            const int u = tid + 256 * i;
+            if (C::NDU % 256 == 0 || u < C::NDU) {
+                const int cq = u % C::CQD, g = (u / C::CQD) % 2, r = u / (2 * C::CQD);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    split8(rd[i], e, Ds + (e * C::CQD + cq) * C::SD + r * C::DROW + g * 16, C::DPL);
+            }
+        }
+    };
+
+    // ---- MFMA operands of one step: raw x rows (3 planes x 3 kernel rows x 5 dwords) and dz (3 planes x 4 dwords)
+    const unsigned char* xb = Xs + (wi * 32 + li) * C::SX + lh * 16 + wk * C::XROW;
+    const unsigned char* db = Ds + (wj * 32 + li) * C::SD + lh * 16 + wk * C::DROW;
+    // x rows live in a ring of register slots: with KSPLIT == 1 consecutive steps share two of their three halo rows, so only
+    // ONE new row is read per step (4 slots); otherwise two sets of three rows.  (256 architectural VGPRs hold the staging
+    // registers, the operands and the addresses; the 144 accumulators live in AGPRs.)
+    constexpr int KS = C::KS;
+    constexpr int ROLL = C::KSPLIT == 1;
+    constexpr int NSLOT = ROLL ? KS + 1 : 2 * KS;
+    constexpr int NEWROWS = ROLL ? 1 : KS;          // halo rows fetched per step
+    constexpr int NPL = C::NPL, NP = C::NP;
+    constexpr int NRD = NEWROWS * 2 * NPL + NPL;    // LDS reads per step: (b128 + b32) x planes per row, + planes of dz
+    constexpr int NMF = NP * C::T;                  // MFMAs per step
+    u32x4 xlo[NSLOT][NPL];     // [row slot][plane]  pixels 8h .. 8h+7
+    unsigned xhi[NSLOT][NPL];  //                    pixels 8h+8, 8h+9
+    u32x4 dzv[2][NPL];         // [set][plane]
+    u32x4 xs1[KS][NPL];        // kx = 1 operands of the current step
+
+    int tile = blockIdx.x;
+    if (tile < a.ntiles) load_tile(tile);
+    while (tile < a.ntiles) {
+        __syncthreads();   // the previous tile's MFMAs are done with LDS
+        store_tile();
+        __syncthreads();
+        const int ntile = tile + gridDim.x;
+        if (ntile < a.ntiles) load_tile(ntile);
+
+        // prologue of the tile: operands of this wave's first row
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                xlo[ky][pl] = *reinterpret_cast<const u32x4*>(xb + pl * C::XPL + ky * C::XROW);
+                xhi[ky][pl] = *reinterpret_cast<const unsigned*>(xb + pl * C::XPL + ky * C::XROW + 16);
+            }
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) dzv[0][pl] = *reinterpret_cast<const u32x4*>(db + pl * C::DPL);
+        __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            const bool has_next = s + 1 < C::NS;
+            const int rn = (s + 1) * C::KSPLIT;   // next row of this wave (relative to wk)
+#pragma unroll
+            for (int j = 0; j < NMF; ++j) {
+                // order: all kx = 0 taps, (kx = 2,) then kx = 1, whose operands are being built meanwhile; inside a group the six
+                // partial products run smallest first and the kernel rows alternate
+                constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+                constexpr int KXO[3] = {0, KS == 3 ? 2 : 1, 1};
+                const int kx = KXO[j / (NP * KS)], pj = (j % (NP * KS)) / KS, ky = j % KS;
+                const int tap = ky * KS + kx;
+                const int sl = ROLL ? (s + ky) % (KS + 1) : cur * KS + ky;
+                const int pa = NPL == 3 ? PA[pj] : 0, pbl = NPL == 3 ? PB[pj] : 0;
+                u32x4 av;
+                if (kx == 0) av = xlo[sl][pa];
+                else if (kx == 1) av = xs1[ky][pa];
+                else {
+                    const u32x4 lo = xlo[sl][pa];
+                    av[0] = lo[1]; av[1] = lo[2]; av[2] = lo[3]; av[3] = xhi[sl][pa];
+                }
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av), as_bf16x8(dzv[cur][pbl]), acc[tap], 0, 0, 0);
+                // one kx = 1 operand (4 v_alignbit) behind each of the first NPL * KS even (three planes) / consecutive (one plane)
+                // MFMAs: all of them before the kx = 1 group starts
+                constexpr int SHS = NPL == 3 ? 2 : 1;
+                if (j < SHS * NPL * KS && j % SHS == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int sky = (j / SHS) / NPL, spl = (j / SHS) % NPL;
+                    const int ssl = ROLL ? (s + sky) % (KS + 1) : cur * KS + sky;
+                    const u32x4 lo = xlo[ssl][spl];
+                    const unsigned hi = xhi[ssl][spl];
+                    xs1[sky][spl][0] = __builtin_amdgcn_alignbit(lo[1], lo[0], 16);
+                    xs1[sky][spl][1] = __builtin_amdgcn_alignbit(lo[2], lo[1], 16);
+                    xs1[sky][spl][2] = __builtin_amdgcn_alignbit(lo[3], lo[2], 16);
+                    xs1[sky][spl][3] = __builtin_amdgcn_alignbit(hi, lo[3], 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // the next step's LDS reads, one at a time, spread evenly over the step.  Ring (KSPLIT == 1): only the new halo
+                // row, into the slot that held row s - 1 and is free during the whole step; otherwise KS rows into the other set.
+                const int n0 = (j * NRD) / NMF, n1 = ((j + 1) * NRD) / NMF;
+#pragma unroll
+                for (int nr = n0; nr < n1; ++nr) {
+                    if (!has_next) break;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (nr < NEWROWS * 2 * NPL) {
+                        const int rrow = (nr / 2) / NPL, rpl = (nr / 2) % NPL;
+                        const int rky = ROLL ? KS - 1 : rrow;
+                        const int nsl = ROLL ? (s + KS) % (KS + 1) : nxt * KS + rrow;
+                        const unsigned char* g = xb + rpl * C::XPL + (rn + rky) * C::XROW;
+                        if ((nr & 1) == 0) xlo[nsl][rpl] = *reinterpret_cast<const u32x4*>(g);
+                        else xhi[nsl][rpl] = *reinterpret_cast<const unsigned*>(g + 16);
+                    } else {
+                        const int rpl = nr - NEWROWS * 2 * NPL;
+                        dzv[nxt][rpl] = *reinterpret_cast<const u32x4*>(db + rpl * C::DPL + rn * C::DROW);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tile = ntile;
+    }
+
+    // ---- sum the KSPLIT row slices of each (wi, wj) block through LDS (fixed order), then one partial per workgroup
+    if (C::KSPLIT > 1) {
+        float* red = reinterpret_cast<float*>(smem_b) + (wi + C::WCI * wj) * (C::T * 16 * 64);
+        for (int s = C::KSPLIT - 1; s >= 1; --s) {
+            __syncthreads();
+            if (wk == s) {
+#pragma unroll
+                for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(tap * 16 + r) * 64 + lane] = acc[tap][r];
+            }
+            __syncthreads();
+            if (wk == s - 1) {
+#pragma unroll
+                for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tap][r] += red[(tap * 16 + r) * 64 + lane];
+            }
+        }
+    }
+    if (wk == 0) {
+        float* wsp = a.ws + (size_t)blockIdx.x * a.ktot * a.cop;
+        const int q32_0 = first ? 0 : (a.c1 + 31) / 32;   // 32-channel chunk index of this source's first chunk in k
+        const int rdz = wj * 32 + li;
+        const int co = co0 + (rdz % C::CQD) * 4 + rdz / C::CQD;
+#pragma unroll
+        for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rxr = wi * 32 + rcf_mfma_row(r, lh);
+                const int ch = cb + (rxr % C::CQX) * 4 + rxr / C::CQX;   // channel inside its source
+                if ((ch & ~31) < csrc && co < a.cop) {
+                    const int k = ((q32_0 + (ch >> 5)) * C::T + tap) * 32 + (ch & 31);
+                    wsp[(size_t)k * a.cop + co] = acc[tap][r];
+                }
+            }
+    }
+}
+
+// workspace [nslot][ktot][cop] -> dW in OIHW.  One thread per (k, co), co fastest (coalesced reads).
+// kind: 0 generic (k = (q*T+tap)*32 + channel-in-chunk), 1 stem (k = tap(ky)*32 + kx*4 + c).
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslot, int ktot,
+                                                           int cop, int c_out, int c1, int c2, int nchunk1, int T, int ksx, int kind) {
+    __shared__ double sm[4][64];
+    const int lane_o = threadIdx.x & 63;     // 64 consecutive (k, co) outputs per block: coalesced 256-B reads per slot
+    const int lane_s = threadIdx.x >> 6;     // 4 slot lanes
+    const int idx = blockIdx.x * 64 + lane_o;
+    const bool live = idx < ktot * cop;
+    double s = 0.0;   // the per-workgroup partials cancel heavily for BN-followed convs: sum them in fp64
+    if (live) {
+        const size_t stride = (size_t)ktot * cop;
+        for (int sl = lane_s; sl < nslot; sl += 4) s += (double)ws[sl * stride + idx];
+    }
+    sm[lane_s][lane_o] = s;
+    __syncthreads();
+    if (lane_s != 0 || !live) return;
+    s = sm[0][lane_o] + sm[1][lane_o] + sm[2][lane_o] + sm[3][lane_o];
+    const int co = idx % cop;
+    const int k = idx / cop;
+    if (co >= c_out) return;
+    const int row = k & 31;
+    const int qt = k >> 5;
+    const int tap = qt % T;
+    const int q = qt / T;
+    int ci, ky, kx;
+    const int ksy_total = (kind == 1) ? T : T / ksx;
+    if (kind == 1) {
+        kx = row >> 2;
+        ci = row & 3;
+        ky = tap;
+        if (kx >= 7 || ci >= c1) return;
+    } else {
+        ky = tap / ksx;
+        kx = tap % ksx;
+        if (q < nchunk1) {
+            ci = q * 32 + row;
+            if (ci >= c1) return;
+        } else {
+            ci = (q - nchunk1) * 32 + row;
+            if (ci >= c2) return;
+            ci += c1;
+        }
+    }
+    const int kw = (kind == 1) ? 7 : ksx;
+    dw[(((size_t)co * (c1 + c2) + ci) * ksy_total + ky) * kw + kx] = (float)s;
+}
+
+// OIHW -> [n-tile][chunk][tap][BN][CK].  kind 0 generic, 1 stem (k = kx*4 + c, tap = ky).
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ dst, size_t total, int w_o, int w_i,
+                                    int ks, int mode, int i_off, int c_out, int c1, int c2, int nchunk1, int nchunk,
+                                    int T, int ksx, int BN, int CK, int kind) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    size_t t = idx;
+    const int k = t % CK;
+    t /= CK;
+    const int j = t % BN;
+    t /= BN;
+    const int tap = t % T;
+    t /= T;
+    const int q = t % nchunk;
+    const int nt = t / nchunk;
+    const int co = nt * BN + j;
+    float v = 0.f;
+    int cin = -1, ky, kx;
+    if (kind == 1) {
+        kx = k >> 2;
+        const int c = k & 3;
+        ky = tap;
+        if (kx < 7 && c < c1) cin = c;
+    } else {
+        ky = tap / ksx;
+        kx = tap % ksx;
+        if (q < nchunk1) {
+            const int c = q * CK + k;
+            if (c < c1) cin = c;
+        } else {
+            const int c = (q - nchunk1) * CK + k;
+            if (c < c2) cin = c1 + c;
+        }
+    }
+    if (cin >= 0 && co < c_out) {
+        if (mode == RCF_W_FORWARD) {
+            v = w[(((size_t)co * w_i + cin) * ks + ky) * ks + kx];
+        } else {   // dgrad: this conv's input channel cin is the forward output channel; taps flipped
+            v = w[(((size_t)cin * w_i + (i_off + co)) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
+        }
+    }
+    dst[idx] = v;
+}
+
+// Phase weights (see include/rcf_hip.h).  Up-2x: output row 2y+a reads source rows {y-1,y} (a=0) / {y,y+1} (a=1); 3x3 tap ky
+// lands on source tap t: a=0 -> (0,1,1), a=1 -> (0,0,1).  Stride-2 dgrad: input row 2y+a receives dZ rows y (tap 0) and y+1
+// (tap 1): a=0 -> ky (1, none), a=1 -> ky (2, 0).
+__device__ __forceinline__ int up2x_tap(int a, int k) { return a == 0 ? (k == 0 ? 0 : 1) : (k == 2 ? 1 : 0); }
+__device__ __forceinline__ int s2_tap_k(int a, int t) { return a == 0 ? (t == 0 ? 1 : -1) : (t == 0 ? 2 : 0); }
+
+__global__ void phase_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I, int mode) {
+    const int total = 4 * O * I * 4;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int t = idx;
+    const int u = t & 1; t >>= 1;
+    const int tt = t & 1; t >>= 1;
+    const int OP = (mode == RCF_PHASE_UP2X_FWD) ? O : I;   // out channels of the phase conv
+    const int IP = (mode == RCF_PHASE_UP2X_FWD) ? I : O;
+    const int ip = t % IP; t /= IP;
+    const int op = t % OP; t /= OP;
+    const int b = t & 1, a = t >> 1;
+    float v = 0.f;
+    if (mode == RCF_PHASE_UP2X_FWD) {
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx)
+                if (up2x_tap(a, ky) == tt && up2x_tap(b, kx) == u) v += w[((op * I + ip) * 3 + ky) * 3 + kx];
+    } else if (mode == RCF_PHASE_UP2X_DGRAD) {   // Wd[n=i][c=o][t'][u'] = Wp[o][i][1-t'][1-u']
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx)
+                if (up2x_tap(a, ky) == 1 - tt && up2x_tap(b, kx) == 1 - u) v += w[((ip * I + op) * 3 + ky) * 3 + kx];
+    } else {   // RCF_PHASE_S2_DGRAD: Wd[n=i][c=o][t][u] = W[o][i][ky(a,t)][kx(b,u)]
+        const int ky = s2_tap_k(a, tt), kx = s2_tap_k(b, u);
+        if (ky >= 0 && kx >= 0) v = w[((ip * I + op) * 3 + ky) * 3 + kx];
+    }
+    out[idx] = v;
+}
+
+__global__ void phase_wgrad_fold_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int O, int I) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= O * I * 9) return;
+    const int kx = idx % 3, ky = (idx / 3) % 3;
+    const int oi = idx / 9;
+    float v = 0.f;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+            v += dwp[(((size_t)(a * 2 + b) * O * I + oi) * 2 + up2x_tap(a, ky)) * 2 + up2x_tap(b, kx)];
+    dw[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// configuration tables
+enum Kind { K3S1 = 0, K3S2 = 1, K1 = 2, K7S2 = 3, K2S1 = 4 };
+
+struct Sel {
+    int kind, ck, nt, px;
+    int th, bn, t, cst;
+    int vt;   // virtual tall image tiling
+    int split;   // fp32 on the bf16 matrix pipe (conv_split_kernel)
+    int small;   // split 3x3 layer too small to fill the chip with 64-co workgroups: 256-pixel x 32-co workgroups instead
+    int bf16;    // rcf_conv_desc.precision == RCF_PREC_BF16 and a split kernel: one bf16 plane, one product
+};
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// Persistent grid: one resident wave of workgroups (occupancy API), split between the n-tiles.  Also the number of
+// BN-statistics partial rows the kernel writes, so rcf_conv2d_query reports the same number.
+template <class C>
+int fwd_grid_x(int ntiles, int ntile_n) {
+    static int resident = 0;   // workgroups that fit on the device at once
+    if (resident == 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C::LDS_BYTES);
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_fwd_kernel<C>, 256, C::LDS_BYTES) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        resident = per_cu * num_cus();
+    }
+    int gx = resident / ntile_n;
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    return gx;
+}
+
+template <class C>
+int launch_fwd(const ConvArgs& a, int ntile_n, hipStream_t st) {
+    const int gx = fwd_grid_x<C>(a.ntiles, ntile_n);
+    dim3 grid(gx, ntile_n, 1);
+    hipLaunchKernelGGL((conv_fwd_kernel<C>), grid, dim3(256), C::LDS_BYTES, st, a);
+    return rcf_launch_status();
+}
+
+template <class C>
+int split_grid_x(int ntiles, int ntile_n) {
+    static int resident = 0;
+    if (resident == 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C::LDS_BYTES);
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_split_kernel<C>, 256, C::LDS_BYTES) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        resident = per_cu * num_cus();
+    }
+    int gx = resident / ntile_n;
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    return gx;
+}
+
+template <class C, bool EPI = false>
+int launch_split(const ConvArgs& a, int ntile_n, hipStream_t st) {
+    const int gx = split_grid_x<C>(a.ntiles, ntile_n);
+    if (EPI) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      C::LDS_BYTES);
+            attr_done = true;
+        }
+    }
+    hipLaunchKernelGGL((conv_split_kernel<C, EPI>), dim3(gx, ntile_n, 1), dim3(256), C::LDS_BYTES, st, a);
+    return rcf_launch_status();
+}
+
+template <class C>
+int launch_wgrad(const ConvArgs& a, int nsplit, int nchunk, int ncog, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C::LDS_BYTES);
+        attr_done = true;
+    }
+    dim3 grid(nsplit, nchunk, ncog);
+    hipLaunchKernelGGL((conv_wgrad_kernel<C>), grid, dim3(256), C::LDS_BYTES, st, a);
+    return rcf_launch_status();
+}
+
+template <class C>
+int launch_wgrad_split(const ConvArgs& a, int nsplit, int gy, int gz, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C::LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_split_kernel<C>), dim3(nsplit, gy, gz), dim3(256), C::LDS_BYTES, st, a);
+    return rcf_launch_status();
+}
+
+#if RCF_CONV_B16
+#define RCF_DMA(expr) RCF_EUNSUPPORTED   /* LDS-DMA copies fp32 tiles verbatim: fp32 tensors only */
+#else
+#define RCF_DMA(expr) (expr)
+#endif
+template <class C>
+int launch_wgrad_dma(const ConvArgs& a, int nsplit, int nchunk, int ncog, hipStream_t st) {
+    using H = Halo<C::CST, C::STRP, C::HXP, C::HYP>;
+    constexpr int red_floats = C::T * 16 * 64;
+    constexpr int tile_floats = H::NA * H::PPI * 32 + C::TP * 32;
+    constexpr int lds_bytes = (tile_floats > red_floats ? tile_floats : red_floats) * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  lds_bytes);
+        attr_done = true;
+    }
+    dim3 grid(nsplit, nchunk, ncog);
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<C>), grid, dim3(256), lds_bytes, st, a);
+    return rcf_launch_status();
+}
+
+//                 KSY KSX XE LS  CK CST STRP NT PX MINW
+using F3S1_16_1_32 = FwdCfg<3, 3, 0, 1, 16, 16, 20, 1, 32, 2>;
+using F3S1_16_2_32 = FwdCfg<3, 3, 0, 1, 16, 16, 20, 2, 32, 2>;
+using F3S1_16_1_16 = FwdCfg<3, 3, 0, 1, 16, 16, 20, 1, 16, 2>;
+using F3S1_16_2_16 = FwdCfg<3, 3, 0, 1, 16, 16, 20, 2, 16, 2>;
+using F3S1_16_1_8 = FwdCfg<3, 3, 0, 1, 16, 16, 20, 1, 8, 2>;
+using F3S1_16_2_8 = FwdCfg<3, 3, 0, 1, 16, 16, 20, 2, 8, 2>;
+using F3S1_8_1_32 = FwdCfg<3, 3, 0, 1, 8, 8, 12, 1, 32, 2>;
+using F3S1_8_2_32 = FwdCfg<3, 3, 0, 1, 8, 8, 12, 2, 32, 2>;
+using F3S1_8_1_16 = FwdCfg<3, 3, 0, 1, 8, 8, 12, 1, 16, 2>;
+using F3S1_8_2_16 = FwdCfg<3, 3, 0, 1, 8, 8, 12, 2, 16, 2>;
+using F3S2_8_1_32 = FwdCfg<3, 3, 0, 2, 8, 8, 12, 1, 32, 1>;
+using F3S2_8_2_32 = FwdCfg<3, 3, 0, 2, 8, 8, 12, 2, 32, 1>;
+using F3S2_8_1_16 = FwdCfg<3, 3, 0, 2, 8, 8, 12, 1, 16, 1>;
+using F3S2_8_2_16 = FwdCfg<3, 3, 0, 2, 8, 8, 12, 2, 16, 1>;
+using F1_32_1_32 = FwdCfg<1, 1, 0, 1, 32, 32, 36, 1, 32, 2>;
+using F1_32_2_32 = FwdCfg<1, 1, 0, 1, 32, 32, 36, 2, 32, 2>;
+using F1_32_1_16 = FwdCfg<1, 1, 0, 1, 32, 32, 36, 1, 16, 2>;
+using F1_32_2_16 = FwdCfg<1, 1, 0, 1, 32, 32, 36, 2, 16, 2>;
+using F1_16_1_32 = FwdCfg<1, 1, 0, 1, 16, 16, 20, 1, 32, 2>;
+using F1_16_2_32 = FwdCfg<1, 1, 0, 1, 16, 16, 20, 2, 32, 2>;
+using F1_16_1_16 = FwdCfg<1, 1, 0, 1, 16, 16, 20, 1, 16, 2>;
+using F1_16_2_16 = FwdCfg<1, 1, 0, 1, 16, 16, 20, 2, 16, 2>;
+using F2_32_1_32 = FwdCfg<2, 2, 0, 1, 32, 32, 36, 1, 32, 2>;
+using F2_32_2_32 = FwdCfg<2, 2, 0, 1, 32, 32, 36, 2, 32, 2>;
+using F2_32_1_16 = FwdCfg<2, 2, 0, 1, 32, 32, 36, 1, 16, 2>;
+using F2_32_2_16 = FwdCfg<2, 2, 0, 1, 32, 32, 36, 2, 16, 2>;
+using F7_32 = FwdCfg<7, 1, 7, 2, 32, 4, 4, 1, 32, 2>;
+using S3_1_32 = SplitCfg<3, 1, 32>;
+using S3_2_32 = SplitCfg<3, 2, 32>;
+using S3_1_16 = SplitCfg<3, 1, 16>;
+using S3_2_16 = SplitCfg<3, 2, 16>;
+using B3_1_32 = SplitCfg<3, 1, 32, 0, 1>;    // bf16-operand variants (one plane, one product)
+using B3_2_32 = SplitCfg<3, 2, 32, 0, 1>;
+using B3_1_16 = SplitCfg<3, 1, 16, 0, 1>;
+using B3_2_16 = SplitCfg<3, 2, 16, 0, 1>;
+using B2_1_32 = SplitCfg<2, 1, 32, 0, 1>;
+using B2_2_32 = SplitCfg<2, 2, 32, 0, 1>;
+using B2_1_16 = SplitCfg<2, 1, 16, 0, 1>;
+using B2_2_16 = SplitCfg<2, 2, 16, 0, 1>;
+using B3_1_32s = SplitCfg<3, 1, 32, 2, 1>;
+using B3_1_16s = SplitCfg<3, 1, 16, 2, 1>;
+using S3_1_32s = SplitCfg<3, 1, 32, 2>;   // 256-pixel x 32-co workgroups: more of them for the small layers
+using S3_1_16s = SplitCfg<3, 1, 16, 2>;
+using S2_1_32 = SplitCfg<2, 1, 32>;
+using S2_2_32 = SplitCfg<2, 2, 32>;
+using S2_1_16 = SplitCfg<2, 1, 16>;
+using S2_2_16 = SplitCfg<2, 2, 16>;
+using F7_16 = FwdCfg<7, 1, 7, 2, 32, 4, 4, 1, 16, 2>;
+
+//               KSY KSX XE LS CST STRP PX TH MINW
+using W3S1_32 = WgCfg<3, 3, 0, 1, 32, 32, 32, 8, 1>;
+using W3S1_16 = WgCfg<3, 3, 0, 1, 32, 32, 16, 16, 1>;
+using W3S1_8 = WgCfg<3, 3, 0, 1, 32, 32, 8, 32, 1>;
+using W3S2_32 = WgCfg<3, 3, 0, 2, 32, 32, 32, 4, 1>;
+using W3S2_16 = WgCfg<3, 3, 0, 2, 32, 32, 16, 8, 1>;
+using W1_32 = WgCfg<1, 1, 0, 1, 32, 32, 32, 8, 2>;
+using W1_16 = WgCfg<1, 1, 0, 1, 32, 32, 16, 16, 2>;
+using W2_32 = WgCfg<2, 2, 0, 1, 32, 32, 32, 8, 1>;
+using W2_16 = WgCfg<2, 2, 0, 1, 32, 32, 16, 16, 1>;
+using W7_32 = WgCfg<7, 1, 7, 2, 4, 4, 32, 8, 2>;
+using W7_16 = WgCfg<7, 1, 7, 2, 4, 4, 16, 16, 2>;
+
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+template <class T>
+struct Tag { using type = T; };
+
+// tile utilisation of a PX x TH tiling of a w x h image
+double tile_eff(int w, int h, int px, int th) {
+    return ((double)w / (ceil_div(w, px) * px)) * ((double)h / (ceil_div(h, th) * th));
+}
+
+// utilisation when the n images are stacked with one separator row each (rows n*(h+1))
+double tile_eff_vt(int w, int h, int n, int px, int th) {
+    return ((double)w / (ceil_div(w, px) * px)) * ((double)n * h / (ceil_div(n * (h + 1), th) * th));
+}
+
+// The split-bf16 kernels (fp32 arithmetic on the bf16 matrix pipe) are the default wherever they exist;
+// RCF_CONV_SPLIT=0 selects the exact-f32-MFMA kernels instead (both are parity-tested).
+bool split_enabled() {
+    const char* e = getenv("RCF_CONV_SPLIT");
+    return e == nullptr || e[0] != '0';
+}
+
+// stride-1 3x3 conv with pad 1 on directly addressed sources: the separator row is the conv's own zero padding
+bool vt_allowed(const rcf_conv_desc* d) {
+    return d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->pad_x == 1 && d->gather1 == RCF_GATHER_DIRECT &&
+           d->out_stride == 1 && d->h_in == d->h_out && d->n > 1 && getenv("RCF_NO_VT") == nullptr;
+}
+
+bool valid_desc(const rcf_conv_desc* d) {
+    if (!d) return false;
+    if (d->n <= 0 || d->h_in <= 0 || d->w_in <= 0 || d->c1 <= 0 || d->c2 < 0 || d->h_out <= 0 || d->w_out <= 0 ||
+        d->c_out <= 0)
+        return false;
+    if (d->ksize != 1 && d->ksize != 2 && d->ksize != 3 && d->ksize != 7) return false;
+    if (d->stride != 1 && d->stride != 2) return false;
+    if (d->gather1 < 0 || d->gather1 > 3) return false;
+    if (d->precision != RCF_PREC_FP32 && d->precision != RCF_PREC_BF16) return false;
+    if (d->storage != RCF_STORE_FP32 && d->storage != RCF_STORE_BF16) return false;
+    if (d->storage == RCF_STORE_BF16 && d->precision != RCF_PREC_BF16) return false;   // bf16 tensors are consumed as bf16 operands
+    if ((d->storage == RCF_STORE_BF16) != SAct::B16) return false;                    // (each translation unit serves one storage)
+    if (d->out_stride != 1 && d->out_stride != 2) return false;
+    if (d->out_h_phys <= 0 || d->out_w_phys <= 0) return false;
+    if (d->gather1 == RCF_GATHER_DIRECT && (d->h_src1 != d->h_in || d->w_src1 != d->w_in)) return false;
+    if (d->h_src1 <= 0 || d->w_src1 <= 0) return false;
+    if (d->ksize != 2) {   // 2x2 phase convs pad asymmetrically: their output grid is given, not derived
+        if ((d->h_in + 2 * d->pad - d->ksize) / d->stride + 1 != d->h_out) return false;
+        if ((d->w_in + 2 * d->pad_x - d->ksize) / d->stride + 1 != d->w_out) return false;
+    } else if (d->stride != 1 || d->w_mode != RCF_W_FORWARD) {
+        return false;
+    }
+    if (d->phase_sum && (d->ksize != 2 || d->gather1 != RCF_GATHER_STRIDED2 || d->c2 != 0)) return false;
+    if (d->w_mode == RCF_W_FORWARD) {
+        if (d->w_o != d->c_out || d->w_i != d->c1 + d->c2) return false;
+    } else if (d->w_mode == RCF_W_DGRAD) {
+        if (d->w_o != d->c1 || d->c2 != 0 || d->w_i_off < 0 || d->w_i_off + d->c_out > d->w_i) return false;
+    } else {
+        return false;
+    }
+    return true;
+}
+
+int select_cfg(const rcf_conv_desc* d, Sel* s) {
+    if (!valid_desc(d)) return RCF_EINVAL;
+    if (d->c_out % 4 != 0) return RCF_EUNSUPPORTED;   // c_out == 1 is the head kernel's job
+    const int cmax = d->c1 > d->c2 ? d->c1 : d->c2;
+    s->nt = d->c_out > 32 ? 2 : 1;
+    if (d->ksize == 7) {
+        if (d->stride != 2 || d->c2 != 0 || d->c1 > 4 || d->gather1 != RCF_GATHER_DIRECT || d->w_mode != RCF_W_FORWARD)
+            return RCF_EUNSUPPORTED;
+        s->kind = K7S2; s->ck = 32; s->cst = 4; s->nt = 1; s->t = 7;
+    } else if (d->ksize == 2) {
+        s->kind = K2S1; s->t = 4; s->ck = 32; s->cst = 32;
+    } else if (d->ksize == 3) {
+        s->t = 9;
+        if (d->stride == 2) { s->kind = K3S2; s->ck = 8; }
+        else { s->kind = K3S1; s->ck = cmax <= 8 ? 8 : 16; }
+        s->cst = s->ck;
+    } else {
+        s->kind = K1; s->t = 1;
+        s->ck = cmax <= 16 ? 16 : 32;
+        s->cst = s->ck;
+    }
+    if ((d->c1 % 4 != 0 || (d->c2 % 4 != 0)) && s->kind != K7S2) {
+        // scalar staging path handles it, but concat boundaries must stay 4-aligned
+        if (d->c2 != 0) return RCF_EUNSUPPORTED;
+    }
+    // tile shape: 32x8 or 16x16 output pixels (8x32 too for the stride-1 3x3 kernels with >= 16 channels), whichever
+    // wastes least at the image edges; stride-1 3x3 convs may also tile the batch as one tall virtual image
+    s->vt = 0;
+    s->split = 0;
+    s->small = 0;
+    s->bf16 = 0;
+    if (((s->kind == K3S1 && s->ck == 16) || (s->kind == K2S1 && cmax >= 16)) && (d->c1 % 4 == 0) && (d->c2 % 4 == 0) &&
+        split_enabled()) {
+        s->split = 1;
+        s->ck = 16;
+        s->cst = 16;
+        // fewer 256-pixel x 64-co workgroups than CUs: halve the workgroup (BN = 32) to double their number
+        const long long wgs = (((long long)d->n * d->h_out * d->w_out + 255) / 256) * ceil_div(d->c_out, 64);
+        if (s->kind == K3S1 && s->nt == 2 && wgs < num_cus()) { s->small = 1; s->nt = 1; }
+        s->bf16 = d->precision == RCF_PREC_BF16 ? 1 : 0;
+    }
+    double best = -1.0;
+    const bool vt_ok = vt_allowed(d);
+    const int pxs[3] = {32, 16, 8};
+    for (int i = 0; i < 3; ++i) {
+        const int px = pxs[i], th = ((s->split && s->nt == 1 && s->kind == K3S1 && !s->small) ? 512 : 256) / px;
+        if (px == 8 && (s->split || !(s->kind == K3S1 && s->ck == 16))) continue;
+        for (int vt = 0; vt <= (vt_ok ? 1 : 0); ++vt) {
+            const double e = vt ? tile_eff_vt(d->w_out, d->h_out, d->n, px, th) : tile_eff(d->w_out, d->h_out, px, th);
+            if (e > best + 1e-9) { best = e; s->px = px; s->vt = vt; }
+        }
+    }
+    s->th = ((s->split && s->nt == 1 && s->kind == K3S1 && !s->small) ? 512 : 256) / s->px;
+    s->bn = 32 * s->nt;
+    return RCF_OK;
+}
+
+void fill_args(const rcf_conv_desc* d, const Sel& s, ConvArgs* a) {
+    a->coef1 = nullptr; a->coef2 = nullptr; a->bias = nullptr; a->res = nullptr;
+    a->n = d->n; a->h_in = d->h_in; a->w_in = d->w_in; a->c1 = d->c1; a->c2 = d->c2;
+    a->h1 = d->h_src1; a->w1 = d->w_src1; a->gather1 = d->gather1;
+    a->h_out = d->h_out; a->w_out = d->w_out; a->c_out = d->c_out; a->pad = d->pad; a->pad_x = d->pad_x; a->stride = d->stride;
+    a->gstep = d->ksize == 1 ? d->stride : 1;
+    a->accumulate = d->accumulate;
+    a->os = d->out_stride; a->ooy = d->out_off_y; a->oox = d->out_off_x; a->ohp = d->out_h_phys; a->owp = d->out_w_phys;
+    a->ioy = d->in_off_y; a->iox = d->in_off_x;
+    a->phase_sum = d->phase_sum; a->wp_phase_stride = 0;
+    a->sy = (float)d->h_src1 / (float)d->h_in;
+    a->sx = (float)d->w_src1 / (float)d->w_in;
+    a->tiles_x = ceil_div(d->w_out, s.px);
+    a->vt = s.vt; a->hp = d->h_out + 1; a->nimg = d->n; a->inv_hp = 1.0f / (float)(d->h_out + 1);
+    if (s.vt) {
+        a->tiles_y = ceil_div(d->n * (d->h_out + 1), s.th);
+        a->ntiles = a->tiles_x * a->tiles_y;
+    } else {
+        a->tiles_y = ceil_div(d->h_out, s.th);
+        a->ntiles = d->n * a->tiles_x * a->tiles_y;
+    }
+    a->nchunk1 = ceil_div(d->c1, s.cst);
+    a->nchunk2 = d->c2 > 0 ? ceil_div(d->c2, s.cst) : 0;
+}
+
+template <class F>
+int dispatch_fwd(const Sel& s, F&& f) {
+    const bool p16 = s.px == 16;
+    switch (s.kind) {
+        case K3S1:
+            if (s.ck == 16) {
+                if (s.px == 8) return s.nt == 1 ? f(Tag<F3S1_16_1_8>{}) : f(Tag<F3S1_16_2_8>{});
+                if (s.nt == 1) return p16 ? f(Tag<F3S1_16_1_16>{}) : f(Tag<F3S1_16_1_32>{});
+                return p16 ? f(Tag<F3S1_16_2_16>{}) : f(Tag<F3S1_16_2_32>{});
+            }
+            if (s.nt == 1) return p16 ? f(Tag<F3S1_8_1_16>{}) : f(Tag<F3S1_8_1_32>{});
+            return p16 ? f(Tag<F3S1_8_2_16>{}) : f(Tag<F3S1_8_2_32>{});
+        case K3S2:
+            if (s.nt == 1) return p16 ? f(Tag<F3S2_8_1_16>{}) : f(Tag<F3S2_8_1_32>{});
+            return p16 ? f(Tag<F3S2_8_2_16>{}) : f(Tag<F3S2_8_2_32>{});
+        case K1:
+            if (s.ck == 32) {
+                if (s.nt == 1) return p16 ? f(Tag<F1_32_1_16>{}) : f(Tag<F1_32_1_32>{});
+                return p16 ? f(Tag<F1_32_2_16>{}) : f(Tag<F1_32_2_32>{});
+            }
+            if (s.nt == 1) return p16 ? f(Tag<F1_16_1_16>{}) : f(Tag<F1_16_1_32>{});
+            return p16 ? f(Tag<F1_16_2_16>{}) : f(Tag<F1_16_2_32>{});
+        case K7S2:
+            return p16 ? f(Tag<F7_16>{}) : f(Tag<F7_32>{});
+        case K2S1:
+            if (s.nt == 1) return p16 ? f(Tag<F2_32_1_16>{}) : f(Tag<F2_32_1_32>{});
+            return p16 ? f(Tag<F2_32_2_16>{}) : f(Tag<F2_32_2_32>{});
+    }
+    return RCF_EUNSUPPORTED;
+}
+
+template <class F>
+int dispatch_split(const Sel& s, F&& f) {
+    if (s.bf16) {
+        if (s.kind == K2S1) {
+            if (s.nt == 1) return s.px == 16 ? f(Tag<B2_1_16>{}) : f(Tag<B2_1_32>{});
+            return s.px == 16 ? f(Tag<B2_2_16>{}) : f(Tag<B2_2_32>{});
+        }
+        if (s.nt == 1 && s.small) return s.px == 16 ? f(Tag<B3_1_16s>{}) : f(Tag<B3_1_32s>{});
+        if (s.nt == 1) return s.px == 16 ? f(Tag<B3_1_16>{}) : f(Tag<B3_1_32>{});
+        return s.px == 16 ? f(Tag<B3_2_16>{}) : f(Tag<B3_2_32>{});
+    }
+    if constexpr (!SAct::B16) {   // the exact 3-plane split exists for fp32 tensors only
+        if (s.kind == K2S1) {
+            if (s.nt == 1) return s.px == 16 ? f(Tag<S2_1_16>{}) : f(Tag<S2_1_32>{});
+            return s.px == 16 ? f(Tag<S2_2_16>{}) : f(Tag<S2_2_32>{});
+        }
+        if (s.nt == 1 && s.small) return s.px == 16 ? f(Tag<S3_1_16s>{}) : f(Tag<S3_1_32s>{});
+        if (s.nt == 1) return s.px == 16 ? f(Tag<S3_1_16>{}) : f(Tag<S3_1_32>{});
+        return s.px == 16 ? f(Tag<S3_2_16>{}) : f(Tag<S3_2_32>{});
+    }
+    return RCF_EUNSUPPORTED;
+}
+
+// wgrad tiling for the forward descriptor
+struct WSel { int kind, px, th, t, cst, nchunk1, nchunk2, ncog, nsplit, ktot, cop, tiles_x, tiles_y, ntiles, vt, split, wci, wco, gy, gz; };
+
+int select_wgrad(const rcf_conv_desc* d, WSel* w) {
+    if (!valid_desc(d) || d->w_mode != RCF_W_FORWARD) return RCF_EINVAL;
+    if (d->c_out % 4 != 0) return RCF_EUNSUPPORTED;
+    if (d->ksize == 7) {
+        if (d->stride != 2 || d->c2 != 0 || d->c1 > 4 || d->gather1 != RCF_GATHER_DIRECT) return RCF_EUNSUPPORTED;
+        w->kind = K7S2; w->t = 7; w->cst = 4;
+    } else if (d->ksize == 2) {
+        w->kind = K2S1; w->t = 4; w->cst = 32;
+    } else if (d->ksize == 3) {
+        w->kind = d->stride == 2 ? K3S2 : K3S1; w->t = 9; w->cst = 32;
+    } else {
+        w->kind = K1; w->t = 1; w->cst = 32;
+    }
+    if ((d->c1 % 4 != 0 || d->c2 % 4 != 0) && w->kind != K7S2 && d->c2 != 0) return RCF_EUNSUPPORTED;
+    const int th32 = (w->kind == K3S2) ? 4 : 8;
+    const int th16 = (w->kind == K3S2) ? 8 : 16;
+    const bool dma_ok = w->kind != K7S2 && (d->c1 % 4 == 0) && (d->c2 % 4 == 0);
+    w->vt = 0;
+    // 3x3 stride-1 layers run on the bf16 matrix pipe (conv_wgrad_split_kernel): 16x8 tiles, 32/64-channel blocks per workgroup
+    w->split = (dma_ok && split_enabled() &&
+                ((w->kind == K3S1 && d->out_stride == 1 && d->out_h_phys == d->h_out && d->out_w_phys == d->w_out &&
+                  (d->gather1 == RCF_GATHER_DIRECT || d->gather1 == RCF_GATHER_NEAREST)) ||
+                 (w->kind == K2S1 && d->gather1 == RCF_GATHER_DIRECT))) ? 1 : 0;
+    // virtual-tall tiling: the DMA / split kernels address the separator rows, the register-staged kernel (the only f32-MFMA
+    // weight-gradient kernel for bf16 tensors) does not
+    const bool vt_ok = dma_ok && vt_allowed(d) && (!SAct::B16 || w->split);
+    w->wci = w->wco = 1; w->gy = w->gz = 0;
+    if (w->split) {   // channels per workgroup: 64 x 64, 32 x 64, 64 x 32 or 32 x 32 (the last with 16-row tiles)
+        w->wco = d->c_out > 32 ? 2 : 1;
+        w->wci = (d->c1 % 64 == 0 && d->c2 % 64 == 0) ? 2 : 1;
+    }
+    const int th_split = (w->wci == 1 && w->wco == 1) ? 16 : 8;
+    double best = -1.0;
+    const int pxs[3] = {32, 16, 8}, ths[3] = {th32, w->split ? th_split : th16, 32};
+    for (int i = 0; i < 3; ++i) {
+        if (w->split && pxs[i] != 16) continue;
+        if (pxs[i] == 8 && (SAct::B16 || !(w->kind == K3S1 && dma_ok))) continue;
+        for (int vt = 0; vt <= (vt_ok ? 1 : 0); ++vt) {
+            const double e = vt ? tile_eff_vt(d->w_out, d->h_out, d->n, pxs[i], ths[i]) : tile_eff(d->w_out, d->h_out, pxs[i], ths[i]);
+            if (e > best + 1e-9) { best = e; w->px = pxs[i]; w->th = ths[i]; w->vt = vt; }
+        }
+    }
+    w->tiles_x = ceil_div(d->w_out, w->px);
+    if (w->vt) {
+        w->tiles_y = ceil_div(d->n * (d->h_out + 1), w->th);
+        w->ntiles = w->tiles_x * w->tiles_y;
+    } else {
+        w->tiles_y = ceil_div(d->h_out, w->th);
+        w->ntiles = d->n * w->tiles_x * w->tiles_y;
+    }
+    w->nchunk1 = (w->kind == K7S2) ? 1 : ceil_div(d->c1, 32);
+    w->nchunk2 = d->c2 > 0 ? ceil_div(d->c2, 32) : 0;
+    w->ncog = ceil_div(d->c_out, 32);
+    const int combos = (w->nchunk1 + w->nchunk2) * w->ncog;
+    int ns = 512 / combos;   // <= one resident wave at 2 workgroups/CU (two at 1/CU); never a nearly empty extra wave
+    if (ns > w->ntiles) ns = w->ntiles;
+    if (ns < 1) ns = 1;
+    w->nsplit = ns;
+    w->ktot = (w->nchunk1 + w->nchunk2) * w->t * 32;
+    w->cop = w->ncog * 32;
+    if (w->split) {
+        w->gy = ceil_div(d->c1, 32 * w->wci) + (d->c2 > 0 ? ceil_div(d->c2, 32 * w->wci) : 0);
+        w->gz = ceil_div(d->c_out, 32 * w->wco);
+        int nsp = num_cus() / (w->gy * w->gz);   // one workgroup per CU
+        if (nsp > w->ntiles) nsp = w->ntiles;
+        if (nsp < 1) nsp = 1;
+        w->nsplit = nsp;
+    }
+    return RCF_OK;
+}
+
+}   // namespace
+
+// ---- entry points.  The fp32 unit owns the public names and hands descriptors with storage == RCF_STORE_BF16 to the bf16 unit.
+#if RCF_CONV_B16
+#define RCF_FN(name) name##_b16impl
+#define RCF_TO_B16(d, call)
+#else
+#define RCF_FN(name) name
+#define RCF_TO_B16(d, call) \
+    if ((d) != nullptr && (d)->storage == RCF_STORE_BF16) return call
+extern "C" {
+int rcf_conv2d_query_b16impl(const rcf_conv_desc* d, rcf_conv_info* info);
+int rcf_conv2d_pack_weights_b16impl(const rcf_conv_desc* d, const float* w_oihw, float* packed, void* stream);
+int rcf_conv2d_fwd_b16impl(const rcf_conv_desc* d, const void* in1, const void* in2, const float* packed, void* out, double* stat_partials,
+                           void* stream);
+int rcf_conv2d_fwd_bn_b16impl(const rcf_conv_desc* d, const void* in1, const float* coef1, const void* in2, const float* coef2,
+                              const float* packed, void* out, double* stat_partials, void* stream);
+int rcf_conv2d_fwd_act_b16impl(const rcf_conv_desc* d, const void* in1, const void* in2, const float* packed, const float* bias,
+                               const void* res, void* out, void* stream);
+int rcf_conv2d_wgrad_b16impl(const rcf_conv_desc* d, const void* in1, const void* in2, const void* dz, float* dw_oihw, float* workspace,
+                             void* stream);
+int rcf_conv2d_wgrad_bn_b16impl(const rcf_conv_desc* d, const void* in1, const float* coef1, const void* in2, const float* coef2,
+                                const void* dz, float* dw_oihw, float* workspace, void* stream);
+}
+#endif
+
+#if !RCF_CONV_B16
+extern "C" int rcf_phase_weights(const float* w_oihw, float* out, int o, int i, int mode, void* stream) {
+    if (!w_oihw || !out || o <= 0 || i <= 0 || mode < 0 || mode > 2) return RCF_EINVAL;
+    const int total = 16 * o * i;
+    hipLaunchKernelGGL(phase_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, out, o, i, mode);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_phase_wgrad_fold(const float* dwp, float* dw_oihw, int o, int i, void* stream) {
+    if (!dwp || !dw_oihw || o <= 0 || i <= 0) return RCF_EINVAL;
+    const int total = 9 * o * i;
+    hipLaunchKernelGGL(phase_wgrad_fold_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, dwp, dw_oihw, o, i);
+    return rcf_launch_status();
+}
+
+#endif   // !RCF_CONV_B16
+
+extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* info) {
+    RCF_TO_B16(d, rcf_conv2d_query_b16impl(d, info));
+    if (!info) return RCF_EINVAL;
+    Sel s;
+    int rc = select_cfg(d, &s);
+    if (rc != RCF_OK) return rc;
+    ConvArgs a;
+    fill_args(d, s, &a);
+    const int ntile_n = ceil_div(d->c_out, s.bn);
+    info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * s.ck;
+    if (s.split) info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.bf16 ? 8 : 24);   // 16 bf16 x planes per row
+    info->n_partials = s.split ? dispatch_split(s, [&](auto tag) { return split_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); })
+                               : dispatch_fwd(s, [&](auto tag) { return fwd_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
+    if (info->n_partials <= 0) return RCF_EUNSUPPORTED;
+    info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0) + (s.small ? 5 : 0) + (s.bf16 ? 20000 : 0);
+    info->wgrad_workspace_floats = 0;
+    info->wgrad_kernel_id = 0;
+    info->bn_on_load = (s.split && d->w_mode == RCF_W_FORWARD && d->c1 + d->c2 <= 512) ? 1 : 0;
+    info->wgrad_bn_on_load = 0;
+    info->fwd_act = (s.split && d->w_mode == RCF_W_FORWARD && !d->accumulate) ? 1 : 0;
+    if (d->w_mode == RCF_W_FORWARD) {
+        WSel w;
+        if (select_wgrad(d, &w) == RCF_OK) {
+            info->wgrad_workspace_floats = (size_t)w.nsplit * w.ktot * w.cop + 64;   // + a zero page for the DMA path
+            info->wgrad_bn_on_load = w.split ? 1 : 0;
+            info->wgrad_kernel_id = 10000 + w.kind * 1000 + (w.px == 16 ? 100 : (w.px == 8 ? 200 : 0)) + (w.vt ? 400 : 0) +
+                                    (w.split ? 5000 + w.wci * 10 + w.wco : 0) + ((w.split && d->precision == RCF_PREC_BF16) ? 20000 : 0);
+        }
+    }
+    return RCF_OK;
+}
+
+extern "C" int RCF_FN(rcf_conv2d_pack_weights)(const rcf_conv_desc* d, const float* w_oihw, float* packed, void* stream) {
+    RCF_TO_B16(d, rcf_conv2d_pack_weights_b16impl(d, w_oihw, packed, stream));
+    if (!w_oihw || !packed) return RCF_EINVAL;
+    Sel s;
+    int rc = select_cfg(d, &s);
+    if (rc != RCF_OK) return rc;
+    ConvArgs a;
+    fill_args(d, s, &a);
+    const int ntile_n = ceil_div(d->c_out, s.bn);
+    const int nchunk = a.nchunk1 + a.nchunk2;
+    const size_t total = (size_t)ntile_n * nchunk * s.t * s.bn * s.ck;
+    if (s.split) {
+        const size_t rows16 = (size_t)ntile_n * nchunk * s.t * s.bn * 16;
+        hipLaunchKernelGGL(pack_weights_split_kernel, dim3((unsigned)((rows16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                           reinterpret_cast<unsigned short*>(packed), rows16, d->w_o, d->w_i, d->w_mode, d->w_i_off, d->c_out, d->c1,
+                           d->c2, a.nchunk1, nchunk, s.bn, d->ksize, s.bf16 ? 1 : 3);
+        return rcf_launch_status();
+    }
+    const int ksx = s.kind == K7S2 ? 1 : d->ksize;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, total, d->w_o,
+                       d->w_i, d->ksize, d->w_mode, d->w_i_off, d->c_out, d->c1, d->c2, a.nchunk1, nchunk, s.t, ksx, s.bn,
+                       s.ck, s.kind == K7S2 ? 1 : 0);
+    return rcf_launch_status();
+}
+
+static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
+                           const float* packed, float* out, double* stat_partials, void* stream);
+
+extern "C" int RCF_FN(rcf_conv2d_fwd)(const rcf_conv_desc* d, const void* in1, const void* in2, const float* packed, void* out,
+                                      double* stat_partials, void* stream) {
+    RCF_TO_B16(d, rcf_conv2d_fwd_b16impl(d, in1, in2, packed, out, stat_partials, stream));
+    return conv2d_fwd_impl(d, (const float*)in1, nullptr, (const float*)in2, nullptr, packed, (float*)out, stat_partials, stream);
+}
+
+extern "C" int RCF_FN(rcf_conv2d_fwd_bn)(const rcf_conv_desc* d, const void* in1, const float* coef1, const void* in2, const float* coef2,
+                                         const float* packed, void* out, double* stat_partials, void* stream) {
+    RCF_TO_B16(d, rcf_conv2d_fwd_bn_b16impl(d, in1, coef1, in2, coef2, packed, out, stat_partials, stream));
+    return conv2d_fwd_impl(d, (const float*)in1, coef1, (const float*)in2, coef2, packed, (float*)out, stat_partials, stream);
+}
+
+static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
+                           const float* packed, float* out, double* stat_partials, void* stream) {
+    if (!in1 || !packed || !out) return RCF_EINVAL;
+    Sel s;
+    int rc = select_cfg(d, &s);
+    if (rc != RCF_OK) return rc;
+    if (d->c2 > 0 && !in2) return RCF_EINVAL;
+    if ((coef1 || coef2) && (!s.split || d->w_mode != RCF_W_FORWARD || d->c1 + d->c2 > 512 || (coef2 && d->c2 == 0)))
+        return RCF_EUNSUPPORTED;   // BN-on-load exists in the split kernels only (rcf_conv_info.bn_on_load)
+    ConvArgs a;
+    fill_args(d, s, &a);
+    a.coef1 = coef1; a.coef2 = coef2;
+    a.in1 = in1; a.in2 = in2; a.wp = packed; a.out = out; a.stats = stat_partials; a.dz = nullptr; a.ws = nullptr;
+    a.ktot = 0; a.cop = 0;
+    const int nn = ceil_div(d->c_out, s.bn);
+    a.wp_phase_stride = (int)((size_t)nn * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.split ? (s.bf16 ? 8 : 24) : s.ck));
+    if (s.split) return dispatch_split(s, [&](auto tag) { return launch_split<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
+    return dispatch_fwd(s, [&](auto tag) { return launch_fwd<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
+}
+
+extern "C" int RCF_FN(rcf_conv2d_fwd_act)(const rcf_conv_desc* d, const void* in1_, const void* in2_, const float* packed,
+                                          const float* bias, const void* res_, void* out_, void* stream) {
+    RCF_TO_B16(d, rcf_conv2d_fwd_act_b16impl(d, in1_, in2_, packed, bias, res_, out_, stream));
+    const float* in1 = (const float*)in1_;
+    const float* in2 = (const float*)in2_;
+    const float* res = (const float*)res_;
+    float* out = (float*)out_;
+    if (!in1 || !packed || !out || !bias) return RCF_EINVAL;
+    Sel s;
+    int rc = select_cfg(d, &s);
+    if (rc != RCF_OK) return rc;
+    if (d->c2 > 0 && !in2) return RCF_EINVAL;
+    if (!s.split || d->w_mode != RCF_W_FORWARD || d->accumulate) return RCF_EUNSUPPORTED;   // rcf_conv_info.fwd_act
+    ConvArgs a;
+    fill_args(d, s, &a);
+    a.bias = bias; a.res = res;
+    a.in1 = in1; a.in2 = in2; a.wp = packed; a.out = out; a.stats = nullptr; a.dz = nullptr; a.ws = nullptr;
+    a.ktot = 0; a.cop = 0;
+    const int nn = ceil_div(d->c_out, s.bn);
+    a.wp_phase_stride = (int)((size_t)nn * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.bf16 ? 8 : 24));
+    return dispatch_split(s, [&](auto tag) { return launch_split<typename decltype(tag)::type, true>(a, nn, (hipStream_t)stream); });
+}
+
+static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
+                             const float* dz, float* dw_oihw, float* workspace, void* stream);
+
+extern "C" int RCF_FN(rcf_conv2d_wgrad)(const rcf_conv_desc* d, const void* in1, const void* in2, const void* dz,
+                                        float* dw_oihw, float* workspace, void* stream) {
+    RCF_TO_B16(d, rcf_conv2d_wgrad_b16impl(d, in1, in2, dz, dw_oihw, workspace, stream));
+    return conv2d_wgrad_impl(d, (const float*)in1, nullptr, (const float*)in2, nullptr, (const float*)dz, dw_oihw, workspace, stream);
+}
+
+extern "C" int RCF_FN(rcf_conv2d_wgrad_bn)(const rcf_conv_desc* d, const void* in1, const float* coef1, const void* in2,
+                                           const float* coef2, const void* dz, float* dw_oihw, float* workspace, void* stream) {
+    RCF_TO_B16(d, rcf_conv2d_wgrad_bn_b16impl(d, in1, coef1, in2, coef2, dz, dw_oihw, workspace, stream));
+    return conv2d_wgrad_impl(d, (const float*)in1, coef1, (const float*)in2, coef2, (const float*)dz, dw_oihw, workspace, stream);
+}
+
+static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
+                             const float* dz, float* dw_oihw, float* workspace, void* stream) {
+    if (!in1 || !dz || !dw_oihw || !workspace) return RCF_EINVAL;
+    WSel w;
+    int rc = select_wgrad(d, &w);
+    if (rc != RCF_OK) return rc;
+    if (d->c2 > 0 && !in2) return RCF_EINVAL;
+    if ((coef1 || coef2) && (!w.split || (coef2 && d->c2 == 0))) return RCF_EUNSUPPORTED;
+    ConvArgs a;
+    a.bias = nullptr; a.res = nullptr;
+    a.coef1 = coef1; a.coef2 = coef2;
+    a.n = d->n; a.h_in = d->h_in; a.w_in = d->w_in; a.c1 = d->c1; a.c2 = d->c2;
+    a.h1 = d->h_src1; a.w1 = d->w_src1; a.gather1 = d->gather1;
+    a.h_out = d->h_out; a.w_out = d->w_out; a.c_out = d->c_out; a.pad = d->pad; a.pad_x = d->pad_x; a.stride = d->stride;
+    a.gstep = d->ksize == 1 ? d->stride : 1;
+    a.accumulate = 0;
+    a.os = d->out_stride; a.ooy = d->out_off_y; a.oox = d->out_off_x; a.ohp = d->out_h_phys; a.owp = d->out_w_phys;
+    a.ioy = d->in_off_y; a.iox = d->in_off_x;
+    a.phase_sum = 0; a.wp_phase_stride = 0;
+    a.vt = w.vt; a.hp = d->h_out + 1; a.nimg = d->n; a.inv_hp = 1.0f / (float)(d->h_out + 1);
+    a.sy = (float)d->h_src1 / (float)d->h_in;
+    a.sx = (float)d->w_src1 / (float)d->w_in;
+    a.tiles_x = w.tiles_x; a.tiles_y = w.tiles_y; a.ntiles = w.ntiles;
+    a.nchunk1 = w.nchunk1; a.nchunk2 = w.nchunk2;
+    a.in1 = in1; a.in2 = in2; a.wp = nullptr; a.out = nullptr; a.stats = nullptr; a.dz = dz; a.ws = workspace;
+    a.ktot = w.ktot; a.cop = w.cop;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = w.nchunk1 + w.nchunk2;
+    const int p16 = w.px == 16;
+    const bool dma = !SAct::B16 && w.kind != K7S2 && (d->c1 % 4 == 0) && (d->c2 % 4 == 0);
+    if (w.split) {
+        a.nchunk1 = ceil_div(d->c1, 32 * w.wci);
+        a.nchunk2 = d->c2 > 0 ? ceil_div(d->c2, 32 * w.wci) : 0;
+        const int cfg = w.wci * 10 + w.wco;
+        if (d->precision == RCF_PREC_BF16) {
+            if (w.kind == K2S1) {
+                if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2, 2, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
+                else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2, 2, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
+                else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 2, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
+                else rc = launch_wgrad_split<WsCfg<1, 1, 2, 16, 1>>(a, w.nsplit, w.gy, w.gz, st);
+            } else if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2, 3, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
+            else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2, 3, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
+            else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 3, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
+            else rc = launch_wgrad_split<WsCfg<1, 1, 3, 16, 1>>(a, w.nsplit, w.gy, w.gz, st);
+        } else if constexpr (!SAct::B16) {
+        if (w.kind == K2S1) {
+            if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2, 2>>(a, w.nsplit, w.gy, w.gz, st);
+            else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2, 2>>(a, w.nsplit, w.gy, w.gz, st);
+            else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 2>>(a, w.nsplit, w.gy, w.gz, st);
+            else rc = launch_wgrad_split<WsCfg<1, 1, 2, 16>>(a, w.nsplit, w.gy, w.gz, st);
+        } else if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2>>(a, w.nsplit, w.gy, w.gz, st);
+        else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2>>(a, w.nsplit, w.gy, w.gz, st);
+        else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1>>(a, w.nsplit, w.gy, w.gz, st);
+        else rc = launch_wgrad_split<WsCfg<1, 1, 3, 16>>(a, w.nsplit, w.gy, w.gz, st);
+        } else return RCF_EUNSUPPORTED;
+    } else
+    switch (w.kind) {
+        case K3S1:
+            if (dma && w.px == 8) rc = RCF_DMA(launch_wgrad_dma<W3S1_8>(a, w.nsplit, nchunk, w.ncog, st));
+            else if (dma) rc = RCF_DMA(p16 ? launch_wgrad_dma<W3S1_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad_dma<W3S1_32>(a, w.nsplit, nchunk, w.ncog, st));
+            else rc = p16 ? launch_wgrad<W3S1_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad<W3S1_32>(a, w.nsplit, nchunk, w.ncog, st);
+            break;
+        case K3S2:
+            if (dma) rc = RCF_DMA(p16 ? launch_wgrad_dma<W3S2_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad_dma<W3S2_32>(a, w.nsplit, nchunk, w.ncog, st));
+            else rc = p16 ? launch_wgrad<W3S2_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad<W3S2_32>(a, w.nsplit, nchunk, w.ncog, st);
+            break;
+        case K1:
+            if (dma) rc = RCF_DMA(p16 ? launch_wgrad_dma<W1_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad_dma<W1_32>(a, w.nsplit, nchunk, w.ncog, st));
+            else rc = p16 ? launch_wgrad<W1_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad<W1_32>(a, w.nsplit, nchunk, w.ncog, st);
+            break;
+        case K2S1:
+            if (dma) rc = RCF_DMA(p16 ? launch_wgrad_dma<W2_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad_dma<W2_32>(a, w.nsplit, nchunk, w.ncog, st));
+            else rc = p16 ? launch_wgrad<W2_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad<W2_32>(a, w.nsplit, nchunk, w.ncog, st);
+            break;
+        case K7S2: rc = p16 ? launch_wgrad<W7_16>(a, w.nsplit, nchunk, w.ncog, st) : launch_wgrad<W7_32>(a, w.nsplit, nchunk, w.ncog, st); break;
+        default: return RCF_EUNSUPPORTED;
+    }
+    if (rc != RCF_OK) return rc;
+    const int total = w.ktot * w.cop;
+    const int ksx = w.kind == K7S2 ? 1 : d->ksize;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, workspace, dw_oihw, w.nsplit, w.ktot,
+                       w.cop, d->c_out, d->c1, d->c2, w.nchunk1, w.t, ksx, w.kind == K7S2 ? 1 : 0);
+    return rcf_launch_status();
+}
+
+#if defined(RCF_PHASE_TIMING) && !RCF_CONV_B16
+// diagnostics build only: summed s_memtime cycles of all conv_split_kernel waves since the last reset (see RCF_TACC slots)
+extern "C" int rcf_debug_phase_cycles(unsigned long long* out8, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return rcf_launch_status();
+    if (out8 != nullptr && hipMemcpyFromSymbol(out8, HIP_SYMBOL(rcf_phase_cycles), 8 * sizeof(unsigned long long)) != hipSuccess)
+        return rcf_launch_status();
+    if (reset) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(rcf_phase_cycles), z, sizeof(z)) != hipSuccess) return rcf_launch_status();
+    }
+    return RCF_OK;
+}
+#endif

@@ -43,26 +43,15 @@ __device__ __forceinline__ Coef4 load_coef(const float* __restrict__ coef, int c
     return k;
 }
 
-__device__ __forceinline__ f32x4 ld4(const float* p, size_t i) {
-#if RCF_NT & 2
-    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i));
-#else
-    return *reinterpret_cast<const f32x4*>(p + i);
-#endif
-}
+// Activation tensors are touched only through these two (element index i, 4 channels): S = StF32 / StB16 is their storage.
 // streams larger than the 256 MB MALL: non-temporal loads measured -5..8 % on the BN kernels, non-temporal stores nothing
-#ifndef RCF_NT
-#define RCF_NT 2
-#endif
-__device__ __forceinline__ void st4(float* p, size_t i, f32x4 v) {
-#if RCF_NT & 1
-    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p + i));
-#else
-    *reinterpret_cast<f32x4*>(p + i) = v;
-#endif
-}
+template <class S>
+__device__ __forceinline__ f32x4 ld4(const float* p, size_t i) { return rcf_ld4_nt<S>(p, i); }
+template <class S>
+__device__ __forceinline__ void st4(float* p, size_t i, f32x4 v) { rcf_st4<S>(p, i, v); }
 
 // ---------------------------------------------------------------- forward
+template <class S>
 __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ coef,
                                                          const float* __restrict__ res, float* __restrict__ out,
                                                          long long n_pix, int c, int act) {
@@ -84,7 +73,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = rcf_lrelu(y[j] + r[j]);
         }
-        st4(out, i, y);
+        st4<S>(out, i, y);
     };
     long long p = (long long)blockIdx.x * ppb + pl;
     for (; p + (EW_U - 1) * stride < n_pix; p += EW_U * stride) {
@@ -92,19 +81,20 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
 #pragma unroll
         for (int u = 0; u < EW_U; ++u) {
             const size_t i = (size_t)(p + u * stride) * c + cg * 4;
-            zz[u] = ld4(z, i);
-            rr[u] = res != nullptr ? ld4(res, i) : zz[u];
+            zz[u] = ld4<S>(z, i);
+            rr[u] = res != nullptr ? ld4<S>(res, i) : zz[u];
         }
 #pragma unroll
         for (int u = 0; u < EW_U; ++u) one(zz[u], rr[u], (size_t)(p + u * stride) * c + cg * 4);
     }
     for (; p < n_pix; p += stride) {
         const size_t i = (size_t)p * c + cg * 4;
-        const f32x4 zz = ld4(z, i);
-        one(zz, res != nullptr ? ld4(res, i) : zz, i);
+        const f32x4 zz = ld4<S>(z, i);
+        one(zz, res != nullptr ? ld4<S>(res, i) : zz, i);
     }
 }
 
+template <class S>
 __global__ void __launch_bounds__(256) fuse_fwd_kernel(const float* __restrict__ zw, const float* __restrict__ coef_w,
                                                        const float* __restrict__ zp, const float* __restrict__ coef_p,
                                                        const float* __restrict__ img, float* __restrict__ out,
@@ -117,13 +107,13 @@ __global__ void __launch_bounds__(256) fuse_fwd_kernel(const float* __restrict__
     const Coef4 kp = load_coef(coef_p, c, cg);
     for (long long p = (long long)blockIdx.x * ppb + pl; p < n_pix; p += (long long)gridDim.x * ppb) {
         const size_t i = (size_t)p * c + cg * 4;
-        const f32x4 yw = ld4(zw, i) * kw.scale + kw.shift;
-        const f32x4 yp = ld4(zp, i) * kp.scale + kp.shift;
-        const f32x4 im = ld4(img, i);
+        const f32x4 yw = ld4<S>(zw, i) * kw.scale + kw.shift;
+        const f32x4 yp = ld4<S>(zp, i) * kp.scale + kp.shift;
+        const f32x4 im = ld4<S>(img, i);
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (1.f / (1.f + expf(-yw[j]))) * yp[j] + im[j];
-        st4(out, i, o);
+        st4<S>(out, i, o);
     }
 }
 
@@ -147,6 +137,7 @@ __device__ __forceinline__ void block_reduce_store(const double (&s)[NS][4], dou
     }
 }
 
+template <class S>
 __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ z,
                                                                 const float* __restrict__ coef, const float* __restrict__ out,
                                                                 double* __restrict__ partials, long long n_pix, int c, int act,
@@ -181,21 +172,22 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(const float* __r
 #pragma unroll
         for (int u = 0; u < EW_U; ++u) {
             const size_t i = (size_t)(p + u * stride) * c + cg * 4;
-            g[u] = ld4(dout, i);
-            zz[u] = ld4(z, i);
-            o[u] = has_res ? ld4(out, i) : zz[u];
+            g[u] = ld4<S>(dout, i);
+            zz[u] = ld4<S>(z, i);
+            o[u] = has_res ? ld4<S>(out, i) : zz[u];
         }
 #pragma unroll
         for (int u = 0; u < EW_U; ++u) one(g[u], zz[u], o[u]);
     }
     for (; p < n_pix; p += stride) {
         const size_t i = (size_t)p * c + cg * 4;
-        const f32x4 zz = ld4(z, i);
-        one(ld4(dout, i), zz, has_res ? ld4(out, i) : zz);
+        const f32x4 zz = ld4<S>(z, i);
+        one(ld4<S>(dout, i), zz, has_res ? ld4<S>(out, i) : zz);
     }
     block_reduce_store<2>(s, partials + (size_t)blockIdx.x * 2 * c, c, cg, pl, sm);
 }
 
+template <class S>
 __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ z,
                                                                const float* __restrict__ coef, const float* __restrict__ out,
                                                                const float* __restrict__ bcoef, float* __restrict__ dz,
@@ -217,7 +209,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const float* __re
             if (dres != nullptr) {
                 f32x4 d = g;
                 if (dres_accumulate) d += dold;
-                st4(dres, i, d);
+                st4<S>(dres, i, d);
             }
         }
         const f32x4 y = zz * k.scale + k.shift;
@@ -229,7 +221,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const float* __re
             if (act == RCF_ACT_LEAKY_RELU) gj *= rcf_lrelu_grad(y[j]);
             r[j] = k.scale[j] * (gj - b0[j] - xh[j] * b1[j]);
         }
-        st4(dz, i, r);
+        st4<S>(dz, i, r);
     };
     long long p = (long long)blockIdx.x * ppb + pl;
     for (; p + (EW_U - 1) * stride < n_pix; p += EW_U * stride) {
@@ -237,18 +229,18 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const float* __re
 #pragma unroll
         for (int u = 0; u < EW_U; ++u) {
             const size_t i = (size_t)(p + u * stride) * c + cg * 4;
-            g[u] = ld4(dout, i);
-            zz[u] = ld4(z, i);
-            o[u] = has_res ? ld4(out, i) : zz[u];
-            dold[u] = (want_dres && dres_accumulate) ? ld4(dres, i) : zz[u];
+            g[u] = ld4<S>(dout, i);
+            zz[u] = ld4<S>(z, i);
+            o[u] = has_res ? ld4<S>(out, i) : zz[u];
+            dold[u] = (want_dres && dres_accumulate) ? ld4<S>(dres, i) : zz[u];
         }
 #pragma unroll
         for (int u = 0; u < EW_U; ++u) one(g[u], zz[u], o[u], dold[u], (size_t)(p + u * stride) * c + cg * 4);
     }
     for (; p < n_pix; p += stride) {
         const size_t i = (size_t)p * c + cg * 4;
-        const f32x4 zz = ld4(z, i);
-        one(ld4(dout, i), zz, has_res ? ld4(out, i) : zz, (want_dres && dres_accumulate) ? ld4(dres, i) : zz, i);
+        const f32x4 zz = ld4<S>(z, i);
+        one(ld4<S>(dout, i), zz, has_res ? ld4<S>(out, i) : zz, (want_dres && dres_accumulate) ? ld4<S>(dres, i) : zz, i);
     }
 }
 
@@ -293,7 +285,7 @@ struct HeadBnTile {
     }
 };
 
-template <int C4N>
+template <int C4N, class S>
 __global__ void __launch_bounds__(256) head_bn_bwd_reduce_kernel(const float* __restrict__ dlogit, const float* __restrict__ w_head,
                                                                  const float* __restrict__ z, const float* __restrict__ coef,
                                                                  double* __restrict__ partials, int n, int h, int w) {
@@ -318,7 +310,7 @@ __global__ void __launch_bounds__(256) head_bn_bwd_reduce_kernel(const float* __
             const int ty = pix / HB_W, tx = pix % HB_W;
             const int oy = oy0 + ty, ox = ox0 + tx;
             if (oy < h && ox < w) {
-                const f32x4 zz = ld4(z, (((size_t)img * h + oy) * w + ox) * C + hb.cg * 4);
+                const f32x4 zz = ld4<S>(z, (((size_t)img * h + oy) * w + ox) * C + hb.cg * 4);
                 const f32x4 g0 = hb.dout(D, ty, tx);
                 const f32x4 y = zz * kc.scale + kc.shift;
                 const f32x4 xh = (zz - kc.mean) * kc.invstd;
@@ -334,7 +326,7 @@ __global__ void __launch_bounds__(256) head_bn_bwd_reduce_kernel(const float* __
     block_reduce_store<2>(s, partials + (size_t)blockIdx.x * 2 * C, C, hb.cg, threadIdx.x / C4N, smd);
 }
 
-template <int C4N>
+template <int C4N, class S>
 __global__ void __launch_bounds__(256) head_bn_bwd_apply_kernel(const float* __restrict__ dlogit, const float* __restrict__ w_head,
                                                                 const float* __restrict__ z, const float* __restrict__ coef,
                                                                 const float* __restrict__ bcoef, float* __restrict__ dz, int n, int h,
@@ -357,18 +349,19 @@ __global__ void __launch_bounds__(256) head_bn_bwd_apply_kernel(const float* __r
         const int oy = oy0 + ty, ox = ox0 + tx;
         if (oy < h && ox < w) {
             const size_t i = (((size_t)img * h + oy) * w + ox) * C + hb.cg * 4;
-            const f32x4 zz = ld4(z, i);
+            const f32x4 zz = ld4<S>(z, i);
             const f32x4 g0 = hb.dout(D, ty, tx);
             const f32x4 y = zz * kc.scale + kc.shift;
             const f32x4 xh = (zz - kc.mean) * kc.invstd;
             f32x4 r;
 #pragma unroll
             for (int j = 0; j < 4; ++j) r[j] = kc.scale[j] * (g0[j] * rcf_lrelu_grad(y[j]) - b0[j] - xh[j] * b1[j]);
-            st4(dz, i, r);
+            st4<S>(dz, i, r);
         }
     }
 }
 
+template <class S>
 __global__ void __launch_bounds__(256) fuse_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ zw,
                                                               const float* __restrict__ coef_w, const float* __restrict__ zp,
                                                               const float* __restrict__ coef_p, double* __restrict__ partials,
@@ -387,9 +380,9 @@ __global__ void __launch_bounds__(256) fuse_bwd_reduce_kernel(const float* __res
         for (int j = 0; j < 4; ++j) s[q][j] = 0.0;
     for (long long p = (long long)blockIdx.x * ppb + pl; p < n_pix; p += (long long)gridDim.x * ppb) {
         const size_t i = (size_t)p * c + cg * 4;
-        const f32x4 g = ld4(dout, i);
-        const f32x4 a = ld4(zw, i);
-        const f32x4 b = ld4(zp, i);
+        const f32x4 g = ld4<S>(dout, i);
+        const f32x4 a = ld4<S>(zw, i);
+        const f32x4 b = ld4<S>(zp, i);
         const f32x4 yw = a * kw.scale + kw.shift;
         const f32x4 yp = b * kp.scale + kp.shift;
         const f32x4 xw = (a - kw.mean) * kw.invstd;
@@ -408,6 +401,7 @@ __global__ void __launch_bounds__(256) fuse_bwd_reduce_kernel(const float* __res
     block_reduce_store<4>(s, partials + (size_t)blockIdx.x * 4 * c, c, cg, pl, sm);
 }
 
+template <class S>
 __global__ void __launch_bounds__(256) fuse_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ zw,
                                                              const float* __restrict__ coef_w, const float* __restrict__ zp,
                                                              const float* __restrict__ coef_p, const float* __restrict__ bcw,
@@ -426,9 +420,9 @@ __global__ void __launch_bounds__(256) fuse_bwd_apply_kernel(const float* __rest
     const f32x4 p1 = *reinterpret_cast<const f32x4*>(bcp + c + cg * 4);
     for (long long p = (long long)blockIdx.x * ppb + pl; p < n_pix; p += (long long)gridDim.x * ppb) {
         const size_t i = (size_t)p * c + cg * 4;
-        const f32x4 g = ld4(dout, i);
-        const f32x4 a = ld4(zw, i);
-        const f32x4 b = ld4(zp, i);
+        const f32x4 g = ld4<S>(dout, i);
+        const f32x4 a = ld4<S>(zw, i);
+        const f32x4 b = ld4<S>(zp, i);
         const f32x4 yw = a * kw.scale + kw.shift;
         const f32x4 yp = b * kp.scale + kp.shift;
         const f32x4 xw = (a - kw.mean) * kw.invstd;
@@ -442,12 +436,12 @@ __global__ void __launch_bounds__(256) fuse_bwd_apply_kernel(const float* __rest
             rw[j] = kw.scale[j] * (gw - w0[j] - xw[j] * w1[j]);
             rp[j] = kp.scale[j] * (gp - p0[j] - xp[j] * p1[j]);
         }
-        st4(dzw, i, rw);
-        st4(dzp, i, rp);
+        st4<S>(dzw, i, rw);
+        st4<S>(dzp, i, rp);
         if (dimg != nullptr) {
             f32x4 d = g;
-            if (dimg_accumulate) d += ld4(dimg, i);
-            st4(dimg, i, d);
+            if (dimg_accumulate) d += ld4<S>(dimg, i);
+            st4<S>(dimg, i, d);
         }
     }
 }
@@ -552,30 +546,33 @@ extern "C" int rcf_bn_finalize(const double* partials, int n_partials, int c, do
     return rcf_launch_status();
 }
 
-extern "C" int rcf_bn_act_fwd(const float* z, const float* coef, const float* res, float* out, long long n_pix, int c,
+template <class S>
+static int bn_act_fwd_impl(const float* z, const float* coef, const float* res, float* out, long long n_pix, int c,
                               int act, void* stream) {
     if (!z || !coef || !out || n_pix <= 0) return RCF_EINVAL;
     if (!c4_ok(c)) return RCF_EUNSUPPORTED;
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, z, coef, res, out,
+    hipLaunchKernelGGL((bn_act_fwd_kernel<S>), dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, z, coef, res, out,
                        n_pix, c, act);
     return rcf_launch_status();
 }
 
-extern "C" int rcf_fuse_fwd(const float* zw, const float* coef_w, const float* zp, const float* coef_p, const float* img,
+template <class S>
+static int fuse_fwd_impl(const float* zw, const float* coef_w, const float* zp, const float* coef_p, const float* img,
                             float* out, long long n_pix, int c, void* stream) {
     if (!zw || !coef_w || !zp || !coef_p || !img || !out || n_pix <= 0) return RCF_EINVAL;
     if (!c4_ok(c)) return RCF_EUNSUPPORTED;
-    hipLaunchKernelGGL(fuse_fwd_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, zw, coef_w, zp, coef_p,
+    hipLaunchKernelGGL((fuse_fwd_kernel<S>), dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, zw, coef_w, zp, coef_p,
                        img, out, n_pix, c);
     return rcf_launch_status();
 }
 
-extern "C" int rcf_bn_act_bwd_reduce(const float* dout, const float* z, const float* coef, const float* out, double* partials,
+template <class S>
+static int bn_act_bwd_reduce_impl(const float* dout, const float* z, const float* coef, const float* out, double* partials,
                                      long long n_pix, int c, int act, int has_res, void* stream) {
     if (!dout || !z || !coef || !partials || n_pix <= 0 || (has_res && !out)) return RCF_EINVAL;
     if (!c4_ok(c)) return RCF_EUNSUPPORTED;
     const int ppb = 256 / (c >> 2);
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), (size_t)ppb * 2 * c * sizeof(double),
+    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<S>), dim3(ew_blocks(n_pix, c)), dim3(256), (size_t)ppb * 2 * c * sizeof(double),
                        (hipStream_t)stream, dout, z, coef, out, partials, n_pix, c, act, has_res);
     return rcf_launch_status();
 }
@@ -589,32 +586,35 @@ extern "C" int rcf_bn_bwd_finalize(const double* partials, int n_blocks, int par
     return rcf_launch_status();
 }
 
-extern "C" int rcf_bn_act_bwd_apply(const float* dout, const float* z, const float* coef, const float* out, const float* bcoef,
+template <class S>
+static int bn_act_bwd_apply_impl(const float* dout, const float* z, const float* coef, const float* out, const float* bcoef,
                                     float* dz, float* dres, int dres_accumulate, long long n_pix, int c, int act, int has_res,
                                     void* stream) {
     if (!dout || !z || !coef || !bcoef || !dz || n_pix <= 0 || (has_res && !out)) return RCF_EINVAL;
     if (!c4_ok(c)) return RCF_EUNSUPPORTED;
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, dout, z, coef, out,
+    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<S>), dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, dout, z, coef, out,
                        bcoef, dz, dres, dres_accumulate, n_pix, c, act, has_res);
     return rcf_launch_status();
 }
 
-extern "C" int rcf_fuse_bwd_reduce(const float* dout, const float* zw, const float* coef_w, const float* zp,
+template <class S>
+static int fuse_bwd_reduce_impl(const float* dout, const float* zw, const float* coef_w, const float* zp,
                                    const float* coef_p, double* partials, long long n_pix, int c, void* stream) {
     if (!dout || !zw || !coef_w || !zp || !coef_p || !partials || n_pix <= 0) return RCF_EINVAL;
     if (!c4_ok(c)) return RCF_EUNSUPPORTED;
     const int ppb = 256 / (c >> 2);
-    hipLaunchKernelGGL(fuse_bwd_reduce_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), (size_t)ppb * 4 * c * sizeof(double),
+    hipLaunchKernelGGL((fuse_bwd_reduce_kernel<S>), dim3(ew_blocks(n_pix, c)), dim3(256), (size_t)ppb * 4 * c * sizeof(double),
                        (hipStream_t)stream, dout, zw, coef_w, zp, coef_p, partials, n_pix, c);
     return rcf_launch_status();
 }
 
-extern "C" int rcf_fuse_bwd_apply(const float* dout, const float* zw, const float* coef_w, const float* zp, const float* coef_p,
+template <class S>
+static int fuse_bwd_apply_impl(const float* dout, const float* zw, const float* coef_w, const float* zp, const float* coef_p,
                                   const float* bcoef_w, const float* bcoef_p, float* dzw, float* dzp, float* dimg,
                                   int dimg_accumulate, long long n_pix, int c, void* stream) {
     if (!dout || !zw || !coef_w || !zp || !coef_p || !bcoef_w || !bcoef_p || !dzw || !dzp || n_pix <= 0) return RCF_EINVAL;
     if (!c4_ok(c)) return RCF_EUNSUPPORTED;
-    hipLaunchKernelGGL(fuse_bwd_apply_kernel, dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, dout, zw, coef_w, zp,
+    hipLaunchKernelGGL((fuse_bwd_apply_kernel<S>), dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, dout, zw, coef_w, zp,
                        coef_p, bcoef_w, bcoef_p, dzw, dzp, dimg, dimg_accumulate, n_pix, c);
     return rcf_launch_status();
 }
@@ -625,7 +625,8 @@ extern "C" int rcf_head_bn_blocks(int n, int h, int w, int c) {
     return (int)(nt < EW_MAX_BLOCKS ? nt : EW_MAX_BLOCKS);
 }
 
-extern "C" int rcf_head_bn_bwd_reduce(const float* dlogit, const float* w_head, const float* z, const float* coef, double* partials,
+template <class S>
+static int head_bn_bwd_reduce_impl(const float* dlogit, const float* w_head, const float* z, const float* coef, double* partials,
                                       int n, int h, int w, int c, void* stream) {
     if (!dlogit || !w_head || !z || !coef || !partials) return RCF_EINVAL;
     const int nb = rcf_head_bn_blocks(n, h, w, c);
@@ -633,7 +634,7 @@ extern "C" int rcf_head_bn_bwd_reduce(const float* dlogit, const float* w_head, 
     const int c4n = c >> 2;
     const size_t lds = (size_t)(256 / c4n) * 2 * c * sizeof(double);
     hipStream_t st = (hipStream_t)stream;
-#define RCF_HBR(N) hipLaunchKernelGGL(head_bn_bwd_reduce_kernel<N>, dim3(nb), dim3(256), lds, st, dlogit, w_head, z, coef, partials, n, h, w)
+#define RCF_HBR(N) hipLaunchKernelGGL((head_bn_bwd_reduce_kernel<N, S>), dim3(nb), dim3(256), lds, st, dlogit, w_head, z, coef, partials, n, h, w)
     switch (c4n) {
         case 1: RCF_HBR(1); break;
         case 2: RCF_HBR(2); break;
@@ -645,13 +646,14 @@ extern "C" int rcf_head_bn_bwd_reduce(const float* dlogit, const float* w_head, 
     return rcf_launch_status();
 }
 
-extern "C" int rcf_head_bn_bwd_apply(const float* dlogit, const float* w_head, const float* z, const float* coef, const float* bcoef,
+template <class S>
+static int head_bn_bwd_apply_impl(const float* dlogit, const float* w_head, const float* z, const float* coef, const float* bcoef,
                                      float* dz, int n, int h, int w, int c, void* stream) {
     if (!dlogit || !w_head || !z || !coef || !bcoef || !dz) return RCF_EINVAL;
     if (rcf_head_bn_blocks(n, h, w, c) <= 0) return RCF_EUNSUPPORTED;
     const unsigned nt = (unsigned)n * ((h + HB_H - 1) / HB_H) * ((w + HB_W - 1) / HB_W);
     hipStream_t st = (hipStream_t)stream;
-#define RCF_HBA(N) hipLaunchKernelGGL(head_bn_bwd_apply_kernel<N>, dim3(nt), dim3(256), 0, st, dlogit, w_head, z, coef, bcoef, dz, n, h, w)
+#define RCF_HBA(N) hipLaunchKernelGGL((head_bn_bwd_apply_kernel<N, S>), dim3(nt), dim3(256), 0, st, dlogit, w_head, z, coef, bcoef, dz, n, h, w)
     switch (c >> 2) {
         case 1: RCF_HBA(1); break;
         case 2: RCF_HBA(2); break;
@@ -662,3 +664,41 @@ extern "C" int rcf_head_bn_bwd_apply(const float* dlogit, const float* w_head, c
 #undef RCF_HBA
     return rcf_launch_status();
 }
+
+// ---- exported instances: NAME for fp32 NHWC tensors, NAME_b16 for bf16 NHWC tensors (same argument lists; see include/rcf_hip.h)
+extern "C" int rcf_bn_act_fwd(const float* z, const float* coef, const float* res, float* out, long long n_pix, int c,
+                              int act, void* stream) { return bn_act_fwd_impl<StF32>(z, coef, res, out, n_pix, c, act, stream); }
+extern "C" int rcf_bn_act_fwd_b16(const float* z, const float* coef, const float* res, float* out, long long n_pix, int c,
+                              int act, void* stream) { return bn_act_fwd_impl<StB16>(z, coef, res, out, n_pix, c, act, stream); }
+extern "C" int rcf_fuse_fwd(const float* zw, const float* coef_w, const float* zp, const float* coef_p, const float* img,
+                            float* out, long long n_pix, int c, void* stream) { return fuse_fwd_impl<StF32>(zw, coef_w, zp, coef_p, img, out, n_pix, c, stream); }
+extern "C" int rcf_fuse_fwd_b16(const float* zw, const float* coef_w, const float* zp, const float* coef_p, const float* img,
+                            float* out, long long n_pix, int c, void* stream) { return fuse_fwd_impl<StB16>(zw, coef_w, zp, coef_p, img, out, n_pix, c, stream); }
+extern "C" int rcf_bn_act_bwd_reduce(const float* dout, const float* z, const float* coef, const float* out, double* partials,
+                                     long long n_pix, int c, int act, int has_res, void* stream) { return bn_act_bwd_reduce_impl<StF32>(dout, z, coef, out, partials, n_pix, c, act, has_res, stream); }
+extern "C" int rcf_bn_act_bwd_reduce_b16(const float* dout, const float* z, const float* coef, const float* out, double* partials,
+                                     long long n_pix, int c, int act, int has_res, void* stream) { return bn_act_bwd_reduce_impl<StB16>(dout, z, coef, out, partials, n_pix, c, act, has_res, stream); }
+extern "C" int rcf_bn_act_bwd_apply(const float* dout, const float* z, const float* coef, const float* out, const float* bcoef,
+                                    float* dz, float* dres, int dres_accumulate, long long n_pix, int c, int act, int has_res,
+                                    void* stream) { return bn_act_bwd_apply_impl<StF32>(dout, z, coef, out, bcoef, dz, dres, dres_accumulate, n_pix, c, act, has_res, stream); }
+extern "C" int rcf_bn_act_bwd_apply_b16(const float* dout, const float* z, const float* coef, const float* out, const float* bcoef,
+                                    float* dz, float* dres, int dres_accumulate, long long n_pix, int c, int act, int has_res,
+                                    void* stream) { return bn_act_bwd_apply_impl<StB16>(dout, z, coef, out, bcoef, dz, dres, dres_accumulate, n_pix, c, act, has_res, stream); }
+extern "C" int rcf_fuse_bwd_reduce(const float* dout, const float* zw, const float* coef_w, const float* zp,
+                                   const float* coef_p, double* partials, long long n_pix, int c, void* stream) { return fuse_bwd_reduce_impl<StF32>(dout, zw, coef_w, zp, coef_p, partials, n_pix, c, stream); }
+extern "C" int rcf_fuse_bwd_reduce_b16(const float* dout, const float* zw, const float* coef_w, const float* zp,
+                                   const float* coef_p, double* partials, long long n_pix, int c, void* stream) { return fuse_bwd_reduce_impl<StB16>(dout, zw, coef_w, zp, coef_p, partials, n_pix, c, stream); }
+extern "C" int rcf_fuse_bwd_apply(const float* dout, const float* zw, const float* coef_w, const float* zp, const float* coef_p,
+                                  const float* bcoef_w, const float* bcoef_p, float* dzw, float* dzp, float* dimg,
+                                  int dimg_accumulate, long long n_pix, int c, void* stream) { return fuse_bwd_apply_impl<StF32>(dout, zw, coef_w, zp, coef_p, bcoef_w, bcoef_p, dzw, dzp, dimg, dimg_accumulate, n_pix, c, stream); }
+extern "C" int rcf_fuse_bwd_apply_b16(const float* dout, const float* zw, const float* coef_w, const float* zp, const float* coef_p,
+                                  const float* bcoef_w, const float* bcoef_p, float* dzw, float* dzp, float* dimg,
+                                  int dimg_accumulate, long long n_pix, int c, void* stream) { return fuse_bwd_apply_impl<StB16>(dout, zw, coef_w, zp, coef_p, bcoef_w, bcoef_p, dzw, dzp, dimg, dimg_accumulate, n_pix, c, stream); }
+extern "C" int rcf_head_bn_bwd_reduce(const float* dlogit, const float* w_head, const float* z, const float* coef, double* partials,
+                                      int n, int h, int w, int c, void* stream) { return head_bn_bwd_reduce_impl<StF32>(dlogit, w_head, z, coef, partials, n, h, w, c, stream); }
+extern "C" int rcf_head_bn_bwd_reduce_b16(const float* dlogit, const float* w_head, const float* z, const float* coef, double* partials,
+                                      int n, int h, int w, int c, void* stream) { return head_bn_bwd_reduce_impl<StB16>(dlogit, w_head, z, coef, partials, n, h, w, c, stream); }
+extern "C" int rcf_head_bn_bwd_apply(const float* dlogit, const float* w_head, const float* z, const float* coef, const float* bcoef,
+                                     float* dz, int n, int h, int w, int c, void* stream) { return head_bn_bwd_apply_impl<StF32>(dlogit, w_head, z, coef, bcoef, dz, n, h, w, c, stream); }
+extern "C" int rcf_head_bn_bwd_apply_b16(const float* dlogit, const float* w_head, const float* z, const float* coef, const float* bcoef,
+                                     float* dz, int n, int h, int w, int c, void* stream) { return head_bn_bwd_apply_impl<StB16>(dlogit, w_head, z, coef, bcoef, dz, n, h, w, c, stream); }

@@ -8,6 +8,7 @@ namespace {
 inline unsigned nblk(long long n, int per) { return (unsigned)((n + per - 1) / per); }
 
 // ---------------------------------------------------------------- MaxPool2d(3, 2, 1)
+template <class S>
 __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                           unsigned char* __restrict__ idx, int n, int h, int w, int c, int ho,
                                                           int wo) {
@@ -30,7 +31,7 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restric
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = ox * 2 - 1 + kx;
                 if (ix < 0 || ix >= w) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((size_t)img * h + iy) * w + ix) * c + cg * 4);
+                const f32x4 v = rcf_ld4<S>(in, (((size_t)img * h + iy) * w + ix) * c + cg * 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (!any || v[j] > best[j] || v[j] != v[j]) { best[j] = v[j]; bi[j] = ky * 3 + kx; }
@@ -39,11 +40,12 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restric
             }
         }
         const size_t o = (((size_t)img * ho + oy) * wo + ox) * c + cg * 4;
-        *reinterpret_cast<f32x4*>(out + o) = best;
+        rcf_st4<S>(out, o, best);
         *reinterpret_cast<unsigned*>(idx + o) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
     }
 }
 
+template <class S>
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ idx,
                                                           float* __restrict__ din, int acc, int n, int h, int w, int c, int ho,
                                                           int wo) {
@@ -67,15 +69,15 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restric
                 const unsigned tap = ky * 3 + (ix - (ox * 2 - 1));
                 const size_t o = (((size_t)img * ho + oy) * wo + ox) * c + cg * 4;
                 const unsigned pk = *reinterpret_cast<const unsigned*>(idx + o);
-                const f32x4 d = *reinterpret_cast<const f32x4*>(dout + o);
+                const f32x4 d = rcf_ld4<S>(dout, o);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (((pk >> (8 * j)) & 0xffu) == tap) s[j] += d[j];
             }
         }
         const size_t i = (((size_t)img * h + iy) * w + ix) * c + cg * 4;
-        if (acc) s += *reinterpret_cast<const f32x4*>(din + i);
-        *reinterpret_cast<f32x4*>(din + i) = s;
+        if (acc) s += rcf_ld4<S>(din, i);
+        rcf_st4<S>(din, i, s);
     }
 }
 
@@ -93,6 +95,7 @@ __device__ __forceinline__ void nearest_range(int s, float scale, int n_src, int
     *hi = d;
 }
 
+template <class S>
 __global__ void __launch_bounds__(256) upsample_bwd_kernel(const float* __restrict__ dup, float* __restrict__ dsrc, int acc,
                                                            int n, int hu, int wu, int hs, int ws, int c, float sy, float sx) {
     const int c4n = c >> 2;
@@ -109,16 +112,17 @@ __global__ void __launch_bounds__(256) upsample_bwd_kernel(const float* __restri
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         for (int yy = y0; yy < y1; ++yy)
             for (int xx = x0; xx < x1; ++xx)
-                s += *reinterpret_cast<const f32x4*>(dup + (((size_t)img * hu + yy) * wu + xx) * c + cg * 4);
+                s += rcf_ld4<S>(dup, (((size_t)img * hu + yy) * wu + xx) * c + cg * 4);
         const size_t i = (((size_t)img * hs + y) * ws + x) * c + cg * 4;
-        if (acc) s += *reinterpret_cast<const f32x4*>(dsrc + i);
-        *reinterpret_cast<f32x4*>(dsrc + i) = s;
+        if (acc) s += rcf_ld4<S>(dsrc, i);
+        rcf_st4<S>(dsrc, i, s);
     }
 }
 
 // ---------------------------------------------------------------- output head: conv3x3 C->1 + depth map
 // One lane per (pixel, 4-channel group): a pixel's C channels are one contiguous run, so each wave load is
 // fully coalesced; the C/4 partial dot products are combined with lane shuffles.
+template <class S>
 __global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
                                                        float* __restrict__ logit, float* __restrict__ depth, int n, int h, int w,
                                                        int c, float dmin, float dmax) {
@@ -148,7 +152,7 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__
                 for (int kx = 0; kx < 3; ++kx) {
                     const int ix = px - 1 + kx;
                     if (ix < 0 || ix >= w) continue;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((img * h + iy) * w + ix) * c + cg * 4);
+                    const f32x4 v = rcf_ld4<S>(x, (size_t)((img * h + iy) * w + ix) * c + cg * 4);
                     const f32x4 k = *reinterpret_cast<const f32x4*>(wl + (ky * 3 + kx) * c + cg * 4);
                     s += v[0] * k[0] + v[1] * k[1] + v[2] * k[2] + v[3] * k[3];
                 }
@@ -171,6 +175,7 @@ __global__ void __launch_bounds__(256) head_bwd_logit_kernel(const float* __rest
     }
 }
 
+template <class S>
 __global__ void __launch_bounds__(256) head_bwd_dgrad_kernel(const float* __restrict__ dl, const float* __restrict__ wgt,
                                                              float* __restrict__ dx, int n, int h, int w, int c) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
@@ -198,7 +203,7 @@ __global__ void __launch_bounds__(256) head_bwd_dgrad_kernel(const float* __rest
                 s += d * *reinterpret_cast<const f32x4*>(wl + (ky * 3 + kx) * c + cg * 4);
             }
         }
-        *reinterpret_cast<f32x4*>(dx + p * c + cg * 4) = s;
+        rcf_st4<S>(dx, (size_t)p * c + cg * 4, s);
     }
 }
 
@@ -231,7 +236,7 @@ __device__ __forceinline__ void head_tile_origin(int tile, int h, int w, int* im
 
 // forward: per halo pixel the nine per-tap dot products T[pixel][tap] = <x[pixel], w[tap]> (x read once, cross-lane sum by DPP),
 // then logit[q] = sum_tap T[q + tap offset][tap] from LDS.
-template <int C4N>
+template <int C4N, class S>
 __global__ void __launch_bounds__(256) head_fwd_tile_kernel(const float* __restrict__ x, const float* __restrict__ coef,
                                                             const float* __restrict__ wgt, float* __restrict__ logit,
                                                             float* __restrict__ depth, int n, int h, int w, float dmin, float dmax) {
@@ -261,7 +266,7 @@ __global__ void __launch_bounds__(256) head_fwd_tile_kernel(const float* __restr
         const int hy = hp / HT_HX, hx = hp - hy * HT_HX;
         const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
         const bool ok = hp < HT_NP && iy >= 0 && iy < h && ix >= 0 && ix < w;
-        f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)img * h + (ok ? iy : 0)) * w + (ok ? ix : 0)) * C + cg * 4);
+        f32x4 v = rcf_ld4<S>(x, (((size_t)img * h + (ok ? iy : 0)) * w + (ok ? ix : 0)) * C + cg * 4);
         if (coef != nullptr) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = rcf_lrelu(v[j] * sc[j] + sh[j]);
@@ -289,7 +294,7 @@ __global__ void __launch_bounds__(256) head_fwd_tile_kernel(const float* __restr
 }
 
 // input gradient: dx[p] = sum_tap dl[p - (ky-1, kx-1)] w[tap]; the dl halo tile sits in LDS, the weights in registers
-template <int C4N>
+template <int C4N, class S>
 __global__ void __launch_bounds__(256) head_bwd_dgrad_tile_kernel(const float* __restrict__ dl, const float* __restrict__ wgt,
                                                                   float* __restrict__ dx, int n, int h, int w) {
     constexpr int C = 4 * C4N;
@@ -318,12 +323,12 @@ __global__ void __launch_bounds__(256) head_bwd_dgrad_tile_kernel(const float* _
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) s += D[(ty + 2 - ky) * HT_HX + tx + 2 - kx] * k[ky * 3 + kx];
-        if (oy < h && ox < w) *reinterpret_cast<f32x4*>(dx + (((size_t)img * h + oy) * w + ox) * C + cg * 4) = s;
+        if (oy < h && ox < w) rcf_st4<S>(dx, (((size_t)img * h + oy) * w + ox) * C + cg * 4, s);
     }
 }
 
 // weight gradient: persistent blocks over tiles; acc[tap] += dl[p - offset] * x[p] with the dl halo tile in LDS
-template <int C4N>
+template <int C4N, class S>
 __global__ void __launch_bounds__(256) head_bwd_wgrad_tile_kernel(const float* __restrict__ x, const float* __restrict__ coef,
                                                                   const float* __restrict__ dl, float* __restrict__ ws, int n, int h,
                                                                   int w) {
@@ -352,7 +357,7 @@ __global__ void __launch_bounds__(256) head_bwd_wgrad_tile_kernel(const float* _
             const int pix = (threadIdx.x + 256 * it) / C4N;
             const int oy = oy0 + pix / HT_W, ox = ox0 + pix % HT_W;
             const bool ok = oy < h && ox < w;
-            v[it] = *reinterpret_cast<const f32x4*>(x + (((size_t)img * h + (ok ? oy : 0)) * w + (ok ? ox : 0)) * C + cg * 4);
+            v[it] = rcf_ld4<S>(x, (((size_t)img * h + (ok ? oy : 0)) * w + (ok ? ox : 0)) * C + cg * 4);
             if (coef != nullptr) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[it][j] = rcf_lrelu(v[it][j] * sc[j] + sh[j]);
@@ -397,6 +402,7 @@ __global__ void __launch_bounds__(256) head_bwd_wgrad_tile_kernel(const float* _
 
 constexpr int HEAD_WG_BLOCKS = 1024;
 
+template <class S>
 __global__ void __launch_bounds__(256) head_bwd_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dl,
                                                              float* __restrict__ ws, int n, int h, int w, int c) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -414,7 +420,7 @@ __global__ void __launch_bounds__(256) head_bwd_wgrad_kernel(const float* __rest
         const int px = p % w;
         const int py = (p / w) % h;
         const long long img = p / ((long long)w * h);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + p * c + cg * 4);
+        const f32x4 v = rcf_ld4<S>(x, (size_t)p * c + cg * 4);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int qy = py + 1 - ky;
@@ -644,35 +650,38 @@ __global__ void __launch_bounds__(256) radar_scatter_kernel(const float* __restr
 
 }   // namespace
 
-extern "C" int rcf_maxpool3x3s2_fwd(const float* in, float* out, unsigned char* idx, int n, int h, int w, int c, void* stream) {
+template <class S>
+static int maxpool3x3s2_fwd_impl(const float* in, float* out, unsigned char* idx, int n, int h, int w, int c, void* stream) {
     if (!in || !out || !idx || n <= 0 || h <= 0 || w <= 0 || c <= 0) return RCF_EINVAL;
     if (c & 3) return RCF_EUNSUPPORTED;
     const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
     const long long total = (long long)n * ho * wo * (c >> 2);
     unsigned b = nblk(total, 256); if (b > 8192) b = 8192;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, in, out, idx, n, h, w, c, ho, wo);
+    hipLaunchKernelGGL((maxpool_fwd_kernel<S>), dim3(b), dim3(256), 0, (hipStream_t)stream, in, out, idx, n, h, w, c, ho, wo);
     return rcf_launch_status();
 }
 
-extern "C" int rcf_maxpool3x3s2_bwd(const float* dout, const unsigned char* idx, float* din, int din_accumulate, int n, int h,
+template <class S>
+static int maxpool3x3s2_bwd_impl(const float* dout, const unsigned char* idx, float* din, int din_accumulate, int n, int h,
                                     int w, int c, void* stream) {
     if (!dout || !idx || !din || n <= 0 || h <= 0 || w <= 0 || c <= 0) return RCF_EINVAL;
     if (c & 3) return RCF_EUNSUPPORTED;
     const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
     const long long total = (long long)n * h * w * (c >> 2);
     unsigned b = nblk(total, 256); if (b > 8192) b = 8192;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, dout, idx, din, din_accumulate, n, h, w, c,
+    hipLaunchKernelGGL((maxpool_bwd_kernel<S>), dim3(b), dim3(256), 0, (hipStream_t)stream, dout, idx, din, din_accumulate, n, h, w, c,
                        ho, wo);
     return rcf_launch_status();
 }
 
-extern "C" int rcf_upsample_nearest_bwd(const float* dup, float* dsrc, int dsrc_accumulate, int n, int h_up, int w_up,
+template <class S>
+static int upsample_nearest_bwd_impl(const float* dup, float* dsrc, int dsrc_accumulate, int n, int h_up, int w_up,
                                         int h_src, int w_src, int c, void* stream) {
     if (!dup || !dsrc || n <= 0 || h_up <= 0 || w_up <= 0 || h_src <= 0 || w_src <= 0 || c <= 0) return RCF_EINVAL;
     if (c & 3) return RCF_EUNSUPPORTED;
     const long long total = (long long)n * h_src * w_src * (c >> 2);
     unsigned b = nblk(total, 256); if (b > 8192) b = 8192;
-    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, dup, dsrc, dsrc_accumulate, n, h_up, w_up,
+    hipLaunchKernelGGL((upsample_bwd_kernel<S>), dim3(b), dim3(256), 0, (hipStream_t)stream, dup, dsrc, dsrc_accumulate, n, h_up, w_up,
                        h_src, w_src, c, (float)h_src / (float)h_up, (float)w_src / (float)w_up);
     return rcf_launch_status();
 }
@@ -683,21 +692,25 @@ static bool head_c_ok(int c) {
     return (c4 & (c4 - 1)) == 0 && c4 <= 64;
 }
 
-static int head_fwd_impl(const float* x, const float* coef, const float* w, float* logit, float* depth, int n, int h, int w_, int c,
+template <class S>
+static int head_fwd_core(const float* x, const float* coef, const float* w, float* logit, float* depth, int n, int h, int w_, int c,
                          float min_depth, float max_depth, void* stream);
 
-extern "C" int rcf_head_fwd(const float* x, const float* w, float* logit, float* depth, int n, int h, int w_, int c,
+template <class S>
+static int head_fwd_impl(const float* x, const float* w, float* logit, float* depth, int n, int h, int w_, int c,
                             float min_depth, float max_depth, void* stream) {
-    return head_fwd_impl(x, nullptr, w, logit, depth, n, h, w_, c, min_depth, max_depth, stream);
+    return head_fwd_core<S>(x, nullptr, w, logit, depth, n, h, w_, c, min_depth, max_depth, stream);
 }
 
-extern "C" int rcf_head_fwd_bn(const float* z, const float* coef, const float* w, float* logit, float* depth, int n, int h, int w_,
+template <class S>
+static int head_fwd_bn_impl(const float* z, const float* coef, const float* w, float* logit, float* depth, int n, int h, int w_,
                                int c, float min_depth, float max_depth, void* stream) {
     if (!coef || (c >> 2) > 16) return coef ? RCF_EUNSUPPORTED : RCF_EINVAL;
-    return head_fwd_impl(z, coef, w, logit, depth, n, h, w_, c, min_depth, max_depth, stream);
+    return head_fwd_core<S>(z, coef, w, logit, depth, n, h, w_, c, min_depth, max_depth, stream);
 }
 
-static int head_fwd_impl(const float* x, const float* coef, const float* w, float* logit, float* depth, int n, int h, int w_, int c,
+template <class S>
+static int head_fwd_core(const float* x, const float* coef, const float* w, float* logit, float* depth, int n, int h, int w_, int c,
                          float min_depth, float max_depth, void* stream) {
     if (!x || !w || !logit || !depth || n <= 0 || h <= 0 || w_ <= 0) return RCF_EINVAL;
     if (!head_c_ok(c)) return RCF_EUNSUPPORTED;
@@ -705,7 +718,7 @@ static int head_fwd_impl(const float* x, const float* coef, const float* w, floa
     if (c4n <= 16) {
         const unsigned nt = (unsigned)n * ((h + HT_H - 1) / HT_H) * ((w_ + HT_W - 1) / HT_W);
         hipStream_t st = (hipStream_t)stream;
-#define RCF_HEAD_FWD(N) hipLaunchKernelGGL(head_fwd_tile_kernel<N>, dim3(nt), dim3(256), 0, st, x, coef, w, logit, depth, n, h, w_, min_depth, max_depth)
+#define RCF_HEAD_FWD(N) hipLaunchKernelGGL((head_fwd_tile_kernel<N, S>), dim3(nt), dim3(256), 0, st, x, coef, w, logit, depth, n, h, w_, min_depth, max_depth)
         switch (c4n) {
             case 1: RCF_HEAD_FWD(1); break;
             case 2: RCF_HEAD_FWD(2); break;
@@ -718,7 +731,7 @@ static int head_fwd_impl(const float* x, const float* coef, const float* w, floa
     }
     const long long total = (long long)n * h * w_ * (c >> 2);
     unsigned b = nblk(total, 256); if (b > 16384) b = 16384;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(b), dim3(256), 9 * c * sizeof(float), (hipStream_t)stream, x, w, logit, depth, n, h,
+    hipLaunchKernelGGL((head_fwd_kernel<S>), dim3(b), dim3(256), 9 * c * sizeof(float), (hipStream_t)stream, x, w, logit, depth, n, h,
                        w_, c, min_depth, max_depth);
     return rcf_launch_status();
 }
@@ -732,14 +745,15 @@ extern "C" int rcf_head_bwd_logit(const float* ddepth, const float* logit, float
     return rcf_launch_status();
 }
 
-extern "C" int rcf_head_bwd_dgrad(const float* dlogit, const float* w, float* dx, int n, int h, int w_, int c, void* stream) {
+template <class S>
+static int head_bwd_dgrad_impl(const float* dlogit, const float* w, float* dx, int n, int h, int w_, int c, void* stream) {
     if (!dlogit || !w || !dx || n <= 0 || h <= 0 || w_ <= 0) return RCF_EINVAL;
     if (!head_c_ok(c)) return RCF_EUNSUPPORTED;
     const int c4n = c >> 2;
     if (c4n <= 16) {
         const unsigned nt = (unsigned)n * ((h + HT_H - 1) / HT_H) * ((w_ + HT_W - 1) / HT_W);
         hipStream_t st = (hipStream_t)stream;
-#define RCF_HEAD_DG(N) hipLaunchKernelGGL(head_bwd_dgrad_tile_kernel<N>, dim3(nt), dim3(256), 0, st, dlogit, w, dx, n, h, w_)
+#define RCF_HEAD_DG(N) hipLaunchKernelGGL((head_bwd_dgrad_tile_kernel<N, S>), dim3(nt), dim3(256), 0, st, dlogit, w, dx, n, h, w_)
         switch (c4n) {
             case 1: RCF_HEAD_DG(1); break;
             case 2: RCF_HEAD_DG(2); break;
@@ -752,7 +766,7 @@ extern "C" int rcf_head_bwd_dgrad(const float* dlogit, const float* w, float* dx
     }
     const long long total = (long long)n * h * w_ * (c >> 2);
     unsigned b = nblk(total, 256); if (b > 16384) b = 16384;
-    hipLaunchKernelGGL(head_bwd_dgrad_kernel, dim3(b), dim3(256), 9 * c * sizeof(float), (hipStream_t)stream, dlogit, w, dx, n, h,
+    hipLaunchKernelGGL((head_bwd_dgrad_kernel<S>), dim3(b), dim3(256), 9 * c * sizeof(float), (hipStream_t)stream, dlogit, w, dx, n, h,
                        w_, c);
     return rcf_launch_status();
 }
@@ -762,21 +776,25 @@ extern "C" size_t rcf_head_wgrad_workspace_floats(int n, int h, int w_, int c) {
     return (size_t)HEAD_WG_BLOCKS * 9 * (size_t)c;
 }
 
-static int head_bwd_wgrad_impl(const float* x, const float* coef, const float* dlogit, float* dw, float* workspace, int n, int h,
+template <class S>
+static int head_bwd_wgrad_core(const float* x, const float* coef, const float* dlogit, float* dw, float* workspace, int n, int h,
                                int w_, int c, void* stream);
 
-extern "C" int rcf_head_bwd_wgrad(const float* x, const float* dlogit, float* dw, float* workspace, int n, int h, int w_, int c,
+template <class S>
+static int head_bwd_wgrad_impl(const float* x, const float* dlogit, float* dw, float* workspace, int n, int h, int w_, int c,
                                   void* stream) {
-    return head_bwd_wgrad_impl(x, nullptr, dlogit, dw, workspace, n, h, w_, c, stream);
+    return head_bwd_wgrad_core<S>(x, nullptr, dlogit, dw, workspace, n, h, w_, c, stream);
 }
 
-extern "C" int rcf_head_bwd_wgrad_bn(const float* z, const float* coef, const float* dlogit, float* dw, float* workspace, int n,
+template <class S>
+static int head_bwd_wgrad_bn_impl(const float* z, const float* coef, const float* dlogit, float* dw, float* workspace, int n,
                                      int h, int w_, int c, void* stream) {
     if (!coef || (c >> 2) > 16) return coef ? RCF_EUNSUPPORTED : RCF_EINVAL;
-    return head_bwd_wgrad_impl(z, coef, dlogit, dw, workspace, n, h, w_, c, stream);
+    return head_bwd_wgrad_core<S>(z, coef, dlogit, dw, workspace, n, h, w_, c, stream);
 }
 
-static int head_bwd_wgrad_impl(const float* x, const float* coef, const float* dlogit, float* dw, float* workspace, int n, int h,
+template <class S>
+static int head_bwd_wgrad_core(const float* x, const float* coef, const float* dlogit, float* dw, float* workspace, int n, int h,
                                int w_, int c, void* stream) {
     if (!x || !dlogit || !dw || !workspace || n <= 0 || h <= 0 || w_ <= 0) return RCF_EINVAL;
     if (!head_c_ok(c)) return RCF_EUNSUPPORTED;
@@ -790,7 +808,7 @@ static int head_bwd_wgrad_impl(const float* x, const float* coef, const float* d
         size_t lds = (size_t)ppb * 9 * c * sizeof(float);
         if (lds < HT_NP * sizeof(float)) lds = HT_NP * sizeof(float);
         hipStream_t st = (hipStream_t)stream;
-#define RCF_HEAD_WG(N) hipLaunchKernelGGL(head_bwd_wgrad_tile_kernel<N>, dim3((unsigned)nb), dim3(256), lds, st, x, coef, dlogit, workspace, n, h, w_)
+#define RCF_HEAD_WG(N) hipLaunchKernelGGL((head_bwd_wgrad_tile_kernel<N, S>), dim3((unsigned)nb), dim3(256), lds, st, x, coef, dlogit, workspace, n, h, w_)
         switch (c4n) {
             case 1: RCF_HEAD_WG(1); break;
             case 2: RCF_HEAD_WG(2); break;
@@ -800,7 +818,7 @@ static int head_bwd_wgrad_impl(const float* x, const float* coef, const float* d
         }
 #undef RCF_HEAD_WG
     } else
-    hipLaunchKernelGGL(head_bwd_wgrad_kernel, dim3((unsigned)nb), dim3(256), (size_t)ppb * 9 * c * sizeof(float),
+    hipLaunchKernelGGL((head_bwd_wgrad_kernel<S>), dim3((unsigned)nb), dim3(256), (size_t)ppb * 9 * c * sizeof(float),
                        (hipStream_t)stream, x, dlogit, workspace, n, h, w_, c);
     int rc = rcf_launch_status();
     if (rc != RCF_OK) return rc;
@@ -926,3 +944,60 @@ extern "C" int rcf_scale_channels(const float* w, const float* scale, float* out
                        n_out, inner);
     return rcf_launch_status();
 }
+
+// ---- element type conversion between the two storages (fp32 <-> bf16, round to nearest even), optionally accumulating into dst
+namespace {
+template <class SS, class SD>
+__global__ void __launch_bounds__(256) convert_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n, int acc) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v = rcf_ld1<SS>(src, (size_t)i);
+        if (acc) v += rcf_ld1<SD>(dst, (size_t)i);
+        rcf_st1<SD>(dst, (size_t)i, v);
+    }
+}
+}   // namespace
+
+extern "C" int rcf_convert(const void* src, int src_storage, void* dst, int dst_storage, long long n, int accumulate, void* stream) {
+    if (!src || !dst || n <= 0) return RCF_EINVAL;
+    if ((src_storage != RCF_STORE_FP32 && src_storage != RCF_STORE_BF16) || (dst_storage != RCF_STORE_FP32 && dst_storage != RCF_STORE_BF16))
+        return RCF_EINVAL;
+    unsigned b = nblk(n, 256); if (b > 16384) b = 16384;
+    hipStream_t st = (hipStream_t)stream;
+    const float* s = (const float*)src;
+    float* d = (float*)dst;
+    if (src_storage == RCF_STORE_FP32 && dst_storage == RCF_STORE_BF16) hipLaunchKernelGGL((convert_kernel<StF32, StB16>), dim3(b), dim3(256), 0, st, s, d, n, accumulate);
+    else if (src_storage == RCF_STORE_BF16 && dst_storage == RCF_STORE_FP32) hipLaunchKernelGGL((convert_kernel<StB16, StF32>), dim3(b), dim3(256), 0, st, s, d, n, accumulate);
+    else if (src_storage == RCF_STORE_BF16) hipLaunchKernelGGL((convert_kernel<StB16, StB16>), dim3(b), dim3(256), 0, st, s, d, n, accumulate);
+    else hipLaunchKernelGGL((convert_kernel<StF32, StF32>), dim3(b), dim3(256), 0, st, s, d, n, accumulate);
+    return rcf_launch_status();
+}
+
+// ---- exported instances: NAME for fp32 NHWC tensors, NAME_b16 for bf16 NHWC tensors (same argument lists; see include/rcf_hip.h)
+extern "C" int rcf_maxpool3x3s2_fwd(const float* in, float* out, unsigned char* idx, int n, int h, int w, int c, void* stream) { return maxpool3x3s2_fwd_impl<StF32>(in, out, idx, n, h, w, c, stream); }
+extern "C" int rcf_maxpool3x3s2_fwd_b16(const float* in, float* out, unsigned char* idx, int n, int h, int w, int c, void* stream) { return maxpool3x3s2_fwd_impl<StB16>(in, out, idx, n, h, w, c, stream); }
+extern "C" int rcf_maxpool3x3s2_bwd(const float* dout, const unsigned char* idx, float* din, int din_accumulate, int n, int h,
+                                    int w, int c, void* stream) { return maxpool3x3s2_bwd_impl<StF32>(dout, idx, din, din_accumulate, n, h, w, c, stream); }
+extern "C" int rcf_maxpool3x3s2_bwd_b16(const float* dout, const unsigned char* idx, float* din, int din_accumulate, int n, int h,
+                                    int w, int c, void* stream) { return maxpool3x3s2_bwd_impl<StB16>(dout, idx, din, din_accumulate, n, h, w, c, stream); }
+extern "C" int rcf_upsample_nearest_bwd(const float* dup, float* dsrc, int dsrc_accumulate, int n, int h_up, int w_up,
+                                        int h_src, int w_src, int c, void* stream) { return upsample_nearest_bwd_impl<StF32>(dup, dsrc, dsrc_accumulate, n, h_up, w_up, h_src, w_src, c, stream); }
+extern "C" int rcf_upsample_nearest_bwd_b16(const float* dup, float* dsrc, int dsrc_accumulate, int n, int h_up, int w_up,
+                                        int h_src, int w_src, int c, void* stream) { return upsample_nearest_bwd_impl<StB16>(dup, dsrc, dsrc_accumulate, n, h_up, w_up, h_src, w_src, c, stream); }
+extern "C" int rcf_head_fwd(const float* x, const float* w, float* logit, float* depth, int n, int h, int w_, int c,
+                            float min_depth, float max_depth, void* stream) { return head_fwd_impl<StF32>(x, w, logit, depth, n, h, w_, c, min_depth, max_depth, stream); }
+extern "C" int rcf_head_fwd_b16(const float* x, const float* w, float* logit, float* depth, int n, int h, int w_, int c,
+                            float min_depth, float max_depth, void* stream) { return head_fwd_impl<StB16>(x, w, logit, depth, n, h, w_, c, min_depth, max_depth, stream); }
+extern "C" int rcf_head_fwd_bn(const float* z, const float* coef, const float* w, float* logit, float* depth, int n, int h, int w_,
+                               int c, float min_depth, float max_depth, void* stream) { return head_fwd_bn_impl<StF32>(z, coef, w, logit, depth, n, h, w_, c, min_depth, max_depth, stream); }
+extern "C" int rcf_head_fwd_bn_b16(const float* z, const float* coef, const float* w, float* logit, float* depth, int n, int h, int w_,
+                               int c, float min_depth, float max_depth, void* stream) { return head_fwd_bn_impl<StB16>(z, coef, w, logit, depth, n, h, w_, c, min_depth, max_depth, stream); }
+extern "C" int rcf_head_bwd_dgrad(const float* dlogit, const float* w, float* dx, int n, int h, int w_, int c, void* stream) { return head_bwd_dgrad_impl<StF32>(dlogit, w, dx, n, h, w_, c, stream); }
+extern "C" int rcf_head_bwd_dgrad_b16(const float* dlogit, const float* w, float* dx, int n, int h, int w_, int c, void* stream) { return head_bwd_dgrad_impl<StB16>(dlogit, w, dx, n, h, w_, c, stream); }
+extern "C" int rcf_head_bwd_wgrad(const float* x, const float* dlogit, float* dw, float* workspace, int n, int h, int w_, int c,
+                                  void* stream) { return head_bwd_wgrad_impl<StF32>(x, dlogit, dw, workspace, n, h, w_, c, stream); }
+extern "C" int rcf_head_bwd_wgrad_b16(const float* x, const float* dlogit, float* dw, float* workspace, int n, int h, int w_, int c,
+                                  void* stream) { return head_bwd_wgrad_impl<StB16>(x, dlogit, dw, workspace, n, h, w_, c, stream); }
+extern "C" int rcf_head_bwd_wgrad_bn(const float* z, const float* coef, const float* dlogit, float* dw, float* workspace, int n,
+                                     int h, int w_, int c, void* stream) { return head_bwd_wgrad_bn_impl<StF32>(z, coef, dlogit, dw, workspace, n, h, w_, c, stream); }
+extern "C" int rcf_head_bwd_wgrad_bn_b16(const float* z, const float* coef, const float* dlogit, float* dw, float* workspace, int n,
+                                     int h, int w_, int c, void* stream) { return head_bwd_wgrad_bn_impl<StB16>(z, coef, dlogit, dw, workspace, n, h, w_, c, stream); }

@@ -17,6 +17,7 @@ namespace {
 // ---------------------------------------------------------------- ROI max pooling
 // One thread per (roi, ph, pw, channel quad).  in: (N, H, W, C); rois: (R, 5) = (batch index, x1, y1, x2, y2);
 // out: (R, PH, PW, out_cstride) at channel offset out_coff; argmax: (R, PH, PW, C) int32 = y * W + x of the maximum (-1: empty).
+template <class S>
 __global__ void __launch_bounds__(256) roi_pool_fwd_kernel(const float* __restrict__ in, const float* __restrict__ rois,
                                                            float* __restrict__ out, int* __restrict__ argmax, int n_roi, int h, int w,
                                                            int c, int ph_n, int pw_n, float scale, int out_cstride, int out_coff) {
@@ -43,19 +44,20 @@ __global__ void __launch_bounds__(256) roi_pool_fwd_kernel(const float* __restri
         int am[4] = {-1, -1, -1, -1};
         for (int y = hs; y < he; ++y)
             for (int x = ws; x < we; ++x) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((size_t)b * h + y) * w + x) * c + cg * 4);
+                const f32x4 v = rcf_ld4<S>(in, (((size_t)b * h + y) * w + x) * c + cg * 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (v[j] > m[j]) { m[j] = v[j]; am[j] = y * w + x; }
             }
         const size_t o = ((size_t)r * ph_n + ph) * pw_n + pw;
-        *reinterpret_cast<f32x4*>(out + o * out_cstride + out_coff + cg * 4) = m;
+        rcf_st4<S>(out, o * out_cstride + out_coff + cg * 4, m);
 #pragma unroll
         for (int j = 0; j < 4; ++j) argmax[o * c + cg * 4 + j] = am[j];
     }
 }
 
 // din (N, H, W, C) must be zeroed by the caller (or hold an earlier contribution): rois overlap, so this is a scatter-add.
+template <class S>
 __global__ void __launch_bounds__(256) roi_pool_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ argmax,
                                                            const float* __restrict__ rois, float* __restrict__ din, int n_roi, int h,
                                                            int w, int c, int ph_n, int pw_n, int dout_cstride, int dout_coff) {
@@ -67,7 +69,7 @@ __global__ void __launch_bounds__(256) roi_pool_bwd_kernel(const float* __restri
         const int a = argmax[g];
         if (a < 0) continue;
         const int b = (int)rois[(size_t)r * 5];
-        atomicAdd(din + ((size_t)b * h * w + a) * c + ch, dout[o * dout_cstride + dout_coff + ch]);
+        atomicAdd(din + ((size_t)b * h * w + a) * c + ch, rcf_ld1<S>(dout, o * dout_cstride + dout_coff + ch));   // din is fp32 for either storage
     }
 }
 
@@ -83,7 +85,7 @@ __device__ __forceinline__ size_t fc_addr(int m, int f, int n_out, int hw, int c
     return ((size_t)m * hw + p) * cstride + coff + cch;
 }
 
-template <int MB>
+template <int MB, class S>
 __global__ void __launch_bounds__(256) fc_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
                                                      const float* __restrict__ bias, float* __restrict__ y, int m_rows, int n_in,
                                                      int n_out, int act, int hw, int cstride, int coff) {
@@ -108,12 +110,12 @@ __global__ void __launch_bounds__(256) fc_fwd_kernel(const float* __restrict__ x
         if (m < m_rows) {
             float v = acc[m] + bv;
             if (act) v = rcf_lrelu(v);
-            y[fc_addr(m, f, n_out, hw, cstride, coff)] = v;
+            rcf_st1<S>(y, fc_addr(m, f, n_out, hw, cstride, coff), v);
         }
 }
 
 // Backward: g = dy * lrelu'(y); dW[f][k] = sum_m g[m][f] x[m][k]; db[f] = sum_m g[m][f] (one thread per output feature).
-template <int MB>
+template <int MB, class S>
 __global__ void __launch_bounds__(256) fc_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                      const float* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db,
                                                      int m_rows, int n_in, int n_out, int act, int hw, int cstride, int coff,
@@ -130,7 +132,7 @@ __global__ void __launch_bounds__(256) fc_bwd_kernel(const float* __restrict__ x
         g[m] = 0.f;
         if (m < m_rows) {
             const size_t a = fc_addr(m, f, n_out, hw, cstride, coff);
-            g[m] = dy[a] * (act ? rcf_lrelu_grad(y[a]) : 1.f);
+            g[m] = rcf_ld1<S>(dy, a) * (act ? rcf_lrelu_grad(rcf_ld1<S>(y, a)) : 1.f);
             gs += g[m];
         }
     }
@@ -146,6 +148,7 @@ __global__ void __launch_bounds__(256) fc_bwd_kernel(const float* __restrict__ x
 
 // Input gradient dx[m][k] = sum_f g[m][f] W[f][k]: a block takes 256 features, keeps their g in LDS and accumulates its partial
 // [m][k] (thread owns column k = t % n_in... of rows m = t / n_in + j * rows_per_pass); partials are summed by fc_dx_reduce_kernel.
+template <class S>
 __global__ void __launch_bounds__(256) fc_dx_partial_kernel(const float* __restrict__ wgt, const float* __restrict__ y,
                                                             const float* __restrict__ dy, float* __restrict__ part, int m_rows,
                                                             int n_in, int n_out, int act, int hw, int cstride, int coff) {
@@ -157,7 +160,7 @@ __global__ void __launch_bounds__(256) fc_dx_partial_kernel(const float* __restr
         float g = 0.f;
         if (f < n_out) {
             const size_t a = fc_addr(m, f, n_out, hw, cstride, coff);
-            g = dy[a] * (act ? rcf_lrelu_grad(y[a]) : 1.f);
+            g = rcf_ld1<S>(dy, a) * (act ? rcf_lrelu_grad(rcf_ld1<S>(y, a)) : 1.f);
         }
         gs[i] = g;
     }
@@ -243,29 +246,32 @@ unsigned grid_for(long long n, unsigned cap) {
 
 }   // namespace
 
-extern "C" int rcf_roi_pool_fwd(const float* in, const float* rois, float* out, int* argmax, int n_roi, int n, int h, int w, int c,
+template <class S>
+static int roi_pool_fwd_impl(const float* in, const float* rois, float* out, int* argmax, int n_roi, int n, int h, int w, int c,
                                 int pooled_h, int pooled_w, float spatial_scale, int out_cstride, int out_coff, void* stream) {
     if (!in || !rois || !out || !argmax || n_roi <= 0 || n <= 0 || h <= 0 || w <= 0 || pooled_h <= 0 || pooled_w <= 0) return RCF_EINVAL;
     if (c < 4 || (c & 3) || out_cstride < out_coff + c || (out_cstride & 3) || (out_coff & 3)) return RCF_EUNSUPPORTED;
     const long long total = (long long)n_roi * pooled_h * pooled_w * (c >> 2);
-    hipLaunchKernelGGL(roi_pool_fwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, in, rois, out, argmax, n_roi,
+    hipLaunchKernelGGL((roi_pool_fwd_kernel<S>), dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, in, rois, out, argmax, n_roi,
                        h, w, c, pooled_h, pooled_w, spatial_scale, out_cstride, out_coff);
     return rcf_launch_status();
 }
 
-extern "C" int rcf_roi_pool_bwd(const float* dout, const int* argmax, const float* rois, float* din, int n_roi, int n, int h, int w,
+template <class S>
+static int roi_pool_bwd_impl(const float* dout, const int* argmax, const float* rois, float* din, int n_roi, int n, int h, int w,
                                 int c, int pooled_h, int pooled_w, int dout_cstride, int dout_coff, void* stream) {
     if (!dout || !argmax || !rois || !din || n_roi <= 0 || n <= 0 || h <= 0 || w <= 0 || pooled_h <= 0 || pooled_w <= 0) return RCF_EINVAL;
     if (c <= 0 || dout_cstride < dout_coff + c) return RCF_EUNSUPPORTED;
     const long long total = (long long)n_roi * pooled_h * pooled_w * c;
-    hipLaunchKernelGGL(roi_pool_bwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dout, argmax, rois, din,
+    hipLaunchKernelGGL((roi_pool_bwd_kernel<S>), dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dout, argmax, rois, din,
                        n_roi, h, w, c, pooled_h, pooled_w, dout_cstride, dout_coff);
     return rcf_launch_status();
 }
 
 // Rows are processed in blocks of at most FC_MAX_M (the per-thread accumulator count): a frame may carry any number of radar
 // points (pipeline.radarnet_forward runs every point of a frame through one call, like src/radarnet_main.py:534-561).
-extern "C" int rcf_fc_fwd(const float* x, const float* w, const float* bias, float* y, int m_rows, int n_in, int n_out, int act,
+template <class S>
+static int fc_fwd_impl(const float* x, const float* w, const float* bias, float* y, int m_rows, int n_in, int n_out, int act,
                           int hw, int cstride, int coff, void* stream) {
     if (!x || !w || !bias || !y || m_rows <= 0 || n_in <= 0 || n_out <= 0) return RCF_EINVAL;
     if ((size_t)FC_MAX_M * n_in * 4 > 48 * 1024 || (hw > 1 && (n_out % hw != 0 || cstride < coff + n_out / hw))) return RCF_EUNSUPPORTED;
@@ -276,10 +282,10 @@ extern "C" int rcf_fc_fwd(const float* x, const float* w, const float* bias, flo
         const int mb = m_rows - m0 < FC_MAX_M ? m_rows - m0 : FC_MAX_M;
         const size_t lds = (size_t)mb * n_in * sizeof(float);
         const float* xb = x + (size_t)m0 * n_in;
-        float* yb = y + (size_t)m0 * ystride;
-        if (mb <= 16) hipLaunchKernelGGL(fc_fwd_kernel<16>, dim3(nb), dim3(256), lds, st, xb, w, bias, yb, mb, n_in, n_out, act, hw, cstride, coff);
-        else if (mb <= 32) hipLaunchKernelGGL(fc_fwd_kernel<32>, dim3(nb), dim3(256), lds, st, xb, w, bias, yb, mb, n_in, n_out, act, hw, cstride, coff);
-        else hipLaunchKernelGGL(fc_fwd_kernel<64>, dim3(nb), dim3(256), lds, st, xb, w, bias, yb, mb, n_in, n_out, act, hw, cstride, coff);
+        float* yb = const_cast<float*>(rcf_at_host<S>(y, (size_t)m0 * ystride));
+        if (mb <= 16) hipLaunchKernelGGL((fc_fwd_kernel<16, S>), dim3(nb), dim3(256), lds, st, xb, w, bias, yb, mb, n_in, n_out, act, hw, cstride, coff);
+        else if (mb <= 32) hipLaunchKernelGGL((fc_fwd_kernel<32, S>), dim3(nb), dim3(256), lds, st, xb, w, bias, yb, mb, n_in, n_out, act, hw, cstride, coff);
+        else hipLaunchKernelGGL((fc_fwd_kernel<64, S>), dim3(nb), dim3(256), lds, st, xb, w, bias, yb, mb, n_in, n_out, act, hw, cstride, coff);
     }
     return rcf_launch_status();
 }
@@ -289,7 +295,8 @@ extern "C" size_t rcf_fc_bwd_workspace_floats(int m_rows, int n_in, int n_out) {
     return (size_t)((n_out + 255) / 256) * m_rows * n_in;
 }
 
-extern "C" int rcf_fc_bwd(const float* x, const float* w, const float* y, const float* dy, float* dw, float* db, float* dx,
+template <class S>
+static int fc_bwd_impl(const float* x, const float* w, const float* y, const float* dy, float* dw, float* db, float* dx,
                           float* workspace, int m_rows, int n_in, int n_out, int act, int hw, int cstride, int coff, void* stream) {
     if (!x || !w || !y || !dy || !dw || !db || m_rows <= 0 || n_in <= 0 || n_out <= 0) return RCF_EINVAL;
     if (dx && !workspace) return RCF_EINVAL;
@@ -300,7 +307,7 @@ extern "C" int rcf_fc_bwd(const float* x, const float* w, const float* y, const 
     if (dx) {
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_dx_partial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_dx_partial_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       256 * FC_MAX_M * (int)sizeof(float));
             attr_done = true;
         }
@@ -310,15 +317,15 @@ extern "C" int rcf_fc_bwd(const float* x, const float* w, const float* y, const 
         const int mb = m_rows - m0 < FC_MAX_M ? m_rows - m0 : FC_MAX_M;
         const size_t lds = (size_t)mb * n_in * sizeof(float);
         const float* xb = x + (size_t)m0 * n_in;
-        const float* yb = y + (size_t)m0 * ystride;
-        const float* dyb = dy + (size_t)m0 * ystride;
+        const float* yb = rcf_at_host<S>(y, (size_t)m0 * ystride);
+        const float* dyb = rcf_at_host<S>(dy, (size_t)m0 * ystride);
         const int acc = m0 > 0 ? 1 : 0;
-        if (mb <= 16) hipLaunchKernelGGL(fc_bwd_kernel<16>, dim3(nb), dim3(256), lds, st, xb, yb, dyb, dw, db, mb, n_in, n_out, act, hw, cstride, coff, acc);
-        else if (mb <= 32) hipLaunchKernelGGL(fc_bwd_kernel<32>, dim3(nb), dim3(256), lds, st, xb, yb, dyb, dw, db, mb, n_in, n_out, act, hw, cstride, coff, acc);
-        else hipLaunchKernelGGL(fc_bwd_kernel<64>, dim3(nb), dim3(256), lds, st, xb, yb, dyb, dw, db, mb, n_in, n_out, act, hw, cstride, coff, acc);
+        if (mb <= 16) hipLaunchKernelGGL((fc_bwd_kernel<16, S>), dim3(nb), dim3(256), lds, st, xb, yb, dyb, dw, db, mb, n_in, n_out, act, hw, cstride, coff, acc);
+        else if (mb <= 32) hipLaunchKernelGGL((fc_bwd_kernel<32, S>), dim3(nb), dim3(256), lds, st, xb, yb, dyb, dw, db, mb, n_in, n_out, act, hw, cstride, coff, acc);
+        else hipLaunchKernelGGL((fc_bwd_kernel<64, S>), dim3(nb), dim3(256), lds, st, xb, yb, dyb, dw, db, mb, n_in, n_out, act, hw, cstride, coff, acc);
         if (dx) {
             float* wsb = workspace + (size_t)nb * m0 * n_in;
-            hipLaunchKernelGGL(fc_dx_partial_kernel, dim3(nb), dim3(256), (size_t)256 * mb * sizeof(float), st, w, yb, dyb, wsb, mb,
+            hipLaunchKernelGGL((fc_dx_partial_kernel<S>), dim3(nb), dim3(256), (size_t)256 * mb * sizeof(float), st, w, yb, dyb, wsb, mb,
                                n_in, n_out, act, hw, cstride, coff);
             const int n = mb * n_in;
             hipLaunchKernelGGL(fc_dx_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, wsb, dx + (size_t)m0 * n_in, (int)nb, n);
@@ -346,3 +353,21 @@ extern "C" int rcf_bce_loss_bwd(const float* logit, const float* target, const f
                        dlogit, n, pos_weight);
     return rcf_launch_status();
 }
+
+// ---- exported instances: NAME for fp32 NHWC tensors, NAME_b16 for bf16 NHWC tensors (same argument lists; see include/rcf_hip.h)
+extern "C" int rcf_roi_pool_fwd(const float* in, const float* rois, float* out, int* argmax, int n_roi, int n, int h, int w, int c,
+                                int pooled_h, int pooled_w, float spatial_scale, int out_cstride, int out_coff, void* stream) { return roi_pool_fwd_impl<StF32>(in, rois, out, argmax, n_roi, n, h, w, c, pooled_h, pooled_w, spatial_scale, out_cstride, out_coff, stream); }
+extern "C" int rcf_roi_pool_fwd_b16(const float* in, const float* rois, float* out, int* argmax, int n_roi, int n, int h, int w, int c,
+                                int pooled_h, int pooled_w, float spatial_scale, int out_cstride, int out_coff, void* stream) { return roi_pool_fwd_impl<StB16>(in, rois, out, argmax, n_roi, n, h, w, c, pooled_h, pooled_w, spatial_scale, out_cstride, out_coff, stream); }
+extern "C" int rcf_roi_pool_bwd(const float* dout, const int* argmax, const float* rois, float* din, int n_roi, int n, int h, int w,
+                                int c, int pooled_h, int pooled_w, int dout_cstride, int dout_coff, void* stream) { return roi_pool_bwd_impl<StF32>(dout, argmax, rois, din, n_roi, n, h, w, c, pooled_h, pooled_w, dout_cstride, dout_coff, stream); }
+extern "C" int rcf_roi_pool_bwd_b16(const float* dout, const int* argmax, const float* rois, float* din, int n_roi, int n, int h, int w,
+                                int c, int pooled_h, int pooled_w, int dout_cstride, int dout_coff, void* stream) { return roi_pool_bwd_impl<StB16>(dout, argmax, rois, din, n_roi, n, h, w, c, pooled_h, pooled_w, dout_cstride, dout_coff, stream); }
+extern "C" int rcf_fc_fwd(const float* x, const float* w, const float* bias, float* y, int m_rows, int n_in, int n_out, int act,
+                          int hw, int cstride, int coff, void* stream) { return fc_fwd_impl<StF32>(x, w, bias, y, m_rows, n_in, n_out, act, hw, cstride, coff, stream); }
+extern "C" int rcf_fc_fwd_b16(const float* x, const float* w, const float* bias, float* y, int m_rows, int n_in, int n_out, int act,
+                          int hw, int cstride, int coff, void* stream) { return fc_fwd_impl<StB16>(x, w, bias, y, m_rows, n_in, n_out, act, hw, cstride, coff, stream); }
+extern "C" int rcf_fc_bwd(const float* x, const float* w, const float* y, const float* dy, float* dw, float* db, float* dx,
+                          float* workspace, int m_rows, int n_in, int n_out, int act, int hw, int cstride, int coff, void* stream) { return fc_bwd_impl<StF32>(x, w, y, dy, dw, db, dx, workspace, m_rows, n_in, n_out, act, hw, cstride, coff, stream); }
+extern "C" int rcf_fc_bwd_b16(const float* x, const float* w, const float* y, const float* dy, float* dw, float* db, float* dx,
+                          float* workspace, int m_rows, int n_in, int n_out, int act, int hw, int cstride, int coff, void* stream) { return fc_bwd_impl<StB16>(x, w, y, dy, dw, db, dx, workspace, m_rows, n_in, n_out, act, hw, cstride, coff, stream); }

@@ -62,6 +62,12 @@ class Engine(object):
 
     # ------------------------------------------------------------------ helpers
     def _new(self, shape, ref):
+        '''An NHWC activation / gradient tensor: fp32, or bf16 in the bf16-storage configuration (ops.set_precision('bf16')).'''
+        return torch.empty(shape, dtype=ops.act_dtype(), device=ref.device)
+
+    @staticmethod
+    def _newf(shape, ref):
+        '''An fp32 buffer whatever the activation storage is: packed weights, coefficients, workspaces, single-channel maps.'''
         return torch.empty(shape, dtype=torch.float32, device=ref.device)
 
     def _mat(self, x):
@@ -113,7 +119,7 @@ class Engine(object):
             t1 = self._mat(x)
         if x2 is not None and t2 is None:
             t2 = self._mat(x2)
-        packed = self._new((info.packed_weight_floats,), t1)
+        packed = self._newf((info.packed_weight_floats,), t1)
         fused = fold is not None and info.fwd_act and k1 is None and k2 is None
         ops.conv_pack(desc, ops.scale_channels(weight.detach(), fold[0][0]) if fused else weight.detach(), packed)
         z = self._new((n, desc.h_out, desc.w_out, desc.c_out), t1)
@@ -135,7 +141,7 @@ class Engine(object):
 
     def _run_packed(self, desc, w_oihw, in1, out, partials=None, coef1=None, bias=None):
         info = ops.conv_query(desc)
-        packed = self._new((info.packed_weight_floats,), in1)
+        packed = self._newf((info.packed_weight_floats,), in1)
         ops.conv_pack(desc, w_oihw, packed)
         if self.prof is not None:
             self.prof.begin(info.kernel_id, ops.algorithmic_flops(desc), desc)
@@ -189,10 +195,10 @@ class Engine(object):
         n, h, w, c1 = self._shape(x)
         weight = layer.conv.weight
         co = weight.shape[0]
-        dwp = self._new((4, co, c1, 2, 2), dz)
+        dwp = self._newf((4, co, c1, 2, 2), dz)
         for ph, d in enumerate(info.up2x):
             qi = ops.conv_query(d)
-            ws = self._new((max(1, qi.wgrad_workspace_floats),), dz)
+            ws = self._newf((max(1, qi.wgrad_workspace_floats),), dz)
             t1, k1 = self._src(x, qi.wgrad_bn_on_load)
             if t1 is None:
                 t1 = self._mat(x)
@@ -210,7 +216,7 @@ class Engine(object):
                 x.g = self._new(tuple(self._shape(x)), dz)
             dd = ops.make_up2x_dgrad_desc(n, h, w, c1, co, 0, 0, acc, phase_sum=True)
             qi = ops.conv_query(dd)
-            packed = self._new((4 * qi.packed_weight_floats,), dz)
+            packed = self._newf((4 * qi.packed_weight_floats,), dz)
             for ph in range(4):
                 ops.conv_pack(dd, wd[ph], packed[ph * qi.packed_weight_floats:(ph + 1) * qi.packed_weight_floats])
             if self.prof is not None:
@@ -225,7 +231,7 @@ class Engine(object):
             return self._conv_up2x_backward(layer, info, x, dz)
         weight = layer.conv.weight
         dw = self.grad_of(weight)
-        ws = self._new((max(1, info.wgrad_workspace_floats),), dz)
+        ws = self._newf((max(1, info.wgrad_workspace_floats),), dz)
         if self.prof is not None:
             self.prof.begin(info.wgrad_kernel_id, ops.algorithmic_flops(desc), desc)
         t1, k1 = self._src(x, info.wgrad_bn_on_load)
@@ -266,7 +272,7 @@ class Engine(object):
 
     def _run_dgrad(self, dd, weight, dz, out):
         info = ops.conv_query(dd)
-        packed = self._new((info.packed_weight_floats,), dz)
+        packed = self._newf((info.packed_weight_floats,), dz)
         ops.conv_pack(dd, weight.detach(), packed)
         if self.prof is not None:
             self.prof.begin(info.kernel_id, ops.algorithmic_flops(dd), dd)
@@ -277,7 +283,7 @@ class Engine(object):
     def _bn_coef(self, layer, partials, info, z):
         bn = layer.batch_norm
         c = z.shape[3]
-        coef = self._new((4, c), z)
+        coef = self._newf((4, c), z)
         count = z.shape[0] * z.shape[1] * z.shape[2]
         ops.bn_finalize(partials, info.n_partials if partials is not None else 0, c, count, bn.weight.detach(),
                         bn.bias.detach(), bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, self.training, coef)
@@ -286,7 +292,7 @@ class Engine(object):
     def _bn_coef_eval(self, layer, ref):
         bn = layer.batch_norm
         c = bn.weight.shape[0]
-        coef = self._new((4, c), ref)
+        coef = self._newf((4, c), ref)
         ops.bn_finalize(None, 0, c, 1, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS,
                         False, coef)
         return coef
@@ -337,7 +343,7 @@ class Engine(object):
                     nb = ops.head_bn_blocks(z.shape[0], z.shape[1], z.shape[2], c)
                     bpart = torch.empty((nb, 2, c), dtype=torch.float64, device=z.device)
                     ops.head_bn_bwd_reduce(dlogit, w_head, z, coef, bpart)
-                    bcoef = self._new((2, c), z)
+                    bcoef = self._newf((2, c), z)
                     ops.bn_bwd_finalize(bpart, nb, 2 * c, c, n_pix, bcoef, self.grad_of(bn.weight), self.grad_of(bn.bias))
                     if not batch_stats:
                         bcoef.zero_()
@@ -351,7 +357,7 @@ class Engine(object):
                 bpart = torch.empty((nb, 2, c), dtype=torch.float64, device=z.device)
                 has_res = res is not None   # out.t is read only then (a deferred activation has no residual)
                 ops.bn_act_bwd_reduce(dout, z, coef, out.t, bpart, n_pix, c, RCF_ACT_LEAKY_RELU, has_res)
-                bcoef = self._new((2, c), z)
+                bcoef = self._newf((2, c), z)
                 ops.bn_bwd_finalize(bpart, nb, 2 * c, c, n_pix, bcoef, self.grad_of(bn.weight), self.grad_of(bn.bias))
                 if not batch_stats:
                     bcoef.zero_()   # eval-mode BN is affine: no batch-statistic terms in dz
@@ -403,8 +409,8 @@ class Engine(object):
                 nb = ops.ew_blocks(n_pix, c)
                 bpart = torch.empty((nb, 4, c), dtype=torch.float64, device=zw.device)
                 ops.fuse_bwd_reduce(dout, zw, coef_w, zp, coef_p, bpart, n_pix, c)
-                bcw = self._new((2, c), zw)
-                bcp = self._new((2, c), zw)
+                bcw = self._newf((2, c), zw)
+                bcp = self._newf((2, c), zw)
                 ops.bn_bwd_finalize(bpart, nb, 4 * c, c, n_pix, bcw, self.grad_of(bnw.weight), self.grad_of(bnw.bias))
                 ops.bn_bwd_finalize(bpart.view(-1)[2 * c:], nb, 4 * c, c, n_pix, bcp, self.grad_of(bnp.weight),
                                     self.grad_of(bnp.bias))
@@ -472,8 +478,8 @@ class Engine(object):
         xcoef = None if x.t is not None else x.coef
         n, h, w, c = xin.shape
         weight = layer.conv.weight
-        logit = self._new((n, h, w), xin)
-        depth = Act(self._new((n, h, w), xin))
+        logit = self._newf((n, h, w), xin)
+        depth = Act(self._newf((n, h, w), xin))
         ops.head_fwd(xin, weight.detach(), logit, depth.t, self.dmin, self.dmax, coef=xcoef)
         if logits:
             depth = Act(logit)
@@ -549,9 +555,17 @@ class Engine(object):
         if self.tape is not None:
             def backward():
                 if x.needs_grad and out.g is not None:
-                    if x.g is None:
-                        x.g = torch.zeros_like(xt)   # rois overlap: scatter-add; later consumers accumulate on top
-                    ops.roi_pool_bwd(out.g, argmax, rois, x.g, out_hw, dout_coff=coff)
+                    if xt.dtype == torch.float32:
+                        if x.g is None:
+                            x.g = torch.zeros_like(xt)   # rois overlap: scatter-add; later consumers accumulate on top
+                        ops.roi_pool_bwd(out.g, argmax, rois, x.g, out_hw, dout_coff=coff)
+                    else:   # bf16 tensors: the scatter-add runs on an fp32 copy (fp32 atomics), then joins the bf16 gradient
+                        tmp = torch.zeros(xt.shape, dtype=torch.float32, device=xt.device)
+                        ops.roi_pool_bwd(out.g, argmax, rois, tmp, out_hw, dout_coff=coff)
+                        acc = x.g is not None
+                        if not acc:
+                            x.g = torch.empty_like(xt)
+                        ops.convert(tmp, x.g, accumulate=acc)
             self.tape.append(backward)
         return out
 
@@ -569,7 +583,7 @@ class Engine(object):
                 ops.fc_fwd(acts[-1], lin.weight.detach(), lin.bias.detach(), latent.t, act_on, hw, ctot, coff)
                 acts.append(latent.t)
             else:
-                y = self._new((points.shape[0], lin.out_features), points)
+                y = self._newf((points.shape[0], lin.out_features), points)
                 ops.fc_fwd(acts[-1], lin.weight.detach(), lin.bias.detach(), y, act_on)
                 acts.append(y)
         if self.tape is not None:
@@ -579,7 +593,7 @@ class Engine(object):
                     fc = layers[i]
                     lin = fc.fully_connected
                     last = i == len(layers) - 1
-                    dx = self._new(tuple(acts[i].shape), acts[i]) if i > 0 else None   # the radar points need no gradient
+                    dx = self._newf(tuple(acts[i].shape), acts[i]) if i > 0 else None   # the radar points need no gradient
                     ops.fc_bwd(acts[i], lin.weight.detach(), acts[i + 1], dy, self.grad_of(lin.weight), self.grad_of(lin.bias), dx,
                                fc.activation_func is not None, hw if last else 1, ctot if last else 0, coff if last else 0)
                     self._wgrad_done(lin.weight, lin.bias)

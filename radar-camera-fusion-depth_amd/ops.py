@@ -38,8 +38,24 @@ def _f64(t):
 
 def _f32(t):
     if t is not None and t.dtype != torch.float32:
-        raise _lib.RcfError('rcf ops are fp32; got %s' % t.dtype)
+        raise _lib.RcfError('this rcf buffer is fp32; got %s' % t.dtype)
     return _p(t)
+
+
+def _a(t):
+    """Pointer of an NHWC activation / gradient tensor: fp32, or bf16 in the bf16-storage configuration."""
+    if t is not None and t.dtype != torch.float32 and t.dtype != torch.bfloat16:
+        raise _lib.RcfError('rcf activations are fp32 or bf16; got %s' % t.dtype)
+    return _p(t)
+
+
+def _fn(name, *acts):
+    """The entry point for the storage of the given activation tensors: NAME (fp32) or NAME_b16 (bf16); they must agree."""
+    kinds = set(t.dtype for t in acts if t is not None)
+    if len(kinds) > 1:
+        raise _lib.RcfError('%s: activation tensors disagree in dtype: %s' % (name, sorted(str(k) for k in kinds)))
+    b16 = bool(kinds) and next(iter(kinds)) == torch.bfloat16
+    return getattr(_lib.load(), name + ('_b16' if b16 else ''))
 
 
 def conv_out_hw(h, w, ksize, stride, pad):
@@ -47,15 +63,30 @@ def conv_out_hw(h, w, ksize, stride, pad):
 
 
 _PRECISION = [0]   # rcf_conv_desc.precision of every descriptor built below (RCF_PREC_FP32 / RCF_PREC_BF16)
+_STORAGE = [0]     # rcf_conv_desc.storage (RCF_STORE_FP32 / RCF_STORE_BF16)
 
 
 def set_precision(p):
-    '''0 / 'fp32': fp32 arithmetic (default).  1 / 'bf16': bf16 operands, fp32 accumulate in the split conv kernels.'''
-    _PRECISION[0] = 1 if p in (1, 'bf16') else 0
+    '''0 / 'fp32': fp32 arithmetic and fp32 tensors (default).  'bf16': bf16 tensors in HBM + bf16 MFMA operands, fp32 accumulate
+    (BASELINE.json configs 2-4).  'bf16_operands': fp32 tensors, operands rounded to bf16 in the split conv kernels.'''
+    _PRECISION[0] = 1 if p in (1, 'bf16', 'bf16_operands') else 0
+    _STORAGE[0] = 1 if p == 'bf16' else 0
 
 
 def get_precision():
     return _PRECISION[0]
+
+
+def act_dtype():
+    '''torch dtype of the NHWC activation / gradient tensors under the current setting.'''
+    return torch.bfloat16 if _STORAGE[0] else torch.float32
+
+
+def _check_storage(desc, *acts):
+    want = torch.bfloat16 if desc.storage else torch.float32
+    for t in acts:
+        if t is not None and t.dtype != want:
+            raise _lib.RcfError('descriptor storage is %s but a tensor is %s' % (want, t.dtype))
 
 
 def make_fwd_desc(n, h_in, w_in, c1, c2, c_out, ksize, stride, h_src1=None, w_src1=None, gather=RCF_GATHER_DIRECT):
@@ -66,7 +97,7 @@ def make_fwd_desc(n, h_in, w_in, c1, c2, c_out, ksize, stride, h_src1=None, w_sr
                     h_src1=h_in if h_src1 is None else h_src1, w_src1=w_in if w_src1 is None else w_src1,
                     gather1=gather, h_out=h_out, w_out=w_out, c_out=c_out, ksize=ksize, stride=stride, pad=pad, pad_x=pad,
                     w_mode=RCF_W_FORWARD, w_o=c_out, w_i=c1 + c2, w_i_off=0, accumulate=0,
-                    out_stride=1, out_off_y=0, out_off_x=0, out_h_phys=h_out, out_w_phys=w_out, in_off_y=0, in_off_x=0, phase_sum=0, precision=_PRECISION[0])
+                    out_stride=1, out_off_y=0, out_off_x=0, out_h_phys=h_out, out_w_phys=w_out, in_off_y=0, in_off_x=0, phase_sum=0, precision=_PRECISION[0], storage=_STORAGE[0])
 
 
 def make_dgrad_desc(fwd, i_off, i_cnt, accumulate):
@@ -81,7 +112,7 @@ def make_dgrad_desc(fwd, i_off, i_cnt, accumulate):
                     gather1=RCF_GATHER_ZERO_INSERT if fwd.stride == 2 else RCF_GATHER_DIRECT,
                     h_out=fwd.h_in, w_out=fwd.w_in, c_out=i_cnt, ksize=k, stride=1, pad=k - 1 - fwd.pad, pad_x=k - 1 - fwd.pad,
                     w_mode=RCF_W_DGRAD, w_o=fwd.w_o, w_i=fwd.w_i, w_i_off=i_off, accumulate=1 if accumulate else 0,
-                    out_stride=1, out_off_y=0, out_off_x=0, out_h_phys=fwd.h_in, out_w_phys=fwd.w_in, in_off_y=0, in_off_x=0, phase_sum=0, precision=_PRECISION[0])
+                    out_stride=1, out_off_y=0, out_off_x=0, out_h_phys=fwd.h_in, out_w_phys=fwd.w_in, in_off_y=0, in_off_x=0, phase_sum=0, precision=_PRECISION[0], storage=_STORAGE[0])
 
 
 # ---- 2x2 phase convolutions (include/rcf_hip.h, RCF_PHASE_*) -------------------------------------------------------
@@ -90,7 +121,7 @@ def make_up2x_fwd_desc(n, hs, ws, c_in, c_out, a, b):
     return ConvDesc(n=n, h_in=hs, w_in=ws, c1=c_in, c2=0, h_src1=hs, w_src1=ws, gather1=RCF_GATHER_DIRECT,
                     h_out=hs, w_out=ws, c_out=c_out, ksize=2, stride=1, pad=1 - a, pad_x=1 - b,
                     w_mode=RCF_W_FORWARD, w_o=c_out, w_i=c_in, w_i_off=0, accumulate=0,
-                    out_stride=2, out_off_y=a, out_off_x=b, out_h_phys=2 * hs, out_w_phys=2 * ws, in_off_y=0, in_off_x=0, phase_sum=0, precision=_PRECISION[0])
+                    out_stride=2, out_off_y=a, out_off_x=b, out_h_phys=2 * hs, out_w_phys=2 * ws, in_off_y=0, in_off_x=0, phase_sum=0, precision=_PRECISION[0], storage=_STORAGE[0])
 
 
 def make_up2x_dgrad_desc(n, hs, ws, c_in, c_out, a, b, accumulate, phase_sum=False):
@@ -100,7 +131,7 @@ def make_up2x_dgrad_desc(n, hs, ws, c_in, c_out, a, b, accumulate, phase_sum=Fal
                     h_out=hs, w_out=ws, c_out=c_in, ksize=2, stride=1, pad=a, pad_x=b,
                     w_mode=RCF_W_FORWARD, w_o=c_in, w_i=c_out, w_i_off=0, accumulate=1 if accumulate else 0,
                     out_stride=1, out_off_y=0, out_off_x=0, out_h_phys=hs, out_w_phys=ws, in_off_y=a, in_off_x=b,
-                    phase_sum=1 if phase_sum else 0, precision=_PRECISION[0])
+                    phase_sum=1 if phase_sum else 0, precision=_PRECISION[0], storage=_STORAGE[0])
 
 
 def make_s2_dgrad_desc(fwd, a, b, accumulate):
@@ -110,7 +141,7 @@ def make_s2_dgrad_desc(fwd, a, b, accumulate):
     return ConvDesc(n=fwd.n, h_in=fwd.h_out, w_in=fwd.w_out, c1=fwd.c_out, c2=0, h_src1=fwd.h_out, w_src1=fwd.w_out,
                     gather1=RCF_GATHER_DIRECT, h_out=hy, w_out=wx, c_out=fwd.c1, ksize=2, stride=1, pad=0, pad_x=0,
                     w_mode=RCF_W_FORWARD, w_o=fwd.c1, w_i=fwd.c_out, w_i_off=0, accumulate=1 if accumulate else 0,
-                    out_stride=2, out_off_y=a, out_off_x=b, out_h_phys=fwd.h_in, out_w_phys=fwd.w_in, in_off_y=0, in_off_x=0, phase_sum=0, precision=_PRECISION[0])
+                    out_stride=2, out_off_y=a, out_off_x=b, out_h_phys=fwd.h_in, out_w_phys=fwd.w_in, in_off_y=0, in_off_x=0, phase_sum=0, precision=_PRECISION[0], storage=_STORAGE[0])
 
 
 def phase_weights(w_oihw, mode):
@@ -147,7 +178,7 @@ def algorithmic_bytes(desc):
         in1 = desc.h_src1 * desc.w_src1 * desc.c1
     in2 = desc.h_in * desc.w_in * desc.c2
     out = desc.h_out * desc.w_out * desc.c_out
-    return 4.0 * n * (in1 + in2 + out * (2 if desc.accumulate else 1))
+    return (2.0 if desc.storage else 4.0) * n * (in1 + in2 + out * (2 if desc.accumulate else 1))
 
 
 class KernelTimer(object):
@@ -214,17 +245,20 @@ def conv_pack(desc, w_oihw, packed):
 
 def conv_fwd(desc, in1, in2, packed, out, stat_partials=None, coef1=None, coef2=None):
     """coef1 / coef2: in1 / in2 are raw conv outputs whose BatchNorm + lrelu is applied on load (rcf_conv_info.bn_on_load)."""
+    # the 7x7 stems read the fp32 network input whatever the storage is (include/rcf_hip.h, rcf_conv_desc.storage)
+    _check_storage(desc, None if desc.ksize == 7 else in1, in2, out)
     if coef1 is None and coef2 is None:
-        check(_lib.load().rcf_conv2d_fwd(ctypes.byref(desc), _f32(in1), _f32(in2), _f32(packed), _f32(out),
+        check(_lib.load().rcf_conv2d_fwd(ctypes.byref(desc), _a(in1), _a(in2), _f32(packed), _a(out),
                                          _f64(stat_partials), _stream()), 'rcf_conv2d_fwd')
     else:
-        check(_lib.load().rcf_conv2d_fwd_bn(ctypes.byref(desc), _f32(in1), _f32(coef1), _f32(in2), _f32(coef2), _f32(packed),
-                                            _f32(out), _f64(stat_partials), _stream()), 'rcf_conv2d_fwd_bn')
+        check(_lib.load().rcf_conv2d_fwd_bn(ctypes.byref(desc), _a(in1), _f32(coef1), _a(in2), _f32(coef2), _f32(packed),
+                                            _a(out), _f64(stat_partials), _stream()), 'rcf_conv2d_fwd_bn')
 
 
 def conv_fwd_act(desc, in1, in2, packed, bias, res, out):
     """Inference epilogue in the matrix kernel: out = lrelu(conv + bias) (then lrelu(. + res)); rcf_conv_info.fwd_act."""
-    check(_lib.load().rcf_conv2d_fwd_act(ctypes.byref(desc), _f32(in1), _f32(in2), _f32(packed), _f32(bias), _f32(res), _f32(out),
+    _check_storage(desc, in1, in2, res, out)
+    check(_lib.load().rcf_conv2d_fwd_act(ctypes.byref(desc), _a(in1), _a(in2), _f32(packed), _f32(bias), _a(res), _a(out),
                                          _stream()), 'rcf_conv2d_fwd_act')
 
 
@@ -238,11 +272,12 @@ def scale_channels(w_oihw, scale):
 
 
 def conv_wgrad(desc, in1, in2, dz, dw, workspace, coef1=None, coef2=None):
+    _check_storage(desc, None if desc.ksize == 7 else in1, in2, dz)
     if coef1 is None and coef2 is None:
-        check(_lib.load().rcf_conv2d_wgrad(ctypes.byref(desc), _f32(in1), _f32(in2), _f32(dz), _f32(dw), _f32(workspace),
+        check(_lib.load().rcf_conv2d_wgrad(ctypes.byref(desc), _a(in1), _a(in2), _a(dz), _f32(dw), _f32(workspace),
                                            _stream()), 'rcf_conv2d_wgrad')
     else:
-        check(_lib.load().rcf_conv2d_wgrad_bn(ctypes.byref(desc), _f32(in1), _f32(coef1), _f32(in2), _f32(coef2), _f32(dz),
+        check(_lib.load().rcf_conv2d_wgrad_bn(ctypes.byref(desc), _a(in1), _f32(coef1), _a(in2), _f32(coef2), _a(dz),
                                               _f32(dw), _f32(workspace), _stream()), 'rcf_conv2d_wgrad_bn')
 
 
@@ -253,12 +288,12 @@ def bn_finalize(partials, n_partials, c, count, gamma, beta, running_mean, runni
 
 
 def bn_act_fwd(z, coef, res, out, n_pix, c, act):
-    check(_lib.load().rcf_bn_act_fwd(_f32(z), _f32(coef), _f32(res), _f32(out), n_pix, c, act, _stream()), 'rcf_bn_act_fwd')
+    check(_fn('rcf_bn_act_fwd', z, res, out)(_a(z), _f32(coef), _a(res), _a(out), n_pix, c, act, _stream()), 'rcf_bn_act_fwd')
 
 
 def fuse_fwd(zw, coef_w, zp, coef_p, img, out, n_pix, c):
-    check(_lib.load().rcf_fuse_fwd(_f32(zw), _f32(coef_w), _f32(zp), _f32(coef_p), _f32(img), _f32(out), n_pix, c,
-                                   _stream()), 'rcf_fuse_fwd')
+    check(_fn('rcf_fuse_fwd', zw, zp, img, out)(_a(zw), _f32(coef_w), _a(zp), _f32(coef_p), _a(img), _a(out), n_pix, c,
+                                                _stream()), 'rcf_fuse_fwd')
 
 
 def ew_blocks(n_pix, c):
@@ -269,8 +304,8 @@ def ew_blocks(n_pix, c):
 
 
 def bn_act_bwd_reduce(dout, z, coef, out, partials, n_pix, c, act, has_res):
-    check(_lib.load().rcf_bn_act_bwd_reduce(_f32(dout), _f32(z), _f32(coef), _f32(out), _f64(partials), n_pix, c, act,
-                                            1 if has_res else 0, _stream()), 'rcf_bn_act_bwd_reduce')
+    check(_fn('rcf_bn_act_bwd_reduce', dout, z, out)(_a(dout), _a(z), _f32(coef), _a(out), _f64(partials), n_pix, c, act,
+                                                     1 if has_res else 0, _stream()), 'rcf_bn_act_bwd_reduce')
 
 
 def bn_bwd_finalize(partials, n_blocks, stride, c, count, bcoef, dgamma, dbeta):
@@ -285,60 +320,60 @@ def head_bn_blocks(n, h, w, c):
 
 def head_bn_bwd_reduce(dlogit, w_head, z, coef, partials):
     n, h, w, c = z.shape
-    check(_lib.load().rcf_head_bn_bwd_reduce(_f32(dlogit), _f32(w_head), _f32(z), _f32(coef), _f64(partials), n, h, w, c, _stream()),
+    check(_fn('rcf_head_bn_bwd_reduce', z)(_f32(dlogit), _f32(w_head), _a(z), _f32(coef), _f64(partials), n, h, w, c, _stream()),
           'rcf_head_bn_bwd_reduce')
 
 
 def head_bn_bwd_apply(dlogit, w_head, z, coef, bcoef, dz):
     n, h, w, c = z.shape
-    check(_lib.load().rcf_head_bn_bwd_apply(_f32(dlogit), _f32(w_head), _f32(z), _f32(coef), _f32(bcoef), _f32(dz), n, h, w, c,
-                                            _stream()), 'rcf_head_bn_bwd_apply')
+    check(_fn('rcf_head_bn_bwd_apply', z, dz)(_f32(dlogit), _f32(w_head), _a(z), _f32(coef), _f32(bcoef), _a(dz), n, h, w, c,
+                                              _stream()), 'rcf_head_bn_bwd_apply')
 
 
 def bn_act_bwd_apply(dout, z, coef, out, bcoef, dz, dres, dres_accumulate, n_pix, c, act, has_res):
-    check(_lib.load().rcf_bn_act_bwd_apply(_f32(dout), _f32(z), _f32(coef), _f32(out), _f32(bcoef), _f32(dz), _f32(dres),
-                                           1 if dres_accumulate else 0, n_pix, c, act, 1 if has_res else 0, _stream()),
+    check(_fn('rcf_bn_act_bwd_apply', dout, z, out, dz, dres)(_a(dout), _a(z), _f32(coef), _a(out), _f32(bcoef), _a(dz), _a(dres),
+                                                              1 if dres_accumulate else 0, n_pix, c, act, 1 if has_res else 0, _stream()),
           'rcf_bn_act_bwd_apply')
 
 
 def fuse_bwd_reduce(dout, zw, coef_w, zp, coef_p, partials, n_pix, c):
-    check(_lib.load().rcf_fuse_bwd_reduce(_f32(dout), _f32(zw), _f32(coef_w), _f32(zp), _f32(coef_p), _f64(partials),
-                                          n_pix, c, _stream()), 'rcf_fuse_bwd_reduce')
+    check(_fn('rcf_fuse_bwd_reduce', dout, zw, zp)(_a(dout), _a(zw), _f32(coef_w), _a(zp), _f32(coef_p), _f64(partials),
+                                                   n_pix, c, _stream()), 'rcf_fuse_bwd_reduce')
 
 
 def fuse_bwd_apply(dout, zw, coef_w, zp, coef_p, bcoef_w, bcoef_p, dzw, dzp, dimg, dimg_accumulate, n_pix, c):
-    check(_lib.load().rcf_fuse_bwd_apply(_f32(dout), _f32(zw), _f32(coef_w), _f32(zp), _f32(coef_p), _f32(bcoef_w),
-                                         _f32(bcoef_p), _f32(dzw), _f32(dzp), _f32(dimg), 1 if dimg_accumulate else 0,
-                                         n_pix, c, _stream()), 'rcf_fuse_bwd_apply')
+    check(_fn('rcf_fuse_bwd_apply', dout, zw, zp, dzw, dzp, dimg)(_a(dout), _a(zw), _f32(coef_w), _a(zp), _f32(coef_p), _f32(bcoef_w),
+                                                                  _f32(bcoef_p), _a(dzw), _a(dzp), _a(dimg), 1 if dimg_accumulate else 0,
+                                                                  n_pix, c, _stream()), 'rcf_fuse_bwd_apply')
 
 
 def maxpool_fwd(x, out, idx):
     n, h, w, c = x.shape
-    check(_lib.load().rcf_maxpool3x3s2_fwd(_f32(x), _f32(out), _p(idx), n, h, w, c, _stream()), 'rcf_maxpool3x3s2_fwd')
+    check(_fn('rcf_maxpool3x3s2_fwd', x, out)(_a(x), _a(out), _p(idx), n, h, w, c, _stream()), 'rcf_maxpool3x3s2_fwd')
 
 
 def maxpool_bwd(dout, idx, din, accumulate):
     n, h, w, c = din.shape
-    check(_lib.load().rcf_maxpool3x3s2_bwd(_f32(dout), _p(idx), _f32(din), 1 if accumulate else 0, n, h, w, c, _stream()),
+    check(_fn('rcf_maxpool3x3s2_bwd', dout, din)(_a(dout), _p(idx), _a(din), 1 if accumulate else 0, n, h, w, c, _stream()),
           'rcf_maxpool3x3s2_bwd')
 
 
 def upsample_nearest_bwd(dup, dsrc, accumulate):
     n, hu, wu, c = dup.shape
     _, hs, ws, _ = dsrc.shape
-    check(_lib.load().rcf_upsample_nearest_bwd(_f32(dup), _f32(dsrc), 1 if accumulate else 0, n, hu, wu, hs, ws, c,
-                                               _stream()), 'rcf_upsample_nearest_bwd')
+    check(_fn('rcf_upsample_nearest_bwd', dup, dsrc)(_a(dup), _a(dsrc), 1 if accumulate else 0, n, hu, wu, hs, ws, c,
+                                                     _stream()), 'rcf_upsample_nearest_bwd')
 
 
 def head_fwd(x, w, logit, depth, dmin, dmax, coef=None):
     """coef given: x is the previous block's raw conv output z; its BatchNorm + lrelu is applied on load."""
     n, h, ww, c = x.shape
     if coef is None:
-        check(_lib.load().rcf_head_fwd(_f32(x), _f32(w), _f32(logit), _f32(depth), n, h, ww, c, dmin, dmax, _stream()),
+        check(_fn('rcf_head_fwd', x)(_a(x), _f32(w), _f32(logit), _f32(depth), n, h, ww, c, dmin, dmax, _stream()),
               'rcf_head_fwd')
     else:
-        check(_lib.load().rcf_head_fwd_bn(_f32(x), _f32(coef), _f32(w), _f32(logit), _f32(depth), n, h, ww, c, dmin, dmax,
-                                          _stream()), 'rcf_head_fwd_bn')
+        check(_fn('rcf_head_fwd_bn', x)(_a(x), _f32(coef), _f32(w), _f32(logit), _f32(depth), n, h, ww, c, dmin, dmax,
+                                        _stream()), 'rcf_head_fwd_bn')
 
 
 def head_bwd_logit(ddepth, logit, dlogit, dmin, dmax):
@@ -348,7 +383,7 @@ def head_bwd_logit(ddepth, logit, dlogit, dmin, dmax):
 
 def head_bwd_dgrad(dlogit, w, dx):
     n, h, ww, c = dx.shape
-    check(_lib.load().rcf_head_bwd_dgrad(_f32(dlogit), _f32(w), _f32(dx), n, h, ww, c, _stream()), 'rcf_head_bwd_dgrad')
+    check(_fn('rcf_head_bwd_dgrad', dx)(_f32(dlogit), _f32(w), _a(dx), n, h, ww, c, _stream()), 'rcf_head_bwd_dgrad')
 
 
 def head_bwd_wgrad(x, dlogit, dw, coef=None):
@@ -356,10 +391,10 @@ def head_bwd_wgrad(x, dlogit, dw, coef=None):
     nws = _lib.load().rcf_head_wgrad_workspace_floats(n, h, ww, c)
     ws = torch.empty(nws, dtype=torch.float32, device=x.device)
     if coef is None:
-        check(_lib.load().rcf_head_bwd_wgrad(_f32(x), _f32(dlogit), _f32(dw), _f32(ws), n, h, ww, c, _stream()),
+        check(_fn('rcf_head_bwd_wgrad', x)(_a(x), _f32(dlogit), _f32(dw), _f32(ws), n, h, ww, c, _stream()),
               'rcf_head_bwd_wgrad')
     else:
-        check(_lib.load().rcf_head_bwd_wgrad_bn(_f32(x), _f32(coef), _f32(dlogit), _f32(dw), _f32(ws), n, h, ww, c, _stream()),
+        check(_fn('rcf_head_bwd_wgrad_bn', x)(_a(x), _f32(coef), _f32(dlogit), _f32(dw), _f32(ws), n, h, ww, c, _stream()),
               'rcf_head_bwd_wgrad_bn')
 
 
@@ -426,20 +461,21 @@ def roi_pool_fwd(x, rois, out, argmax, pooled_hw, spatial_scale, out_coff=0):
     n, h, w, c = x.shape
     if argmax.dtype != torch.int32:
         raise _lib.RcfError('roi_pool argmax must be int32')
-    check(_lib.load().rcf_roi_pool_fwd(_f32(x), _f32(rois), _f32(out), _p(argmax), rois.shape[0], n, h, w, c, pooled_hw[0],
-                                       pooled_hw[1], float(spatial_scale), out.shape[-1], out_coff, _stream()), 'rcf_roi_pool_fwd')
+    check(_fn('rcf_roi_pool_fwd', x, out)(_a(x), _f32(rois), _a(out), _p(argmax), rois.shape[0], n, h, w, c, pooled_hw[0],
+                                          pooled_hw[1], float(spatial_scale), out.shape[-1], out_coff, _stream()), 'rcf_roi_pool_fwd')
 
 
 def roi_pool_bwd(dout, argmax, rois, din, pooled_hw, dout_coff=0):
     n, h, w, c = din.shape
-    check(_lib.load().rcf_roi_pool_bwd(_f32(dout), _p(argmax), _f32(rois), _f32(din), rois.shape[0], n, h, w, c, pooled_hw[0],
-                                       pooled_hw[1], dout.shape[-1], dout_coff, _stream()), 'rcf_roi_pool_bwd')
+    # din is fp32 for either storage of dout (the scatter uses fp32 atomics)
+    check(_fn('rcf_roi_pool_bwd', dout)(_a(dout), _p(argmax), _f32(rois), _f32(din), rois.shape[0], n, h, w, c, pooled_hw[0],
+                                        pooled_hw[1], dout.shape[-1], dout_coff, _stream()), 'rcf_roi_pool_bwd')
 
 
 def fc_fwd(x, w, b, y, act, hw=1, cstride=0, coff=0):
     m, n_in = x.shape
-    check(_lib.load().rcf_fc_fwd(_f32(x), _f32(w), _f32(b), _f32(y), m, n_in, w.shape[0], 1 if act else 0, hw, cstride, coff,
-                                 _stream()), 'rcf_fc_fwd')
+    check(_fn('rcf_fc_fwd', y)(_f32(x), _f32(w), _f32(b), _a(y), m, n_in, w.shape[0], 1 if act else 0, hw, cstride, coff,
+                               _stream()), 'rcf_fc_fwd')
 
 
 def fc_bwd(x, w, y, dy, dw, db, dx, act, hw=1, cstride=0, coff=0):
@@ -447,8 +483,8 @@ def fc_bwd(x, w, y, dy, dw, db, dx, act, hw=1, cstride=0, coff=0):
     ws = None
     if dx is not None:
         ws = torch.empty(_lib.load().rcf_fc_bwd_workspace_floats(m, n_in, w.shape[0]), dtype=torch.float32, device=x.device)
-    check(_lib.load().rcf_fc_bwd(_f32(x), _f32(w), _f32(y), _f32(dy), _f32(dw), _f32(db), _f32(dx), _f32(ws), m, n_in, w.shape[0],
-                                 1 if act else 0, hw, cstride, coff, _stream()), 'rcf_fc_bwd')
+    check(_fn('rcf_fc_bwd', y, dy)(_f32(x), _f32(w), _a(y), _a(dy), _f32(dw), _f32(db), _f32(dx), _f32(ws), m, n_in, w.shape[0],
+                                   1 if act else 0, hw, cstride, coff, _stream()), 'rcf_fc_bwd')
 
 
 def bce_loss_fwd(logit, target, valid, sums, loss, pos_weight):
@@ -560,3 +596,13 @@ def points_to_depth_map(points, depth, height, width):
     if n_bad:
         raise IndexError('%d point(s) fall outside the %d x %d image' % (n_bad, height, width))
     return out
+
+
+def convert(src, dst, accumulate=False):
+    """dst (+)= src between fp32 and bf16 tensors of the same element count (rcf_convert)."""
+    kinds = {torch.float32: _lib.RCF_STORE_FP32, torch.bfloat16: _lib.RCF_STORE_BF16}
+    if src.dtype not in kinds or dst.dtype not in kinds or src.numel() != dst.numel():
+        raise _lib.RcfError('convert: fp32 / bf16 tensors of equal size expected')
+    check(_lib.load().rcf_convert(_p(src), kinds[src.dtype], _p(dst), kinds[dst.dtype], src.numel(), 1 if accumulate else 0, _stream()),
+          'rcf_convert')
+    return dst

@@ -1,0 +1,408 @@
+'''
+GPU tests of the bf16-STORAGE configuration (BASELINE.json configs 2-4: bf16 NHWC tensors in HBM, bf16 MFMA operands, fp32
+accumulation; fp32 weights / BatchNorm statistics / loss / optimizer), kernel by kernel, through the C ABI.
+
+Oracle for a kernel with bf16 tensors: the SAME computation in fp32 (stock PyTorch CPU ops) on the bf16-valued inputs, rounded to
+bf16 once at the end -- what `x.bfloat16()` tensors mean.  Elementwise kernels do fp32 arithmetic on the loaded values and round on
+store, so they must agree with the fp32 twin run on the same (bf16-valued) inputs after one rounding, to one bf16 ulp; the
+convolutions accumulate in fp32, so they must agree with torch's fp32 convolution of the bf16-valued operands to accumulation-order
+noise (1e-5) plus the final rounding (2^-9 relative).
+'''
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF16_EPS = 2.0 ** -8   # one bf16 ulp relative to the value (8 significant bits)
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import rcf_amd  # noqa: F401
+    from rcf_amd import _lib, ops as _ops
+    assert torch.cuda.is_available()
+    _lib.load()
+    return _ops
+
+
+@pytest.fixture(autouse=True)
+def _restore_precision(ops):
+    yield
+    ops.set_precision('fp32')
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def b16(t):
+    '''the fp32 tensor holding the bf16-rounded values of t'''
+    return t.bfloat16().float()
+
+
+def nhwc_b(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda().bfloat16()
+
+
+def nhwc_f(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.detach().float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def close_bf16(got, want, slack=1.0):
+    '''got (bf16-valued) equals round_bf16(want) up to `slack` ulps of the larger of the two'''
+    got, want = got.double(), want.double()
+    tol = slack * BF16_EPS * torch.maximum(got.abs(), want.abs()) + 1e-30
+    bad = (got - want).abs() > tol
+    return int(bad.sum()), float(((got - want).abs() / (want.abs().max() + 1e-30)).max())
+
+
+# (ksize, stride, c1, c2, cout, n, h, w, up_from)
+CASES = [
+    (3, 1, 16, 0, 32, 2, 20, 37, None),
+    (3, 1, 64, 32, 64, 2, 17, 40, None),        # decoder concat
+    (3, 1, 32, 0, 32, 1, 40, 100, None),
+    (3, 1, 8, 8, 8, 2, 35, 51, None),           # tiny net, f32-MFMA kernel with bf16 tensors
+    (3, 1, 256, 0, 128, 1, 29, 50, (15, 25)),   # non-2x nearest gather
+    (3, 1, 64, 0, 64, 3, 33, 40, None),         # batch 3: virtual-tall tiling
+    (3, 2, 32, 0, 64, 2, 45, 80, None),         # stride 2
+    (1, 1, 16, 0, 32, 2, 35, 51, None),         # fusion 1x1
+    (1, 2, 32, 0, 64, 2, 45, 80, None),         # projection
+    (7, 2, 3, 0, 32, 2, 70, 102, None),         # stem: fp32 input, bf16 output
+    (7, 2, 2, 0, 16, 2, 70, 102, None),
+]
+
+
+def _case(case, seed):
+    k, s, c1, c2, co, n, h, w, up = case
+    hs, ws = (h, w) if up is None else up
+    x1 = rnd(n, c1, hs, ws, seed=seed)
+    if k != 7:
+        x1 = b16(x1)            # the stems read the fp32 network input as it is
+    x2 = b16(rnd(n, c2, h, w, seed=seed + 1)) if c2 else None
+    wt = rnd(co, c1 + c2, k, k, seed=seed + 2, scale=1.0 / np.sqrt((c1 + c2) * k * k))
+    return x1, x2, wt
+
+
+def _ref(case, x1, x2, wt, operands_bf16):
+    k, s, c1, c2, co, n, h, w, up = case
+    xin = x1 if up is None else F.interpolate(x1, size=(h, w))
+    if x2 is not None:
+        xin = torch.cat([xin, x2], 1)
+    if operands_bf16:
+        return F.conv2d(b16(xin).double(), b16(wt).double(), stride=s, padding=k // 2).float()
+    return F.conv2d(xin.double(), wt.double(), stride=s, padding=k // 2).float()
+
+
+def _desc(ops, case):
+    k, s, c1, c2, co, n, h, w, up = case
+    hs, ws = (h, w) if up is None else up
+    return ops.make_fwd_desc(n, h, w, c1, c2, co, k, s, hs, ws, 0 if up is None else 1)
+
+
+@pytest.mark.parametrize('case', CASES, ids=[str(c) for c in CASES])
+def test_conv_forward_bf16_tensors(ops, case):
+    ops.set_precision('bf16')
+    k = case[0]
+    x1, x2, wt = _case(case, 10)
+    d = _desc(ops, case)
+    assert d.storage == 1
+    info = ops.conv_query(d)
+    split = (info.kernel_id % 20000) // 1000 in (5, 9)
+    ref = _ref(case, x1, x2, wt, operands_bf16=split)     # f32-MFMA kernels (1x1, stride 2, stems, tiny) keep fp32 operands
+    packed = torch.empty(info.packed_weight_floats, device='cuda')
+    ops.conv_pack(d, wt.cuda(), packed)
+    out = torch.full((d.n, d.h_out, d.w_out, d.c_out), float('nan'), device='cuda').bfloat16()
+    partials = torch.full((info.n_partials, 2, d.c_out), float('nan'), device='cuda', dtype=torch.float64)
+    in1 = nhwc_f(x1) if k == 7 else nhwc_b(x1)
+    ops.conv_fwd(d, in1, None if x2 is None else nhwc_b(x2), packed, out, partials)
+    torch.cuda.synchronize()
+    got = nchw(out)
+    nbad, e = close_bf16(got, ref, slack=1.01)
+    assert nbad <= max(2, got.numel() // 2000), (nbad, e)     # accumulation-order noise can flip a rounding at a tie
+    assert e < 2 * BF16_EPS
+    # BatchNorm statistics are those of the STORED (rounded) values
+    s = partials.sum(0).cpu()
+    gd = got.double()
+    assert float((s[0] - gd.sum((0, 2, 3))).abs().max()) < 1e-6 * max(1.0, float(gd.abs().sum((0, 2, 3)).max()))
+    assert float(((s[1] - (gd ** 2).sum((0, 2, 3))).abs() / (gd ** 2).sum((0, 2, 3))).max()) < 1e-9
+
+
+@pytest.mark.parametrize('case', [c for c in CASES if c[0] != 7], ids=[str(c) for c in CASES if c[0] != 7])
+def test_conv_input_gradient_bf16_tensors(ops, case):
+    ops.set_precision('bf16')
+    k, s, c1, c2, co, n, h, w, up = case
+    x1, x2, wt = _case(case, 20)
+    d = _desc(ops, case)
+    dz = b16(rnd(n, co, d.h_out, d.w_out, seed=33))
+    for src, off, cnt in ((x1, 0, c1), (x2, c1, c2)):
+        if src is None:
+            continue
+        for accumulate in (False, True):
+            dd = ops.make_dgrad_desc(d, off, cnt, accumulate and not (src is x1 and up is not None))
+            info = ops.conv_query(dd)
+            split = (info.kernel_id % 20000) // 1000 in (5, 9)
+            wq = b16(wt) if split else wt
+            xs = torch.zeros(n, c1 + c2, h, w, dtype=torch.double, requires_grad=True)
+            (F.conv2d(xs, wq.double(), stride=s, padding=k // 2) * dz.double()).sum().backward()
+            want_full = xs.grad[:, off:off + cnt].float()
+            packed = torch.empty(info.packed_weight_floats, device='cuda')
+            ops.conv_pack(dd, wt.cuda(), packed)
+            if src is x1 and up is not None:
+                tmp = torch.full((n, h, w, cnt), float('nan'), device='cuda').bfloat16()
+                ops.conv_fwd(dd, nhwc_b(dz), None, packed, tmp, None)
+                base = b16(rnd(n, cnt, up[0], up[1], seed=5)) if accumulate else torch.zeros(n, cnt, up[0], up[1])
+                dst = nhwc_b(base) if accumulate else torch.full((n, up[0], up[1], cnt), float('nan'), device='cuda').bfloat16()
+                ops.upsample_nearest_bwd(tmp, dst, accumulate)
+                torch.cuda.synchronize()
+                # the fan-out sum of the ROUNDED full-resolution gradient, in fp32, rounded once more
+                full = b16(want_full)
+                xsrc = torch.zeros(n, cnt, up[0], up[1], requires_grad=True)
+                (F.interpolate(xsrc, size=(h, w)) * full).sum().backward()
+                want = xsrc.grad + base
+                nbad, e = close_bf16(nchw(dst), want, slack=2.0)
+            else:
+                base = b16(rnd(n, cnt, h, w, seed=5)) if accumulate else torch.zeros(n, cnt, h, w)
+                dst = nhwc_b(base) if accumulate else torch.full((n, h, w, cnt), float('nan'), device='cuda').bfloat16()
+                ops.conv_fwd(dd, nhwc_b(dz), None, packed, dst, None)
+                torch.cuda.synchronize()
+                want = want_full + base
+                nbad, e = close_bf16(nchw(dst), want, slack=1.01)
+            assert nbad <= max(2, dst.numel() // 1000), (off, accumulate, nbad, e)
+            assert e < 3 * BF16_EPS
+
+
+@pytest.mark.parametrize('case', CASES, ids=[str(c) for c in CASES])
+def test_conv_weight_gradient_bf16_tensors(ops, case):
+    ops.set_precision('bf16')
+    k, s, c1, c2, co, n, h, w, up = case
+    x1, x2, wt = _case(case, 30)
+    d = _desc(ops, case)
+    info = ops.conv_query(d)
+    dz = b16(rnd(n, co, d.h_out, d.w_out, seed=44))
+    wd = wt.clone().double().requires_grad_(True)
+    xin = x1 if up is None else F.interpolate(x1, size=(h, w))
+    if x2 is not None:
+        xin = torch.cat([xin, x2], 1)
+    # split kernels round x and dz to bf16 (they already are, the stem input excepted -- and stems run on the f32 MFMA)
+    (F.conv2d(xin.double(), wd, stride=s, padding=k // 2) * dz.double()).sum().backward()
+    ws = torch.empty(max(1, info.wgrad_workspace_floats), device='cuda')
+    dw = torch.full(tuple(wt.shape), float('nan'), device='cuda')
+    in1 = nhwc_f(x1) if k == 7 else nhwc_b(x1)
+    ops.conv_wgrad(d, in1, None if x2 is None else nhwc_b(x2), nhwc_b(dz), dw, ws)
+    torch.cuda.synchronize()
+    e = float((dw.cpu().double() - wd.grad).abs().max() / wd.grad.abs().max())
+    assert e < 2e-4, e      # operands are exact: only fp32 accumulation order differs (the gradient itself stays fp32)
+
+
+def test_phase_convolutions_bf16_tensors(ops):
+    '''Exact-2x UpConv as four 2x2 phase convolutions, its merged-phase input gradient and its weight gradient on bf16 tensors,
+    against the 9-tap reference (phase weights are pre-summed in fp32 and then rounded once: 1 extra bf16 ulp of slack).'''
+    from rcf_amd._lib import RCF_PHASE_UP2X_DGRAD, RCF_PHASE_UP2X_FWD
+    ops.set_precision('bf16')
+    n, c1, co, h, w = 2, 64, 32, 35, 51
+    x = b16(rnd(n, c1, h, w, seed=1))
+    wt = rnd(co, c1, 3, 3, seed=2, scale=1.0 / np.sqrt(c1 * 9))
+    xr = x.clone().double().requires_grad_(True)
+    wr = wt.clone().double().requires_grad_(True)
+    ref = F.conv2d(F.interpolate(xr, scale_factor=2), wr, padding=1)
+    dz = b16(rnd(n, co, 2 * h, 2 * w, seed=3))
+    (ref * dz.double()).sum().backward()
+    wp = ops.phase_weights(wt.cuda(), RCF_PHASE_UP2X_FWD)
+    z = torch.full((n, 2 * h, 2 * w, co), float('nan'), device='cuda').bfloat16()
+    xg = nhwc_b(x)
+    descs = []
+    for ph in range(4):
+        d = ops.make_up2x_fwd_desc(n, h, w, c1, co, ph >> 1, ph & 1)
+        info = ops.conv_query(d)
+        packed = torch.empty(info.packed_weight_floats, device='cuda')
+        ops.conv_pack(d, wp[ph], packed)
+        ops.conv_fwd(d, xg, None, packed, z, None)
+        descs.append(d)
+    torch.cuda.synchronize()
+    e = float((nchw(z).double() - ref.detach()).abs().max() / ref.detach().abs().max())
+    assert e < 3 * BF16_EPS, e
+    # weight gradient: four 2x2 wgrads folded back to 3x3
+    dwp = torch.empty((4, co, c1, 2, 2), device='cuda')
+    dzg = nhwc_b(dz)
+    for ph, d in enumerate(descs):
+        qi = ops.conv_query(d)
+        ws = torch.empty(max(1, qi.wgrad_workspace_floats), device='cuda')
+        ops.conv_wgrad(d, xg, None, dzg, dwp[ph], ws)
+    dw = torch.empty((co, c1, 3, 3), device='cuda')
+    ops.phase_wgrad_fold(dwp, dw)
+    torch.cuda.synchronize()
+    e = float((dw.cpu().double() - wr.grad).abs().max() / wr.grad.abs().max())
+    assert e < 2e-4, e
+    # input gradient: the four phases of dZ summed inside one launch
+    wd = ops.phase_weights(wt.cuda(), RCF_PHASE_UP2X_DGRAD)
+    dd = ops.make_up2x_dgrad_desc(n, h, w, c1, co, 0, 0, False, phase_sum=True)
+    qi = ops.conv_query(dd)
+    packed = torch.empty(4 * qi.packed_weight_floats, device='cuda')
+    for ph in range(4):
+        ops.conv_pack(dd, wd[ph], packed[ph * qi.packed_weight_floats:(ph + 1) * qi.packed_weight_floats])
+    dx = torch.full((n, h, w, c1), float('nan'), device='cuda').bfloat16()
+    ops.conv_fwd(dd, dzg, None, packed, dx, None)
+    torch.cuda.synchronize()
+    e = float((nchw(dx).double() - xr.grad).abs().max() / xr.grad.abs().max())
+    assert e < 3 * BF16_EPS, e
+
+
+@pytest.mark.parametrize('c,n,h,w,has_res', [(32, 2, 19, 23, False), (64, 1, 30, 17, True), (4, 2, 35, 51, True), (256, 2, 8, 13, False)])
+def test_elementwise_twins_equal_fp32_kernels_on_bf16_values(ops, c, n, h, w, has_res):
+    '''bn_act fwd / bwd_reduce / bwd_apply, fuse fwd / bwd, max pool, nearest-upsample backward: NAME_b16 on bf16 tensors ==
+    NAME on the same values held in fp32, rounded to bf16 once (bit-exact for the elementwise results, exact for the fp64 sums).'''
+    from rcf_amd._lib import RCF_ACT_LEAKY_RELU
+    npix = n * h * w
+    z = b16(rnd(n, h, w, c, seed=1, scale=2.0) + 0.3).cuda()
+    res = b16(rnd(n, h, w, c, seed=2)).cuda()
+    dout = b16(rnd(n, h, w, c, seed=3)).cuda()
+    coef = torch.stack([rnd(c, seed=4) * 0.5 + 1.0, rnd(c, seed=5) * 0.1, rnd(c, seed=6) * 0.1 + 0.3, rnd(c, seed=7) * 0.2 + 1.0]).cuda()
+    bcoef = torch.stack([rnd(c, seed=8) * 0.01, rnd(c, seed=9) * 0.01]).cuda()
+
+    def both(fn):
+        return fn(lambda t: t), fn(lambda t: None if t is None else t.bfloat16())
+
+    # forward
+    def fwd(cast):
+        out = torch.empty_like(cast(z))
+        ops.bn_act_fwd(cast(z), coef, cast(res) if has_res else None, out, npix, c, RCF_ACT_LEAKY_RELU)
+        return out
+    of, ob = both(fwd)
+    assert torch.equal(ob.float(), of.bfloat16().float())
+    out_act = of.bfloat16()     # what the network keeps
+    # backward reduce: identical fp64 partial sums (same values, same order)
+    nb = ops.ew_blocks(npix, c)
+
+    def red(cast):
+        part = torch.empty((nb, 2, c), dtype=torch.float64, device='cuda')
+        ops.bn_act_bwd_reduce(cast(dout), cast(z), coef, cast(out_act.float()), part, npix, c, RCF_ACT_LEAKY_RELU, has_res)
+        return part
+    pf, pb = both(red)
+    assert torch.equal(pf, pb)
+
+    def app(cast):
+        dz = torch.empty_like(cast(z))
+        dres = torch.empty_like(cast(z)) if has_res else None
+        ops.bn_act_bwd_apply(cast(dout), cast(z), coef, cast(out_act.float()), bcoef, dz, dres, False, npix, c, RCF_ACT_LEAKY_RELU, has_res)
+        return dz if dres is None else torch.cat([dz, dres])
+    af, ab = both(app)
+    assert torch.equal(ab.float(), af.bfloat16().float())
+    # max pool + its backward (indices identical, values pass through unrounded)
+    if c >= 4:
+        def pool(cast):
+            ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            out = torch.empty((n, ho, wo, c), device='cuda', dtype=cast(z).dtype)
+            idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device='cuda')
+            ops.maxpool_fwd(cast(z), out, idx)
+            din = torch.empty_like(cast(z))
+            ops.maxpool_bwd(cast(dout)[:, :ho, :wo].contiguous(), idx, din, False)
+            return out, idx, din
+        (o1, i1, d1), (o2, i2, d2) = both(pool)
+        assert torch.equal(i1, i2) and torch.equal(o2.float(), o1) and torch.equal(d2.float(), d1.bfloat16().float())
+
+
+def test_fusion_twins_equal_fp32_kernels_on_bf16_values(ops):
+    n, h, w, c = 2, 17, 23, 64
+    npix = n * h * w
+    zw = b16(rnd(n, h, w, c, seed=1, scale=2.0)).cuda()
+    zp = b16(rnd(n, h, w, c, seed=2, scale=2.0)).cuda()
+    img = b16(rnd(n, h, w, c, seed=3)).cuda()
+    dout = b16(rnd(n, h, w, c, seed=4)).cuda()
+    cw = torch.stack([rnd(c, seed=5) * 0.5 + 1.0, rnd(c, seed=6) * 0.1, rnd(c, seed=7) * 0.1, rnd(c, seed=8) * 0.2 + 1.0]).cuda()
+    cp = torch.stack([rnd(c, seed=9) * 0.5 + 1.0, rnd(c, seed=10) * 0.1, rnd(c, seed=11) * 0.1, rnd(c, seed=12) * 0.2 + 1.0]).cuda()
+    bw = torch.stack([rnd(c, seed=13) * 0.01, rnd(c, seed=14) * 0.01]).cuda()
+    bp = torch.stack([rnd(c, seed=15) * 0.01, rnd(c, seed=16) * 0.01]).cuda()
+    res = []
+    for cast in (lambda t: t, lambda t: t.bfloat16()):
+        out = torch.empty_like(cast(zw))
+        ops.fuse_fwd(cast(zw), cw, cast(zp), cp, cast(img), out, npix, c)
+        nb = ops.ew_blocks(npix, c)
+        part = torch.empty((nb, 4, c), dtype=torch.float64, device='cuda')
+        ops.fuse_bwd_reduce(cast(dout), cast(zw), cw, cast(zp), cp, part, npix, c)
+        dzw, dzp, dimg = torch.empty_like(out), torch.empty_like(out), torch.empty_like(out)
+        ops.fuse_bwd_apply(cast(dout), cast(zw), cw, cast(zp), cp, bw, bp, dzw, dzp, dimg, False, npix, c)
+        res.append((out, part, dzw, dzp, dimg))
+    f, b = res
+    assert torch.equal(f[1], b[1])
+    for i in (0, 2, 3, 4):
+        assert torch.equal(b[i].float(), f[i].bfloat16().float()), i
+
+
+def test_head_kernels_bf16_input(ops):
+    '''3x3 C->1 head on a bf16 activation (and on a deferred bf16 z + coefficients): logits / depth stay fp32 and equal the fp32
+    kernel's on the same values; the input gradient is the fp32 one rounded once.'''
+    n, h, w, c = 2, 37, 50, 32
+    x = b16(rnd(n, h, w, c, seed=1)).cuda()
+    wt = (rnd(1, c, 3, 3, seed=2) * 0.1).cuda()
+    coef = torch.stack([rnd(c, seed=4) * 0.5 + 1.0, rnd(c, seed=5) * 0.1, rnd(c, seed=6) * 0.1, rnd(c, seed=7) * 0.2 + 1.0]).cuda()
+    dl = rnd(n, h, w, seed=9).cuda()
+    for cf in (None, coef):
+        outs = []
+        for cast in (lambda t: t, lambda t: t.bfloat16()):
+            logit = torch.empty((n, h, w), device='cuda')
+            depth = torch.empty((n, h, w), device='cuda')
+            ops.head_fwd(cast(x), wt, logit, depth, 1.0, 100.0, coef=cf)
+            dw = torch.empty_like(wt)
+            ops.head_bwd_wgrad(cast(x), dl, dw, coef=cf)
+            outs.append((logit, depth, dw))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert float((outs[0][2] - outs[1][2]).abs().max()) <= 1e-6 * float(outs[0][2].abs().max())
+    dx_f = torch.empty((n, h, w, c), device='cuda')
+    dx_b = torch.empty((n, h, w, c), device='cuda').bfloat16()
+    ops.head_bwd_dgrad(dl, wt, dx_f)
+    ops.head_bwd_dgrad(dl, wt, dx_b)
+    assert torch.equal(dx_b.float(), dx_f.bfloat16().float())
+
+
+def test_convert_round_trip(ops):
+    x = rnd(1000003, seed=3).cuda()
+    y = torch.empty_like(x).bfloat16()
+    ops.convert(x, y)
+    assert torch.equal(y, x.bfloat16())          # round to nearest even, like torch
+    z = torch.ones_like(x)
+    ops.convert(y, z, accumulate=True)
+    assert torch.equal(z, 1.0 + y.float())
+
+
+def test_tiny_network_train_step_bf16_storage_against_oracle(ops):
+    '''End to end on the tiny topology (odd sizes at every level): one training step with bf16 tensors against the fp32 CPU oracle.'''
+    from oracle.fusionnet_oracle import FusionNetOracle
+    from rcf_amd import synth, train
+    m = train.build_model(synth.TINY, device='cuda')
+    synth.fill_state_dict_([m.encoder, m.decoder], 7)
+    m.compute_dtype = 'bf16'
+    o = FusionNetOracle(**synth.TINY)
+    synth.fill_state_dict_([o.encoder, o.decoder], 7)
+    cb = synth.make_batch(2, 70, 102, 8, seed=77)
+    b = {k: v.cuda() for k, v in cb.items()}
+    opt = train.make_optimizer(m, lr=1e-3)
+    m.train()
+    loss, _, out = train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])
+    torch.cuda.synchronize()
+    o.train()
+    ref = o.forward(cb['image'], cb['input_depth'])
+    ref_loss = o.compute_loss(ref, cb['ground_truth'], cb['lidar_map'], 2.0)[0]
+    ref_loss.backward()
+    e = float((out.detach().cpu() - ref.detach()).abs().max() / ref.detach().abs().max())
+    print('tiny bf16-storage step: out rel %.2e, loss %.5f vs %.5f' % (e, float(loss), float(ref_loss)))
+    assert e < 6e-2 and abs(float(loss) - float(ref_loss)) < 2e-2 * abs(float(ref_loss))
+    # parameter order differs (arena order vs module order): compare per named tensor
+    names_m = dict(list(m.encoder.named_parameters()) + [('d.' + k, v) for k, v in m.decoder.named_parameters()])
+    names_o = dict(list(o.encoder.named_parameters()) + [('d.' + k, v) for k, v in o.decoder.named_parameters()])
+    num = den_a = den_b = 0.0
+    for k, p in names_o.items():
+        if p.grad is None:
+            continue
+        a, bb = names_m[k].grad.double().cpu().reshape(-1), p.grad.double().reshape(-1)
+        num += float(torch.dot(a, bb)); den_a += float(torch.dot(a, a)); den_b += float(torch.dot(bb, bb))
+    cos = num / np.sqrt(den_a * den_b)
+    print('gradient cosine vs fp32 oracle %.4f' % cos)
+    assert cos > 0.95

@@ -380,7 +380,7 @@ def test_bf16_compute_mode_published_net(env, golden_dir):
     n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
     b = _gpu_batch(synth.make_batch(n, h, w, k, seed=dseed))
     outs = {}
-    for mode in ('fp32', 'bf16'):
+    for mode in ('fp32', 'bf16_operands', 'bf16'):
         m = _build(env, synth.PUBLISHED, wseed)
         m.compute_dtype = mode
         m.train()
@@ -389,18 +389,20 @@ def test_bf16_compute_mode_published_net(env, golden_dir):
         loss.backward()
         torch.cuda.synchronize()
         outs[mode] = (out.detach(), float(loss.detach()), m)
-    e32, e16 = _rel(outs['fp32'][0], g['output']), _rel(outs['bf16'][0], g['output'])
-    print('output rel err vs reference: fp32 %.2e, bf16 %.2e; loss %.5f / %.5f / ref %.5f' % (e32, e16, outs['fp32'][1], outs['bf16'][1], float(g['loss'][0])))
+    e32 = _rel(outs['fp32'][0], g['output'])
     assert e32 < BAR
-    assert 1e-4 < e16 < 5e-2
-    assert abs(outs['bf16'][1] - float(g['loss'][0])) < 2e-2 * abs(float(g['loss'][0]))
-    grads = dict(_named(outs['bf16'][2], 'p'))
-    bad = 0
-    for key, l2 in zip(g['grad_keys'].tolist(), g['grad_l2'].tolist()):
-        got = float(grads[key].grad.double().norm())
-        if abs(got - l2) > 0.25 * l2 + 1e-9:
-            bad += 1
-    assert bad <= len(g['grad_keys']) // 20, bad     # gradient norms within 25 % for (nearly) every parameter
+    for mode, bar in (('bf16_operands', 5e-2), ('bf16', 6e-2)):   # 'bf16': bf16 tensors in HBM as well (one more rounding per layer)
+        e16 = _rel(outs[mode][0], g['output'])
+        print('output rel err vs reference: fp32 %.2e, %s %.2e; loss %.5f / %.5f / ref %.5f' % (e32, mode, e16, outs['fp32'][1], outs[mode][1], float(g['loss'][0])))
+        assert 1e-4 < e16 < bar
+        assert abs(outs[mode][1] - float(g['loss'][0])) < 2e-2 * abs(float(g['loss'][0]))
+        grads = dict(_named(outs[mode][2], 'p'))
+        bad = 0
+        for key, l2 in zip(g['grad_keys'].tolist(), g['grad_l2'].tolist()):
+            got = float(grads[key].grad.double().norm())
+            if abs(got - l2) > 0.25 * l2 + 1e-9:
+                bad += 1
+        assert bad <= len(g['grad_keys']) // 20, (mode, bad)     # gradient norms within 25 % for (nearly) every parameter
 
 
 @pytest.mark.gpu

@@ -793,7 +793,7 @@ def test_bf16_operand_mode_matches_bf16_rounded_reference(ops, ksize, c1, c2, co
     rnd = lambda t: t.to(torch.bfloat16).to(torch.float32)
     x1 = torch.randn(n, h, w, c1, device=dev)
     x2 = torch.randn(n, h, w, c2, device=dev) if c2 else None
-    ops.set_precision('bf16')
+    ops.set_precision('bf16_operands')   # fp32 tensors, bf16 MFMA operands (the bf16-TENSOR configuration: tests/test_hip_bf16.py)
     try:
         if up:   # phase (1, 0) of the exact-2x UpConv: 2x2 conv, strided output
             wt = torch.randn(co, c1, 2, 2, device=dev) * 0.2
