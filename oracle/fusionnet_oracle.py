@@ -82,16 +82,42 @@ class ResNetBlock(torch.nn.Module):
         return F.leaky_relu(conv2 + X, LEAKY_SLOPE)
 
 
-class DecoderBlock(torch.nn.Module):
-    '''src/net_utils.py:473-569 with deconv_type='up' (hard-coded by src/fusionnet_main.py:190).'''
+class TransposeConv2d(torch.nn.Module):
+    '''src/net_utils.py:94-153 -- ConvTranspose2d(3, stride 2, padding 1, output_padding 1, bias=False) -> optional BN -> leaky_relu.'''
 
-    def __init__(self, in_channels, skip_channels, out_channels, use_batch_norm):
+    def __init__(self, in_channels, out_channels, use_batch_norm):
+        super().__init__()
+        self.deconv = torch.nn.ConvTranspose2d(in_channels, out_channels, kernel_size=3, stride=2, padding=1, output_padding=1,
+                                               bias=False)
+        self.use_batch_norm = use_batch_norm
+        if use_batch_norm:
+            self.batch_norm = torch.nn.BatchNorm2d(out_channels, eps=BN_EPS, momentum=BN_MOMENTUM)
+
+    def forward(self, x):
+        y = self.deconv(x)
+        if self.use_batch_norm:
+            y = self.batch_norm(y)
+        return F.leaky_relu(y, LEAKY_SLOPE)
+
+
+class DecoderBlock(torch.nn.Module):
+    '''src/net_utils.py:473-569; deconv_type 'up' (hard-coded by src/fusionnet_main.py:190) or 'transpose' (:507-513, :550-551).'''
+
+    def __init__(self, in_channels, skip_channels, out_channels, use_batch_norm, deconv_type='up'):
         super().__init__()
         self.skip_channels = skip_channels
-        self.deconv = UpConv2d(in_channels, out_channels, use_batch_norm)
+        self.deconv_type = deconv_type
+        if deconv_type == 'transpose':
+            self.deconv = TransposeConv2d(in_channels, out_channels, use_batch_norm)
+        else:
+            self.deconv = UpConv2d(in_channels, out_channels, use_batch_norm)
         self.conv = Conv2d(skip_channels + out_channels, out_channels, 3, 1, 'leaky_relu', use_batch_norm)
 
     def forward(self, x, skip=None, shape=None):
+        if self.deconv_type == 'transpose':
+            deconv = self.deconv(x)
+            concat = torch.cat([deconv, skip], dim=1) if self.skip_channels > 0 else deconv
+            return self.conv(concat)
         if skip is not None:
             shape = skip.shape[2:4]
         elif shape is None:
@@ -147,14 +173,14 @@ class FusionNetEncoder(torch.nn.Module):
 class MultiScaleDecoder(torch.nn.Module):
     '''src/networks.py:1337-1657 on the n_resolution=1, output_func='linear' path.'''
 
-    def __init__(self, input_channels, n_filters, n_skips, use_batch_norm):
+    def __init__(self, input_channels, n_filters, n_skips, use_batch_norm, deconv_type='up'):
         super().__init__()
         depth = len(n_filters)
         assert 5 <= depth < 8 and len(n_skips) == depth
         self.names = ['deconv%d' % i for i in range(depth - 1, -1, -1)]   # deconv5..deconv0 for 6
         cin = input_channels
         for name, skip_c, out_c in zip(self.names, n_skips, n_filters):
-            setattr(self, name, DecoderBlock(cin, skip_c, out_c, use_batch_norm))
+            setattr(self, name, DecoderBlock(cin, skip_c, out_c, use_batch_norm, deconv_type))
             cin = out_c
         self.output0 = Conv2d(cin, 1, 3, 1, 'linear', False)                # :1548-1555
 
@@ -179,14 +205,14 @@ class FusionNetOracle(object):
                  n_filters_encoder_depth=(16, 32, 64, 128, 128, 128),
                  n_filters_decoder=(256, 256, 128, 64, 64, 32),
                  encoder_batch_norm=True, decoder_batch_norm=True,
-                 min_predict_depth=1.0, max_predict_depth=100.0):
+                 min_predict_depth=1.0, max_predict_depth=100.0, deconv_type='up'):
         self.min_predict_depth = min_predict_depth
         self.max_predict_depth = max_predict_depth
         fi = list(n_filters_encoder_image)
         self.encoder = FusionNetEncoder(input_channels_image, input_channels_depth,
                                         fi, list(n_filters_encoder_depth), encoder_batch_norm)
         n_skips = fi[:-1][::-1] + [0]                                        # :118-119
-        self.decoder = MultiScaleDecoder(fi[-1], list(n_filters_decoder), n_skips, decoder_batch_norm)
+        self.decoder = MultiScaleDecoder(fi[-1], list(n_filters_decoder), n_skips, decoder_batch_norm, deconv_type)
 
     def forward(self, image, input_depth):
         latent, skips = self.encoder(image, input_depth)

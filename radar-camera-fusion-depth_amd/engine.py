@@ -108,6 +108,10 @@ class Engine(object):
         if x2 is not None and tuple(self._shape(x2)[1:3]) != (h_in, w_in):
             raise ValueError('skip connection and upsampled tensor disagree in size')
         weight = layer.conv.weight
+        if getattr(layer, 'deconv', None) is not None and weight.dim() == 4 and isinstance(layer.deconv, torch.nn.ConvTranspose2d):
+            if x2 is not None or up_hw is not None:
+                raise ValueError('a transposed convolution takes one source at its own resolution')
+            return self._conv_transpose(layer, x, want_stats, fold)
         if (self.use_phase_convs and gather == RCF_GATHER_NEAREST and x2 is None and layer.kernel_size == 3
                 and layer.stride == 1 and (h_in, w_in) == (2 * h, 2 * w) and c1 % 4 == 0):
             return self._conv_up2x(layer, x, want_stats, fold)
@@ -191,6 +195,61 @@ class Engine(object):
             return z, None, info, partials, fused
         return z, None, info, partials
 
+    def _conv_transpose(self, layer, x, want_stats, fold=None):
+        '''
+        TransposeConv2d's ConvTranspose2d(3, stride 2, padding 1, output_padding 1) (src/net_utils.py:94-153): y (2H x 2W) is the
+        input gradient of a VIRTUAL 3x3 stride-2 convolution 2H x 2W -> H x W whose OIHW weight [in][out][3][3] is exactly the
+        transposed convolution's weight tensor -- so it runs on the same four 2x2 phase convolutions as the input gradient of the
+        encoder's stride-2 convolutions (output phase (a, b) only sees the taps of its parity: 1 + 2 + 2 + 4 = 9 real taps).
+        '''
+        n, h, w, ci = self._shape(x)
+        weight = layer.conv.weight
+        co = weight.shape[1]
+        if ci % 4 != 0 or co % 4 != 0 or weight.shape[0] != ci:
+            raise ValueError('transposed convolution: channel counts must be multiples of 4 and match the input')
+        virt = ops.make_fwd_desc(n, 2 * h, 2 * w, co, 0, ci, 3, 2)       # the convolution this one is the transpose of
+        t1 = self._mat(x)
+        wd = ops.phase_weights(weight.detach(), RCF_PHASE_S2_DGRAD)
+        z = self._new((n, 2 * h, 2 * w, co), t1)
+        partials, n_part = None, 0
+        for ph in range(4):
+            d = ops.make_s2_dgrad_desc(virt, ph >> 1, ph & 1, False)
+            if ph == 0:
+                n_part = ops.conv_query(d).n_partials
+                if want_stats:
+                    partials = torch.empty((4 * n_part, 2, co), dtype=torch.float64, device=t1.device)
+            self._run_packed(d, wd[ph], t1, z, None if partials is None else partials[ph * n_part:(ph + 1) * n_part])
+
+        class _Info(object):
+            pass
+        info = _Info()
+        info.n_partials = 4 * n_part
+        info.transpose = virt
+        if fold is not None:
+            return z, None, info, partials, False
+        return z, None, info, partials
+
+    def _conv_transpose_backward(self, layer, info, x, dz):
+        '''dW = the weight gradient of the virtual stride-2 convolution with the roles swapped (its input is dY, its output
+        gradient is x) -- already in the [in][out][3][3] layout of ConvTranspose2d.weight; dX = that convolution applied to dY.'''
+        virt = info.transpose
+        weight = layer.conv.weight
+        qi = ops.conv_query(virt)
+        ws = self._newf((max(1, qi.wgrad_workspace_floats),), dz)
+        if self.prof is not None:
+            self.prof.begin(qi.wgrad_kernel_id, ops.algorithmic_flops(virt), virt)
+        ops.conv_wgrad(virt, dz, None, self._mat(x), self.grad_of(weight), ws)
+        if self.prof is not None:
+            self.prof.end()
+        self._wgrad_done(weight)
+        if x.needs_grad:
+            acc = x.g is not None
+            if not acc:
+                x.g = self._new(tuple(self._shape(x)), dz)
+            dd = ops.make_fwd_desc(virt.n, virt.h_in, virt.w_in, virt.c1, 0, virt.c_out, 3, 2)
+            dd.accumulate = 1 if acc else 0
+            self._run_packed(dd, weight.detach(), dz, x.g)
+
     def _conv_up2x_backward(self, layer, info, x, dz):
         n, h, w, c1 = self._shape(x)
         weight = layer.conv.weight
@@ -227,6 +286,8 @@ class Engine(object):
 
     def _conv_backward(self, layer, desc, info, x, x2, dz):
         '''dW (written once into the parameter's gradient) and dX / dX2 (accumulated into the producers' .g).'''
+        if desc is None and hasattr(info, 'transpose'):
+            return self._conv_transpose_backward(layer, info, x, dz)
         if desc is None:
             return self._conv_up2x_backward(layer, info, x, dz)
         weight = layer.conv.weight
@@ -459,7 +520,16 @@ class Engine(object):
         return self.conv_bn_act(block.conv2, c1, res=shortcut)
 
     def decoder_block(self, block, x, skip=None, shape=None, feeds_head=False):
-        '''DecoderBlock.forward (src/net_utils.py:535-569), deconv_type 'up'.'''
+        '''DecoderBlock.forward (src/net_utils.py:535-569), deconv_type 'up' or 'transpose'.'''
+        if block.deconv_type == 'transpose':
+            deconv = self.conv_bn_act(block.deconv, x)       # always 2x; `shape` is ignored like in the reference (:554-555)
+            if skip is not None and tuple(self._shape(skip)[1:3]) != tuple(self._shape(deconv)[1:3]):
+                # the reference fails in torch.cat here (e.g. 15 -> 30 against a 29-row skip at 900 x 1600)
+                raise RuntimeError('Sizes of tensors must match except in dimension 1: transposed convolution gives %s, skip is %s'
+                                   % (tuple(self._shape(deconv)[1:3]), tuple(self._shape(skip)[1:3])))
+            if block.skip_channels > 0:
+                return self.conv_bn_act(block.conv, deconv, x2=skip, feeds_head=feeds_head)
+            return self.conv_bn_act(block.conv, deconv, feeds_head=feeds_head)
         if skip is not None:
             shape = self._shape(skip)[1:3]
         elif shape is None:

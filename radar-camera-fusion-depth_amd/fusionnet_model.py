@@ -193,7 +193,7 @@ class FusionNetModel(object):
             conv_block(getattr(enc, 'conv%d_weight' % lvl)); conv_block(getattr(enc, 'conv%d_project' % lvl))
         for name in dec.block_names:
             blk = getattr(dec, name)
-            conv_block(blk.deconv.conv); conv_block(blk.conv)
+            conv_block(blk.deconv if blk.deconv_type == 'transpose' else blk.deconv.conv); conv_block(blk.conv)
         conv_block(dec.output0)
         return order
 

@@ -72,6 +72,43 @@ class UpConv2d(_NoForward):
                            use_batch_norm=use_batch_norm)
 
 
+class TransposeConv2d(_NoForward):
+    '''src/net_utils.py:94-153: ConvTranspose2d(k, stride 2, padding k // 2, output_padding 1, bias=False) + optional BatchNorm2d
+    + optional activation.  State-dict names as in the reference: `deconv.weight` ([in, out, k, k]), `batch_norm.*`.
+
+    The reference class only works with its default initializer: for the others it touches `self.conv`, which does not exist
+    (src/net_utils.py:135-140, AttributeError).  Here those initializers are applied to the transposed-convolution weight --
+    what the code evidently meant.  On the engine the forward is the 4-phase transposed convolution that already serves as the
+    input gradient of the stride-2 convolutions; its own gradients are a stride-2 convolution (dX) and a stride-2 weight gradient.'''
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, weight_initializer='kaiming_uniform',
+                 activation_func='leaky_relu', use_batch_norm=False):
+        super(TransposeConv2d, self).__init__()
+        if kernel_size != 3:
+            raise ValueError('Transposed convolution on the HIP path is 3x3 (the only size DecoderBlock builds, src/net_utils.py:510)')
+        self.use_batch_norm = use_batch_norm
+        self.kernel_size = kernel_size
+        self.stride = 2
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.deconv = torch.nn.ConvTranspose2d(in_channels, out_channels, kernel_size=kernel_size, stride=2,
+                                               padding=kernel_size // 2, output_padding=1, bias=False)
+        if weight_initializer == 'kaiming_normal':
+            torch.nn.init.kaiming_normal_(self.deconv.weight)
+        elif weight_initializer == 'xavier_normal':
+            torch.nn.init.xavier_normal_(self.deconv.weight)
+        elif weight_initializer == 'xavier_uniform':
+            torch.nn.init.xavier_uniform_(self.deconv.weight)
+        self.activation_func = activation_func
+        if self.use_batch_norm:
+            self.batch_norm = torch.nn.BatchNorm2d(out_channels)
+
+    @property
+    def conv(self):
+        '''the module holding `.weight`, under the name the engine uses for every convolution block'''
+        return self.deconv
+
+
 class ResNetBlock(_NoForward):
     '''src/net_utils.py:253-323.  `projection` (1x1, no BN, no activation) is always allocated (:300-307) and only
     used when the block changes shape (:317-320) -- 10 of them never receive gradients in the published net.'''
@@ -93,7 +130,9 @@ class ResNetBlock(_NoForward):
 
 
 class DecoderBlock(_NoForward):
-    '''src/net_utils.py:473-569 with deconv_type 'up' (the only one the reference can run).'''
+    '''src/net_utils.py:473-569.  deconv_type 'up' is what the shipped entry points hard-code (src/fusionnet_main.py:190);
+    'transpose' (src/net_utils.py:507-513) needs every level to be exactly 2x the previous one, i.e. input sizes divisible by 64
+    such as the 448 x 448 training crop -- at 900 x 1600 the reference itself fails in torch.cat.'''
 
     def __init__(self, in_channels, skip_channels, out_channels, weight_initializer='kaiming_uniform',
                  activation_func='leaky_relu', use_batch_norm=False, deconv_type='up'):
@@ -102,10 +141,11 @@ class DecoderBlock(_NoForward):
         self.deconv_type = deconv_type
         if deconv_type == 'up':
             self.deconv = UpConv2d(in_channels, out_channels, 3, weight_initializer, activation_func, use_batch_norm)
+        elif deconv_type == 'transpose':
+            self.deconv = TransposeConv2d(in_channels, out_channels, 3, weight_initializer, activation_func, use_batch_norm)
         else:
-            # src/net_utils.py:94-153: TransposeConv2d cannot run at 900x1600 (odd sizes) and crashes for
-            # non-default initialisers in the reference itself; the shipped entry points hard-code 'up'.
-            raise ValueError('Unsupported deconv type on the HIP path: {}'.format(deconv_type))
+            # the reference leaves self.deconv undefined for any other value (AttributeError at the first forward)
+            raise ValueError('Unsupported deconv type: {}'.format(deconv_type))
         self.conv = Conv2d(skip_channels + out_channels, out_channels, 3, 1, weight_initializer, activation_func,
                            use_batch_norm)
 

@@ -165,7 +165,7 @@ class RadarNetModel(object):
             order.extend([fc.fully_connected.weight, fc.fully_connected.bias])
         for name in dec.block_names:
             blk = getattr(dec, name)
-            conv_block(blk.deconv.conv)
+            conv_block(blk.deconv if blk.deconv_type == 'transpose' else blk.deconv.conv)
             conv_block(blk.conv)
         conv_block(dec.output0)
         return order

@@ -77,7 +77,7 @@ def fill_state_dict_(modules, seed):
                 t.zero_()
                 continue
             shape = tuple(t.shape)
-            if k.endswith('conv.weight') or k.endswith('fully_connected.weight'):
+            if k.endswith('conv.weight') or k.endswith('fully_connected.weight') or k.endswith('deconv.deconv.weight'):
                 fan_in = int(np.prod(shape[1:]))
                 b = 1.0 / np.sqrt(fan_in)
                 v = rs.uniform(-b, b, size=shape)

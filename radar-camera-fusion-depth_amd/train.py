@@ -9,7 +9,7 @@ from .fusionnet_model import FusionNetModel
 from .optim import FusedAdam
 
 
-def build_model(cfg=None, device='cuda', weight_initializer='kaiming_uniform'):
+def build_model(cfg=None, device='cuda', weight_initializer='kaiming_uniform', deconv_type='up'):
     '''FusionNetModel with the shipped flags (bash/train_fusionnet_nuscenes.sh:27-40; deconv 'up' per src/fusionnet_main.py:190).'''
     cfg = synth.PUBLISHED if cfg is None else cfg
     return FusionNetModel(
@@ -22,7 +22,7 @@ def build_model(cfg=None, device='cuda', weight_initializer='kaiming_uniform'):
         decoder_type=['multiscale', 'batch_norm'],
         n_resolution_decoder=1,
         n_filters_decoder=cfg['n_filters_decoder'],
-        deconv_type='up',
+        deconv_type=deconv_type,
         activation_func='leaky_relu',
         weight_initializer=weight_initializer,
         min_predict_depth=1.0,

@@ -122,6 +122,85 @@ def test_t0_tiny_train_step_matches_reference_golden(env, golden_dir):
     print('T0 worst gradient rel err %.2e' % worst)
 
 
+def _build_transpose(env, cfg, seed):
+    synth, train = env
+    m = train.build_model(cfg, device='cuda', deconv_type='transpose')
+    synth.fill_state_dict_([m.encoder, m.decoder], seed)
+    return m
+
+
+def test_t10_transposed_convolution_decoder_matches_reference_golden(env, golden_dir):
+    '''deconv_type='transpose' (net_utils.TransposeConv2d, src/net_utils.py:94-153; selected at :507-513): forward as the 4-phase
+    transposed convolution, dX as a stride-2 convolution, dW as a stride-2 weight gradient -- against fixture T10 from the REAL
+    reference: output, loss, every parameter gradient (tiny net) and the gradient norms of the published net.'''
+    synth, _ = env
+    g = np.load(os.path.join(golden_dir, 'T10_transpose_tiny_train.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    m = _build_transpose(env, synth.TINY, wseed)
+    assert [k2 for k2 in m.decoder.state_dict() if k2.endswith('deconv.deconv.weight')], 'reference state-dict names'
+    b = _gpu_batch(synth.make_batch(n, h, w, k, seed=dseed))
+    m.train()
+    out = m.forward(image=b['image'], input_depth=b['input_depth'])
+    loss, info = _loss(m, b, out)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert _rel(out, g['output']) < BAR
+    np.testing.assert_allclose([float(loss), float(info['loss_supervised']), float(info['loss_lidar'])], g['loss'], rtol=BAR)
+    unused = set(g['unused'].tolist())
+    worst = 0.0
+    for key, p in _named(m, 'p'):
+        if key in unused:
+            assert p.grad is None, key
+            continue
+        e = _rel(p.grad, g['grad:' + key])
+        worst = max(worst, e)
+        assert e < BAR, (key, e)
+    for key, buf in _named(m, 'b'):
+        assert _rel(buf, g['buf:' + key]) < BAR, key
+    print('T10a worst gradient rel err %.2e' % worst)
+    g = np.load(os.path.join(golden_dir, 'T10_transpose_published_train.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    m = _build_transpose(env, synth.PUBLISHED, wseed)
+    b = _gpu_batch(synth.make_batch(n, h, w, k, seed=dseed))
+    m.train()
+    out = m.forward(image=b['image'], input_depth=b['input_depth'])
+    loss, info = _loss(m, b, out)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert _rel(out, g['output']) < BAR
+    np.testing.assert_allclose([float(loss), float(info['loss_supervised']), float(info['loss_lidar'])], g['loss'], rtol=BAR)
+    grads = dict(_named(m, 'p'))
+    for key, l2 in zip(g['grad_keys'].tolist(), g['grad_l2'].tolist()):
+        got = float(grads[key].grad.double().norm())
+        assert abs(got - l2) <= 5 * BAR * l2 + 1e-12, (key, got, l2)
+
+
+def test_transposed_convolution_decoder_448_crop_eval_and_size_rule(env):
+    '''The shipped training crop (448 x 448, bash/train_fusionnet_nuscenes.sh:25-26), batch 2, against the oracle (pinned to the
+    reference by T10): train-mode output / loss, eval-mode output; and at 900 x 1600 the same failure as the reference
+    (15 -> 30 rows against a 29-row skip).'''
+    from oracle.fusionnet_oracle import FusionNetOracle
+    synth, _ = env
+    cb = synth.make_batch(2, 448, 448, 32, seed=611)
+    b = _gpu_batch(cb)
+    m = _build_transpose(env, synth.PUBLISHED, 61)
+    o = FusionNetOracle(deconv_type='transpose', **synth.PUBLISHED)
+    synth.fill_state_dict_([o.encoder, o.decoder], 61)
+    for mode in ('train', 'eval'):
+        getattr(m, mode)(); getattr(o, mode)()
+        with torch.no_grad():
+            out = m.forward(b['image'], b['input_depth'])
+            ref = o.forward(cb['image'], cb['input_depth'])
+            ref_loss = float(o.compute_loss(ref, cb['ground_truth'], cb['lidar_map'], 2.0)[0])
+        loss, _ = _loss(m, b, out)
+        assert _rel(out, ref) < BAR, mode
+        assert abs(float(loss) - ref_loss) < BAR * abs(ref_loss)
+    m.train()
+    big = _gpu_batch(synth.make_batch(1, 900, 1600, 8, seed=5))
+    with pytest.raises(RuntimeError, match='Sizes of tensors must match'):
+        m.forward(big['image'], big['input_depth'])
+
+
 def test_t1_published_config1_matches_reference_golden(env, golden_dir):
     synth, _ = env
     g = np.load(os.path.join(golden_dir, 'T1_published_train.npz'))

@@ -107,13 +107,16 @@ def test_error_behaviour_mirrors_reference(pkg):
                 n_filters_decoder=[32, 32, 16, 8, 8, 4], deconv_type='up', activation_func='leaky_relu',
                 weight_initializer='kaiming_uniform', min_predict_depth=1.0, max_predict_depth=100.0, device='cpu')
     for key, bad in (('fusion_type', 'bogus'), ('encoder_type', ['vgg11']), ('decoder_type', ['unet']),
-                     ('activation_func', 'swish'), ('deconv_type', 'transpose')):
+                     ('activation_func', 'swish'), ('deconv_type', 'bilinear')):
         kw = dict(base); kw[key] = bad
         with pytest.raises(ValueError):           # src/fusionnet_model.py:82, :90, :115, :135; src/net_utils.py:23
             FusionNetModel(**kw)
     with pytest.raises(ValueError):
         net_utils.activation_func('tanh')
     m = FusionNetModel(**base)
+    t = FusionNetModel(**dict(base, deconv_type='transpose'))      # src/net_utils.py:507-513: reference state-dict names
+    assert tuple(t.decoder.state_dict()['deconv5.deconv.deconv.weight'].shape) == (32, 32, 3, 3)
+    assert 'deconv5.deconv.batch_norm.running_var' in t.decoder.state_dict()
     with pytest.raises(ValueError):               # src/fusionnet_model.py:275
         m.compute_loss(None, torch.zeros(1, 1, 4, 4), torch.zeros(1, 1, 4, 4), torch.zeros(1, 1, 4, 4), 'huber', 0.0, -1, None, 2.0)
 

@@ -158,3 +158,30 @@ def test_radarnet_oracle_reproduces_reference_fixture_t5(golden_dir):
         else:
             ref = g['grad:' + k]
             assert float(np.abs(p.grad.numpy() - ref).max()) <= 5e-4 * float(np.abs(ref).max()) + 1e-9, k
+
+
+def test_t10_transposed_convolution_decoder(golden_dir):
+    '''deconv_type='transpose' (net_utils.TransposeConv2d, src/net_utils.py:94-153): the oracle against the real reference's
+    output, loss, every gradient and BatchNorm buffer (fixture T10, tests/golden/make_golden_transpose.py).'''
+    g = np.load(os.path.join(golden_dir, 'T10_transpose_tiny_train.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    m = FusionNetOracle(deconv_type='transpose', **synth.TINY)
+    synth.fill_state_dict_([m.encoder, m.decoder], wseed)
+    b = synth.make_batch(n, h, w, k, seed=dseed)
+    m.train()
+    out = m.forward(b['image'], b['input_depth'])
+    loss, ls, ll = m.compute_loss(out, b['ground_truth'], b['lidar_map'], 2.0)
+    loss.backward()
+    assert _rel(out.detach(), g['output']) < 1e-5
+    np.testing.assert_allclose([float(loss), float(ls), float(ll)], g['loss'], rtol=1e-5)
+    unused = set(g['unused'].tolist())
+    seen_deconv = 0
+    for key, p in _named(m, 'p'):
+        if key in unused:
+            assert p.grad is None
+            continue
+        assert _rel(p.grad, g['grad:' + key]) < 2e-4, key
+        seen_deconv += key.endswith('deconv.deconv.weight')
+    assert seen_deconv == 6          # deconv5 .. deconv0 all carry a ConvTranspose2d weight of shape [in, out, 3, 3]
+    for key, buf in _named(m, 'b'):
+        assert _rel(buf, g['buf:' + key]) < 1e-5, key
