@@ -260,6 +260,12 @@ int rcf_outlier_removal(const float* depth, float* out, float* scratch, int n, i
 int rcf_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, void* stream);
 
+/* The same update with the step count and the hyper-parameters in DEVICE memory, so a recorded launch sequence (hipGraph) performs
+ * a correct optimizer.step() on every replay: state (device float[8]) = {step count so far, lr, beta1, beta2, eps, weight_decay,
+ * scratch, scratch}.  The call advances state[0] by one, derives the bias corrections from it (in double, like the host path) and
+ * applies torch.optim.Adam's update (src/fusionnet_main.py:399).  The host changes lr etc. by writing state[1..5]. */
+int rcf_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, float* state, void* stream);
+
 /* NCHW (the reference's public tensor layout) <-> NHWC (kernel layout). */
 int rcf_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, void* stream);
 int rcf_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, void* stream);

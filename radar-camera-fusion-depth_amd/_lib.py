@@ -91,6 +91,7 @@ _SIGNATURES = {
     'rcf_l1_loss_bwd': (c_int, [_P, _P, _P, _P, _P, c_float, _P, c_longlong, _P]),
     'rcf_outlier_removal': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     'rcf_adam_step': (c_int, [_P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
+    'rcf_adam_step_dev': (c_int, [_P, _P, _P, _P, c_longlong, _P, _P]),
     'rcf_nchw_to_nhwc': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     'rcf_nhwc_to_nchw': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     'rcf_radar_scatter': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),

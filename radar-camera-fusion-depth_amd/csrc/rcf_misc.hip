@@ -582,6 +582,35 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// Graph-capturable form: the step count and the hyper-parameters live in device memory (state[8] = step, lr, beta1, beta2, eps,
+// weight_decay, step_size, 1/sqrt(bias_correction2)); adam_tick_kernel advances the count and derives the two bias-correction
+// factors in double (as the host does for rcf_adam_step), adam_dev_kernel applies the update with what it finds there.
+__global__ void adam_tick_kernel(float* __restrict__ state) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float step = state[0] + 1.f;
+    state[0] = step;
+    const double bc1 = 1.0 - pow((double)state[2], (double)step);
+    const double bc2 = 1.0 - pow((double)state[3], (double)step);
+    state[6] = (float)((double)state[1] / bc1);
+    state[7] = (float)(1.0 / sqrt(bc2));
+}
+
+__global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long long n, const float* __restrict__ state) {
+    const float b1 = state[2], b2 = state[3], eps = state[4], wd = state[5], step_size = state[6], inv_bc2_sqrt = state[7];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
 // ---------------------------------------------------------------- layout
 __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int c,
                                                            long long hw) {
@@ -887,6 +916,15 @@ extern "C" int rcf_adam_step(float* p, const float* g, float* m, float* v, long 
     unsigned b = nblk(n, 256); if (b > 8192) b = 8192;
     hipLaunchKernelGGL(adam_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
                        step_size, inv_bc2_sqrt);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, float* state, void* stream) {
+    if (!p || !g || !m || !v || !state || n <= 0) return RCF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st, state);
+    unsigned b = nblk(n, 256); if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(b), dim3(256), 0, st, p, g, m, v, n, state);
     return rcf_launch_status();
 }
 

@@ -467,6 +467,86 @@ class FusionNetModel(object):
         run.graph = graph
         return run
 
+    def capture_training_step(self, optimizer, image, input_depth, ground_truth, lidar_map, w_lidar_loss=2.0, outlier_removal=None,
+                              warmup=2):
+        '''
+        Records ONE whole training step of the reference's loop body (src/fusionnet_main.py:369-399: forward -> outlier removal ->
+        compute_loss -> zero_grad -> backward -> optimizer.step) for inputs of this shape into a single hipGraph and returns
+        `step(image, input_depth, ground_truth, lidar_map) -> loss`: each call copies the batch into the graph's static buffers and
+        replays the ~1100 kernel launches with one hipGraphLaunch (host time per step drops from ~12 ms of Python to well under
+        1 ms).  Everything a replay must see fresh lives in device memory: parameters, gradients, Adam moments, the Adam step count
+        and hyper-parameters (rcf_adam_step_dev), BatchNorm statistics.  Capturing has no side effect on the training state: the
+        warm-up steps it needs are rolled back.  Single-GPU only (the data-parallel exchange is not recorded); the optimizer must
+        be rcf_amd.optim.FusedAdam.  Passing None for an input reuses what the static buffer holds.
+        '''
+        from . import train
+        from .optim import FusedAdam
+        if self._dp is not None:
+            raise _lib.RcfError('capture_training_step records the single-GPU step; data-parallel runs launch eagerly')
+        if not isinstance(optimizer, FusedAdam):
+            raise _lib.RcfError('capture_training_step needs rcf_amd.optim.FusedAdam (step count and hyper-parameters on the device)')
+        if not self._training:
+            raise _lib.RcfError('capture_training_step records the train-mode step: call train() first')
+        if not image.is_cuda:
+            raise _lib.RcfError('capture_training_step needs CUDA(HIP) tensors (got %s)' % image.device)
+        dev = image.device
+        static = [t.detach().clone() for t in (image, input_depth, ground_truth, lidar_map)]
+
+        def one():
+            return train.train_step(self, optimizer, static[0], static[1], static[2], static[3], w_lidar_loss=w_lidar_loss,
+                                    outlier_removal=outlier_removal)[0]
+
+        # ---- snapshot of everything a training step changes
+        buffers = [b for mod in (self.encoder, self.decoder) for b in mod.buffers()]
+        snap = {'params': self._param_arena.clone(), 'buffers': [b.clone() for b in buffers], 'nbt': self._nbt.clone(),
+                'moments': {k: (m.clone(), v.clone()) for k, (m, v) in optimizer._moment_arenas.items()},
+                'steps': {k: float(t) for k, t in optimizer._shared_steps.items()}, 'had_state': len(optimizer.state) > 0}
+        prof, self._engine.prof = self._engine.prof, None
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):   # lazy one-time state (function attributes, allocator pools, optimizer state) before recording
+            for _ in range(max(1, warmup)):
+                one()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = one()
+        self._engine.prof = prof
+        # ---- roll the warm-up back (the capture itself executed nothing)
+        with torch.no_grad():
+            self._param_arena.copy_(snap['params'])
+            for b, saved in zip(buffers, snap['buffers']):
+                b.copy_(saved)
+            self._nbt.copy_(snap['nbt'])
+            for k, (m, v) in optimizer._moment_arenas.items():
+                if k in snap['moments']:
+                    m.copy_(snap['moments'][k][0]); v.copy_(snap['moments'][k][1])
+                else:
+                    m.zero_(); v.zero_()
+            for k, t in optimizer._shared_steps.items():
+                t.fill_(snap['steps'].get(k, 0.0))
+            for k, ds in optimizer._dev_state.items():
+                step0 = snap['steps'].get(k, 0.0)
+                ds[0][0:1].fill_(step0)
+                ds[2] = int(step0)
+        torch.cuda.synchronize(dev)
+        shapes = [tuple(t.shape) for t in static]
+
+        def step(image=None, input_depth=None, ground_truth=None, lidar_map=None):
+            for dst, src, shp in zip(static, (image, input_depth, ground_truth, lidar_map), shapes):
+                if src is None or src.data_ptr() == dst.data_ptr():
+                    continue
+                if tuple(src.shape) != shp:
+                    raise _lib.RcfError('captured for %s, got %s' % (shp, tuple(src.shape)))
+                dst.copy_(src, non_blocking=True)
+            graph.replay()
+            optimizer.note_replayed_step()
+            return static_loss
+        step.graph = graph
+        step.static_inputs = static
+        return step
+
     def log_summary(self, summary_writer, tag, step, image=None, input_depth=None, input_response=None,
                     output_depth=None, ground_truth=None, scalars={}, n_display=4):
         '''

@@ -432,6 +432,11 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
                                     step, _stream()), 'rcf_adam_step')
 
 
+def adam_step_dev(p, g, m, v, state):
+    """Adam with step count and hyper-parameters in the device buffer `state` (float32[8]): capturable in a hipGraph."""
+    check(_lib.load().rcf_adam_step_dev(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), _f32(state), _stream()), 'rcf_adam_step_dev')
+
+
 def nchw_to_nhwc(x):
     n, c, h, w = x.shape
     out = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)

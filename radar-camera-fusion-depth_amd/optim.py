@@ -19,6 +19,10 @@ class FusedAdam(torch.optim.Optimizer):
                         decoupled_weight_decay=False)
         super(FusedAdam, self).__init__(params, defaults)
         self._moment_arenas = {}   # id(param arena) -> (exp_avg arena, exp_avg_sq arena)
+        # flat path: step count + hyper-parameters in device memory (rcf_adam_step_dev), so that a hipGraph-captured training step
+        # performs a correct update on every replay.  id(param arena) -> [device float32[8], host copy of its hyper-parameters]
+        self._dev_state = {}
+        self._shared_steps = {}    # id(param arena) -> the host-side step tensor its parameters' states share
 
     def _init_state(self, p):
         state = self.state[p]
@@ -29,6 +33,9 @@ class FusedAdam(torch.optim.Optimizer):
         if arena is not None:
             parena, _, off = arena
             key = id(parena)
+            # parameters of one arena step together: ONE host-side step tensor shared by their states (one increment per step
+            # instead of ~270; state_dict() still reports it per parameter, like torch.optim.Adam)
+            state['step'] = self._shared_steps.setdefault(key, state['step'])
             if key not in self._moment_arenas:
                 self._moment_arenas[key] = (torch.zeros_like(parena), torch.zeros_like(parena))
             m, v = self._moment_arenas[key]
@@ -57,7 +64,9 @@ class FusedAdam(torch.optim.Optimizer):
                     view = ar[off:off + p.numel()].view(p.shape)
                     view.copy_(st[name])
                     st[name] = view
-                st['step'] = torch.as_tensor(float(st['step']), dtype=torch.float32)
+                shared = self._shared_steps.setdefault(key, torch.tensor(0.0, dtype=torch.float32))
+                shared.fill_(float(st['step']))
+                st['step'] = shared
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -73,8 +82,11 @@ class FusedAdam(torch.optim.Optimizer):
                 raise ValueError('FusedAdam: amsgrad / maximize are not implemented')
             beta1, beta2 = group['betas']
             states = [self._init_state(p) for p in params]
+            bumped = set()
             for st in states:
-                st['step'] += 1
+                if id(st['step']) not in bumped:     # states of one arena share their step tensor
+                    bumped.add(id(st['step']))
+                    st['step'] += 1
             if not self._flat_step(group, params, states, beta1, beta2):
                 for p, st in zip(params, states):
                     g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
@@ -110,6 +122,24 @@ class FusedAdam(torch.optim.Optimizer):
         if hi - lo != total:
             return False
         m, v = self._moment_arenas[id(parena)]
-        ops.adam_step(parena[lo:hi], garena[lo:hi], m[lo:hi], v[lo:hi], group['lr'], beta1, beta2, group['eps'],
-                      group['weight_decay'], step0)
+        hyper = (float(group['lr']), float(beta1), float(beta2), float(group['eps']), float(group['weight_decay']))
+        ds = self._dev_state.get(id(parena))
+        if ds is None or ds[2] != step0 - 1:
+            # first use, or the host-side step count moved on its own (load_state_dict): (re)seed the device counter
+            dev = torch.tensor([float(step0 - 1)] + list(hyper) + [0.0, 0.0], dtype=torch.float32).to(parena.device)
+            ds = [dev, hyper, step0 - 1]
+            self._dev_state[id(parena)] = ds
+        elif ds[1] != hyper:
+            ds[0][1:6].copy_(torch.tensor(hyper, dtype=torch.float32))   # learning-rate schedule etc. (never inside a capture)
+            ds[1] = hyper
+        ops.adam_step_dev(parena[lo:hi], garena[lo:hi], m[lo:hi], v[lo:hi], ds[0])
+        ds[2] = step0
         return True
+
+    def note_replayed_step(self):
+        '''A hipGraph replay of a captured step() has advanced the device-side step count: advance the host-side mirror (the
+        per-parameter 'step' entries that state_dict() reports) without launching anything.'''
+        for shared in self._shared_steps.values():
+            shared += 1
+        for ds in self._dev_state.values():
+            ds[2] += 1

@@ -537,3 +537,69 @@ def test_inference_with_folded_batchnorm_matches_unfused_eval_path(env, golden_d
         assert _rel(outs[True], outs[False]) < 2e-5
         if tag == 'published':
             assert not torch.equal(outs[True], outs[False])
+
+
+def test_hipgraph_captured_training_step_is_bitwise_the_eager_step(env, golden_dir):
+    '''FusionNetModel.capture_training_step: forward + outlier removal + loss + backward + Adam recorded into ONE hipGraph.  Three
+    replays on the three batches of fixture T2 against three eager steps from the same start: losses, parameters, Adam moments,
+    BatchNorm running statistics and step counts are bitwise equal; the trajectory matches the reference's (T2); capturing itself
+    leaves the training state untouched.'''
+    from rcf_amd.net_utils import OutlierRemoval
+    synth, train = env
+    g = np.load(os.path.join(golden_dir, 'T2_tiny_adam3.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    batches = [_gpu_batch(synth.make_batch(n, h, w, k, seed=dseed + i)) for i in range(3)]
+    runs = {}
+    for mode in ('eager', 'graph'):
+        m = _build(env, synth.TINY, wseed)
+        opt = train.make_optimizer(m, lr=1e-3)
+        m.train()
+        before = m._param_arena.clone()
+        if mode == 'graph':
+            b0 = batches[0]
+            step = m.capture_training_step(opt, b0['image'], b0['input_depth'], b0['ground_truth'], b0['lidar_map'])
+            assert torch.equal(m._param_arena, before), 'capturing changed the parameters'
+            assert len(opt._shared_steps) == 1 and float(list(opt._shared_steps.values())[0]) == 0.0
+        losses = []
+        for b in batches:
+            if mode == 'graph':
+                loss = step(b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])
+            else:
+                loss = train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])[0]
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        moments = list(opt._moment_arenas.values())[0]
+        runs[mode] = (losses, m._param_arena.clone(), moments[0].clone(), moments[1].clone(),
+                      torch.cat([b.reshape(-1).float() for b in m.encoder.buffers()] + [b.reshape(-1).float() for b in m.decoder.buffers()]),
+                      float(list(opt._shared_steps.values())[0]), opt.state_dict()['state'][0]['step'])
+    e, gr = runs['eager'], runs['graph']
+    assert e[0] == gr[0], (e[0], gr[0])
+    for i in range(1, 5):
+        assert torch.equal(e[i], gr[i]), i
+    assert e[5] == gr[5] == 3.0 and float(gr[6]) == 3.0
+    np.testing.assert_allclose(gr[0], g['losses'], rtol=BAR)      # and it is the reference's trajectory (without outlier removal)
+
+
+def test_captured_training_step_full_resolution_matches_eager(env):
+    '''The benchmark's own step (published net, 900x1600, outlier removal) at batch 2: replay == eager, bitwise, after two steps.'''
+    from rcf_amd.net_utils import OutlierRemoval
+    synth, train = env
+    b = _gpu_batch(synth.make_batch(2, 900, 1600, 64, seed=1234))
+    outl = OutlierRemoval(7, 1.5)
+    res = {}
+    for mode in ('eager', 'graph'):
+        m = _build(env, synth.PUBLISHED, 1234)
+        opt = train.make_optimizer(m, lr=1e-3)
+        m.train()
+        if mode == 'graph':
+            step = m.capture_training_step(opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'], outlier_removal=outl)
+            losses = [float(step().detach()) for _ in range(2)]
+        else:
+            losses = [float(train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'],
+                                             outlier_removal=outl)[0].detach()) for _ in range(2)]
+        torch.cuda.synchronize()
+        res[mode] = (losses, m._param_arena.clone())
+        del m, opt
+        torch.cuda.empty_cache()
+    assert res['eager'][0] == res['graph'][0]
+    assert torch.equal(res['eager'][1], res['graph'][1])
