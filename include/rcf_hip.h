@@ -153,6 +153,12 @@ int rcf_conv2d_wgrad_bn(const rcf_conv_desc* d, const void* in1, const float* co
  * of an up-2x conv back to the 3x3 gradient: dw[o][i][ky][kx] = sum_{a,b} dwp[a][b][o][i][t(a,ky)][u(b,kx)]. */
 int rcf_phase_weights(const float* w_oihw, float* out, int o, int i, int mode, void* stream);
 int rcf_phase_wgrad_fold(const float* dwp, float* dw_oihw, int o, int i, void* stream);
+/* Weight gradient of a 3x3 STRIDE-2 convolution from four 2x2 weight gradients: phase (a,b) is rcf_conv2d_wgrad of the descriptor
+ * {ksize 2, pad 1, pad_x 1, gather1 RCF_GATHER_STRIDED2, in_off (a,b), source = the conv's input, h_in/w_in/h_out/w_out = the conv's
+ * OUTPUT extent} against the same dZ, written to dwp[a*2+b][o][i][2][2]; this call picks the nine real taps:
+ * dw[o][i][ky][kx] = dwp[a(ky)][b(kx)][o][i][t(ky)][u(kx)], (a,t)(0) = (1,0), (a,t)(1) = (0,1), (a,t)(2) = (1,1).  (16 taps computed
+ * for 9 used, on the bf16 matrix pipe instead of the f32 one.) */
+int rcf_phase_wgrad_gather_s2(const float* dwp, float* dw_oihw, int o, int i, void* stream);
 
 /* BatchNorm2d batch statistics -> affine coefficients.  partials: [n_partials][2][c] from rcf_conv2d_fwd.
  * coef: [4][c] = scale (gamma*invstd), shift (beta-mean*scale), mean, invstd.

@@ -47,6 +47,7 @@ _SIGNATURES = {
     'rcf_conv2d_wgrad_bn': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'rcf_phase_weights': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'rcf_phase_wgrad_fold': (c_int, [_P, _P, c_int, c_int, _P]),
+    'rcf_phase_wgrad_gather_s2': (c_int, [_P, _P, c_int, c_int, _P]),
     'rcf_bn_finalize': (c_int, [_P, c_int, c_int, c_double, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P]),
     'rcf_bn_act_fwd': (c_int, [_P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
     'rcf_fuse_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, _P]),

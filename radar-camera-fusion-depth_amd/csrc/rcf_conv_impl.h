@@ -432,13 +432,15 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // KERNEL ROW (KSX taps) at a time into a double-buffered LDS piece, so only the A tile needs the two-barrier hand-over.
 // NPL_ = 3: fp32 results (exact split, six partial products).  NPL_ = 1: rcf_conv_desc.precision == RCF_PREC_BF16 -- operands
 // rounded to bf16 (nearest even), ONE product, fp32 accumulate: the "bf16" configurations of BASELINE.json.
-template <int KS_, int NT_, int PX_, int MT_ = 0, int NPL_ = 3>
+// LSTEP_ = 2: stride-2 convolution -- the halo tile holds EVERY input pixel under the tile (a 3-tap kernel at stride 2 touches them
+// all) and neighbouring output pixels read halo pixels two apart; everything else (weights, epilogue) is the stride-1 kernel.
+template <int KS_, int NT_, int PX_, int MT_ = 0, int NPL_ = 3, int LSTEP_ = 1>
 struct SplitCfg {
     static constexpr int NPL = NPL_, NP = NPL_ == 3 ? 6 : 1;   // operand planes, partial products per MAC
-    static constexpr int KSY = KS_, KSX = KS_, T = KS_ * KS_, LSTEP = 1, CK = 16, CST = 16;
+    static constexpr int KSY = KS_, KSX = KS_, T = KS_ * KS_, LSTEP = LSTEP_, CK = 16, CST = 16;
     static constexpr int NT = NT_, BN = 32 * NT_;
     static constexpr int PX = PX_, PY = 32 / PX_, MT = MT_ ? MT_ : ((NT_ == 1 && KS_ == 3) ? 4 : 2), NW = 4, TH = PY * MT * NW;   // 3x3 32-co layers: 512-pixel tiles
-    static constexpr int HXP = PX + KS_ - 1, HYP = TH + KS_ - 1, NPIX = HXP * HYP;
+    static constexpr int HXP = (PX - 1) * LSTEP + KS_, HYP = (TH - 1) * LSTEP + KS_, NPIX = HXP * HYP;
     static constexpr int A_PLANE_BYTES = NPIX * 32;        // 16 bf16 per halo pixel
     static constexpr int A_BYTES = NPL * A_PLANE_BYTES;
     static constexpr int B_PLANE_BYTES = KSX * BN * 32;    // one kernel row: 16 bf16 per (tap, co)
@@ -447,7 +449,7 @@ struct SplitCfg {
     static constexpr int COEF_BYTES = 2 * COEF_MAX_C * 4;
     static constexpr int LDS_BYTES = A_BYTES + 2 * B_PIECE_BYTES + COEF_BYTES;
     static constexpr int WCHUNK_BYTES = KSY * B_PIECE_BYTES;   // one chunk of pre-split packed weights
-    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+    static_assert(2 * LDS_BYTES <= 160 * 1024 || (LSTEP == 2 && LDS_BYTES <= 160 * 1024), "two workgroups per CU (stride 2, three planes: one)");
 };
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
@@ -502,7 +504,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
     for (int mi = 0; mi < C::MT; ++mi) {
         const int tr = (wave * C::MT + mi) * C::PY + li / C::PX;
         const int tc = li % C::PX;
-        apix[mi] = tr * C::HXP + tc;
+        apix[mi] = tr * C::LSTEP * C::HXP + tc * C::LSTEP;
     }
     const int bbase = li * 32 + ((lh ^ ((li >> 3) & 1)) * 16);   // row co = ni*32 + li; (ni*32) keeps (co>>3)&1 == (li>>3)&1
 
@@ -527,8 +529,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
         const int img = t / a.tiles_y;
         const int pa = a.phase_sum ? (ph >> 1) : a.pad, pb = a.phase_sum ? (ph & 1) : a.pad_x;
         const int ioy = a.phase_sum ? (ph >> 1) : a.ioy, iox = a.phase_sum ? (ph & 1) : a.iox;
-        const int iy0 = ty * C::TH - pa;
-        const int ix0 = tx * C::PX - pb;
+        const int iy0 = ty * C::TH * C::LSTEP - pa;
+        const int ix0 = tx * C::PX * C::LSTEP - pb;
         const int hs = first ? a.h1 : a.h_in, ws = first ? a.w1 : a.w_in;
         const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
 #pragma unroll
@@ -1376,7 +1378,11 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 rowbase = (im * hs + y) * ws;
             } else {
                 rowok = rowok && (unsigned)ly < (unsigned)a.h_in;
-                const int py = (!FAST && gmode == RCF_GATHER_NEAREST) ? min((int)floorf((float)ly * a.sy), hs - 1) : ly;
+                int py = (!FAST && gmode == RCF_GATHER_NEAREST) ? min((int)floorf((float)ly * a.sy), hs - 1) : ly;
+                if (!FAST && gmode == RCF_GATHER_STRIDED2) {   // one phase of the source: logical row ly is physical row 2 ly + ioy
+                    py = 2 * ly + a.ioy;
+                    rowok = rowok && py < hs;
+                }
                 rowbase = (img * hs + py) * ws;
             }
             const float* rowptr = rcf_at<SX>(src, (size_t)(rowok ? rowbase : 0) * csrc + (rowok ? ch : 0));
@@ -1385,8 +1391,12 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             for (int j = 0; j < 8; ++j) {
                 const int hx = 8 * g + j;
                 const int lx = ix0 + hx;
-                const bool ok = rowok && hx < C::HXP && (unsigned)lx < (unsigned)a.w_in;
-                const int px = (!FAST && gmode == RCF_GATHER_NEAREST) ? min((int)floorf((float)lx * a.sx), ws - 1) : lx;
+                bool ok = rowok && hx < C::HXP && (unsigned)lx < (unsigned)a.w_in;
+                int px = (!FAST && gmode == RCF_GATHER_NEAREST) ? min((int)floorf((float)lx * a.sx), ws - 1) : lx;
+                if (!FAST && gmode == RCF_GATHER_STRIDED2) {
+                    px = 2 * lx + a.iox;
+                    ok = ok && px < ws;
+                }
                 rx[i][j] = rcf_ld4<SX>(ok ? rcf_at<SX>(rowptr, px * csrc) : rcf_zero_page, 0);
                 if (cfx != nullptr) m |= ok ? (1u << j) : 0u;
             }
@@ -1761,6 +1771,19 @@ __global__ void phase_wgrad_fold_kernel(const float* __restrict__ dwp, float* __
     dw[idx] = v;
 }
 
+// dW of a 3x3 stride-2 convolution from the four 2x2 weight gradients on the phase images of its input (RCF_PHASE_S2_WGRAD):
+// tap k reads input row 2 oy + k - 1: k = 0 -> odd rows at oy - 1 (phase 1, tap 0), k = 1 -> even rows at oy (phase 0, tap 1),
+// k = 2 -> odd rows at oy (phase 1, tap 1).  Each 3x3 tap is exactly one phase tap (9 of the 16 are real).
+__global__ void phase_wgrad_gather_s2_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int O, int I) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= O * I * 9) return;
+    const int kx = idx % 3, ky = (idx / 3) % 3;
+    const int oi = idx / 9;
+    const int a = ky == 1 ? 0 : 1, t = ky == 0 ? 0 : 1;
+    const int b = kx == 1 ? 0 : 1, u = kx == 0 ? 0 : 1;
+    dw[idx] = dwp[((size_t)(a * 2 + b) * O * I + oi) * 4 + t * 2 + u];
+}
+
 // ------------------------------------------------------------------------------------------------
 // configuration tables
 enum Kind { K3S1 = 0, K3S2 = 1, K1 = 2, K7S2 = 3, K2S1 = 4 };
@@ -1935,6 +1958,14 @@ using B3_1_32s = SplitCfg<3, 1, 32, 2, 1>;
 using B3_1_16s = SplitCfg<3, 1, 16, 2, 1>;
 using S3_1_32s = SplitCfg<3, 1, 32, 2>;   // 256-pixel x 32-co workgroups: more of them for the small layers
 using S3_1_16s = SplitCfg<3, 1, 16, 2>;
+using S3S2_1_32 = SplitCfg<3, 1, 32, 1, 3, 2>;   // 3x3 stride 2, three planes: 128-pixel tiles (the 65 x 9 halo tile in three planes is 56 KB)
+using S3S2_2_32 = SplitCfg<3, 2, 32, 1, 3, 2>;
+using S3S2_1_16 = SplitCfg<3, 1, 16, 1, 3, 2>;
+using S3S2_2_16 = SplitCfg<3, 2, 16, 1, 3, 2>;
+using B3S2_1_32 = SplitCfg<3, 1, 32, 2, 1, 2>;   // bf16 operands: one plane, 256-pixel tiles, two workgroups per CU
+using B3S2_2_32 = SplitCfg<3, 2, 32, 2, 1, 2>;
+using B3S2_1_16 = SplitCfg<3, 1, 16, 2, 1, 2>;
+using B3S2_2_16 = SplitCfg<3, 2, 16, 2, 1, 2>;
 using S2_1_32 = SplitCfg<2, 1, 32>;
 using S2_2_32 = SplitCfg<2, 2, 32>;
 using S2_1_16 = SplitCfg<2, 1, 16>;
@@ -1974,6 +2005,14 @@ double tile_eff_vt(int w, int h, int n, int px, int th) {
 bool split_enabled() {
     const char* e = getenv("RCF_CONV_SPLIT");
     return e == nullptr || e[0] != '0';
+}
+
+// 3x3 stride-2 forward convolutions on the bf16 matrix pipe (LSTEP = 2 split kernels); RCF_S2_SPLIT=0 keeps them on the f32 MFMA
+bool s2_split_enabled(const rcf_conv_desc* d) {
+    const char* e = getenv("RCF_S2_SPLIT");
+    if (e != nullptr) return e[0] != '0';
+    (void)d;
+    return true;
 }
 
 // stride-1 3x3 conv with pad 1 on directly addressed sources: the separator row is the conv's own zero padding
@@ -2046,7 +2085,9 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     s->split = 0;
     s->small = 0;
     s->bf16 = 0;
-    if (((s->kind == K3S1 && s->ck == 16) || (s->kind == K2S1 && cmax >= 16)) && (d->c1 % 4 == 0) && (d->c2 % 4 == 0) &&
+    const bool s2_split = s->kind == K3S2 && cmax >= 16 && d->w_mode == RCF_W_FORWARD && d->gather1 == RCF_GATHER_DIRECT && d->c2 == 0 &&
+                          d->out_stride == 1 && s2_split_enabled(d);
+    if (((s->kind == K3S1 && s->ck == 16) || (s->kind == K2S1 && cmax >= 16) || s2_split) && (d->c1 % 4 == 0) && (d->c2 % 4 == 0) &&
         split_enabled()) {
         s->split = 1;
         s->ck = 16;
@@ -2059,15 +2100,17 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     double best = -1.0;
     const bool vt_ok = vt_allowed(d);
     const int pxs[3] = {32, 16, 8};
+    // pixels per workgroup tile: 256; 512 for the 32-co 3x3 split layers; 128 for the three-plane stride-2 split kernel
+    const int tile_px = (s->split && s->kind == K3S2 && !s->bf16) ? 128 : ((s->split && s->nt == 1 && s->kind == K3S1 && !s->small) ? 512 : 256);
     for (int i = 0; i < 3; ++i) {
-        const int px = pxs[i], th = ((s->split && s->nt == 1 && s->kind == K3S1 && !s->small) ? 512 : 256) / px;
+        const int px = pxs[i], th = tile_px / px;
         if (px == 8 && (s->split || !(s->kind == K3S1 && s->ck == 16))) continue;
         for (int vt = 0; vt <= (vt_ok ? 1 : 0); ++vt) {
             const double e = vt ? tile_eff_vt(d->w_out, d->h_out, d->n, px, th) : tile_eff(d->w_out, d->h_out, px, th);
             if (e > best + 1e-9) { best = e; s->px = px; s->vt = vt; }
         }
     }
-    s->th = ((s->split && s->nt == 1 && s->kind == K3S1 && !s->small) ? 512 : 256) / s->px;
+    s->th = tile_px / s->px;
     s->bn = 32 * s->nt;
     return RCF_OK;
 }
@@ -2135,11 +2178,19 @@ int dispatch_split(const Sel& s, F&& f) {
             if (s.nt == 1) return s.px == 16 ? f(Tag<B2_1_16>{}) : f(Tag<B2_1_32>{});
             return s.px == 16 ? f(Tag<B2_2_16>{}) : f(Tag<B2_2_32>{});
         }
+        if (s.kind == K3S2) {
+            if (s.nt == 1) return s.px == 16 ? f(Tag<B3S2_1_16>{}) : f(Tag<B3S2_1_32>{});
+            return s.px == 16 ? f(Tag<B3S2_2_16>{}) : f(Tag<B3S2_2_32>{});
+        }
         if (s.nt == 1 && s.small) return s.px == 16 ? f(Tag<B3_1_16s>{}) : f(Tag<B3_1_32s>{});
         if (s.nt == 1) return s.px == 16 ? f(Tag<B3_1_16>{}) : f(Tag<B3_1_32>{});
         return s.px == 16 ? f(Tag<B3_2_16>{}) : f(Tag<B3_2_32>{});
     }
     if constexpr (!SAct::B16) {   // the exact 3-plane split exists for fp32 tensors only
+        if (s.kind == K3S2) {
+            if (s.nt == 1) return s.px == 16 ? f(Tag<S3S2_1_16>{}) : f(Tag<S3S2_1_32>{});
+            return s.px == 16 ? f(Tag<S3S2_2_16>{}) : f(Tag<S3S2_2_32>{});
+        }
         if (s.kind == K2S1) {
             if (s.nt == 1) return s.px == 16 ? f(Tag<S2_1_16>{}) : f(Tag<S2_1_32>{});
             return s.px == 16 ? f(Tag<S2_2_16>{}) : f(Tag<S2_2_32>{});
@@ -2176,7 +2227,7 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
     w->split = (dma_ok && split_enabled() &&
                 ((w->kind == K3S1 && d->out_stride == 1 && d->out_h_phys == d->h_out && d->out_w_phys == d->w_out &&
                   (d->gather1 == RCF_GATHER_DIRECT || d->gather1 == RCF_GATHER_NEAREST)) ||
-                 (w->kind == K2S1 && d->gather1 == RCF_GATHER_DIRECT))) ? 1 : 0;
+                 (w->kind == K2S1 && (d->gather1 == RCF_GATHER_DIRECT || d->gather1 == RCF_GATHER_STRIDED2)))) ? 1 : 0;
     // virtual-tall tiling: the DMA / split kernels address the separator rows, the register-staged kernel (the only f32-MFMA
     // weight-gradient kernel for bf16 tensors) does not
     const bool vt_ok = dma_ok && vt_allowed(d) && (!SAct::B16 || w->split);
@@ -2267,6 +2318,15 @@ extern "C" int rcf_phase_wgrad_fold(const float* dwp, float* dw_oihw, int o, int
 }
 
 #endif   // !RCF_CONV_B16
+
+#if !RCF_CONV_B16
+extern "C" int rcf_phase_wgrad_gather_s2(const float* dwp, float* dw_oihw, int o, int i, void* stream) {
+    if (!dwp || !dw_oihw || o <= 0 || i <= 0) return RCF_EINVAL;
+    const int total = 9 * o * i;
+    hipLaunchKernelGGL(phase_wgrad_gather_s2_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, dwp, dw_oihw, o, i);
+    return rcf_launch_status();
+}
+#endif
 
 extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* info) {
     RCF_TO_B16(d, rcf_conv2d_query_b16impl(d, info));

@@ -59,6 +59,11 @@ class Engine(object):
         # inference (eval mode, no tape): BatchNorm folded into the conv weights, bias + LeakyReLU (+ residual) in the split kernels'
         # epilogue (rcf_conv2d_fwd_act): no z tensor and no BN pass for those layers
         self.fuse_eval = True
+        # 3x3 stride-2 weight gradients as four 2x2 phase weight gradients on the bf16 matrix pipe (16 taps computed for 9 used):
+        # 3.5x faster than the register-staged f32-MFMA kernel with bf16 tensors; RCF_S2_WGRAD_PHASES=0/1 overrides
+        import os
+        self.s2_wgrad_phases = os.environ.get('RCF_S2_WGRAD_PHASES', '1') != '0'
+        self.bn_on_load = os.environ.get('RCF_BN_ON_LOAD', '0') == '1'
 
     # ------------------------------------------------------------------ helpers
     def _new(self, shape, ref):
@@ -292,18 +297,34 @@ class Engine(object):
             return self._conv_up2x_backward(layer, info, x, dz)
         weight = layer.conv.weight
         dw = self.grad_of(weight)
-        ws = self._newf((max(1, info.wgrad_workspace_floats),), dz)
-        if self.prof is not None:
-            self.prof.begin(info.wgrad_kernel_id, ops.algorithmic_flops(desc), desc)
-        t1, k1 = self._src(x, info.wgrad_bn_on_load)
-        t2, k2 = self._src(x2, info.wgrad_bn_on_load)
-        if t1 is None:
+        if (self.use_phase_convs and self.s2_wgrad_phases and desc.stride == 2 and desc.ksize == 3 and x2 is None and desc.c1 % 4 == 0
+                and desc.c1 >= 16 and desc.gather1 == RCF_GATHER_DIRECT):
+            # 3x3 stride-2 weight gradient as four 2x2 weight gradients on the phase images of x (bf16 matrix pipe)
             t1 = self._mat(x)
-        if x2 is not None and t2 is None:
-            t2 = self._mat(x2)
-        ops.conv_wgrad(desc, t1, t2, dz, dw, ws, coef1=k1, coef2=k2)
-        if self.prof is not None:
-            self.prof.end()
+            dwp = self._newf((4, desc.c_out, desc.c1, 2, 2), dz)
+            for ph in range(4):
+                d = ops.make_s2_wgrad_desc(desc, ph >> 1, ph & 1)
+                qi = ops.conv_query(d)
+                wsp = self._newf((max(1, qi.wgrad_workspace_floats),), dz)
+                if self.prof is not None:
+                    self.prof.begin(qi.wgrad_kernel_id, ops.algorithmic_flops(d), d)
+                ops.conv_wgrad(d, t1, None, dz, dwp[ph], wsp)
+                if self.prof is not None:
+                    self.prof.end()
+            ops.phase_wgrad_gather_s2(dwp, dw)
+        else:
+            ws = self._newf((max(1, info.wgrad_workspace_floats),), dz)
+            if self.prof is not None:
+                self.prof.begin(info.wgrad_kernel_id, ops.algorithmic_flops(desc), desc)
+            t1, k1 = self._src(x, info.wgrad_bn_on_load)
+            t2, k2 = self._src(x2, info.wgrad_bn_on_load)
+            if t1 is None:
+                t1 = self._mat(x)
+            if x2 is not None and t2 is None:
+                t2 = self._mat(x2)
+            ops.conv_wgrad(desc, t1, t2, dz, dw, ws, coef1=k1, coef2=k2)
+            if self.prof is not None:
+                self.prof.end()
         self._wgrad_done(weight)
         for src, off, cnt in ((x, 0, desc.c1), (x2, desc.c1, desc.c2)):
             if src is None or not src.needs_grad:

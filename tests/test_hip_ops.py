@@ -879,3 +879,36 @@ def test_transforms_match_reference_fixture_t8(ops):
     assert out.shape == img.shape and float(out.max()) <= 1.0 and float(out.min()) >= 0.0
     [out2] = Transforms(normalized_image_range=[0, 1]).transform([img])
     np.testing.assert_allclose(out2.cpu().numpy(), np.floor(g['image0']) / 255.0, rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize('c1,co,n,h,w', [(32, 64, 2, 45, 80), (64, 128, 1, 57, 101), (128, 256, 2, 29, 50), (16, 32, 3, 35, 51)])
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_stride2_weight_gradient_as_four_phase_weight_gradients(ops, c1, co, n, h, w, prec):
+    '''dW of a 3x3 stride-2 convolution = the nine real taps of four 2x2 weight gradients on the phase images of its input
+    (rcf_phase_wgrad_gather_s2), odd and even extents, against torch's weight gradient; with bf16 tensors the operands are exact
+    (bf16-valued), so the bar is the same.'''
+    x = rnd(n, c1, h, w, seed=1)
+    wt = rnd(co, c1, 3, 3, seed=2, scale=1.0 / np.sqrt(c1 * 9))
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    dz = rnd(n, co, ho, wo, seed=3)
+    if prec == 'bf16':
+        x, dz = x.bfloat16().float(), dz.bfloat16().float()
+    wd = wt.clone().double().requires_grad_(True)
+    (F.conv2d(x.double(), wd, stride=2, padding=1) * dz.double()).sum().backward()
+    ops.set_precision(prec)
+    try:
+        cast = (lambda t: t.bfloat16()) if prec == 'bf16' else (lambda t: t)
+        d = ops.make_fwd_desc(n, h, w, c1, 0, co, 3, 2)
+        xg, dzg = cast(nhwc(x)), cast(nhwc(dz))
+        dwp = torch.full((4, co, c1, 2, 2), float('nan'), device='cuda')
+        for ph in range(4):
+            dp = ops.make_s2_wgrad_desc(d, ph >> 1, ph & 1)
+            qi = ops.conv_query(dp)
+            ws = torch.empty(max(1, qi.wgrad_workspace_floats), device='cuda')
+            ops.conv_wgrad(dp, xg, None, dzg, dwp[ph], ws)
+        dw = torch.full((co, c1, 3, 3), float('nan'), device='cuda')
+        ops.phase_wgrad_gather_s2(dwp, dw)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision('fp32')
+    assert rel(dw.cpu().double(), wd.grad) < TOL
