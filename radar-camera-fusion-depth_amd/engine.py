@@ -60,10 +60,13 @@ class Engine(object):
         # epilogue (rcf_conv2d_fwd_act): no z tensor and no BN pass for those layers
         self.fuse_eval = True
         # 3x3 stride-2 weight gradients as four 2x2 phase weight gradients on the bf16 matrix pipe (16 taps computed for 9 used):
-        # 3.5x faster than the register-staged f32-MFMA kernel with bf16 tensors; RCF_S2_WGRAD_PHASES=0/1 overrides
+        # 3.5x faster than the register-staged f32-MFMA kernel with bf16 tensors, 1 % slower than the LDS-DMA f32-MFMA kernel with
+        # fp32 tensors (measured) -- so: None = only in the bf16 configuration; RCF_S2_WGRAD_PHASES=0/1 overrides
         import os
-        self.s2_wgrad_phases = os.environ.get('RCF_S2_WGRAD_PHASES', '1') != '0'
-        self.bn_on_load = os.environ.get('RCF_BN_ON_LOAD', '0') == '1'
+        e = os.environ.get('RCF_S2_WGRAD_PHASES')
+        self.s2_wgrad_phases = None if e is None else (e != '0')
+        if os.environ.get('RCF_BN_ON_LOAD') is not None:
+            self.bn_on_load = os.environ['RCF_BN_ON_LOAD'] == '1'
 
     # ------------------------------------------------------------------ helpers
     def _new(self, shape, ref):
@@ -297,7 +300,8 @@ class Engine(object):
             return self._conv_up2x_backward(layer, info, x, dz)
         weight = layer.conv.weight
         dw = self.grad_of(weight)
-        if (self.use_phase_convs and self.s2_wgrad_phases and desc.stride == 2 and desc.ksize == 3 and x2 is None and desc.c1 % 4 == 0
+        s2_phases = self.s2_wgrad_phases if self.s2_wgrad_phases is not None else (ops.act_dtype() == torch.bfloat16)
+        if (self.use_phase_convs and s2_phases and desc.stride == 2 and desc.ksize == 3 and x2 is None and desc.c1 % 4 == 0
                 and desc.c1 >= 16 and desc.gather1 == RCF_GATHER_DIRECT):
             # 3x3 stride-2 weight gradient as four 2x2 weight gradients on the phase images of x (bf16 matrix pipe)
             t1 = self._mat(x)

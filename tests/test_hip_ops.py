@@ -912,3 +912,26 @@ def test_stride2_weight_gradient_as_four_phase_weight_gradients(ops, c1, co, n, 
     finally:
         ops.set_precision('fp32')
     assert rel(dw.cpu().double(), wd.grad) < TOL
+
+
+@pytest.mark.parametrize('c1,co,n,h,w', [(32, 64, 2, 45, 80), (64, 128, 2, 57, 100), (128, 256, 1, 29, 51)])
+def test_stride2_forward_on_the_three_plane_split_kernel(ops, c1, co, n, h, w, monkeypatch):
+    '''The LSTEP = 2 split kernel with fp32 precision (opt-in, RCF_S2_SPLIT=1; the default for bf16 operands): fp32-accurate --
+    its error against an fp64 reference is within 1.5x of the exact f32-MFMA kernel's on the same data.'''
+    x = rnd(n, c1, h, w, seed=1) + 0.3
+    wt = rnd(co, c1, 3, 3, seed=2, scale=1.0 / np.sqrt(c1 * 9))
+    ref = F.conv2d(x.double(), wt.double(), stride=2, padding=1)
+    mag = F.conv2d(x.double().abs(), wt.double().abs(), stride=2, padding=1)
+    errs = {}
+    for flag in ('0', '1'):
+        monkeypatch.setenv('RCF_S2_SPLIT', flag)
+        d = ops.make_fwd_desc(n, h, w, c1, 0, co, 3, 2)
+        info = ops.conv_query(d)
+        assert (info.kernel_id // 1000 == 6) == (flag == '1'), info.kernel_id
+        packed = torch.empty(info.packed_weight_floats, device='cuda')
+        ops.conv_pack(d, dev(wt), packed)
+        out = torch.full((n, d.h_out, d.w_out, co), float('nan'), device='cuda')
+        ops.conv_fwd(d, nhwc(x), None, packed, out, None)
+        torch.cuda.synchronize()
+        errs[flag] = float(((nchw(out).double() - ref).abs() / mag).max())
+    assert errs['1'] < 1.5 * errs['0'] + 1e-8 and errs['1'] < 1e-6, errs
