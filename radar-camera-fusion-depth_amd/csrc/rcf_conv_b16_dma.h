@@ -1,0 +1,358 @@
+// conv_b16_kernel: the 3x3 / 2x2 forward and input-gradient convolution for bf16 NHWC tensors (RCF_STORE_BF16), included by
+// rcf_conv_impl.h in the bf16 translation unit only.
+//
+// With bf16 tensors the operands are already in the MFMA's format, so nothing has to pass through the VALU on its way to LDS:
+//  * the halo tile of a 16-channel chunk ([pixel][16 bf16] = two 16-B pieces per pixel, halves XOR-swizzled by bit 3 of the pixel
+//    index exactly like conv_split_kernel's planes) arrives by LDS-DMA (global_load_lds_dwordx4) with PER-LANE source addresses --
+//    the gather (zero padding through a zero page, nearest upsample, strided phases, the virtual tall image) is address arithmetic
+//    done once per tile, the copy itself uses no registers and no ds_write;
+//  * the chunk's packed weights ([tap][co][16 bf16], 18 KB for 64 output channels) arrive the same way;
+//  * A and B are double-buffered, so ONE barrier per chunk publishes chunk q while the DMA of chunk q + 1 is already in flight
+//    behind the 9 x MT x NT MFMAs of chunk q (conv_split_kernel: two barriers per chunk + one per kernel row, because its A tile is
+//    produced by the waves themselves);
+//  * epilogue: two lanes that hold neighbouring output channels exchange one value (DPP) and each stores ONE dword (two bf16) per
+//    pixel pair instead of two 2-byte stores per pixel; BatchNorm statistics are taken from the rounded values, summed in fp32 over
+//    the 16 values of an accumulator and in fp64 across tiles.
+// Phase timing of conv_split_kernel with bf16 tensors showed why (tools/phase_timing.py, RCF_BENCH_PREC=bf16): MFMA rows 11-14 % of
+// the wave time, row prologues 23-36 %, epilogue 11-39 %, barriers 15-25 %.
+//
+// Everything conv_split_kernel does for the network is kept: channel concat (two sources), nearest-upsample gather, strided
+// (phase) gather + phase_sum, strided / offset output (phase convolutions), += accumulation, the fused inference epilogue
+// (bias + LeakyReLU + residual), the virtual tall image, and stride 2 (LSTEP = 2).  Not kept: BatchNorm-on-load (a DMA cannot
+// transform), channel counts that are not multiples of 16 (those layers stay on conv_split_kernel).
+#pragma once
+
+template <int KS_, int NT_, int PX_, int MT_, int LSTEP_ = 1>
+struct DmaCfg {
+    static constexpr int KS = KS_, T = KS_ * KS_, LSTEP = LSTEP_;
+    static constexpr int NT = NT_, BN = 32 * NT_;
+    static constexpr int PX = PX_, PY = 32 / PX_, MT = MT_, NW = 4, TH = PY * MT * NW;
+    static constexpr int HXP = (PX - 1) * LSTEP + KS, HYP = (TH - 1) * LSTEP + KS, NPIX = HXP * HYP;
+    static constexpr int NA = (2 * NPIX + 255) / 256;        // LDS-DMA instructions per thread and A tile (one 16-B piece per lane)
+    static constexpr int A_BYTES = NA * 256 * 16;            // every lane of every instruction lands somewhere
+    static constexpr int B_BYTES = T * BN * 32;              // one chunk of packed weights
+    static constexpr int NKB = B_BYTES / 1024;
+    static constexpr int LDS_BYTES = 2 * (A_BYTES + B_BYTES);
+    static_assert(B_BYTES % 1024 == 0, "weight chunk must be whole KiB");
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+};
+
+template <int CTRL>
+__device__ __forceinline__ unsigned rcf_dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+
+template <class C, bool EPI>
+__global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    // [A buf 0][A buf 1][B buf 0][B buf 1]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+
+    int apix[C::MT];   // halo pixel of this lane's output pixel at tap (0, 0)
+#pragma unroll
+    for (int mi = 0; mi < C::MT; ++mi) {
+        const int tr = (wave * C::MT + mi) * C::PY + li / C::PX;
+        const int tc = li % C::PX;
+        apix[mi] = tr * C::LSTEP * C::HXP + tc * C::LSTEP;
+    }
+    const int bbase = li * 32 + ((lh ^ ((li >> 3) & 1)) * 16);
+
+    f32x16 acc[C::MT][C::NT];
+    const int nchunk = a.nchunk1 + a.nchunk2;
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.wp) + (size_t)blockIdx.y * nchunk * C::B_BYTES;
+    const int n0 = blockIdx.y * C::BN;
+    const int nitem = a.phase_sum ? 4 * nchunk : nchunk;
+
+    // A staging: piece s = i * 256 + tid of the tile -> halo pixel s >> 1, LDS half s & 1, source half (s & 1) ^ ((pixel >> 3) & 1)
+    int pix[C::NA];      // element offset (pixel index * channels of the source) of the piece's pixel, -1: zero
+    auto setup = [&](int tile, bool first, int ph) {
+        int t = tile;
+        const int tx = t % a.tiles_x;
+        t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        const int img = t / a.tiles_y;
+        const int pa = a.phase_sum ? (ph >> 1) : a.pad, pb = a.phase_sum ? (ph & 1) : a.pad_x;
+        const int ioy = a.phase_sum ? (ph >> 1) : a.ioy, iox = a.phase_sum ? (ph & 1) : a.iox;
+        const int iy0 = ty * C::TH * C::LSTEP - pa;
+        const int ix0 = tx * C::PX * C::LSTEP - pb;
+        const int hs = first ? a.h1 : a.h_in, ws = first ? a.w1 : a.w_in;
+        const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
+#pragma unroll
+        for (int i = 0; i < C::NA; ++i) {
+            const int p = (i * 256 + tid) >> 1;
+            const int hy = p / C::HXP;
+            const int hx = p - hy * C::HXP;
+            const int ly = iy0 + hy, lx = ix0 + hx;
+            int v = -1;
+            if (p < C::NPIX && ly >= 0 && lx >= 0 && lx < a.w_in) {
+                if (a.vt) {
+                    const int im = (int)(((float)ly + 0.5f) * a.inv_hp);
+                    const int y = ly - im * a.hp;
+                    if (im < a.nimg && y < a.h_in) v = (im * hs + y) * ws + lx;
+                } else if (ly < a.h_in) {
+                    int py = ly, px = lx;
+                    bool ok = true;
+                    if (gmode == RCF_GATHER_NEAREST) {
+                        py = min((int)floorf((float)ly * a.sy), hs - 1);
+                        px = min((int)floorf((float)lx * a.sx), ws - 1);
+                    } else if (gmode == RCF_GATHER_STRIDED2) {
+                        py = 2 * ly + ioy;
+                        px = 2 * lx + iox;
+                        ok = py < hs && px < ws;
+                    } else if (gmode == RCF_GATHER_ZERO_INSERT) {
+                        ok = ((ly | lx) & 1) == 0;
+                        py = ly >> 1;
+                        px = lx >> 1;
+                        ok = ok && py < hs && px < ws;
+                    }
+                    if (ok) v = (img * hs + py) * ws + px;
+                }
+            }
+            pix[i] = v;
+        }
+    };
+    // item -> (phase, chunk); issue the DMA of one item's A tile and weight chunk into buffer `buf`
+    auto issue = [&](int tile, int item, int buf) {
+        const int ph = a.phase_sum ? item / nchunk : 0;
+        const int q = a.phase_sum ? item - ph * nchunk : item;
+        const bool first = q < a.nchunk1;
+        if (q == 0 || q == a.nchunk1) setup(tile, first, ph);
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(first ? a.in1 : a.in2);
+        const int csrc = first ? a.c1 : a.c2;
+        const int cb = (first ? q : q - a.nchunk1) * 16;
+        unsigned char* Ab = smem_b + buf * C::A_BYTES;
+#pragma unroll
+        for (int i = 0; i < C::NA; ++i) {
+            const int s = i * 256 + tid;
+            const int p = s >> 1;
+            const int hh = (s & 1) ^ ((p >> 3) & 1);
+            const unsigned char* g = pix[i] >= 0 ? src + ((size_t)pix[i] * csrc + cb + hh * 8) * 2
+                                                 : reinterpret_cast<const unsigned char*>(rcf_zero_page);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(Ab + (i * 256 + wave_u * 64) * 16), 16, 0, 0);
+        }
+        const unsigned char* wsrc = wp + (size_t)ph * a.wp_phase_stride * 4 + (size_t)q * C::B_BYTES + lane * 16;
+        unsigned char* Bb = smem_b + 2 * C::A_BYTES + buf * C::B_BYTES;
+#pragma unroll
+        for (int i = 0; i < (C::NKB + 3) / 4; ++i) {
+            int kb = i * 4 + wave_u;
+            if ((i + 1) * 4 > C::NKB) kb = kb < C::NKB ? kb : C::NKB - 1;   // ragged tail: a duplicate copy of the last KiB is harmless
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 1024),
+                                             (__attribute__((address_space(3))) void*)(Bb + kb * 1024), 16, 0, 0);
+        }
+    };
+
+    // BatchNorm statistics: per lane two channels (its own and its pair partner's, see the epilogue), fp64 across tiles
+    double st1[C::NT][2], st2[C::NT][2];
+#pragma unroll
+    for (int ni = 0; ni < C::NT; ++ni) { st1[ni][0] = st1[ni][1] = 0.0; st2[ni][0] = st2[ni][1] = 0.0; }
+
+    int tile = blockIdx.x;
+    int q = 0;
+    int buf = 0;
+    if (tile < a.ntiles) issue(tile, 0, 0);
+    while (tile < a.ntiles) {
+        int ntile = tile, nq = q + 1;
+        if (nq == nitem) { nq = 0; ntile = tile + gridDim.x; }
+        const bool more = ntile < a.ntiles;
+        rcf_wait_dma();       // this item's pieces issued by this wave have landed ...
+        __syncthreads();      // ... and everybody's; everybody is also done reading the other buffer (previous item)
+        if (more) issue(ntile, nq, buf ^ 1);
+        if (q == 0) {
+#pragma unroll
+            for (int mi = 0; mi < C::MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        }
+        {
+            const unsigned char* Ab = smem_b + buf * C::A_BYTES;
+            const unsigned char* Bb = smem_b + 2 * C::A_BYTES + buf * C::B_BYTES;
+            bf16x8 av[2][C::MT], bv[2][C::NT];
+            auto fetch = [&](int tap, int slot) {
+                const int ky = tap / C::KS, kx = tap % C::KS;
+#pragma unroll
+                for (int mi = 0; mi < C::MT; ++mi) {
+                    const int p = apix[mi] + ky * C::HXP + kx;
+                    av[slot][mi] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ab + p * 32 + ((lh ^ ((p >> 3) & 1)) * 16)));
+                }
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni)
+                    bv[slot][ni] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bb + (tap * C::BN + ni * 32) * 32 + bbase));
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int tap = 0; tap < C::T; ++tap) {
+                const int cur = tap & 1;
+                if (tap + 1 < C::T) fetch(tap + 1, cur ^ 1);   // next tap's operands on their way while this tap's MFMAs issue
+#pragma unroll
+                for (int mi = 0; mi < C::MT; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < C::NT; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][mi], bv[cur][ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        if (q == nitem - 1) {
+            // ---- epilogue.  Lane (li, lh) holds channel co = n0 + ni * 32 + li of 16 pixels per accumulator.  Lanes li (even) and
+            // li + 1 exchange one value per pixel pair: the even lane stores channels (co, co + 1) of the pair's first pixel, the odd
+            // lane those of the second pixel -- one dword (two bf16) per lane and pixel pair.
+            int t = tile;
+            const int tx = t % a.tiles_x;
+            t /= a.tiles_x;
+            const int ty = t % a.tiles_y;
+            const int img = t / a.tiles_y;
+            const int oy0 = ty * C::TH, ox0 = tx * C::PX;
+            const bool want_stats = !EPI && a.stats != nullptr;
+            const int odd = li & 1;
+            unsigned short* outp = reinterpret_cast<unsigned short*>(a.out);
+            const unsigned short* addp = reinterpret_cast<const unsigned short*>(EPI ? a.res : a.out);
+            const bool do_add = EPI ? a.res != nullptr : a.accumulate != 0;
+            float eb[C::NT][2];
+            if (EPI) {
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni) {
+                    const int cp = (n0 + ni * 32 + li) & ~1;
+                    eb[ni][0] = a.bias[cp < a.c_out ? cp : 0];
+                    eb[ni][1] = a.bias[cp + 1 < a.c_out ? cp + 1 : 0];
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < C::MT; ++mi) {
+                float s1[C::NT][2], s2[C::NT][2];
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni) { s1[ni][0] = s1[ni][1] = 0.f; s2[ni][0] = s2[ni][1] = 0.f; }
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += 4) {
+                    // rows r0 .. r0 + 3 of a lane are four consecutive pixels of ONE tile row (PX a multiple of 4)
+                    const int row = rcf_mfma_row(r0, lh);
+                    int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
+                    const int ox = ox0 + row % C::PX;
+                    int im = img;
+                    if (a.vt) {   // virtual row -> (image, row); separator rows produce no output
+                        im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                        oy -= im * a.hp;
+                        if (im >= a.nimg) oy = a.h_out;
+                    }
+                    const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+                    const bool rowvalid = oy < a.h_out && py < a.ohp;
+                    const size_t base0 = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
+                    const int pstep = a.os * a.c_out;
+#pragma unroll
+                    for (int jp = 0; jp < 4; jp += 2) {
+                        const int jm = jp + odd;                                          // the pixel this lane stores
+                        const bool pok = rowvalid && ox + jm < a.w_out && px + jm * a.os < a.owp;
+                        const size_t pb = base0 + (size_t)(jm * pstep);
+#pragma unroll
+                        for (int ni = 0; ni < C::NT; ++ni) {
+                            const int co = n0 + ni * 32 + li;
+                            const int cp = co & ~1;
+                            const bool ok = pok && cp < a.c_out;
+                            const float mine = acc[mi][ni][r0 + jm];                      // my channel at my pixel
+                            const float give = acc[mi][ni][r0 + jp + (odd ^ 1)];          // my channel at the partner's pixel
+                            const float got = __uint_as_float(rcf_dpp_u32<0xB1>(__float_as_uint(give)));   // partner's channel at my pixel
+                            float lo = odd ? got : mine, hi = odd ? mine : got;           // channels cp, cp + 1
+                            float alo = 0.f, ahi = 0.f;
+                            if (do_add) {
+                                const unsigned w = *reinterpret_cast<const unsigned*>(addp + (ok ? pb + cp : 0));
+                                alo = __uint_as_float(w << 16);
+                                ahi = __uint_as_float(w & 0xffff0000u);
+                            }
+                            if (EPI) {
+                                lo = rcf_lrelu(lo + eb[ni][0]);
+                                hi = rcf_lrelu(hi + eb[ni][1]);
+                                if (do_add) { lo = rcf_lrelu(lo + alo); hi = rcf_lrelu(hi + ahi); }
+                            } else {
+                                lo += alo;
+                                hi += ahi;
+                            }
+                            const unsigned blo = rcf_f2b(lo), bhi = rcf_f2b(hi);
+                            if (ok) {
+                                *reinterpret_cast<unsigned*>(outp + pb + cp) = blo | (bhi << 16);
+                                if (want_stats) {   // of the values the tensor holds
+                                    const float rlo = rcf_b2f(blo), rhi = rcf_b2f(bhi);
+                                    s1[ni][0] += rlo; s2[ni][0] += rlo * rlo;
+                                    s1[ni][1] += rhi; s2[ni][1] += rhi * rhi;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (want_stats) {
+#pragma unroll
+                    for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) { st1[ni][e] += (double)s1[ni][e]; st2[ni][e] += (double)s2[ni][e]; }
+                }
+            }
+        }
+        tile = ntile;
+        q = nq;
+        buf ^= 1;
+    }
+
+    if (a.stats != nullptr) {
+        rcf_wait_dma();
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem_b);   // [4 waves][BN][2]
+#pragma unroll
+        for (int ni = 0; ni < C::NT; ++ni) {
+            // channel cp (even lane's own) = slot 0 of both lanes of the pair, channel cp + 1 (odd lane's own) = slot 1 of both
+            const double a10 = st1[ni][0], a11 = st1[ni][1], a20 = st2[ni][0], a21 = st2[ni][1];
+            const double t10 = a10 + __shfl_xor(a10, 1), t11 = a11 + __shfl_xor(a11, 1);
+            const double t20 = a20 + __shfl_xor(a20, 1), t21 = a21 + __shfl_xor(a21, 1);
+            double t1 = (li & 1) ? t11 : t10, t2 = (li & 1) ? t21 : t20;
+            t1 += __shfl_xor(t1, 32);
+            t2 += __shfl_xor(t2, 32);
+            if (lh == 0) {
+                red[(wave * C::BN + ni * 32 + li) * 2 + 0] = t1;
+                red[(wave * C::BN + ni * 32 + li) * 2 + 1] = t2;
+            }
+        }
+        __syncthreads();
+        if (tid < C::BN) {
+            const int co = n0 + tid;
+            if (co < a.c_out) {
+                double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < C::NW; ++w) {
+                    t1 += red[(w * C::BN + tid) * 2 + 0];
+                    t2 += red[(w * C::BN + tid) * 2 + 1];
+                }
+                a.stats[((size_t)blockIdx.x * 2 + 0) * a.c_out + co] = t1;
+                a.stats[((size_t)blockIdx.x * 2 + 1) * a.c_out + co] = t2;
+            }
+        }
+    }
+}
+
+template <class C>
+int dma_grid_x(int ntiles, int ntile_n) {
+    static int resident = 0;
+    if (resident == 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b16_kernel<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b16_kernel<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C::LDS_BYTES);
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_b16_kernel<C, false>, 256, C::LDS_BYTES) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        resident = per_cu * num_cus();
+    }
+    int gx = resident / ntile_n;
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    return gx;
+}
+
+template <class C, bool EPI = false>
+int launch_dma(const ConvArgs& a, int ntile_n, hipStream_t st) {
+    const int gx = dma_grid_x<C>(a.ntiles, ntile_n);
+    hipLaunchKernelGGL((conv_b16_kernel<C, EPI>), dim3(gx, ntile_n, 1), dim3(256), C::LDS_BYTES, st, a);
+    return rcf_launch_status();
+}

@@ -1795,6 +1795,7 @@ struct Sel {
     int split;   // fp32 on the bf16 matrix pipe (conv_split_kernel)
     int small;   // split 3x3 layer too small to fill the chip with 64-co workgroups: 256-pixel x 32-co workgroups instead
     int bf16;    // rcf_conv_desc.precision == RCF_PREC_BF16 and a split kernel: one bf16 plane, one product
+    int dma;     // bf16 tensors, channel counts multiples of 16: conv_b16_kernel (operands reach LDS by DMA, rcf_conv_b16_dma.h)
 };
 
 int num_cus() {
@@ -1807,6 +1808,26 @@ int num_cus() {
     }
     return n;
 }
+
+#if RCF_CONV_B16
+}   // namespace
+namespace {
+#include "rcf_conv_b16_dma.h"
+using D3_2_32 = DmaCfg<3, 2, 32, 2>;
+using D3_2_16 = DmaCfg<3, 2, 16, 2>;
+using D3_1_32 = DmaCfg<3, 1, 32, 4>;     // 32-co layers: 512-pixel tiles
+using D3_1_16 = DmaCfg<3, 1, 16, 4>;
+using D3_1_32s = DmaCfg<3, 1, 32, 2>;    // small layers: 256-pixel x 32-co workgroups
+using D3_1_16s = DmaCfg<3, 1, 16, 2>;
+using D2_2_32 = DmaCfg<2, 2, 32, 2>;
+using D2_2_16 = DmaCfg<2, 2, 16, 2>;
+using D2_1_32 = DmaCfg<2, 1, 32, 2>;
+using D2_1_16 = DmaCfg<2, 1, 16, 2>;
+using D3S2_2_32 = DmaCfg<3, 2, 32, 1, 2>;   // stride 2: 128-pixel tiles (the 65 x 9 halo tile is 18 KB per buffer)
+using D3S2_2_16 = DmaCfg<3, 2, 16, 1, 2>;
+using D3S2_1_32 = DmaCfg<3, 1, 32, 1, 2>;
+using D3S2_1_16 = DmaCfg<3, 1, 16, 1, 2>;
+#endif
 
 // Persistent grid: one resident wave of workgroups (occupancy API), split between the n-tiles.  Also the number of
 // BN-statistics partial rows the kernel writes, so rcf_conv2d_query reports the same number.
@@ -2088,6 +2109,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     s->split = 0;
     s->small = 0;
     s->bf16 = 0;
+    s->dma = 0;
     const bool s2_split = s->kind == K3S2 && cmax >= 16 && d->w_mode == RCF_W_FORWARD && d->gather1 == RCF_GATHER_DIRECT && d->c2 == 0 &&
                           d->out_stride == 1 && s2_split_enabled(d);
     if (((s->kind == K3S1 && s->ck == 16) || (s->kind == K2S1 && cmax >= 16) || s2_split) && (d->c1 % 4 == 0) && (d->c2 % 4 == 0) &&
@@ -2099,12 +2121,16 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
         const long long wgs = (((long long)d->n * d->h_out * d->w_out + 255) / 256) * ceil_div(d->c_out, 64);
         if (s->kind == K3S1 && s->nt == 2 && wgs < num_cus()) { s->small = 1; s->nt = 1; }
         s->bf16 = d->precision == RCF_PREC_BF16 ? 1 : 0;
+#if RCF_CONV_B16
+        const char* e = getenv("RCF_B16_DMA");
+        s->dma = (s->bf16 && d->c1 % 16 == 0 && d->c2 % 16 == 0 && (e == nullptr || e[0] != '0')) ? 1 : 0;
+#endif
     }
     double best = -1.0;
     const bool vt_ok = vt_allowed(d);
     const int pxs[3] = {32, 16, 8};
     // pixels per workgroup tile: 256; 512 for the 32-co 3x3 split layers; 128 for the three-plane stride-2 split kernel
-    const int tile_px = (s->split && s->kind == K3S2 && !s->bf16) ? 128 : ((s->split && s->nt == 1 && s->kind == K3S1 && !s->small) ? 512 : 256);
+    const int tile_px = (s->split && s->kind == K3S2 && (!s->bf16 || s->dma)) ? 128 : ((s->split && s->nt == 1 && s->kind == K3S1 && !s->small) ? 512 : 256);
     for (int i = 0; i < 3; ++i) {
         const int px = pxs[i], th = tile_px / px;
         if (px == 8 && (s->split || !(s->kind == K3S1 && s->ck == 16))) continue;
@@ -2173,6 +2199,24 @@ int dispatch_fwd(const Sel& s, F&& f) {
     }
     return RCF_EUNSUPPORTED;
 }
+
+#if RCF_CONV_B16
+template <class F>
+int dispatch_dma(const Sel& s, F&& f) {
+    const bool p16 = s.px == 16;
+    if (s.kind == K2S1) {
+        if (s.nt == 1) return p16 ? f(Tag<D2_1_16>{}) : f(Tag<D2_1_32>{});
+        return p16 ? f(Tag<D2_2_16>{}) : f(Tag<D2_2_32>{});
+    }
+    if (s.kind == K3S2) {
+        if (s.nt == 1) return p16 ? f(Tag<D3S2_1_16>{}) : f(Tag<D3S2_1_32>{});
+        return p16 ? f(Tag<D3S2_2_16>{}) : f(Tag<D3S2_2_32>{});
+    }
+    if (s.nt == 1 && s.small) return p16 ? f(Tag<D3_1_16s>{}) : f(Tag<D3_1_32s>{});
+    if (s.nt == 1) return p16 ? f(Tag<D3_1_16>{}) : f(Tag<D3_1_32>{});
+    return p16 ? f(Tag<D3_2_16>{}) : f(Tag<D3_2_32>{});
+}
+#endif
 
 template <class F>
 int dispatch_split(const Sel& s, F&& f) {
@@ -2342,13 +2386,17 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
     const int ntile_n = ceil_div(d->c_out, s.bn);
     info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * s.ck;
     if (s.split) info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.bf16 ? 8 : 24);   // 16 bf16 x planes per row
+#if RCF_CONV_B16
+    if (s.dma) info->n_partials = dispatch_dma(s, [&](auto tag) { return dma_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
+    else
+#endif
     info->n_partials = s.split ? dispatch_split(s, [&](auto tag) { return split_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); })
                                : dispatch_fwd(s, [&](auto tag) { return fwd_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
     if (info->n_partials <= 0) return RCF_EUNSUPPORTED;
     info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0) + (s.small ? 5 : 0) + (s.bf16 ? 20000 : 0);
     info->wgrad_workspace_floats = 0;
     info->wgrad_kernel_id = 0;
-    info->bn_on_load = (s.split && d->w_mode == RCF_W_FORWARD && d->c1 + d->c2 <= 512) ? 1 : 0;
+    info->bn_on_load = (s.split && !s.dma && d->w_mode == RCF_W_FORWARD && d->c1 + d->c2 <= 512) ? 1 : 0;   // a DMA cannot transform
     info->wgrad_bn_on_load = 0;
     info->fwd_act = (s.split && d->w_mode == RCF_W_FORWARD && !d->accumulate) ? 1 : 0;
     if (d->w_mode == RCF_W_FORWARD) {
@@ -2420,6 +2468,11 @@ static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float
     a.ktot = 0; a.cop = 0;
     const int nn = ceil_div(d->c_out, s.bn);
     a.wp_phase_stride = (int)((size_t)nn * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.split ? (s.bf16 ? 8 : 24) : s.ck));
+#if RCF_CONV_B16
+    if (s.dma && !coef1 && !coef2)
+        return dispatch_dma(s, [&](auto tag) { return launch_dma<typename decltype(tag)::type, false>(a, nn, (hipStream_t)stream); });
+    if (s.dma) return RCF_EUNSUPPORTED;   // rcf_conv_info.bn_on_load is 0 for these descriptors (the tile geometry differs)
+#endif
     if (s.split) return dispatch_split(s, [&](auto tag) { return launch_split<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
     return dispatch_fwd(s, [&](auto tag) { return launch_fwd<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
 }
@@ -2444,6 +2497,9 @@ extern "C" int RCF_FN(rcf_conv2d_fwd_act)(const rcf_conv_desc* d, const void* in
     a.ktot = 0; a.cop = 0;
     const int nn = ceil_div(d->c_out, s.bn);
     a.wp_phase_stride = (int)((size_t)nn * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.bf16 ? 8 : 24));
+#if RCF_CONV_B16
+    if (s.dma) return dispatch_dma(s, [&](auto tag) { return launch_dma<typename decltype(tag)::type, true>(a, nn, (hipStream_t)stream); });
+#endif
     return dispatch_split(s, [&](auto tag) { return launch_split<typename decltype(tag)::type, true>(a, nn, (hipStream_t)stream); });
 }
 
@@ -2547,9 +2603,9 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
     return rcf_launch_status();
 }
 
-#if defined(RCF_PHASE_TIMING) && !RCF_CONV_B16
+#if defined(RCF_PHASE_TIMING)
 // diagnostics build only: summed s_memtime cycles of all conv_split_kernel waves since the last reset (see RCF_TACC slots)
-extern "C" int rcf_debug_phase_cycles(unsigned long long* out8, int reset) {
+extern "C" int RCF_FN(rcf_debug_phase_cycles)(unsigned long long* out8, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return rcf_launch_status();
     if (out8 != nullptr && hipMemcpyFromSymbol(out8, HIP_SYMBOL(rcf_phase_cycles), 8 * sizeof(unsigned long long)) != hipSuccess)
         return rcf_launch_status();

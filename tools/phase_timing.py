@@ -1,7 +1,7 @@
 '''Where the waves of conv_split_kernel spend their cycles (s_memtime stamps, diagnostics build of the library).
 Build (container):  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DRCF_PHASE_TIMING -I include \
                         radar-camera-fusion-depth_amd/csrc/*.hip -o tools/probe/librcf_hip_timing.so
-Run (GPU box):      RCF_HIP_LIB=tools/probe/librcf_hip_timing.so python tools/phase_timing.py'''
+Run (GPU box):      RCF_HIP_LIB=tools/probe/librcf_hip_timing.so [RCF_BENCH_PREC=bf16] python tools/phase_timing.py'''
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,23 +14,26 @@ LAYERS = [('blocks2 64->64 @225x400', 64, 0, 64, 225, 400, None), ('blocks3 128-
 NAMES = ['row prologue (B reads, DMA/load issue)', 'row MFMAs + interleaved LDS reads', 'output epilogue', 'barrier: A tile free',
          'store_a (load wait, split, ds_write)', 'DMA wait + barrier after store_a', 'DMA wait + barrier between rows', 'whole wave']
 lib = _lib.load()
-fn = lib.rcf_debug_phase_cycles
+ops.set_precision(os.environ.get('RCF_BENCH_PREC', 'fp32'))
+ADT = ops.act_dtype()
+fn = lib.rcf_debug_phase_cycles_b16impl if ADT == torch.bfloat16 else lib.rcf_debug_phase_cycles
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = (ctypes.c_ulonglong * 8)()
 N = 8
 for name, c1, c2, co, h, w, _ in LAYERS:
-    x1 = torch.randn(N, h, w, c1, device='cuda')
-    x2 = torch.randn(N, h, w, c2, device='cuda') if c2 else None
+    x1 = torch.randn(N, h, w, c1, device='cuda').to(ADT)
+    x2 = torch.randn(N, h, w, c2, device='cuda').to(ADT) if c2 else None
     wt = torch.randn(co, c1 + c2, 3, 3, device='cuda') * 0.05
     desc = ops.make_fwd_desc(N, h, w, c1, c2, co, 3, 1)
     info = ops.conv_query(desc)
     packed = torch.empty(info.packed_weight_floats, device='cuda')
     ops.conv_pack(desc, wt, packed)
-    z = torch.empty(N, h, w, co, device='cuda')
-    for _ in range(3): ops.conv_fwd(desc, x1, x2, packed, z, None)
+    z = torch.empty(N, h, w, co, device='cuda', dtype=ADT)
+    part = torch.empty(info.n_partials, 2, co, device='cuda', dtype=torch.float64)
+    for _ in range(3): ops.conv_fwd(desc, x1, x2, packed, z, part)
     fn(None, 1)
     reps = 5
-    for _ in range(reps): ops.conv_fwd(desc, x1, x2, packed, z, None)
+    for _ in range(reps): ops.conv_fwd(desc, x1, x2, packed, z, part)
     fn(buf, 1)
     tot = buf[7]
     print('%s (kernel id %d)' % (name, info.kernel_id))
