@@ -155,14 +155,23 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
     int tile = blockIdx.x;
     int q = 0;
     int buf = 0;
+#ifdef RCF_PHASE_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     if (tile < a.ntiles) issue(tile, 0, 0);
     while (tile < a.ntiles) {
         int ntile = tile, nq = q + 1;
         if (nq == nitem) { nq = 0; ntile = tile + gridDim.x; }
         const bool more = ntile < a.ntiles;
+        RCF_T(t_w0);
         rcf_wait_dma();       // this item's pieces issued by this wave have landed ...
         __syncthreads();      // ... and everybody's; everybody is also done reading the other buffer (previous item)
+        RCF_T(t_w1);
+        RCF_TACC(0, t_w1, t_w0);   // 0: DMA wait + barrier
         if (more) issue(ntile, nq, buf ^ 1);
+        RCF_T(t_w2);
+        RCF_TACC(1, t_w2, t_w1);   // 1: address arithmetic + DMA issue of the next item
         if (q == 0) {
 #pragma unroll
             for (int mi = 0; mi < C::MT; ++mi)
@@ -187,17 +196,47 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                     bv[slot][ni] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bb + (tap * C::BN + ni * 32) * 32 + bbase));
             };
             fetch(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tap = 0; tap < C::T; ++tap) {
-                const int cur = tap & 1;
-                if (tap + 1 < C::T) fetch(tap + 1, cur ^ 1);   // next tap's operands on their way while this tap's MFMAs issue
+                const int cur = tap & 1, nxt = cur ^ 1;
+                // The MT x NT MFMAs of this tap with the next tap's MT + NT operand reads issued ONE AT A TIME between them, in the
+                // order the next tap's MFMAs will want them (a block of reads stalls the wave's MFMA issue for as long as the LDS
+                // queue takes them); sched_barrier pins the hand-written order -- left alone, hipcc sinks the reads behind the MFMAs
+                // and puts s_waitcnt lgkmcnt(0) in front of every second MFMA.
+                constexpr int MN = C::MT * C::NT, NRD = C::MT + C::NT;
+                const bool has_next = tap + 1 < C::T;
+                const int nky = (tap + 1) / C::KS, nkx = (tap + 1) % C::KS;
+                int nr = 0;
 #pragma unroll
-                for (int mi = 0; mi < C::MT; ++mi)
+                for (int j = 0; j < MN; ++j) {
+                    const int mi = j / C::NT, ni = j % C::NT;
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][mi], bv[cur][ni], acc[mi][ni], 0, 0, 0);
+                    if (has_next) {
 #pragma unroll
-                    for (int ni = 0; ni < C::NT; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][mi], bv[cur][ni], acc[mi][ni], 0, 0, 0);
+                        for (int rep = 0; rep < 3; ++rep) {
+                            if (nr < NRD && nr * (MN - 1) < (j + 1) * NRD) {   // front-loaded: the last read leaves before the last MFMA
+                                __builtin_amdgcn_sched_barrier(0);
+                                // read order: A tile 0, all B tiles, then the remaining A tiles
+                                if (nr == 0 || nr > C::NT) {
+                                    const int rmi = nr == 0 ? 0 : nr - C::NT;
+                                    const int p = apix[rmi] + nky * C::HXP + nkx;
+                                    av[nxt][rmi] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ab + p * 32 + ((lh ^ ((p >> 3) & 1)) * 16)));
+                                } else {
+                                    const int rni = nr - 1;
+                                    bv[nxt][rni] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bb + ((tap + 1) * C::BN + rni * 32) * 32 + bbase));
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                ++nr;
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        RCF_T(t_w3);
+        RCF_TACC(2, t_w3, t_w2);   // 2: accumulator init + MFMAs + LDS reads
         if (q == nitem - 1) {
             // ---- epilogue.  Lane (li, lh) holds channel co = n0 + ni * 32 + li of 16 pixels per accumulator.  Lanes li (even) and
             // li + 1 exchange one value per pixel pair: the even lane stores channels (co, co + 1) of the pair's first pixel, the odd
@@ -222,58 +261,83 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                     eb[ni][1] = a.bias[cp + 1 < a.c_out ? cp + 1 : 0];
                 }
             }
+            // ADD (accumulate into out / add the residual) is a COMPILE-TIME variant of the loop: the plain path must contain no
+            // load at all -- gfx9 counts stores in vmcnt, so one load in the loop makes hipcc wait for every previous store before
+            // the next one (measured: the epilogue was 55-72 % of the wave time that way).  With ADD all 8 x NT old dwords of an
+            // accumulator row group are requested first and consumed afterwards.
+            auto epilogue = [&](auto add_tag) __attribute__((always_inline)) {
+                constexpr bool ADD = decltype(add_tag)::value;
 #pragma unroll
-            for (int mi = 0; mi < C::MT; ++mi) {
-                float s1[C::NT][2], s2[C::NT][2];
+                for (int mi = 0; mi < C::MT; ++mi) {
+                    float s1[C::NT][2], s2[C::NT][2];
 #pragma unroll
-                for (int ni = 0; ni < C::NT; ++ni) { s1[ni][0] = s1[ni][1] = 0.f; s2[ni][0] = s2[ni][1] = 0.f; }
+                    for (int ni = 0; ni < C::NT; ++ni) { s1[ni][0] = s1[ni][1] = 0.f; s2[ni][0] = s2[ni][1] = 0.f; }
+                    size_t pbs[8];
+                    bool poks[8];
 #pragma unroll
-                for (int r0 = 0; r0 < 16; r0 += 4) {
-                    // rows r0 .. r0 + 3 of a lane are four consecutive pixels of ONE tile row (PX a multiple of 4)
-                    const int row = rcf_mfma_row(r0, lh);
-                    int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
-                    const int ox = ox0 + row % C::PX;
-                    int im = img;
-                    if (a.vt) {   // virtual row -> (image, row); separator rows produce no output
-                        im = (int)(((float)oy + 0.5f) * a.inv_hp);
-                        oy -= im * a.hp;
-                        if (im >= a.nimg) oy = a.h_out;
+                    for (int r0 = 0; r0 < 16; r0 += 4) {
+                        // rows r0 .. r0 + 3 of a lane are four consecutive pixels of ONE tile row (PX a multiple of 4)
+                        const int row = rcf_mfma_row(r0, lh);
+                        int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
+                        const int ox = ox0 + row % C::PX;
+                        int im = img;
+                        if (a.vt) {   // virtual row -> (image, row); separator rows produce no output
+                            im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                            oy -= im * a.hp;
+                            if (im >= a.nimg) oy = a.h_out;
+                        }
+                        const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+                        const bool rowvalid = oy < a.h_out && py < a.ohp;
+                        const size_t base0 = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
+                        const int pstep = a.os * a.c_out;
+#pragma unroll
+                        for (int jp = 0; jp < 4; jp += 2) {
+                            const int jm = jp + odd;                                          // the pixel this lane stores
+                            poks[(r0 + jp) >> 1] = rowvalid && ox + jm < a.w_out && px + jm * a.os < a.owp;
+                            pbs[(r0 + jp) >> 1] = base0 + (size_t)(jm * pstep);
+                        }
                     }
-                    const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
-                    const bool rowvalid = oy < a.h_out && py < a.ohp;
-                    const size_t base0 = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
-                    const int pstep = a.os * a.c_out;
+                    unsigned oldw[8][C::NT];
+                    if (ADD) {
 #pragma unroll
-                    for (int jp = 0; jp < 4; jp += 2) {
-                        const int jm = jp + odd;                                          // the pixel this lane stores
-                        const bool pok = rowvalid && ox + jm < a.w_out && px + jm * a.os < a.owp;
-                        const size_t pb = base0 + (size_t)(jm * pstep);
+                        for (int g = 0; g < 8; ++g)
+#pragma unroll
+                            for (int ni = 0; ni < C::NT; ++ni) {
+                                const int cp = (n0 + ni * 32 + li) & ~1;
+                                oldw[g][ni] = *reinterpret_cast<const unsigned*>(addp + ((poks[g] && cp < a.c_out) ? pbs[g] + cp : 0));
+                            }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const int rj = 2 * g;   // accumulator row of the pair's first pixel
 #pragma unroll
                         for (int ni = 0; ni < C::NT; ++ni) {
                             const int co = n0 + ni * 32 + li;
                             const int cp = co & ~1;
-                            const bool ok = pok && cp < a.c_out;
-                            const float mine = acc[mi][ni][r0 + jm];                      // my channel at my pixel
-                            const float give = acc[mi][ni][r0 + jp + (odd ^ 1)];          // my channel at the partner's pixel
+                            const bool ok = poks[g] && cp < a.c_out;
+                            // (static register indices + a select: indexing the accumulator with the lane-dependent `odd` makes
+                            // hipcc walk all 16 registers with compare/select pairs -- 60 VALU instructions per value)
+                            const float a0 = acc[mi][ni][rj], a1 = acc[mi][ni][rj + 1];
+                            const float mine = odd ? a1 : a0;                                 // my channel at my pixel
+                            const float give = odd ? a0 : a1;                                 // my channel at the partner's pixel
                             const float got = __uint_as_float(rcf_dpp_u32<0xB1>(__float_as_uint(give)));   // partner's channel at my pixel
-                            float lo = odd ? got : mine, hi = odd ? mine : got;           // channels cp, cp + 1
+                            float lo = odd ? got : mine, hi = odd ? mine : got;               // channels cp, cp + 1
                             float alo = 0.f, ahi = 0.f;
-                            if (do_add) {
-                                const unsigned w = *reinterpret_cast<const unsigned*>(addp + (ok ? pb + cp : 0));
-                                alo = __uint_as_float(w << 16);
-                                ahi = __uint_as_float(w & 0xffff0000u);
+                            if (ADD) {
+                                alo = __uint_as_float(oldw[g][ni] << 16);
+                                ahi = __uint_as_float(oldw[g][ni] & 0xffff0000u);
                             }
                             if (EPI) {
                                 lo = rcf_lrelu(lo + eb[ni][0]);
                                 hi = rcf_lrelu(hi + eb[ni][1]);
-                                if (do_add) { lo = rcf_lrelu(lo + alo); hi = rcf_lrelu(hi + ahi); }
-                            } else {
+                                if (ADD) { lo = rcf_lrelu(lo + alo); hi = rcf_lrelu(hi + ahi); }
+                            } else if (ADD) {
                                 lo += alo;
                                 hi += ahi;
                             }
                             const unsigned blo = rcf_f2b(lo), bhi = rcf_f2b(hi);
                             if (ok) {
-                                *reinterpret_cast<unsigned*>(outp + pb + cp) = blo | (bhi << 16);
+                                *reinterpret_cast<unsigned*>(outp + pbs[g] + cp) = blo | (bhi << 16);
                                 if (want_stats) {   // of the values the tensor holds
                                     const float rlo = rcf_b2f(blo), rhi = rcf_b2f(bhi);
                                     s1[ni][0] += rlo; s2[ni][0] += rlo * rlo;
@@ -282,19 +346,28 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                             }
                         }
                     }
-                }
-                if (want_stats) {
+                    if (want_stats) {
 #pragma unroll
-                    for (int ni = 0; ni < C::NT; ++ni)
+                        for (int ni = 0; ni < C::NT; ++ni)
 #pragma unroll
-                        for (int e = 0; e < 2; ++e) { st1[ni][e] += (double)s1[ni][e]; st2[ni][e] += (double)s2[ni][e]; }
+                            for (int e = 0; e < 2; ++e) { st1[ni][e] += (double)s1[ni][e]; st2[ni][e] += (double)s2[ni][e]; }
+                    }
                 }
-            }
+            };
+            if (do_add) epilogue(std::true_type{});
+            else epilogue(std::false_type{});
         }
+        RCF_T(t_w4);
+        RCF_TACC(3, t_w4, t_w3);   // 3: epilogue
         tile = ntile;
         q = nq;
         buf ^= 1;
     }
+#ifdef RCF_PHASE_TIMING
+    tacc[7] = __builtin_amdgcn_s_memtime() - t_begin;
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&rcf_phase_cycles[i], tacc[i]);
+#endif
 
     if (a.stats != nullptr) {
         rcf_wait_dma();

@@ -132,7 +132,7 @@ def test_conv_forward_bf16_tensors(ops, case):
     s = partials.sum(0).cpu()
     gd = got.double()
     assert float((s[0] - gd.sum((0, 2, 3))).abs().max()) < 1e-6 * max(1.0, float(gd.abs().sum((0, 2, 3)).max()))
-    assert float(((s[1] - (gd ** 2).sum((0, 2, 3))).abs() / (gd ** 2).sum((0, 2, 3))).max()) < 1e-9
+    assert float(((s[1] - (gd ** 2).sum((0, 2, 3))).abs() / (gd ** 2).sum((0, 2, 3))).max()) < 1e-6   # fp32 partial sums per accumulator, fp64 across tiles
 
 
 @pytest.mark.parametrize('case', [c for c in CASES if c[0] != 7], ids=[str(c) for c in CASES if c[0] != 7])

@@ -11,6 +11,7 @@ from rcf_amd import ops, _lib
 LAYERS = [('blocks2 64->64 @225x400', 64, 0, 64, 225, 400, None), ('blocks3 128->128 @113x200', 128, 0, 128, 113, 200, None),
           ('deconv0.conv 32->32 @900x1600', 32, 0, 32, 900, 1600, None), ('deconv1.conv 64+32->64 @450x800', 64, 32, 64, 450, 800, None),
           ('blocks4 256->256 @57x100', 256, 0, 256, 57, 100, None)]
+DMA_NAMES = ['DMA wait + barrier', 'address arithmetic + DMA issue (next item)', 'acc init + MFMAs + LDS reads', 'epilogue', '-', '-', '-', 'whole wave']
 NAMES = ['row prologue (B reads, DMA/load issue)', 'row MFMAs + interleaved LDS reads', 'output epilogue', 'barrier: A tile free',
          'store_a (load wait, split, ds_write)', 'DMA wait + barrier after store_a', 'DMA wait + barrier between rows', 'whole wave']
 lib = _lib.load()
@@ -37,6 +38,7 @@ for name, c1, c2, co, h, w, _ in LAYERS:
     fn(buf, 1)
     tot = buf[7]
     print('%s (kernel id %d)' % (name, info.kernel_id))
+    names = DMA_NAMES if (ADT == torch.bfloat16 and os.environ.get('RCF_B16_DMA', '1') != '0') else NAMES
     for i in range(7):
-        print('   %-42s %5.1f %%' % (NAMES[i], 100.0 * buf[i] / tot))
+        print('   %-42s %5.1f %%' % (names[i], 100.0 * buf[i] / tot))
     print('   %-42s %5.1f %%   (%.0f cycles per wave per launch)' % ('other (tile bookkeeping, acc init)', 100.0 * (tot - sum(buf[:7])) / tot, tot / reps / (512 * 4)))
