@@ -72,7 +72,8 @@ def parse():
                     help='untimed steps run for this many seconds after the W warm-up steps, so the timed steps see the clocks '
                          'of a board at its power limit and not the boost clocks of a cold one')
     ap.add_argument('--graph', type=int, default=-1, help='train: replay the step from one hipGraph (1) or launch it eagerly (0); '
-                                                          'default: eager')
+                                                          'default: the graph on one GPU (bitwise the eager step, tests/'
+                                                          'test_hip_model.py), eager under data parallelism')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--kernel-table', type=str, default='', help='write the per-kernel event table (JSON) here')
     return ap.parse_args()
@@ -235,14 +236,18 @@ def run_rank(args):
 
     step = eager_step
     first_loss = None
-    use_graph = args.graph == 1 and world == 1 and hasattr(model, 'capture_training_step')
+    use_graph = args.graph != 0 and world == 1 and hasattr(model, 'capture_training_step')
+    graph_note = None
     n_pre = 0
     for i in range(max(args.warmup, 0)):
         loss = step()
         if i == 0:
             first_loss = float(loss.detach())
     if use_graph:
-        step = model.capture_training_step(opt, image, input_depth, gt, lidar, outlier_removal=outlier)
+        try:
+            step = model.capture_training_step(opt, image, input_depth, gt, lidar, outlier_removal=outlier)
+        except Exception as e:   # a box whose runtime cannot capture: measure the eager step and say so
+            use_graph, graph_note = False, 'eager launches (hipGraph capture failed: %s)' % str(e)[:120]
     if args.preheat_s > 0:   # untimed: board at its power limit, clocks settled
         torch.cuda.synchronize()
         t_pre = time.time()
@@ -324,7 +329,7 @@ def run_rank(args):
                                   'configs[1]' if dtype == 'f32' else 'configs[3] on %d GPU(s)' % world),
                    'global_batch': world * batch, 'parallelism': 'dp%d' % world,
                    'step': 'forward + outlier removal + masked L1 + backward + Adam, train-mode BatchNorm',
-                   'launch': 'one hipGraph replay per step' if use_graph else 'eager launches',
+                   'launch': 'one hipGraph replay per step (bitwise the eager step)' if use_graph else (graph_note or 'eager launches'),
                    'first_step_loss': None if first_loss is None else round(first_loss, 5), 'final_loss': round(final_loss, 5),
                    'preheat_steps': n_pre},
         'rccl_ranks': dist.get_world_size() if world > 1 else 1,

@@ -68,7 +68,7 @@ typedef struct rcf_conv_desc {
     int h_src1, w_src1; /* physical extent of source 1 (== h_in,w_in for RCF_GATHER_DIRECT) */
     int gather1;        /* RCF_GATHER_* */
     int h_out, w_out, c_out;
-    int ksize;          /* 1, 2 (phase convs), 3 or 7 */
+    int ksize;          /* 1, 2 (phase convs), 3, 4 (the stems on the space-to-depth image, bf16 tensors) or 7 */
     int stride;         /* 1 or 2 */
     int pad;            /* top pad; ksize/2 for the reference's Conv2d (src/net_utils.py:61); ksize-1-pad for its dgrad */
     int pad_x;          /* left pad (== pad except for the 2x2 phase convs) */
@@ -407,6 +407,16 @@ int rcf_fc_fwd_b16(const float* x, const float* w, const float* bias, float* y, 
                    int cstride, int coff, void* stream);
 int rcf_fc_bwd_b16(const float* x, const float* w, const float* y, const float* dy, float* dw, float* db, float* dx, float* workspace,
                    int m_rows, int n_in, int n_out, int act, int hw, int cstride, int coff, void* stream);
+/* The two 7x7 stride-2 stem convolutions (FusionNetEncoder conv1_image / conv1_depth, src/networks.py:332-352, :854-855; ResNetEncoder
+ * conv1, :70-78) with bf16 tensors: a 7-tap kernel at stride 2 is a 4-tap kernel at stride 1 on the space-to-depth image whose 16
+ * channels are the 2 x 2 pixel phases x (up to) 4 input channels.  rcf_s2d_image_b16 builds that image straight from the reference's
+ * NCHW fp32 input (replacing rcf_nchw_to_nhwc for the forward pass): out[n][y][x][a*8 + b*4 + c] = bf16(img[n][c][2y + a][2x + b]),
+ * (ceil(h/2), ceil(w/2)) pixels, zero where the source ends.  rcf_stem_weights_s2d rewrites the OIHW 7x7 weight as an OIHW 4x4 weight
+ * over those 16 channels.  The convolution is then rcf_conv2d_fwd with {ksize 4, stride 1, pad 2, pad_x 2, c1 16, storage BF16, h_in /
+ * w_in = the space-to-depth extent, h_out / w_out = the stem's output extent}.  Its weight gradient is taken on the 7x7 form. */
+int rcf_s2d_image_b16(const float* img_nchw, void* out, int n, int c, int h, int w, void* stream);
+int rcf_stem_weights_s2d(const float* w7_oihw, float* w4_oihw, int c_out, int c_in, void* stream);
+
 /* dst[i] = (accumulate ? dst[i] : 0) + src[i] for n elements, each side RCF_STORE_FP32 or RCF_STORE_BF16 (torch's .to(dtype) of the
  * reference-side glue; also how an fp32 scatter result joins a bf16 gradient). */
 int rcf_convert(const void* src, int src_storage, void* dst, int dst_storage, long long n, int accumulate, void* stream);

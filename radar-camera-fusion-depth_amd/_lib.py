@@ -104,6 +104,8 @@ B16_TWINS = ('rcf_bn_act_fwd', 'rcf_fuse_fwd', 'rcf_bn_act_bwd_reduce', 'rcf_bn_
 for _name in B16_TWINS:   # NAME_b16: same argument list, NHWC activation tensors hold bf16 (include/rcf_hip.h)
     _SIGNATURES[_name + '_b16'] = _SIGNATURES[_name]
 _SIGNATURES['rcf_convert'] = (c_int, [_P, c_int, _P, c_int, c_longlong, c_int, _P])
+_SIGNATURES['rcf_s2d_image_b16'] = (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P])
+_SIGNATURES['rcf_stem_weights_s2d'] = (c_int, [_P, _P, c_int, c_int, _P])
 '''Every symbol include/rcf_hip.h declares, with its ctypes signature.'''
 
 _lib = None

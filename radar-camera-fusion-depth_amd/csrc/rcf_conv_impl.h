@@ -1786,7 +1786,7 @@ __global__ void phase_wgrad_gather_s2_kernel(const float* __restrict__ dwp, floa
 
 // ------------------------------------------------------------------------------------------------
 // configuration tables
-enum Kind { K3S1 = 0, K3S2 = 1, K1 = 2, K7S2 = 3, K2S1 = 4 };
+enum Kind { K3S1 = 0, K3S2 = 1, K1 = 2, K7S2 = 3, K2S1 = 4, K4S1 = 7 };   // K4S1: the 7x7 stride-2 stem as a 4x4 conv on the space-to-depth image (bf16 tensors)
 
 struct Sel {
     int kind, ck, nt, px;
@@ -1827,6 +1827,8 @@ using D3S2_2_32 = DmaCfg<3, 2, 32, 1, 2>;   // stride 2: 128-pixel tiles (the 65
 using D3S2_2_16 = DmaCfg<3, 2, 16, 1, 2>;
 using D3S2_1_32 = DmaCfg<3, 1, 32, 1, 2>;
 using D3S2_1_16 = DmaCfg<3, 1, 16, 1, 2>;
+using D4_1_32 = DmaCfg<4, 1, 32, 2>;        // the stems: 4x4 on the 16-channel space-to-depth image, <= 32 output channels
+using D4_1_16 = DmaCfg<4, 1, 16, 2>;
 #endif
 
 // Persistent grid: one resident wave of workgroups (occupancy API), split between the n-tiles.  Also the number of
@@ -2050,7 +2052,7 @@ bool valid_desc(const rcf_conv_desc* d) {
     if (d->n <= 0 || d->h_in <= 0 || d->w_in <= 0 || d->c1 <= 0 || d->c2 < 0 || d->h_out <= 0 || d->w_out <= 0 ||
         d->c_out <= 0)
         return false;
-    if (d->ksize != 1 && d->ksize != 2 && d->ksize != 3 && d->ksize != 7) return false;
+    if (d->ksize != 1 && d->ksize != 2 && d->ksize != 3 && d->ksize != 4 && d->ksize != 7) return false;
     if (d->stride != 1 && d->stride != 2) return false;
     if (d->gather1 < 0 || d->gather1 > 3) return false;
     if (d->precision != RCF_PREC_FP32 && d->precision != RCF_PREC_BF16) return false;
@@ -2061,6 +2063,11 @@ bool valid_desc(const rcf_conv_desc* d) {
     if (d->out_h_phys <= 0 || d->out_w_phys <= 0) return false;
     if (d->gather1 == RCF_GATHER_DIRECT && (d->h_src1 != d->h_in || d->w_src1 != d->w_in)) return false;
     if (d->h_src1 <= 0 || d->w_src1 <= 0) return false;
+    if (d->ksize == 4) {   // the stem on the space-to-depth image: output grid given (pad 2 on top / left, what is left at the bottom / right)
+        if (d->stride != 1 || d->w_mode != RCF_W_FORWARD || d->c1 != 16 || d->c2 != 0 || d->gather1 != RCF_GATHER_DIRECT || d->pad != 2 ||
+            d->pad_x != 2 || d->out_stride != 1 || d->accumulate)
+            return false;
+    } else
     if (d->ksize != 2) {   // 2x2 phase convs pad asymmetrically: their output grid is given, not derived
         if ((d->h_in + 2 * d->pad - d->ksize) / d->stride + 1 != d->h_out) return false;
         if ((d->w_in + 2 * d->pad_x - d->ksize) / d->stride + 1 != d->w_out) return false;
@@ -2087,6 +2094,9 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
         if (d->stride != 2 || d->c2 != 0 || d->c1 > 4 || d->gather1 != RCF_GATHER_DIRECT || d->w_mode != RCF_W_FORWARD)
             return RCF_EUNSUPPORTED;
         s->kind = K7S2; s->ck = 32; s->cst = 4; s->nt = 1; s->t = 7;
+    } else if (d->ksize == 4) {
+        if (!SAct::B16 || d->c_out > 32) return RCF_EUNSUPPORTED;   // bf16 tensors only (conv_b16_kernel), one 32-co tile
+        s->kind = K4S1; s->t = 16; s->ck = 16; s->cst = 16; s->nt = 1;
     } else if (d->ksize == 2) {
         s->kind = K2S1; s->t = 4; s->ck = 32; s->cst = 32;
     } else if (d->ksize == 3) {
@@ -2126,6 +2136,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
         s->dma = (s->bf16 && d->c1 % 16 == 0 && d->c2 % 16 == 0 && (e == nullptr || e[0] != '0')) ? 1 : 0;
 #endif
     }
+    if (s->kind == K4S1) { s->split = 1; s->ck = 16; s->cst = 16; s->bf16 = 1; s->dma = 1; }
     double best = -1.0;
     const bool vt_ok = vt_allowed(d);
     const int pxs[3] = {32, 16, 8};
@@ -2208,6 +2219,7 @@ int dispatch_dma(const Sel& s, F&& f) {
         if (s.nt == 1) return p16 ? f(Tag<D2_1_16>{}) : f(Tag<D2_1_32>{});
         return p16 ? f(Tag<D2_2_16>{}) : f(Tag<D2_2_32>{});
     }
+    if (s.kind == K4S1) return p16 ? f(Tag<D4_1_16>{}) : f(Tag<D4_1_32>{});
     if (s.kind == K3S2) {
         if (s.nt == 1) return p16 ? f(Tag<D3S2_1_16>{}) : f(Tag<D3S2_1_32>{});
         return p16 ? f(Tag<D3S2_2_16>{}) : f(Tag<D3S2_2_32>{});
@@ -2255,6 +2267,7 @@ struct WSel { int kind, px, th, t, cst, nchunk1, nchunk2, ncog, nsplit, ktot, co
 int select_wgrad(const rcf_conv_desc* d, WSel* w) {
     if (!valid_desc(d) || d->w_mode != RCF_W_FORWARD) return RCF_EINVAL;
     if (d->c_out % 4 != 0) return RCF_EUNSUPPORTED;
+    if (d->ksize == 4) return RCF_EUNSUPPORTED;   // the stem's weight gradient is taken on the 7x7 form (fp32 NHWC input)
     if (d->ksize == 7) {
         if (d->stride != 2 || d->c2 != 0 || d->c1 > 4 || d->gather1 != RCF_GATHER_DIRECT) return RCF_EUNSUPPORTED;
         w->kind = K7S2; w->t = 7; w->cst = 4;
@@ -2473,6 +2486,7 @@ static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float
         return dispatch_dma(s, [&](auto tag) { return launch_dma<typename decltype(tag)::type, false>(a, nn, (hipStream_t)stream); });
     if (s.dma) return RCF_EUNSUPPORTED;   // rcf_conv_info.bn_on_load is 0 for these descriptors (the tile geometry differs)
 #endif
+    if (s.kind == K4S1) return RCF_EUNSUPPORTED;
     if (s.split) return dispatch_split(s, [&](auto tag) { return launch_split<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
     return dispatch_fwd(s, [&](auto tag) { return launch_fwd<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
 }

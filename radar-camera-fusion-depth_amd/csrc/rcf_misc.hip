@@ -983,6 +983,63 @@ extern "C" int rcf_scale_channels(const float* w, const float* scale, float* out
     return rcf_launch_status();
 }
 
+// ---- the 7x7 stride-2 stems as 4x4 stride-1 convolutions on the space-to-depth image (bf16 tensors) -------------------------------
+// out[oy] = sum_ky W[ky] x[2 oy + ky - 3]; with ky' = ky + 1: 2 oy + ky' - 4 = 2 (oy + (ky' >> 1) - 2) + (ky' & 1), i.e. row
+// oy + t - 2 (t = ky' >> 1 in 0..3) of row phase a = ky' & 1 -- a 4-tap kernel with pad 2 on the image whose channels are the four
+// (row, column) phases of a pixel quad: S[n][y][x][a * 8 + b * 4 + c] = img[n][c][2 y + a][2 x + b] (16 channels, c < 4, zero padded).
+namespace {
+__global__ void __launch_bounds__(256) s2d_image_kernel(const float* __restrict__ img, unsigned short* __restrict__ out, int n, int c,
+                                                        int h, int w, int hs, int ws) {
+    const long long total = (long long)n * hs * ws * 4;   // one thread per (pixel quad, phase): 4 channels = 8 bytes
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const int ph = (int)(g & 3);
+        const long long q = g >> 2;
+        const int x = (int)(q % ws);
+        const int y = (int)((q / ws) % hs);
+        const int im = (int)(q / ((long long)ws * hs));
+        const int iy = 2 * y + (ph >> 1), ix = 2 * x + (ph & 1);
+        unsigned v[4] = {0u, 0u, 0u, 0u};
+        if (iy < h && ix < w) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+                if (ch < c) v[ch] = rcf_f2b(img[(((size_t)im * c + ch) * h + iy) * w + ix]);
+        }
+        rcf_u32x2 pk;
+        pk[0] = v[0] | (v[1] << 16);
+        pk[1] = v[2] | (v[3] << 16);
+        *reinterpret_cast<rcf_u32x2*>(out + (size_t)q * 16 + ph * 4) = pk;
+    }
+}
+
+// W4[co][a * 8 + b * 4 + c][t][u] = W7[co][c][2 t + a - 1][2 u + b - 1] (0 outside the 7x7 kernel or for c >= C)
+__global__ void __launch_bounds__(256) stem_weights_s2d_kernel(const float* __restrict__ w7, float* __restrict__ w4, int co_n, int c) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= co_n * 16 * 16) return;
+    const int u = idx & 3, t = (idx >> 2) & 3, ci = (idx >> 4) & 15, co = idx >> 8;
+    const int a = ci >> 3, b = (ci >> 2) & 1, ch = ci & 3;
+    const int ky = 2 * t + a - 1, kx = 2 * u + b - 1;
+    float v = 0.f;
+    if (ch < c && ky >= 0 && ky < 7 && kx >= 0 && kx < 7) v = w7[(((size_t)co * c + ch) * 7 + ky) * 7 + kx];
+    w4[idx] = v;
+}
+}   // namespace
+
+extern "C" int rcf_s2d_image_b16(const float* img_nchw, void* out, int n, int c, int h, int w, void* stream) {
+    if (!img_nchw || !out || n <= 0 || c <= 0 || h <= 0 || w <= 0) return RCF_EINVAL;
+    if (c > 4) return RCF_EUNSUPPORTED;
+    const int hs = (h + 1) / 2, ws = (w + 1) / 2;
+    unsigned b = nblk((long long)n * hs * ws * 4, 256); if (b > 16384) b = 16384;
+    hipLaunchKernelGGL(s2d_image_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, img_nchw, (unsigned short*)out, n, c, h, w, hs, ws);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_stem_weights_s2d(const float* w7_oihw, float* w4_oihw, int c_out, int c_in, void* stream) {
+    if (!w7_oihw || !w4_oihw || c_out <= 0 || c_in <= 0) return RCF_EINVAL;
+    if (c_in > 4) return RCF_EUNSUPPORTED;
+    hipLaunchKernelGGL(stem_weights_s2d_kernel, dim3((c_out * 256 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w7_oihw, w4_oihw, c_out, c_in);
+    return rcf_launch_status();
+}
+
 // ---- element type conversion between the two storages (fp32 <-> bf16, round to nearest even), optionally accumulating into dst
 namespace {
 template <class SS, class SD>

@@ -27,7 +27,7 @@ BN_MOMENTUM = 0.1
 
 class Act(object):
     '''An activation tensor and (during backward) its gradient accumulator.'''
-    __slots__ = ('t', 'g', 'needs_grad', 'head_fusable', 'g_head', 'z', 'coef')
+    __slots__ = ('t', 'g', 'needs_grad', 'head_fusable', 'g_head', 'z', 'coef', 's2d', 'hw')
 
     def __init__(self, t, needs_grad=True):
         self.t = t
@@ -37,6 +37,8 @@ class Act(object):
         self.g_head = None          # (dlogit, head weight): the gradient in un-materialised form
         self.z = None               # deferred activation: t is None and the consumer applies coef (BN + lrelu) to z on load
         self.coef = None
+        self.s2d = None             # network input only (bf16 configuration): its space-to-depth image for the stem, and (H, W)
+        self.hw = None
 
 
 class Engine(object):
@@ -108,6 +110,8 @@ class Engine(object):
         '''conv (+ folded nearest-upsample of x to up_hw, + folded channel concat with x2) -> raw output z.
         fold = (coef, res tensor or None): inference -- BatchNorm scale folded into the weights, bias + LeakyReLU (+ residual) in the
         kernel's epilogue where it has one (info.fwd_act); the returned tensor is then the ACTIVATION and the 5th result True.'''
+        if x.s2d is not None and layer.kernel_size == 7 and layer.stride == 2 and x2 is None and up_hw is None:
+            return self._conv_stem_s2d(layer, x, want_stats, fold)
         n, h, w, c1 = self._shape(x)
         c2 = 0 if x2 is None else self._shape(x2)[3]
         h_in, w_in, gather = h, w, RCF_GATHER_DIRECT
@@ -203,6 +207,38 @@ class Engine(object):
             return z, None, info, partials, fused
         return z, None, info, partials
 
+    def _conv_stem_s2d(self, layer, x, want_stats, fold=None):
+        '''
+        The 7x7 stride-2 stem with bf16 tensors: a 4x4 stride-1 convolution on the space-to-depth image of the network input
+        (ops.s2d_image, built straight from the NCHW input) on the bf16 matrix pipe -- the f32-MFMA stem kernel is compute bound at
+        ~55 TFLOP/s.  The weight gradient (training) is taken on the 7x7 form from the fp32 NHWC input as before.
+        '''
+        n = x.s2d.shape[0]
+        h, w = x.hw
+        weight = layer.conv.weight
+        co = weight.shape[0]
+        d = ops.make_stem_s2d_desc(n, h, w, co)
+        info = ops.conv_query(d)
+        fused = fold is not None and bool(info.fwd_act) and fold[1] is None
+        w7 = ops.scale_channels(weight.detach(), fold[0][0]) if fused else weight.detach()
+        packed = self._newf((info.packed_weight_floats,), x.s2d)
+        ops.conv_pack(d, ops.stem_weights_s2d(w7), packed)
+        z = torch.empty((n, d.h_out, d.w_out, co), dtype=torch.bfloat16, device=x.s2d.device)
+        partials = torch.empty((info.n_partials, 2, co), dtype=torch.float64, device=z.device) if want_stats else None
+        if fused:
+            ops.conv_fwd_act(d, x.s2d, None, packed, fold[0][1], None, z)
+        else:
+            ops.conv_fwd(d, x.s2d, None, packed, z, partials)
+
+        class _Info(object):
+            pass
+        sinfo = _Info()
+        sinfo.n_partials = info.n_partials
+        sinfo.stem = True
+        if fold is not None:
+            return z, None, sinfo, partials, fused
+        return z, None, sinfo, partials
+
     def _conv_transpose(self, layer, x, want_stats, fold=None):
         '''
         TransposeConv2d's ConvTranspose2d(3, stride 2, padding 1, output_padding 1) (src/net_utils.py:94-153): y (2H x 2W) is the
@@ -294,6 +330,11 @@ class Engine(object):
 
     def _conv_backward(self, layer, desc, info, x, x2, dz):
         '''dW (written once into the parameter's gradient) and dX / dX2 (accumulated into the producers' .g).'''
+        if desc is None and hasattr(info, 'stem'):
+            # the stem ran on the space-to-depth image; its weight gradient is the 7x7 one on the fp32 NHWC input (no input gradient)
+            n, h, w, c = x.t.shape
+            desc = ops.make_fwd_desc(n, h, w, c, 0, layer.conv.weight.shape[0], 7, 2)
+            info = ops.conv_query(desc)
         if desc is None and hasattr(info, 'transpose'):
             return self._conv_transpose_backward(layer, info, x, dz)
         if desc is None:
@@ -394,7 +435,7 @@ class Engine(object):
         if self.fuse_eval and not self.training and self.tape is None and not feeds_head:
             # inference: eval-mode BatchNorm is affine per channel -> scale into the weights, shift + LeakyReLU (+ residual tail) into the
             # conv kernel's epilogue; layers whose kernel has no such epilogue (f32-MFMA 1x1 / stride-2 / stem) fall through
-            src = x.t if x.t is not None else x.z
+            src = x.t if x.t is not None else (x.z if x.z is not None else x.s2d)
             coef = self._bn_coef_eval(layer, src)
             z, desc, info, partials, fused = self._conv(layer, x, x2, up_hw, want_stats=False,
                                                         fold=(coef, None if res is None else self._mat(res)))
@@ -600,16 +641,26 @@ class Engine(object):
         return depth
 
     # ------------------------------------------------------------------ the network
-    def forward(self, image_nhwc, depth_nhwc, training, record):
+    @staticmethod
+    def _input(nhwc, s2d, hw):
+        a = Act(nhwc, needs_grad=False)
+        a.s2d, a.hw = s2d, hw
+        return a
+
+    def forward(self, image_nhwc, depth_nhwc, training, record, image_s2d=None, depth_s2d=None, hw=None):
         '''
         image_nhwc (N,H,W,3), depth_nhwc (N,H,W,2) -> depth (N,H,W) as an Act.  record=True keeps the tape for
         backward(); record=False is the no_grad / eval path of validate()/run() (src/fusionnet_main.py:517, :814).
+        bf16 configuration: image_s2d / depth_s2d (ops.s2d_image of the NCHW inputs) feed the stems and hw = (H, W); the fp32 NHWC
+        inputs are then only needed for the stems' weight gradients (record=True) and may be None otherwise.
         '''
         enc, dec = self.encoder, self.decoder
         self.training = bool(training)
         self.tape = [] if record else None
-        img = self.conv_bn_act(enc.conv1_image, Act(image_nhwc, needs_grad=False))
-        dep = self.conv_bn_act(enc.conv1_depth, Act(depth_nhwc, needs_grad=False))
+        if hw is None:
+            hw = tuple(image_nhwc.shape[1:3])
+        img = self.conv_bn_act(enc.conv1_image, self._input(image_nhwc, image_s2d, hw))
+        dep = self.conv_bn_act(enc.conv1_depth, self._input(depth_nhwc, depth_s2d, hw))
         layers = [self.fuse(enc.conv1_weight, enc.conv1_project, dep, img)]
         img = self.max_pool(img)
         dep = self.max_pool(dep)
@@ -619,7 +670,7 @@ class Engine(object):
                 dep = self.resnet_block(blk_d, dep)
             layers.append(self.fuse(getattr(enc, 'conv%d_weight' % lvl), getattr(enc, 'conv%d_project' % lvl), dep, img))
         latent, skips = layers[-1], layers[:-1]
-        out = self.head(dec.output0, self._decode(latent, skips, image_nhwc.shape[1:3]))
+        out = self.head(dec.output0, self._decode(latent, skips, hw))
         tape, self.tape = self.tape, None
         return out, tape
 
@@ -695,7 +746,7 @@ class Engine(object):
                     dy = dx
             self.tape.append(backward)
 
-    def forward_radarnet(self, image_nhwc, points, rois, training, record):
+    def forward_radarnet(self, image_nhwc, points, rois, training, record, image_s2d=None, hw=None):
         '''
         RadarNetV1Encoder.forward (src/networks.py:1203-1256) + MultiScaleDecoder.forward + output0 -> logits (M,H,W) as an Act;
         image_nhwc (N,H,W,3), points (M,3), rois (M,5) = (image index, x1, y1, x2, y2).
@@ -706,7 +757,7 @@ class Engine(object):
         self.tape = [] if record else None
         shape = (int(enc.input_patch_size_image[0]), int(enc.input_patch_size_image[1]))
         # ResNetEncoder.forward (src/networks.py:232-268)
-        x = self.conv_bn_act(ei.conv1, Act(image_nhwc, needs_grad=False))
+        x = self.conv_bn_act(ei.conv1, self._input(image_nhwc, image_s2d, hw if hw is not None else tuple(image_nhwc.shape[1:3])))
         layers = [x]
         x = self.max_pool(x)
         for lvl in range(2, ei.network_depth + 1):
@@ -720,7 +771,7 @@ class Engine(object):
         m = rois.shape[0]
         c_img = self._shape(latent_image)[3]
         c_dep = enc.n_neuron_latent_depth
-        latent = Act(self._new((m, lat_hw[0], lat_hw[1], c_img + c_dep), image_nhwc))
+        latent = Act(self._new((m, lat_hw[0], lat_hw[1], c_img + c_dep), rois))
         skips = [self.roi_pool(s, rois, (int(shape[0] * skip_scales[i]), int(shape[1] * skip_scales[i])), skip_scales[i])
                  for i, s in enumerate(skips_image)]
         # radar point branch -> channels [c_img, c_img + c_dep) of the latent, pooled image latent -> [0, c_img)

@@ -270,10 +270,20 @@ class FusionNetModel(object):
         _lib.load()
         if image.dtype != torch.float32 or input_depth.dtype != torch.float32:
             raise _lib.RcfError('FusionNetModel.forward is fp32')
-        x_img = ops.nchw_to_nhwc(image.contiguous())
-        x_dep = ops.nchw_to_nhwc(input_depth.contiguous())
         training = self._training
-        out, tape = self._engine.forward(x_img, x_dep, training=training, record=record)
+        image, input_depth = image.contiguous(), input_depth.contiguous()
+        hw = (int(image.shape[2]), int(image.shape[3]))
+        if ops.act_dtype() == torch.bfloat16 and image.shape[1] <= 4 and input_depth.shape[1] <= 4:
+            # bf16 configuration: the stems run on the space-to-depth image, built straight from the NCHW inputs; the fp32 NHWC
+            # copies are only read by the stems' weight gradients
+            s_img, s_dep = ops.s2d_image(image), ops.s2d_image(input_depth)
+            x_img = ops.nchw_to_nhwc(image) if record else None
+            x_dep = ops.nchw_to_nhwc(input_depth) if record else None
+            out, tape = self._engine.forward(x_img, x_dep, training=training, record=record, image_s2d=s_img, depth_s2d=s_dep, hw=hw)
+        else:
+            x_img = ops.nchw_to_nhwc(image)
+            x_dep = ops.nchw_to_nhwc(input_depth)
+            out, tape = self._engine.forward(x_img, x_dep, training=training, record=record)
         if training:
             self._nbt += 1
         return out, tape

@@ -196,9 +196,14 @@ class RadarNetModel(object):
         _lib.load()
         if image.dtype != torch.float32:
             raise _lib.RcfError('RadarNetModel.forward is fp32')
-        x_img = ops.nchw_to_nhwc(image.contiguous())
-        out, tape = self._engine.forward_radarnet(x_img, point.contiguous().to(torch.float32), rois, training=self._training,
-                                                  record=record)
+        image = image.contiguous()
+        pts = point.contiguous().to(torch.float32)
+        if ops.act_dtype() == torch.bfloat16 and image.shape[1] <= 4:   # bf16 configuration: stem on the space-to-depth image
+            out, tape = self._engine.forward_radarnet(ops.nchw_to_nhwc(image) if record else None, pts, rois, training=self._training,
+                                                      record=record, image_s2d=ops.s2d_image(image),
+                                                      hw=(int(image.shape[2]), int(image.shape[3])))
+        else:
+            out, tape = self._engine.forward_radarnet(ops.nchw_to_nhwc(image), pts, rois, training=self._training, record=record)
         if self._training:
             self._nbt += 1
         return out, tape

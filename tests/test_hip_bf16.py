@@ -406,3 +406,33 @@ def test_tiny_network_train_step_bf16_storage_against_oracle(ops):
     cos = num / np.sqrt(den_a * den_b)
     print('gradient cosine vs fp32 oracle %.4f' % cos)
     assert cos > 0.95
+
+
+@pytest.mark.parametrize('c,co,n,h,w', [(3, 32, 2, 70, 102), (2, 16, 2, 71, 101), (3, 8, 1, 64, 96), (2, 4, 3, 33, 35)])
+def test_stem_as_4x4_convolution_on_the_space_to_depth_image(ops, c, co, n, h, w):
+    '''The 7x7 stride-2 stems with bf16 tensors: rcf_s2d_image_b16 + rcf_stem_weights_s2d + the ksize-4 convolution == torch's
+    conv2d(k 7, stride 2, pad 3) of the bf16-rounded image and weights (fp32 accumulate), rounded once; odd and even extents.'''
+    ops.set_precision('bf16')
+    x = rnd(n, c, h, w, seed=1)
+    wt = rnd(co, c, 7, 7, seed=2, scale=1.0 / np.sqrt(c * 49))
+    ref = F.conv2d(b16(x).double(), b16(wt).double(), stride=2, padding=3).float()
+    s2d = ops.s2d_image(x.cuda())
+    # the space-to-depth image itself
+    hs, ws = (h + 1) // 2, (w + 1) // 2
+    want = torch.zeros(n, hs, ws, 16)
+    for a in range(2):
+        for b in range(2):
+            sub = b16(x)[:, :, a::2, b::2]
+            want[:, :sub.shape[2], :sub.shape[3], a * 8 + b * 4:a * 8 + b * 4 + c] = sub.permute(0, 2, 3, 1)
+    assert torch.equal(s2d.float().cpu(), want)
+    d = ops.make_stem_s2d_desc(n, h, w, co)
+    info = ops.conv_query(d)
+    packed = torch.empty(info.packed_weight_floats, device='cuda')
+    ops.conv_pack(d, ops.stem_weights_s2d(wt.cuda()), packed)
+    out = torch.full((n, d.h_out, d.w_out, co), float('nan'), device='cuda').bfloat16()
+    part = torch.empty((info.n_partials, 2, co), dtype=torch.float64, device='cuda')
+    ops.conv_fwd(d, s2d, None, packed, out, part)
+    torch.cuda.synchronize()
+    assert tuple(nchw(out).shape) == tuple(ref.shape)
+    nbad, e = close_bf16(nchw(out), ref, slack=1.01)
+    assert nbad <= max(2, out.numel() // 2000) and e < 2 * BF16_EPS, (nbad, e)
