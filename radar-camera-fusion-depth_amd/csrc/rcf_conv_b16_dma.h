@@ -429,3 +429,194 @@ int launch_dma(const ConvArgs& a, int ntile_n, hipStream_t st) {
     hipLaunchKernelGGL((conv_b16_kernel<C, EPI>), dim3(gx, ntile_n, 1), dim3(256), C::LDS_BYTES, st, a);
     return rcf_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// conv1x1_b16_kernel: 1x1 convolutions (the encoder's fusion convs W1 d, W2 d and the ResNet projections, src/networks.py:863-866,
+// src/net_utils.py:300-307) and their input gradients on bf16 tensors.  A 1x1 convolution is a [pixels x Cin] x [Cin x Cout] GEMM with
+// a tiny K (16 ... 64 at the resolutions that matter): HBM-bound, and there is nothing to stage -- 32 pixels x 16 channels of an NHWC
+// bf16 tensor ARE one contiguous KiB in exactly the MFMA's A layout (lane (pixel, k half) <- 16 B), so the operand goes from global
+// memory straight into the MFMA's registers; the whole weight matrix (<= 8192 elements) lives in registers for the lifetime of the
+// wave.  No LDS, no barrier in the main loop.  (The f32-MFMA implicit-GEMM kernel ran these layers at 13-40 TFLOP/s = ~1.2 TB/s.)
+template <int KST_, int NT_>
+struct PwCfg {
+    static constexpr int KST = KST_, NT = NT_, MT = NT_ <= 2 ? 4 : 2;   // k-steps of 16 input channels, 32-co tiles, 32-pixel blocks per trip
+};
+
+template <class C>
+__global__ void __launch_bounds__(256, 2) conv1x1_b16_kernel(ConvArgs a) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int odd = li & 1;
+    // weights: [chunk s][co][16] bf16, halves swizzled by (co >> 3) & 1 (pack_weights_split_kernel with BN = 32 NT, one n-tile)
+    bf16x8 bw[C::KST][C::NT];
+    {
+        const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.wp);
+#pragma unroll
+        for (int s = 0; s < C::KST; ++s)
+#pragma unroll
+            for (int ni = 0; ni < C::NT; ++ni) {
+                const int co = ni * 32 + li;
+                bw[s][ni] = as_bf16x8(*reinterpret_cast<const u32x4*>(wp + ((size_t)(s * 32 * C::NT + co) * 32) + ((lh ^ ((co >> 3) & 1)) * 16)));
+            }
+    }
+    const long long npix = (long long)a.n * a.h_out * a.w_out;
+    const long long nblk32 = (npix + 31) / 32;
+    const int nwaves = gridDim.x * 4;
+    const unsigned short* src = reinterpret_cast<const unsigned short*>(a.in1);
+    unsigned short* outp = reinterpret_cast<unsigned short*>(a.out);
+    const bool want_stats = a.stats != nullptr;
+    double st1[C::NT][2], st2[C::NT][2];
+#pragma unroll
+    for (int ni = 0; ni < C::NT; ++ni) { st1[ni][0] = st1[ni][1] = 0.0; st2[ni][0] = st2[ni][1] = 0.0; }
+
+    for (long long blk0 = ((long long)blockIdx.x * 4 + wave) * C::MT; blk0 < nblk32; blk0 += (long long)nwaves * C::MT) {
+        // A operands of MT blocks: lane (li, lh) <- channels 16 s + 8 lh .. + 7 of output pixel blk * 32 + li (source pixel through the stride)
+        u32x4 av[C::MT][C::KST];
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+            const long long p = (blk0 + mt) * 32 + li;
+            const bool ok = p < npix;
+            size_t sp = 0;
+            if (ok) {
+                if (a.stride == 1) sp = (size_t)p;
+                else {
+                    const int ox = (int)(p % a.w_out);
+                    const long long t = p / a.w_out;
+                    const int oy = (int)(t % a.h_out);
+                    const int im = (int)(t / a.h_out);
+                    sp = ((size_t)im * a.h_in + (size_t)oy * a.stride) * a.w_in + (size_t)ox * a.stride;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < C::KST; ++s)
+                av[mt][s] = ok ? *reinterpret_cast<const u32x4*>(src + sp * a.c1 + s * 16 + lh * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+        f32x16 acc[C::MT][C::NT];
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+            for (int ni = 0; ni < C::NT; ++ni) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][ni][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < C::KST; ++s)
+                    acc[mt][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[mt][s]), bw[s][ni], acc[mt][ni], 0, 0, 0);
+            }
+        // epilogue: lane holds channel ni * 32 + li of pixels row(r); pairs of lanes exchange one value and store one dword per pixel pair
+        auto epilogue = [&](auto add_tag) __attribute__((always_inline)) {
+            constexpr bool ADD = decltype(add_tag)::value;
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt) {
+                float s1[C::NT][2], s2[C::NT][2];
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni) { s1[ni][0] = s1[ni][1] = 0.f; s2[ni][0] = s2[ni][1] = 0.f; }
+                const long long pb0 = (blk0 + mt) * 32;
+                unsigned oldw[8][C::NT];
+                if (ADD) {
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const long long p = pb0 + rcf_mfma_row(2 * g, lh) + odd;
+#pragma unroll
+                        for (int ni = 0; ni < C::NT; ++ni) {
+                            const int cp = (ni * 32 + li) & ~1;
+                            oldw[g][ni] = *reinterpret_cast<const unsigned*>(outp + ((p < npix && cp < a.c_out) ? (size_t)p * a.c_out + cp : 0));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const int rj = 2 * g;                                    // accumulator rows rj, rj + 1 are consecutive pixels
+                    const long long p = pb0 + rcf_mfma_row(rj, lh) + odd;   // the pixel this lane stores
+#pragma unroll
+                    for (int ni = 0; ni < C::NT; ++ni) {
+                        const int cp = (ni * 32 + li) & ~1;
+                        const bool ok = p < npix && cp < a.c_out;
+                        const float a0 = acc[mt][ni][rj], a1 = acc[mt][ni][rj + 1];
+                        const float mine = odd ? a1 : a0, give = odd ? a0 : a1;
+                        const float got = __uint_as_float(rcf_dpp_u32<0xB1>(__float_as_uint(give)));
+                        float lo = odd ? got : mine, hi = odd ? mine : got;
+                        if (ADD) {
+                            lo += __uint_as_float(oldw[g][ni] << 16);
+                            hi += __uint_as_float(oldw[g][ni] & 0xffff0000u);
+                        }
+                        const unsigned blo = rcf_f2b(lo), bhi = rcf_f2b(hi);
+                        if (ok) {
+                            *reinterpret_cast<unsigned*>(outp + (size_t)p * a.c_out + cp) = blo | (bhi << 16);
+                            if (want_stats) {
+                                const float rlo = rcf_b2f(blo), rhi = rcf_b2f(bhi);
+                                s1[ni][0] += rlo; s2[ni][0] += rlo * rlo;
+                                s1[ni][1] += rhi; s2[ni][1] += rhi * rhi;
+                            }
+                        }
+                    }
+                }
+                if (want_stats) {
+#pragma unroll
+                    for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) { st1[ni][e] += (double)s1[ni][e]; st2[ni][e] += (double)s2[ni][e]; }
+                }
+            }
+        };
+        if (a.accumulate) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
+    }
+    if (want_stats) {
+        __shared__ double red[4 * 32 * C::NT * 2];
+#pragma unroll
+        for (int ni = 0; ni < C::NT; ++ni) {
+            const double a10 = st1[ni][0], a11 = st1[ni][1], a20 = st2[ni][0], a21 = st2[ni][1];
+            const double t10 = a10 + __shfl_xor(a10, 1), t11 = a11 + __shfl_xor(a11, 1);
+            const double t20 = a20 + __shfl_xor(a20, 1), t21 = a21 + __shfl_xor(a21, 1);
+            double t1 = (li & 1) ? t11 : t10, t2 = (li & 1) ? t21 : t20;
+            t1 += __shfl_xor(t1, 32);
+            t2 += __shfl_xor(t2, 32);
+            if (lh == 0) {
+                red[((wave * C::NT + ni) * 32 + li) * 2 + 0] = t1;
+                red[((wave * C::NT + ni) * 32 + li) * 2 + 1] = t2;
+            }
+        }
+        __syncthreads();
+        if (tid < 32 * C::NT && tid < a.c_out) {
+            double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                t1 += red[((w * C::NT + tid / 32) * 32 + (tid & 31)) * 2 + 0];
+                t2 += red[((w * C::NT + tid / 32) * 32 + (tid & 31)) * 2 + 1];
+            }
+            a.stats[((size_t)blockIdx.x * 2 + 0) * a.c_out + tid] = t1;
+            a.stats[((size_t)blockIdx.x * 2 + 1) * a.c_out + tid] = t2;
+        }
+    }
+}
+
+// grid of the pointwise kernel = number of BatchNorm partial rows it writes
+inline int pw_grid(long long npix, int nt) {
+    const int per_trip = 32 * 4 * (nt <= 2 ? 4 : 2);                   // 4 waves x MT blocks of 32 pixels per workgroup trip
+    const long long trips = (npix + per_trip - 1) / per_trip;
+    long long g = 2 * (long long)num_cus() * 2;                        // two workgroups per CU, two trips' worth of slack
+    if (g > trips) g = trips;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+template <class C>
+int launch_pw(const ConvArgs& a, hipStream_t st) {
+    const int g = pw_grid((long long)a.n * a.h_out * a.w_out, C::NT);
+    hipLaunchKernelGGL((conv1x1_b16_kernel<C>), dim3(g), dim3(256), 0, st, a);
+    return rcf_launch_status();
+}
+
+template <class F>
+int dispatch_pw(int kst, int nt, F&& f) {
+#define RCF_PW(K, N) if (kst == K && nt == N) return f(PwCfg<K, N>{})
+    RCF_PW(1, 1); RCF_PW(1, 2); RCF_PW(1, 3); RCF_PW(1, 4);
+    RCF_PW(2, 1); RCF_PW(2, 2); RCF_PW(2, 3); RCF_PW(2, 4);
+    RCF_PW(3, 1); RCF_PW(3, 2);
+    RCF_PW(4, 1); RCF_PW(4, 2); RCF_PW(4, 3); RCF_PW(4, 4);
+#undef RCF_PW
+    return RCF_EUNSUPPORTED;
+}

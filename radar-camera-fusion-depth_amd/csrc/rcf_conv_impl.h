@@ -1796,6 +1796,7 @@ struct Sel {
     int small;   // split 3x3 layer too small to fill the chip with 64-co workgroups: 256-pixel x 32-co workgroups instead
     int bf16;    // rcf_conv_desc.precision == RCF_PREC_BF16 and a split kernel: one bf16 plane, one product
     int dma;     // bf16 tensors, channel counts multiples of 16: conv_b16_kernel (operands reach LDS by DMA, rcf_conv_b16_dma.h)
+    int pw;      // bf16 tensors, 1x1, <= 64 input and <= 128 output channels: conv1x1_b16_kernel (operands straight from global memory)
 };
 
 int num_cus() {
@@ -2120,6 +2121,20 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     s->small = 0;
     s->bf16 = 0;
     s->dma = 0;
+    s->pw = 0;
+#if RCF_CONV_B16
+    {
+        const char* e = getenv("RCF_B16_PW");
+        if (s->kind == K1 && d->precision == RCF_PREC_BF16 && d->c2 == 0 && d->c1 % 16 == 0 && d->c1 <= 64 && d->c_out <= 128 &&
+            d->gather1 == RCF_GATHER_DIRECT && d->out_stride == 1 && (d->w_mode == RCF_W_FORWARD || d->stride == 1) &&
+            (e == nullptr || e[0] != '0')) {
+            s->pw = 1; s->split = 1; s->bf16 = 1; s->ck = 16; s->cst = 16;
+            s->nt = ceil_div(d->c_out, 32);
+            s->px = 32; s->th = 8; s->bn = 32 * s->nt;
+            return RCF_OK;
+        }
+    }
+#endif
     const bool s2_split = s->kind == K3S2 && cmax >= 16 && d->w_mode == RCF_W_FORWARD && d->gather1 == RCF_GATHER_DIRECT && d->c2 == 0 &&
                           d->out_stride == 1 && s2_split_enabled(d);
     if (((s->kind == K3S1 && s->ck == 16) || (s->kind == K2S1 && cmax >= 16) || s2_split) && (d->c1 % 4 == 0) && (d->c2 % 4 == 0) &&
@@ -2400,7 +2415,8 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
     info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * s.ck;
     if (s.split) info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.bf16 ? 8 : 24);   // 16 bf16 x planes per row
 #if RCF_CONV_B16
-    if (s.dma) info->n_partials = dispatch_dma(s, [&](auto tag) { return dma_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
+    if (s.pw) info->n_partials = pw_grid((long long)d->n * d->h_out * d->w_out, s.nt);
+    else if (s.dma) info->n_partials = dispatch_dma(s, [&](auto tag) { return dma_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
     else
 #endif
     info->n_partials = s.split ? dispatch_split(s, [&](auto tag) { return split_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); })
@@ -2409,9 +2425,9 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
     info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0) + (s.small ? 5 : 0) + (s.bf16 ? 20000 : 0);
     info->wgrad_workspace_floats = 0;
     info->wgrad_kernel_id = 0;
-    info->bn_on_load = (s.split && !s.dma && d->w_mode == RCF_W_FORWARD && d->c1 + d->c2 <= 512) ? 1 : 0;   // a DMA cannot transform
+    info->bn_on_load = (s.split && !s.dma && !s.pw && d->w_mode == RCF_W_FORWARD && d->c1 + d->c2 <= 512) ? 1 : 0;   // a DMA cannot transform
     info->wgrad_bn_on_load = 0;
-    info->fwd_act = (s.split && d->w_mode == RCF_W_FORWARD && !d->accumulate) ? 1 : 0;
+    info->fwd_act = (s.split && !s.pw && d->w_mode == RCF_W_FORWARD && !d->accumulate) ? 1 : 0;
     if (d->w_mode == RCF_W_FORWARD) {
         WSel w;
         if (select_wgrad(d, &w) == RCF_OK) {
@@ -2482,6 +2498,10 @@ static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float
     const int nn = ceil_div(d->c_out, s.bn);
     a.wp_phase_stride = (int)((size_t)nn * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.split ? (s.bf16 ? 8 : 24) : s.ck));
 #if RCF_CONV_B16
+    if (s.pw) {
+        if (coef1 || coef2) return RCF_EUNSUPPORTED;
+        return dispatch_pw(d->c1 / 16, s.nt, [&](auto cfg) { return launch_pw<decltype(cfg)>(a, (hipStream_t)stream); });
+    }
     if (s.dma && !coef1 && !coef2)
         return dispatch_dma(s, [&](auto tag) { return launch_dma<typename decltype(tag)::type, false>(a, nn, (hipStream_t)stream); });
     if (s.dma) return RCF_EUNSUPPORTED;   // rcf_conv_info.bn_on_load is 0 for these descriptors (the tile geometry differs)
@@ -2503,7 +2523,7 @@ extern "C" int RCF_FN(rcf_conv2d_fwd_act)(const rcf_conv_desc* d, const void* in
     int rc = select_cfg(d, &s);
     if (rc != RCF_OK) return rc;
     if (d->c2 > 0 && !in2) return RCF_EINVAL;
-    if (!s.split || d->w_mode != RCF_W_FORWARD || d->accumulate) return RCF_EUNSUPPORTED;   // rcf_conv_info.fwd_act
+    if (!s.split || s.pw || d->w_mode != RCF_W_FORWARD || d->accumulate) return RCF_EUNSUPPORTED;   // rcf_conv_info.fwd_act
     ConvArgs a;
     fill_args(d, s, &a);
     a.bias = bias; a.res = res;
