@@ -115,7 +115,7 @@ def test_conv_forward_bf16_tensors(ops, case):
     d = _desc(ops, case)
     assert d.storage == 1
     info = ops.conv_query(d)
-    split = (info.kernel_id % 20000) // 1000 in (5, 6, 9)
+    split = (info.kernel_id % 20000) // 1000 in (5, 6, 7, 9)
     ref = _ref(case, x1, x2, wt, operands_bf16=split)     # f32-MFMA kernels (1x1, stride 2, stems, tiny) keep fp32 operands
     packed = torch.empty(info.packed_weight_floats, device='cuda')
     ops.conv_pack(d, wt.cuda(), packed)
@@ -148,7 +148,7 @@ def test_conv_input_gradient_bf16_tensors(ops, case):
         for accumulate in (False, True):
             dd = ops.make_dgrad_desc(d, off, cnt, accumulate and not (src is x1 and up is not None))
             info = ops.conv_query(dd)
-            split = (info.kernel_id % 20000) // 1000 in (5, 6, 9)
+            split = (info.kernel_id % 20000) // 1000 in (5, 6, 7, 9)
             wq = b16(wt) if split else wt
             xs = torch.zeros(n, c1 + c2, h, w, dtype=torch.double, requires_grad=True)
             (F.conv2d(xs, wq.double(), stride=s, padding=k // 2) * dz.double()).sum().backward()
