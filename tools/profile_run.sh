@@ -14,7 +14,7 @@ python3 bench.py --workload infer --dtype f32 --steps 10 --warmup 3 > $out/bench
 python3 bench.py --workload radarnet --dtype f32 --steps 10 --warmup 3 > $out/bench_radarnet_f32.log 2>&1
 # eager launches under the profiler (a replayed hipGraph hides the per-launch events bench.py's roofline uses)
 rocprofv3 --kernel-trace --stats -d /tmp/trace_$tag -o r -- python3 bench.py --graph 0 --steps 5 --warmup 3 --preheat-s 0 --no-cpu-baseline > $out/trace.log 2>&1
-tail -1 $out/trace.log > $out/trace_bench_line.json
+grep "^{" $out/trace.log | tail -1 > $out/trace_bench_line.json
 python3 tools/trace_summary.py /tmp/trace_$tag 8 60 > $out/fp32_train_kernels.txt
 rocprofv3 --kernel-trace --stats -d /tmp/trace_b16_$tag -o r -- python3 bench.py --dtype bf16 --graph 0 --steps 5 --warmup 3 --preheat-s 0 --no-cpu-baseline > $out/trace_b16.log 2>&1
 python3 tools/trace_summary.py /tmp/trace_b16_$tag 8 60 > $out/bf16_train_kernels.txt
