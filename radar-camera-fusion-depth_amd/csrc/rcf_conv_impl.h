@@ -1348,7 +1348,13 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
         }
     }
     unsigned mx[C::RX];   // BN-on-load only: bit j = pixel j of the unit is real data (padding must stay 0 after the transform)
-    f32x4 rx[C::RX][8], rd[C::RD][8];
+    // staging registers: fp32 tensors -> 4 channels as f32x4; bf16 tensors -> the same 4 channels RAW (two dwords: half the
+    // registers, no conversion; the transpose below picks 16-bit halves with one v_perm per pixel pair)
+    constexpr bool RAWX = SX::B16, RAWD = SD::B16;
+    using RXT = std::conditional_t<RAWX, u32x2, f32x4>;
+    using RDT = std::conditional_t<RAWD, u32x2, f32x4>;
+    RXT rx[C::RX][8];
+    RDT rd[C::RD][8];
     // loads are branch-free: padding / out-of-image / out-of-range-channel elements read a zero page (rcf_zero_page), so the values need
     // no masking afterwards
     // FAST (compile-time): plain layers -- source read as is, one image per tile, unit output stride -- address their pixels with an
@@ -1397,7 +1403,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                     px = 2 * lx + a.iox;
                     ok = ok && px < ws;
                 }
-                rx[i][j] = rcf_ld4<SX>(ok ? rcf_at<SX>(rowptr, px * csrc) : rcf_zero_page, 0);
+                if constexpr (RAWX) rx[i][j] = *reinterpret_cast<const u32x2*>(ok ? rcf_at<SX>(rowptr, px * csrc) : rcf_zero_page);
+                else rx[i][j] = rcf_ld4<SX>(ok ? rcf_at<SX>(rowptr, px * csrc) : rcf_zero_page, 0);
                 if (cfx != nullptr) m |= ok ? (1u << j) : 0u;
             }
             mx[i] = m;
@@ -1421,7 +1428,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             for (int j = 0; j < 8; ++j) {
                 const int ox = ox0 + 8 * g + j;
                 const int px = FAST ? ox : ox * a.os + a.oox;
-                rd[i][j] = rcf_ld4<SD>((rowok && ox < a.w_out && px < a.owp) ? rcf_at<SD>(rowptr, px * a.c_out) : rcf_zero_page, 0);
+                if constexpr (RAWD) rd[i][j] = *reinterpret_cast<const u32x2*>((rowok && ox < a.w_out && px < a.owp) ? rcf_at<SD>(rowptr, px * a.c_out) : rcf_zero_page);
+                else rd[i][j] = rcf_ld4<SD>((rowok && ox < a.w_out && px < a.owp) ? rcf_at<SD>(rowptr, px * a.c_out) : rcf_zero_page, 0);
             }
         }
     };
@@ -1431,6 +1439,14 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
         else load_tile_impl(tile, std::false_type{});
     };
     // 8 pixels of one channel -> three 16-B bf16 vectors (exact truncation split), written to the channel's LDS row
+    // bf16 tensors: 8 pixels of channel e (raw dwords e >> 1, half e & 1) -> one 16-B vector of the channel's LDS row
+    auto pack8 = [&](const u32x2 (&v)[8], int e, unsigned char* dst) {
+        u32x4 w0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            w0[d] = __builtin_amdgcn_perm(v[2 * d + 1][e >> 1], v[2 * d][e >> 1], (e & 1) ? 0x07060302u : 0x05040100u);
+        *reinterpret_cast<u32x4*>(dst) = w0;
+    };
     auto split8 = [&](const f32x4 (&v)[8], int e, unsigned char* dst, int plane_bytes) {
         u32x4 w0, w1, w2;
 #pragma unroll
@@ -1465,6 +1481,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             const int u = tid + 256 * i;
             if (C::NXU % 256 == 0 || u < C::NXU) {
                 const int cq = u % C::CQX, g = (u / C::CQX) % 3, hy = u / (3 * C::CQX);
+                if constexpr (!RAWX)
                 if (cfx != nullptr) {   // the producer's BatchNorm + LeakyReLU on the 8 x 4 values; padding stays zero
                     const f32x4 sc = *reinterpret_cast<const f32x4*>(coef_lds + cq * 4);
                     const f32x4 sh = *reinterpret_cast<const f32x4*>(coef_lds + C::NCI + cq * 4);
@@ -1476,7 +1493,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    split8(rx[i], e, Xs + (e * C::CQX + cq) * C::SX + hy * C::XROW + g * 16, C::XPL);
+                    if constexpr (RAWX) pack8(rx[i], e, Xs + (e * C::CQX + cq) * C::SX + hy * C::XROW + g * 16);
+                    else split8(rx[i], e, Xs + (e * C::CQX + cq) * C::SX + hy * C::XROW + g * 16, C::XPL);
             }
         }
 #pragma unroll
@@ -1486,7 +1504,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 const int cq = u % C::CQD, g = (u / C::CQD) % 2, r = u / (2 * C::CQD);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    split8(rd[i], e, Ds + (e * C::CQD + cq) * C::SD + r * C::DROW + g * 16, C::DPL);
+                    if constexpr (RAWD) pack8(rd[i], e, Ds + (e * C::CQD + cq) * C::SD + r * C::DROW + g * 16);
+                    else split8(rd[i], e, Ds + (e * C::CQD + cq) * C::SD + r * C::DROW + g * 16, C::DPL);
             }
         }
     };
@@ -2311,7 +2330,8 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
         w->wco = d->c_out > 32 ? 2 : 1;
         w->wci = (d->c1 % 64 == 0 && d->c2 % 64 == 0) ? 2 : 1;
     }
-    const int th_split = (w->wci == 1 && w->wco == 1) ? 16 : 8;
+    // rows per tile: bf16 tensors stage raw (half the registers) and their MFMA phase is 6x shorter: twice the rows per barrier pair
+    const int th_split = ((w->wci == 1 && w->wco == 1) || SAct::B16) ? 16 : 8;
     double best = -1.0;
     const int pxs[3] = {32, 16, 8}, ths[3] = {th32, w->split ? th_split : th16, 32};
     for (int i = 0; i < 3; ++i) {
@@ -2432,7 +2452,7 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
         WSel w;
         if (select_wgrad(d, &w) == RCF_OK) {
             info->wgrad_workspace_floats = (size_t)w.nsplit * w.ktot * w.cop + 64;   // + a zero page for the DMA path
-            info->wgrad_bn_on_load = w.split ? 1 : 0;
+            info->wgrad_bn_on_load = (w.split && !SAct::B16) ? 1 : 0;   // bf16 tensors are staged raw: nothing to apply BatchNorm to
             info->wgrad_kernel_id = 10000 + w.kind * 1000 + (w.px == 16 ? 100 : (w.px == 8 ? 200 : 0)) + (w.vt ? 400 : 0) +
                                     (w.split ? 5000 + w.wci * 10 + w.wco : 0) + ((w.split && d->precision == RCF_PREC_BF16) ? 20000 : 0);
         }
@@ -2559,7 +2579,7 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
     int rc = select_wgrad(d, &w);
     if (rc != RCF_OK) return rc;
     if (d->c2 > 0 && !in2) return RCF_EINVAL;
-    if ((coef1 || coef2) && (!w.split || (coef2 && d->c2 == 0))) return RCF_EUNSUPPORTED;
+    if ((coef1 || coef2) && (!w.split || SAct::B16 || (coef2 && d->c2 == 0))) return RCF_EUNSUPPORTED;
     ConvArgs a;
     a.bias = nullptr; a.res = nullptr;
     a.coef1 = coef1; a.coef2 = coef2;
@@ -2587,14 +2607,15 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
         a.nchunk2 = d->c2 > 0 ? ceil_div(d->c2, 32 * w.wci) : 0;
         const int cfg = w.wci * 10 + w.wco;
         if (d->precision == RCF_PREC_BF16) {
+            constexpr int THB = SAct::B16 ? 16 : 8;   // tile rows (select_wgrad: th_split)
             if (w.kind == K2S1) {
-                if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2, 2, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
-                else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2, 2, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
-                else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 2, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
+                if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2, 2, THB, 1>>(a, w.nsplit, w.gy, w.gz, st);
+                else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2, 2, THB, 1>>(a, w.nsplit, w.gy, w.gz, st);
+                else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 2, THB, 1>>(a, w.nsplit, w.gy, w.gz, st);
                 else rc = launch_wgrad_split<WsCfg<1, 1, 2, 16, 1>>(a, w.nsplit, w.gy, w.gz, st);
-            } else if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2, 3, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
-            else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2, 3, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
-            else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 3, 8, 1>>(a, w.nsplit, w.gy, w.gz, st);
+            } else if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2, 3, THB, 1>>(a, w.nsplit, w.gy, w.gz, st);
+            else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2, 3, THB, 1>>(a, w.nsplit, w.gy, w.gz, st);
+            else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 3, THB, 1>>(a, w.nsplit, w.gy, w.gz, st);
             else rc = launch_wgrad_split<WsCfg<1, 1, 3, 16, 1>>(a, w.nsplit, w.gy, w.gz, st);
         } else if constexpr (!SAct::B16) {
         if (w.kind == K2S1) {
