@@ -436,3 +436,25 @@ def test_stem_as_4x4_convolution_on_the_space_to_depth_image(ops, c, co, n, h, w
     assert tuple(nchw(out).shape) == tuple(ref.shape)
     nbad, e = close_bf16(nchw(out), ref, slack=1.01)
     assert nbad <= max(2, out.numel() // 2000) and e < 2 * BF16_EPS, (nbad, e)
+
+
+def test_bf16_training_trajectory_tracks_fp32(ops):
+    '''Ten Adam steps on one batch (published net, 128x192): the loss goes down in the bf16 configuration as it does in fp32 --
+    bf16 tensors + fp32 master weights / BatchNorm statistics / optimizer keep the optimisation on track (every step within 5 % of
+    the fp32 run's loss, the same overall decrease).'''
+    from rcf_amd import synth, train
+    cb = synth.make_batch(2, 128, 192, 16, seed=5)
+    b = {k: v.cuda() for k, v in cb.items()}
+    traj = {}
+    for mode in ('fp32', 'bf16'):
+        m = train.build_model(synth.PUBLISHED, device='cuda')
+        synth.fill_state_dict_([m.encoder, m.decoder], 3)
+        m.compute_dtype = mode
+        opt = train.make_optimizer(m, lr=1e-3)
+        m.train()
+        traj[mode] = [float(train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])[0].detach())
+                      for _ in range(10)]
+    f, h = np.array(traj['fp32']), np.array(traj['bf16'])
+    print('loss fp32 %s\nloss bf16 %s' % (np.round(f, 3), np.round(h, 3)))
+    assert f[-1] < 0.8 * f[0] and h[-1] < 0.8 * h[0]
+    assert np.max(np.abs(h - f) / f) < 0.05
