@@ -1360,18 +1360,17 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
     // FAST (compile-time): plain layers -- source read as is, one image per tile, unit output stride -- address their pixels with an
     // add and a compare each; the general path (nearest-upsample gather, virtual tall image, strided phase outputs) costs ~3x the
     // VALU instructions per load, and a VALU wave-instruction costs about a fifth of an MFMA in energy (these kernels are power-limited)
-    // The loads of a tile are numbered L = 8 i + j (x units first, then the dz units); [lo, hi) selects a slice of them, so the tile
-    // loop can issue them a few at a time between the MFMA steps of the previous tile.  Issued as one block in front of the MFMA
-    // loop they are NOT hidden: with one wave per SIMD the wave sits in the issue until the memory system has accepted every request
-    // (all 256 workgroups ask at once -- 35 MB per round), which measured 20-34 % of the wave time with fp32 tensors and 45-63 % with
-    // bf16 tensors (tools/phase_timing_wgrad.py).  After unrolling lo / hi are constants and the slice tests fold away.
-    constexpr int NLX = C::RX * 8, NLOADS = (C::RX + C::RD) * 8;
-    auto load_tile_impl = [&](int img, int oy0, int ox0, auto fast_tag, int lo, int hi) __attribute__((always_inline)) {
+    auto load_tile_impl = [&](int tile, auto fast_tag) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fast_tag)::value;
+        int t = tile;
+        const int tx = t % a.tiles_x;
+        t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        const int img = t / a.tiles_y;
+        const int oy0 = ty * C::TH, ox0 = tx * C::PX;
         const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad_x;
 #pragma unroll
         for (int i = 0; i < C::RX; ++i) {
-            if (!(8 * i < hi && 8 * i + 8 > lo)) continue;
             const int u = tid + 256 * i;
             const int cq = u % C::CQX, g = (u / C::CQX) % 3, hy = u / (3 * C::CQX);
             const int ch = cb + cq * 4;
@@ -1396,7 +1395,6 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             unsigned m = 0u;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                if (!(8 * i + j >= lo && 8 * i + j < hi)) continue;
                 const int hx = 8 * g + j;
                 const int lx = ix0 + hx;
                 bool ok = rowok && hx < C::HXP && (unsigned)lx < (unsigned)a.w_in;
@@ -1409,11 +1407,10 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 else rx[i][j] = rcf_ld4<SX>(ok ? rcf_at<SX>(rowptr, px * csrc) : rcf_zero_page, 0);
                 if (cfx != nullptr) m |= ok ? (1u << j) : 0u;
             }
-            mx[i] |= m;   // zeroed by the caller before the tile's first slice
+            mx[i] = m;
         }
 #pragma unroll
         for (int i = 0; i < C::RD; ++i) {
-            if (!(NLX + 8 * i < hi && NLX + 8 * i + 8 > lo)) continue;
             const int u = tid + 256 * i;
             const int cq = u % C::CQD, g = (u / C::CQD) % 2, r = u / (2 * C::CQD);
             const int dc = co0 + cq * 4;
@@ -1429,7 +1426,6 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             const float* rowptr = rcf_at<SD>(a.dz, (size_t)(rowok ? (im * a.ohp + py) * a.owp : 0) * a.c_out + (rowok ? dc : 0));
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                if (!(NLX + 8 * i + j >= lo && NLX + 8 * i + j < hi)) continue;
                 const int ox = ox0 + 8 * g + j;
                 const int px = FAST ? ox : ox * a.os + a.oox;
                 if constexpr (RAWD) rd[i][j] = *reinterpret_cast<const u32x2*>((rowok && ox < a.w_out && px < a.owp) ? rcf_at<SD>(rowptr, px * a.c_out) : rcf_zero_page);
@@ -1438,21 +1434,9 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
         }
     };
     const bool plain_tile = gmode == RCF_GATHER_DIRECT && !a.vt && a.os == 1 && a.ooy == 0 && a.oox == 0;
-    int lt_img = 0, lt_oy0 = 0, lt_ox0 = 0;   // origin of the tile whose loads are being issued
-    auto tile_origin = [&](int tile) __attribute__((always_inline)) {
-        int t = tile;
-        const int tx = t % a.tiles_x;
-        t /= a.tiles_x;
-        const int ty = t % a.tiles_y;
-        lt_img = t / a.tiles_y;
-        lt_oy0 = ty * C::TH;
-        lt_ox0 = tx * C::PX;
-#pragma unroll
-        for (int i = 0; i < C::RX; ++i) mx[i] = 0u;
-    };
-    auto load_slice = [&](int lo, int hi) __attribute__((always_inline)) {
-        if (plain_tile) load_tile_impl(lt_img, lt_oy0, lt_ox0, std::true_type{}, lo, hi);
-        else load_tile_impl(lt_img, lt_oy0, lt_ox0, std::false_type{}, lo, hi);
+    auto load_tile = [&](int tile) __attribute__((always_inline)) {
+        if (plain_tile) load_tile_impl(tile, std::true_type{});
+        else load_tile_impl(tile, std::false_type{});
     };
     // 8 pixels of one channel -> three 16-B bf16 vectors (exact truncation split), written to the channel's LDS row
     // bf16 tensors: 8 pixels of channel e (raw dwords e >> 1, half e & 1) -> one 16-B vector of the channel's LDS row
@@ -1545,30 +1529,13 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
     u32x4 xs1[KS][NPL];        // kx = 1 operands of the current step
 
     int tile = blockIdx.x;
-#ifdef RCF_PHASE_TIMING
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-#endif
-    if (tile < a.ntiles) {
-        tile_origin(tile);
-        load_slice(0, NLOADS);
-    }
+    if (tile < a.ntiles) load_tile(tile);
     while (tile < a.ntiles) {
-        RCF_T(t_g0);
         __syncthreads();   // the previous tile's MFMAs are done with LDS
-        RCF_T(t_g1);
-        RCF_TACC(0, t_g1, t_g0);   // 0: barrier "LDS free"
         store_tile();
-        RCF_T(t_g2);
-        RCF_TACC(1, t_g2, t_g1);   // 1: wait for the tile's global loads + transpose into LDS
         __syncthreads();
-        RCF_T(t_g3);
-        RCF_TACC(2, t_g3, t_g2);   // 2: publishing barrier
         const int ntile = tile + gridDim.x;
-        const bool more = ntile < a.ntiles;
-        if (more) tile_origin(ntile);   // its loads go out in slices between the MFMA steps below
-        RCF_T(t_g4);
-        RCF_TACC(3, t_g4, t_g3);   // 3: address arithmetic + global-load issue of the next tile
+        if (ntile < a.ntiles) load_tile(ntile);
 
         // prologue of the tile: operands of this wave's first row
 #pragma unroll
@@ -1584,12 +1551,6 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
 
 #pragma unroll
         for (int s = 0; s < C::NS; ++s) {
-            {   // this step's share of the next tile's global loads, ahead of the step's MFMAs
-                constexpr int LPS = (NLOADS + C::NS - 1) / C::NS;
-                const int lo = s * LPS, hi = (s + 1) * LPS < NLOADS ? (s + 1) * LPS : NLOADS;
-                if (more && lo < hi) load_slice(lo, hi);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             const int cur = s & 1, nxt = cur ^ 1;
             const bool has_next = s + 1 < C::NS;
             const int rn = (s + 1) * C::KSPLIT;   // next row of this wave (relative to wk)
@@ -1649,13 +1610,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        RCF_T(t_g5);
-        RCF_TACC(4, t_g5, t_g4);   // 4: MFMA steps (+ interleaved LDS reads, operand shifts)
         tile = ntile;
     }
-#ifdef RCF_PHASE_TIMING
-    const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
-#endif
 
     // ---- sum the KSPLIT row slices of each (wi, wj) block through LDS (fixed order), then one partial per workgroup
     if (C::KSPLIT > 1) {
@@ -1694,12 +1650,6 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 }
             }
     }
-#ifdef RCF_PHASE_TIMING
-    tacc[5] = __builtin_amdgcn_s_memtime() - t_loop;   // 5: slice reduction + partial write
-    tacc[7] = __builtin_amdgcn_s_memtime() - t_begin;
-    if (lane == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&rcf_phase_cycles[i], tacc[i]);
-#endif
 }
 
 // workspace [nslot][ktot][cop] -> dW in OIHW.  One thread per (k, co), co fastest (coalesced reads).
