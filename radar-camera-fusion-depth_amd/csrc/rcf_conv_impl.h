@@ -1529,13 +1529,28 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
     u32x4 xs1[KS][NPL];        // kx = 1 operands of the current step
 
     int tile = blockIdx.x;
+#ifdef RCF_PHASE_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     if (tile < a.ntiles) load_tile(tile);
     while (tile < a.ntiles) {
+        RCF_T(t_g0);
         __syncthreads();   // the previous tile's MFMAs are done with LDS
+        RCF_T(t_g1);
+        RCF_TACC(0, t_g1, t_g0);   // 0: barrier "LDS free"
         store_tile();
+        RCF_T(t_g2);
+        RCF_TACC(1, t_g2, t_g1);   // 1: wait for the tile's global loads + transpose into LDS
         __syncthreads();
+        RCF_T(t_g3);
+        RCF_TACC(2, t_g3, t_g2);   // 2: publishing barrier
         const int ntile = tile + gridDim.x;
+        // (issuing these loads in slices between the MFMA steps below was tried and is NOT faster: the phase is bound by the
+        // address arithmetic of the ~50 loads, not by the memory system accepting them -- tools/phase_timing_wgrad.py)
         if (ntile < a.ntiles) load_tile(ntile);
+        RCF_T(t_g4);
+        RCF_TACC(3, t_g4, t_g3);   // 3: address arithmetic + global-load issue of the next tile
 
         // prologue of the tile: operands of this wave's first row
 #pragma unroll
@@ -1610,8 +1625,13 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        RCF_T(t_g5);
+        RCF_TACC(4, t_g5, t_g4);   // 4: MFMA steps (+ interleaved LDS reads, operand shifts)
         tile = ntile;
     }
+#ifdef RCF_PHASE_TIMING
+    const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- sum the KSPLIT row slices of each (wi, wj) block through LDS (fixed order), then one partial per workgroup
     if (C::KSPLIT > 1) {
@@ -1650,6 +1670,12 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 }
             }
     }
+#ifdef RCF_PHASE_TIMING
+    tacc[5] = __builtin_amdgcn_s_memtime() - t_loop;   // 5: slice reduction + partial write
+    tacc[7] = __builtin_amdgcn_s_memtime() - t_begin;
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&rcf_phase_cycles[i], tacc[i]);
+#endif
 }
 
 // workspace [nslot][ktot][cop] -> dW in OIHW.  One thread per (k, co), co fastest (coalesced reads).
@@ -2295,6 +2321,18 @@ int dispatch_split(const Sel& s, F&& f) {
     return RCF_EUNSUPPORTED;
 }
 
+// The split weight-gradient kernel addresses a virtual-tall tile through its general path (~3x the address arithmetic per load of
+// the plain path, and that arithmetic is 20-60 % of its wave time: tools/phase_timing_wgrad.py), so the virtual-tall tiling must
+// win more than a few per cent of tile utilisation to pay: its utilisation is discounted by this factor (RCF_WGRAD_VT_BIAS to tune).
+double wgrad_vt_bias(int split) {
+    static double bias = -1.0;
+    if (bias < 0.0) {
+        const char* e = getenv("RCF_WGRAD_VT_BIAS");
+        bias = e ? atof(e) : 0.8;
+    }
+    return split ? bias : 1.0;
+}
+
 // wgrad tiling for the forward descriptor
 struct WSel { int kind, px, th, t, cst, nchunk1, nchunk2, ncog, nsplit, ktot, cop, tiles_x, tiles_y, ntiles, vt, split, wci, wco, gy, gz; };
 
@@ -2339,7 +2377,7 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
         if (pxs[i] == 8 && (SAct::B16 || !(w->kind == K3S1 && dma_ok))) continue;
         for (int vt = 0; vt <= (vt_ok ? 1 : 0); ++vt) {
             const double e = vt ? tile_eff_vt(d->w_out, d->h_out, d->n, pxs[i], ths[i]) : tile_eff(d->w_out, d->h_out, pxs[i], ths[i]);
-            if (e > best + 1e-9) { best = e; w->px = pxs[i]; w->th = ths[i]; w->vt = vt; }
+            if (e * (vt ? wgrad_vt_bias(w->split) : 1.0) > best + 1e-9) { best = e * (vt ? wgrad_vt_bias(w->split) : 1.0); w->px = pxs[i]; w->th = ths[i]; w->vt = vt; }
         }
     }
     w->tiles_x = ceil_div(d->w_out, w->px);
