@@ -64,8 +64,10 @@ def parse():
     ap.add_argument('--height', type=int, default=900)
     ap.add_argument('--width', type=int, default=1600)
     ap.add_argument('--points', type=int, default=64)
-    ap.add_argument('--dtype', choices=('f32', 'bf16'), default=None,
-                    help='f32: the reference arithmetic (the metric; default for train).  bf16: bf16 tensors in HBM and bf16 MFMA '
+    ap.add_argument('--dtype', choices=('f32', 'f32x3', 'bf16'), default=None,
+                    help='f32: the reference arithmetic (the metric; default for train).  f32x3 (train only): fp32 tensors, the split '
+                         'convolution kernels on two bf16 planes / three products per multiply (16-17 significant bits, errors ~1e-5: '
+                         'inside north_star\'s 1e-3, NOT exact fp32 -- reported beside the metric, never as it).  bf16: bf16 tensors in HBM and bf16 MFMA '
                          'operands, fp32 accumulate / master weights / BatchNorm statistics (BASELINE.json configs 2-4; default for '
                          'infer and radarnet)')
     ap.add_argument('--preheat-s', type=float, default=4.0,
@@ -211,6 +213,8 @@ def run_rank(args):
     dev = torch.device('cuda', local_rank if (world > 1 and not single_dev) else 0)
     torch.cuda.set_device(dev)
     if args.workload != 'train':
+        if args.dtype == 'f32x3':
+            raise SystemExit('--dtype f32x3 is a training leg')
         if world > 1:
             raise SystemExit('--workload %s is a single-GPU leg' % args.workload)
         return run_infer(args, dev) if args.workload == 'infer' else run_radarnet(args, dev)
@@ -219,7 +223,7 @@ def run_rank(args):
 
     model = train.build_model(synth.PUBLISHED, device=dev)
     synth.fill_state_dict_([model.encoder, model.decoder], 1234)   # seeded U(+-1/sqrt(fan_in)) weights, identical on every rank
-    model.compute_dtype = 'bf16' if dtype == 'bf16' else 'fp32'
+    model.compute_dtype = {'bf16': 'bf16', 'f32x3': 'bf16x3'}.get(dtype, 'fp32')
     if world > 1:
         model.data_parallel()
     opt = train.make_optimizer(model, lr=1e-3)
@@ -297,7 +301,7 @@ def run_rank(args):
     # aggregate kernel ids (kind*1000 + ck*10 + nt [+100 for the 16x16 tile]; wgrad ids are 10000 + ...) by kernel family
     fam = {}
     for kid, (cnt, flops, ms) in table.items():
-        kid0 = kid - 20000 if kid >= 20000 else kid        # + 20000: bf16 variant of the same kernel family
+        kid0 = kid % 20000        # + 20000: bf16 variant of the same kernel family, + 40000: two-plane (bf16x3) variant
         f = (10 + (kid0 - 10000) // 1000) if kid0 >= 10000 else kid0 // 1000
         r = fam.setdefault(f, [0, 0.0, 0.0, 0.0])
         r[0] += cnt; r[1] += flops; r[2] += ms; r[3] += getattr(timer, 'bytes', {}).get(kid, 0.0)
@@ -324,9 +328,10 @@ def run_rank(args):
         'dtype': dtype,
         'data': 'synthetic',
         'config': {'workload': 'FusionNet %s training, per-GPU batch %d, %dx%d, %d-point radar maps (BASELINE.json %s)'
-                               % ('fp32' if dtype == 'f32' else 'bf16 (bf16 tensors in HBM + bf16 MFMA operands, fp32 accumulate / '
-                                  'master weights / BN statistics)', batch, args.height, args.width, args.points,
-                                  'configs[1]' if dtype == 'f32' else 'configs[3] on %d GPU(s)' % world),
+                               % ({'f32': 'fp32', 'f32x3': 'fp32-tensor / bf16x3-product (two bf16 planes, three products per multiply in the '
+                                   'split conv kernels: NOT exact fp32)'}.get(dtype, 'bf16 (bf16 tensors in HBM + bf16 MFMA operands, fp32 accumulate / '
+                                  'master weights / BN statistics)'), batch, args.height, args.width, args.points,
+                                  'configs[1]' if dtype in ('f32', 'f32x3') else 'configs[3] on %d GPU(s)' % world),
                    'global_batch': world * batch, 'parallelism': 'dp%d' % world,
                    'step': 'forward + outlier removal + masked L1 + backward + Adam, train-mode BatchNorm',
                    'launch': 'one hipGraph replay per step (bitwise the eager step)' if use_graph else (graph_note or 'eager launches'),
@@ -344,7 +349,7 @@ def run_rank(args):
     if is_headline and first_loss is not None:
         want = _expected_first_loss('train_b8_900x1600_p64')
         if want is not None:
-            tol = 1e-3 if dtype == 'f32' else 3e-2
+            tol = 3e-2 if dtype == 'bf16' else 1e-3
             relerr = abs(first_loss - want) / abs(want)
             loss_ok = relerr < tol
             rec['config']['loss_check'] = {'oracle_first_step_loss': round(want, 5), 'rel_err': float('%.3e' % relerr), 'tol': tol,
@@ -354,7 +359,7 @@ def run_rank(args):
         algorithmic = flops / (ms * 1e-3) / 1e12
         is_split = dom in (5, 9, 15, 19)
         # split kernels are bound by the bf16 matrix pipe: price them on the bf16 FLOPs they execute (6 per fp32 MAC)
-        achieved = algorithmic * ((1 if dtype == 'bf16' else SPLIT_PRODUCTS) if is_split else 1)
+        achieved = algorithmic * ({'bf16': 1, 'f32x3': 3}.get(dtype, SPLIT_PRODUCTS) if is_split else 1)
         peak = BF16_MFMA_PEAK_TFLOPS if is_split else F32_MFMA_PEAK_TFLOPS
         traffic, traffic_src = _pmc_traffic(KERNEL_NAMES.get(dom, ''))
         conv_ms = sum(r[2] for r in fam.values())
@@ -368,7 +373,8 @@ def run_rank(args):
             'useful_frac': round(algorithmic / peak, 4),
             'useful_frac_of_f32_mfma_peak': round(algorithmic / F32_MFMA_PEAK_TFLOPS, 4),
             'frac_of_power_limited_peak': round(achieved / BF16_MFMA_SUSTAINED_TFLOPS, 4) if is_split else None,
-            'pipe': ('bf16 MFMA, bf16 operands, fp32 accumulate' if dtype == 'bf16' else 'bf16 MFMA, 6 exact partial products per fp32 multiply, fp32 accumulate') if is_split else 'f32 MFMA',
+            'pipe': {'bf16': 'bf16 MFMA, bf16 operands, fp32 accumulate', 'f32x3': 'bf16 MFMA, 3 partial products of two-plane operands per multiply, fp32 accumulate'}.get(
+                dtype, 'bf16 MFMA, 6 exact partial products per fp32 multiply, fp32 accumulate') if is_split else 'f32 MFMA',
             'traffic': traffic, 'traffic_source': traffic_src,
             'algorithmic_gbytes_per_launch': round(abytes / cnt / 1e9, 4),
             'launches_per_step': cnt // ev_steps, 'avg_launch_ms': round(ms / cnt, 4),

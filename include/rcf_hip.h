@@ -56,6 +56,7 @@ extern "C" {
  * and source 1 may be gathered (nearest upsample / zero insert).  */
 #define RCF_PREC_FP32 0
 #define RCF_PREC_BF16 1
+#define RCF_PREC_BF16X3 2
 /* Storage of the NHWC activation / gradient tensors a call reads and writes. */
 #define RCF_STORE_FP32 0 /* fp32 tensors: the reference's configuration */
 #define RCF_STORE_BF16 1 /* bf16 tensors in HBM (BASELINE.json configs 2-4): bf16 storage and MFMA operands, fp32 accumulation; weights,
@@ -87,7 +88,10 @@ typedef struct rcf_conv_desc {
     int phase_sum;
     /* RCF_PREC_FP32 (0): fp32 results (the reference's arithmetic; f32 MFMA or the exact 3-plane bf16 split).
      * RCF_PREC_BF16 (1): operands rounded to bf16 (nearest even), fp32 accumulate; honoured by the split kernels, every other
-     * kernel keeps computing in fp32. */
+     * kernel keeps computing in fp32.
+     * RCF_PREC_BF16X3 (2), fp32 tensors only: each operand as TWO bf16 planes (16-17 significant bits), the three products
+     * a0*b0 + a0*b1 + a1*b0, fp32 accumulate -- errors of order 1e-5 of |a||b| (cuDNN's default TF32 convolutions keep 10 bits),
+     * half the matrix work of RCF_PREC_FP32 on the split kernels; every other kernel keeps computing in fp32. */
     int precision;
     /* RCF_STORE_FP32 / RCF_STORE_BF16: element type of in1, in2, out, res and dz (`const void*` below).  The two 7x7 stem
      * convolutions (c1 <= 4) always read an fp32 input -- the network input is never rounded -- and write `storage`. */

@@ -30,7 +30,7 @@ class ConvInfo(Structure):
                 ('bn_on_load', c_int), ('wgrad_bn_on_load', c_int), ('fwd_act', c_int)]
 
 
-RCF_PREC_FP32, RCF_PREC_BF16 = 0, 1
+RCF_PREC_FP32, RCF_PREC_BF16, RCF_PREC_BF16X3 = 0, 1, 2
 RCF_STORE_FP32, RCF_STORE_BF16 = 0, 1
 
 _P = c_void_p

@@ -432,11 +432,13 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // KERNEL ROW (KSX taps) at a time into a double-buffered LDS piece, so only the A tile needs the two-barrier hand-over.
 // NPL_ = 3: fp32 results (exact split, six partial products).  NPL_ = 1: rcf_conv_desc.precision == RCF_PREC_BF16 -- operands
 // rounded to bf16 (nearest even), ONE product, fp32 accumulate: the "bf16" configurations of BASELINE.json.
+// NPL_ = 2: RCF_PREC_BF16X3 -- two planes (the top 8 significant bits, then the remainder rounded to 8 more: 16-17 significant
+// bits per operand), the THREE products a0b0 + a0b1 + a1b0, fp32 accumulate: errors ~1e-5 of |a||b|, half the matrix work.
 // LSTEP_ = 2: stride-2 convolution -- the halo tile holds EVERY input pixel under the tile (a 3-tap kernel at stride 2 touches them
 // all) and neighbouring output pixels read halo pixels two apart; everything else (weights, epilogue) is the stride-1 kernel.
 template <int KS_, int NT_, int PX_, int MT_ = 0, int NPL_ = 3, int LSTEP_ = 1>
 struct SplitCfg {
-    static constexpr int NPL = NPL_, NP = NPL_ == 3 ? 6 : 1;   // operand planes, partial products per MAC
+    static constexpr int NPL = NPL_, NP = NPL_ == 3 ? 6 : (NPL_ == 2 ? 3 : 1);   // operand planes, partial products per MAC
     static constexpr int KSY = KS_, KSX = KS_, T = KS_ * KS_, LSTEP = LSTEP_, CK = 16, CST = 16;
     static constexpr int NT = NT_, BN = 32 * NT_;
     static constexpr int PX = PX_, PY = 32 / PX_, MT = MT_ ? MT_ : ((NT_ == 1 && KS_ == 3) ? 4 : 2), NW = 4, TH = PY * MT * NW;   // 3x3 32-co layers: 512-pixel tiles
@@ -614,7 +616,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                     xin[e] = x;
                     x0[e] = __float_as_uint(x) & 0xffff0000u;
                     const float r1 = x - __uint_as_float(x0[e]);
-                    x1[e] = __float_as_uint(r1) & 0xffff0000u;
+                    x1[e] = (C::NPL == 2 ? rcf_bf16_rne(r1) : __float_as_uint(r1)) & 0xffff0000u;   // last plane: rounded
                     const float r2 = r1 - __uint_as_float(x1[e]);
                     x2[e] = __float_as_uint(r2);
                 }
@@ -633,8 +635,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                     u32x2 w1 = {(x1[0] >> 16) | x1[1], (x1[2] >> 16) | x1[3]};
                     u32x2 w2 = {(x2[0] >> 16) | (x2[1] & 0xffff0000u), (x2[2] >> 16) | (x2[3] & 0xffff0000u)};
                     *reinterpret_cast<u32x2*>(dst) = w0;
-                    *reinterpret_cast<u32x2*>(dst + (C::NPL > 1 ? 1 : 0) * C::A_PLANE_BYTES) = w1;
-                    *reinterpret_cast<u32x2*>(dst + (C::NPL > 2 ? 2 : 0) * C::A_PLANE_BYTES) = w2;
+                    *reinterpret_cast<u32x2*>(dst + C::A_PLANE_BYTES) = w1;
+                    if (C::NPL == 3) *reinterpret_cast<u32x2*>(dst + 2 * C::A_PLANE_BYTES) = w2;
                 }
             }
         }
@@ -746,8 +748,9 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < NMF; ++j) {
                     constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
+                    constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};                    // two planes: a1b0, a0b1, a0b0
                     const int pj = j / MN, mi = (j % MN) / C::NT, ni = j % C::NT;
-                    const int pa = C::NPL == 3 ? PA[pj] : 0, pbl = C::NPL == 3 ? PB[pj] : 0;
+                    const int pa = C::NPL == 3 ? PA[pj] : (C::NPL == 2 ? PA2[pj % 3] : 0), pbl = C::NPL == 3 ? PB[pj] : (C::NPL == 2 ? PB2[pj % 3] : 0);
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][pa][mi], bv[cur][pbl][ni], acc[mi][ni], 0, 0, 0);
                     if (has_next) {
 #pragma unroll
@@ -978,6 +981,11 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned 
         return;
     }
     dst[base] = (unsigned short)(x0 >> 16);
+    if (npl == 2) {   // RCF_PREC_BF16X3: the second plane is the remainder rounded to nearest even
+        const unsigned u = __float_as_uint(r1);
+        dst[base + plane_elems] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        return;
+    }
     dst[base + plane_elems] = (unsigned short)(x1 >> 16);
     dst[base + 2 * plane_elems] = (unsigned short)(x2 >> 16);
 }
@@ -1289,7 +1297,7 @@ constexpr int ws_pitch(int bytes) { return ((bytes - 16 + 127) / 128) * 128 + 16
 template <int WCI_, int WCO_, int KS_ = 3, int TH_ = 8, int NPL_ = 3>
 struct WsCfg {
     static constexpr int KS = KS_, T = KS_ * KS_;
-    static constexpr int NPL = NPL_, NP = NPL_ == 3 ? 6 : 1;   // operand planes / partial products (1: bf16 operands, RCF_PREC_BF16)
+    static constexpr int NPL = NPL_, NP = NPL_ == 3 ? 6 : (NPL_ == 2 ? 3 : 1);   // operand planes / partial products (1: RCF_PREC_BF16, 2: RCF_PREC_BF16X3)
     static constexpr int WCI = WCI_, WCO = WCO_, KSPLIT = 4 / (WCI_ * WCO_);
     static constexpr int NCI = 32 * WCI_, NCO = 32 * WCO_;
     static constexpr int PX = 16, TH = TH_, HXP = PX + KS - 1, HYP = TH + KS - 1;
@@ -1457,7 +1465,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 const float x = v[2 * d + h][e];
                 x0[h] = __float_as_uint(x) & 0xffff0000u;
                 const float r1 = x - __uint_as_float(x0[h]);
-                x1[h] = __float_as_uint(r1) & 0xffff0000u;
+                x1[h] = (C::NPL == 2 ? rcf_bf16_rne(r1) : __float_as_uint(r1)) & 0xffff0000u;   // last plane: rounded
                 const float r2 = r1 - __uint_as_float(x1[h]);
                 x2[h] = __float_as_uint(r2);
             }
@@ -1470,10 +1478,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             }
         }
         *reinterpret_cast<u32x4*>(dst) = w0;
-        if (C::NPL == 3) {
-            *reinterpret_cast<u32x4*>(dst + plane_bytes) = w1;
-            *reinterpret_cast<u32x4*>(dst + 2 * plane_bytes) = w2;
-        }
+        if (C::NPL >= 2) *reinterpret_cast<u32x4*>(dst + plane_bytes) = w1;
+        if (C::NPL == 3) *reinterpret_cast<u32x4*>(dst + 2 * plane_bytes) = w2;
     };
     auto store_tile = [&]() {
 #pragma unroll
@@ -1574,11 +1580,12 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 // order: all kx = 0 taps, (kx = 2,) then kx = 1, whose operands are being built meanwhile; inside a group the six
                 // partial products run smallest first and the kernel rows alternate
                 constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+                constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
                 constexpr int KXO[3] = {0, KS == 3 ? 2 : 1, 1};
                 const int kx = KXO[j / (NP * KS)], pj = (j % (NP * KS)) / KS, ky = j % KS;
                 const int tap = ky * KS + kx;
                 const int sl = ROLL ? (s + ky) % (KS + 1) : cur * KS + ky;
-                const int pa = NPL == 3 ? PA[pj] : 0, pbl = NPL == 3 ? PB[pj] : 0;
+                const int pa = NPL == 3 ? PA[pj] : (NPL == 2 ? PA2[pj % 3] : 0), pbl = NPL == 3 ? PB[pj] : (NPL == 2 ? PB2[pj % 3] : 0);
                 u32x4 av;
                 if (kx == 0) av = xlo[sl][pa];
                 else if (kx == 1) av = xs1[ky][pa];
@@ -1840,6 +1847,7 @@ struct Sel {
     int split;   // fp32 on the bf16 matrix pipe (conv_split_kernel)
     int small;   // split 3x3 layer too small to fill the chip with 64-co workgroups: 256-pixel x 32-co workgroups instead
     int bf16;    // rcf_conv_desc.precision == RCF_PREC_BF16 and a split kernel: one bf16 plane, one product
+    int npl;     // operand planes of a split kernel: 3 (exact fp32), 2 (RCF_PREC_BF16X3), 1 (bf16)
     int dma;     // bf16 tensors, channel counts multiples of 16: conv_b16_kernel (operands reach LDS by DMA, rcf_conv_b16_dma.h)
     int pw;      // bf16 tensors, 1x1, <= 64 input and <= 128 output channels: conv1x1_b16_kernel (operands straight from global memory)
 };
@@ -2084,7 +2092,7 @@ bool split_enabled() {
 bool s2_split_enabled(const rcf_conv_desc* d) {
     const char* e = getenv("RCF_S2_SPLIT");
     if (e != nullptr) return e[0] != '0';
-    return d->precision == RCF_PREC_BF16;
+    return d->precision != RCF_PREC_FP32;
 }
 
 // stride-1 3x3 conv with pad 1 on directly addressed sources: the separator row is the conv's own zero padding
@@ -2101,7 +2109,7 @@ bool valid_desc(const rcf_conv_desc* d) {
     if (d->ksize != 1 && d->ksize != 2 && d->ksize != 3 && d->ksize != 4 && d->ksize != 7) return false;
     if (d->stride != 1 && d->stride != 2) return false;
     if (d->gather1 < 0 || d->gather1 > 3) return false;
-    if (d->precision != RCF_PREC_FP32 && d->precision != RCF_PREC_BF16) return false;
+    if (d->precision != RCF_PREC_FP32 && d->precision != RCF_PREC_BF16 && d->precision != RCF_PREC_BF16X3) return false;
     if (d->storage != RCF_STORE_FP32 && d->storage != RCF_STORE_BF16) return false;
     if (d->storage == RCF_STORE_BF16 && d->precision != RCF_PREC_BF16) return false;   // bf16 tensors are consumed as bf16 operands
     if ((d->storage == RCF_STORE_BF16) != SAct::B16) return false;                    // (each translation unit serves one storage)
@@ -2165,6 +2173,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     s->split = 0;
     s->small = 0;
     s->bf16 = 0;
+    s->npl = 3;
     s->dma = 0;
     s->pw = 0;
 #if RCF_CONV_B16
@@ -2173,7 +2182,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
         if (s->kind == K1 && d->precision == RCF_PREC_BF16 && d->c2 == 0 && d->c1 % 16 == 0 && d->c1 <= 64 && d->c_out <= 128 &&
             d->gather1 == RCF_GATHER_DIRECT && d->out_stride == 1 && (d->w_mode == RCF_W_FORWARD || d->stride == 1) &&
             (e == nullptr || e[0] != '0')) {
-            s->pw = 1; s->split = 1; s->bf16 = 1; s->ck = 16; s->cst = 16;
+            s->pw = 1; s->split = 1; s->bf16 = 1; s->npl = 1; s->ck = 16; s->cst = 16;
             s->nt = ceil_div(d->c_out, 32);
             s->px = 32; s->th = 8; s->bn = 32 * s->nt;
             return RCF_OK;
@@ -2191,12 +2200,13 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
         const long long wgs = (((long long)d->n * d->h_out * d->w_out + 255) / 256) * ceil_div(d->c_out, 64);
         if (s->kind == K3S1 && s->nt == 2 && wgs < num_cus()) { s->small = 1; s->nt = 1; }
         s->bf16 = d->precision == RCF_PREC_BF16 ? 1 : 0;
+        s->npl = s->bf16 ? 1 : (d->precision == RCF_PREC_BF16X3 ? 2 : 3);
 #if RCF_CONV_B16
         const char* e = getenv("RCF_B16_DMA");
         s->dma = (s->bf16 && d->c1 % 16 == 0 && d->c2 % 16 == 0 && (e == nullptr || e[0] != '0')) ? 1 : 0;
 #endif
     }
-    if (s->kind == K4S1) { s->split = 1; s->ck = 16; s->cst = 16; s->bf16 = 1; s->dma = 1; }
+    if (s->kind == K4S1) { s->split = 1; s->ck = 16; s->cst = 16; s->bf16 = 1; s->npl = 1; s->dma = 1; }
     double best = -1.0;
     const bool vt_ok = vt_allowed(d);
     const int pxs[3] = {32, 16, 8};
@@ -2290,6 +2300,23 @@ int dispatch_dma(const Sel& s, F&& f) {
 }
 #endif
 
+// fp32 tensors: NPL = 3 (the S* configurations above: exact) or NPL = 2 (RCF_PREC_BF16X3), same tile shapes
+template <int NPL, class F>
+int dispatch_split_planes(const Sel& s, F&& f) {
+    const bool p16 = s.px == 16;
+    if (s.kind == K3S2) {
+        if (s.nt == 1) return p16 ? f(Tag<SplitCfg<3, 1, 16, 1, NPL, 2>>{}) : f(Tag<SplitCfg<3, 1, 32, 1, NPL, 2>>{});
+        return p16 ? f(Tag<SplitCfg<3, 2, 16, 1, NPL, 2>>{}) : f(Tag<SplitCfg<3, 2, 32, 1, NPL, 2>>{});
+    }
+    if (s.kind == K2S1) {
+        if (s.nt == 1) return p16 ? f(Tag<SplitCfg<2, 1, 16, 0, NPL>>{}) : f(Tag<SplitCfg<2, 1, 32, 0, NPL>>{});
+        return p16 ? f(Tag<SplitCfg<2, 2, 16, 0, NPL>>{}) : f(Tag<SplitCfg<2, 2, 32, 0, NPL>>{});
+    }
+    if (s.nt == 1 && s.small) return p16 ? f(Tag<SplitCfg<3, 1, 16, 2, NPL>>{}) : f(Tag<SplitCfg<3, 1, 32, 2, NPL>>{});
+    if (s.nt == 1) return p16 ? f(Tag<SplitCfg<3, 1, 16, 0, NPL>>{}) : f(Tag<SplitCfg<3, 1, 32, 0, NPL>>{});
+    return p16 ? f(Tag<SplitCfg<3, 2, 16, 0, NPL>>{}) : f(Tag<SplitCfg<3, 2, 32, 0, NPL>>{});
+}
+
 template <class F>
 int dispatch_split(const Sel& s, F&& f) {
     if (s.bf16) {
@@ -2305,18 +2332,8 @@ int dispatch_split(const Sel& s, F&& f) {
         if (s.nt == 1) return s.px == 16 ? f(Tag<B3_1_16>{}) : f(Tag<B3_1_32>{});
         return s.px == 16 ? f(Tag<B3_2_16>{}) : f(Tag<B3_2_32>{});
     }
-    if constexpr (!SAct::B16) {   // the exact 3-plane split exists for fp32 tensors only
-        if (s.kind == K3S2) {
-            if (s.nt == 1) return s.px == 16 ? f(Tag<S3S2_1_16>{}) : f(Tag<S3S2_1_32>{});
-            return s.px == 16 ? f(Tag<S3S2_2_16>{}) : f(Tag<S3S2_2_32>{});
-        }
-        if (s.kind == K2S1) {
-            if (s.nt == 1) return s.px == 16 ? f(Tag<S2_1_16>{}) : f(Tag<S2_1_32>{});
-            return s.px == 16 ? f(Tag<S2_2_16>{}) : f(Tag<S2_2_32>{});
-        }
-        if (s.nt == 1 && s.small) return s.px == 16 ? f(Tag<S3_1_16s>{}) : f(Tag<S3_1_32s>{});
-        if (s.nt == 1) return s.px == 16 ? f(Tag<S3_1_16>{}) : f(Tag<S3_1_32>{});
-        return s.px == 16 ? f(Tag<S3_2_16>{}) : f(Tag<S3_2_32>{});
+    if constexpr (!SAct::B16) {   // the multi-plane splits exist for fp32 tensors only
+        return s.npl == 2 ? dispatch_split_planes<2>(s, f) : dispatch_split_planes<3>(s, f);
     }
     return RCF_EUNSUPPORTED;
 }
@@ -2471,7 +2488,7 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
     fill_args(d, s, &a);
     const int ntile_n = ceil_div(d->c_out, s.bn);
     info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * s.ck;
-    if (s.split) info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.bf16 ? 8 : 24);   // 16 bf16 x planes per row
+    if (s.split) info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * 8 * s.npl;   // 16 bf16 x planes per row
 #if RCF_CONV_B16
     if (s.pw) info->n_partials = pw_grid((long long)d->n * d->h_out * d->w_out, s.nt);
     else if (s.dma) info->n_partials = dispatch_dma(s, [&](auto tag) { return dma_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
@@ -2480,7 +2497,7 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
     info->n_partials = s.split ? dispatch_split(s, [&](auto tag) { return split_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); })
                                : dispatch_fwd(s, [&](auto tag) { return fwd_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
     if (info->n_partials <= 0) return RCF_EUNSUPPORTED;
-    info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0) + (s.small ? 5 : 0) + (s.bf16 ? 20000 : 0);
+    info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0) + (s.small ? 5 : 0) + (s.bf16 ? 20000 : 0) + ((s.split && s.npl == 2) ? 40000 : 0);
     info->wgrad_workspace_floats = 0;
     info->wgrad_kernel_id = 0;
     info->bn_on_load = (s.split && !s.dma && !s.pw && d->w_mode == RCF_W_FORWARD && d->c1 + d->c2 <= 512) ? 1 : 0;   // a DMA cannot transform
@@ -2492,7 +2509,8 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
             info->wgrad_workspace_floats = (size_t)w.nsplit * w.ktot * w.cop + 64;   // + a zero page for the DMA path
             info->wgrad_bn_on_load = (w.split && !SAct::B16) ? 1 : 0;   // bf16 tensors are staged raw: nothing to apply BatchNorm to
             info->wgrad_kernel_id = 10000 + w.kind * 1000 + (w.px == 16 ? 100 : (w.px == 8 ? 200 : 0)) + (w.vt ? 400 : 0) +
-                                    (w.split ? 5000 + w.wci * 10 + w.wco : 0) + ((w.split && d->precision == RCF_PREC_BF16) ? 20000 : 0);
+                                    (w.split ? 5000 + w.wci * 10 + w.wco : 0) + ((w.split && d->precision == RCF_PREC_BF16) ? 20000 : 0) +
+                                    ((w.split && d->precision == RCF_PREC_BF16X3) ? 40000 : 0);
         }
     }
     return RCF_OK;
@@ -2513,7 +2531,7 @@ extern "C" int RCF_FN(rcf_conv2d_pack_weights)(const rcf_conv_desc* d, const flo
         const size_t rows16 = (size_t)ntile_n * nchunk * s.t * s.bn * 16;
         hipLaunchKernelGGL(pack_weights_split_kernel, dim3((unsigned)((rows16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw,
                            reinterpret_cast<unsigned short*>(packed), rows16, d->w_o, d->w_i, d->w_mode, d->w_i_off, d->c_out, d->c1,
-                           d->c2, a.nchunk1, nchunk, s.bn, d->ksize, s.bf16 ? 1 : 3);
+                           d->c2, a.nchunk1, nchunk, s.bn, d->ksize, s.npl);
         return rcf_launch_status();
     }
     const int ksx = s.kind == K7S2 ? 1 : d->ksize;
@@ -2554,7 +2572,7 @@ static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float
     a.in1 = in1; a.in2 = in2; a.wp = packed; a.out = out; a.stats = stat_partials; a.dz = nullptr; a.ws = nullptr;
     a.ktot = 0; a.cop = 0;
     const int nn = ceil_div(d->c_out, s.bn);
-    a.wp_phase_stride = (int)((size_t)nn * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.split ? (s.bf16 ? 8 : 24) : s.ck));
+    a.wp_phase_stride = (int)((size_t)nn * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.split ? 8 * s.npl : s.ck));
 #if RCF_CONV_B16
     if (s.pw) {
         if (coef1 || coef2) return RCF_EUNSUPPORTED;
@@ -2588,11 +2606,26 @@ extern "C" int RCF_FN(rcf_conv2d_fwd_act)(const rcf_conv_desc* d, const void* in
     a.in1 = in1; a.in2 = in2; a.wp = packed; a.out = out; a.stats = nullptr; a.dz = nullptr; a.ws = nullptr;
     a.ktot = 0; a.cop = 0;
     const int nn = ceil_div(d->c_out, s.bn);
-    a.wp_phase_stride = (int)((size_t)nn * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.bf16 ? 8 : 24));
+    a.wp_phase_stride = (int)((size_t)nn * (a.nchunk1 + a.nchunk2) * s.t * s.bn * 8 * s.npl);
 #if RCF_CONV_B16
     if (s.dma) return dispatch_dma(s, [&](auto tag) { return launch_dma<typename decltype(tag)::type, true>(a, nn, (hipStream_t)stream); });
 #endif
     return dispatch_split(s, [&](auto tag) { return launch_split<typename decltype(tag)::type, true>(a, nn, (hipStream_t)stream); });
+}
+
+// split weight-gradient kernels on fp32 tensors: NPL = 3 (exact) or 2 (RCF_PREC_BF16X3); same tilings (select_wgrad)
+template <int NPL>
+static int launch_wgrad_split_planes(const ConvArgs& a, const WSel& w, int cfg, hipStream_t st) {
+    if (w.kind == K2S1) {
+        if (cfg == 22) return launch_wgrad_split<WsCfg<2, 2, 2, 8, NPL>>(a, w.nsplit, w.gy, w.gz, st);
+        if (cfg == 12) return launch_wgrad_split<WsCfg<1, 2, 2, 8, NPL>>(a, w.nsplit, w.gy, w.gz, st);
+        if (cfg == 21) return launch_wgrad_split<WsCfg<2, 1, 2, 8, NPL>>(a, w.nsplit, w.gy, w.gz, st);
+        return launch_wgrad_split<WsCfg<1, 1, 2, 16, NPL>>(a, w.nsplit, w.gy, w.gz, st);
+    }
+    if (cfg == 22) return launch_wgrad_split<WsCfg<2, 2, 3, 8, NPL>>(a, w.nsplit, w.gy, w.gz, st);
+    if (cfg == 12) return launch_wgrad_split<WsCfg<1, 2, 3, 8, NPL>>(a, w.nsplit, w.gy, w.gz, st);
+    if (cfg == 21) return launch_wgrad_split<WsCfg<2, 1, 3, 8, NPL>>(a, w.nsplit, w.gy, w.gz, st);
+    return launch_wgrad_split<WsCfg<1, 1, 3, 16, NPL>>(a, w.nsplit, w.gy, w.gz, st);
 }
 
 static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
@@ -2656,15 +2689,7 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
             else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 3, THB, 1>>(a, w.nsplit, w.gy, w.gz, st);
             else rc = launch_wgrad_split<WsCfg<1, 1, 3, 16, 1>>(a, w.nsplit, w.gy, w.gz, st);
         } else if constexpr (!SAct::B16) {
-        if (w.kind == K2S1) {
-            if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2, 2>>(a, w.nsplit, w.gy, w.gz, st);
-            else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2, 2>>(a, w.nsplit, w.gy, w.gz, st);
-            else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 2>>(a, w.nsplit, w.gy, w.gz, st);
-            else rc = launch_wgrad_split<WsCfg<1, 1, 2, 16>>(a, w.nsplit, w.gy, w.gz, st);
-        } else if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2>>(a, w.nsplit, w.gy, w.gz, st);
-        else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2>>(a, w.nsplit, w.gy, w.gz, st);
-        else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1>>(a, w.nsplit, w.gy, w.gz, st);
-        else rc = launch_wgrad_split<WsCfg<1, 1, 3, 16>>(a, w.nsplit, w.gy, w.gz, st);
+            rc = d->precision == RCF_PREC_BF16X3 ? launch_wgrad_split_planes<2>(a, w, cfg, st) : launch_wgrad_split_planes<3>(a, w, cfg, st);
         } else return RCF_EUNSUPPORTED;
     } else
     switch (w.kind) {

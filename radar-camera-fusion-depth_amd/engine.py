@@ -341,7 +341,7 @@ class Engine(object):
             return self._conv_up2x_backward(layer, info, x, dz)
         weight = layer.conv.weight
         dw = self.grad_of(weight)
-        s2_phases = self.s2_wgrad_phases if self.s2_wgrad_phases is not None else (ops.act_dtype() == torch.bfloat16)
+        s2_phases = self.s2_wgrad_phases if self.s2_wgrad_phases is not None else (ops.act_dtype() == torch.bfloat16 or ops.get_precision() == 2)
         if (self.use_phase_convs and s2_phases and desc.stride == 2 and desc.ksize == 3 and x2 is None and desc.c1 % 4 == 0
                 and desc.c1 >= 16 and desc.gather1 == RCF_GATHER_DIRECT):
             # 3x3 stride-2 weight gradient as four 2x2 weight gradients on the phase images of x (bf16 matrix pipe)

@@ -244,8 +244,10 @@ class FusionNetModel(object):
     # ------------------------------------------------------------------ arithmetic of the convolutions
     compute_dtype = 'fp32'
     '''
-    'fp32' (default, the reference's arithmetic) or 'bf16': the split convolution kernels round their operands to bf16 (nearest
-    even) and accumulate in fp32 -- the "bf16" configurations of BASELINE.json; tensors, BatchNorm, loss and optimizer stay fp32.
+    'fp32' (default): the reference's arithmetic (exact fp32 products).  'bf16': bf16 tensors in HBM and bf16 matrix operands,
+    fp32 accumulation -- the "bf16" configurations of BASELINE.json; weights, BatchNorm statistics, loss and optimizer stay fp32.
+    'bf16_operands': fp32 tensors, operands of the split convolution kernels rounded to bf16.  'bf16x3': fp32 tensors, operands of
+    the split convolution kernels carried as two bf16 planes / three products (16-17 significant bits, ops.set_precision).
     '''
 
     def _run_engine(self, image, input_depth, record):

@@ -68,8 +68,12 @@ _STORAGE = [0]     # rcf_conv_desc.storage (RCF_STORE_FP32 / RCF_STORE_BF16)
 
 def set_precision(p):
     '''0 / 'fp32': fp32 arithmetic and fp32 tensors (default).  'bf16': bf16 tensors in HBM + bf16 MFMA operands, fp32 accumulate
-    (BASELINE.json configs 2-4).  'bf16_operands': fp32 tensors, operands rounded to bf16 in the split conv kernels.'''
-    _PRECISION[0] = 1 if p in (1, 'bf16', 'bf16_operands') else 0
+    (BASELINE.json configs 2-4).  'bf16_operands': fp32 tensors, operands rounded to bf16 in the split conv kernels.
+    'bf16x3': fp32 tensors, each operand of the split conv kernels as two bf16 planes and three products (16-17 significant bits;
+    RCF_PREC_BF16X3 in include/rcf_hip.h) -- half the matrix work of 'fp32', errors ~1e-5.'''
+    if p not in (0, 1, 'fp32', 'bf16', 'bf16_operands', 'bf16x3'):
+        raise ValueError('unknown precision %r' % (p,))
+    _PRECISION[0] = 1 if p in (1, 'bf16', 'bf16_operands') else (_lib.RCF_PREC_BF16X3 if p == 'bf16x3' else 0)
     _STORAGE[0] = 1 if p == 'bf16' else 0
 
 

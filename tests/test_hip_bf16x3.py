@@ -1,0 +1,293 @@
+'''
+GPU parity tests of the 'bf16x3' arithmetic (rcf_conv_desc.precision = RCF_PREC_BF16X3, include/rcf_hip.h): fp32 tensors, each
+operand of the split convolution kernels carried as two bf16 planes (top 8 significant bits + the remainder rounded to 8 more) and
+multiplied as a0*b0 + a0*b1 + a1*b0 with fp32 accumulation.
+
+Two bars.  (1) Against an fp64 evaluation of exactly that three-product formula the kernels differ only by fp32 summation order
+(2e-5 of max-abs).  (2) Against the plain fp32 reference (stock PyTorch CPU ops / the golden fixtures of the real reference) the
+results sit at ~1e-5, two orders inside north_star's bar of 1e-3 relative, which is what the model-level tests assert.
+'''
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+NORTH_STAR = 1e-3     # BASELINE.json north_star: "within 1e-3 rel fp32"
+X3_TOL = 5e-5         # what two planes / three products leave, as a fraction of the reference tensor's max-abs
+ORDER_TOL = 2e-5      # fp32 summation order only (against the emulated three-product formula)
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import rcf_amd  # noqa: F401
+    from rcf_amd import _lib, ops as _ops
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    assert _lib.load().rcf_device_ok() == 1, 'librcf_hip.so: no gfx950 device'
+    if os.environ.get('RCF_CONV_SPLIT') == '0':
+        pytest.skip('bf16x3 lives in the split kernels, which RCF_CONV_SPLIT=0 turns off')
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.detach().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+def planes(t):
+    '''The two bf16 planes of an fp32 tensor as the kernels form them: truncation to the top 16 bits, then the remainder rounded
+    to nearest even (both returned as float64).'''
+    t = t.float().contiguous()
+    hi = (t.view(torch.int32) & -65536).view(torch.float32)
+    lo = (t - hi).to(torch.bfloat16).to(torch.float32)
+    return hi.double(), lo.double()
+
+
+def x3(fn, a, b):
+    '''fn bilinear in (a, b): the three products of the two-plane operands, in fp64.'''
+    a0, a1 = planes(a)
+    b0, b1 = planes(b)
+    return fn(a0, b0) + fn(a0, b1) + fn(a1, b0)
+
+
+# (ksize, stride, c1, c2, cout, n, h, w, up_from)
+CASES = [
+    (3, 1, 64, 0, 64, 2, 33, 64, None),
+    (3, 1, 64, 32, 64, 2, 17, 40, None),        # decoder concat
+    (3, 1, 32, 0, 32, 1, 40, 100, None),        # 32-co tiles, 16-pixel rows
+    (3, 1, 128, 128, 128, 1, 15, 26, None),
+    (3, 1, 64, 0, 32, 1, 70, 102, (35, 51)),    # nearest-upsample gather on load
+    (3, 1, 256, 0, 256, 2, 8, 13, None),        # small layer: 32-co half workgroups
+    (3, 2, 32, 0, 64, 2, 45, 80, None),         # stride 2 on the split kernel
+    (3, 2, 128, 0, 256, 1, 29, 50, None),
+]
+
+
+def _case(case, seed):
+    k, s, c1, c2, co, n, h, w, up = case
+    hs, ws = (h, w) if up is None else up
+    x1 = rnd(n, c1, hs, ws, seed=seed)
+    x2 = rnd(n, c2, h, w, seed=seed + 1) if c2 else None
+    wt = rnd(co, c1 + c2, k, k, seed=seed + 2, scale=1.0 / np.sqrt((c1 + c2) * k * k))
+    xin = x1 if up is None else F.interpolate(x1, size=(h, w))
+    if x2 is not None:
+        xin = torch.cat([xin, x2], 1)
+    return x1, x2, wt, xin
+
+
+@pytest.mark.parametrize('case', CASES, ids=[str(c) for c in CASES])
+def test_conv_forward_input_gradient_weight_gradient(ops, case):
+    k, s, c1, c2, co, n, h, w, up = case
+    x1, x2, wt, xin = _case(case, 40)
+    hs, ws = (h, w) if up is None else up
+    ops.set_precision('bf16x3')
+    try:
+        d = ops.make_fwd_desc(n, h, w, c1, c2, co, k, s, hs, ws, 0 if up is None else 1)
+        info = ops.conv_query(d)
+        assert info.kernel_id >= 40000, info.kernel_id            # a two-plane split kernel was selected
+        packed = torch.empty(info.packed_weight_floats, device='cuda')
+        ops.conv_pack(d, wt.cuda(), packed)
+        out = torch.full((n, d.h_out, d.w_out, co), float('nan'), device='cuda')
+        part = torch.full((info.n_partials, 2, co), float('nan'), device='cuda', dtype=torch.float64)
+        ops.conv_fwd(d, nhwc(x1), None if x2 is None else nhwc(x2), packed, out, part)
+        got = nchw(out)
+        conv = lambda a, b: F.conv2d(a, b, stride=s, padding=k // 2)
+        ref64 = conv(xin.double(), wt.double())
+        assert rel(got, x3(conv, xin, wt)) < ORDER_TOL
+        e = rel(got, ref64)
+        assert e < X3_TOL, e
+        # BatchNorm statistics of the written values (fp64 sums of the fp32 outputs)
+        st = part.sum(0).cpu()
+        np.testing.assert_allclose(st[0].numpy(), got.double().sum((0, 2, 3)).numpy(), rtol=1e-9, atol=1e-7)
+        np.testing.assert_allclose(st[1].numpy(), (got.double() ** 2).sum((0, 2, 3)).numpy(), rtol=1e-9, atol=1e-7)
+
+        # weight gradient
+        dz = rnd(n, co, d.h_out, d.w_out, seed=77)
+        dw = torch.full(wt.shape, float('nan'), device='cuda')
+        wsb = torch.empty(max(1, info.wgrad_workspace_floats), device='cuda')
+        ops.conv_wgrad(d, nhwc(x1), None if x2 is None else nhwc(x2), nhwc(dz), dw, wsb)
+        wg = lambda a, b: torch.nn.grad.conv2d_weight(a, wt.shape, b, stride=s, padding=k // 2)
+        if s == 1:
+            assert info.wgrad_kernel_id >= 40000, info.wgrad_kernel_id
+            assert rel(dw.cpu(), x3(wg, xin, dz)) < ORDER_TOL
+        assert rel(dw.cpu(), wg(xin.double(), dz.double())) < X3_TOL
+
+        # input gradient of source 1 (stride 1: the same kernel on flipped weights; the stride-2 one is four phase convolutions,
+        # covered by test_stride2_gradients_as_phase_convolutions)
+        if s == 1 and up is None:
+            dd = ops.make_dgrad_desc(d, 0, c1, False)
+            di = ops.conv_query(dd)
+            assert di.kernel_id >= 40000
+            pk = torch.empty(di.packed_weight_floats, device='cuda')
+            ops.conv_pack(dd, wt.cuda(), pk)
+            dx = torch.full((n, h, w, c1), float('nan'), device='cuda')
+            ops.conv_fwd(dd, nhwc(dz), None, pk, dx, None)
+            dg = lambda a, b: torch.nn.grad.conv2d_input(xin.shape, b, a, stride=1, padding=k // 2)[:, :c1]
+            assert rel(nchw(dx), x3(dg, dz, wt)) < ORDER_TOL
+            assert rel(nchw(dx), dg(dz.double(), wt.double())) < X3_TOL
+    finally:
+        ops.set_precision('fp32')
+
+
+def test_precision_levels_are_distinct_and_ordered(ops):
+    '''One 64 -> 64 layer under the three arithmetic levels of fp32 tensors: 'fp32' (exact products) < 'bf16x3' < 'bf16_operands' in
+    error against fp64, each by more than an order of magnitude -- i.e. each descriptor really selects its own kernels.'''
+    case = (3, 1, 64, 0, 64, 2, 33, 64, None)
+    k, s, c1, c2, co, n, h, w, up = case
+    x1, _, wt, xin = _case(case, 5)
+    ref = F.conv2d(xin.double(), wt.double(), padding=1)
+    err = {}
+    try:
+        for mode in ('fp32', 'bf16x3', 'bf16_operands'):
+            ops.set_precision(mode)
+            d = ops.make_fwd_desc(n, h, w, c1, c2, co, k, s, h, w, 0)
+            info = ops.conv_query(d)
+            packed = torch.empty(info.packed_weight_floats, device='cuda')
+            ops.conv_pack(d, wt.cuda(), packed)
+            out = torch.empty(n, h, w, co, device='cuda')
+            ops.conv_fwd(d, nhwc(x1), None, packed, out, None)
+            err[mode] = rel(nchw(out), ref)
+    finally:
+        ops.set_precision('fp32')
+    print(err)
+    assert err['fp32'] < 1e-6
+    assert 10 * err['fp32'] < err['bf16x3'] < X3_TOL
+    assert 10 * err['bf16x3'] < err['bf16_operands'] < 1e-2
+
+
+@pytest.mark.parametrize('cin,cout,n,hs,ws', [(64, 32, 1, 35, 51), (64, 64, 2, 12, 20)])
+def test_up2x_conv_as_four_phase_convs(ops, cin, cout, n, hs, ws):
+    '''The exact-2x UpConv (nearest upsample + 3x3) as four 2x2 phase convolutions writing the strided output (RCF_PHASE_UP2X_FWD).'''
+    x = rnd(n, cin, hs, ws, seed=3)
+    wt = rnd(cout, cin, 3, 3, seed=4, scale=1.0 / np.sqrt(cin * 9))
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2), wt.double(), padding=1)
+    ops.set_precision('bf16x3')
+    try:
+        out = torch.full((n, 2 * hs, 2 * ws, cout), float('nan'), device='cuda')
+        from rcf_amd._lib import RCF_PHASE_UP2X_FWD
+        wph = ops.phase_weights(wt.cuda(), RCF_PHASE_UP2X_FWD)
+        for a in range(2):
+            for b in range(2):
+                d = ops.make_up2x_fwd_desc(n, hs, ws, cin, cout, a, b)
+                info = ops.conv_query(d)
+                assert info.kernel_id >= 40000
+                packed = torch.empty(info.packed_weight_floats, device='cuda')
+                ops.conv_pack(d, wph[a * 2 + b], packed)
+                ops.conv_fwd(d, nhwc(x), None, packed, out, None)
+        assert rel(nchw(out), ref) < X3_TOL
+    finally:
+        ops.set_precision('fp32')
+
+
+def _named(model):
+    out = []
+    for prefix, mod in (('encoder.', model.encoder), ('decoder.', model.decoder)):
+        out += [(prefix + k, v) for k, v in mod.named_parameters()]
+    return out
+
+
+@pytest.fixture(scope='module')
+def env():
+    import rcf_amd  # noqa: F401
+    from rcf_amd import synth, train
+    return synth, train
+
+
+def _step(env, cfg, g, mode, deconv_type='up'):
+    synth, train = env
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    m = train.build_model(cfg, device='cuda', deconv_type=deconv_type)
+    synth.fill_state_dict_([m.encoder, m.decoder], wseed)
+    m.compute_dtype = mode
+    m.train()
+    b = {kk: v.cuda() for kk, v in synth.make_batch(n, h, w, k, seed=dseed).items()}
+    out = m.forward(image=b['image'], input_depth=b['input_depth'])
+    loss, info = m.compute_loss(image=b['image'], output_depth=out, ground_truth=b['ground_truth'], lidar_map=b['lidar_map'],
+                                loss_func='l1', w_smoothness=0.0, loss_smoothness_kernel_size=-1,
+                                validity_map_loss_smoothness=None, w_lidar_loss=2.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    return m, out.detach(), float(loss.detach())
+
+
+@pytest.mark.parametrize('fixture,deconv', [('T1_published_train.npz', 'up'), ('T10_transpose_published_train.npz', 'transpose')])
+def test_published_net_train_step_against_the_reference_fixture(env, golden_dir, fixture, deconv):
+    '''One training step of the published FusionNet under compute_dtype='bf16x3' against the fixture generated by the REAL reference
+    (fp32 PyTorch CPU): output and loss within north_star's 1e-3 (measured: ~1e-5), parameter-gradient norms within 1 %, and the
+    mode is really in use (the output differs from the exact-fp32 path).'''
+    synth, _ = env
+    g = np.load(os.path.join(golden_dir, fixture))
+    m, out, loss = _step(env, synth.PUBLISHED, g, 'bf16x3', deconv)
+    _, out32, _ = _step(env, synth.PUBLISHED, g, 'fp32', deconv)
+    e = rel(out.cpu(), torch.as_tensor(g['output']))
+    e32 = rel(out32.cpu(), torch.as_tensor(g['output']))
+    print('output rel err vs the reference: bf16x3 %.2e (fp32 path %.2e); loss %.6f ref %.6f' % (e, e32, loss, float(g['loss'][0])))
+    assert e < NORTH_STAR and e < 2e-4
+    assert not torch.equal(out, out32)
+    assert abs(loss - float(g['loss'][0])) < 1e-4 * abs(float(g['loss'][0]))
+    grads = dict(_named(m))
+    worst = 0.0
+    for key, l2 in zip(g['grad_keys'].tolist(), g['grad_l2'].tolist()):
+        got = float(grads[key].grad.double().norm())
+        worst = max(worst, abs(got - l2) / max(l2, 1e-6))
+    print('worst parameter-gradient norm deviation: %.2e' % worst)
+    assert worst < 1e-2
+
+
+def test_three_adam_steps_follow_the_reference_trajectory(env, golden_dir):
+    '''Fixture T2 (three Adam steps of the real reference on the tiny net): the losses under bf16x3 stay within north_star's bar.'''
+    synth, train = env
+    g = np.load(os.path.join(golden_dir, 'T2_tiny_adam3.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    m = train.build_model(synth.TINY, device='cuda')
+    synth.fill_state_dict_([m.encoder, m.decoder], wseed)
+    m.compute_dtype = 'bf16x3'
+    m.train()
+    opt = train.make_optimizer(m, lr=1e-3)
+    losses = []
+    for step in range(3):
+        b = {kk: v.cuda() for kk, v in synth.make_batch(n, h, w, k, seed=dseed + step).items()}
+        losses.append(float(train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])[0]))
+    np.testing.assert_allclose(losses, g['losses'][:3], rtol=NORTH_STAR)
+    psum = float(sum(p.detach().double().abs().sum() for p in m.parameters()))
+    assert abs(psum - float(g['param_abs_sum'])) < 1e-4 * float(g['param_abs_sum'])
+
+
+def test_captured_training_step_is_bitwise_the_eager_step(env, golden_dir):
+    synth, train = env
+    g = np.load(os.path.join(golden_dir, 'T1_published_train.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    b = {kk: v.cuda() for kk, v in synth.make_batch(n, h, w, k, seed=dseed).items()}
+    args = (b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])
+    res = []
+    for captured in (False, True):
+        m = train.build_model(synth.PUBLISHED, device='cuda')
+        synth.fill_state_dict_([m.encoder, m.decoder], wseed)
+        m.compute_dtype = 'bf16x3'
+        m.train()
+        opt = train.make_optimizer(m, lr=1e-3)
+        if captured:
+            step = m.capture_training_step(opt, *args)
+            ls = [float(step(*args).detach()) for _ in range(2)]
+        else:
+            ls = [float(train.train_step(m, opt, *args)[0]) for _ in range(2)]
+        torch.cuda.synchronize()
+        res.append((ls, [p.detach().clone() for _, p in _named(m)]))
+    assert res[0][0] == res[1][0]
+    for a, c in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, c)
