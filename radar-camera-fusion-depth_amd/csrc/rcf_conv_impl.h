@@ -351,6 +351,11 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
                                 const int co = n0 + ni * 32 + li;
                                 old[j][ni] = rcf_ld1<SO>(a.out, (pok[j] && co < a.c_out) ? pbase[j] + co : 0);
                             }
+                        // land the loads inside this branch, or every store below waits on vmcnt(0) (see conv_split_kernel's epilogue)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(old[j][ni]));
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
@@ -799,6 +804,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                             ebias[ni] = a.bias[co < a.c_out ? co : 0];
                         }
                     }
+                    const bool add_old = EPI ? a.res != nullptr : a.accumulate != 0;
 #pragma unroll
                     for (int mi = 0; mi < C::MT; ++mi) {
 #pragma unroll
@@ -845,8 +851,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                 }
                             }
                             float old[4][C::NT];
-                            const float* addsrc = EPI ? a.res : a.out;
-                            if (EPI ? a.res != nullptr : a.accumulate != 0) {   // all old values of the group in flight together (clamped address)
+                            if (add_old) {   // all old values of the group in flight together (clamped address)
+                                const auto* addsrc = EPI ? a.res : a.out;
 #pragma unroll
                                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -854,6 +860,15 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                         const int co = n0 + ni * 32 + li;
                                         old[j][ni] = rcf_ld1<SO>(addsrc, (pok[j] && co < a.c_out) ? pbase[j] + co : 0);
                                     }
+                                // Land the loads INSIDE this branch (the empty asm uses the registers, so the s_waitcnt goes here).
+                                // On gfx9 stores count in vmcnt like loads: with the old values still pending at the join, hipcc put an
+                                // s_waitcnt vmcnt(0) in front of EVERY store -- of the plain path too -- and the 64 stores of a tile
+                                // ran one HBM round trip after the other (20-40 % of a wave's time).  (Wrapping the body in a lambda with
+                                // a compile-time ADD instead costs the 512-pixel configuration ~60 spilled VGPRs: measured, slower.)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(old[j][ni]));
                             } else {
 #pragma unroll
                                 for (int j = 0; j < 4; ++j)
