@@ -310,7 +310,7 @@ def run_rank(args):
     ev_steps = 3 if use_graph else args.steps
 
     side = None
-    if args.dtype is None and not args.no_side_leg:   # the default run also reports the three-product arithmetic, beside the metric
+    if args.dtype is None and not args.no_side_leg and world == 1:   # the default 1-GPU run also reports the three-product arithmetic, beside the metric
         del step
         try:
             side = side_leg(args, dev, world, rank, batch, 'f32x3')
