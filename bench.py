@@ -49,7 +49,7 @@ TRAIN_GFLOP_PER_SAMPLE = 994.8  # forward + dgrad + wgrad of the r
 FWD_GFLOP_PER_SAMPLE = 333.09
 KERNEL_NAMES = {
     0: 'conv_fwd_kernel 3x3 s1', 1: 'conv_fwd_kernel 3x3 s2', 2: 'conv_fwd_kernel 1x1', 3: 'conv_fwd_kernel 7x7 s2 stem',
-    5: 'conv_split_kernel 3x3 s1 (fp32 via bf16x3 split)', 9: 'conv_split_kernel 2x2 phases (fp32 via bf16x3 split)',
+    5: 'conv_split_kernel 3x3 s1 (fp32 via 3-plane bf16 split)', 9: 'conv_split_kernel 2x2 phases (fp32 via 3-plane bf16 split)',
     10: 'conv_wgrad_kernel 3x3 s1', 11: 'conv_wgrad_kernel 3x3 s2', 12: 'conv_wgrad_kernel 1x1', 13: 'conv_wgrad_kernel 7x7 s2 stem',
 }
 
@@ -372,11 +372,17 @@ def run_rank(args):
         # split kernels are bound by the bf16 matrix pipe: price them on the bf16 FLOPs they execute (6 per fp32 MAC)
         achieved = algorithmic * ({'bf16': 1, 'f32x3': 3}.get(dtype, SPLIT_PRODUCTS) if is_split else 1)
         peak = BF16_MFMA_PEAK_TFLOPS if is_split else F32_MFMA_PEAK_TFLOPS
-        traffic, traffic_src = _pmc_traffic(KERNEL_NAMES.get(dom, ''))
+        kname = KERNEL_NAMES.get(dom, str(dom))
+        if dtype == 'f32':
+            traffic, traffic_src = _pmc_traffic(kname)
+        else:   # the committed PMC passes profile the fp32 step
+            traffic, traffic_src = None, 'the committed PMC passes (profiles/) were collected on the fp32 step'
+            kname = kname.replace('fp32 via 3-plane bf16 split', 'bf16 tensors and operands' if dtype == 'bf16' else
+                                  'fp32 tensors, 2-plane bf16 operands, 3 products')
         conv_ms = sum(r[2] for r in fam.values())
         conv_flops = sum(r[1] for r in fam.values())
         rec['roofline'] = {
-            'bound': 'mfma', 'kernel': KERNEL_NAMES.get(dom, str(dom)),
+            'bound': 'mfma', 'kernel': kname,
             'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
             'frac': round(achieved / peak, 4), 'algorithmic_fp32_tflops': round(algorithmic, 2),
             # the honest fraction: useful (algorithmic) FLOP/s over the peak of the pipe the kernel runs on -- `frac` above prices

@@ -15,9 +15,9 @@ tag = sys.argv[4] if len(sys.argv) > 4 else 'r01'
 prof = os.path.join(ROOT, 'profiles')
 
 FAMILIES = [   # (bench.py KERNEL_NAMES entry, kernel-name prefix)
-    ('conv_split_kernel 3x3 s1 (fp32 via bf16x3 split)', 'conv_split_kernel<SplitCfg<3,'),
-    ('conv_split_kernel 2x2 phases (fp32 via bf16x3 split)', 'conv_split_kernel<SplitCfg<2,'),
-    ('conv_wgrad_split_kernel 3x3 s1 (fp32 via bf16x3 split)', 'conv_wgrad_split_kernel<'),
+    ('conv_split_kernel 3x3 s1 (fp32 via 3-plane bf16 split)', 'conv_split_kernel<SplitCfg<3,'),
+    ('conv_split_kernel 2x2 phases (fp32 via 3-plane bf16 split)', 'conv_split_kernel<SplitCfg<2,'),
+    ('conv_wgrad_split_kernel 3x3 s1 (fp32 via 3-plane bf16 split)', 'conv_wgrad_split_kernel<'),
     ('conv_fwd_kernel 3x3 s1', 'conv_fwd_kernel<FwdCfg<3, 3, 0, 1'),
 ]
 
