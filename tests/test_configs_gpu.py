@@ -322,3 +322,8 @@ def test_bench_single_gpu_line_carries_the_contract_fields():
     assert rec['config']['loss_check']['ok'] is True          # first step == the CPU oracle's loss for these seeds
     for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'useful_frac'):
         assert key in rec['roofline'], key
+    # the default run carries the same step under the bf16x3 arithmetic beside the metric: same first loss (to 1e-5), not slower
+    side = rec['f32x3']
+    assert 'error' not in side, side
+    assert side['dtype'] == 'f32x3' and side['value'] > 0 and side['ms_per_step'] < 1.1 * rec['ms_per_step']
+    assert side['first_step_loss_rel_err_vs_oracle'] < 1e-5
