@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
             const int p = s >> 1;
             const int hh = (s & 1) ^ ((p >> 3) & 1);
             const unsigned char* g = pix[i] >= 0 ? src + ((size_t)pix[i] * csrc + cb + hh * 8) * 2
-                                                 : reinterpret_cast<const unsigned char*>(rcf_zero_page);
+                                                 : reinterpret_cast<const unsigned char*>(a.zero);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(Ab + (i * 256 + wave_u * 64) * 16), 16, 0, 0);
         }

@@ -43,8 +43,12 @@ template <class C>
 using SInOf = std::conditional_t<(C::CST == 4), StF32, SAct>;
 
 // padding / out-of-image / out-of-range-channel lanes of the DMA and split weight-gradient kernels load from here instead of
-// branching: a zero-initialised device global (one copy per device, nothing allocated at run time)
-__device__ __attribute__((aligned(256))) const float rcf_zero_page[64] = {};
+// branching: a zero-initialised device global (one copy per device, nothing allocated at run time).  The kernels take its address
+// from ConvArgs::zero (host: zero_page_ptr()), never from the symbol: named in device code, a `const` array sits in the constant
+// address space, the select between it and a global pointer is a generic pointer and every staging load of
+// conv_wgrad_split_kernel was a flat_load (which counts in lgkmcnt too: each wait for an LDS read also waited for the next tile's
+// global loads); a non-const one is reached through the GOT, an s_load + s_waitcnt lgkmcnt(0) in front of every load.
+__device__ __attribute__((aligned(256))) float rcf_zero_page[64] = {};
 
 struct ConvArgs {
     const float* bias;   // fused inference epilogue (conv_split_kernel<C, true>): out = lrelu(acc + bias[co]), then lrelu(. + res) if res
@@ -57,6 +61,7 @@ struct ConvArgs {
     float* out;
     double* stats;
     const float* dz;   // wgrad only
+    const float* zero; // rcf_zero_page (a kernel argument: see there)
     float* ws;         // wgrad only
     int n, h_in, w_in, c1, c2, h1, w1, gather1;
     int h_out, w_out, c_out, pad, pad_x, stride, gstep, accumulate;
@@ -1212,7 +1217,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(ConvArgs a) {
         __syncthreads();   // the previous tile's MFMAs are done with LDS
 #pragma unroll
         for (int i = 0; i < H::NA; ++i) {
-            const float* g = (cok && halo.pix[i] >= 0) ? src + (size_t)halo.pix[i] * csrc + cch : rcf_zero_page;
+            const float* g = (cok && halo.pix[i] >= 0) ? src + (size_t)halo.pix[i] * csrc + cch : a.zero;
             float* dst = As + (i * H::PPI + wave * 8) * 32;   // wave-uniform; lane l lands 16*l bytes further
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -1230,7 +1235,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(ConvArgs a) {
             }
             const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
             const bool ok = dok && oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
-            const float* g = ok ? a.dz + (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out + dc : rcf_zero_page;
+            const float* g = ok ? a.dz + (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out + dc : a.zero;
             float* dst = Ds + (i * 32 + wave * 8) * 32;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -1426,8 +1431,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                     px = 2 * lx + a.iox;
                     ok = ok && px < ws;
                 }
-                if constexpr (RAWX) rx[i][j] = *reinterpret_cast<const u32x2*>(ok ? rcf_at<SX>(rowptr, px * csrc) : rcf_zero_page);
-                else rx[i][j] = rcf_ld4<SX>(ok ? rcf_at<SX>(rowptr, px * csrc) : rcf_zero_page, 0);
+                if constexpr (RAWX) rx[i][j] = *reinterpret_cast<const u32x2*>(ok ? rcf_at<SX>(rowptr, px * csrc) : a.zero);
+                else rx[i][j] = rcf_ld4<SX>(ok ? rcf_at<SX>(rowptr, px * csrc) : a.zero, 0);
                 if (cfx != nullptr) m |= ok ? (1u << j) : 0u;
             }
             mx[i] = m;
@@ -1451,8 +1456,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             for (int j = 0; j < 8; ++j) {
                 const int ox = ox0 + 8 * g + j;
                 const int px = FAST ? ox : ox * a.os + a.oox;
-                if constexpr (RAWD) rd[i][j] = *reinterpret_cast<const u32x2*>((rowok && ox < a.w_out && px < a.owp) ? rcf_at<SD>(rowptr, px * a.c_out) : rcf_zero_page);
-                else rd[i][j] = rcf_ld4<SD>((rowok && ox < a.w_out && px < a.owp) ? rcf_at<SD>(rowptr, px * a.c_out) : rcf_zero_page, 0);
+                if constexpr (RAWD) rd[i][j] = *reinterpret_cast<const u32x2*>((rowok && ox < a.w_out && px < a.owp) ? rcf_at<SD>(rowptr, px * a.c_out) : a.zero);
+                else rd[i][j] = rcf_ld4<SD>((rowok && ox < a.w_out && px < a.owp) ? rcf_at<SD>(rowptr, px * a.c_out) : a.zero, 0);
             }
         }
     };
@@ -2240,8 +2245,19 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     return RCF_OK;
 }
 
+// device address of rcf_zero_page (this translation unit's copy), looked up once
+const float* zero_page_ptr() {
+    static const float* p = nullptr;
+    if (p == nullptr) {
+        void* q = nullptr;
+        if (hipGetSymbolAddress(&q, HIP_SYMBOL(rcf_zero_page)) == hipSuccess) p = static_cast<const float*>(q);
+    }
+    return p;
+}
+
 void fill_args(const rcf_conv_desc* d, const Sel& s, ConvArgs* a) {
     a->coef1 = nullptr; a->coef2 = nullptr; a->bias = nullptr; a->res = nullptr;
+    a->zero = zero_page_ptr();
     a->n = d->n; a->h_in = d->h_in; a->w_in = d->w_in; a->c1 = d->c1; a->c2 = d->c2;
     a->h1 = d->h_src1; a->w1 = d->w_src1; a->gather1 = d->gather1;
     a->h_out = d->h_out; a->w_out = d->w_out; a->c_out = d->c_out; a->pad = d->pad; a->pad_x = d->pad_x; a->stride = d->stride;
@@ -2583,6 +2599,7 @@ static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float
         return RCF_EUNSUPPORTED;   // BN-on-load exists in the split kernels only (rcf_conv_info.bn_on_load)
     ConvArgs a;
     fill_args(d, s, &a);
+    if (a.zero == nullptr) return (int)hipErrorInvalidSymbol;
     a.coef1 = coef1; a.coef2 = coef2;
     a.in1 = in1; a.in2 = in2; a.wp = packed; a.out = out; a.stats = stat_partials; a.dz = nullptr; a.ws = nullptr;
     a.ktot = 0; a.cop = 0;
@@ -2617,6 +2634,7 @@ extern "C" int RCF_FN(rcf_conv2d_fwd_act)(const rcf_conv_desc* d, const void* in
     if (!s.split || s.pw || d->w_mode != RCF_W_FORWARD || d->accumulate) return RCF_EUNSUPPORTED;   // rcf_conv_info.fwd_act
     ConvArgs a;
     fill_args(d, s, &a);
+    if (a.zero == nullptr) return (int)hipErrorInvalidSymbol;
     a.bias = bias; a.res = res;
     a.in1 = in1; a.in2 = in2; a.wp = packed; a.out = out; a.stats = nullptr; a.dz = nullptr; a.ws = nullptr;
     a.ktot = 0; a.cop = 0;
@@ -2668,6 +2686,8 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
     if ((coef1 || coef2) && (!w.split || SAct::B16 || (coef2 && d->c2 == 0))) return RCF_EUNSUPPORTED;
     ConvArgs a;
     a.bias = nullptr; a.res = nullptr;
+    a.zero = zero_page_ptr();
+    if (a.zero == nullptr) return (int)hipErrorInvalidSymbol;
     a.coef1 = coef1; a.coef2 = coef2;
     a.n = d->n; a.h_in = d->h_in; a.w_in = d->w_in; a.c1 = d->c1; a.c2 = d->c2;
     a.h1 = d->h_src1; a.w1 = d->w_src1; a.gather1 = d->gather1;
