@@ -1572,8 +1572,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
         RCF_T(t_g3);
         RCF_TACC(2, t_g3, t_g2);   // 2: publishing barrier
         const int ntile = tile + gridDim.x;
-        // (issuing these loads in slices between the MFMA steps below was tried and is NOT faster: the phase is bound by the
-        // address arithmetic of the ~50 loads, not by the memory system accepting them -- tools/phase_timing_wgrad.py)
+        // (issuing these loads in slices between the MFMA steps below was tried twice -- as flat loads and, after the zero page
+        // became a kernel argument, as global loads -- and is NOT faster: +-2 % with fp32 tensors, -6...-15 % with bf16 tensors)
         if (ntile < a.ntiles) load_tile(ntile);
         RCF_T(t_g4);
         RCF_TACC(3, t_g4, t_g3);   // 3: address arithmetic + global-load issue of the next tile
