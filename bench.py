@@ -106,10 +106,22 @@ def spawn_ranks(args):
                     'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'HSA_ENABLE_IPC_MODE_LEGACY': '0',
                     'RCF_BENCH_SELF_SPAWNED': '1'})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # fail fast: a rank that dies would leave the others waiting in a collective until the backend's (30-minute) timeout
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                sys.stderr.write('bench.py: a rank exited with code %d; stopping the other %d\n' % (code, len(live)))
+                for q in live:
+                    q.terminate()
+        if live:
+            time.sleep(0.2)
     return rc
 
 

@@ -118,6 +118,15 @@ int rcf_conv2d_query(const rcf_conv_desc* d, rcf_conv_info* info);
 /* OIHW -> kernel layout [n-tile][k-chunk][tap][BN][CK].  Replaces nothing in the reference; it is the
  * price of keeping torch.nn.Conv2d.weight's layout at the boundary. */
 int rcf_conv2d_pack_weights(const rcf_conv_desc* d, const float* w_oihw, float* packed, void* stream);
+/* The same for n (descriptor, weight, destination) triples in ceil(n / 36) launches instead of n: a training step packs ~200
+ * weights of a few thousand elements each, every one a 4-5 us launch (all weights are constant from the start of the forward
+ * pass to the end of the backward pass, so the host can pack them all up front).  Results are identical to n single calls. */
+typedef struct rcf_pack_item {
+    const rcf_conv_desc* desc;
+    const float* w_oihw;
+    float* packed;
+} rcf_pack_item;
+int rcf_conv2d_pack_weights_batch(const rcf_pack_item* items, int n, void* stream);
 
 /* torch.nn.Conv2d.forward, bias=False (src/net_utils.py:85); with gather1=NEAREST also the F.interpolate of
  * UpConv2d.forward (src/net_utils.py:195-198); with c2>0 also the torch.cat of DecoderBlock.forward
@@ -156,6 +165,13 @@ int rcf_conv2d_wgrad_bn(const rcf_conv_desc* d, const void* in1, const float* co
  * rcf_conv2d_pack_weights (ksize 2, RCF_W_FORWARD).  rcf_phase_wgrad_fold maps the four 2x2 phase weight gradients
  * of an up-2x conv back to the 3x3 gradient: dw[o][i][ky][kx] = sum_{a,b} dwp[a][b][o][i][t(a,ky)][u(b,kx)]. */
 int rcf_phase_weights(const float* w_oihw, float* out, int o, int i, int mode, void* stream);
+/* n phase-weight transforms in ceil(n / 96) launches; identical results to n calls of rcf_phase_weights. */
+typedef struct rcf_phase_item {
+    const float* w_oihw;
+    float* out;
+    int o, i, mode;
+} rcf_phase_item;
+int rcf_phase_weights_batch(const rcf_phase_item* items, int n, void* stream);
 int rcf_phase_wgrad_fold(const float* dwp, float* dw_oihw, int o, int i, void* stream);
 /* Weight gradient of a 3x3 STRIDE-2 convolution from four 2x2 weight gradients: phase (a,b) is rcf_conv2d_wgrad of the descriptor
  * {ksize 2, pad 1, pad_x 1, gather1 RCF_GATHER_STRIDED2, in_off (a,b), source = the conv's input, h_in/w_in/h_out/w_out = the conv's

@@ -30,6 +30,14 @@ class ConvInfo(Structure):
                 ('bn_on_load', c_int), ('wgrad_bn_on_load', c_int), ('fwd_act', c_int)]
 
 
+class PackItem(Structure):     # rcf_pack_item
+    _fields_ = [('desc', POINTER(ConvDesc)), ('w_oihw', c_void_p), ('packed', c_void_p)]
+
+
+class PhaseItem(Structure):    # rcf_phase_item
+    _fields_ = [('w_oihw', c_void_p), ('out', c_void_p), ('o', c_int), ('i', c_int), ('mode', c_int)]
+
+
 RCF_PREC_FP32, RCF_PREC_BF16, RCF_PREC_BF16X3 = 0, 1, 2
 RCF_STORE_FP32, RCF_STORE_BF16 = 0, 1
 
@@ -39,6 +47,8 @@ _SIGNATURES = {
     'rcf_device_ok': (c_int, []),
     'rcf_conv2d_query': (c_int, [POINTER(ConvDesc), POINTER(ConvInfo)]),
     'rcf_conv2d_pack_weights': (c_int, [POINTER(ConvDesc), _P, _P, _P]),
+    'rcf_conv2d_pack_weights_batch': (c_int, [POINTER(PackItem), c_int, _P]),
+    'rcf_phase_weights_batch': (c_int, [POINTER(PhaseItem), c_int, _P]),
     'rcf_conv2d_fwd': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     'rcf_conv2d_fwd_bn': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'rcf_conv2d_fwd_act': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),

@@ -962,11 +962,10 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
 }
 
 // OIHW fp32 -> pre-split bf16 planes [n-tile][chunk][kernel row][plane][kx][BN][16], halves swapped when (co >> 3) & 1.
-__global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, size_t total_rows16, int w_o,
-                                          int w_i, int mode, int i_off, int c_out, int c1, int c2, int nchunk1, int nchunk, int BN,
-                                          int ks, int npl) {
+__device__ __forceinline__ void pack_weights_split_body(size_t idx, const float* __restrict__ w, unsigned short* __restrict__ dst,
+                                                        size_t total_rows16, int w_o, int w_i, int mode, int i_off, int c_out, int c1,
+                                                        int c2, int nchunk1, int nchunk, int BN, int ks, int npl) {
     // one thread per (n-tile, chunk, tap, co, k) element; writes its three planes
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total_rows16) return;
     size_t t = idx;
     const int k = t % 16; t /= 16;
@@ -1009,6 +1008,30 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned 
     dst[base + plane_elems] = (unsigned short)(x1 >> 16);
     dst[base + 2 * plane_elems] = (unsigned short)(x2 >> 16);
 }
+
+__global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, size_t total_rows16, int w_o,
+                                          int w_i, int mode, int i_off, int c_out, int c1, int c2, int nchunk1, int nchunk, int BN,
+                                          int ks, int npl) {
+    pack_weights_split_body((size_t)blockIdx.x * blockDim.x + threadIdx.x, w, dst, total_rows16, w_o, w_i, mode, i_off, c_out, c1, c2,
+                            nchunk1, nchunk, BN, ks, npl);
+}
+
+// Many weight packings in ONE launch (rcf_conv2d_pack_weights_batch): the per-item arguments travel by value in the kernel
+// argument block (<= 4 KB), a workgroup finds its item by its block index.  `split` items run pack_weights_split_body, the others
+// pack_weights_body.
+struct PackArgs {
+    const float* w;
+    void* dst;
+    unsigned long long total;
+    int w_o, w_i, ks, mode, i_off, c_out, c1, c2, nchunk1, nchunk, T, ksx, BN, CK, kind, npl, split;
+};
+constexpr int PACK_BATCH = 36;
+struct PackBatch {
+    int n;
+    unsigned blk_start[PACK_BATCH + 1];
+    PackArgs it[PACK_BATCH];
+};
+static_assert(sizeof(PackBatch) <= 4096, "the batch travels as kernel arguments");
 
 // ------------------------------------------------------------------------------------------------
 // Weight gradient.  GEMM view: dW[k][co] = sum_pixels A[pixel][k] * dZ[pixel][co]; MFMA rows i = 32
@@ -1754,10 +1777,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 }
 
 // OIHW -> [n-tile][chunk][tap][BN][CK].  kind 0 generic, 1 stem (k = kx*4 + c, tap = ky).
-__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ dst, size_t total, int w_o, int w_i,
-                                    int ks, int mode, int i_off, int c_out, int c1, int c2, int nchunk1, int nchunk,
-                                    int T, int ksx, int BN, int CK, int kind) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_weights_body(size_t idx, const float* __restrict__ w, float* __restrict__ dst, size_t total, int w_o,
+                                                  int w_i, int ks, int mode, int i_off, int c_out, int c1, int c2, int nchunk1, int nchunk,
+                                                  int T, int ksx, int BN, int CK, int kind) {
     if (idx >= total) return;
     size_t t = idx;
     const int k = t % CK;
@@ -1797,15 +1819,34 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     dst[idx] = v;
 }
 
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ dst, size_t total, int w_o, int w_i,
+                                    int ks, int mode, int i_off, int c_out, int c1, int c2, int nchunk1, int nchunk,
+                                    int T, int ksx, int BN, int CK, int kind) {
+    pack_weights_body((size_t)blockIdx.x * blockDim.x + threadIdx.x, w, dst, total, w_o, w_i, ks, mode, i_off, c_out, c1, c2, nchunk1,
+                      nchunk, T, ksx, BN, CK, kind);
+}
+
+__global__ void __launch_bounds__(256) pack_weights_batch_kernel(PackBatch b) {
+    int i = 0;
+    while (i + 1 < b.n && blockIdx.x >= b.blk_start[i + 1]) ++i;   // wave-uniform
+    const PackArgs& p = b.it[i];
+    const size_t idx = (size_t)(blockIdx.x - b.blk_start[i]) * 256 + threadIdx.x;
+    if (p.split)
+        pack_weights_split_body(idx, p.w, static_cast<unsigned short*>(p.dst), p.total, p.w_o, p.w_i, p.mode, p.i_off, p.c_out, p.c1,
+                                p.c2, p.nchunk1, p.nchunk, p.BN, p.ks, p.npl);
+    else
+        pack_weights_body(idx, p.w, static_cast<float*>(p.dst), p.total, p.w_o, p.w_i, p.ks, p.mode, p.i_off, p.c_out, p.c1, p.c2,
+                          p.nchunk1, p.nchunk, p.T, p.ksx, p.BN, p.CK, p.kind);
+}
+
 // Phase weights (see include/rcf_hip.h).  Up-2x: output row 2y+a reads source rows {y-1,y} (a=0) / {y,y+1} (a=1); 3x3 tap ky
 // lands on source tap t: a=0 -> (0,1,1), a=1 -> (0,0,1).  Stride-2 dgrad: input row 2y+a receives dZ rows y (tap 0) and y+1
 // (tap 1): a=0 -> ky (1, none), a=1 -> ky (2, 0).
 __device__ __forceinline__ int up2x_tap(int a, int k) { return a == 0 ? (k == 0 ? 0 : 1) : (k == 2 ? 1 : 0); }
 __device__ __forceinline__ int s2_tap_k(int a, int t) { return a == 0 ? (t == 0 ? 1 : -1) : (t == 0 ? 2 : 0); }
 
-__global__ void phase_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I, int mode) {
+__device__ __forceinline__ void phase_weights_body(int idx, const float* __restrict__ w, float* __restrict__ out, int O, int I, int mode) {
     const int total = 4 * O * I * 4;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     int t = idx;
     const int u = t & 1; t >>= 1;
@@ -1829,6 +1870,26 @@ __global__ void phase_weights_kernel(const float* __restrict__ w, float* __restr
         if (ky >= 0 && kx >= 0) v = w[((ip * I + op) * 3 + ky) * 3 + kx];
     }
     out[idx] = v;
+}
+
+__global__ void phase_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I, int mode) {
+    phase_weights_body(blockIdx.x * blockDim.x + threadIdx.x, w, out, O, I, mode);
+}
+
+struct PhaseArgs { const float* w; float* out; int O, I, mode, pad; };
+constexpr int PHASE_BATCH = 96;
+struct PhaseBatch {
+    int n;
+    unsigned blk_start[PHASE_BATCH + 1];
+    PhaseArgs it[PHASE_BATCH];
+};
+static_assert(sizeof(PhaseBatch) <= 4096, "the batch travels as kernel arguments");
+
+__global__ void __launch_bounds__(256) phase_weights_batch_kernel(PhaseBatch b) {
+    int i = 0;
+    while (i + 1 < b.n && blockIdx.x >= b.blk_start[i + 1]) ++i;   // wave-uniform
+    const PhaseArgs& p = b.it[i];
+    phase_weights_body((int)(blockIdx.x - b.blk_start[i]) * 256 + threadIdx.x, p.w, p.out, p.O, p.I, p.mode);
 }
 
 __global__ void phase_wgrad_fold_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int O, int I) {
@@ -2478,6 +2539,7 @@ int rcf_conv2d_fwd_act_b16impl(const rcf_conv_desc* d, const void* in1, const vo
                                const void* res, void* out, void* stream);
 int rcf_conv2d_wgrad_b16impl(const rcf_conv_desc* d, const void* in1, const void* in2, const void* dz, float* dw_oihw, float* workspace,
                              void* stream);
+int rcf_conv2d_pack_weights_batch_b16impl(const rcf_pack_item* items, int n, void* stream);
 int rcf_conv2d_wgrad_bn_b16impl(const rcf_conv_desc* d, const void* in1, const float* coef1, const void* in2, const float* coef2,
                                 const void* dz, float* dw_oihw, float* workspace, void* stream);
 }
@@ -2488,6 +2550,29 @@ extern "C" int rcf_phase_weights(const float* w_oihw, float* out, int o, int i, 
     if (!w_oihw || !out || o <= 0 || i <= 0 || mode < 0 || mode > 2) return RCF_EINVAL;
     const int total = 16 * o * i;
     hipLaunchKernelGGL(phase_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, out, o, i, mode);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_phase_weights_batch(const rcf_phase_item* items, int n, void* stream) {
+    if (!items || n <= 0) return RCF_EINVAL;
+    static PhaseBatch b;
+    int i = 0;
+    while (i < n) {
+        b.n = 0;
+        unsigned nblk = 0;
+        while (i < n && b.n < PHASE_BATCH) {
+            const rcf_phase_item& it = items[i];
+            if (!it.w_oihw || !it.out || it.o <= 0 || it.i <= 0 || it.mode < 0 || it.mode > 2) return RCF_EINVAL;
+            b.it[b.n].w = it.w_oihw; b.it[b.n].out = it.out; b.it[b.n].O = it.o; b.it[b.n].I = it.i; b.it[b.n].mode = it.mode; b.it[b.n].pad = 0;
+            b.blk_start[b.n] = nblk;
+            nblk += (unsigned)((16 * it.o * it.i + 255) / 256);
+            ++b.n;
+            ++i;
+        }
+        b.blk_start[b.n] = nblk;
+        for (int j = b.n + 1; j <= PHASE_BATCH; ++j) b.blk_start[j] = nblk;
+        if (nblk > 0) hipLaunchKernelGGL(phase_weights_batch_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, b);
+    }
     return rcf_launch_status();
 }
 
@@ -2547,9 +2632,9 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
     return RCF_OK;
 }
 
-extern "C" int RCF_FN(rcf_conv2d_pack_weights)(const rcf_conv_desc* d, const float* w_oihw, float* packed, void* stream) {
-    RCF_TO_B16(d, rcf_conv2d_pack_weights_b16impl(d, w_oihw, packed, stream));
-    if (!w_oihw || !packed) return RCF_EINVAL;
+// arguments of one weight packing (shared by the single and the batched entry point)
+static int pack_args(const rcf_conv_desc* d, const float* w_oihw, float* packed, PackArgs* p, unsigned* blocks) {
+    if (!d || !w_oihw || !packed) return RCF_EINVAL;
     Sel s;
     int rc = select_cfg(d, &s);
     if (rc != RCF_OK) return rc;
@@ -2557,19 +2642,70 @@ extern "C" int RCF_FN(rcf_conv2d_pack_weights)(const rcf_conv_desc* d, const flo
     fill_args(d, s, &a);
     const int ntile_n = ceil_div(d->c_out, s.bn);
     const int nchunk = a.nchunk1 + a.nchunk2;
-    const size_t total = (size_t)ntile_n * nchunk * s.t * s.bn * s.ck;
-    if (s.split) {
-        const size_t rows16 = (size_t)ntile_n * nchunk * s.t * s.bn * 16;
-        hipLaunchKernelGGL(pack_weights_split_kernel, dim3((unsigned)((rows16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                           reinterpret_cast<unsigned short*>(packed), rows16, d->w_o, d->w_i, d->w_mode, d->w_i_off, d->c_out, d->c1,
-                           d->c2, a.nchunk1, nchunk, s.bn, d->ksize, s.npl);
-        return rcf_launch_status();
+    p->w = w_oihw; p->dst = packed;
+    p->w_o = d->w_o; p->w_i = d->w_i; p->ks = d->ksize; p->mode = d->w_mode; p->i_off = d->w_i_off; p->c_out = d->c_out;
+    p->c1 = d->c1; p->c2 = d->c2; p->nchunk1 = a.nchunk1; p->nchunk = nchunk; p->T = s.t; p->BN = s.bn; p->CK = s.ck;
+    p->ksx = s.kind == K7S2 ? 1 : d->ksize; p->kind = s.kind == K7S2 ? 1 : 0; p->npl = s.npl; p->split = s.split ? 1 : 0;
+    p->total = s.split ? (unsigned long long)ntile_n * nchunk * s.t * s.bn * 16 : (unsigned long long)ntile_n * nchunk * s.t * s.bn * s.ck;
+    *blocks = (unsigned)((p->total + 255) / 256);
+    return RCF_OK;
+}
+
+extern "C" int RCF_FN(rcf_conv2d_pack_weights)(const rcf_conv_desc* d, const float* w_oihw, float* packed, void* stream) {
+    RCF_TO_B16(d, rcf_conv2d_pack_weights_b16impl(d, w_oihw, packed, stream));
+    if (!w_oihw || !packed) return RCF_EINVAL;
+    PackArgs p;
+    unsigned blocks = 0;
+    const int rc = pack_args(d, w_oihw, packed, &p, &blocks);
+    if (rc != RCF_OK) return rc;
+    if (p.split)
+        hipLaunchKernelGGL(pack_weights_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p.w, static_cast<unsigned short*>(p.dst),
+                           (size_t)p.total, p.w_o, p.w_i, p.mode, p.i_off, p.c_out, p.c1, p.c2, p.nchunk1, p.nchunk, p.BN, p.ks, p.npl);
+    else
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p.w, static_cast<float*>(p.dst), (size_t)p.total,
+                           p.w_o, p.w_i, p.ks, p.mode, p.i_off, p.c_out, p.c1, p.c2, p.nchunk1, p.nchunk, p.T, p.ksx, p.BN, p.CK, p.kind);
+    return rcf_launch_status();
+}
+
+// rcf_conv2d_pack_weights_batch: the items of THIS translation unit's storage, PACK_BATCH per launch
+extern "C" int RCF_FN(rcf_conv2d_pack_weights_batch)(const rcf_pack_item* items, int n, void* stream) {
+    if (!items || n <= 0) return RCF_EINVAL;
+#if !RCF_CONV_B16
+    {   // bf16-tensor descriptors go to the bf16 unit as one batch (a model uses one storage: all or nothing is the common case)
+        int nb = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!items[i].desc || !items[i].w_oihw || !items[i].packed) return RCF_EINVAL;
+            nb += items[i].desc->storage == RCF_STORE_BF16;
+        }
+        if (nb == n && n > 0) return rcf_conv2d_pack_weights_batch_b16impl(items, n, stream);
+        if (nb > 0) {
+            for (int i = 0; i < n; ++i) {
+                const int rc = items[i].desc->storage == RCF_STORE_BF16 ? rcf_conv2d_pack_weights_batch_b16impl(items + i, 1, stream)
+                                                                          : rcf_conv2d_pack_weights_batch(items + i, 1, stream);
+                if (rc != RCF_OK) return rc;
+            }
+            return RCF_OK;
+        }
     }
-    const int ksx = s.kind == K7S2 ? 1 : d->ksize;
-    const unsigned blocks = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, total, d->w_o,
-                       d->w_i, d->ksize, d->w_mode, d->w_i_off, d->c_out, d->c1, d->c2, a.nchunk1, nchunk, s.t, ksx, s.bn,
-                       s.ck, s.kind == K7S2 ? 1 : 0);
+#endif
+    static PackBatch b;   // ~3 KB: not on the stack of a ctypes caller's thread; single-threaded use like the rest of the library
+    int i = 0;
+    while (i < n) {
+        b.n = 0;
+        unsigned nblk = 0;
+        while (i < n && b.n < PACK_BATCH) {
+            unsigned blocks = 0;
+            const int rc = pack_args(items[i].desc, items[i].w_oihw, items[i].packed, &b.it[b.n], &blocks);
+            if (rc != RCF_OK) return rc;
+            b.blk_start[b.n] = nblk;
+            nblk += blocks;
+            ++b.n;
+            ++i;
+        }
+        b.blk_start[b.n] = nblk;
+        for (int j = b.n + 1; j <= PACK_BATCH; ++j) b.blk_start[j] = nblk;
+        if (nblk > 0) hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, b);
+    }
     return rcf_launch_status();
 }
 

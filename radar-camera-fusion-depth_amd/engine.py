@@ -21,6 +21,83 @@ from . import ops
 from ._lib import (RCF_ACT_LEAKY_RELU, RCF_ACT_NONE, RCF_GATHER_DIRECT, RCF_GATHER_NEAREST, RCF_PHASE_S2_DGRAD,
                    RCF_PHASE_UP2X_DGRAD, RCF_PHASE_UP2X_FWD)
 
+class WeightPlan(object):
+    '''
+    All weight transforms of a training step in a handful of launches.  A step packs ~200 weights into the kernels' layouts (the
+    forward form of every layer, the flipped form for its input gradient, the four 2x2 phase forms of the up-2x and stride-2
+    layers), each a 4-5 us launch of a few thousand elements: ~1 ms of GPU time and a fifth of the step's launches.  The weights
+    do not change between the start of the forward pass and the end of the backward pass, so they can all be packed up front.
+
+    The plan is positional.  In the first training step (state 'record') the engine's _phase_w / _pack / _pack_n do their work one
+    launch at a time, as without a plan, into PERSISTENT buffers and note (kind, descriptor, source pointers, buffer).  end() seals
+    the list into two ctypes arrays.  From then on (state 'replay') begin() issues rcf_phase_weights_batch +
+    rcf_conv2d_pack_weights_batch over the arrays -- they read the parameters' current values -- and the i-th request of the step
+    only checks that it is the request recorded at position i (same kind, descriptor bytes and source pointers) and returns the
+    buffer.  Any mismatch (another shape, another precision, a model that changed) marks the plan dirty: the rest of that step packs
+    one launch at a time again, and the next step records afresh.  Results are bitwise those of the unbatched path.
+    '''
+
+    def __init__(self):
+        self.state = 'off'      # 'off' | 'record' | 'replay'
+        self.entries = []
+        self.pos = 0
+        self.dirty = False
+        self._pack_items = self._phase_items = None
+        self._n_pack = self._n_phase = 0
+
+    def enable(self):
+        if self.state == 'off':
+            self.state = 'record'
+
+    def begin(self):
+        if self.state == 'off':
+            return
+        if self.state == 'replay' and not self.dirty:
+            if self._n_phase:
+                ops.phase_weights_batch(self._phase_items, self._n_phase)
+            if self._n_pack:
+                ops.conv_pack_batch(self._pack_items, self._n_pack)
+        else:
+            self.state, self.entries, self.dirty = 'record', [], False
+        self.pos = 0
+
+    def end(self):
+        if self.state == 'record':
+            self._seal()
+        elif self.state == 'replay' and self.pos != len(self.entries):
+            self.dirty = True
+
+    def _seal(self):
+        import ctypes
+        from ._lib import PackItem, PhaseItem
+        packs, phases = [], []
+        for e in self.entries:
+            if e['kind'] == 'phase':
+                phases.append((e['w'].data_ptr(), e['out'].data_ptr(), e['w'].shape[0], e['w'].shape[1], e['mode']))
+            else:
+                for w, dst in zip(e['srcs'], e['dsts']):
+                    packs.append((e['desc'], w.data_ptr(), dst.data_ptr()))
+        self._n_pack, self._n_phase = len(packs), len(phases)
+        self._pack_items = (PackItem * max(1, len(packs)))()
+        for i, (d, w, dst) in enumerate(packs):
+            self._pack_items[i].desc = ctypes.pointer(d)      # the descriptor object stays alive in its entry
+            self._pack_items[i].w_oihw = w
+            self._pack_items[i].packed = dst
+        self._phase_items = (PhaseItem * max(1, len(phases)))()
+        for i, (w, out, o, ii, mode) in enumerate(phases):
+            self._phase_items[i].w_oihw, self._phase_items[i].out = w, out
+            self._phase_items[i].o, self._phase_items[i].i, self._phase_items[i].mode = o, ii, mode
+        self.state = 'replay'
+
+    def _next(self, kind):
+        if self.dirty or self.pos >= len(self.entries) or self.entries[self.pos]['kind'] != kind:
+            self.dirty = True
+            return None
+        e = self.entries[self.pos]
+        self.pos += 1
+        return e
+
+
 BN_EPS = 1e-5       # torch.nn.BatchNorm2d default (src/net_utils.py:82)
 BN_MOMENTUM = 0.1
 
@@ -51,6 +128,7 @@ class Engine(object):
         self.on_param_grad = None  # callable(parameter): called once the parameter's gradient is enqueued
         self.tape = None
         self.training = True
+        self.plan = WeightPlan()   # batched weight transforms of a training step (off until the model enables it)
         self.kernel_log = None     # optional list collecting (layer, kernel_id) for profiling
         self.prof = None           # optional KernelTimer: brackets conv launches with events on the launch stream
         self.use_phase_convs = True  # exact-2x UpConv and stride-2 dgrad as 2x2 phase convs (False: 9-tap / zero-insert forms)
@@ -79,6 +157,49 @@ class Engine(object):
     def _newf(shape, ref):
         '''An fp32 buffer whatever the activation storage is: packed weights, coefficients, workspaces, single-channel maps.'''
         return torch.empty(shape, dtype=torch.float32, device=ref.device)
+
+
+    # ---- weight transforms (through the step's WeightPlan when it is active: training, tape on)
+    def _plan_on(self):
+        return self.tape is not None and self.plan.state != 'off'
+
+    def _phase_w(self, w, mode):
+        '''ops.phase_weights(w, mode): [4][O'][I'][2][2].'''
+        plan = self.plan
+        if not self._plan_on() or plan.dirty:
+            return ops.phase_weights(w, mode)
+        if plan.state == 'record':
+            out = ops.phase_weights(w, mode)
+            plan.entries.append({'kind': 'phase', 'w': w, 'mode': mode, 'out': out, 'ptr': w.data_ptr()})
+            return out
+        e = plan._next('phase')
+        if e is None or e['ptr'] != w.data_ptr() or e['mode'] != mode or tuple(e['w'].shape) != tuple(w.shape):
+            plan.dirty = True
+            return ops.phase_weights(w, mode)
+        return e['out']
+
+    def _pack(self, desc, w, like):
+        '''A packed-weight buffer holding ops.conv_pack(desc, w, .).'''
+        return self._pack_n(desc, [w], like)
+
+    def _pack_n(self, desc, ws, like):
+        '''len(ws) packings under one descriptor, back to back in one buffer (the four phases of a merged up-2x input gradient).'''
+        plan = self.plan
+        key = bytes(desc)
+        if self._plan_on() and not plan.dirty and plan.state == 'replay':
+            e = plan._next('pack')
+            if e is not None and e['key'] == key and e['ptrs'] == [w.data_ptr() for w in ws]:
+                return e['out']
+            plan.dirty = True
+        nf = ops.conv_query(desc).packed_weight_floats
+        out = self._newf((len(ws) * nf,), like)
+        dsts = [out[k * nf:(k + 1) * nf] for k in range(len(ws))]
+        for w, dst in zip(ws, dsts):
+            ops.conv_pack(desc, w, dst)
+        if self._plan_on() and not plan.dirty and plan.state == 'record':
+            plan.entries.append({'kind': 'pack', 'desc': desc, 'key': key, 'srcs': list(ws), 'ptrs': [w.data_ptr() for w in ws],
+                                 'dsts': dsts, 'out': out})
+        return out
 
     def _mat(self, x):
         '''The activation tensor of x; a deferred one (raw conv output + BN coefficients) is materialised once, on demand.'''
@@ -135,9 +256,12 @@ class Engine(object):
             t1 = self._mat(x)
         if x2 is not None and t2 is None:
             t2 = self._mat(x2)
-        packed = self._newf((info.packed_weight_floats,), t1)
         fused = fold is not None and info.fwd_act and k1 is None and k2 is None
-        ops.conv_pack(desc, ops.scale_channels(weight.detach(), fold[0][0]) if fused else weight.detach(), packed)
+        if fused:
+            packed = self._newf((info.packed_weight_floats,), t1)
+            ops.conv_pack(desc, ops.scale_channels(weight.detach(), fold[0][0]), packed)
+        else:
+            packed = self._pack(desc, weight.detach(), t1)
         z = self._new((n, desc.h_out, desc.w_out, desc.c_out), t1)
         partials = torch.empty((info.n_partials, 2, desc.c_out), dtype=torch.float64, device=t1.device) if want_stats else None
         if self.prof is not None:
@@ -157,8 +281,7 @@ class Engine(object):
 
     def _run_packed(self, desc, w_oihw, in1, out, partials=None, coef1=None, bias=None):
         info = ops.conv_query(desc)
-        packed = self._newf((info.packed_weight_floats,), in1)
-        ops.conv_pack(desc, w_oihw, packed)
+        packed = self._pack(desc, w_oihw, in1)
         if self.prof is not None:
             self.prof.begin(info.kernel_id, ops.algorithmic_flops(desc), desc)
         if bias is not None:
@@ -186,8 +309,8 @@ class Engine(object):
                 qi = ops.conv_query(d)
                 n_part = qi.n_partials
                 fused = fold is not None and bool(qi.fwd_act) and fold[1] is None
-                wsrc = ops.scale_channels(weight.detach(), fold[0][0]) if fused else weight.detach()
-                wp = ops.phase_weights(wsrc, RCF_PHASE_UP2X_FWD)
+                wp = ops.phase_weights(ops.scale_channels(weight.detach(), fold[0][0]), RCF_PHASE_UP2X_FWD) if fused else \
+                    self._phase_w(weight.detach(), RCF_PHASE_UP2X_FWD)
                 t1, k1 = self._src(x, qi.bn_on_load and not fused)
                 if t1 is None:
                     t1 = self._mat(x)
@@ -253,7 +376,7 @@ class Engine(object):
             raise ValueError('transposed convolution: channel counts must be multiples of 4 and match the input')
         virt = ops.make_fwd_desc(n, 2 * h, 2 * w, co, 0, ci, 3, 2)       # the convolution this one is the transpose of
         t1 = self._mat(x)
-        wd = ops.phase_weights(weight.detach(), RCF_PHASE_S2_DGRAD)
+        wd = self._phase_w(weight.detach(), RCF_PHASE_S2_DGRAD)
         z = self._new((n, 2 * h, 2 * w, co), t1)
         partials, n_part = None, 0
         for ph in range(4):
@@ -313,15 +436,13 @@ class Engine(object):
         ops.phase_wgrad_fold(dwp, self.grad_of(weight))
         self._wgrad_done(weight)
         if x.needs_grad:
-            wd = ops.phase_weights(weight.detach(), RCF_PHASE_UP2X_DGRAD)
+            wd = self._phase_w(weight.detach(), RCF_PHASE_UP2X_DGRAD)
             acc = x.g is not None
             if not acc:
                 x.g = self._new(tuple(self._shape(x)), dz)
             dd = ops.make_up2x_dgrad_desc(n, h, w, c1, co, 0, 0, acc, phase_sum=True)
             qi = ops.conv_query(dd)
-            packed = self._newf((4 * qi.packed_weight_floats,), dz)
-            for ph in range(4):
-                ops.conv_pack(dd, wd[ph], packed[ph * qi.packed_weight_floats:(ph + 1) * qi.packed_weight_floats])
+            packed = self._pack_n(dd, [wd[ph] for ph in range(4)], dz)
             if self.prof is not None:
                 self.prof.begin(qi.kernel_id, ops.algorithmic_flops(dd), dd)
             ops.conv_fwd(dd, dz, None, packed, x.g, None)
@@ -387,7 +508,7 @@ class Engine(object):
                 acc = src.g is not None
                 if not acc:
                     src.g = self._new(tuple(self._shape(src)), dz)
-                wd = ops.phase_weights(weight.detach(), RCF_PHASE_S2_DGRAD)
+                wd = self._phase_w(weight.detach(), RCF_PHASE_S2_DGRAD)
                 for ph in range(4):
                     self._run_packed(ops.make_s2_dgrad_desc(desc, ph >> 1, ph & 1, acc), wd[ph], dz, src.g)
             else:
@@ -399,8 +520,7 @@ class Engine(object):
 
     def _run_dgrad(self, dd, weight, dz, out):
         info = ops.conv_query(dd)
-        packed = self._newf((info.packed_weight_floats,), dz)
-        ops.conv_pack(dd, weight.detach(), packed)
+        packed = self._pack(dd, weight.detach(), dz)
         if self.prof is not None:
             self.prof.begin(info.kernel_id, ops.algorithmic_flops(dd), dd)
         ops.conv_fwd(dd, dz, None, packed, out, None)

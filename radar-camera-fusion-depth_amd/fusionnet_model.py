@@ -16,6 +16,8 @@ what the bucketed RCCL all-reduce and the fused Adam operate on).  There is no C
 CPU tensor raises.
 '''
 
+import os
+
 import torch
 
 from . import _lib, networks, ops
@@ -242,6 +244,12 @@ class FusionNetModel(object):
 
     # ------------------------------------------------------------------ engine entry points
     # ------------------------------------------------------------------ arithmetic of the convolutions
+    batch_weight_packing = os.environ.get('RCF_BATCH_PACK', '1') != '0'
+    '''
+    Training: pack all weights of a step with a few batched launches at the start of the forward pass instead of ~200 small launches
+    spread over the step (engine.WeightPlan; bitwise the same results).  RCF_BATCH_PACK=0 switches it off.
+    '''
+
     compute_dtype = 'fp32'
     '''
     'fp32' (default): the reference's arithmetic (exact fp32 products).  'bf16': bf16 tensors in HBM and bf16 matrix operands,
@@ -275,6 +283,10 @@ class FusionNetModel(object):
         training = self._training
         image, input_depth = image.contiguous(), input_depth.contiguous()
         hw = (int(image.shape[2]), int(image.shape[3]))
+        if record and training:   # every weight transform of the step in a few launches, up front (engine.WeightPlan)
+            if self.batch_weight_packing:
+                self._engine.plan.enable()
+            self._engine.plan.begin()
         if ops.act_dtype() == torch.bfloat16 and image.shape[1] <= 4 and input_depth.shape[1] <= 4:
             # bf16 configuration: the stems run on the space-to-depth image, built straight from the NCHW inputs; the fp32 NHWC
             # copies are only read by the stems' weight gradients
@@ -303,6 +315,7 @@ class FusionNetModel(object):
                 Engine.backward(out, tape, ddepth)
         finally:
             ops.set_precision('fp32')
+        self._engine.plan.end()
         if self._dp is not None:
             self._dp.finish_backward()
         if prev is not None:

@@ -262,6 +262,15 @@ def conv_pack(desc, w_oihw, packed):
           'rcf_conv2d_pack_weights')
 
 
+def conv_pack_batch(items, n):
+    """items: ctypes array of _lib.PackItem (built once, reused every step); rcf_conv2d_pack_weights_batch."""
+    check(_lib.load().rcf_conv2d_pack_weights_batch(items, n, _stream()), 'rcf_conv2d_pack_weights_batch')
+
+
+def phase_weights_batch(items, n):
+    check(_lib.load().rcf_phase_weights_batch(items, n, _stream()), 'rcf_phase_weights_batch')
+
+
 def conv_fwd(desc, in1, in2, packed, out, stat_partials=None, coef1=None, coef2=None):
     """coef1 / coef2: in1 / in2 are raw conv outputs whose BatchNorm + lrelu is applied on load (rcf_conv_info.bn_on_load)."""
     # the 7x7 stems read the fp32 network input whatever the storage is (include/rcf_hip.h, rcf_conv_desc.storage)

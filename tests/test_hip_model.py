@@ -382,6 +382,7 @@ def _dp_gpu_worker(rank, world, port, tmpdir):
     dist.destroy_process_group()
 
 
+@pytest.mark.timeout(300)   # a rank that never joins must not hold the suite
 def test_data_parallel_step_two_ranks_on_one_gpu(env, tmp_path):
     '''
     The DP training step end to end (bucketed SUM all-reduce launched from the tape, loss normalised by the GLOBAL valid
@@ -603,3 +604,106 @@ def test_captured_training_step_full_resolution_matches_eager(env):
         torch.cuda.empty_cache()
     assert res['eager'][0] == res['graph'][0]
     assert torch.equal(res['eager'][1], res['graph'][1])
+
+
+# ---------------------------------------------------------------- batched weight packing (engine.WeightPlan)
+@pytest.mark.gpu
+def test_batched_pack_and_phase_weights_equal_the_single_calls():
+    '''rcf_conv2d_pack_weights_batch / rcf_phase_weights_batch against n calls of the single entry points: bitwise, for every kind of
+    item a training step holds (split 3-plane / 2-plane / bf16 forward and input-gradient forms, f32-MFMA forms, stems, phases).'''
+    import ctypes
+    import rcf_amd  # noqa: F401
+    from rcf_amd import _lib, ops
+    from rcf_amd._lib import RCF_PHASE_S2_DGRAD, RCF_PHASE_UP2X_DGRAD, RCF_PHASE_UP2X_FWD
+    g = torch.Generator().manual_seed(3)
+    items, keep = [], []
+    for prec in ('fp32', 'bf16x3', 'bf16'):
+        ops.set_precision(prec)
+        try:
+            for (k, s, c1, c2, co) in [(3, 1, 64, 0, 64), (3, 1, 64, 32, 64), (3, 1, 32, 0, 32), (1, 1, 32, 0, 64), (3, 2, 32, 0, 64), (3, 1, 256, 0, 256),
+                                       (3, 1, 128, 128, 128), (1, 2, 32, 0, 64)]:
+                w = (torch.rand(co, c1 + c2, k, k, generator=g) - 0.5).cuda()
+                d = ops.make_fwd_desc(2, 40, 56, c1, c2, co, k, s)
+                items.append((d, w))
+                if s == 1 and k == 3:
+                    items.append((ops.make_dgrad_desc(d, 0, c1, False), w))
+            if prec != 'bf16':
+                w7 = (torch.rand(32, 3, 7, 7, generator=g) - 0.5).cuda()
+                items.append((ops.make_fwd_desc(2, 70, 102, 3, 0, 32, 7, 2), w7))
+            wp = ops.phase_weights((torch.rand(32, 64, 3, 3, generator=g) - 0.5).cuda(), RCF_PHASE_UP2X_FWD)
+            keep.append(wp)
+            items.append((ops.make_up2x_fwd_desc(2, 20, 28, 64, 32, 1, 0), wp[2]))
+        finally:
+            ops.set_precision('fp32')
+    n = len(items)
+    assert n > 36                                  # more than one launch of the batched kernel
+    single, batched = [], []
+    arr = (_lib.PackItem * n)()
+    for i, (d, w) in enumerate(items):
+        nf = ops.conv_query(d).packed_weight_floats
+        a = torch.full((nf,), float('nan'), device='cuda')
+        b = torch.full((nf,), float('nan'), device='cuda')
+        ops.conv_pack(d, w, a)
+        single.append(a); batched.append(b)
+        arr[i].desc = ctypes.pointer(d)
+        arr[i].w_oihw = w.data_ptr()
+        arr[i].packed = b.data_ptr()
+    ops.conv_pack_batch(arr, n)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(single, batched)):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), i
+    # phase weights
+    ws = [(torch.rand(o, i, 3, 3, generator=g) - 0.5).cuda() for (o, i) in [(32, 64), (64, 64), (128, 64), (4, 8)]]
+    modes = [RCF_PHASE_UP2X_FWD, RCF_PHASE_UP2X_DGRAD, RCF_PHASE_S2_DGRAD]
+    parr = (_lib.PhaseItem * (len(ws) * len(modes)))()
+    outs, refs = [], []
+    for wi, w in enumerate(ws):
+        for mi, m in enumerate(modes):
+            r = ops.phase_weights(w, m)
+            o = torch.full_like(r, float('nan'))
+            it = parr[wi * len(modes) + mi]
+            it.w_oihw, it.out, it.o, it.i, it.mode = w.data_ptr(), o.data_ptr(), w.shape[0], w.shape[1], m
+            outs.append(o); refs.append(r)
+    ops.phase_weights_batch(parr, len(outs))
+    torch.cuda.synchronize()
+    for o, r in zip(outs, refs):
+        assert torch.equal(o, r)
+    # invalid items are refused before anything is launched
+    arr[0].packed = None
+    with pytest.raises(_lib.RcfError):
+        ops.conv_pack_batch(arr, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['fp32', 'bf16x3', 'bf16'])
+def test_weight_plan_training_is_bitwise_the_unbatched_training(env, golden_dir, mode):
+    '''Three Adam steps with the step's weight transforms batched up front (engine.WeightPlan, default) against the same steps with
+    one launch per transform (batch_weight_packing = False): parameters, loss and BatchNorm buffers bitwise equal; the plan replays
+    (>= 60 recorded requests); a change of input size falls back and re-records without changing results.'''
+    synth, train = env
+    g = np.load(os.path.join(golden_dir, 'T2_tiny_adam3.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    res = {}
+    for batched in (True, False):
+        m = _build(env, synth.PUBLISHED, wseed)
+        m.batch_weight_packing = batched
+        m.compute_dtype = mode
+        m.train()
+        opt = train.make_optimizer(m, lr=1e-3)
+        losses = []
+        sizes = [(h, w), (h, w), (h, w), (h + 16, w), (h + 16, w), (h, w)]
+        for step, (hh, ww) in enumerate(sizes):
+            b = _gpu_batch(synth.make_batch(n, hh, ww, k, seed=dseed + step))
+            losses.append(float(train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])[0].detach()))
+            if batched and step == 2:
+                assert m._engine.plan.state == 'replay' and not m._engine.plan.dirty and len(m._engine.plan.entries) >= 60
+            if batched and step == 3:
+                assert m._engine.plan.dirty or m._engine.plan.state == 'record' or m._engine.plan.pos == len(m._engine.plan.entries)
+        if not batched:
+            assert m._engine.plan.state == 'off'
+        torch.cuda.synchronize()
+        res[batched] = (losses, m._param_arena.clone(), [b.clone() for _, b in _named(m, 'b')])
+    assert res[True][0] == res[False][0], (res[True][0], res[False][0])
+    assert torch.equal(res[True][1], res[False][1])
+    for a, b in zip(res[True][2], res[False][2]):
+        assert torch.equal(a, b)

@@ -184,6 +184,7 @@ def _dp_worker(rank, world, port, tmpdir):
     dist.destroy_process_group()
 
 
+@pytest.mark.timeout(300)   # a rank that never joins must not hold the suite
 def test_gradient_buckets_all_reduce_two_ranks_gloo(pkg, tmp_path):
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() % 2000)
