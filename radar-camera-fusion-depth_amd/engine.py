@@ -42,6 +42,8 @@ class WeightPlan(object):
         self.entries = []
         self.pos = 0
         self.dirty = False
+        self.active = False         # between begin() and end(): the forward AND the backward pass of one training step
+        self.last_mismatch = None   # (position, requested kind, what differed): diagnostics
         self._pack_items = self._phase_items = None
         self._n_pack = self._n_phase = 0
 
@@ -60,8 +62,12 @@ class WeightPlan(object):
         else:
             self.state, self.entries, self.dirty = 'record', [], False
         self.pos = 0
+        self.active = True
 
     def end(self):
+        if not self.active:
+            return
+        self.active = False
         if self.state == 'record':
             self._seal()
         elif self.state == 'replay' and self.pos != len(self.entries):
@@ -91,6 +97,8 @@ class WeightPlan(object):
 
     def _next(self, kind):
         if self.dirty or self.pos >= len(self.entries) or self.entries[self.pos]['kind'] != kind:
+            if not self.dirty:
+                self.last_mismatch = (self.pos, kind, self.entries[self.pos]['kind'] if self.pos < len(self.entries) else 'past the end')
             self.dirty = True
             return None
         e = self.entries[self.pos]
@@ -161,7 +169,7 @@ class Engine(object):
 
     # ---- weight transforms (through the step's WeightPlan when it is active: training, tape on)
     def _plan_on(self):
-        return self.tape is not None and self.plan.state != 'off'
+        return self.plan.active
 
     def _phase_w(self, w, mode):
         '''ops.phase_weights(w, mode): [4][O'][I'][2][2].'''
@@ -190,6 +198,8 @@ class Engine(object):
             e = plan._next('pack')
             if e is not None and e['key'] == key and e['ptrs'] == [w.data_ptr() for w in ws]:
                 return e['out']
+            if e is not None:
+                plan.last_mismatch = (plan.pos - 1, 'pack', 'descriptor' if e['key'] != key else 'source pointer')
             plan.dirty = True
         nf = ops.conv_query(desc).packed_weight_floats
         out = self._newf((len(ws) * nf,), like)

@@ -283,6 +283,7 @@ class FusionNetModel(object):
         training = self._training
         image, input_depth = image.contiguous(), input_depth.contiguous()
         hw = (int(image.shape[2]), int(image.shape[3]))
+        self._engine.plan.active = False
         if record and training:   # every weight transform of the step in a few launches, up front (engine.WeightPlan)
             if self.batch_weight_packing:
                 self._engine.plan.enable()
