@@ -39,6 +39,14 @@ __device__ __forceinline__ unsigned rcf_f2b(float x) {
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 __device__ __forceinline__ float rcf_b2f(unsigned h) { return __uint_as_float(h << 16); }
+// two at once, packed (lo in bits 0-15): one v_cvt_pk_bf16_f32 on gfx950 instead of 2 x (bfe, add3, shift) + or; the same
+// round-to-nearest-even on every finite value
+typedef __bf16 rcf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rcf_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned rcf_f2b2(float lo, float hi) {
+    const rcf_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, rcf_bf16x2));
+}
 // the value a bf16 tensor will hold for x (fp32 tensors: x itself)
 template <class S>
 __device__ __forceinline__ float rcf_round_st(float x) { return S::B16 ? rcf_b2f(rcf_f2b(x)) : x; }
@@ -75,8 +83,8 @@ template <class S>
 __device__ __forceinline__ void rcf_st4(float* p, size_t i, f32x4 v) {
     if constexpr (S::B16) {
         rcf_u32x2 w;
-        w[0] = rcf_f2b(v[0]) | (rcf_f2b(v[1]) << 16);
-        w[1] = rcf_f2b(v[2]) | (rcf_f2b(v[3]) << 16);
+        w[0] = rcf_f2b2(v[0], v[1]);
+        w[1] = rcf_f2b2(v[2], v[3]);
         *reinterpret_cast<rcf_u32x2*>(reinterpret_cast<unsigned short*>(p) + i) = w;
     } else {
         *reinterpret_cast<f32x4*>(p + i) = v;

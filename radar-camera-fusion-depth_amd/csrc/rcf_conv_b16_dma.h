@@ -335,11 +335,11 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                                 lo += alo;
                                 hi += ahi;
                             }
-                            const unsigned blo = rcf_f2b(lo), bhi = rcf_f2b(hi);
+                            const unsigned pk = rcf_f2b2(lo, hi);
                             if (ok) {
-                                *reinterpret_cast<unsigned*>(outp + pbs[g] + cp) = blo | (bhi << 16);
+                                *reinterpret_cast<unsigned*>(outp + pbs[g] + cp) = pk;
                                 if (want_stats) {   // of the values the tensor holds
-                                    const float rlo = rcf_b2f(blo), rhi = rcf_b2f(bhi);
+                                    const float rlo = __uint_as_float(pk << 16), rhi = __uint_as_float(pk & 0xffff0000u);
                                     s1[ni][0] += rlo; s2[ni][0] += rlo * rlo;
                                     s1[ni][1] += rhi; s2[ni][1] += rhi * rhi;
                                 }
@@ -542,11 +542,11 @@ __global__ void __launch_bounds__(256, 2) conv1x1_b16_kernel(ConvArgs a) {
                             lo += __uint_as_float(oldw[g][ni] << 16);
                             hi += __uint_as_float(oldw[g][ni] & 0xffff0000u);
                         }
-                        const unsigned blo = rcf_f2b(lo), bhi = rcf_f2b(hi);
+                        const unsigned pk = rcf_f2b2(lo, hi);
                         if (ok) {
-                            *reinterpret_cast<unsigned*>(outp + (size_t)p * a.c_out + cp) = blo | (bhi << 16);
+                            *reinterpret_cast<unsigned*>(outp + (size_t)p * a.c_out + cp) = pk;
                             if (want_stats) {
-                                const float rlo = rcf_b2f(blo), rhi = rcf_b2f(bhi);
+                                const float rlo = __uint_as_float(pk << 16), rhi = __uint_as_float(pk & 0xffff0000u);
                                 s1[ni][0] += rlo; s2[ni][0] += rlo * rlo;
                                 s1[ni][1] += rhi; s2[ni][1] += rhi * rhi;
                             }
