@@ -25,7 +25,8 @@ rocprofv3 --kernel-trace --stats -d /tmp/trace_inf_$tag -o r -- python3 bench.py
 python3 tools/trace_summary.py /tmp/trace_inf_$tag 8 40 > $out/bf16_infer_kernels.txt
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   d=$out/pmc/$(echo $set | cut -d' ' -f1)
-  rocprofv3 --pmc $set --output-format csv -d $d -o b -- python3 bench.py --graph 0 --steps 1 --warmup 1 --preheat-s 0 --no-cpu-baseline --no-side-leg > $d.log 2>&1
+  # RCF_BATCH_PACK=0: the warm-up step and the counted step then issue the same dispatches (make_profile.py takes the second half)
+  RCF_BATCH_PACK=0 rocprofv3 --pmc $set --output-format csv -d $d -o b -- python3 bench.py --graph 0 --steps 1 --warmup 1 --preheat-s 0 --no-cpu-baseline --no-side-leg > $d.log 2>&1
 done
 python3 tools/make_profile.py /tmp/trace_$tag $out/pmc $out/trace_bench_line.json $tag $head > $out/make_profile.log 2>&1
 mkdir -p $out/profiles && cp profiles/${tag}_* $out/profiles/ 2>/dev/null
