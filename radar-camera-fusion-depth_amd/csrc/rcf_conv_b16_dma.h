@@ -260,6 +260,10 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                     eb[ni][0] = a.bias[cp < a.c_out ? cp : 0];
                     eb[ni][1] = a.bias[cp + 1 < a.c_out ? cp + 1 : 0];
                 }
+                // land the bias loads here: used first inside the masked store blocks, they put an s_waitcnt vmcnt(0) -- which also
+                // waits for the previous store -- in front of every store of the inference epilogue
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(eb[ni][0]), "+v"(eb[ni][1]));
             }
             // ADD (accumulate into out / add the residual) is a COMPILE-TIME variant of the loop: the plain path must contain no
             // load at all -- gfx9 counts stores in vmcnt, so one load in the loop makes hipcc wait for every previous store before
@@ -306,6 +310,12 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                                 const int cp = (n0 + ni * 32 + li) & ~1;
                                 oldw[g][ni] = *reinterpret_cast<const unsigned*>(addp + ((poks[g] && cp < a.c_out) ? pbs[g] + cp : 0));
                             }
+                        // one wait for all of them HERE (the empty asm uses the registers): left to the first use inside the masked
+                        // store blocks below, hipcc waits with vmcnt(0) in every block -- i.e. for the previous block's store too
+#pragma unroll
+                        for (int g = 0; g < 8; ++g)
+#pragma unroll
+                            for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(oldw[g][ni]));
                     }
 #pragma unroll
                     for (int g = 0; g < 8; ++g) {
@@ -525,6 +535,10 @@ __global__ void __launch_bounds__(256, 2) conv1x1_b16_kernel(ConvArgs a) {
                             oldw[g][ni] = *reinterpret_cast<const unsigned*>(outp + ((p < npix && cp < a.c_out) ? (size_t)p * a.c_out + cp : 0));
                         }
                     }
+#pragma unroll
+                    for (int g = 0; g < 8; ++g)   // one wait for all of them here, not a vmcnt(0) in front of every masked store below
+#pragma unroll
+                        for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(oldw[g][ni]));
                 }
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {

@@ -808,6 +808,9 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                             const int co = n0 + ni * 32 + li;
                             ebias[ni] = a.bias[co < a.c_out ? co : 0];
                         }
+                        // land the bias loads here, not inside every masked store block below (see the note on `old`)
+#pragma unroll
+                        for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(ebias[ni]));
                     }
                     const bool add_old = EPI ? a.res != nullptr : a.accumulate != 0;
 #pragma unroll
