@@ -868,16 +868,25 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                         const int co = n0 + ni * 32 + li;
                                         old[j][ni] = rcf_ld1<SO>(addsrc, (pok[j] && co < a.c_out) ? pbase[j] + co : 0);
                                     }
-                                // Land the loads INSIDE this branch (the empty asm uses the registers, so the s_waitcnt goes here).
+                                if constexpr (!EPI) {   // gradient accumulation: straight into the accumulators, inside this branch
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                        for (int ni = 0; ni < C::NT; ++ni) acc[mi][ni][r0 + j] += old[j][ni];
+                                }
+                                // Land the loads INSIDE this branch (training: by adding them into the accumulators here; inference: the
+                                // empty asm below uses the registers -- either way the s_waitcnt goes here).
                                 // On gfx9 stores count in vmcnt like loads: with the old values still pending at the join, hipcc put an
                                 // s_waitcnt vmcnt(0) in front of EVERY store -- of the plain path too -- and the 64 stores of a tile
                                 // ran one HBM round trip after the other (20-40 % of a wave's time).  (Wrapping the body in a lambda with
                                 // a compile-time ADD instead costs the 512-pixel configuration ~60 spilled VGPRs: measured, slower.)
+                                if constexpr (EPI) {
 #pragma unroll
-                                for (int j = 0; j < 4; ++j)
+                                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                                    for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(old[j][ni]));
-                            } else {
+                                        for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(old[j][ni]));
+                                }
+                            } else if constexpr (EPI) {
 #pragma unroll
                                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -889,9 +898,9 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                 for (int ni = 0; ni < C::NT; ++ni) {
                                     const int co = n0 + ni * 32 + li;
                                     if (pok[j] && co < a.c_out) {
-                                        float v = acc[mi][ni][r0 + j] + (EPI ? ebias[ni] : old[j][ni]);
+                                        float v = acc[mi][ni][r0 + j];
                                         if (EPI) {
-                                            v = rcf_lrelu(v);
+                                            v = rcf_lrelu(v + ebias[ni]);
                                             if (a.res != nullptr) v = rcf_lrelu(v + old[j][ni]);
                                         }
                                         v = rcf_round_st<SO>(v);   // BatchNorm statistics of the values the tensor holds
