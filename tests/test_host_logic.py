@@ -299,3 +299,17 @@ def test_bench_expected_loss_fixture_is_the_oracle_on_the_bench_inputs(pkg):
     assert 'train_b8_900x1600_p64' in rec and rec['train_b8_900x1600_p64']['first_step_loss'] > 0
     got = mk.first_step_loss(2, 224, 384, 32)
     assert abs(got - rec['train_b2_224x384_p32']['first_step_loss']) < 1e-5 * abs(got)
+
+
+def test_generated_code_of_the_small_units_is_clean():
+    '''tools/isa_lint.py (no GPU: hipcc -S for gfx950) on the elementwise / format / transform units: no flat accesses, no GOT loads,
+    no spills, no store sitting behind an s_waitcnt vmcnt(0) -- the four code-generation patterns that cost the convolution
+    kernels 3-30 % before they were found.  The two convolution units take minutes and are linted by hand.'''
+    import subprocess, sys
+    units = [os.path.join(ROOT, 'radar-camera-fusion-depth_amd', 'csrc', u) for u in ('rcf_elementwise.hip', 'rcf_formats.hip', 'rcf_transforms.hip')]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'isa_lint.py')] + units, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.endswith('flagged')]
+    assert len(lines) == 3, r.stdout[-800:]
+    for ln in lines:
+        assert ln.endswith(' 0 flagged'), r.stdout[-1500:]
