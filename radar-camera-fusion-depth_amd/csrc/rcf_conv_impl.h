@@ -432,6 +432,29 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
 //  * activations are split while staged (and/sub, ~5.5 VALU per element); weights are pre-split by the pack kernel.
 //  * persistent + register-prefetched like conv_fwd_kernel; same epilogue (store, +=, fp64 BN statistics).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// The matrix instruction of the split kernels.  Diagnostics build -DRCF_X3_F16 (tools/f16_plane_probe.py): the TWO-plane variants
+// carry fp16 planes (11 + 11 significant bits, no scaling: a probe for data inside fp16's range) instead of bf16 planes (8 + 8).
+#ifdef RCF_X3_F16
+typedef _Float16 rcf_f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 rcf_f16x2 __attribute__((ext_vector_type(2)));
+struct rcf_f16_pair { unsigned p0, p1; };
+// two fp32 -> (fp16 plane 0, fp16 plane 1) dwords, value `a` in the low half
+__device__ __forceinline__ rcf_f16_pair rcf_f16_planes(float a, float b) {
+    const rcf_f16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    rcf_f16_pair r;
+    r.p0 = __builtin_bit_cast(unsigned, h);
+    r.p1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]));
+    return r;
+}
+#endif
+template <int NPL>
+__device__ __forceinline__ f32x16 rcf_mfma_split(bf16x8 a, bf16x8 b, f32x16 c) {
+#ifdef RCF_X3_F16
+    if constexpr (NPL == 2)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rcf_f16x8, a), __builtin_bit_cast(rcf_f16x8, b), c, 0, 0, 0);
+#endif
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -643,6 +666,13 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                 } else {
                     u32x2 w0 = {(x0[0] >> 16) | x0[1], (x0[2] >> 16) | x0[3]};
                     u32x2 w1 = {(x1[0] >> 16) | x1[1], (x1[2] >> 16) | x1[3]};
+#ifdef RCF_X3_F16
+                    if (C::NPL == 2) {
+                        const rcf_f16_pair q0 = rcf_f16_planes(xin[0], xin[1]), q1 = rcf_f16_planes(xin[2], xin[3]);
+                        w0[0] = q0.p0; w1[0] = q0.p1;
+                        w0[1] = q1.p0; w1[1] = q1.p1;
+                    }
+#endif
                     u32x2 w2 = {(x2[0] >> 16) | (x2[1] & 0xffff0000u), (x2[2] >> 16) | (x2[3] & 0xffff0000u)};
                     *reinterpret_cast<u32x2*>(dst) = w0;
                     *reinterpret_cast<u32x2*>(dst + C::A_PLANE_BYTES) = w1;
@@ -761,7 +791,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                     constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};                    // two planes: a1b0, a0b1, a0b0
                     const int pj = j / MN, mi = (j % MN) / C::NT, ni = j % C::NT;
                     const int pa = C::NPL == 3 ? PA[pj] : (C::NPL == 2 ? PA2[pj % 3] : 0), pbl = C::NPL == 3 ? PB[pj] : (C::NPL == 2 ? PB2[pj % 3] : 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][pa][mi], bv[cur][pbl][ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = rcf_mfma_split<C::NPL>(av[cur][pa][mi], bv[cur][pbl][ni], acc[mi][ni]);
                     if (has_next) {
 #pragma unroll
                         for (int rep = 0; rep < 3; ++rep) {
@@ -1013,6 +1043,14 @@ __device__ __forceinline__ void pack_weights_split_body(size_t idx, const float*
     }
     dst[base] = (unsigned short)(x0 >> 16);
     if (npl == 2) {   // RCF_PREC_BF16X3: the second plane is the remainder rounded to nearest even
+#ifdef RCF_X3_F16
+        {
+            const rcf_f16_pair q = rcf_f16_planes(v, 0.f);
+            dst[base] = (unsigned short)q.p0;
+            dst[base + plane_elems] = (unsigned short)q.p1;
+            return;
+        }
+#endif
         const unsigned u = __float_as_uint(r1);
         dst[base + plane_elems] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
         return;
@@ -1530,6 +1568,13 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 w0[d] = __builtin_amdgcn_perm(x0[1], x0[0], 0x07060302u);   // high halves of the pixel pair
                 w1[d] = __builtin_amdgcn_perm(x1[1], x1[0], 0x07060302u);
                 w2[d] = __builtin_amdgcn_perm(x2[1], x2[0], 0x07060302u);
+#ifdef RCF_X3_F16
+                if (C::NPL == 2) {
+                    const rcf_f16_pair q = rcf_f16_planes(v[2 * d][e], v[2 * d + 1][e]);
+                    w0[d] = q.p0;
+                    w1[d] = q.p1;
+                }
+#endif
             }
         }
         *reinterpret_cast<u32x4*>(dst) = w0;
@@ -1648,7 +1693,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                     const u32x4 lo = xlo[sl][pa];
                     av[0] = lo[1]; av[1] = lo[2]; av[2] = lo[3]; av[3] = xhi[sl][pa];
                 }
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av), as_bf16x8(dzv[cur][pbl]), acc[tap], 0, 0, 0);
+                acc[tap] = rcf_mfma_split<NPL>(as_bf16x8(av), as_bf16x8(dzv[cur][pbl]), acc[tap]);
                 // one kx = 1 operand (4 v_alignbit) behind each of the first NPL * KS even (three planes) / consecutive (one plane)
                 // MFMAs: all of them before the kx = 1 group starts
                 constexpr int SHS = NPL == 3 ? 2 : 1;
