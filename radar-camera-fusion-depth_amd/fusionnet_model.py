@@ -571,6 +571,9 @@ class FusionNetModel(object):
             return static_loss
         step.graph = graph
         step.static_inputs = static
+        # the recorded launches read and write the weight plan's persistent buffers: keep THESE alive with the graph even if the
+        # engine later re-records its plan (another input size run eagerly in between)
+        step.weight_plan_buffers = list(self._engine.plan.entries)
         return step
 
     def log_summary(self, summary_writer, tag, step, image=None, input_depth=None, input_response=None,
