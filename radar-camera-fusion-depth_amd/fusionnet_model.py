@@ -528,34 +528,42 @@ class FusionNetModel(object):
                 'moments': {k: (m.clone(), v.clone()) for k, (m, v) in optimizer._moment_arenas.items()},
                 'steps': {k: float(t) for k, t in optimizer._shared_steps.items()}, 'had_state': len(optimizer.state) > 0}
         prof, self._engine.prof = self._engine.prof, None
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):   # lazy one-time state (function attributes, allocator pools, optimizer state) before recording
-            for _ in range(max(1, warmup)):
-                one()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = one()
-        self._engine.prof = prof
-        # ---- roll the warm-up back (the capture itself executed nothing)
-        with torch.no_grad():
-            self._param_arena.copy_(snap['params'])
-            for b, saved in zip(buffers, snap['buffers']):
-                b.copy_(saved)
-            self._nbt.copy_(snap['nbt'])
-            for k, (m, v) in optimizer._moment_arenas.items():
-                if k in snap['moments']:
-                    m.copy_(snap['moments'][k][0]); v.copy_(snap['moments'][k][1])
-                else:
-                    m.zero_(); v.zero_()
-            for k, t in optimizer._shared_steps.items():
-                t.fill_(snap['steps'].get(k, 0.0))
-            for k, ds in optimizer._dev_state.items():
-                step0 = snap['steps'].get(k, 0.0)
-                ds[0][0:1].fill_(step0)
-                ds[2] = int(step0)
+
+        def roll_back():
+            with torch.no_grad():
+                self._param_arena.copy_(snap['params'])
+                for b, saved in zip(buffers, snap['buffers']):
+                    b.copy_(saved)
+                self._nbt.copy_(snap['nbt'])
+                for k, (m, v) in optimizer._moment_arenas.items():
+                    if k in snap['moments']:
+                        m.copy_(snap['moments'][k][0]); v.copy_(snap['moments'][k][1])
+                    else:
+                        m.zero_(); v.zero_()
+                for k, t in optimizer._shared_steps.items():
+                    t.fill_(snap['steps'].get(k, 0.0))
+                for k, ds in optimizer._dev_state.items():   # k = (id(param arena), lo, hi)
+                    step0 = snap['steps'].get(k[0], 0.0)
+                    ds[0][0:1].fill_(step0)
+                    ds[2] = int(step0)
+
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):   # lazy one-time state (function attributes, allocator pools, optimizer state) before recording
+                for _ in range(max(1, warmup)):
+                    one()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = one()
+        finally:
+            # whether or not the capture succeeded: the profiler hook back, the warm-up steps rolled back (the capture itself executed
+            # nothing), so a caller that falls back to eager launches continues from the state it had
+            self._engine.prof = prof
+            torch.cuda.synchronize(dev)
+            roll_back()
         torch.cuda.synchronize(dev)
         shapes = [tuple(t.shape) for t in static]
 
@@ -566,6 +574,7 @@ class FusionNetModel(object):
                 if tuple(src.shape) != shp:
                     raise _lib.RcfError('captured for %s, got %s' % (shp, tuple(src.shape)))
                 dst.copy_(src, non_blocking=True)
+            optimizer.sync_hyper_parameters()   # a learning-rate schedule between replays reaches the recorded Adam launch
             graph.replay()
             optimizer.note_replayed_step()
             return static_loss

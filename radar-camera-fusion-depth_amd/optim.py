@@ -74,6 +74,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        bumped = set()   # ONE increment per optimizer.step() for a step tensor, however many param groups share its arena
         for group in self.param_groups:
             params = [p for p in group['params'] if p.grad is not None]
             if not params:
@@ -82,7 +83,6 @@ class FusedAdam(torch.optim.Optimizer):
                 raise ValueError('FusedAdam: amsgrad / maximize are not implemented')
             beta1, beta2 = group['betas']
             states = [self._init_state(p) for p in params]
-            bumped = set()
             for st in states:
                 if id(st['step']) not in bumped:     # states of one arena share their step tensor
                     bumped.add(id(st['step']))
@@ -123,18 +123,32 @@ class FusedAdam(torch.optim.Optimizer):
             return False
         m, v = self._moment_arenas[id(parena)]
         hyper = (float(group['lr']), float(beta1), float(beta2), float(group['eps']), float(group['weight_decay']))
-        ds = self._dev_state.get(id(parena))
+        # one device counter per launched slice: two param groups of one arena are two launches, each ticking its own counter
+        dkey = (id(parena), lo, hi)
+        ds = self._dev_state.get(dkey)
         if ds is None or ds[2] != step0 - 1:
             # first use, or the host-side step count moved on its own (load_state_dict): (re)seed the device counter
             dev = torch.tensor([float(step0 - 1)] + list(hyper) + [0.0, 0.0], dtype=torch.float32).to(parena.device)
-            ds = [dev, hyper, step0 - 1]
-            self._dev_state[id(parena)] = ds
+            ds = [dev, hyper, step0 - 1, group]
+            self._dev_state[dkey] = ds
         elif ds[1] != hyper:
             ds[0][1:6].copy_(torch.tensor(hyper, dtype=torch.float32))   # learning-rate schedule etc. (never inside a capture)
             ds[1] = hyper
         ops.adam_step_dev(parena[lo:hi], garena[lo:hi], m[lo:hi], v[lo:hi], ds[0])
         ds[2] = step0
         return True
+
+    def sync_hyper_parameters(self):
+        '''Before a hipGraph replay of a captured step(): the recorded Adam launch reads lr / betas / eps / weight_decay from device
+        memory, so a change made on the host since the last step (the reference's learning-rate schedule rewrites g['lr'],
+        src/fusionnet_main.py:354-362) is copied there now -- outside the graph, on the replay's stream.'''
+        for ds in self._dev_state.values():
+            group = ds[3]
+            hyper = (float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),
+                     float(group['weight_decay']))
+            if ds[1] != hyper:
+                ds[0][1:6].copy_(torch.tensor(hyper, dtype=torch.float32))
+                ds[1] = hyper
 
     def note_replayed_step(self):
         '''A hipGraph replay of a captured step() has advanced the device-side step count: advance the host-side mirror (the

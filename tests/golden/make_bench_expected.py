@@ -5,7 +5,7 @@ train-mode BatchNorm, ground-truth outlier removal (7, 1.5), masked L1 + 2.0 x l
 loss with this value (1e-3 relative in fp32) and exits non-zero on a mismatch, so the throughput it prints always belongs to a
 step that computed the right thing at the full batch-8 900x1600 workload.
 
-    python tests/golden/make_bench_expected.py            # ~2-3 minutes on 8 cores; writes tests/golden/bench_expected.json
+    python tests/golden/make_bench_expected.py            # ~20 minutes on 8 cores (8 data seeds); writes tests/golden/bench_expected.json
 '''
 import json
 import os
@@ -23,6 +23,11 @@ from oracle.fusionnet_oracle import FusionNetOracle, remove_outliers   # noqa: E
 
 
 def first_step_loss(batch, height, width, points, wseed=1234, dseed=1234):
+    '''-> (loss, sums): the oracle's loss of this rank-local batch, and the four numbers a data-parallel run needs to form the
+    reference's ONE masked mean over the gathered batch (src/fusionnet_main.py:385, src/fusionnet_model.py:245-253):
+    sum|out - gt| and count over gt > 0 (after outlier removal and the lidar zeroing of :214-221), sum|out - lidar| and count
+    over lidar > 0.  BatchNorm is per replica under nn.DataParallel, so a per-seed run at the per-GPU batch is exactly one
+    replica's forward.'''
     model = FusionNetOracle(**synth.PUBLISHED)
     synth.fill_state_dict_([model.encoder, model.decoder], wseed)
     b = synth.make_batch(batch, height, width, points, seed=dseed)
@@ -30,8 +35,13 @@ def first_step_loss(batch, height, width, points, wseed=1234, dseed=1234):
     with torch.no_grad():
         out = model.forward(b['image'], b['input_depth'])
         gt = remove_outliers(b['ground_truth'], 7, 1.5)
-        loss = model.compute_loss(out, gt, b['lidar_map'], 2.0)[0]
-    return float(loss)
+        lidar = b['lidar_map']
+        loss = model.compute_loss(out, gt, lidar, 2.0)[0]
+        gt = gt * torch.where(lidar > 0.0, torch.zeros_like(lidar), torch.ones_like(lidar))
+        vg, vl = gt > 0, lidar > 0
+        sums = {'sum_abs_gt': float((out[vg].double() - gt[vg].double()).abs().sum()), 'count_gt': int(vg.sum()),
+                'sum_abs_lidar': float((out[vl].double() - lidar[vl].double()).abs().sum()), 'count_lidar': int(vl.sum())}
+    return float(loss), sums
 
 
 if __name__ == '__main__':
@@ -40,9 +50,15 @@ if __name__ == '__main__':
         cases = {'train_b2_224x384_p32': (2, 224, 384, 32)}
     path = os.path.join(ROOT, 'tests', 'golden', 'bench_expected.json')
     rec = json.load(open(path)) if os.path.exists(path) else {}
+    n_ranks = 8   # bench.py's rank r uses data seed 1234 + r
     for key, (n, h, w, k) in cases.items():
         t0 = time.time()
-        rec[key] = {'first_step_loss': first_step_loss(n, h, w, k), 'weights_seed': 1234, 'data_seed': 1234,
+        per_seed = {}
+        for r in range(n_ranks):
+            loss, sums = first_step_loss(n, h, w, k, dseed=1234 + r)
+            sums['loss'] = loss
+            per_seed[str(1234 + r)] = sums
+            print(key, 1234 + r, sums, '%.1f s' % (time.time() - t0), flush=True)
+        rec[key] = {'first_step_loss': per_seed['1234']['loss'], 'weights_seed': 1234, 'data_seed': 1234, 'per_data_seed': per_seed,
                     'source': 'oracle/fusionnet_oracle.py (CPU fp32, pinned to the reference by make_golden.py)'}
-        print(key, rec[key], '%.1f s' % (time.time() - t0))
-    json.dump(rec, open(path, 'w'), indent=1, sort_keys=True)
+        json.dump(rec, open(path, 'w'), indent=1, sort_keys=True)

@@ -318,6 +318,25 @@ def test_bench_two_ranks_spawned_by_bench_itself():
     assert len(rec['per_rank_ms_per_step']) == 2 and rec['config']['global_batch'] == 4
     assert rec['dp']['buckets'] >= 2 and rec['dp']['gradient_bytes'] == 14142208 * 4
     assert rec['value'] > 0
+    assert rec['config']['loss_check']['ok'] is True       # the global masked mean of the two ranks' batches, against the oracle's
+
+
+def test_bench_two_ranks_at_the_headline_shape_pass_their_own_loss_check():
+    '''`python bench.py --gpus 2` at the DEFAULT shape (published net, per-GPU batch 8, 900x1600) -- what the driver's scaling run
+    launches.  Rank r trains on data seed 1234 + r and the loss is the reference's single masked mean over the gathered batch, so the
+    first-step loss must equal the oracle's GLOBAL value formed from the per-seed sums of tests/golden/bench_expected.json (round 2
+    compared it with rank 0's own mean and exited 3).  On a 1-GPU box the two ranks share cuda:0 over gloo (2 x 30 GB).'''
+    two = torch.cuda.device_count() >= 2
+    extra_env = {} if two else {'RCF_BENCH_SINGLE_DEVICE': '1', 'RCF_DIST_BACKEND': 'gloo'}
+    args = ['--gpus', '2', '--steps', '2', '--warmup', '1', '--preheat-s', '0', '--no-cpu-baseline']
+    r, rec = _run_bench(args, extra_env, timeout=900)
+    assert r.returncode == 0 and rec is not None, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2 and rec['config']['global_batch'] == 16
+    chk = rec['config']['loss_check']
+    assert chk['ok'] is True and chk['rel_err'] < 1e-4, chk
+    single = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_expected.json')))['train_b8_900x1600_p64']['first_step_loss']
+    assert abs(chk['oracle_first_step_loss'] - single) > 1e-3 * single     # and the global value is NOT rank 0's own mean
+    assert 'overlap_frac' in rec['dp']
 
 
 def test_bench_single_gpu_line_carries_the_contract_fields():

@@ -581,6 +581,49 @@ def test_hipgraph_captured_training_step_is_bitwise_the_eager_step(env, golden_d
     np.testing.assert_allclose(gr[0], g['losses'], rtol=BAR)      # and it is the reference's trajectory (without outlier removal)
 
 
+def test_captured_training_step_follows_a_learning_rate_schedule_and_two_param_groups(env, golden_dir):
+    '''The reference loop rewrites g['lr'] on its schedule (src/fusionnet_main.py:354-362).  A replayed step must see that: the
+    recorded Adam launch reads its hyper-parameters from device memory, refreshed before each replay.  Also two param groups on the
+    one arena (different lr): one step count per optimizer.step().  Replay == eager, bitwise, with lr changed between steps.'''
+    from rcf_amd.optim import FusedAdam
+    synth, train = env
+    g = np.load(os.path.join(golden_dir, 'T2_tiny_adam3.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    b = _gpu_batch(synth.make_batch(n, h, w, k, seed=dseed))
+    schedule = [(1e-3, 5e-4), (2e-4, 5e-4), (2e-4, 1e-4), (5e-5, 1e-4)]
+    runs = {}
+    for mode in ('eager', 'graph'):
+        m = _build(env, synth.TINY, wseed)
+        ps = m._used_params
+        half = len(ps) // 2
+        unused = [p for p in m.parameters() if all(p is not q for q in ps)]
+        opt = FusedAdam([{'params': ps[:half], 'lr': schedule[0][0]}, {'params': ps[half:] + unused, 'lr': schedule[0][1]}])
+        m.train()
+        if mode == 'graph':
+            step = m.capture_training_step(opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])
+        losses = []
+        for lr0, lr1 in schedule:
+            opt.param_groups[0]['lr'], opt.param_groups[1]['lr'] = lr0, lr1
+            if mode == 'graph':
+                loss = step()
+            else:
+                loss = train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])[0]
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        steps = sorted(set(float(st['step']) for st in opt.state_dict()['state'].values()))
+        runs[mode] = (losses, m._param_arena.clone(), steps)
+    assert runs['eager'][2] == runs['graph'][2] == [4.0], (runs['eager'][2], runs['graph'][2])
+    assert runs['eager'][0] == runs['graph'][0]
+    assert torch.equal(runs['eager'][1], runs['graph'][1])
+    # and the schedule mattered: a constant-lr run ends elsewhere
+    m = _build(env, synth.TINY, wseed)
+    opt = train.make_optimizer(m, lr=1e-3)
+    m.train()
+    for _ in schedule:
+        train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])
+    assert not torch.equal(m._param_arena, runs['graph'][1])
+
+
 def test_captured_training_step_full_resolution_matches_eager(env):
     '''The benchmark's own step (published net, 900x1600, outlier removal) at batch 2: replay == eager, bitwise, after two steps.'''
     from rcf_amd.net_utils import OutlierRemoval

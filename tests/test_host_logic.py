@@ -142,6 +142,66 @@ def test_fused_adam_state_dict_is_torch_adam_compatible(pkg):
     assert torch.allclose(st['exp_avg'], ref.state[p0]['exp_avg'])
 
 
+def test_fused_adam_counts_one_step_per_step_call_with_several_param_groups(pkg, monkeypatch):
+    '''Two param groups (different lr) on ONE arena: torch.optim.Adam semantics are one step count per optimizer.step(), shared by
+    every parameter; each group's launch carries its own device counter and hyper-parameters.  The kernel launch is replaced by a
+    host emulation of rcf_adam_step_dev's bookkeeping (tick the counter, read lr) -- no GPU here.'''
+    from rcf_amd import ops, synth, train
+    from rcf_amd.optim import FusedAdam
+    m = train.build_model(synth.TINY, device='cpu')
+    ps = m._used_params
+    half = len(ps) // 2
+    opt = FusedAdam([{'params': ps[:half], 'lr': 1e-3}, {'params': ps[half:], 'lr': 5e-4}])
+    seen = []
+
+    def fake_adam_step_dev(p, g, m_, v, state):
+        state[0] += 1.0
+        seen.append((p.numel(), float(state[0]), float(state[1])))
+    monkeypatch.setattr(ops, 'adam_step_dev', fake_adam_step_dev)
+    for p in ps:
+        p.grad = m._grad_views[id(p)]
+    n0, n1 = sum(p.numel() for p in ps[:half]), sum(p.numel() for p in ps[half:])
+    for k in (1, 2, 3):
+        del seen[:]
+        opt.step()
+        assert seen == [(n0, float(k), pytest.approx(1e-3)), (n1, float(k), pytest.approx(5e-4))], seen
+        assert float(opt.state[ps[0]]['step']) == float(opt.state[ps[-1]]['step']) == float(k)
+    assert all(float(st['step']) == 3.0 for st in opt.state_dict()['state'].values())
+    # a learning-rate schedule reaches the device copy of the right group, also on the replay path
+    opt.param_groups[1]['lr'] = 2.5e-4
+    opt.sync_hyper_parameters()
+    lrs = sorted(float(ds[0][1]) for ds in opt._dev_state.values())
+    assert lrs == [pytest.approx(2.5e-4), pytest.approx(1e-3)]
+
+
+def test_bench_expected_loss_under_data_parallelism_is_the_global_masked_mean(pkg):
+    '''bench.py --gpus N checks its first-step loss against the oracle's ONE masked mean over all ranks' batches (rank r = data seed
+    1234 + r), formed from per-seed sums and counts -- not against rank 0's own mean.  Here: the per-seed records exist for 8 ranks
+    at both shapes, world 1 reproduces the single-rank loss, and the 2-rank value of the small case equals the oracle run on the
+    concatenated sums computed afresh.'''
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import make_bench_expected as mk
+    rec = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_expected.json')))
+    for key in ('train_b8_900x1600_p64', 'train_b2_224x384_p32'):
+        per = rec[key]['per_data_seed']
+        assert sorted(per) == [str(1234 + r) for r in range(8)]
+        one = per['1234']
+        assert abs(one['sum_abs_gt'] / one['count_gt'] + 2.0 * one['sum_abs_lidar'] / one['count_lidar'] - rec[key]['first_step_loss']) \
+            < 2e-6 * rec[key]['first_step_loss']
+        assert bench._expected_first_loss(key, 1) == rec[key]['first_step_loss']
+        for world in (2, 4, 8):
+            w = bench._expected_first_loss(key, world)
+            lo, hi = min(per[str(1234 + r)]['loss'] for r in range(world)), max(per[str(1234 + r)]['loss'] for r in range(world))
+            assert lo <= w <= hi
+    sums = [mk.first_step_loss(2, 224, 384, 32, dseed=1234 + r)[1] for r in range(2)]
+    want = (sums[0]['sum_abs_gt'] + sums[1]['sum_abs_gt']) / (sums[0]['count_gt'] + sums[1]['count_gt']) \
+        + 2.0 * (sums[0]['sum_abs_lidar'] + sums[1]['sum_abs_lidar']) / (sums[0]['count_lidar'] + sums[1]['count_lidar'])
+    assert abs(bench._expected_first_loss('train_b2_224x384_p32', 2) - want) < 1e-6 * want
+
+
 def test_synthetic_inputs_are_deterministic(pkg):
     from rcf_amd import synth
     a = synth.make_batch(2, 64, 96, 8, seed=5)
@@ -297,7 +357,7 @@ def test_bench_expected_loss_fixture_is_the_oracle_on_the_bench_inputs(pkg):
     import make_bench_expected as mk
     rec = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_expected.json')))
     assert 'train_b8_900x1600_p64' in rec and rec['train_b8_900x1600_p64']['first_step_loss'] > 0
-    got = mk.first_step_loss(2, 224, 384, 32)
+    got = mk.first_step_loss(2, 224, 384, 32)[0]
     assert abs(got - rec['train_b2_224x384_p32']['first_step_loss']) < 1e-5 * abs(got)
 
 
