@@ -246,7 +246,7 @@ def run_rank(args):
 
     model = train.build_model(synth.PUBLISHED, device=dev)
     synth.fill_state_dict_([model.encoder, model.decoder], 1234)   # seeded U(+-1/sqrt(fan_in)) weights, identical on every rank
-    model.compute_dtype = {'bf16': 'bf16', 'f32x3': 'bf16x3'}.get(dtype, 'fp32')
+    model.compute_dtype = {'bf16': 'bf16', 'f32x3': 'f16x2'}.get(dtype, 'fp32')
     if world > 1:
         model.data_parallel()
     opt = train.make_optimizer(model, lr=1e-3)
@@ -455,7 +455,7 @@ def side_leg(args, dev, world, rank, batch, dtype):
     from rcf_amd.net_utils import OutlierRemoval
     model = train.build_model(synth.PUBLISHED, device=dev)
     synth.fill_state_dict_([model.encoder, model.decoder], 1234)
-    model.compute_dtype = {'f32x3': 'bf16x3'}[dtype]
+    model.compute_dtype = {'f32x3': 'f16x2'}[dtype]
     if world > 1:
         model.data_parallel()
     opt = train.make_optimizer(model, lr=1e-3)

@@ -56,7 +56,7 @@ extern "C" {
  * and source 1 may be gathered (nearest upsample / zero insert).  */
 #define RCF_PREC_FP32 0
 #define RCF_PREC_BF16 1
-#define RCF_PREC_BF16X3 2
+#define RCF_PREC_F16X2 2
 /* Storage of the NHWC activation / gradient tensors a call reads and writes. */
 #define RCF_STORE_FP32 0 /* fp32 tensors: the reference's configuration */
 #define RCF_STORE_BF16 1 /* bf16 tensors in HBM (BASELINE.json configs 2-4): bf16 storage and MFMA operands, fp32 accumulation; weights,
@@ -89,9 +89,12 @@ typedef struct rcf_conv_desc {
     /* RCF_PREC_FP32 (0): fp32 results (the reference's arithmetic; f32 MFMA or the exact 3-plane bf16 split).
      * RCF_PREC_BF16 (1): operands rounded to bf16 (nearest even), fp32 accumulate; honoured by the split kernels, every other
      * kernel keeps computing in fp32.
-     * RCF_PREC_BF16X3 (2), fp32 tensors only: each operand as TWO bf16 planes (16-17 significant bits), the three products
-     * a0*b0 + a0*b1 + a1*b0, fp32 accumulate -- errors of order 1e-5 of |a||b| (cuDNN's default TF32 convolutions keep 10 bits),
-     * half the matrix work of RCF_PREC_FP32 on the split kernels; every other kernel keeps computing in fp32. */
+     * RCF_PREC_F16X2 (2), fp32 tensors only: each operand of the split kernels as TWO fp16 planes of x * s, s the power of two that
+     * puts its tensor's max|x| into [2^14, 2^15) (22-23 significant bits, fp16 denormals honoured by the MFMA), the three products
+     * a0*b0 + a0*b1 + a1*b0, fp32 accumulate, result * 1/(s_a s_b): the accuracy class of the three-plane bf16 split (measured against
+     * fp64: within 2x of the f32 MFMA) at half its matrix work.  The per-tensor maxima arrive by device pointer (rcf_conv_scales; the
+     * kernels that write the tensors accumulate them: rcf_*_amax below); a null maximum means scale 1 (data inside fp16's range).
+     * Every other kernel keeps computing in fp32. */
     int precision;
     /* RCF_STORE_FP32 / RCF_STORE_BF16: element type of in1, in2, out, res and dz (`const void*` below).  The two 7x7 stem
      * convolutions (c1 <= 4) always read an fp32 input -- the network input is never rounded -- and write `storage`. */
@@ -118,6 +121,9 @@ int rcf_conv2d_query(const rcf_conv_desc* d, rcf_conv_info* info);
 /* OIHW -> kernel layout [n-tile][k-chunk][tap][BN][CK].  Replaces nothing in the reference; it is the
  * price of keeping torch.nn.Conv2d.weight's layout at the boundary. */
 int rcf_conv2d_pack_weights(const rcf_conv_desc* d, const float* w_oihw, float* packed, void* stream);
+/* RCF_PREC_F16X2: the two fp16 planes hold w * s_w, s_w from *amax_w = max|w| over the tensor (device pointer, nullable = scale 1;
+ * an upper bound is fine).  The same pointer goes to rcf_conv2d_fwd_scaled, whose epilogue divides s_w out again. */
+int rcf_conv2d_pack_weights_scaled(const rcf_conv_desc* d, const float* w_oihw, float* packed, const float* amax_w, void* stream);
 /* The same for n (descriptor, weight, destination) triples in ceil(n / 36) launches instead of n: a training step packs ~200
  * weights of a few thousand elements each, every one a 4-5 us launch (all weights are constant from the start of the forward
  * pass to the end of the backward pass, so the host can pack them all up front).  Results are identical to n single calls. */
@@ -125,8 +131,29 @@ typedef struct rcf_pack_item {
     const rcf_conv_desc* desc;
     const float* w_oihw;
     float* packed;
+    const float* amax_w; /* RCF_PREC_F16X2 descriptors: as in rcf_conv2d_pack_weights_scaled; ignored otherwise */
 } rcf_pack_item;
 int rcf_conv2d_pack_weights_batch(const rcf_pack_item* items, int n, void* stream);
+
+/* Per-tensor maxima for RCF_PREC_F16X2 (each a DEVICE pointer to one float holding max|x| of the tensor or an upper bound of it;
+ * nullable = scale 1).  amax_in2 is read only when c2 > 0: the two sources of a concat share the scale of the larger maximum. */
+typedef struct rcf_conv_scales {
+    const float* amax_in1;
+    const float* amax_in2;
+    const float* amax_w;  /* forward / input gradient: the weight tensor `packed` was built from (rcf_conv2d_pack_weights_scaled) */
+    const float* amax_dz; /* weight gradient: the output gradient */
+} rcf_conv_scales;
+/* max|x| over n floats, accumulated into *amax (amax = max(amax, max|x|): zero it first for a fresh maximum).  The network's own
+ * activations and gradients get theirs from the kernels that write them (rcf_bn_act_fwd_amax, ...); this entry point serves the
+ * network inputs, the weights and the tests. */
+int rcf_amax(const float* x, long long n, float* amax, void* stream);
+typedef struct rcf_amax_item {
+    const float* x;
+    long long n;
+    float* amax;
+} rcf_amax_item;
+/* n of those in ceil(n / 128) launches (all weights of a training step up front). */
+int rcf_amax_batch(const rcf_amax_item* items, int n, void* stream);
 
 /* torch.nn.Conv2d.forward, bias=False (src/net_utils.py:85); with gather1=NEAREST also the F.interpolate of
  * UpConv2d.forward (src/net_utils.py:195-198); with c2>0 also the torch.cat of DecoderBlock.forward
@@ -135,6 +162,9 @@ int rcf_conv2d_pack_weights_batch(const rcf_pack_item* items, int n, void* strea
  * rcf_bn_finalize -- the batch statistics of torch.nn.BatchNorm2d (src/net_utils.py:82,86). */
 int rcf_conv2d_fwd(const rcf_conv_desc* d, const void* in1, const void* in2, const float* packed,
                    void* out, double* stat_partials, void* stream);
+/* The same for RCF_PREC_F16X2 descriptors on the split kernels (rcf_conv_info.kernel_id >= 45000), with the operands' maxima. */
+int rcf_conv2d_fwd_scaled(const rcf_conv_desc* d, const void* in1, const void* in2, const float* packed,
+                          void* out, double* stat_partials, const rcf_conv_scales* scales, void* stream);
 /* BatchNorm + LeakyReLU of the PRODUCING block applied while the operand is staged ("BN on load"): in1 / in2 are raw conv
  * outputs z and coef1 / coef2 (nullable, one per source) the rcf_bn_finalize coefficients [4][c] of the block that produced
  * them; the kernel uses y = lrelu(z * coef[0][c] + coef[1][c]).  That block's activation tensor (net_utils.Conv2d.forward,
@@ -157,6 +187,8 @@ int rcf_scale_channels(const float* w, const float* scale, float* out, int n_out
  * loss.backward() (src/fusionnet_main.py:398). */
 int rcf_conv2d_wgrad(const rcf_conv_desc* d, const void* in1, const void* in2, const void* dz,
                      float* dw_oihw, float* workspace, void* stream);
+int rcf_conv2d_wgrad_scaled(const rcf_conv_desc* d, const void* in1, const void* in2, const void* dz,
+                            float* dw_oihw, float* workspace, const rcf_conv_scales* scales, void* stream);
 int rcf_conv2d_wgrad_bn(const rcf_conv_desc* d, const void* in1, const float* coef1, const void* in2, const float* coef2,
                         const void* dz, float* dw_oihw, float* workspace, void* stream);
 
@@ -193,10 +225,16 @@ int rcf_bn_finalize(const double* partials, int n_partials, int c, double count,
  * ResNetBlock.forward (src/net_utils.py:309-323).  n_pix = N*H*W. */
 int rcf_bn_act_fwd(const float* z, const float* coef, const float* res, float* out,
                    long long n_pix, int c, int act, void* stream);
+/* ..._amax variants (fp32 tensors): the same kernel also accumulates max|value written| into *amax (device, zeroed by the caller;
+ * see rcf_amax) -- the per-tensor maximum RCF_PREC_F16X2 consumers scale their fp16 planes by, at no extra pass over the tensor. */
+int rcf_bn_act_fwd_amax(const float* z, const float* coef, const float* res, float* out,
+                        long long n_pix, int c, int act, float* amax, void* stream);
 
 /* skip = sigmoid(BN_w(zw)) * BN_p(zp) + img : FusionNetEncoder 'weight_and_project' fusion (src/networks.py:863-866). */
 int rcf_fuse_fwd(const float* zw, const float* coef_w, const float* zp, const float* coef_p,
                  const float* img, float* out, long long n_pix, int c, void* stream);
+int rcf_fuse_fwd_amax(const float* zw, const float* coef_w, const float* zp, const float* coef_p,
+                      const float* img, float* out, long long n_pix, int c, float* amax, void* stream);
 
 /* Backward of rcf_bn_act_fwd, two passes around a per-channel reduction (BatchNorm2d backward).
  * reduce: partials[n_blocks][2][c] (fp64: these sums cancel heavily, and PyTorch's CPU BatchNorm accumulates float
@@ -212,6 +250,10 @@ int rcf_bn_bwd_finalize(const double* partials, int n_blocks, int partial_stride
 int rcf_bn_act_bwd_apply(const float* dout, const float* z, const float* coef, const float* out,
                          const float* bcoef, float* dz, float* dres, int dres_accumulate,
                          long long n_pix, int c, int act, int has_res, void* stream);
+/* amax: max|dz| (the operand of the layer's input- and weight-gradient convolutions). */
+int rcf_bn_act_bwd_apply_amax(const float* dout, const float* z, const float* coef, const float* out,
+                              const float* bcoef, float* dz, float* dres, int dres_accumulate,
+                              long long n_pix, int c, int act, int has_res, float* amax, void* stream);
 
 /* BatchNorm + LeakyReLU backward of the layer that feeds the output head (MultiScaleDecoder deconv0.conv -> output0,
  * src/networks.py:1548-1555, :1649-1654), fused with rcf_head_bwd_dgrad: dout is recomputed from dlogit (N,H,W) and the head
@@ -222,6 +264,8 @@ int rcf_head_bn_bwd_reduce(const float* dlogit, const float* w_head, const float
                            int n, int h, int w, int c, void* stream);
 int rcf_head_bn_bwd_apply(const float* dlogit, const float* w_head, const float* z, const float* coef, const float* bcoef,
                           float* dz, int n, int h, int w, int c, void* stream);
+int rcf_head_bn_bwd_apply_amax(const float* dlogit, const float* w_head, const float* z, const float* coef, const float* bcoef,
+                               float* dz, int n, int h, int w, int c, float* amax, void* stream);
 
 /* Backward of rcf_fuse_fwd. partials[n_blocks][4][c]: (sum gw, sum gw*xhat_w, sum gp, sum gp*xhat_p). */
 int rcf_fuse_bwd_reduce(const float* dout, const float* zw, const float* coef_w, const float* zp,

@@ -31,14 +31,22 @@ class ConvInfo(Structure):
 
 
 class PackItem(Structure):     # rcf_pack_item
-    _fields_ = [('desc', POINTER(ConvDesc)), ('w_oihw', c_void_p), ('packed', c_void_p)]
+    _fields_ = [('desc', POINTER(ConvDesc)), ('w_oihw', c_void_p), ('packed', c_void_p), ('amax_w', c_void_p)]
+
+
+class ConvScales(Structure):   # rcf_conv_scales: device pointers to per-tensor maxima (RCF_PREC_F16X2), nullable
+    _fields_ = [('amax_in1', c_void_p), ('amax_in2', c_void_p), ('amax_w', c_void_p), ('amax_dz', c_void_p)]
+
+
+class AmaxItem(Structure):     # rcf_amax_item
+    _fields_ = [('x', c_void_p), ('n', c_longlong), ('amax', c_void_p)]
 
 
 class PhaseItem(Structure):    # rcf_phase_item
     _fields_ = [('w_oihw', c_void_p), ('out', c_void_p), ('o', c_int), ('i', c_int), ('mode', c_int)]
 
 
-RCF_PREC_FP32, RCF_PREC_BF16, RCF_PREC_BF16X3 = 0, 1, 2
+RCF_PREC_FP32, RCF_PREC_BF16, RCF_PREC_F16X2 = 0, 1, 2
 RCF_STORE_FP32, RCF_STORE_BF16 = 0, 1
 
 _P = c_void_p
@@ -113,6 +121,18 @@ B16_TWINS = ('rcf_bn_act_fwd', 'rcf_fuse_fwd', 'rcf_bn_act_bwd_reduce', 'rcf_bn_
              'rcf_roi_pool_bwd', 'rcf_fc_fwd', 'rcf_fc_bwd')
 for _name in B16_TWINS:   # NAME_b16: same argument list, NHWC activation tensors hold bf16 (include/rcf_hip.h)
     _SIGNATURES[_name + '_b16'] = _SIGNATURES[_name]
+_SIGNATURES.update({
+    # two fp16 operand planes with per-tensor scales (RCF_PREC_F16X2)
+    'rcf_conv2d_pack_weights_scaled': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P]),
+    'rcf_conv2d_fwd_scaled': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, POINTER(ConvScales), _P]),
+    'rcf_conv2d_wgrad_scaled': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, POINTER(ConvScales), _P]),
+    'rcf_amax': (c_int, [_P, c_longlong, _P, _P]),
+    'rcf_amax_batch': (c_int, [POINTER(AmaxItem), c_int, _P]),
+    'rcf_bn_act_fwd_amax': (c_int, [_P, _P, _P, _P, c_longlong, c_int, c_int, _P, _P]),
+    'rcf_fuse_fwd_amax': (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, _P, _P]),
+    'rcf_bn_act_bwd_apply_amax': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_longlong, c_int, c_int, c_int, _P, _P]),
+    'rcf_head_bn_bwd_apply_amax': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+})
 _SIGNATURES['rcf_convert'] = (c_int, [_P, c_int, _P, c_int, c_longlong, c_int, _P])
 _SIGNATURES['rcf_s2d_image_b16'] = (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P])
 _SIGNATURES['rcf_stem_weights_s2d'] = (c_int, [_P, _P, c_int, c_int, _P])

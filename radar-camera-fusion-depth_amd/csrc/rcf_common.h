@@ -23,6 +23,41 @@ __device__ __forceinline__ float rcf_sigmoid(float v) { return 1.f / (1.f + __ex
 // MFMA 32x32x2 f32 C/D fragment: value r of lane l sits at row (r&3)+8*(r>>2)+4*(l>>5), column l&31.
 __device__ __forceinline__ int rcf_mfma_row(int r, int lane_half) { return (r & 3) + 8 * (r >> 2) + 4 * lane_half; }
 
+// ---- two fp16 operand planes with a per-tensor power-of-two scale (RCF_PREC_F16X2, include/rcf_hip.h) ------------------------------
+// An fp32 operand x of a tensor with max|x| = amax is carried into the matrix pipe as  x * s = p0 + p1  with p0 = fp16(x * s) and
+// p1 = fp16(x * s - p0), both round-to-nearest-even: 22-23 significant bits, error <= 2^-23 |x| + 2^-25 / s (the second term is the
+// fp16 denormal floor: 2^-39 amax).  s is the power of two that puts amax into [2^14, 2^15) -- exact in fp32, no fp16 overflow
+// (max 65504), and gfx950's v_mfma_f32_32x32x16_f16 honours fp16 denormal inputs (tools/probe/f16_denorm_probe.hip).  The products
+// a0*b0 + a0*b1 + a1*b0 are accumulated in fp32 and the result is multiplied by inv_a * inv_b (two exact multiplications).
+struct RcfScale { float s, inv; };
+__host__ __device__ inline RcfScale rcf_scale_of_amax(float amax) {
+    union { float f; unsigned u; } c;
+    c.f = amax;
+    const unsigned b = c.u & 0x7fffffffu;
+    RcfScale r = {1.f, 1.f};
+    if (b == 0u) return r;                       // an all-zero tensor
+    int se = 268 - (int)(b >> 23);               // biased exponent of s: 127 + 14 - (E - 127)
+    se = se < 1 ? 1 : (se > 253 ? 253 : se);     // keep s and 1/s normal (tensors beyond 2^127 / below 2^-112 are not rescaled further)
+    c.u = (unsigned)se << 23; r.s = c.f;
+    c.u = (unsigned)(254 - se) << 23; r.inv = c.f;
+    return r;
+}
+// max|x| of a tensor, accumulated by the kernels that write it: wave maximum by shuffles, then ONE atomic per wave on the bit pattern
+// (non-negative floats order like their bit patterns; the slot is zeroed by the host before the producers run) -- skipped when the
+// slot already holds a larger value, which is the common case after the first few waves.
+__device__ __forceinline__ void rcf_amax_commit(float m, float* amax_slot) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned mb = __float_as_uint(m);
+        unsigned* slot = reinterpret_cast<unsigned*>(amax_slot);
+        if (mb > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, mb);
+    }
+}
+__device__ __forceinline__ float rcf_amax4(float m, f32x4 v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+
 // ---- storage type of the NHWC activation / gradient tensors -------------------------------------------------------------------
 // StF32: fp32 tensors (the reference's arithmetic).  StB16: bf16 tensors in HBM (BASELINE.json configs 2-4: bf16 storage and MFMA
 // operands, fp32 accumulation, fp32 master weights and BatchNorm statistics).  Kernels are templated on the tag and touch such a

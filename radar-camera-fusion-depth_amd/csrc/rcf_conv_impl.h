@@ -63,6 +63,12 @@ struct ConvArgs {
     const float* dz;   // wgrad only
     const float* zero; // rcf_zero_page (a kernel argument: see there)
     float* ws;         // wgrad only
+    // RCF_PREC_F16X2 (two fp16 operand planes): device pointers to max|x| of the A operand's sources (forward / input gradient: in1,
+    // in2; weight gradient: in1, in2) and of the B operand (the weights the packed buffer was built from; weight gradient: dz).
+    // Null = unscaled (scale 1: data inside fp16's range).  The two sources of a concat share the scale of the larger maximum.
+    const float* amax_a1;
+    const float* amax_a2;
+    const float* amax_b;
     int n, h_in, w_in, c1, c2, h1, w1, gather1;
     int h_out, w_out, c_out, pad, pad_x, stride, gstep, accumulate;
     int os, ooy, oox, ohp, owp;   // output (and wgrad dZ) phase addressing
@@ -432,28 +438,38 @@ __global__ void __launch_bounds__(256, C::MINW) conv_fwd_kernel(ConvArgs a) {
 //  * activations are split while staged (and/sub, ~5.5 VALU per element); weights are pre-split by the pack kernel.
 //  * persistent + register-prefetched like conv_fwd_kernel; same epilogue (store, +=, fp64 BN statistics).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-// The matrix instruction of the split kernels.  Diagnostics build -DRCF_X3_F16 (tools/f16_plane_probe.py): the TWO-plane variants
-// carry fp16 planes (11 + 11 significant bits, no scaling: a probe for data inside fp16's range) instead of bf16 planes (8 + 8).
-#ifdef RCF_X3_F16
+// The matrix instruction of the split kernels.  NPL = 3 / 1: bf16 planes.  NPL = 2 (RCF_PREC_F16X2): two fp16 planes of the operand
+// scaled by its tensor's power-of-two scale (rcf_common.h: rcf_scale_of_amax) -- 22-23 significant bits in two planes where bf16 needs
+// three, so three products a1*b0 + a0*b1 + a0*b0 instead of six.
 typedef _Float16 rcf_f16x8 __attribute__((ext_vector_type(8)));
-typedef __fp16 rcf_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 rcf_f16x2 __attribute__((ext_vector_type(2)));
 struct rcf_f16_pair { unsigned p0, p1; };
-// two fp32 -> (fp16 plane 0, fp16 plane 1) dwords, value `a` in the low half
+// two (already scaled) fp32 values -> (fp16 plane 0, fp16 plane 1) dwords, value `a` in the low half; both planes round to nearest
+// even (v_cvt_pk_f16_f32), the residual a - p0 is exact in fp32
 __device__ __forceinline__ rcf_f16_pair rcf_f16_planes(float a, float b) {
-    const rcf_f16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    rcf_f16_pair r;
-    r.p0 = __builtin_bit_cast(unsigned, h);
-    r.p1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]));
-    return r;
+    const rcf_f32x2 v = {a, b};
+    const rcf_f16x2 h = __builtin_convertvector(v, rcf_f16x2);
+    const rcf_f32x2 r = {a - (float)h[0], b - (float)h[1]};
+    rcf_f16_pair q;
+    q.p0 = __builtin_bit_cast(unsigned, h);
+    q.p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, rcf_f16x2));
+    return q;
 }
-#endif
+// scale and 1/scale of the A operand (common to both sources) and of the B operand, from the kernel's amax pointers (wave-uniform)
+struct SplitScales { float sa, ia, sb, ib; };
+__device__ __forceinline__ SplitScales rcf_split_scales(const float* amax_a1, const float* amax_a2, const float* amax_b) {
+    float ma = amax_a1 ? *amax_a1 : 0.f;
+    if (amax_a2) ma = fmaxf(ma, *amax_a2);
+    const RcfScale a = (amax_a1 || amax_a2) ? rcf_scale_of_amax(ma) : RcfScale{1.f, 1.f};
+    const RcfScale b = amax_b ? rcf_scale_of_amax(*amax_b) : RcfScale{1.f, 1.f};
+    return SplitScales{a.s, a.inv, b.s, b.inv};
+}
 template <int NPL>
 __device__ __forceinline__ f32x16 rcf_mfma_split(bf16x8 a, bf16x8 b, f32x16 c) {
-#ifdef RCF_X3_F16
     if constexpr (NPL == 2)
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rcf_f16x8, a), __builtin_bit_cast(rcf_f16x8, b), c, 0, 0, 0);
-#endif
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -465,7 +481,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // KERNEL ROW (KSX taps) at a time into a double-buffered LDS piece, so only the A tile needs the two-barrier hand-over.
 // NPL_ = 3: fp32 results (exact split, six partial products).  NPL_ = 1: rcf_conv_desc.precision == RCF_PREC_BF16 -- operands
 // rounded to bf16 (nearest even), ONE product, fp32 accumulate: the "bf16" configurations of BASELINE.json.
-// NPL_ = 2: RCF_PREC_BF16X3 -- two planes (the top 8 significant bits, then the remainder rounded to 8 more: 16-17 significant
+// NPL_ = 2: RCF_PREC_F16X2 -- two planes (the top 8 significant bits, then the remainder rounded to 8 more: 16-17 significant
 // bits per operand), the THREE products a0b0 + a0b1 + a1b0, fp32 accumulate: errors ~1e-5 of |a||b|, half the matrix work.
 // LSTEP_ = 2: stride-2 convolution -- the halo tile holds EVERY input pixel under the tile (a 3-tap kernel at stride 2 touches them
 // all) and neighbouring output pixels read halo pixels two apart; everything else (weights, epilogue) is the stride-1 kernel.
@@ -533,6 +549,9 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
         // store_a comes first: make it explicit
         __syncthreads();
     }
+
+    SplitScales sc = {1.f, 1.f, 1.f, 1.f};   // NPL == 2: operand scales (the packed weights already carry theirs)
+    if constexpr (C::NPL == 2) sc = rcf_split_scales(a.amax_a1, a.amax_a2, a.amax_b);
 
     int apix[C::MT];   // halo pixel of this lane's output pixel at tap (0, 0)
 #pragma unroll
@@ -649,7 +668,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                     xin[e] = x;
                     x0[e] = __float_as_uint(x) & 0xffff0000u;
                     const float r1 = x - __uint_as_float(x0[e]);
-                    x1[e] = (C::NPL == 2 ? rcf_bf16_rne(r1) : __float_as_uint(r1)) & 0xffff0000u;   // last plane: rounded
+                    x1[e] = __float_as_uint(r1) & 0xffff0000u;
                     const float r2 = r1 - __uint_as_float(x1[e]);
                     x2[e] = __float_as_uint(r2);
                 }
@@ -666,13 +685,11 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                 } else {
                     u32x2 w0 = {(x0[0] >> 16) | x0[1], (x0[2] >> 16) | x0[3]};
                     u32x2 w1 = {(x1[0] >> 16) | x1[1], (x1[2] >> 16) | x1[3]};
-#ifdef RCF_X3_F16
-                    if (C::NPL == 2) {
-                        const rcf_f16_pair q0 = rcf_f16_planes(xin[0], xin[1]), q1 = rcf_f16_planes(xin[2], xin[3]);
+                    if constexpr (C::NPL == 2) {   // two fp16 planes of the scaled value
+                        const rcf_f16_pair q0 = rcf_f16_planes(xin[0] * sc.sa, xin[1] * sc.sa), q1 = rcf_f16_planes(xin[2] * sc.sa, xin[3] * sc.sa);
                         w0[0] = q0.p0; w1[0] = q0.p1;
                         w0[1] = q1.p0; w1[1] = q1.p1;
                     }
-#endif
                     u32x2 w2 = {(x2[0] >> 16) | (x2[1] & 0xffff0000u), (x2[2] >> 16) | (x2[3] & 0xffff0000u)};
                     *reinterpret_cast<u32x2*>(dst) = w0;
                     *reinterpret_cast<u32x2*>(dst + C::A_PLANE_BYTES) = w1;
@@ -843,6 +860,14 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                         for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(ebias[ni]));
                     }
                     const bool add_old = EPI ? a.res != nullptr : a.accumulate != 0;
+                    if constexpr (C::NPL == 2) {   // undo the operand scales: two exact multiplications by powers of two
+#pragma unroll
+                        for (int mi = 0; mi < C::MT; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = acc[mi][ni][r] * sc.ia * sc.ib;
+                    }
 #pragma unroll
                     for (int mi = 0; mi < C::MT; ++mi) {
 #pragma unroll
@@ -1006,7 +1031,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
 // OIHW fp32 -> pre-split bf16 planes [n-tile][chunk][kernel row][plane][kx][BN][16], halves swapped when (co >> 3) & 1.
 __device__ __forceinline__ void pack_weights_split_body(size_t idx, const float* __restrict__ w, unsigned short* __restrict__ dst,
                                                         size_t total_rows16, int w_o, int w_i, int mode, int i_off, int c_out, int c1,
-                                                        int c2, int nchunk1, int nchunk, int BN, int ks, int npl) {
+                                                        int c2, int nchunk1, int nchunk, int BN, int ks, int npl, const float* __restrict__ amax_w) {
     // one thread per (n-tile, chunk, tap, co, k) element; writes its three planes
     if (idx >= total_rows16) return;
     size_t t = idx;
@@ -1042,17 +1067,11 @@ __device__ __forceinline__ void pack_weights_split_body(size_t idx, const float*
         return;
     }
     dst[base] = (unsigned short)(x0 >> 16);
-    if (npl == 2) {   // RCF_PREC_BF16X3: the second plane is the remainder rounded to nearest even
-#ifdef RCF_X3_F16
-        {
-            const rcf_f16_pair q = rcf_f16_planes(v, 0.f);
-            dst[base] = (unsigned short)q.p0;
-            dst[base + plane_elems] = (unsigned short)q.p1;
-            return;
-        }
-#endif
-        const unsigned u = __float_as_uint(r1);
-        dst[base + plane_elems] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    if (npl == 2) {   // RCF_PREC_F16X2: two fp16 planes of w * (the weight tensor's power-of-two scale)
+        const float sw = amax_w ? rcf_scale_of_amax(*amax_w).s : 1.f;
+        const rcf_f16_pair q = rcf_f16_planes(v * sw, 0.f);
+        dst[base] = (unsigned short)q.p0;
+        dst[base + plane_elems] = (unsigned short)q.p1;
         return;
     }
     dst[base + plane_elems] = (unsigned short)(x1 >> 16);
@@ -1061,9 +1080,9 @@ __device__ __forceinline__ void pack_weights_split_body(size_t idx, const float*
 
 __global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, size_t total_rows16, int w_o,
                                           int w_i, int mode, int i_off, int c_out, int c1, int c2, int nchunk1, int nchunk, int BN,
-                                          int ks, int npl) {
+                                          int ks, int npl, const float* __restrict__ amax_w) {
     pack_weights_split_body((size_t)blockIdx.x * blockDim.x + threadIdx.x, w, dst, total_rows16, w_o, w_i, mode, i_off, c_out, c1, c2,
-                            nchunk1, nchunk, BN, ks, npl);
+                            nchunk1, nchunk, BN, ks, npl, amax_w);
 }
 
 // Many weight packings in ONE launch (rcf_conv2d_pack_weights_batch): the per-item arguments travel by value in the kernel
@@ -1072,10 +1091,11 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned 
 struct PackArgs {
     const float* w;
     void* dst;
+    const float* amax;   // RCF_PREC_F16X2 split items: max|w| of the weight tensor (device, nullable)
     unsigned long long total;
     int w_o, w_i, ks, mode, i_off, c_out, c1, c2, nchunk1, nchunk, T, ksx, BN, CK, kind, npl, split;
 };
-constexpr int PACK_BATCH = 36;
+constexpr int PACK_BATCH = 34;
 struct PackBatch {
     int n;
     unsigned blk_start[PACK_BATCH + 1];
@@ -1390,7 +1410,7 @@ constexpr int ws_pitch(int bytes) { return ((bytes - 16 + 127) / 128) * 128 + 16
 template <int WCI_, int WCO_, int KS_ = 3, int TH_ = 8, int NPL_ = 3>
 struct WsCfg {
     static constexpr int KS = KS_, T = KS_ * KS_;
-    static constexpr int NPL = NPL_, NP = NPL_ == 3 ? 6 : (NPL_ == 2 ? 3 : 1);   // operand planes / partial products (1: RCF_PREC_BF16, 2: RCF_PREC_BF16X3)
+    static constexpr int NPL = NPL_, NP = NPL_ == 3 ? 6 : (NPL_ == 2 ? 3 : 1);   // operand planes / partial products (1: RCF_PREC_BF16, 2: RCF_PREC_F16X2)
     static constexpr int WCI = WCI_, WCO = WCO_, KSPLIT = 4 / (WCI_ * WCO_);
     static constexpr int NCI = 32 * WCI_, NCO = 32 * WCO_;
     static constexpr int PX = 16, TH = TH_, HXP = PX + KS - 1, HYP = TH + KS - 1;
@@ -1436,6 +1456,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
     for (int tap = 0; tap < C::T; ++tap)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tap][r] = 0.f;
+    SplitScales sc = {1.f, 1.f, 1.f, 1.f};   // NPL == 2: scales of x (A operand) and dz (B operand)
+    if constexpr (C::NPL == 2) sc = rcf_split_scales(a.amax_a1, a.amax_a2, a.amax_b);
 
     // ---- staging: fp32 [pixel][channel] in HBM -> registers (next tile, during this tile's MFMAs) -> bf16 planes in LDS
     // BN-on-load (x is a raw conv output, y = lrelu(z * scale + shift) applied while staging): coefficient table in LDS
@@ -1548,7 +1570,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             w0[d] = __builtin_amdgcn_perm(v[2 * d + 1][e >> 1], v[2 * d][e >> 1], (e & 1) ? 0x07060302u : 0x05040100u);
         *reinterpret_cast<u32x4*>(dst) = w0;
     };
-    auto split8 = [&](const f32x4 (&v)[8], int e, unsigned char* dst, int plane_bytes) {
+    auto split8 = [&](const f32x4 (&v)[8], int e, unsigned char* dst, int plane_bytes, float scale) {
         u32x4 w0, w1, w2;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -1558,7 +1580,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 const float x = v[2 * d + h][e];
                 x0[h] = __float_as_uint(x) & 0xffff0000u;
                 const float r1 = x - __uint_as_float(x0[h]);
-                x1[h] = (C::NPL == 2 ? rcf_bf16_rne(r1) : __float_as_uint(r1)) & 0xffff0000u;   // last plane: rounded
+                x1[h] = __float_as_uint(r1) & 0xffff0000u;
                 const float r2 = r1 - __uint_as_float(x1[h]);
                 x2[h] = __float_as_uint(r2);
             }
@@ -1568,13 +1590,11 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 w0[d] = __builtin_amdgcn_perm(x0[1], x0[0], 0x07060302u);   // high halves of the pixel pair
                 w1[d] = __builtin_amdgcn_perm(x1[1], x1[0], 0x07060302u);
                 w2[d] = __builtin_amdgcn_perm(x2[1], x2[0], 0x07060302u);
-#ifdef RCF_X3_F16
-                if (C::NPL == 2) {
-                    const rcf_f16_pair q = rcf_f16_planes(v[2 * d][e], v[2 * d + 1][e]);
+                if constexpr (C::NPL == 2) {   // two fp16 planes of the scaled values
+                    const rcf_f16_pair q = rcf_f16_planes(v[2 * d][e] * scale, v[2 * d + 1][e] * scale);
                     w0[d] = q.p0;
                     w1[d] = q.p1;
                 }
-#endif
             }
         }
         *reinterpret_cast<u32x4*>(dst) = w0;
@@ -1600,7 +1620,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if constexpr (RAWX) pack8(rx[i], e, Xs + (e * C::CQX + cq) * C::SX + hy * C::XROW + g * 16);
-                    else split8(rx[i], e, Xs + (e * C::CQX + cq) * C::SX + hy * C::XROW + g * 16, C::XPL);
+                    else split8(rx[i], e, Xs + (e * C::CQX + cq) * C::SX + hy * C::XROW + g * 16, C::XPL, sc.sa);
             }
         }
 #pragma unroll
@@ -1611,7 +1631,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if constexpr (RAWD) pack8(rd[i], e, Ds + (e * C::CQD + cq) * C::SD + r * C::DROW + g * 16);
-                    else split8(rd[i], e, Ds + (e * C::CQD + cq) * C::SD + r * C::DROW + g * 16, C::DPL);
+                    else split8(rd[i], e, Ds + (e * C::CQD + cq) * C::SD + r * C::DROW + g * 16, C::DPL, sc.sb);
             }
         }
     };
@@ -1740,6 +1760,12 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
     const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
 #endif
 
+    if constexpr (C::NPL == 2) {   // undo the operand scales (exact: powers of two)
+#pragma unroll
+        for (int tap = 0; tap < C::T; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tap][r] = acc[tap][r] * sc.ia * sc.ib;
+    }
     // ---- sum the KSPLIT row slices of each (wi, wj) block through LDS (fixed order), then one partial per workgroup
     if (C::KSPLIT > 1) {
         float* red = reinterpret_cast<float*>(smem_b) + (wi + C::WCI * wj) * (C::T * 16 * 64);
@@ -1890,7 +1916,7 @@ __global__ void __launch_bounds__(256) pack_weights_batch_kernel(PackBatch b) {
     const size_t idx = (size_t)(blockIdx.x - b.blk_start[i]) * 256 + threadIdx.x;
     if (p.split)
         pack_weights_split_body(idx, p.w, static_cast<unsigned short*>(p.dst), p.total, p.w_o, p.w_i, p.mode, p.i_off, p.c_out, p.c1,
-                                p.c2, p.nchunk1, p.nchunk, p.BN, p.ks, p.npl);
+                                p.c2, p.nchunk1, p.nchunk, p.BN, p.ks, p.npl, p.amax);
     else
         pack_weights_body(idx, p.w, static_cast<float*>(p.dst), p.total, p.w_o, p.w_i, p.ks, p.mode, p.i_off, p.c_out, p.c1, p.c2,
                           p.nchunk1, p.nchunk, p.T, p.ksx, p.BN, p.CK, p.kind);
@@ -1985,7 +2011,7 @@ struct Sel {
     int split;   // fp32 on the bf16 matrix pipe (conv_split_kernel)
     int small;   // split 3x3 layer too small to fill the chip with 64-co workgroups: 256-pixel x 32-co workgroups instead
     int bf16;    // rcf_conv_desc.precision == RCF_PREC_BF16 and a split kernel: one bf16 plane, one product
-    int npl;     // operand planes of a split kernel: 3 (exact fp32), 2 (RCF_PREC_BF16X3), 1 (bf16)
+    int npl;     // operand planes of a split kernel: 3 (exact fp32), 2 (RCF_PREC_F16X2), 1 (bf16)
     int dma;     // bf16 tensors, channel counts multiples of 16: conv_b16_kernel (operands reach LDS by DMA, rcf_conv_b16_dma.h)
     int pw;      // bf16 tensors, 1x1, <= 64 input and <= 128 output channels: conv1x1_b16_kernel (operands straight from global memory)
 };
@@ -2247,7 +2273,7 @@ bool valid_desc(const rcf_conv_desc* d) {
     if (d->ksize != 1 && d->ksize != 2 && d->ksize != 3 && d->ksize != 4 && d->ksize != 7) return false;
     if (d->stride != 1 && d->stride != 2) return false;
     if (d->gather1 < 0 || d->gather1 > 3) return false;
-    if (d->precision != RCF_PREC_FP32 && d->precision != RCF_PREC_BF16 && d->precision != RCF_PREC_BF16X3) return false;
+    if (d->precision != RCF_PREC_FP32 && d->precision != RCF_PREC_BF16 && d->precision != RCF_PREC_F16X2) return false;
     if (d->storage != RCF_STORE_FP32 && d->storage != RCF_STORE_BF16) return false;
     if (d->storage == RCF_STORE_BF16 && d->precision != RCF_PREC_BF16) return false;   // bf16 tensors are consumed as bf16 operands
     if ((d->storage == RCF_STORE_BF16) != SAct::B16) return false;                    // (each translation unit serves one storage)
@@ -2338,7 +2364,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
         const long long wgs = (((long long)d->n * d->h_out * d->w_out + 255) / 256) * ceil_div(d->c_out, 64);
         if (s->kind == K3S1 && s->nt == 2 && wgs < num_cus()) { s->small = 1; s->nt = 1; }
         s->bf16 = d->precision == RCF_PREC_BF16 ? 1 : 0;
-        s->npl = s->bf16 ? 1 : (d->precision == RCF_PREC_BF16X3 ? 2 : 3);
+        s->npl = s->bf16 ? 1 : (d->precision == RCF_PREC_F16X2 ? 2 : 3);
 #if RCF_CONV_B16
         const char* e = getenv("RCF_B16_DMA");
         s->dma = (s->bf16 && d->c1 % 16 == 0 && d->c2 % 16 == 0 && (e == nullptr || e[0] != '0')) ? 1 : 0;
@@ -2375,6 +2401,7 @@ const float* zero_page_ptr() {
 
 void fill_args(const rcf_conv_desc* d, const Sel& s, ConvArgs* a) {
     a->coef1 = nullptr; a->coef2 = nullptr; a->bias = nullptr; a->res = nullptr;
+    a->amax_a1 = nullptr; a->amax_a2 = nullptr; a->amax_b = nullptr;
     a->zero = zero_page_ptr();
     a->n = d->n; a->h_in = d->h_in; a->w_in = d->w_in; a->c1 = d->c1; a->c2 = d->c2;
     a->h1 = d->h_src1; a->w1 = d->w_src1; a->gather1 = d->gather1;
@@ -2449,7 +2476,7 @@ int dispatch_dma(const Sel& s, F&& f) {
 }
 #endif
 
-// fp32 tensors: NPL = 3 (the S* configurations above: exact) or NPL = 2 (RCF_PREC_BF16X3), same tile shapes
+// fp32 tensors: NPL = 3 (the S* configurations above: exact) or NPL = 2 (RCF_PREC_F16X2), same tile shapes
 template <int NPL, class F>
 int dispatch_split_planes(const Sel& s, F&& f) {
     const bool p16 = s.px == 16;
@@ -2673,24 +2700,24 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
     info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0) + (s.small ? 5 : 0) + (s.bf16 ? 20000 : 0) + ((s.split && s.npl == 2) ? 40000 : 0);
     info->wgrad_workspace_floats = 0;
     info->wgrad_kernel_id = 0;
-    info->bn_on_load = (s.split && !s.dma && !s.pw && d->w_mode == RCF_W_FORWARD && d->c1 + d->c2 <= 512) ? 1 : 0;   // a DMA cannot transform
+    info->bn_on_load = (s.split && !s.dma && !s.pw && d->w_mode == RCF_W_FORWARD && d->c1 + d->c2 <= 512 && s.npl != 2) ? 1 : 0;   // a DMA cannot transform; fp16 planes need the maximum of the TRANSFORMED tensor
     info->wgrad_bn_on_load = 0;
     info->fwd_act = (s.split && !s.pw && d->w_mode == RCF_W_FORWARD && !d->accumulate) ? 1 : 0;
     if (d->w_mode == RCF_W_FORWARD) {
         WSel w;
         if (select_wgrad(d, &w) == RCF_OK) {
             info->wgrad_workspace_floats = (size_t)w.nsplit * w.ktot * w.cop + 64;   // + a zero page for the DMA path
-            info->wgrad_bn_on_load = (w.split && !SAct::B16) ? 1 : 0;   // bf16 tensors are staged raw: nothing to apply BatchNorm to
+            info->wgrad_bn_on_load = (w.split && !SAct::B16 && d->precision != RCF_PREC_F16X2) ? 1 : 0;   // bf16 tensors are staged raw: nothing to apply BatchNorm to
             info->wgrad_kernel_id = 10000 + w.kind * 1000 + (w.px == 16 ? 100 : (w.px == 8 ? 200 : 0)) + (w.vt ? 400 : 0) +
                                     (w.split ? 5000 + w.wci * 10 + w.wco : 0) + ((w.split && d->precision == RCF_PREC_BF16) ? 20000 : 0) +
-                                    ((w.split && d->precision == RCF_PREC_BF16X3) ? 40000 : 0);
+                                    ((w.split && d->precision == RCF_PREC_F16X2) ? 40000 : 0);
         }
     }
     return RCF_OK;
 }
 
 // arguments of one weight packing (shared by the single and the batched entry point)
-static int pack_args(const rcf_conv_desc* d, const float* w_oihw, float* packed, PackArgs* p, unsigned* blocks) {
+static int pack_args(const rcf_conv_desc* d, const float* w_oihw, float* packed, const float* amax_w, PackArgs* p, unsigned* blocks) {
     if (!d || !w_oihw || !packed) return RCF_EINVAL;
     Sel s;
     int rc = select_cfg(d, &s);
@@ -2699,7 +2726,7 @@ static int pack_args(const rcf_conv_desc* d, const float* w_oihw, float* packed,
     fill_args(d, s, &a);
     const int ntile_n = ceil_div(d->c_out, s.bn);
     const int nchunk = a.nchunk1 + a.nchunk2;
-    p->w = w_oihw; p->dst = packed;
+    p->w = w_oihw; p->dst = packed; p->amax = amax_w;
     p->w_o = d->w_o; p->w_i = d->w_i; p->ks = d->ksize; p->mode = d->w_mode; p->i_off = d->w_i_off; p->c_out = d->c_out;
     p->c1 = d->c1; p->c2 = d->c2; p->nchunk1 = a.nchunk1; p->nchunk = nchunk; p->T = s.t; p->BN = s.bn; p->CK = s.ck;
     p->ksx = s.kind == K7S2 ? 1 : d->ksize; p->kind = s.kind == K7S2 ? 1 : 0; p->npl = s.npl; p->split = s.split ? 1 : 0;
@@ -2708,21 +2735,31 @@ static int pack_args(const rcf_conv_desc* d, const float* w_oihw, float* packed,
     return RCF_OK;
 }
 
-extern "C" int RCF_FN(rcf_conv2d_pack_weights)(const rcf_conv_desc* d, const float* w_oihw, float* packed, void* stream) {
-    RCF_TO_B16(d, rcf_conv2d_pack_weights_b16impl(d, w_oihw, packed, stream));
+static int pack_weights_impl(const rcf_conv_desc* d, const float* w_oihw, float* packed, const float* amax_w, void* stream) {
     if (!w_oihw || !packed) return RCF_EINVAL;
     PackArgs p;
     unsigned blocks = 0;
-    const int rc = pack_args(d, w_oihw, packed, &p, &blocks);
+    const int rc = pack_args(d, w_oihw, packed, amax_w, &p, &blocks);
     if (rc != RCF_OK) return rc;
     if (p.split)
         hipLaunchKernelGGL(pack_weights_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p.w, static_cast<unsigned short*>(p.dst),
-                           (size_t)p.total, p.w_o, p.w_i, p.mode, p.i_off, p.c_out, p.c1, p.c2, p.nchunk1, p.nchunk, p.BN, p.ks, p.npl);
+                           (size_t)p.total, p.w_o, p.w_i, p.mode, p.i_off, p.c_out, p.c1, p.c2, p.nchunk1, p.nchunk, p.BN, p.ks, p.npl, p.amax);
     else
         hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p.w, static_cast<float*>(p.dst), (size_t)p.total,
                            p.w_o, p.w_i, p.ks, p.mode, p.i_off, p.c_out, p.c1, p.c2, p.nchunk1, p.nchunk, p.T, p.ksx, p.BN, p.CK, p.kind);
     return rcf_launch_status();
 }
+
+extern "C" int RCF_FN(rcf_conv2d_pack_weights)(const rcf_conv_desc* d, const float* w_oihw, float* packed, void* stream) {
+    RCF_TO_B16(d, rcf_conv2d_pack_weights_b16impl(d, w_oihw, packed, stream));
+    return pack_weights_impl(d, w_oihw, packed, nullptr, stream);
+}
+#if !RCF_CONV_B16
+extern "C" int rcf_conv2d_pack_weights_scaled(const rcf_conv_desc* d, const float* w_oihw, float* packed, const float* amax_w, void* stream) {
+    if (d != nullptr && (d->storage == RCF_STORE_BF16 || d->precision != RCF_PREC_F16X2)) return RCF_EUNSUPPORTED;
+    return pack_weights_impl(d, w_oihw, packed, amax_w, stream);
+}
+#endif
 
 // rcf_conv2d_pack_weights_batch: the items of THIS translation unit's storage, PACK_BATCH per launch
 extern "C" int RCF_FN(rcf_conv2d_pack_weights_batch)(const rcf_pack_item* items, int n, void* stream) {
@@ -2752,7 +2789,8 @@ extern "C" int RCF_FN(rcf_conv2d_pack_weights_batch)(const rcf_pack_item* items,
         unsigned nblk = 0;
         while (i < n && b.n < PACK_BATCH) {
             unsigned blocks = 0;
-            const int rc = pack_args(items[i].desc, items[i].w_oihw, items[i].packed, &b.it[b.n], &blocks);
+            const int rc = pack_args(items[i].desc, items[i].w_oihw, items[i].packed,
+                                     items[i].desc->precision == RCF_PREC_F16X2 ? items[i].amax_w : nullptr, &b.it[b.n], &blocks);
             if (rc != RCF_OK) return rc;
             b.blk_start[b.n] = nblk;
             nblk += blocks;
@@ -2767,7 +2805,7 @@ extern "C" int RCF_FN(rcf_conv2d_pack_weights_batch)(const rcf_pack_item* items,
 }
 
 static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
-                           const float* packed, float* out, double* stat_partials, void* stream);
+                           const float* packed, float* out, double* stat_partials, void* stream, const rcf_conv_scales* sc = nullptr);
 
 extern "C" int RCF_FN(rcf_conv2d_fwd)(const rcf_conv_desc* d, const void* in1, const void* in2, const float* packed, void* out,
                                       double* stat_partials, void* stream) {
@@ -2781,8 +2819,17 @@ extern "C" int RCF_FN(rcf_conv2d_fwd_bn)(const rcf_conv_desc* d, const void* in1
     return conv2d_fwd_impl(d, (const float*)in1, coef1, (const float*)in2, coef2, packed, (float*)out, stat_partials, stream);
 }
 
+#if !RCF_CONV_B16
+extern "C" int rcf_conv2d_fwd_scaled(const rcf_conv_desc* d, const void* in1, const void* in2, const float* packed, void* out,
+                                     double* stat_partials, const rcf_conv_scales* scales, void* stream) {
+    if (!scales) return RCF_EINVAL;
+    if (d != nullptr && (d->storage == RCF_STORE_BF16 || d->precision != RCF_PREC_F16X2)) return RCF_EUNSUPPORTED;
+    return conv2d_fwd_impl(d, (const float*)in1, nullptr, (const float*)in2, nullptr, packed, (float*)out, stat_partials, stream, scales);
+}
+#endif
+
 static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
-                           const float* packed, float* out, double* stat_partials, void* stream) {
+                           const float* packed, float* out, double* stat_partials, void* stream, const rcf_conv_scales* sc) {
     if (!in1 || !packed || !out) return RCF_EINVAL;
     Sel s;
     int rc = select_cfg(d, &s);
@@ -2796,6 +2843,10 @@ static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float
     a.coef1 = coef1; a.coef2 = coef2;
     a.in1 = in1; a.in2 = in2; a.wp = packed; a.out = out; a.stats = stat_partials; a.dz = nullptr; a.ws = nullptr;
     a.ktot = 0; a.cop = 0;
+    if (sc != nullptr) {
+        if (!s.split || s.npl != 2) return RCF_EUNSUPPORTED;   // scales belong to the two-plane fp16 split kernels
+        a.amax_a1 = sc->amax_in1; a.amax_a2 = d->c2 > 0 ? sc->amax_in2 : nullptr; a.amax_b = sc->amax_w;
+    }
     const int nn = ceil_div(d->c_out, s.bn);
     a.wp_phase_stride = (int)((size_t)nn * (a.nchunk1 + a.nchunk2) * s.t * s.bn * (s.split ? 8 * s.npl : s.ck));
 #if RCF_CONV_B16
@@ -2839,7 +2890,7 @@ extern "C" int RCF_FN(rcf_conv2d_fwd_act)(const rcf_conv_desc* d, const void* in
     return dispatch_split(s, [&](auto tag) { return launch_split<typename decltype(tag)::type, true>(a, nn, (hipStream_t)stream); });
 }
 
-// split weight-gradient kernels on fp32 tensors: NPL = 3 (exact) or 2 (RCF_PREC_BF16X3); same tilings (select_wgrad)
+// split weight-gradient kernels on fp32 tensors: NPL = 3 (exact) or 2 (RCF_PREC_F16X2); same tilings (select_wgrad)
 template <int NPL>
 static int launch_wgrad_split_planes(const ConvArgs& a, const WSel& w, int cfg, hipStream_t st) {
     if (w.kind == K2S1) {
@@ -2855,7 +2906,7 @@ static int launch_wgrad_split_planes(const ConvArgs& a, const WSel& w, int cfg, 
 }
 
 static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
-                             const float* dz, float* dw_oihw, float* workspace, void* stream);
+                             const float* dz, float* dw_oihw, float* workspace, void* stream, const rcf_conv_scales* sc = nullptr);
 
 extern "C" int RCF_FN(rcf_conv2d_wgrad)(const rcf_conv_desc* d, const void* in1, const void* in2, const void* dz,
                                         float* dw_oihw, float* workspace, void* stream) {
@@ -2869,8 +2920,17 @@ extern "C" int RCF_FN(rcf_conv2d_wgrad_bn)(const rcf_conv_desc* d, const void* i
     return conv2d_wgrad_impl(d, (const float*)in1, coef1, (const float*)in2, coef2, (const float*)dz, dw_oihw, workspace, stream);
 }
 
+#if !RCF_CONV_B16
+extern "C" int rcf_conv2d_wgrad_scaled(const rcf_conv_desc* d, const void* in1, const void* in2, const void* dz, float* dw_oihw,
+                                       float* workspace, const rcf_conv_scales* scales, void* stream) {
+    if (!scales) return RCF_EINVAL;
+    if (d != nullptr && (d->storage == RCF_STORE_BF16 || d->precision != RCF_PREC_F16X2)) return RCF_EUNSUPPORTED;
+    return conv2d_wgrad_impl(d, (const float*)in1, nullptr, (const float*)in2, nullptr, (const float*)dz, dw_oihw, workspace, stream, scales);
+}
+#endif
+
 static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
-                             const float* dz, float* dw_oihw, float* workspace, void* stream) {
+                             const float* dz, float* dw_oihw, float* workspace, void* stream, const rcf_conv_scales* sc) {
     if (!in1 || !dz || !dw_oihw || !workspace) return RCF_EINVAL;
     WSel w;
     int rc = select_wgrad(d, &w);
@@ -2879,6 +2939,11 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
     if ((coef1 || coef2) && (!w.split || SAct::B16 || (coef2 && d->c2 == 0))) return RCF_EUNSUPPORTED;
     ConvArgs a;
     a.bias = nullptr; a.res = nullptr;
+    a.amax_a1 = nullptr; a.amax_a2 = nullptr; a.amax_b = nullptr;
+    if (sc != nullptr) {
+        if (!w.split || d->precision != RCF_PREC_F16X2) return RCF_EUNSUPPORTED;
+        a.amax_a1 = sc->amax_in1; a.amax_a2 = d->c2 > 0 ? sc->amax_in2 : nullptr; a.amax_b = sc->amax_dz;
+    }
     a.zero = zero_page_ptr();
     if (a.zero == nullptr) return (int)hipErrorInvalidSymbol;
     a.coef1 = coef1; a.coef2 = coef2;
@@ -2917,7 +2982,7 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
             else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 3, THB, 1>>(a, w.nsplit, w.gy, w.gz, st);
             else rc = launch_wgrad_split<WsCfg<1, 1, 3, 16, 1>>(a, w.nsplit, w.gy, w.gz, st);
         } else if constexpr (!SAct::B16) {
-            rc = d->precision == RCF_PREC_BF16X3 ? launch_wgrad_split_planes<2>(a, w, cfg, st) : launch_wgrad_split_planes<3>(a, w, cfg, st);
+            rc = d->precision == RCF_PREC_F16X2 ? launch_wgrad_split_planes<2>(a, w, cfg, st) : launch_wgrad_split_planes<3>(a, w, cfg, st);
         } else return RCF_EUNSUPPORTED;
     } else
     switch (w.kind) {

@@ -51,10 +51,12 @@ template <class S>
 __device__ __forceinline__ void st4(float* p, size_t i, f32x4 v) { rcf_st4<S>(p, i, v); }
 
 // ---------------------------------------------------------------- forward
-template <class S>
+// AM: also accumulate max|value written| into *amax (rcf_common.h: the per-tensor maximum of the two-plane fp16 convolutions)
+template <class S, bool AM = false>
 __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ coef,
                                                          const float* __restrict__ res, float* __restrict__ out,
-                                                         long long n_pix, int c, int act) {
+                                                         long long n_pix, int c, int act, float* __restrict__ amax = nullptr) {
+    float am = 0.f;
     const int c4n = c >> 2;
     const int cg = threadIdx.x % c4n;
     const int pl = threadIdx.x / c4n;
@@ -74,6 +76,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
             for (int j = 0; j < 4; ++j) y[j] = rcf_lrelu(y[j] + r[j]);
         }
         st4<S>(out, i, y);
+        if (AM) am = rcf_amax4(am, y);
     };
     long long p = (long long)blockIdx.x * ppb + pl;
     for (; p + (EW_U - 1) * stride < n_pix; p += EW_U * stride) {
@@ -92,13 +95,15 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
         const f32x4 zz = ld4<S>(z, i);
         one(zz, res != nullptr ? ld4<S>(res, i) : zz, i);
     }
+    if (AM) rcf_amax_commit(am, amax);
 }
 
-template <class S>
+template <class S, bool AM = false>
 __global__ void __launch_bounds__(256) fuse_fwd_kernel(const float* __restrict__ zw, const float* __restrict__ coef_w,
                                                        const float* __restrict__ zp, const float* __restrict__ coef_p,
                                                        const float* __restrict__ img, float* __restrict__ out,
-                                                       long long n_pix, int c) {
+                                                       long long n_pix, int c, float* __restrict__ amax = nullptr) {
+    float am = 0.f;
     const int c4n = c >> 2;
     const int cg = threadIdx.x % c4n;
     const int pl = threadIdx.x / c4n;
@@ -114,7 +119,9 @@ __global__ void __launch_bounds__(256) fuse_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (1.f / (1.f + expf(-yw[j]))) * yp[j] + im[j];
         st4<S>(out, i, o);
+        if (AM) am = rcf_amax4(am, o);
     }
+    if (AM) rcf_amax_commit(am, amax);
 }
 
 // ---------------------------------------------------------------- block reduction of NS per-channel sums
@@ -187,12 +194,13 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(const float* __r
     block_reduce_store<2>(s, partials + (size_t)blockIdx.x * 2 * c, c, cg, pl, sm);
 }
 
-template <class S>
+template <class S, bool AM = false>
 __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ z,
                                                                const float* __restrict__ coef, const float* __restrict__ out,
                                                                const float* __restrict__ bcoef, float* __restrict__ dz,
                                                                float* __restrict__ dres, int dres_accumulate, long long n_pix,
-                                                               int c, int act, int has_res) {
+                                                               int c, int act, int has_res, float* __restrict__ amax = nullptr) {
+    float am = 0.f;
     const int c4n = c >> 2;
     const int cg = threadIdx.x % c4n;
     const int pl = threadIdx.x / c4n;
@@ -222,6 +230,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const float* __re
             r[j] = k.scale[j] * (gj - b0[j] - xh[j] * b1[j]);
         }
         st4<S>(dz, i, r);
+        if (AM) am = rcf_amax4(am, r);
     };
     long long p = (long long)blockIdx.x * ppb + pl;
     for (; p + (EW_U - 1) * stride < n_pix; p += EW_U * stride) {
@@ -242,6 +251,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const float* __re
         const f32x4 zz = ld4<S>(z, i);
         one(ld4<S>(dout, i), zz, has_res ? ld4<S>(out, i) : zz, (want_dres && dres_accumulate) ? ld4<S>(dres, i) : zz, i);
     }
+    if (AM) rcf_amax_commit(am, amax);
 }
 
 // ---- BatchNorm backward of the layer that feeds the 3x3 C->1 output head, fused with the head's input gradient:
@@ -326,11 +336,12 @@ __global__ void __launch_bounds__(256) head_bn_bwd_reduce_kernel(const float* __
     block_reduce_store<2>(s, partials + (size_t)blockIdx.x * 2 * C, C, hb.cg, threadIdx.x / C4N, smd);
 }
 
-template <int C4N, class S>
+template <int C4N, class S, bool AM = false>
 __global__ void __launch_bounds__(256) head_bn_bwd_apply_kernel(const float* __restrict__ dlogit, const float* __restrict__ w_head,
                                                                 const float* __restrict__ z, const float* __restrict__ coef,
                                                                 const float* __restrict__ bcoef, float* __restrict__ dz, int n, int h,
-                                                                int w) {
+                                                                int w, float* __restrict__ amax = nullptr) {
+    float am = 0.f;
     constexpr int C = 4 * C4N;
     __shared__ __attribute__((aligned(16))) float wl[9 * C];
     __shared__ float D[HB_NP];
@@ -357,8 +368,10 @@ __global__ void __launch_bounds__(256) head_bn_bwd_apply_kernel(const float* __r
 #pragma unroll
             for (int j = 0; j < 4; ++j) r[j] = kc.scale[j] * (g0[j] * rcf_lrelu_grad(y[j]) - b0[j] - xh[j] * b1[j]);
             st4<S>(dz, i, r);
+            if (AM) am = rcf_amax4(am, r);
         }
     }
+    if (AM) rcf_amax_commit(am, amax);
 }
 
 template <class S>
@@ -546,23 +559,23 @@ extern "C" int rcf_bn_finalize(const double* partials, int n_partials, int c, do
     return rcf_launch_status();
 }
 
-template <class S>
+template <class S, bool AM = false>
 static int bn_act_fwd_impl(const float* z, const float* coef, const float* res, float* out, long long n_pix, int c,
-                              int act, void* stream) {
-    if (!z || !coef || !out || n_pix <= 0) return RCF_EINVAL;
+                              int act, void* stream, float* amax = nullptr) {
+    if (!z || !coef || !out || n_pix <= 0 || (AM && !amax)) return RCF_EINVAL;
     if (!c4_ok(c)) return RCF_EUNSUPPORTED;
-    hipLaunchKernelGGL((bn_act_fwd_kernel<S>), dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, z, coef, res, out,
-                       n_pix, c, act);
+    hipLaunchKernelGGL((bn_act_fwd_kernel<S, AM>), dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, z, coef, res, out,
+                       n_pix, c, act, amax);
     return rcf_launch_status();
 }
 
-template <class S>
+template <class S, bool AM = false>
 static int fuse_fwd_impl(const float* zw, const float* coef_w, const float* zp, const float* coef_p, const float* img,
-                            float* out, long long n_pix, int c, void* stream) {
-    if (!zw || !coef_w || !zp || !coef_p || !img || !out || n_pix <= 0) return RCF_EINVAL;
+                            float* out, long long n_pix, int c, void* stream, float* amax = nullptr) {
+    if (!zw || !coef_w || !zp || !coef_p || !img || !out || n_pix <= 0 || (AM && !amax)) return RCF_EINVAL;
     if (!c4_ok(c)) return RCF_EUNSUPPORTED;
-    hipLaunchKernelGGL((fuse_fwd_kernel<S>), dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, zw, coef_w, zp, coef_p,
-                       img, out, n_pix, c);
+    hipLaunchKernelGGL((fuse_fwd_kernel<S, AM>), dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, zw, coef_w, zp, coef_p,
+                       img, out, n_pix, c, amax);
     return rcf_launch_status();
 }
 
@@ -586,14 +599,14 @@ extern "C" int rcf_bn_bwd_finalize(const double* partials, int n_blocks, int par
     return rcf_launch_status();
 }
 
-template <class S>
+template <class S, bool AM = false>
 static int bn_act_bwd_apply_impl(const float* dout, const float* z, const float* coef, const float* out, const float* bcoef,
                                     float* dz, float* dres, int dres_accumulate, long long n_pix, int c, int act, int has_res,
-                                    void* stream) {
-    if (!dout || !z || !coef || !bcoef || !dz || n_pix <= 0 || (has_res && !out)) return RCF_EINVAL;
+                                    void* stream, float* amax = nullptr) {
+    if (!dout || !z || !coef || !bcoef || !dz || n_pix <= 0 || (has_res && !out) || (AM && !amax)) return RCF_EINVAL;
     if (!c4_ok(c)) return RCF_EUNSUPPORTED;
-    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<S>), dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, dout, z, coef, out,
-                       bcoef, dz, dres, dres_accumulate, n_pix, c, act, has_res);
+    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<S, AM>), dim3(ew_blocks(n_pix, c)), dim3(256), 0, (hipStream_t)stream, dout, z, coef, out,
+                       bcoef, dz, dres, dres_accumulate, n_pix, c, act, has_res, amax);
     return rcf_launch_status();
 }
 
@@ -646,14 +659,14 @@ static int head_bn_bwd_reduce_impl(const float* dlogit, const float* w_head, con
     return rcf_launch_status();
 }
 
-template <class S>
+template <class S, bool AM = false>
 static int head_bn_bwd_apply_impl(const float* dlogit, const float* w_head, const float* z, const float* coef, const float* bcoef,
-                                     float* dz, int n, int h, int w, int c, void* stream) {
-    if (!dlogit || !w_head || !z || !coef || !bcoef || !dz) return RCF_EINVAL;
+                                     float* dz, int n, int h, int w, int c, void* stream, float* amax = nullptr) {
+    if (!dlogit || !w_head || !z || !coef || !bcoef || !dz || (AM && !amax)) return RCF_EINVAL;
     if (rcf_head_bn_blocks(n, h, w, c) <= 0) return RCF_EUNSUPPORTED;
     const unsigned nt = (unsigned)n * ((h + HB_H - 1) / HB_H) * ((w + HB_W - 1) / HB_W);
     hipStream_t st = (hipStream_t)stream;
-#define RCF_HBA(N) hipLaunchKernelGGL((head_bn_bwd_apply_kernel<N, S>), dim3(nt), dim3(256), 0, st, dlogit, w_head, z, coef, bcoef, dz, n, h, w)
+#define RCF_HBA(N) hipLaunchKernelGGL((head_bn_bwd_apply_kernel<N, S, AM>), dim3(nt), dim3(256), 0, st, dlogit, w_head, z, coef, bcoef, dz, n, h, w, amax)
     switch (c >> 2) {
         case 1: RCF_HBA(1); break;
         case 2: RCF_HBA(2); break;
@@ -702,3 +715,14 @@ extern "C" int rcf_head_bn_bwd_apply(const float* dlogit, const float* w_head, c
                                      float* dz, int n, int h, int w, int c, void* stream) { return head_bn_bwd_apply_impl<StF32>(dlogit, w_head, z, coef, bcoef, dz, n, h, w, c, stream); }
 extern "C" int rcf_head_bn_bwd_apply_b16(const float* dlogit, const float* w_head, const float* z, const float* coef, const float* bcoef,
                                      float* dz, int n, int h, int w, int c, void* stream) { return head_bn_bwd_apply_impl<StB16>(dlogit, w_head, z, coef, bcoef, dz, n, h, w, c, stream); }
+
+// ---- the same kernels also accumulating max|value written| (fp32 tensors; include/rcf_hip.h: rcf_*_amax)
+extern "C" int rcf_bn_act_fwd_amax(const float* z, const float* coef, const float* res, float* out, long long n_pix, int c, int act,
+                                   float* amax, void* stream) { return bn_act_fwd_impl<StF32, true>(z, coef, res, out, n_pix, c, act, stream, amax); }
+extern "C" int rcf_fuse_fwd_amax(const float* zw, const float* coef_w, const float* zp, const float* coef_p, const float* img, float* out,
+                                 long long n_pix, int c, float* amax, void* stream) { return fuse_fwd_impl<StF32, true>(zw, coef_w, zp, coef_p, img, out, n_pix, c, stream, amax); }
+extern "C" int rcf_bn_act_bwd_apply_amax(const float* dout, const float* z, const float* coef, const float* out, const float* bcoef,
+                                         float* dz, float* dres, int dres_accumulate, long long n_pix, int c, int act, int has_res,
+                                         float* amax, void* stream) { return bn_act_bwd_apply_impl<StF32, true>(dout, z, coef, out, bcoef, dz, dres, dres_accumulate, n_pix, c, act, has_res, stream, amax); }
+extern "C" int rcf_head_bn_bwd_apply_amax(const float* dlogit, const float* w_head, const float* z, const float* coef, const float* bcoef,
+                                          float* dz, int n, int h, int w, int c, float* amax, void* stream) { return head_bn_bwd_apply_impl<StF32, true>(dlogit, w_head, z, coef, bcoef, dz, n, h, w, c, stream, amax); }

@@ -975,6 +975,72 @@ __global__ void __launch_bounds__(256) scale_channels_kernel(const float* __rest
 }
 }   // namespace
 
+// ---- max|x| of a tensor (the per-tensor scale of the two-plane fp16 convolutions; rcf_common.h) ------------------------------------
+namespace {
+// each block takes <= AMAX_SLICE elements: 16-B loads where the slice is aligned, one atomic per wave at the end
+constexpr long long AMAX_SLICE = 16384;
+__device__ __forceinline__ void amax_slice(const float* __restrict__ x, long long n, long long blk, float* __restrict__ amax) {
+    const long long lo = blk * AMAX_SLICE;
+    const long long hi = lo + AMAX_SLICE < n ? lo + AMAX_SLICE : n;
+    float m = 0.f;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const long long hi4 = lo + ((hi - lo) & ~3ll);
+        for (long long i = lo + 4 * threadIdx.x; i < hi4; i += 1024) m = rcf_amax4(m, *reinterpret_cast<const f32x4*>(x + i));
+        for (long long i = hi4 + threadIdx.x; i < hi; i += 256) m = fmaxf(m, fabsf(x[i]));
+    } else {
+        for (long long i = lo + threadIdx.x; i < hi; i += 256) m = fmaxf(m, fabsf(x[i]));
+    }
+    rcf_amax_commit(m, amax);
+}
+__global__ void __launch_bounds__(256) amax_kernel(const float* __restrict__ x, long long n, float* __restrict__ amax) {
+    amax_slice(x, n, blockIdx.x, amax);
+}
+struct AmaxArgs { const float* x; float* amax; long long n; };
+constexpr int AMAX_BATCH = 128;
+struct AmaxBatch {
+    int n;
+    unsigned blk_start[AMAX_BATCH + 1];
+    AmaxArgs it[AMAX_BATCH];
+};
+static_assert(sizeof(AmaxBatch) <= 4096, "the batch travels as kernel arguments");
+__global__ void __launch_bounds__(256) amax_batch_kernel(AmaxBatch b) {
+    int lo = 0, hi = b.n - 1;   // the item of this block: last i with blk_start[i] <= blockIdx.x (wave-uniform binary search)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (b.blk_start[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    amax_slice(b.it[lo].x, b.it[lo].n, blockIdx.x - b.blk_start[lo], b.it[lo].amax);
+}
+}   // namespace
+
+extern "C" int rcf_amax(const float* x, long long n, float* amax, void* stream) {
+    if (!x || !amax || n <= 0) return RCF_EINVAL;
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)((n + AMAX_SLICE - 1) / AMAX_SLICE)), dim3(256), 0, (hipStream_t)stream, x, n, amax);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_amax_batch(const rcf_amax_item* items, int n, void* stream) {
+    if (!items || n <= 0) return RCF_EINVAL;
+    for (int i = 0; i < n; ++i)
+        if (!items[i].x || !items[i].amax || items[i].n <= 0) return RCF_EINVAL;
+    static AmaxBatch b;   // ~4 KB: not on a ctypes caller's stack; single-threaded use like the other batch entry points
+    int i = 0;
+    while (i < n) {
+        b.n = 0;
+        unsigned nblk = 0;
+        while (i < n && b.n < AMAX_BATCH) {
+            b.it[b.n].x = items[i].x; b.it[b.n].amax = items[i].amax; b.it[b.n].n = items[i].n;
+            b.blk_start[b.n] = nblk;
+            nblk += (unsigned)((items[i].n + AMAX_SLICE - 1) / AMAX_SLICE);
+            ++b.n;
+            ++i;
+        }
+        for (int j = b.n; j <= AMAX_BATCH; ++j) b.blk_start[j] = nblk;
+        hipLaunchKernelGGL(amax_batch_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, b);
+    }
+    return rcf_launch_status();
+}
+
 extern "C" int rcf_scale_channels(const float* w, const float* scale, float* out, int n_out, int inner, void* stream) {
     if (!w || !scale || !out || n_out <= 0 || inner <= 0) return RCF_EINVAL;
     const long long total = (long long)n_out * inner;

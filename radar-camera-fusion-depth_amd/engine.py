@@ -19,7 +19,7 @@ import torch
 
 from . import ops
 from ._lib import (RCF_ACT_LEAKY_RELU, RCF_ACT_NONE, RCF_GATHER_DIRECT, RCF_GATHER_NEAREST, RCF_PHASE_S2_DGRAD,
-                   RCF_PHASE_UP2X_DGRAD, RCF_PHASE_UP2X_FWD)
+                   RCF_PHASE_UP2X_DGRAD, RCF_PHASE_UP2X_FWD, RCF_PREC_F16X2, RCF_PREC_FP32, ConvDesc)
 
 class WeightPlan(object):
     '''
@@ -35,6 +35,10 @@ class WeightPlan(object):
     only checks that it is the request recorded at position i (same kind, descriptor bytes and source pointers) and returns the
     buffer.  Any mismatch (another shape, another precision, a model that changed) marks the plan dirty: the rest of that step packs
     one launch at a time again, and the next step records afresh.  Results are bitwise those of the unbatched path.
+
+    Two-plane fp16 arithmetic (RCF_PREC_F16X2) adds a third kind of entry: max|w| of every weight tensor (and phase-weight buffer)
+    the split kernels consume, one device scalar each in a persistent arena -- replayed as ONE memset + rcf_amax_batch between the
+    phase-weight batch (whose outputs it reads) and the packing batch (which scales by it).
     '''
 
     def __init__(self):
@@ -44,8 +48,10 @@ class WeightPlan(object):
         self.dirty = False
         self.active = False         # between begin() and end(): the forward AND the backward pass of one training step
         self.last_mismatch = None   # (position, requested kind, what differed): diagnostics
-        self._pack_items = self._phase_items = None
-        self._n_pack = self._n_phase = 0
+        self._pack_items = self._phase_items = self._amax_items = None
+        self._n_pack = self._n_phase = self._n_amax = 0
+        self.wamax = None           # arena of the weight maxima (device scalars) of the recorded step
+        self._wamax_used = 0
 
     def enable(self):
         if self.state == 'off':
@@ -57,10 +63,14 @@ class WeightPlan(object):
         if self.state == 'replay' and not self.dirty:
             if self._n_phase:
                 ops.phase_weights_batch(self._phase_items, self._n_phase)
+            if self._n_amax:
+                self.wamax.zero_()
+                ops.amax_batch(self._amax_items, self._n_amax)
             if self._n_pack:
                 ops.conv_pack_batch(self._pack_items, self._n_pack)
         else:
             self.state, self.entries, self.dirty = 'record', [], False
+            self.wamax, self._wamax_used = None, 0
         self.pos = 0
         self.active = True
 
@@ -73,22 +83,37 @@ class WeightPlan(object):
         elif self.state == 'replay' and self.pos != len(self.entries):
             self.dirty = True
 
+    def new_wamax_slot(self, like):
+        '''A zeroed device scalar of the recorded step's weight-maximum arena.'''
+        if self.wamax is None:
+            self.wamax = torch.zeros(1024, dtype=torch.float32, device=like.device)
+        if self._wamax_used >= self.wamax.numel():
+            raise RuntimeError('weight-maximum arena exhausted')
+        self._wamax_used += 1
+        return self.wamax[self._wamax_used - 1:self._wamax_used]
+
     def _seal(self):
         import ctypes
-        from ._lib import PackItem, PhaseItem
-        packs, phases = [], []
+        from ._lib import AmaxItem, PackItem, PhaseItem
+        packs, phases, amaxes = [], [], []
         for e in self.entries:
             if e['kind'] == 'phase':
                 phases.append((e['w'].data_ptr(), e['out'].data_ptr(), e['w'].shape[0], e['w'].shape[1], e['mode']))
+            elif e['kind'] == 'amax':
+                amaxes.append((e['ptr'], e['n'], e['out'].data_ptr()))
             else:
                 for w, dst in zip(e['srcs'], e['dsts']):
-                    packs.append((e['desc'], w.data_ptr(), dst.data_ptr()))
-        self._n_pack, self._n_phase = len(packs), len(phases)
+                    packs.append((e['desc'], w.data_ptr(), dst.data_ptr(), None if e.get('amax') is None else e['amax'].data_ptr()))
+        self._n_pack, self._n_phase, self._n_amax = len(packs), len(phases), len(amaxes)
         self._pack_items = (PackItem * max(1, len(packs)))()
-        for i, (d, w, dst) in enumerate(packs):
+        for i, (d, w, dst, am) in enumerate(packs):
             self._pack_items[i].desc = ctypes.pointer(d)      # the descriptor object stays alive in its entry
             self._pack_items[i].w_oihw = w
             self._pack_items[i].packed = dst
+            self._pack_items[i].amax_w = am
+        self._amax_items = (AmaxItem * max(1, len(amaxes)))()
+        for i, (x, n, out) in enumerate(amaxes):
+            self._amax_items[i].x, self._amax_items[i].n, self._amax_items[i].amax = x, n, out
         self._phase_items = (PhaseItem * max(1, len(phases)))()
         for i, (w, out, o, ii, mode) in enumerate(phases):
             self._phase_items[i].w_oihw, self._phase_items[i].out = w, out
@@ -112,7 +137,7 @@ BN_MOMENTUM = 0.1
 
 class Act(object):
     '''An activation tensor and (during backward) its gradient accumulator.'''
-    __slots__ = ('t', 'g', 'needs_grad', 'head_fusable', 'g_head', 'z', 'coef', 's2d', 'hw')
+    __slots__ = ('t', 'g', 'needs_grad', 'head_fusable', 'g_head', 'z', 'coef', 's2d', 'hw', 'amax')
 
     def __init__(self, t, needs_grad=True):
         self.t = t
@@ -124,6 +149,7 @@ class Act(object):
         self.coef = None
         self.s2d = None             # network input only (bf16 configuration): its space-to-depth image for the stem, and (H, W)
         self.hw = None
+        self.amax = None            # two-plane fp16 arithmetic: device scalar holding max|t| (or an upper bound), from its producer
 
 
 class Engine(object):
@@ -155,6 +181,10 @@ class Engine(object):
         self.s2_wgrad_phases = None if e is None else (e != '0')
         if os.environ.get('RCF_BN_ON_LOAD') is not None:
             self.bn_on_load = os.environ['RCF_BN_ON_LOAD'] == '1'
+        # two-plane fp16 arithmetic (RCF_PREC_F16X2): per-step arena of activation / gradient maxima, per-step cache of weight maxima
+        self._amax_arena = None
+        self._amax_used = 0
+        self._wamax_cache = {}
 
     # ------------------------------------------------------------------ helpers
     def _new(self, shape, ref):
@@ -166,6 +196,59 @@ class Engine(object):
         '''An fp32 buffer whatever the activation storage is: packed weights, coefficients, workspaces, single-channel maps.'''
         return torch.empty(shape, dtype=torch.float32, device=ref.device)
 
+
+    # ---- per-tensor maxima of the two-plane fp16 arithmetic (RCF_PREC_F16X2; rcf_common.h)
+    @staticmethod
+    def _f16():
+        return ops.get_precision() == RCF_PREC_F16X2
+
+    def _begin_step_scales(self, ref):
+        self._wamax_cache = {}
+        self._amax_used = 0
+        self._amax_arena = torch.zeros(512, dtype=torch.float32, device=ref.device) if self._f16() else None
+
+    def _amax_slot(self):
+        '''A zeroed device scalar for the maximum of a tensor this step produces (None outside the fp16 arithmetic).'''
+        if self._amax_arena is None or not self._f16():
+            return None
+        if self._amax_used >= self._amax_arena.numel():
+            raise RuntimeError('activation-maximum arena exhausted')
+        self._amax_used += 1
+        return self._amax_arena[self._amax_used - 1:self._amax_used]
+
+    def _w_amax(self, w):
+        '''max|w| of a weight tensor or phase-weight buffer as a device scalar, computed once per step (through the weight plan when
+        it is active: one batched launch up front).'''
+        key = (w.data_ptr(), w.numel())
+        hit = self._wamax_cache.get(key)
+        if hit is not None:
+            return hit
+        plan = self.plan
+        out = None
+        if self._plan_on() and not plan.dirty:
+            if plan.state == 'replay':
+                e = plan._next('amax')
+                if e is not None and e['ptr'] == w.data_ptr() and e['n'] == w.numel():
+                    out = e['out']
+                else:
+                    plan.dirty = True
+            elif plan.state == 'record':
+                out = plan.new_wamax_slot(w)
+                ops.amax(w, out, accumulate=True)   # the slot is zero
+                plan.entries.append({'kind': 'amax', 'w': w, 'ptr': w.data_ptr(), 'n': w.numel(), 'out': out})
+        if out is None:
+            out = ops.amax(w)
+        self._wamax_cache[key] = out
+        return out
+
+    @staticmethod
+    def _exact_unless(desc, *amaxes):
+        '''A descriptor built under RCF_PREC_F16X2 keeps that arithmetic only when every operand's maximum is known; otherwise it
+        is (a copy) on the exact three-plane arithmetic.  Returns the descriptor to use.'''
+        if desc.precision == RCF_PREC_F16X2 and any(a is None for a in amaxes):
+            desc = ConvDesc.from_buffer_copy(bytes(desc))
+            desc.precision = RCF_PREC_FP32
+        return desc
 
     # ---- weight transforms (through the step's WeightPlan when it is active: training, tape on)
     def _plan_on(self):
@@ -186,17 +269,19 @@ class Engine(object):
             return ops.phase_weights(w, mode)
         return e['out']
 
-    def _pack(self, desc, w, like):
-        '''A packed-weight buffer holding ops.conv_pack(desc, w, .).'''
-        return self._pack_n(desc, [w], like)
+    def _pack(self, desc, w, like, amax=None):
+        '''A packed-weight buffer holding ops.conv_pack(desc, w, ., amax).'''
+        return self._pack_n(desc, [w], like, amax)
 
-    def _pack_n(self, desc, ws, like):
-        '''len(ws) packings under one descriptor, back to back in one buffer (the four phases of a merged up-2x input gradient).'''
+    def _pack_n(self, desc, ws, like, amax=None):
+        '''len(ws) packings under one descriptor, back to back in one buffer (the four phases of a merged up-2x input gradient).
+        amax: the weights' maximum (two-plane fp16 descriptors on the split kernels), common to all of ws.'''
         plan = self.plan
         key = bytes(desc)
         if self._plan_on() and not plan.dirty and plan.state == 'replay':
             e = plan._next('pack')
-            if e is not None and e['key'] == key and e['ptrs'] == [w.data_ptr() for w in ws]:
+            if (e is not None and e['key'] == key and e['ptrs'] == [w.data_ptr() for w in ws]
+                    and (None if e['amax'] is None else e['amax'].data_ptr()) == (None if amax is None else amax.data_ptr())):
                 return e['out']
             if e is not None:
                 plan.last_mismatch = (plan.pos - 1, 'pack', 'descriptor' if e['key'] != key else 'source pointer')
@@ -205,18 +290,29 @@ class Engine(object):
         out = self._newf((len(ws) * nf,), like)
         dsts = [out[k * nf:(k + 1) * nf] for k in range(len(ws))]
         for w, dst in zip(ws, dsts):
-            ops.conv_pack(desc, w, dst)
+            ops.conv_pack(desc, w, dst, amax)
         if self._plan_on() and not plan.dirty and plan.state == 'record':
             plan.entries.append({'kind': 'pack', 'desc': desc, 'key': key, 'srcs': list(ws), 'ptrs': [w.data_ptr() for w in ws],
-                                 'dsts': dsts, 'out': out})
+                                 'dsts': dsts, 'out': out, 'amax': amax})
         return out
+
+    @staticmethod
+    def _two_plane(kernel_id):
+        '''rcf_conv_info.kernel_id of a forward / input-gradient split kernel on two fp16 planes (ids 40000 .. 49999).'''
+        return 40000 <= kernel_id < 50000
+
+    @staticmethod
+    def _two_plane_wgrad(kernel_id):
+        '''rcf_conv_info.wgrad_kernel_id of a split weight-gradient kernel on two fp16 planes (10000 + 40000 + ...).'''
+        return kernel_id >= 50000
 
     def _mat(self, x):
         '''The activation tensor of x; a deferred one (raw conv output + BN coefficients) is materialised once, on demand.'''
         if x.t is None:
             z = x.z
             x.t = torch.empty_like(z)
-            ops.bn_act_fwd(z, x.coef, None, x.t, z.shape[0] * z.shape[1] * z.shape[2], z.shape[3], RCF_ACT_LEAKY_RELU)
+            x.amax = self._amax_slot() if z.dtype == torch.float32 else None
+            ops.bn_act_fwd(z, x.coef, None, x.t, z.shape[0] * z.shape[1] * z.shape[2], z.shape[3], RCF_ACT_LEAKY_RELU, amax=x.amax)
         return x.t
 
     @staticmethod
@@ -259,6 +355,14 @@ class Engine(object):
                 and layer.stride == 1 and (h_in, w_in) == (2 * h, 2 * w) and c1 % 4 == 0):
             return self._conv_up2x(layer, x, want_stats, fold)
         desc = ops.make_fwd_desc(n, h_in, w_in, c1, c2, weight.shape[0], layer.kernel_size, layer.stride, h, w, gather)
+        if desc.precision == RCF_PREC_F16X2:
+            # two fp16 planes need the operands' maxima: materialise deferred activations now (their producer pass supplies it); an
+            # operand without one (network input, a tensor from the inference epilogue) or the folded inference weights keep the layer
+            # on the exact three-plane arithmetic
+            self._mat(x)
+            if x2 is not None:
+                self._mat(x2)
+            desc = self._exact_unless(desc, x.amax, None if fold is not None else 0, 0 if x2 is None else x2.amax)
         info = ops.conv_query(desc)
         t1, k1 = self._src(x, info.bn_on_load)
         t2, k2 = self._src(x2, info.bn_on_load)
@@ -267,9 +371,14 @@ class Engine(object):
         if x2 is not None and t2 is None:
             t2 = self._mat(x2)
         fused = fold is not None and info.fwd_act and k1 is None and k2 is None
+        scales = None
         if fused:
             packed = self._newf((info.packed_weight_floats,), t1)
             ops.conv_pack(desc, ops.scale_channels(weight.detach(), fold[0][0]), packed)
+        elif self._two_plane(info.kernel_id):
+            wmax = self._w_amax(weight.detach())
+            packed = self._pack(desc, weight.detach(), t1, wmax)
+            scales = ops.make_scales(x.amax, None if x2 is None else x2.amax, wmax)
         else:
             packed = self._pack(desc, weight.detach(), t1)
         z = self._new((n, desc.h_out, desc.w_out, desc.c_out), t1)
@@ -279,7 +388,7 @@ class Engine(object):
         if fused:
             ops.conv_fwd_act(desc, t1, t2, packed, fold[0][1], fold[1], z)
         else:
-            ops.conv_fwd(desc, t1, t2, packed, z, partials, coef1=k1, coef2=k2)
+            ops.conv_fwd(desc, t1, t2, packed, z, partials, coef1=k1, coef2=k2, scales=scales)
         if self.prof is not None:
             self.prof.end()
         if self.kernel_log is not None and desc is not None:
@@ -289,15 +398,22 @@ class Engine(object):
             return z, desc, info, partials, fused
         return z, desc, info, partials
 
-    def _run_packed(self, desc, w_oihw, in1, out, partials=None, coef1=None, bias=None):
+    def _run_packed(self, desc, w_oihw, in1, out, partials=None, coef1=None, bias=None, amax_in=None, amax_w=None):
+        '''amax_in / amax_w: the maxima of in1 and of the weight BUFFER w_oihw is a slice of (two-plane fp16 descriptors; the
+        caller has put the descriptor on the exact arithmetic when one of them is unknown).'''
         info = ops.conv_query(desc)
-        packed = self._pack(desc, w_oihw, in1)
+        scales = None
+        if self._two_plane(info.kernel_id):
+            packed = self._pack(desc, w_oihw, in1, amax_w)
+            scales = ops.make_scales(amax_in, None, amax_w)
+        else:
+            packed = self._pack(desc, w_oihw, in1)
         if self.prof is not None:
             self.prof.begin(info.kernel_id, ops.algorithmic_flops(desc), desc)
         if bias is not None:
             ops.conv_fwd_act(desc, in1, None, packed, bias, None, out)
         else:
-            ops.conv_fwd(desc, in1, None, packed, out, partials, coef1=coef1)
+            ops.conv_fwd(desc, in1, None, packed, out, partials, coef1=coef1, scales=scales)
         if self.prof is not None:
             self.prof.end()
         return info
@@ -311,16 +427,23 @@ class Engine(object):
         weight = layer.conv.weight
         co = weight.shape[0]
         descs, partials, n_part = [], None, 0
-        t1 = k1 = z = None
+        t1 = k1 = z = wmax = None
         fused = False
+        f16 = self._f16()
+        if f16:
+            self._mat(x)   # two fp16 planes need max|x|: a deferred activation is materialised (its producer pass supplies it)
         for ph in range(4):
             d = ops.make_up2x_fwd_desc(n, h, w, c1, co, ph >> 1, ph & 1)
+            if f16:
+                d = self._exact_unless(d, x.amax, None if fold is not None else 0)
             if ph == 0:
                 qi = ops.conv_query(d)
                 n_part = qi.n_partials
                 fused = fold is not None and bool(qi.fwd_act) and fold[1] is None
                 wp = ops.phase_weights(ops.scale_channels(weight.detach(), fold[0][0]), RCF_PHASE_UP2X_FWD) if fused else \
                     self._phase_w(weight.detach(), RCF_PHASE_UP2X_FWD)
+                if self._two_plane(qi.kernel_id):
+                    wmax = self._w_amax(wp)   # one maximum for the four phases' pre-summed weights
                 t1, k1 = self._src(x, qi.bn_on_load and not fused)
                 if t1 is None:
                     t1 = self._mat(x)
@@ -328,7 +451,7 @@ class Engine(object):
                 if want_stats:
                     partials = torch.empty((4 * n_part, 2, co), dtype=torch.float64, device=t1.device)
             self._run_packed(d, wp[ph], t1, z, None if partials is None else partials[ph * n_part:(ph + 1) * n_part], coef1=k1,
-                             bias=fold[0][1] if fused else None)
+                             bias=fold[0][1] if fused else None, amax_in=x.amax, amax_w=wmax)
             descs.append(d)
 
         class _Info(object):
@@ -388,14 +511,18 @@ class Engine(object):
         t1 = self._mat(x)
         wd = self._phase_w(weight.detach(), RCF_PHASE_S2_DGRAD)
         z = self._new((n, 2 * h, 2 * w, co), t1)
-        partials, n_part = None, 0
+        partials, n_part, wmax = None, 0, None
         for ph in range(4):
-            d = ops.make_s2_dgrad_desc(virt, ph >> 1, ph & 1, False)
+            d = self._exact_unless(ops.make_s2_dgrad_desc(virt, ph >> 1, ph & 1, False), x.amax)
             if ph == 0:
-                n_part = ops.conv_query(d).n_partials
+                qi = ops.conv_query(d)
+                n_part = qi.n_partials
+                if self._two_plane(qi.kernel_id):
+                    wmax = self._w_amax(wd)
                 if want_stats:
                     partials = torch.empty((4 * n_part, 2, co), dtype=torch.float64, device=t1.device)
-            self._run_packed(d, wd[ph], t1, z, None if partials is None else partials[ph * n_part:(ph + 1) * n_part])
+            self._run_packed(d, wd[ph], t1, z, None if partials is None else partials[ph * n_part:(ph + 1) * n_part],
+                             amax_in=x.amax, amax_w=wmax)
 
         class _Info(object):
             pass
@@ -406,16 +533,17 @@ class Engine(object):
             return z, None, info, partials, False
         return z, None, info, partials
 
-    def _conv_transpose_backward(self, layer, info, x, dz):
+    def _conv_transpose_backward(self, layer, info, x, dz, dz_amax=None):
         '''dW = the weight gradient of the virtual stride-2 convolution with the roles swapped (its input is dY, its output
         gradient is x) -- already in the [in][out][3][3] layout of ConvTranspose2d.weight; dX = that convolution applied to dY.'''
-        virt = info.transpose
+        virt = self._exact_unless(info.transpose, dz_amax, x.amax)
         weight = layer.conv.weight
         qi = ops.conv_query(virt)
         ws = self._newf((max(1, qi.wgrad_workspace_floats),), dz)
+        scales = ops.make_scales(dz_amax, None, None, x.amax) if self._two_plane_wgrad(qi.wgrad_kernel_id) else None
         if self.prof is not None:
             self.prof.begin(qi.wgrad_kernel_id, ops.algorithmic_flops(virt), virt)
-        ops.conv_wgrad(virt, dz, None, self._mat(x), self.grad_of(weight), ws)
+        ops.conv_wgrad(virt, dz, None, self._mat(x), self.grad_of(weight), ws, scales=scales)
         if self.prof is not None:
             self.prof.end()
         self._wgrad_done(weight)
@@ -425,22 +553,26 @@ class Engine(object):
                 x.g = self._new(tuple(self._shape(x)), dz)
             dd = ops.make_fwd_desc(virt.n, virt.h_in, virt.w_in, virt.c1, 0, virt.c_out, 3, 2)
             dd.accumulate = 1 if acc else 0
-            self._run_packed(dd, weight.detach(), dz, x.g)
+            dd = self._exact_unless(dd, dz_amax)
+            wmax = self._w_amax(weight.detach()) if self._two_plane(ops.conv_query(dd).kernel_id) else None
+            self._run_packed(dd, weight.detach(), dz, x.g, amax_in=dz_amax, amax_w=wmax)
 
-    def _conv_up2x_backward(self, layer, info, x, dz):
+    def _conv_up2x_backward(self, layer, info, x, dz, dz_amax=None):
         n, h, w, c1 = self._shape(x)
         weight = layer.conv.weight
         co = weight.shape[0]
         dwp = self._newf((4, co, c1, 2, 2), dz)
         for ph, d in enumerate(info.up2x):
+            d = self._exact_unless(d, x.amax, dz_amax)
             qi = ops.conv_query(d)
             ws = self._newf((max(1, qi.wgrad_workspace_floats),), dz)
             t1, k1 = self._src(x, qi.wgrad_bn_on_load)
             if t1 is None:
                 t1 = self._mat(x)
+            scales = ops.make_scales(x.amax, None, None, dz_amax) if self._two_plane_wgrad(qi.wgrad_kernel_id) else None
             if self.prof is not None:
                 self.prof.begin(qi.wgrad_kernel_id, ops.algorithmic_flops(d), d)
-            ops.conv_wgrad(d, t1, None, dz, dwp[ph], ws, coef1=k1)
+            ops.conv_wgrad(d, t1, None, dz, dwp[ph], ws, coef1=k1, scales=scales)
             if self.prof is not None:
                 self.prof.end()
         ops.phase_wgrad_fold(dwp, self.grad_of(weight))
@@ -450,28 +582,37 @@ class Engine(object):
             acc = x.g is not None
             if not acc:
                 x.g = self._new(tuple(self._shape(x)), dz)
-            dd = ops.make_up2x_dgrad_desc(n, h, w, c1, co, 0, 0, acc, phase_sum=True)
+            dd = self._exact_unless(ops.make_up2x_dgrad_desc(n, h, w, c1, co, 0, 0, acc, phase_sum=True), dz_amax)
             qi = ops.conv_query(dd)
-            packed = self._pack_n(dd, [wd[ph] for ph in range(4)], dz)
+            scales = None
+            if self._two_plane(qi.kernel_id):
+                wmax = self._w_amax(wd)
+                packed = self._pack_n(dd, [wd[ph] for ph in range(4)], dz, wmax)
+                scales = ops.make_scales(dz_amax, None, wmax)
+            else:
+                packed = self._pack_n(dd, [wd[ph] for ph in range(4)], dz)
             if self.prof is not None:
                 self.prof.begin(qi.kernel_id, ops.algorithmic_flops(dd), dd)
-            ops.conv_fwd(dd, dz, None, packed, x.g, None)
+            ops.conv_fwd(dd, dz, None, packed, x.g, None, scales=scales)
             if self.prof is not None:
                 self.prof.end()
 
-    def _conv_backward(self, layer, desc, info, x, x2, dz):
-        '''dW (written once into the parameter's gradient) and dX / dX2 (accumulated into the producers' .g).'''
+    def _conv_backward(self, layer, desc, info, x, x2, dz, dz_amax=None):
+        '''dW (written once into the parameter's gradient) and dX / dX2 (accumulated into the producers' .g).  dz_amax: device
+        scalar with max|dz| from the kernel that wrote dz (two-plane fp16 arithmetic; None: these layers run exact).'''
         if desc is None and hasattr(info, 'stem'):
             # the stem ran on the space-to-depth image; its weight gradient is the 7x7 one on the fp32 NHWC input (no input gradient)
             n, h, w, c = x.t.shape
             desc = ops.make_fwd_desc(n, h, w, c, 0, layer.conv.weight.shape[0], 7, 2)
             info = ops.conv_query(desc)
         if desc is None and hasattr(info, 'transpose'):
-            return self._conv_transpose_backward(layer, info, x, dz)
+            return self._conv_transpose_backward(layer, info, x, dz, dz_amax)
         if desc is None:
-            return self._conv_up2x_backward(layer, info, x, dz)
+            return self._conv_up2x_backward(layer, info, x, dz, dz_amax)
         weight = layer.conv.weight
         dw = self.grad_of(weight)
+        x_amax = x.amax
+        x2_amax = 0 if x2 is None else x2.amax
         s2_phases = self.s2_wgrad_phases if self.s2_wgrad_phases is not None else (ops.act_dtype() == torch.bfloat16 or ops.get_precision() == 2)
         if (self.use_phase_convs and s2_phases and desc.stride == 2 and desc.ksize == 3 and x2 is None and desc.c1 % 4 == 0
                 and desc.c1 >= 16 and desc.gather1 == RCF_GATHER_DIRECT):
@@ -479,26 +620,34 @@ class Engine(object):
             t1 = self._mat(x)
             dwp = self._newf((4, desc.c_out, desc.c1, 2, 2), dz)
             for ph in range(4):
-                d = ops.make_s2_wgrad_desc(desc, ph >> 1, ph & 1)
+                d = self._exact_unless(ops.make_s2_wgrad_desc(desc, ph >> 1, ph & 1), x_amax, dz_amax)
                 qi = ops.conv_query(d)
                 wsp = self._newf((max(1, qi.wgrad_workspace_floats),), dz)
+                scales = ops.make_scales(x_amax, None, None, dz_amax) if self._two_plane_wgrad(qi.wgrad_kernel_id) else None
                 if self.prof is not None:
                     self.prof.begin(qi.wgrad_kernel_id, ops.algorithmic_flops(d), d)
-                ops.conv_wgrad(d, t1, None, dz, dwp[ph], wsp)
+                ops.conv_wgrad(d, t1, None, dz, dwp[ph], wsp, scales=scales)
                 if self.prof is not None:
                     self.prof.end()
             ops.phase_wgrad_gather_s2(dwp, dw)
         else:
-            ws = self._newf((max(1, info.wgrad_workspace_floats),), dz)
+            wdesc, winfo = desc, info
+            if desc.precision == RCF_PREC_F16X2 and (dz_amax is None or x_amax is None or x2_amax is None):
+                wdesc = self._exact_unless(desc, None)
+                winfo = ops.conv_query(wdesc)
+            ws = self._newf((max(1, winfo.wgrad_workspace_floats),), dz)
             if self.prof is not None:
-                self.prof.begin(info.wgrad_kernel_id, ops.algorithmic_flops(desc), desc)
-            t1, k1 = self._src(x, info.wgrad_bn_on_load)
-            t2, k2 = self._src(x2, info.wgrad_bn_on_load)
+                self.prof.begin(winfo.wgrad_kernel_id, ops.algorithmic_flops(wdesc), wdesc)
+            t1, k1 = self._src(x, winfo.wgrad_bn_on_load)
+            t2, k2 = self._src(x2, winfo.wgrad_bn_on_load)
             if t1 is None:
                 t1 = self._mat(x)
             if x2 is not None and t2 is None:
                 t2 = self._mat(x2)
-            ops.conv_wgrad(desc, t1, t2, dz, dw, ws, coef1=k1, coef2=k2)
+            scales = None
+            if self._two_plane_wgrad(winfo.wgrad_kernel_id):
+                scales = ops.make_scales(x_amax, None if x2 is None else x2_amax, None, dz_amax)
+            ops.conv_wgrad(wdesc, t1, t2, dz, dw, ws, coef1=k1, coef2=k2, scales=scales)
             if self.prof is not None:
                 self.prof.end()
         self._wgrad_done(weight)
@@ -508,7 +657,7 @@ class Engine(object):
             if src is x and desc.gather1 == RCF_GATHER_NEAREST:
                 dd = ops.make_dgrad_desc(desc, off, cnt, False)
                 tmp = self._new((desc.n, desc.h_in, desc.w_in, cnt), dz)
-                self._run_dgrad(dd, weight, dz, tmp)
+                self._run_dgrad(dd, weight, dz, tmp, dz_amax)
                 acc = src.g is not None
                 if not acc:
                     src.g = self._new(tuple(self._shape(src)), dz)
@@ -519,21 +668,32 @@ class Engine(object):
                 if not acc:
                     src.g = self._new(tuple(self._shape(src)), dz)
                 wd = self._phase_w(weight.detach(), RCF_PHASE_S2_DGRAD)
+                wmax = None
                 for ph in range(4):
-                    self._run_packed(ops.make_s2_dgrad_desc(desc, ph >> 1, ph & 1, acc), wd[ph], dz, src.g)
+                    d = self._exact_unless(ops.make_s2_dgrad_desc(desc, ph >> 1, ph & 1, acc), dz_amax)
+                    if ph == 0 and self._two_plane(ops.conv_query(d).kernel_id):
+                        wmax = self._w_amax(wd)
+                    self._run_packed(d, wd[ph], dz, src.g, amax_in=dz_amax, amax_w=wmax)
             else:
                 acc = src.g is not None
                 if not acc:
                     src.g = self._new(tuple(self._shape(src)), dz)
                 dd = ops.make_dgrad_desc(desc, off, cnt, acc)
-                self._run_dgrad(dd, weight, dz, src.g)
+                self._run_dgrad(dd, weight, dz, src.g, dz_amax)
 
-    def _run_dgrad(self, dd, weight, dz, out):
+    def _run_dgrad(self, dd, weight, dz, out, dz_amax=None):
+        dd = self._exact_unless(dd, dz_amax)
         info = ops.conv_query(dd)
-        packed = self._pack(dd, weight.detach(), dz)
+        scales = None
+        if self._two_plane(info.kernel_id):
+            wmax = self._w_amax(weight.detach())
+            packed = self._pack(dd, weight.detach(), dz, wmax)
+            scales = ops.make_scales(dz_amax, None, wmax)
+        else:
+            packed = self._pack(dd, weight.detach(), dz)
         if self.prof is not None:
             self.prof.begin(info.kernel_id, ops.algorithmic_flops(dd), dd)
-        ops.conv_fwd(dd, dz, None, packed, out, None)
+        ops.conv_fwd(dd, dz, None, packed, out, None, scales=scales)
         if self.prof is not None:
             self.prof.end()
 
@@ -586,7 +746,8 @@ class Engine(object):
             out.z, out.coef = z, coef
         else:
             out = Act(torch.empty_like(z))
-            ops.bn_act_fwd(z, coef, None if res is None else self._mat(res), out.t, n_pix, c, RCF_ACT_LEAKY_RELU)
+            out.amax = self._amax_slot() if z.dtype == torch.float32 else None
+            ops.bn_act_fwd(z, coef, None if res is None else self._mat(res), out.t, n_pix, c, RCF_ACT_LEAKY_RELU, amax=out.amax)
         out.head_fusable = res is None
         if self.tape is not None:
             bn = layer.batch_norm
@@ -606,8 +767,9 @@ class Engine(object):
                         bcoef.zero_()
                     self._wgrad_done(bn.weight, bn.bias)
                     dz = torch.empty_like(z)
-                    ops.head_bn_bwd_apply(dlogit, w_head, z, coef, bcoef, dz)
-                    self._conv_backward(layer, desc, info, x, x2, dz)
+                    dz_amax = self._amax_slot() if z.dtype == torch.float32 else None
+                    ops.head_bn_bwd_apply(dlogit, w_head, z, coef, bcoef, dz, amax=dz_amax)
+                    self._conv_backward(layer, desc, info, x, x2, dz, dz_amax)
                     return
                 dout = out.g
                 nb = ops.ew_blocks(n_pix, c)
@@ -626,9 +788,10 @@ class Engine(object):
                     if not dres_acc:
                         res.g = torch.empty_like(res.t)
                     dres = res.g
-                ops.bn_act_bwd_apply(dout, z, coef, out.t, bcoef, dz, dres, dres_acc, n_pix, c, RCF_ACT_LEAKY_RELU, has_res)
+                dz_amax = self._amax_slot() if z.dtype == torch.float32 else None
+                ops.bn_act_bwd_apply(dout, z, coef, out.t, bcoef, dz, dres, dres_acc, n_pix, c, RCF_ACT_LEAKY_RELU, has_res, amax=dz_amax)
                 out.g = None
-                self._conv_backward(layer, desc, info, x, x2, dz)
+                self._conv_backward(layer, desc, info, x, x2, dz, dz_amax)
 
             self.tape.append(backward)
         return out
@@ -656,7 +819,8 @@ class Engine(object):
         n_pix = zw.shape[0] * zw.shape[1] * zw.shape[2]
         c = zw.shape[3]
         out = Act(torch.empty_like(zw))
-        ops.fuse_fwd(zw, coef_w, zp, coef_p, self._mat(img), out.t, n_pix, c)
+        out.amax = self._amax_slot() if zw.dtype == torch.float32 else None
+        ops.fuse_fwd(zw, coef_w, zp, coef_p, self._mat(img), out.t, n_pix, c, amax=out.amax)
         if self.tape is not None:
             bnw, bnp = layer_w.batch_norm, layer_p.batch_norm
             batch_stats = self.training
@@ -697,6 +861,7 @@ class Engine(object):
         n, h, w, c = xt.shape
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         out = Act(self._new((n, ho, wo, c), xt))
+        out.amax = x.amax   # a maximum over windows of x: max|x| bounds it
         idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=xt.device)
         ops.maxpool_fwd(xt, out.t, idx)
         if self.tape is not None:
@@ -789,6 +954,7 @@ class Engine(object):
         self.tape = [] if record else None
         if hw is None:
             hw = tuple(image_nhwc.shape[1:3])
+        self._begin_step_scales(image_nhwc if image_nhwc is not None else image_s2d)
         img = self.conv_bn_act(enc.conv1_image, self._input(image_nhwc, image_s2d, hw))
         dep = self.conv_bn_act(enc.conv1_depth, self._input(depth_nhwc, depth_s2d, hw))
         layers = [self.fuse(enc.conv1_weight, enc.conv1_project, dep, img)]
@@ -885,6 +1051,7 @@ class Engine(object):
         ei = enc.encoder_image
         self.training = bool(training)
         self.tape = [] if record else None
+        self._begin_step_scales(image_nhwc if image_nhwc is not None else image_s2d)
         shape = (int(enc.input_patch_size_image[0]), int(enc.input_patch_size_image[1]))
         # ResNetEncoder.forward (src/networks.py:232-268)
         x = self.conv_bn_act(ei.conv1, self._input(image_nhwc, image_s2d, hw if hw is not None else tuple(image_nhwc.shape[1:3])))

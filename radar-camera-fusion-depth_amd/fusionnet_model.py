@@ -252,10 +252,11 @@ class FusionNetModel(object):
 
     compute_dtype = 'fp32'
     '''
-    'fp32' (default): the reference's arithmetic (exact fp32 products).  'bf16': bf16 tensors in HBM and bf16 matrix operands,
+    'fp32' (default): the reference's arithmetic -- fp32 tensors, fp32-accurate products (ops.precision_of: the 3x3 / 2x2 split
+    kernels on two scaled fp16 planes, or with RCF_FP32_TIER=3plane / 'fp32_3plane' on three bf16 planes; the other kernels on the
+    f32 MFMA).  'f16x2' names the two-plane arithmetic explicitly.  'bf16': bf16 tensors in HBM and bf16 matrix operands,
     fp32 accumulation -- the "bf16" configurations of BASELINE.json; weights, BatchNorm statistics, loss and optimizer stay fp32.
-    'bf16_operands': fp32 tensors, operands of the split convolution kernels rounded to bf16.  'bf16x3': fp32 tensors, operands of
-    the split convolution kernels carried as two bf16 planes / three products (16-17 significant bits, ops.set_precision).
+    'bf16_operands': fp32 tensors, operands of the split convolution kernels rounded to bf16.
     '''
 
     def _run_engine(self, image, input_depth, record):
@@ -264,7 +265,7 @@ class FusionNetModel(object):
                                 'path (inputs on %s, model on %s)' % (image.device, self._param_arena.device))
         if image.device != self._param_arena.device:
             raise _lib.RcfError('inputs live on %s but the model on %s' % (image.device, self._param_arena.device))
-        ops.set_precision(self.compute_dtype)
+        ops.set_precision(ops.precision_of(self.compute_dtype))
         try:
             # every kernel is enqueued on the CURRENT stream of the CURRENT device: make that the model's device for the whole
             # call, whatever device the calling thread had selected
@@ -310,7 +311,7 @@ class FusionNetModel(object):
         if self._dp is not None:
             self._dp.begin_backward()
         self._engine.on_param_grad = self._dp.on_param_grad if self._dp is not None else None
-        ops.set_precision(self.compute_dtype)
+        ops.set_precision(ops.precision_of(self.compute_dtype))
         try:
             with torch.cuda.device(self._grad_arena.device):
                 Engine.backward(out, tape, ddepth)

@@ -69,16 +69,33 @@ _STORAGE = [0]     # rcf_conv_desc.storage (RCF_STORE_FP32 / RCF_STORE_BF16)
 def set_precision(p):
     '''0 / 'fp32': fp32 arithmetic and fp32 tensors (default).  'bf16': bf16 tensors in HBM + bf16 MFMA operands, fp32 accumulate
     (BASELINE.json configs 2-4).  'bf16_operands': fp32 tensors, operands rounded to bf16 in the split conv kernels.
-    'bf16x3': fp32 tensors, each operand of the split conv kernels as two bf16 planes and three products (16-17 significant bits;
-    RCF_PREC_BF16X3 in include/rcf_hip.h) -- half the matrix work of 'fp32', errors ~1e-5.'''
-    if p not in (0, 1, 'fp32', 'bf16', 'bf16_operands', 'bf16x3'):
+    'f16x2': fp32 tensors, each operand of the split conv kernels as two fp16 planes of x * (its tensor's power-of-two scale) and
+    three products (22-23 significant bits; RCF_PREC_F16X2 in include/rcf_hip.h) -- half the matrix work of the three-plane bf16
+    split at its accuracy class; the per-tensor maxima travel as device scalars (`scales=` of conv_fwd / conv_wgrad).'''
+    if p not in (0, 1, 'fp32', 'bf16', 'bf16_operands', 'f16x2'):
         raise ValueError('unknown precision %r' % (p,))
-    _PRECISION[0] = 1 if p in (1, 'bf16', 'bf16_operands') else (_lib.RCF_PREC_BF16X3 if p == 'bf16x3' else 0)
+    _PRECISION[0] = 1 if p in (1, 'bf16', 'bf16_operands') else (_lib.RCF_PREC_F16X2 if p == 'f16x2' else 0)
     _STORAGE[0] = 1 if p == 'bf16' else 0
 
 
 def get_precision():
     return _PRECISION[0]
+
+
+def precision_of(compute_dtype):
+    '''The ops.set_precision name a model's compute_dtype stands for.  'fp32' -- the reference's arithmetic, the configuration the
+    benchmark metric is quoted on -- runs the split convolution kernels on two scaled fp16 planes ('f16x2': fp32-convolution-class
+    errors against fp64, tests/test_hip_f16x2.py) unless RCF_FP32_TIER=3plane asks for the three-plane bf16 split ('fp32_3plane' as a
+    compute_dtype does the same per model).  Everything else passes through.'''
+    import os
+    if compute_dtype == 'fp32':
+        return 'fp32' if os.environ.get('RCF_FP32_TIER', FP32_TIER_DEFAULT) == '3plane' else 'f16x2'
+    if compute_dtype == 'fp32_3plane':
+        return 'fp32'
+    return compute_dtype
+
+
+FP32_TIER_DEFAULT = '3plane'
 
 
 def act_dtype():
@@ -257,9 +274,34 @@ def conv_query(desc):
     return info
 
 
-def conv_pack(desc, w_oihw, packed):
+def conv_pack(desc, w_oihw, packed, amax_w=None):
+    """amax_w (RCF_PREC_F16X2 descriptors): device scalar holding max|w| -- the fp16 planes hold w * its power-of-two scale."""
+    if amax_w is not None:
+        check(_lib.load().rcf_conv2d_pack_weights_scaled(ctypes.byref(desc), _f32(w_oihw), _f32(packed), _f32(amax_w), _stream()),
+              'rcf_conv2d_pack_weights_scaled')
+        return
     check(_lib.load().rcf_conv2d_pack_weights(ctypes.byref(desc), _f32(w_oihw), _f32(packed), _stream()),
           'rcf_conv2d_pack_weights')
+
+
+def make_scales(amax_in1=None, amax_in2=None, amax_w=None, amax_dz=None):
+    """rcf_conv_scales from device scalars (None = unscaled operand)."""
+    return _lib.ConvScales(_f32(amax_in1), _f32(amax_in2), _f32(amax_w), _f32(amax_dz))
+
+
+def amax(x, out=None, accumulate=False):
+    """max|x| over an fp32 tensor as a device scalar (rcf_amax); out given: written there (after zeroing unless accumulate)."""
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float32, device=x.device)
+    elif not accumulate:
+        out.zero_()
+    check(_lib.load().rcf_amax(_f32(x), x.numel(), _f32(out), _stream()), 'rcf_amax')
+    return out
+
+
+def amax_batch(items, n):
+    """items: ctypes array of _lib.AmaxItem; the output slots must have been zeroed (rcf_amax_batch accumulates)."""
+    check(_lib.load().rcf_amax_batch(items, n, _stream()), 'rcf_amax_batch')
 
 
 def conv_pack_batch(items, n):
@@ -271,11 +313,15 @@ def phase_weights_batch(items, n):
     check(_lib.load().rcf_phase_weights_batch(items, n, _stream()), 'rcf_phase_weights_batch')
 
 
-def conv_fwd(desc, in1, in2, packed, out, stat_partials=None, coef1=None, coef2=None):
-    """coef1 / coef2: in1 / in2 are raw conv outputs whose BatchNorm + lrelu is applied on load (rcf_conv_info.bn_on_load)."""
+def conv_fwd(desc, in1, in2, packed, out, stat_partials=None, coef1=None, coef2=None, scales=None):
+    """coef1 / coef2: in1 / in2 are raw conv outputs whose BatchNorm + lrelu is applied on load (rcf_conv_info.bn_on_load).
+    scales (make_scales; RCF_PREC_F16X2 descriptors on the split kernels): the operands' per-tensor maxima."""
     # the 7x7 stems read the fp32 network input whatever the storage is (include/rcf_hip.h, rcf_conv_desc.storage)
     _check_storage(desc, None if desc.ksize == 7 else in1, in2, out)
-    if coef1 is None and coef2 is None:
+    if scales is not None:
+        check(_lib.load().rcf_conv2d_fwd_scaled(ctypes.byref(desc), _a(in1), _a(in2), _f32(packed), _a(out), _f64(stat_partials),
+                                                ctypes.byref(scales), _stream()), 'rcf_conv2d_fwd_scaled')
+    elif coef1 is None and coef2 is None:
         check(_lib.load().rcf_conv2d_fwd(ctypes.byref(desc), _a(in1), _a(in2), _f32(packed), _a(out),
                                          _f64(stat_partials), _stream()), 'rcf_conv2d_fwd')
     else:
@@ -299,9 +345,12 @@ def scale_channels(w_oihw, scale):
     return out
 
 
-def conv_wgrad(desc, in1, in2, dz, dw, workspace, coef1=None, coef2=None):
+def conv_wgrad(desc, in1, in2, dz, dw, workspace, coef1=None, coef2=None, scales=None):
     _check_storage(desc, None if desc.ksize == 7 else in1, in2, dz)
-    if coef1 is None and coef2 is None:
+    if scales is not None:
+        check(_lib.load().rcf_conv2d_wgrad_scaled(ctypes.byref(desc), _a(in1), _a(in2), _a(dz), _f32(dw), _f32(workspace),
+                                                  ctypes.byref(scales), _stream()), 'rcf_conv2d_wgrad_scaled')
+    elif coef1 is None and coef2 is None:
         check(_lib.load().rcf_conv2d_wgrad(ctypes.byref(desc), _a(in1), _a(in2), _a(dz), _f32(dw), _f32(workspace),
                                            _stream()), 'rcf_conv2d_wgrad')
     else:
@@ -315,11 +364,20 @@ def bn_finalize(partials, n_partials, c, count, gamma, beta, running_mean, runni
                                       _f32(coef), _stream()), 'rcf_bn_finalize')
 
 
-def bn_act_fwd(z, coef, res, out, n_pix, c, act):
+def bn_act_fwd(z, coef, res, out, n_pix, c, act, amax=None):
+    """amax (fp32 tensors): zeroed device scalar that also receives max|out| (rcf_bn_act_fwd_amax)."""
+    if amax is not None:
+        check(_lib.load().rcf_bn_act_fwd_amax(_f32(z), _f32(coef), _f32(res), _f32(out), n_pix, c, act, _f32(amax), _stream()),
+              'rcf_bn_act_fwd_amax')
+        return
     check(_fn('rcf_bn_act_fwd', z, res, out)(_a(z), _f32(coef), _a(res), _a(out), n_pix, c, act, _stream()), 'rcf_bn_act_fwd')
 
 
-def fuse_fwd(zw, coef_w, zp, coef_p, img, out, n_pix, c):
+def fuse_fwd(zw, coef_w, zp, coef_p, img, out, n_pix, c, amax=None):
+    if amax is not None:
+        check(_lib.load().rcf_fuse_fwd_amax(_f32(zw), _f32(coef_w), _f32(zp), _f32(coef_p), _f32(img), _f32(out), n_pix, c,
+                                            _f32(amax), _stream()), 'rcf_fuse_fwd_amax')
+        return
     check(_fn('rcf_fuse_fwd', zw, zp, img, out)(_a(zw), _f32(coef_w), _a(zp), _f32(coef_p), _a(img), _a(out), n_pix, c,
                                                 _stream()), 'rcf_fuse_fwd')
 
@@ -352,13 +410,22 @@ def head_bn_bwd_reduce(dlogit, w_head, z, coef, partials):
           'rcf_head_bn_bwd_reduce')
 
 
-def head_bn_bwd_apply(dlogit, w_head, z, coef, bcoef, dz):
+def head_bn_bwd_apply(dlogit, w_head, z, coef, bcoef, dz, amax=None):
     n, h, w, c = z.shape
+    if amax is not None:
+        check(_lib.load().rcf_head_bn_bwd_apply_amax(_f32(dlogit), _f32(w_head), _f32(z), _f32(coef), _f32(bcoef), _f32(dz), n, h, w, c,
+                                                     _f32(amax), _stream()), 'rcf_head_bn_bwd_apply_amax')
+        return
     check(_fn('rcf_head_bn_bwd_apply', z, dz)(_f32(dlogit), _f32(w_head), _a(z), _f32(coef), _f32(bcoef), _a(dz), n, h, w, c,
                                               _stream()), 'rcf_head_bn_bwd_apply')
 
 
-def bn_act_bwd_apply(dout, z, coef, out, bcoef, dz, dres, dres_accumulate, n_pix, c, act, has_res):
+def bn_act_bwd_apply(dout, z, coef, out, bcoef, dz, dres, dres_accumulate, n_pix, c, act, has_res, amax=None):
+    if amax is not None:
+        check(_lib.load().rcf_bn_act_bwd_apply_amax(_f32(dout), _f32(z), _f32(coef), _f32(out), _f32(bcoef), _f32(dz), _f32(dres),
+                                                    1 if dres_accumulate else 0, n_pix, c, act, 1 if has_res else 0, _f32(amax),
+                                                    _stream()), 'rcf_bn_act_bwd_apply_amax')
+        return
     check(_fn('rcf_bn_act_bwd_apply', dout, z, out, dz, dres)(_a(dout), _a(z), _f32(coef), _a(out), _f32(bcoef), _a(dz), _a(dres),
                                                               1 if dres_accumulate else 0, n_pix, c, act, 1 if has_res else 0, _stream()),
           'rcf_bn_act_bwd_apply')

@@ -183,7 +183,7 @@ class RadarNetModel(object):
                                 'path (inputs on %s, model on %s)' % (image.device, self._param_arena.device))
         if image.device != self._param_arena.device:
             raise _lib.RcfError('inputs live on %s but the model on %s' % (image.device, self._param_arena.device))
-        ops.set_precision(self.compute_dtype)
+        ops.set_precision(ops.precision_of(self.compute_dtype))
         try:
             with torch.cuda.device(self._param_arena.device):   # kernels go to the current stream of the current device
                 return self._run_engine_impl(image, point, rois, record)

@@ -1,0 +1,480 @@
+'''
+GPU parity tests of the two-plane fp16 arithmetic (rcf_conv_desc.precision = RCF_PREC_F16X2, include/rcf_hip.h): fp32 tensors, each
+operand x of the split convolution kernels carried as two fp16 planes of x * s -- s the power of two that puts its tensor's max|x|
+into [2^14, 2^15) -- multiplied as a0*b0 + a0*b1 + a1*b0 with fp32 accumulation and rescaled by 1 / (s_a s_b).  The per-tensor
+maxima arrive as device scalars (ops.amax here; in the network, from the kernels that write the tensors).
+
+Bars.  (1) Against an fp64 evaluation of exactly that formula the kernels differ only by fp32 summation order.  (2) Against an fp64
+convolution of the fp32 operands the error must be that of the EXACT tier: within 2x of the f32-MFMA kernel's error (the bar
+tests/test_hip_ops.py::test_split_bf16_conv_is_fp32_accurate holds the three-plane bf16 split to).  (3) Operand distributions that
+stress a per-tensor scale: heavy tails, one huge outlier, all-zero and denormal tensors.  (4) The published net against the real
+reference's fixtures at north_star's 1e-3 (measured ~1e-6, like the exact tier).
+'''
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+NORTH_STAR = 1e-3     # BASELINE.json north_star: "within 1e-3 rel fp32"
+EXACT_TOL = 2e-6      # against fp64, as a fraction of the reference tensor's max-abs: fp32-convolution class (K <= 4608 terms)
+ORDER_TOL = 2e-6      # fp32 summation order only (against the emulated three-product formula)
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import rcf_amd  # noqa: F401
+    from rcf_amd import _lib, ops as _ops
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    assert _lib.load().rcf_device_ok() == 1, 'librcf_hip.so: no gfx950 device'
+    if os.environ.get('RCF_CONV_SPLIT') == '0':
+        pytest.skip('the two-plane arithmetic lives in the split kernels, which RCF_CONV_SPLIT=0 turns off')
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.detach().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+def scale_of(amax):
+    '''rcf_scale_of_amax (csrc/rcf_common.h): the power of two that puts amax into [2^14, 2^15); 1 for an all-zero tensor.'''
+    amax = float(amax)
+    if amax == 0.0:
+        return 1.0
+    e = int(np.floor(np.log2(amax))) if amax >= 2.0 ** -126 else -127
+    return 2.0 ** min(max(14 - e, -126), 126)
+
+
+def planes(t, s):
+    '''The two fp16 planes of t * s as the kernels form them (both round to nearest even), returned in float64.'''
+    ts = (t.float() * s).contiguous()
+    p0 = ts.to(torch.float16).to(torch.float32)
+    p1 = (ts - p0).to(torch.float16).to(torch.float32)
+    return p0.double(), p1.double()
+
+
+def x3(fn, a, b, amax_a=None, amax_b=None):
+    '''fn bilinear in (a, b): the three products of the two-plane operands, in fp64, rescaled.'''
+    sa = scale_of(a.abs().max() if amax_a is None else amax_a)
+    sb = scale_of(b.abs().max() if amax_b is None else amax_b)
+    a0, a1 = planes(a, sa)
+    b0, b1 = planes(b, sb)
+    return (fn(a0, b0) + fn(a0, b1) + fn(a1, b0)) / (sa * sb)
+
+
+def dev_amax(ops, *ts):
+    '''Device scalar holding the maximum of |.| over the given host tensors (what a producing kernel would have accumulated).'''
+    out = torch.zeros(1, device='cuda')
+    for t in ts:
+        ops.amax(t.contiguous().cuda(), out, accumulate=True)
+    return out
+
+
+# (ksize, stride, c1, c2, cout, n, h, w, up_from)
+CASES = [
+    (3, 1, 64, 0, 64, 2, 33, 64, None),
+    (3, 1, 64, 32, 64, 2, 17, 40, None),        # decoder concat
+    (3, 1, 32, 0, 32, 1, 40, 100, None),        # 32-co tiles, 16-pixel rows
+    (3, 1, 128, 128, 128, 1, 15, 26, None),
+    (3, 1, 64, 0, 32, 1, 70, 102, (35, 51)),    # nearest-upsample gather on load
+    (3, 1, 256, 0, 256, 2, 8, 13, None),        # small layer: 32-co half workgroups
+    (3, 2, 32, 0, 64, 2, 45, 80, None),         # stride 2 on the split kernel
+    (3, 2, 128, 0, 256, 1, 29, 50, None),
+]
+
+
+def _case(case, seed):
+    k, s, c1, c2, co, n, h, w, up = case
+    hs, ws = (h, w) if up is None else up
+    x1 = rnd(n, c1, hs, ws, seed=seed)
+    x2 = rnd(n, c2, h, w, seed=seed + 1) if c2 else None
+    wt = rnd(co, c1 + c2, k, k, seed=seed + 2, scale=1.0 / np.sqrt((c1 + c2) * k * k))
+    xin = x1 if up is None else F.interpolate(x1, size=(h, w))
+    if x2 is not None:
+        xin = torch.cat([xin, x2], 1)
+    return x1, x2, wt, xin
+
+
+def _run_fwd(ops, d, x1, x2, wt, amax_x=None, amax_w=None, stats=False):
+    '''conv forward under descriptor d; with maxima (device scalars) the scaled entry points, else the plain ones.'''
+    info = ops.conv_query(d)
+    packed = torch.empty(info.packed_weight_floats, device='cuda')
+    ops.conv_pack(d, wt.cuda(), packed, amax_w)
+    out = torch.full((d.n, d.h_out, d.w_out, d.c_out), float('nan'), device='cuda')
+    part = torch.full((info.n_partials, 2, d.c_out), float('nan'), device='cuda', dtype=torch.float64) if stats else None
+    sc = ops.make_scales(amax_x, amax_x if x2 is not None else None, amax_w) if amax_w is not None else None
+    ops.conv_fwd(d, nhwc(x1), None if x2 is None else nhwc(x2), packed, out, part, scales=sc)
+    torch.cuda.synchronize()
+    return nchw(out), part, info
+
+
+@pytest.mark.parametrize('case', CASES, ids=[str(c) for c in CASES])
+def test_conv_forward_input_gradient_weight_gradient(ops, case):
+    k, s, c1, c2, co, n, h, w, up = case
+    x1, x2, wt, xin = _case(case, 40)
+    hs, ws = (h, w) if up is None else up
+    ops.set_precision('f16x2')
+    try:
+        d = ops.make_fwd_desc(n, h, w, c1, c2, co, k, s, hs, ws, 0 if up is None else 1)
+        ax, aw = dev_amax(ops, xin), dev_amax(ops, wt)
+        got, part, info = _run_fwd(ops, d, x1, x2, wt, ax, aw, stats=True)
+        assert 40000 <= info.kernel_id < 50000, info.kernel_id            # a two-plane split kernel was selected
+        conv = lambda a, b: F.conv2d(a, b, stride=s, padding=k // 2)
+        ref64 = conv(xin.double(), wt.double())
+        assert rel(got, x3(conv, xin, wt)) < ORDER_TOL
+        e = rel(got, ref64)
+        assert e < EXACT_TOL, e
+        # BatchNorm statistics of the written values (fp64 sums of the fp32 outputs)
+        st = part.sum(0).cpu()
+        np.testing.assert_allclose(st[0].numpy(), got.double().sum((0, 2, 3)).numpy(), rtol=1e-9, atol=1e-7)
+        np.testing.assert_allclose(st[1].numpy(), (got.double() ** 2).sum((0, 2, 3)).numpy(), rtol=1e-9, atol=1e-7)
+
+        # weight gradient
+        dz = rnd(n, co, d.h_out, d.w_out, seed=77, scale=1e-3)    # gradients live decades below the activations
+        adz = dev_amax(ops, dz)
+        dw = torch.full(wt.shape, float('nan'), device='cuda')
+        wsb = torch.empty(max(1, info.wgrad_workspace_floats), device='cuda')
+        two_plane_wgrad = info.wgrad_kernel_id >= 50000
+        ops.conv_wgrad(d, nhwc(x1), None if x2 is None else nhwc(x2), nhwc(dz), dw, wsb,
+                       scales=ops.make_scales(ax, ax if x2 is not None else None, None, adz) if two_plane_wgrad else None)
+        wg = lambda a, b: torch.nn.grad.conv2d_weight(a, wt.shape, b, stride=s, padding=k // 2)
+        if s == 1:
+            assert two_plane_wgrad, info.wgrad_kernel_id
+            assert rel(dw.cpu(), x3(wg, xin, dz)) < ORDER_TOL
+        assert rel(dw.cpu(), wg(xin.double(), dz.double())) < EXACT_TOL
+
+        # input gradient of source 1 (stride 1: the same kernel on flipped weights; the stride-2 one is four phase convolutions)
+        if s == 1 and up is None:
+            dd = ops.make_dgrad_desc(d, 0, c1, False)
+            di = ops.conv_query(dd)
+            assert 40000 <= di.kernel_id < 50000
+            pk = torch.empty(di.packed_weight_floats, device='cuda')
+            ops.conv_pack(dd, wt.cuda(), pk, aw)
+            dx = torch.full((n, h, w, c1), float('nan'), device='cuda')
+            ops.conv_fwd(dd, nhwc(dz), None, pk, dx, None, scales=ops.make_scales(adz, None, aw))
+            dg = lambda a, b: torch.nn.grad.conv2d_input(xin.shape, b, a, stride=1, padding=k // 2)[:, :c1]
+            assert rel(nchw(dx), x3(dg, dz, wt)) < ORDER_TOL
+            assert rel(nchw(dx), dg(dz.double(), wt.double())) < EXACT_TOL
+    finally:
+        ops.set_precision('fp32')
+
+
+ACC_CASES = [(3, 1, 64, 0, 64, 2, 33, 64, None), (3, 1, 256, 256, 256, 1, 15, 26, None), (3, 1, 32, 0, 32, 1, 40, 100, None)]
+
+
+@pytest.mark.parametrize('case', ACC_CASES, ids=[str(c) for c in ACC_CASES])
+def test_two_fp16_planes_are_as_accurate_as_the_exact_tier(ops, case, monkeypatch):
+    '''The admission bar of the exact tier (tests/test_hip_ops.py::test_split_bf16_conv_is_fp32_accurate): against an fp64 reference the
+    kernel must be within 2x of the exact f32-MFMA kernel's error, on the forward pass and on the input gradient.  Printed next to it:
+    the three-plane bf16 split.'''
+    k, s, c1, c2, co, n, h, w, up = case
+    x1, x2, wt, xin = _case(case, 10)
+    ref64 = F.conv2d(xin.double(), wt.double(), padding=1)
+    dz = rnd(*ref64.shape, seed=33, scale=1e-3)
+    want_dx = torch.nn.grad.conv2d_input(xin.shape, wt.double(), dz.double(), padding=1)[:, :c1]
+    errs = {}
+    for mode in ('f32mfma', 'bf16x3planes', 'f16x2'):
+        monkeypatch.setenv('RCF_CONV_SPLIT', '0' if mode == 'f32mfma' else '1')
+        ops.set_precision('f16x2' if mode == 'f16x2' else 'fp32')
+        try:
+            d = ops.make_fwd_desc(n, h, w, c1, c2, co, k, s, h, w, 0)
+            f16 = mode == 'f16x2'
+            ax, aw, adz = (dev_amax(ops, xin), dev_amax(ops, wt), dev_amax(ops, dz)) if f16 else (None, None, None)
+            got, _, info = _run_fwd(ops, d, x1, x2, wt, ax, aw)
+            assert (40000 <= info.kernel_id < 50000) == f16 and (info.kernel_id >= 5000) == (mode != 'f32mfma')
+            errs['fwd ' + mode] = rel(got, ref64)
+            dd = ops.make_dgrad_desc(d, 0, c1, False)
+            pk = torch.empty(ops.conv_query(dd).packed_weight_floats, device='cuda')
+            ops.conv_pack(dd, wt.cuda(), pk, aw)
+            dx = torch.full((n, h, w, c1), float('nan'), device='cuda')
+            ops.conv_fwd(dd, nhwc(dz), None, pk, dx, None, scales=ops.make_scales(adz, None, aw) if f16 else None)
+            errs['dx ' + mode] = rel(nchw(dx), want_dx)
+        finally:
+            ops.set_precision('fp32')
+    print('error against fp64 (max-abs, relative to max|ref|):', {k_: '%.2e' % v for k_, v in errs.items()})
+    assert errs['fwd f16x2'] < 2.0 * errs['fwd f32mfma'] + 1e-7 and errs['dx f16x2'] < 2.0 * errs['dx f32mfma'] + 1e-7
+    assert errs['fwd f16x2'] < 1e-5 and errs['dx f16x2'] < 1e-5
+
+
+def _dist(kind, shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(*shape, generator=g) * 2 - 1
+    if kind == 'uniform':
+        return u
+    if kind == 'heavy_tail':       # log-uniform magnitudes over eleven decades, random signs
+        return torch.sign(u) * torch.pow(10.0, torch.rand(*shape, generator=g) * 11.0 - 8.0)
+    if kind == 'outlier':          # one element 1e6 times everything else
+        t = u.clone()
+        t.view(-1)[t.numel() // 3] = 1.0e6
+        return t
+    if kind == 'tiny':             # a tensor living at 1e-30 (fp32 normal, far below fp16's range without the scale)
+        return u * 1e-30
+    if kind == 'huge':
+        return u * 1e25
+    if kind == 'denormal':         # fp32 denormals only
+        return u * 1e-40
+    if kind == 'zero':
+        return torch.zeros(*shape)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize('xkind,wkind', [('heavy_tail', 'uniform'), ('uniform', 'heavy_tail'), ('heavy_tail', 'heavy_tail'),
+                                         ('outlier', 'uniform'), ('uniform', 'outlier'), ('tiny', 'uniform'), ('huge', 'tiny'),
+                                         ('denormal', 'uniform'), ('zero', 'uniform'), ('uniform', 'zero')])
+def test_per_tensor_scale_on_hostile_operand_distributions(ops, xkind, wkind, monkeypatch):
+    '''What a per-tensor scale has to survive.  The error model (csrc/rcf_common.h): each operand element carries
+    <= 2^-23 |x| + 2^-39 max|x| of error, so an output is off by at most  sum |a||b| * 2^-22  +  (2^-38 amax_a amax_b) * K  -- checked
+    against fp64 per output element with that bound (x4 for the fp32 accumulation), and against the exact f32-MFMA kernel's own
+    error where that is larger.  All-zero tensors give exact zeros; a tensor of fp32 denormals (1e-40) is representable after the
+    scale and gives the f32 kernel's result up to its flush-to-zero of denormal products.'''
+    n, c, co, h, w = 2, 64, 64, 20, 36
+    x = _dist(xkind, (n, c, h, w), 1)
+    wt = _dist(wkind, (co, c, 3, 3), 2) * (1.0 / 24.0 if wkind == 'uniform' else 1.0)
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    bound = (F.conv2d(x.double().abs(), wt.double().abs(), padding=1) * 2.0 ** -22
+             + 2.0 ** -38 * float(x.abs().max()) * float(wt.abs().max()) * 9 * c) * 4.0
+    ops.set_precision('f16x2')
+    try:
+        d = ops.make_fwd_desc(n, h, w, c, 0, co, 3, 1, h, w, 0)
+        got, _, info = _run_fwd(ops, d, x, None, wt, dev_amax(ops, x), dev_amax(ops, wt))
+        assert 40000 <= info.kernel_id < 50000
+    finally:
+        ops.set_precision('fp32')
+    monkeypatch.setenv('RCF_CONV_SPLIT', '0')
+    got32, _, _ = _run_fwd(ops, ops.make_fwd_desc(n, h, w, c, 0, co, 3, 1, h, w, 0), x, None, wt)
+    assert bool(torch.isfinite(got).all())
+    err, err32 = (got.double() - ref).abs(), (got32.double() - ref).abs()
+    if 'zero' in (xkind, wkind):
+        assert float(got.abs().max()) == 0.0
+        return
+    if xkind == 'denormal':
+        # products of 1e-40 and 0.04 are fp32 denormals: both kernels are at the mercy of the denormal floor; the scaled kernel must
+        # not be worse than a few ulps of the smallest normal
+        assert float(err.max()) <= max(4.0 * float(err32.max()), 2.0 ** -126)
+        return
+    worst = float((err / torch.maximum(bound, 2.0 * err32 + 1e-45)).max())
+    print('%s x %s: max err / bound %.3f; max-abs rel %.2e (f32 MFMA %.2e)' % (xkind, wkind, worst, rel(got, ref), rel(got32, ref)))
+    assert worst <= 1.0
+    assert rel(got, ref) < 2.0 * rel(got32, ref) + 1e-7
+
+
+def test_unscaled_call_equals_scale_one_and_amax_entry_points(ops):
+    '''rcf_amax accumulates a maximum (several tensors into one slot, misaligned and odd-sized inputs), rcf_amax_batch equals n single
+    calls, the _amax variants of the elementwise kernels report the maximum of what they wrote -- and a conv called without maxima
+    (null pointers = scale 1) equals the scaled call when the data already sits where the scale would put it.'''
+    import ctypes
+    from rcf_amd._lib import AmaxItem
+    g = torch.Generator().manual_seed(9)
+    ts = [torch.randn(n, generator=g).cuda() * sc for n, sc in ((1, 3.0), (7, 1e-3), (16384, 1.0), (16385, 2.0), (100003, 0.5), (5, 0.0))]
+    for t in ts + [ts[4][1:]]:   # the last one is 4-byte aligned only
+        assert float(ops.amax(t)) == float(t.abs().max())
+    slot = torch.zeros(1, device='cuda')
+    for t in ts:
+        ops.amax(t, slot, accumulate=True)
+    assert float(slot) == max(float(t.abs().max()) for t in ts)
+    items = (AmaxItem * len(ts))()
+    outs = torch.zeros(len(ts), device='cuda')
+    for i, t in enumerate(ts):
+        items[i].x, items[i].n, items[i].amax = t.data_ptr(), t.numel(), outs[i:i + 1].data_ptr()
+    ops.amax_batch(items, len(ts))
+    assert outs.tolist() == [float(t.abs().max()) for t in ts]
+    # elementwise producers
+    from rcf_amd._lib import RCF_ACT_LEAKY_RELU
+    n_pix, c = 5 * 13 * 17, 32
+    z = torch.randn(n_pix, c, generator=g).cuda() * 3
+    res = torch.randn(n_pix, c, generator=g).cuda()
+    coef = torch.stack([torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g), torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5]).cuda().contiguous()
+    for r in (None, res):
+        out, out2, am = torch.empty_like(z), torch.empty_like(z), torch.zeros(1, device='cuda')
+        ops.bn_act_fwd(z, coef, r, out, n_pix, c, RCF_ACT_LEAKY_RELU, amax=am)
+        ops.bn_act_fwd(z, coef, r, out2, n_pix, c, RCF_ACT_LEAKY_RELU)
+        assert torch.equal(out, out2) and float(am) == float(out.abs().max())
+    bcoef = torch.randn(2, c, generator=g).cuda() * 0.1
+    dout = torch.randn(n_pix, c, generator=g).cuda() * 1e-3
+    dz, dz2, am = torch.empty_like(z), torch.empty_like(z), torch.zeros(1, device='cuda')
+    ops.bn_act_bwd_apply(dout, z, coef, None, bcoef, dz, None, False, n_pix, c, RCF_ACT_LEAKY_RELU, False, amax=am)
+    ops.bn_act_bwd_apply(dout, z, coef, None, bcoef, dz2, None, False, n_pix, c, RCF_ACT_LEAKY_RELU, False)
+    assert torch.equal(dz, dz2) and float(am) == float(dz.abs().max())
+    zp, img = torch.randn(n_pix, c, generator=g).cuda(), torch.randn(n_pix, c, generator=g).cuda()
+    fo, fo2, am = torch.empty_like(z), torch.empty_like(z), torch.zeros(1, device='cuda')
+    ops.fuse_fwd(z, coef, zp, coef, img, fo, n_pix, c, amax=am)
+    ops.fuse_fwd(z, coef, zp, coef, img, fo2, n_pix, c)
+    assert torch.equal(fo, fo2) and float(am) == float(fo.abs().max())
+    # scale 1: data with max in [2^14, 2^15) for x and w -> the scaled and the unscaled call are the same arithmetic
+    n, cc, h, w = 1, 32, 12, 20
+    x = rnd(n, cc, h, w, seed=3) * 2.0 ** 14.5
+    wt = rnd(cc, cc, 3, 3, seed=4) * 2.0 ** 14.5
+    ops.set_precision('f16x2')
+    try:
+        d = ops.make_fwd_desc(n, h, w, cc, 0, cc, 3, 1, h, w, 0)
+        a, _, _ = _run_fwd(ops, d, x, None, wt, dev_amax(ops, x), dev_amax(ops, wt))
+        b, _, _ = _run_fwd(ops, d, x, None, wt)
+        assert torch.equal(a, b)
+    finally:
+        ops.set_precision('fp32')
+
+
+def test_precision_levels_are_distinct_and_ordered(ops):
+    '''One 64 -> 64 layer under the arithmetic levels of fp32 tensors: exact three-plane split ~ two fp16 planes (both fp32-class)
+    << 'bf16_operands', i.e. each descriptor really selects its own kernels.'''
+    case = (3, 1, 64, 0, 64, 2, 33, 64, None)
+    k, s, c1, c2, co, n, h, w, up = case
+    x1, _, wt, xin = _case(case, 5)
+    ref = F.conv2d(xin.double(), wt.double(), padding=1)
+    err, outs = {}, {}
+    try:
+        for mode in ('fp32', 'f16x2', 'bf16_operands'):
+            ops.set_precision(mode)
+            d = ops.make_fwd_desc(n, h, w, c1, c2, co, k, s, h, w, 0)
+            f16 = mode == 'f16x2'
+            outs[mode], _, _ = _run_fwd(ops, d, x1, None, wt, dev_amax(ops, xin) if f16 else None, dev_amax(ops, wt) if f16 else None)
+            err[mode] = rel(outs[mode], ref)
+    finally:
+        ops.set_precision('fp32')
+    print(err)
+    assert err['fp32'] < 1e-6 and err['f16x2'] < 1e-6
+    assert not torch.equal(outs['fp32'], outs['f16x2'])
+    assert 100 * err['f16x2'] < err['bf16_operands'] < 1e-2
+
+
+@pytest.mark.parametrize('cin,cout,n,hs,ws', [(64, 32, 1, 35, 51), (64, 64, 2, 12, 20)])
+def test_up2x_conv_as_four_phase_convs(ops, cin, cout, n, hs, ws):
+    '''The exact-2x UpConv (nearest upsample + 3x3) as four 2x2 phase convolutions writing the strided output (RCF_PHASE_UP2X_FWD);
+    the four phases' pre-summed weights share one maximum.'''
+    x = rnd(n, cin, hs, ws, seed=3)
+    wt = rnd(cout, cin, 3, 3, seed=4, scale=1.0 / np.sqrt(cin * 9))
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2), wt.double(), padding=1)
+    ops.set_precision('f16x2')
+    try:
+        out = torch.full((n, 2 * hs, 2 * ws, cout), float('nan'), device='cuda')
+        from rcf_amd._lib import RCF_PHASE_UP2X_FWD
+        wph = ops.phase_weights(wt.cuda(), RCF_PHASE_UP2X_FWD)
+        ax, aw = dev_amax(ops, x), ops.amax(wph)
+        for a in range(2):
+            for b in range(2):
+                d = ops.make_up2x_fwd_desc(n, hs, ws, cin, cout, a, b)
+                info = ops.conv_query(d)
+                assert 40000 <= info.kernel_id < 50000
+                packed = torch.empty(info.packed_weight_floats, device='cuda')
+                ops.conv_pack(d, wph[a * 2 + b], packed, aw)
+                ops.conv_fwd(d, nhwc(x), None, packed, out, None, scales=ops.make_scales(ax, None, aw))
+        assert rel(nchw(out), ref) < EXACT_TOL
+    finally:
+        ops.set_precision('fp32')
+
+
+def _named(model):
+    out = []
+    for prefix, mod in (('encoder.', model.encoder), ('decoder.', model.decoder)):
+        out += [(prefix + k, v) for k, v in mod.named_parameters()]
+    return out
+
+
+@pytest.fixture(scope='module')
+def env():
+    import rcf_amd  # noqa: F401
+    from rcf_amd import synth, train
+    if os.environ.get('RCF_CONV_SPLIT') == '0':
+        pytest.skip('the two-plane arithmetic lives in the split kernels, which RCF_CONV_SPLIT=0 turns off')
+    return synth, train
+
+
+def _step(env, cfg, g, mode, deconv_type='up'):
+    synth, train = env
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    m = train.build_model(cfg, device='cuda', deconv_type=deconv_type)
+    synth.fill_state_dict_([m.encoder, m.decoder], wseed)
+    m.compute_dtype = mode
+    m.train()
+    b = {kk: v.cuda() for kk, v in synth.make_batch(n, h, w, k, seed=dseed).items()}
+    out = m.forward(image=b['image'], input_depth=b['input_depth'])
+    loss, info = m.compute_loss(image=b['image'], output_depth=out, ground_truth=b['ground_truth'], lidar_map=b['lidar_map'],
+                                loss_func='l1', w_smoothness=0.0, loss_smoothness_kernel_size=-1,
+                                validity_map_loss_smoothness=None, w_lidar_loss=2.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    return m, out.detach(), float(loss.detach())
+
+
+@pytest.mark.parametrize('fixture,deconv', [('T1_published_train.npz', 'up'), ('T10_transpose_published_train.npz', 'transpose')])
+def test_published_net_train_step_against_the_reference_fixture(env, golden_dir, fixture, deconv):
+    '''One training step of the published FusionNet under compute_dtype='f16x2' against the fixture generated by the REAL reference
+    (fp32 PyTorch CPU): output and loss within north_star's 1e-3 (measured: ~1e-6), parameter-gradient norms within 1 %, and the
+    mode is really in use (the output differs from the exact-fp32 path).'''
+    synth, _ = env
+    g = np.load(os.path.join(golden_dir, fixture))
+    m, out, loss = _step(env, synth.PUBLISHED, g, 'f16x2', deconv)
+    _, out32, _ = _step(env, synth.PUBLISHED, g, 'fp32', deconv)
+    e = rel(out.cpu(), torch.as_tensor(g['output']))
+    e32 = rel(out32.cpu(), torch.as_tensor(g['output']))
+    print('output rel err vs the reference: f16x2 %.2e (fp32 path %.2e); loss %.6f ref %.6f' % (e, e32, loss, float(g['loss'][0])))
+    assert e < NORTH_STAR and e < 2e-5
+    assert not torch.equal(out, out32)
+    assert abs(loss - float(g['loss'][0])) < 1e-4 * abs(float(g['loss'][0]))
+    grads = dict(_named(m))
+    worst = 0.0
+    for key, l2 in zip(g['grad_keys'].tolist(), g['grad_l2'].tolist()):
+        got = float(grads[key].grad.double().norm())
+        worst = max(worst, abs(got - l2) / max(l2, 1e-6))
+    print('worst parameter-gradient norm deviation: %.2e' % worst)
+    assert worst < 1e-2
+
+
+def test_three_adam_steps_follow_the_reference_trajectory(env, golden_dir):
+    '''Fixture T2 (three Adam steps of the real reference on the tiny net): the losses under f16x2 stay within north_star's bar.'''
+    synth, train = env
+    g = np.load(os.path.join(golden_dir, 'T2_tiny_adam3.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    m = train.build_model(synth.TINY, device='cuda')
+    synth.fill_state_dict_([m.encoder, m.decoder], wseed)
+    m.compute_dtype = 'f16x2'
+    m.train()
+    opt = train.make_optimizer(m, lr=1e-3)
+    losses = []
+    for step in range(3):
+        b = {kk: v.cuda() for kk, v in synth.make_batch(n, h, w, k, seed=dseed + step).items()}
+        losses.append(float(train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])[0]))
+    np.testing.assert_allclose(losses, g['losses'][:3], rtol=NORTH_STAR)
+    psum = float(sum(p.detach().double().abs().sum() for p in m.parameters()))
+    assert abs(psum - float(g['param_abs_sum'])) < 1e-4 * float(g['param_abs_sum'])
+
+
+def test_captured_training_step_is_bitwise_the_eager_step(env, golden_dir):
+    synth, train = env
+    g = np.load(os.path.join(golden_dir, 'T1_published_train.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    b = {kk: v.cuda() for kk, v in synth.make_batch(n, h, w, k, seed=dseed).items()}
+    args = (b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])
+    res = []
+    for captured in (False, True):
+        m = train.build_model(synth.PUBLISHED, device='cuda')
+        synth.fill_state_dict_([m.encoder, m.decoder], wseed)
+        m.compute_dtype = 'f16x2'
+        m.train()
+        opt = train.make_optimizer(m, lr=1e-3)
+        if captured:
+            step = m.capture_training_step(opt, *args)
+            ls = [float(step(*args).detach()) for _ in range(2)]
+        else:
+            ls = [float(train.train_step(m, opt, *args)[0]) for _ in range(2)]
+        torch.cuda.synchronize()
+        res.append((ls, [p.detach().clone() for _, p in _named(m)]))
+    assert res[0][0] == res[1][0]
+    for a, c in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, c)
