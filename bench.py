@@ -18,7 +18,8 @@ than N devices are visible; it never silently measures fewer GPUs than it was as
 Rank 0 prints ONE JSON line.  `roofline` is measured live: every launch of the dominant kernel family (the 3x3
 stride-1 implicit-GEMM convolution, forward + input-gradient launches) is bracketed by events on the launch
 stream inside the timed steps; achieved = algorithmic FLOP / event time.  `cpu_baseline` (N = 1 only) times the CPU
-oracle on the host cores on a bounded sample (1 warm-up + 3 timed training steps at batch 1, 900x1600, median).
+oracle on the host cores on a bounded sample (2 warm-up + 5 timed training steps at batch 1, 900x1600, median; --cpu-baseline-batch8
+adds a batch-8 leg).
 The loss of the first step is compared with the value the CPU oracle computed for the same seeds
 (tests/golden/bench_expected.json): a wrong step is not timed.
 
@@ -44,12 +45,18 @@ HBM_PEAK_GBS = 8000.0
 # what a loop of nothing but v_mfma_f32_32x32x16_bf16 on random operand bits sustains at the ~1.4 kW board limit
 # (tools/probe/mfma_issue_probe.hip: 17.0 ns per MFMA per SIMD) -- reported next to `frac`, never instead of it
 BF16_MFMA_SUSTAINED_TFLOPS = 1970.0
-SPLIT_PRODUCTS = 6              # bf16 partial products executed per fp32 multiply-add in the split kernels
+# partial products the split kernels execute per fp32 multiply-add, by arithmetic tier
+SPLIT_PRODUCTS = {'f32': 3, 'f32_3plane': 6, 'bf16': 1}
+SPLIT_PIPE = {
+    'f32': 'fp16 MFMA (v_mfma_f32_32x32x16_f16): 3 partial products of two scaled fp16 planes per fp32 multiply, fp32 accumulate',
+    'f32_3plane': 'bf16 MFMA: 6 exact partial products of three bf16 planes per fp32 multiply, fp32 accumulate',
+    'bf16': 'bf16 MFMA, bf16 operands, fp32 accumulate'}
+TIER_TEXT = {'f32': 'fp32 tensors, two scaled fp16 planes', 'f32_3plane': 'fp32 tensors, three bf16 planes', 'bf16': 'bf16 tensors and operands'}
 TRAIN_GFLOP_PER_SAMPLE = 994.8  # forward + dgrad + wgrad of the reference's 9-tap convolutions at 900x1600
 FWD_GFLOP_PER_SAMPLE = 333.09
 KERNEL_NAMES = {
     0: 'conv_fwd_kernel 3x3 s1', 1: 'conv_fwd_kernel 3x3 s2', 2: 'conv_fwd_kernel 1x1', 3: 'conv_fwd_kernel 7x7 s2 stem',
-    5: 'conv_split_kernel 3x3 s1 (fp32 via 3-plane bf16 split)', 9: 'conv_split_kernel 2x2 phases (fp32 via 3-plane bf16 split)',
+    5: 'conv_split_kernel 3x3 s1', 9: 'conv_split_kernel 2x2 phases',
     10: 'conv_wgrad_kernel 3x3 s1', 11: 'conv_wgrad_kernel 3x3 s2', 12: 'conv_wgrad_kernel 1x1', 13: 'conv_wgrad_kernel 7x7 s2 stem',
 }
 
@@ -64,12 +71,13 @@ def parse():
     ap.add_argument('--height', type=int, default=900)
     ap.add_argument('--width', type=int, default=1600)
     ap.add_argument('--points', type=int, default=64)
-    ap.add_argument('--dtype', choices=('f32', 'f32x3', 'bf16'), default=None,
-                    help='f32: the reference arithmetic (the metric; default for train).  f32x3 (train only): fp32 tensors, the split '
-                         'convolution kernels on two bf16 planes / three products per multiply (16-17 significant bits, errors ~1e-5: '
-                         'inside north_star\'s 1e-3, NOT exact fp32 -- reported beside the metric, never as it).  bf16: bf16 tensors in HBM and bf16 MFMA '
-                         'operands, fp32 accumulate / master weights / BatchNorm statistics (BASELINE.json configs 2-4; default for '
-                         'infer and radarnet)')
+    ap.add_argument('--dtype', choices=('f32', 'f32_3plane', 'bf16'), default=None,
+                    help='f32: the reference arithmetic (the metric; default for train): fp32 tensors, fp32-accurate products -- the 3x3 / '
+                         '2x2 split kernels on two scaled fp16 planes (three products per multiply; fp32-convolution-class error against '
+                         'fp64, tests/test_hip_f16x2.py), the rest on the f32 MFMA.  f32_3plane (train only): the same with the split '
+                         'kernels on three bf16 planes / six products (the previous rounds\' exact tier).  bf16: bf16 tensors in HBM and '
+                         'bf16 MFMA operands, fp32 accumulate / master weights / BatchNorm statistics (BASELINE.json configs 2-4; default '
+                         'for infer and radarnet)')
     ap.add_argument('--preheat-s', type=float, default=4.0,
                     help='untimed steps run for this many seconds after the W warm-up steps, so the timed steps see the clocks '
                          'of a board at its power limit and not the boost clocks of a cold one')
@@ -77,7 +85,10 @@ def parse():
                                                           'default: the graph on one GPU (bitwise the eager step, tests/'
                                                           'test_hip_model.py), eager under data parallelism')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-side-leg', action='store_true', help='skip the untimed-by-the-metric f32x3 leg of the default run')
+    ap.add_argument('--side-leg', action='store_true', help='also time the same step on the three-plane bf16 split (f32_3plane), reported '
+                                                            'beside the metric in its own object')
+    ap.add_argument('--no-side-leg', action='store_true', help='(accepted for older command lines; the side leg is opt-in now)')
+    ap.add_argument('--cpu-baseline-batch8', action='store_true', help='cpu_baseline: add a batch-8 leg (1 warm-up + 2 timed steps, ~3 min)')
     ap.add_argument('--kernel-table', type=str, default='', help='write the per-kernel event table (JSON) here')
     return ap.parse_args()
 
@@ -136,9 +147,25 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(height, width, points):
-    '''The CPU oracle (stock PyTorch fp32, oneDNN) on the host cores: training steps at batch 1, 1 warm-up + 3 timed, median
-    (SURVEY.md 8d asks 2 + 5; bounded here to ~35 s on the GPU box's host so the default run stays within minutes).'''
+def _cpu_steps(model, opt, b, n_steps, torch):
+    times = []
+    for i in range(n_steps):
+        t0 = time.time()
+        out = model.forward(b['image'], b['input_depth'])
+        loss = model.compute_loss(out, b['ground_truth'], b['lidar_map'], 2.0)[0]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.time() - t0)
+        if i == 0 and times[0] > 60.0:   # a slow host: keep the run bounded, report the single step and say so
+            break
+    return times
+
+
+def cpu_baseline(height, width, points, batch8=False):
+    '''The CPU oracle (stock PyTorch fp32, oneDNN) on the host cores, SURVEY.md 8d's protocol: training steps at batch 1, 2 warm-up +
+    5 timed, median (~50 s on the GPU box's host).  batch8=True adds the batch-8 leg (1 warm-up + 2 timed: ~3 min, behind a flag so
+    the default run stays within minutes).'''
     import torch
     from rcf_amd import synth
     from oracle.fusionnet_oracle import FusionNetOracle
@@ -147,26 +174,21 @@ def cpu_baseline(height, width, points):
     model = FusionNetOracle(**synth.PUBLISHED)
     synth.fill_state_dict_([model.encoder, model.decoder], 1234)
     opt = torch.optim.Adam([{'params': model.parameters(), 'weight_decay': 0.0}], lr=1e-3)
-    b = synth.make_batch(1, height, width, points, seed=99)
     model.train()
-    times = []
-    for i in range(4):
-        t0 = time.time()
-        out = model.forward(b['image'], b['input_depth'])
-        loss = model.compute_loss(out, b['ground_truth'], b['lidar_map'], 2.0)[0]
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        times.append(time.time() - t0)
-        if i == 0 and times[0] > 30.0:   # a slow host: keep the run bounded, report the single step and say so
-            break
-    timed = sorted(times[1:]) if len(times) > 1 else times
+    times = _cpu_steps(model, opt, synth.make_batch(1, height, width, points, seed=99), 7, torch)
+    timed = sorted(times[2:]) if len(times) > 2 else times
     dt = timed[len(timed) // 2]
-    return {'value': round(1.0 / dt, 5), 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'cpu': _cpu_model(), 'logical_cpus': os.cpu_count(),
-            'sample': '%s training steps (fwd+loss+bwd+Adam) at batch 1, %dx%d, published net, CPU oracle (stock PyTorch fp32, oneDNN); '
-                      'step times %s s' % ('1 warm-up + median of %d timed' % len(timed) if len(times) > 1 else '1 cold', height, width,
-                                           [round(t, 2) for t in times])}
+    rec = {'value': round(1.0 / dt, 5), 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+           'cpu': _cpu_model(), 'logical_cpus': os.cpu_count(),
+           'sample': '%s training steps (fwd+loss+bwd+Adam) at batch 1, %dx%d, published net, CPU oracle (stock PyTorch fp32, oneDNN); '
+                     'step times %s s' % ('2 warm-up + median of %d timed' % len(timed) if len(times) > 2 else '1 cold', height, width,
+                                          [round(t, 2) for t in times])}
+    if batch8:
+        t8 = _cpu_steps(model, opt, synth.make_batch(8, height, width, points, seed=1234), 3, torch)
+        timed8 = sorted(t8[1:]) if len(t8) > 1 else t8
+        rec['batch8'] = {'value': round(8.0 / timed8[len(timed8) // 2], 5), 'unit': 'samples/s',
+                         'sample': '1 warm-up + median of %d timed training steps at batch 8; step times %s s' % (len(timed8), [round(t, 2) for t in t8])}
+    return rec
 
 
 # ---------------------------------------------------------------------------------------------------------------- helpers
@@ -198,6 +220,23 @@ def _pmc_traffic(kernel_name):
     if meta.get('csrc_sha') != _csrc_sha():
         return None, 'stale: ' + src + ' profiled other kernel sources than this tree (was %s GB)' % val
     return val, src
+
+
+def _encoder_3x3(timer, ev_steps, dtype):
+    flops = ms = 0.0
+    n = 0
+    for (kid, tag), (c, f, m) in getattr(timer, 'layers', {}).items():
+        if tag.startswith('encoder ') and (' k3 ' in tag or ' k2 ' in tag):   # k2: the phase forms of the stride-2 layers' gradients
+            flops += f; ms += m; n += c
+    if ms <= 0.0:
+        return None
+    tf = flops / (ms * 1e-3) / 1e12
+    prod = SPLIT_PRODUCTS[dtype]
+    return {'launches_per_step': n // max(1, ev_steps), 'gflop_per_step': round(flops / max(1, ev_steps) / 1e9, 1),
+            'ms_per_step': round(ms / max(1, ev_steps), 3), 'tflops_algorithmic': round(tf, 2),
+            'tflops_executed': round(tf * prod, 1), 'frac_of_pipe_peak': round(tf * prod / BF16_MFMA_PEAK_TFLOPS, 4),
+            'note': 'forward + input-gradient + weight-gradient launches of the encoder\'s 3x3 convolutions; executed = algorithmic x %d '
+                    'partial products (the few stride-2 forward launches on the f32 MFMA are priced the same way)' % prod}
 
 
 def _expected_first_loss(key, world=1, w_lidar=2.0):
@@ -236,8 +275,8 @@ def run_rank(args):
     dev = torch.device('cuda', local_rank if (world > 1 and not single_dev) else 0)
     torch.cuda.set_device(dev)
     if args.workload != 'train':
-        if args.dtype == 'f32x3':
-            raise SystemExit('--dtype f32x3 is a training leg')
+        if args.dtype == 'f32_3plane':
+            raise SystemExit('--dtype f32_3plane is a training leg')
         if world > 1:
             raise SystemExit('--workload %s is a single-GPU leg' % args.workload)
         return run_infer(args, dev) if args.workload == 'infer' else run_radarnet(args, dev)
@@ -246,7 +285,7 @@ def run_rank(args):
 
     model = train.build_model(synth.PUBLISHED, device=dev)
     synth.fill_state_dict_([model.encoder, model.decoder], 1234)   # seeded U(+-1/sqrt(fan_in)) weights, identical on every rank
-    model.compute_dtype = {'bf16': 'bf16', 'f32x3': 'f16x2'}.get(dtype, 'fp32')
+    model.compute_dtype = {'bf16': 'bf16', 'f32_3plane': 'fp32_3plane'}.get(dtype, 'fp32')
     if world > 1:
         model.data_parallel()
     opt = train.make_optimizer(model, lr=1e-3)
@@ -324,7 +363,7 @@ def run_rank(args):
     # aggregate kernel ids (kind*1000 + ck*10 + nt [+100 for the 16x16 tile]; wgrad ids are 10000 + ...) by kernel family
     fam = {}
     for kid, (cnt, flops, ms) in table.items():
-        kid0 = kid % 20000        # + 20000: bf16 variant of the same kernel family, + 40000: two-plane (bf16x3) variant
+        kid0 = kid % 20000        # + 20000: bf16 variant of the same kernel family, + 40000: two-plane fp16 variant
         f = (10 + (kid0 - 10000) // 1000) if kid0 >= 10000 else kid0 // 1000
         r = fam.setdefault(f, [0, 0.0, 0.0, 0.0])
         r[0] += cnt; r[1] += flops; r[2] += ms; r[3] += getattr(timer, 'bytes', {}).get(kid, 0.0)
@@ -332,10 +371,10 @@ def run_rank(args):
     ev_steps = 3 if use_graph else args.steps
 
     side = None
-    if args.dtype is None and not args.no_side_leg and world == 1:   # the default 1-GPU run also reports the three-product arithmetic, beside the metric
+    if args.side_leg and dtype == 'f32' and world == 1:   # opt-in: the same step on the three-plane bf16 split, beside the metric
         del step
         try:
-            side = side_leg(args, dev, world, rank, batch, 'f32x3')
+            side = side_leg(args, dev, world, rank, batch, 'f32_3plane')
         except Exception as e:
             side = {'error': str(e)[:200]}
 
@@ -359,13 +398,19 @@ def run_rank(args):
         'dtype': dtype,
         'data': 'synthetic',
         'config': {'workload': 'FusionNet %s training, per-GPU batch %d, %dx%d, %d-point radar maps (BASELINE.json %s)'
-                               % ({'f32': 'fp32', 'f32x3': 'fp32-tensor / bf16x3-product (two bf16 planes, three products per multiply in the '
-                                   'split conv kernels: NOT exact fp32)'}.get(dtype, 'bf16 (bf16 tensors in HBM + bf16 MFMA operands, fp32 accumulate / '
-                                  'master weights / BN statistics)'), batch, args.height, args.width, args.points,
-                                  'configs[1]' if dtype in ('f32', 'f32x3') else 'configs[3] on %d GPU(s)' % world),
+                               % ({'f32': 'fp32', 'f32_3plane': 'fp32 (split conv kernels on three bf16 planes)'}.get(
+                                   dtype, 'bf16 (bf16 tensors in HBM + bf16 MFMA operands, fp32 accumulate / master weights / BN statistics)'),
+                                  batch, args.height, args.width, args.points,
+                                  'configs[1]' if dtype in ('f32', 'f32_3plane') else 'configs[3] on %d GPU(s)' % world),
                    'global_batch': world * batch, 'parallelism': 'dp%d' % world,
                    'step': 'forward + outlier removal + masked L1 + backward + Adam, train-mode BatchNorm',
                    'launch': 'one hipGraph replay per step (bitwise the eager step)' if use_graph else (graph_note or 'eager launches'),
+                   'arithmetic': {'f32': 'fp32 tensors; 3x3 / 2x2 convolutions as three fp16-MFMA products of two scaled fp16 planes per operand '
+                                         '(22-23 significant bits, per-tensor power-of-two scales from the producing kernels; error against fp64 within '
+                                         'the f32 MFMA\'s: tests/test_hip_f16x2.py), 1x1 / 7x7 / stride-2 forward on the f32 MFMA, everything '
+                                         'else fp32 with fp64 BatchNorm sums',
+                                  'f32_3plane': 'fp32 tensors; 3x3 / 2x2 convolutions as six bf16-MFMA products of three bf16 planes per operand'}.get(
+                                      dtype, 'bf16 tensors and MFMA operands, fp32 accumulate'),
                    'first_step_loss': None if first_loss is None else round(first_loss, 5), 'final_loss': round(final_loss, 5),
                    'preheat_steps': n_pre},
         'rccl_ranks': dist.get_world_size() if world > 1 else 1,
@@ -376,7 +421,7 @@ def run_rank(args):
     if dp_info is not None:
         rec['dp'] = dp_info
     if side is not None:
-        rec['f32x3'] = side
+        rec['f32_3plane'] = side
     # the step that is being timed must be the right step: its first loss against the CPU oracle's value for these seeds
     loss_ok = True
     small = (args.height, args.width, args.points, batch) == (224, 384, 32, 2)   # the shape the 2-rank tests run
@@ -395,15 +440,15 @@ def run_rank(args):
         algorithmic = flops / (ms * 1e-3) / 1e12
         is_split = dom in (5, 9, 15, 19)
         # split kernels are bound by the bf16 matrix pipe: price them on the bf16 FLOPs they execute (6 per fp32 MAC)
-        achieved = algorithmic * ({'bf16': 1, 'f32x3': 3}.get(dtype, SPLIT_PRODUCTS) if is_split else 1)
-        peak = BF16_MFMA_PEAK_TFLOPS if is_split else F32_MFMA_PEAK_TFLOPS
+        achieved = algorithmic * (SPLIT_PRODUCTS[dtype] if is_split else 1)
+        peak = BF16_MFMA_PEAK_TFLOPS if is_split else F32_MFMA_PEAK_TFLOPS   # the guide's dense peak is the same for bf16 and fp16
         kname = KERNEL_NAMES.get(dom, str(dom))
         if dtype == 'f32':
             traffic, traffic_src = _pmc_traffic(kname)
         else:   # the committed PMC passes profile the fp32 step
             traffic, traffic_src = None, 'the committed PMC passes (profiles/) were collected on the fp32 step'
-            kname = kname.replace('fp32 via 3-plane bf16 split', 'bf16 tensors and operands' if dtype == 'bf16' else
-                                  'fp32 tensors, 2-plane bf16 operands, 3 products')
+        if is_split:
+            kname += ' (%s)' % TIER_TEXT[dtype]
         conv_ms = sum(r[2] for r in fam.values())
         conv_flops = sum(r[1] for r in fam.values())
         rec['roofline'] = {
@@ -411,17 +456,22 @@ def run_rank(args):
             'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
             'frac': round(achieved / peak, 4), 'algorithmic_fp32_tflops': round(algorithmic, 2),
             # the honest fraction: useful (algorithmic) FLOP/s over the peak of the pipe the kernel runs on -- `frac` above prices
-            # the 6 partial products of the exact fp32 split as work, this one does not
+            # the partial products of the split as work, this one does not
             'useful_frac': round(algorithmic / peak, 4),
             'useful_frac_of_f32_mfma_peak': round(algorithmic / F32_MFMA_PEAK_TFLOPS, 4),
             'frac_of_power_limited_peak': round(achieved / BF16_MFMA_SUSTAINED_TFLOPS, 4) if is_split else None,
-            'pipe': {'bf16': 'bf16 MFMA, bf16 operands, fp32 accumulate', 'f32x3': 'bf16 MFMA, 3 partial products of two-plane operands per multiply, fp32 accumulate'}.get(
-                dtype, 'bf16 MFMA, 6 exact partial products per fp32 multiply, fp32 accumulate') if is_split else 'f32 MFMA',
+            'pipe': SPLIT_PIPE[dtype] if is_split else 'f32 MFMA',
+            'products_per_multiply': SPLIT_PRODUCTS[dtype] if is_split else 1,
+            'events_from': ('%d eager steps after the timed region (a replayed hipGraph has no per-launch events)' % ev_steps) if use_graph
+                           else 'HIP events around every launch of the family inside the timed steps',
             'traffic': traffic, 'traffic_source': traffic_src,
             'algorithmic_gbytes_per_launch': round(abytes / cnt / 1e9, 4),
             'launches_per_step': cnt // ev_steps, 'avg_launch_ms': round(ms / cnt, 4),
             'algorithmic_gflop_per_launch': round(flops / cnt / 1e9, 3),
             'share_of_step_time': round(ms / ev_steps / (1000.0 * dt / args.steps), 4),
+            # the subset north_star's ">= 70 % MFMA utilisation" names: the encoder's 3x3 convolutions (ResNet blocks, both branches;
+            # forward + input gradient + weight gradient launches), from the same events
+            'encoder_3x3': _encoder_3x3(timer, ev_steps, dtype),
             'all_conv_kernels': {'achieved': round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
                                  'share_of_step_time': round(conv_ms / ev_steps / (1000.0 * dt / args.steps), 4),
                                  'gflop_per_sample': round(conv_flops / (batch * ev_steps) / 1e9, 2)},
@@ -434,7 +484,7 @@ def run_rank(args):
         with open(args.kernel_table, 'w') as fh:
             json.dump({'steps': ev_steps, 'ms_per_step': 1000.0 * dt / args.steps, 'kernels': rows, 'layers': layers}, fh, indent=1)
     if world == 1 and not args.no_cpu_baseline:
-        rec['cpu_baseline'] = cpu_baseline(args.height, args.width, args.points)
+        rec['cpu_baseline'] = cpu_baseline(args.height, args.width, args.points, batch8=args.cpu_baseline_batch8)
     print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -446,16 +496,16 @@ def run_rank(args):
 
 
 def side_leg(args, dev, world, rank, batch, dtype):
-    '''The same training step, same seeds, under another arithmetic of the split convolution kernels (f32x3: fp32 tensors, two bf16
-    planes / three products per multiply -- ~1e-5 errors, inside north_star's 1e-3 but not exact fp32, so it is reported BESIDE the
-    metric and never as `value`).  Its own model, warm-up, pre-heat and barrier-bracketed timed region (half the steps).'''
+    '''The same training step, same seeds, under the other fp32-accurate arithmetic of the split convolution kernels (f32_3plane: three
+    bf16 planes, six products per multiply -- the previous rounds' exact tier), reported BESIDE the metric, never as `value`.  Its own
+    model, warm-up, pre-heat and barrier-bracketed timed region (half the steps).'''
     import torch
     import torch.distributed as dist
     from rcf_amd import synth, train
     from rcf_amd.net_utils import OutlierRemoval
     model = train.build_model(synth.PUBLISHED, device=dev)
     synth.fill_state_dict_([model.encoder, model.decoder], 1234)
-    model.compute_dtype = {'f32x3': 'f16x2'}[dtype]
+    model.compute_dtype = {'f32_3plane': 'fp32_3plane'}[dtype]
     if world > 1:
         model.data_parallel()
     opt = train.make_optimizer(model, lr=1e-3)
@@ -496,8 +546,7 @@ def side_leg(args, dev, world, rank, batch, dtype):
         dt = float(t.item())
     want = _expected_first_loss('train_b8_900x1600_p64') if (args.height, args.width, args.points, batch) == (900, 1600, 64, 8) else None
     return {'value': round(world * batch * steps / dt, 4), 'unit': 'samples/s', 'ms_per_step': round(1000.0 * dt / steps, 3), 'steps': steps,
-            'dtype': dtype, 'arithmetic': 'fp32 tensors; split conv kernels on two bf16 planes, three products per multiply, fp32 accumulate '
-                                          '(tests/test_hip_bf16x3.py: ~5e-5 of max-abs against the reference fixtures; north_star bar 1e-3)',
+            'dtype': dtype, 'arithmetic': 'fp32 tensors; split conv kernels on three bf16 planes, six products per multiply, fp32 accumulate',
             'launch': 'hipGraph replay' if graph else 'eager',
             'first_step_loss': round(first_loss, 5),
             'first_step_loss_rel_err_vs_oracle': None if want is None else float('%.3e' % (abs(first_loss - want) / abs(want)))}

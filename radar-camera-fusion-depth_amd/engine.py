@@ -185,6 +185,7 @@ class Engine(object):
         self._amax_arena = None
         self._amax_used = 0
         self._wamax_cache = {}
+        self._scope = None
 
     # ------------------------------------------------------------------ helpers
     def _new(self, shape, ref):
@@ -196,6 +197,12 @@ class Engine(object):
         '''An fp32 buffer whatever the activation storage is: packed weights, coefficients, workspaces, single-channel maps.'''
         return torch.empty(shape, dtype=torch.float32, device=ref.device)
 
+
+    def _set_scope(self, scope):
+        '''Which part of the network the following launches belong to ('encoder' / 'decoder'): profiling tags only.'''
+        self._scope = scope
+        if self.prof is not None:
+            self.prof.scope = scope
 
     # ---- per-tensor maxima of the two-plane fp16 arithmetic (RCF_PREC_F16X2; rcf_common.h)
     @staticmethod
@@ -752,8 +759,10 @@ class Engine(object):
         if self.tape is not None:
             bn = layer.batch_norm
             batch_stats = self.training
+            scope = self._scope
 
             def backward():
+                self._set_scope(scope)
                 if out.g is None and out.g_head is not None:
                     # the only consumer was the output head: its input gradient is recomputed inside both BN-backward passes
                     dlogit, w_head = out.g_head
@@ -803,7 +812,10 @@ class Engine(object):
         z, desc, info, _ = self._conv(layer, x)
         out = Act(z)
         if self.tape is not None:
+            scope = self._scope
+
             def backward():
+                self._set_scope(scope)
                 dz = out.g
                 out.g = None
                 self._conv_backward(layer, desc, info, x, None, dz)
@@ -824,8 +836,10 @@ class Engine(object):
         if self.tape is not None:
             bnw, bnp = layer_w.batch_norm, layer_p.batch_norm
             batch_stats = self.training
+            scope = self._scope
 
             def backward():
+                self._set_scope(scope)
                 dout = out.g
                 nb = ops.ew_blocks(n_pix, c)
                 bpart = torch.empty((nb, 4, c), dtype=torch.float64, device=zw.device)
@@ -955,6 +969,7 @@ class Engine(object):
         if hw is None:
             hw = tuple(image_nhwc.shape[1:3])
         self._begin_step_scales(image_nhwc if image_nhwc is not None else image_s2d)
+        self._set_scope('encoder')
         img = self.conv_bn_act(enc.conv1_image, self._input(image_nhwc, image_s2d, hw))
         dep = self.conv_bn_act(enc.conv1_depth, self._input(depth_nhwc, depth_s2d, hw))
         layers = [self.fuse(enc.conv1_weight, enc.conv1_project, dep, img)]
@@ -973,6 +988,7 @@ class Engine(object):
     def _decode(self, latent, skips, shape):
         '''MultiScaleDecoder.forward, n_resolution == 1 (src/networks.py:1571-1657), up to the input of output0.'''
         dec = self.decoder
+        self._set_scope('decoder')
         x = latent
         n = len(skips) - 1
         names = dec.block_names

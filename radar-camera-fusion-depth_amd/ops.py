@@ -95,7 +95,7 @@ def precision_of(compute_dtype):
     return compute_dtype
 
 
-FP32_TIER_DEFAULT = '3plane'
+FP32_TIER_DEFAULT = 'f16x2'
 
 
 def act_dtype():
@@ -225,6 +225,7 @@ class KernelTimer(object):
         self.only = None if only_ids is None else set(only_ids)
         self.pending = []
         self.cur = None
+        self.scope = None   # set by the engine: 'encoder' / 'decoder' (whose layer the bracketed launch belongs to)
 
     def begin(self, kid, flops, desc=None):
         if self.only is not None and kid not in self.only:
@@ -236,9 +237,9 @@ class KernelTimer(object):
         self.bytes = getattr(self, 'bytes', {})
         if desc is not None:
             self.bytes[kid] = self.bytes.get(kid, 0.0) + (algorithmic_bytes(desc) if kid < 10000 else 0.0)
-            tag = '%s k%d s%d %d+%d->%d @%dx%d g%d' % ('dgrad' if desc.w_mode == RCF_W_DGRAD else ('wgrad' if kid >= 10000 else 'fwd'),
-                                                      desc.ksize, desc.stride, desc.c1, desc.c2, desc.c_out, desc.h_out, desc.w_out,
-                                                      desc.gather1)
+            tag = '%s %s k%d s%d %d+%d->%d @%dx%d g%d' % (self.scope or '-', 'dgrad' if desc.w_mode == RCF_W_DGRAD else ('wgrad' if kid >= 10000 else 'fwd'),
+                                                         desc.ksize, desc.stride, desc.c1, desc.c2, desc.c_out, desc.h_out, desc.w_out,
+                                                         desc.gather1)
         self.cur = (kid, flops, ev, tag)
 
     def end(self):

@@ -118,15 +118,18 @@ def test_config1_fp32_batch8_900x1600_train_forward_and_loss_against_oracle(env)
     assert abs(float(l2) - rec['first_step_loss']) < BAR * rec['first_step_loss']
 
 
-def test_config1_fp32_batch8_gradients_are_the_sum_of_batch1_gradients(env):
+@pytest.mark.parametrize('tier', ['fp32', 'fp32_3plane'])
+def test_config1_fp32_batch8_gradients_are_the_sum_of_batch1_gradients(env, tier):
     '''Full batch, full resolution, forward AND backward, without a minutes-long CPU backward: with eval-mode BatchNorm the samples
-    are independent, so (i) row i of the batch-8 output is BITWISE the batch-1 output of sample i (tiles that straddle images in
+    are independent, so (i) row i of the batch-8 output is the batch-1 output of sample i (tiles that straddle images in
     the virtual-tall tiling, 64-bit offsets into 30 GB of activations) and (ii) the batch-8 parameter gradient is the sum of
-    the eight batch-1 gradients for the same upstream gradient.'''
+    the eight batch-1 gradients for the same upstream gradient.  On the three-plane bf16 split (i) holds BITWISE; on the two-plane fp16
+    arithmetic the operand scale is a property of the whole tensor (max|x| over the batch), so a batch-1 call may round its planes one
+    binade finer than the batch-8 call: equal to fp32 round-off (1e-5 of max-abs) instead of bitwise.'''
     synth, _ = env
     cb = synth.make_batch(8, 900, 1600, 64, seed=77)
     b = {k: v.cuda() for k, v in cb.items()}
-    m = _build(env, 21)
+    m = _build(env, 21, tier)
     m.eval()
     torch.manual_seed(5)
     dd = (torch.rand(8, 1, 900, 1600, device='cuda') - 0.5) * 1e-3
@@ -139,7 +142,12 @@ def test_config1_fp32_batch8_gradients_are_the_sum_of_batch1_gradients(env):
     for i in range(8):
         o1 = m.forward(b['image'][i:i + 1].contiguous(), b['input_depth'][i:i + 1].contiguous())
         if i in (0, 3, 7):
-            assert torch.equal(o1[0], out8.detach()[i]), 'sample %d: batch-8 row differs from the batch-1 output' % i
+            if tier == 'fp32_3plane':
+                assert torch.equal(o1[0], out8.detach()[i]), 'sample %d: batch-8 row differs from the batch-1 output' % i
+            else:
+                e = _rel(o1[0], out8.detach()[i])
+                print('sample %d: batch-8 row vs batch-1 output rel %.2e' % (i, e))
+                assert e < 1e-5, 'sample %d: batch-8 row differs from the batch-1 output by %.2e' % (i, e)
         for p in m.parameters():
             p.grad = None
         o1.backward(dd[i:i + 1].contiguous())
@@ -340,17 +348,20 @@ def test_bench_two_ranks_at_the_headline_shape_pass_their_own_loss_check():
 
 
 def test_bench_single_gpu_line_carries_the_contract_fields():
-    r, rec = _run_bench(['--steps', '2', '--warmup', '1', '--preheat-s', '0', '--no-cpu-baseline'])
+    r, rec = _run_bench(['--steps', '2', '--warmup', '1', '--preheat-s', '0', '--no-cpu-baseline', '--side-leg'])
     assert r.returncode == 0 and rec is not None, (r.returncode, r.stderr[-1500:])
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
                 'dtype', 'data', 'config', 'roofline', 'algorithmic_tflops'):
         assert key in rec, key
     assert rec['n_gpus'] == 1 and rec['steps'] == 2 and rec['dtype'] == 'f32'
     assert rec['config']['loss_check']['ok'] is True          # first step == the CPU oracle's loss for these seeds
-    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'useful_frac'):
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'useful_frac', 'pipe', 'events_from', 'products_per_multiply'):
         assert key in rec['roofline'], key
-    # the default run carries the same step under the bf16x3 arithmetic beside the metric: same first loss (to 1e-5), not slower
-    side = rec['f32x3']
+    assert rec['roofline']['products_per_multiply'] == 3 and 'fp16' in rec['roofline']['pipe']
+    enc = rec['roofline']['encoder_3x3']
+    assert enc['tflops_algorithmic'] > 0 and 0 < enc['frac_of_pipe_peak'] < 1 and enc['gflop_per_step'] > 0
+    # --side-leg: the same step on the three-plane bf16 split beside the metric: same first loss (to 1e-5), and not faster
+    side = rec['f32_3plane']
     assert 'error' not in side, side
-    assert side['dtype'] == 'f32x3' and side['value'] > 0 and side['ms_per_step'] < 1.1 * rec['ms_per_step']
+    assert side['dtype'] == 'f32_3plane' and side['value'] > 0 and side['ms_per_step'] > 0.95 * rec['ms_per_step']
     assert side['first_step_loss_rel_err_vs_oracle'] < 1e-5

@@ -416,14 +416,14 @@ def _step(env, cfg, g, mode, deconv_type='up'):
 def test_published_net_train_step_against_the_reference_fixture(env, golden_dir, fixture, deconv):
     '''One training step of the published FusionNet under compute_dtype='f16x2' against the fixture generated by the REAL reference
     (fp32 PyTorch CPU): output and loss within north_star's 1e-3 (measured: ~1e-6), parameter-gradient norms within 1 %, and the
-    mode is really in use (the output differs from the exact-fp32 path).'''
+    mode is really in use (the output differs from the three-plane path's).'''
     synth, _ = env
     g = np.load(os.path.join(golden_dir, fixture))
     m, out, loss = _step(env, synth.PUBLISHED, g, 'f16x2', deconv)
-    _, out32, _ = _step(env, synth.PUBLISHED, g, 'fp32', deconv)
+    _, out32, _ = _step(env, synth.PUBLISHED, g, 'fp32_3plane', deconv)
     e = rel(out.cpu(), torch.as_tensor(g['output']))
     e32 = rel(out32.cpu(), torch.as_tensor(g['output']))
-    print('output rel err vs the reference: f16x2 %.2e (fp32 path %.2e); loss %.6f ref %.6f' % (e, e32, loss, float(g['loss'][0])))
+    print('output rel err vs the reference: f16x2 %.2e (three-plane path %.2e); loss %.6f ref %.6f' % (e, e32, loss, float(g['loss'][0])))
     assert e < NORTH_STAR and e < 2e-5
     assert not torch.equal(out, out32)
     assert abs(loss - float(g['loss'][0])) < 1e-4 * abs(float(g['loss'][0]))

@@ -8,27 +8,27 @@ out=gpurun_out/prof_$tag
 mkdir -p $out/pmc
 python3 bench.py --steps 20 --warmup 5 > $out/bench_line.log 2> $out/bench_line.err
 python3 bench.py --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_bf16.log 2>&1
-python3 bench.py --dtype f32x3 --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_f32x3.log 2>&1
+python3 bench.py --dtype f32_3plane --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_f32_3plane.log 2>&1
 python3 bench.py --workload infer --steps 20 --warmup 5 > $out/bench_infer.log 2>&1
 python3 bench.py --workload radarnet --steps 10 --warmup 3 > $out/bench_radarnet.log 2>&1
 python3 bench.py --workload infer --dtype f32 --steps 10 --warmup 3 > $out/bench_infer_f32.log 2>&1
 python3 bench.py --workload radarnet --dtype f32 --steps 10 --warmup 3 > $out/bench_radarnet_f32.log 2>&1
 # eager launches under the profiler (a replayed hipGraph hides the per-launch events bench.py's roofline uses)
-rocprofv3 --kernel-trace --stats -d /tmp/trace_$tag -o r -- python3 bench.py --graph 0 --steps 5 --warmup 3 --preheat-s 0 --no-cpu-baseline --no-side-leg > $out/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/trace_$tag -o r -- python3 bench.py --graph 0 --steps 5 --warmup 3 --preheat-s 0 --no-cpu-baseline > $out/trace.log 2>&1
 grep "^{" $out/trace.log | tail -1 > $out/trace_bench_line.json
 python3 tools/trace_summary.py /tmp/trace_$tag 8 60 > $out/fp32_train_kernels.txt
 rocprofv3 --kernel-trace --stats -d /tmp/trace_b16_$tag -o r -- python3 bench.py --dtype bf16 --graph 0 --steps 5 --warmup 3 --preheat-s 0 --no-cpu-baseline > $out/trace_b16.log 2>&1
 python3 tools/trace_summary.py /tmp/trace_b16_$tag 8 60 > $out/bf16_train_kernels.txt
-rocprofv3 --kernel-trace --stats -d /tmp/trace_x3_$tag -o r -- python3 bench.py --dtype f32x3 --graph 0 --steps 5 --warmup 3 --preheat-s 0 --no-cpu-baseline > $out/trace_x3.log 2>&1
-python3 tools/trace_summary.py /tmp/trace_x3_$tag 8 60 > $out/f32x3_train_kernels.txt
+rocprofv3 --kernel-trace --stats -d /tmp/trace_3p_$tag -o r -- python3 bench.py --dtype f32_3plane --graph 0 --steps 5 --warmup 3 --preheat-s 0 --no-cpu-baseline > $out/trace_3p.log 2>&1
+python3 tools/trace_summary.py /tmp/trace_3p_$tag 8 60 > $out/f32_3plane_train_kernels.txt
 rocprofv3 --kernel-trace --stats -d /tmp/trace_inf_$tag -o r -- python3 bench.py --workload infer --graph 0 --steps 5 --warmup 3 --preheat-s 0 > $out/trace_inf.log 2>&1
 python3 tools/trace_summary.py /tmp/trace_inf_$tag 8 40 > $out/bf16_infer_kernels.txt
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   d=$out/pmc/$(echo $set | cut -d' ' -f1)
   # RCF_BATCH_PACK=0: the warm-up step and the counted step then issue the same dispatches (make_profile.py takes the second half)
-  RCF_BATCH_PACK=0 rocprofv3 --pmc $set --output-format csv -d $d -o b -- python3 bench.py --graph 0 --steps 1 --warmup 1 --preheat-s 0 --no-cpu-baseline --no-side-leg > $d.log 2>&1
+  RCF_BATCH_PACK=0 rocprofv3 --pmc $set --output-format csv -d $d -o b -- python3 bench.py --graph 0 --steps 1 --warmup 1 --preheat-s 0 --no-cpu-baseline > $d.log 2>&1
 done
 python3 tools/make_profile.py /tmp/trace_$tag $out/pmc $out/trace_bench_line.json $tag $head > $out/make_profile.log 2>&1
 mkdir -p $out/profiles && cp profiles/${tag}_* $out/profiles/ 2>/dev/null
 tail -2 $out/make_profile.log
-for f in bench_line bench_f32x3 bench_bf16 bench_infer bench_radarnet bench_infer_f32 bench_radarnet_f32; do tail -1 $out/$f.log | cut -c1-260; done
+for f in bench_line bench_f32_3plane bench_bf16 bench_infer bench_radarnet bench_infer_f32 bench_radarnet_f32; do tail -1 $out/$f.log | cut -c1-260; done
