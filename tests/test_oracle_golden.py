@@ -185,3 +185,25 @@ def test_t10_transposed_convolution_decoder(golden_dir):
     assert seen_deconv == 6          # deconv5 .. deconv0 all carry a ConvTranspose2d weight of shape [in, out, 3, 3]
     for key, buf in _named(m, 'b'):
         assert _rel(buf, g['buf:' + key]) < 1e-5, key
+
+
+def test_t11_two_replica_data_parallel_step(golden_dir):
+    '''Fixture T11 (tests/golden/make_golden_dp.py): the real reference's nn.DataParallel semantics for two replicas -- per-replica
+    BatchNorm statistics, ONE masked mean over the gathered batch, reduce-added gradients, replica 0's running statistics -- restated
+    with the oracle: forward per chunk, compute_loss on the concatenated batch, one backward.'''
+    g = np.load(os.path.join(golden_dir, 'T11_dp2_tiny_train.npz'))
+    n, h, w, k, dseed0, wseed = [int(v) for v in g['meta']]
+    m = FusionNetOracle(**synth.TINY)
+    synth.fill_state_dict_([m.encoder, m.decoder], wseed)
+    chunks = [synth.make_batch(n, h, w, k, seed=dseed0 + r) for r in range(2)]
+    m.train()
+    outs = [m.forward(b['image'], b['input_depth']) for b in chunks]
+    out = torch.cat(outs, 0)
+    loss, ls, ll = m.compute_loss(out, torch.cat([b['ground_truth'] for b in chunks], 0), torch.cat([b['lidar_map'] for b in chunks], 0), 2.0)
+    loss.backward()
+    assert _rel(out.detach(), g['output']) < 1e-5
+    np.testing.assert_allclose([float(loss.detach()), float(ls.detach()), float(ll.detach())], g['loss'], rtol=1e-5)
+    grads = dict(_named(m, 'p'))
+    for key in g['grad_keys'].tolist():
+        assert _rel(grads[key].grad, g['grad_' + key]) < 2e-4, key
+    assert abs(float(loss.detach()) - float(g['single_replica_loss'])) > 1e-4 * float(loss.detach())
