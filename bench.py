@@ -239,6 +239,18 @@ def _encoder_3x3(timer, ev_steps, dtype):
                     'partial products (the few stride-2 forward launches on the f32 MFMA are priced the same way)' % prod}
 
 
+def _pmc_value(kernel_name, field):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_bench.json')))
+    try:
+        pmc = json.load(open(cands[-1]))
+        if pmc.get('_meta', {}).get('csrc_sha') != _csrc_sha():
+            return None
+        return round(float(pmc[kernel_name][field]), 4)
+    except Exception:
+        return None
+
+
 def _expected_first_loss(key, world=1, w_lidar=2.0):
     '''The CPU oracle's loss of the first step.  Under data parallelism the step computes the reference's ONE masked mean over the
     gathered batch (src/fusionnet_main.py:385, src/fusionnet_model.py:245-253): rank r trains on data seed 1234 + r, so the expected
@@ -445,8 +457,10 @@ def run_rank(args):
         kname = KERNEL_NAMES.get(dom, str(dom))
         if dtype == 'f32':
             traffic, traffic_src = _pmc_traffic(kname)
+            mfma_busy = _pmc_value(kname, 'mfma_busy_fraction')
         else:   # the committed PMC passes profile the fp32 step
             traffic, traffic_src = None, 'the committed PMC passes (profiles/) were collected on the fp32 step'
+            mfma_busy = None
         if is_split:
             kname += ' (%s)' % TIER_TEXT[dtype]
         conv_ms = sum(r[2] for r in fam.values())
@@ -465,6 +479,7 @@ def run_rank(args):
             'events_from': ('%d eager steps after the timed region (a replayed hipGraph has no per-launch events)' % ev_steps) if use_graph
                            else 'HIP events around every launch of the family inside the timed steps',
             'traffic': traffic, 'traffic_source': traffic_src,
+            'mfma_busy_pmc': mfma_busy,   # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) of the family, same committed passes
             'algorithmic_gbytes_per_launch': round(abytes / cnt / 1e9, 4),
             'launches_per_step': cnt // ev_steps, 'avg_launch_ms': round(ms / cnt, 4),
             'algorithmic_gflop_per_launch': round(flops / cnt / 1e9, 3),

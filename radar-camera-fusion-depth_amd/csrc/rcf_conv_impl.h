@@ -589,7 +589,10 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
         const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int p = (tid >> 2) + i * 64;
+            int p = (tid >> 2) + i * 64;
+            // 512-pixel tiles sit at the 256-VGPR limit: keep the compiler from hoisting the 2 x NA tile-invariant (hy, hx) out of the
+            // tile loop (20 registers for a few integer instructions per tile)
+            if (C::MT > 2) asm volatile("" : "+v"(p));
             const int hy = p / C::HXP;
             const int hx = p - hy * C::HXP;
             const int ly = iy0 + hy, lx = ix0 + hx;
@@ -847,7 +850,11 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                     const int img = t / a.tiles_y;
                     const int oy0 = ty * C::TH;
                     const int ox0 = tx * C::PX;
+#ifdef RCF_DIAG_NO_STATS
+                    const bool want_stats = false;
+#else
                     const bool want_stats = !EPI && a.stats != nullptr;
+#endif
                     float ebias[C::NT];
                     if (EPI) {
 #pragma unroll
@@ -952,7 +959,11 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
 #pragma unroll
                                 for (int ni = 0; ni < C::NT; ++ni) {
                                     const int co = n0 + ni * 32 + li;
+#ifdef RCF_DIAG_NO_STORE
+                                    if (pok[j] && co < a.c_out && a.tiles_x < 0) {
+#else
                                     if (pok[j] && co < a.c_out) {
+#endif
                                         float v = acc[mi][ni][r0 + j];
                                         if (EPI) {
                                             v = rcf_lrelu(v + ebias[ni]);

@@ -361,6 +361,35 @@ def test_bench_expected_loss_fixture_is_the_oracle_on_the_bench_inputs(pkg):
     assert abs(got - rec['train_b2_224x384_p32']['first_step_loss']) < 1e-5 * abs(got)
 
 
+# kernels allowed to spill VGPRs / use private scratch: cold variants only (never above 0.2 ms per step in profiles/r03_*_kernels.txt)
+SPILL_ALLOW = [
+    r'conv1x1_b16_kernel<PwCfg<\d, [34]>',                      # bf16 1x1 with 48 / 64 input channels: HBM-bound, 33 us launches
+    r'conv_split_kernel<SplitCfg<3, [12], (16|32), 2, 1, 2>',   # bf16-OPERAND stride 2 on fp32 / bf16 tensors without the DMA path: unused by the shipped configurations
+    r'conv_wgrad_dma_kernel<WgCfg<',                            # f32-MFMA weight gradients: RCF_CONV_SPLIT=0 builds and the 1x1 / stride-2 leftovers
+    r'conv_fwd_kernel<FwdCfg<2, 2, 0, 1, 32, 32, 36, 2, 32, 2>',  # f32-MFMA 2x2 phases: RCF_CONV_SPLIT=0 only
+    r'conv_split_kernel<SplitCfg<3, 1, (16|32), 0, 3, 1>',      # three-plane 512-pixel tiles: the fp32_3plane side tier
+    r'conv_split_kernel<SplitCfg<3, 1, 32, 0, 1, 1>, false, StB16',   # bf16 tensors without the DMA path (RCF_B16_DMA=0)
+]
+
+
+def test_no_hot_kernel_spills_or_uses_scratch(pkg):
+    '''Every kernel of the built library, from the code objects themselves (tools/kernel_meta.py: metadata + disassembly; no GPU, no
+    recompilation): zero spilled VGPRs and not one scratch_load / scratch_store instruction, except an explicit allow-list of cold
+    variants.  (A kernel whose SGPRs spill into VGPR lanes reports a non-zero private segment size -- the frame slots of those
+    spills -- without touching scratch memory; counting the instructions tells that apart from a real spill.)  The default fp32
+    tier's kernels (two fp16 planes: SplitCfg<..., 2, .>, WsCfg<..., 2>), the bf16 DMA kernels and every weight-gradient split kernel
+    must be clean.'''
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import kernel_meta
+    ks = kernel_meta.kernels(count_scratch_ops=True)
+    assert len(ks) > 300
+    dirty = lambda k: k['vgpr_spill'] > 0 or (k['scratch_ops'] or 0) > 0
+    bad = [k for k in ks if dirty(k) and not any(re.search(p, k['name']) for p in SPILL_ALLOW)]
+    assert not bad, '\n'.join('%s: %d spilled VGPRs, %d scratch instructions' % (k['name'], k['vgpr_spill'], k['scratch_ops']) for k in bad)
+    hot = [k for k in ks if re.search(r'SplitCfg<\d, \d, \d+, \d, 2, \d>|WsCfg<\d, \d, \d, \d+, \d>|conv_b16_kernel', k['name'])]
+    assert len(hot) > 60 and not any(dirty(k) for k in hot)
+
+
 def test_generated_code_of_the_small_units_is_clean():
     '''tools/isa_lint.py (no GPU: hipcc -S for gfx950) on the elementwise / format / transform units: no flat accesses, no GOT loads,
     no spills, no store sitting behind an s_waitcnt vmcnt(0) -- the four code-generation patterns that cost the convolution

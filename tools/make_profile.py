@@ -15,9 +15,9 @@ tag = sys.argv[4] if len(sys.argv) > 4 else 'r01'
 prof = os.path.join(ROOT, 'profiles')
 
 FAMILIES = [   # (bench.py KERNEL_NAMES entry, kernel-name prefix)
-    ('conv_split_kernel 3x3 s1 (fp32 via 3-plane bf16 split)', 'conv_split_kernel<SplitCfg<3,'),
-    ('conv_split_kernel 2x2 phases (fp32 via 3-plane bf16 split)', 'conv_split_kernel<SplitCfg<2,'),
-    ('conv_wgrad_split_kernel 3x3 s1 (fp32 via 3-plane bf16 split)', 'conv_wgrad_split_kernel<'),
+    ('conv_split_kernel 3x3 s1', 'conv_split_kernel<SplitCfg<3,'),
+    ('conv_split_kernel 2x2 phases', 'conv_split_kernel<SplitCfg<2,'),
+    ('conv_wgrad_split_kernel', 'conv_wgrad_split_kernel<'),
     ('conv_fwd_kernel 3x3 s1', 'conv_fwd_kernel<FwdCfg<3, 3, 0, 1'),
 ]
 
@@ -111,6 +111,7 @@ with open(os.path.join(prof, tag + '_summary.md'), 'w') as f:
     f.write('Total kernel time %.1f ms = %.1f ms/step (bench wall clock without the profiler: see %s_bench_line.json).\n\n'
             % (tot / 1e3, tot / 1e3 / nstep, tag))
     rl = line.get('roofline', {})
+    f.write('Arithmetic of the fp32 metric (bench.py `config.arithmetic`): %s\n\n' % line.get('config', {}).get('arithmetic', '-'))
     f.write('Dominant kernel family for `roofline`: `%s`: %.4f ms per launch from events inside bench.py, %.1f algorithmic fp32 TFLOP/s.\n\n'
             % (rl.get('kernel'), rl.get('avg_launch_ms', 0), rl.get('algorithmic_fp32_tflops', rl.get('achieved', 0))))
     f.write('PMC passes (`%s_pmc_bench.json`):\n\n| family | launches | MFMA-busy fraction | HBM GB per launch (FETCH x2 + WRITE) |\n|---|---|---|---|\n' % tag)
