@@ -194,6 +194,35 @@ def test_config3_bf16_train_step_900x1600_against_fp32_oracle(env):
     assert cos > 0.9
 
 
+def test_config3_bf16_batch8_900x1600_step_is_the_benchmarked_step(env):
+    '''One GPU's share of BASELINE.json configs[3] exactly as bench.py --dtype bf16 runs it: batch 8, 900x1600, bf16 tensors, train-mode
+    BatchNorm over the 8 images, outlier removal, masked L1.  The first-step loss against the CPU oracle's recorded value
+    (tests/golden/bench_expected.json), the output against the fp32 HIP output of the same step (itself pinned to the oracle by
+    test_config1_*), backward + Adam finite.'''
+    from rcf_amd.net_utils import OutlierRemoval
+    synth, train = env
+    rec = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_expected.json')))['train_b8_900x1600_p64']
+    b = {k: v.cuda() for k, v in synth.make_batch(8, 900, 1600, 64, seed=1234).items()}
+    outl = OutlierRemoval(7, 1.5)
+    outs = {}
+    for dtype in ('fp32', 'bf16'):
+        m = _build(env, 1234, dtype)
+        opt = train.make_optimizer(m, lr=1e-3)
+        m.train()
+        loss, _, out = train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'], outlier_removal=outl)
+        torch.cuda.synchronize()
+        outs[dtype] = (out.detach().float().cpu(), float(loss.detach()))
+        assert bool(torch.isfinite(m._grad_arena[:m._n_used]).all()) and bool(torch.isfinite(m._param_arena).all())
+        del m, opt
+        torch.cuda.empty_cache()
+    e = _rel(outs['bf16'][0], outs['fp32'][0])
+    le = abs(outs['bf16'][1] - rec['first_step_loss']) / rec['first_step_loss']
+    print('bf16 batch-8 900x1600 step: first loss %.5f vs oracle %.5f (rel %.2e, bar %.0e); output vs fp32 HIP rel %.2e (bar %.0e)'
+          % (outs['bf16'][1], rec['first_step_loss'], le, BF16_LOSS_BAR, e, BF16_OUT_BAR))
+    assert abs(outs['fp32'][1] - rec['first_step_loss']) < BAR * rec['first_step_loss']
+    assert le < BF16_LOSS_BAR and e < BF16_OUT_BAR
+
+
 # ------------------------------------------------------------------------------------------------------------ configs[4]
 def test_config4_bf16_batch32_hipgraph_inference_900x1600(env):
     '''Batch 32 at 900x1600, eval-mode BatchNorm folded, bf16: the hipGraph replay is bitwise the eager forward, a second replay on
@@ -224,13 +253,13 @@ def test_config4_bf16_batch32_hipgraph_inference_900x1600(env):
 # ------------------------------------------------------------------------------------------------------------ configs[2]
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_config2_radarnet_900x288_patches_against_oracle(env, dtype):
-    '''RadarNet stage 1 at the shipped geometry (900x1888 edge-padded images, 900x288 crops): 4 images x 4 radar points, training
-    step; logits and loss against the CPU restatement (pinned to the reference by fixtures T5/T6), gradients finite; bf16 against
-    the same fp32 oracle at the bf16 bar.'''
+    '''RadarNet stage 1 at the workload `bench.py --workload radarnet` times (BASELINE.json configs[2]: 16 images x 4 radar points =
+    64 crops of 900x288 from 900x1888 edge-padded images, the bench's own seeds), training step; logits and loss against the CPU
+    restatement (pinned to the reference by fixtures T5/T6), gradients finite; bf16 against the same fp32 oracle at the bf16 bar.'''
     from oracle.radarnet_oracle import RadarNetOracle
     from rcf_amd import radarnet_model
     synth, _ = env
-    cb = synth.make_radarnet_batch(17, n=4, k=4, h=900, w=1888, patch_w=288)
+    cb = synth.make_radarnet_batch(7, n=16, k=4, h=900, w=1888, patch_w=288)
     m = radarnet_model.RadarNetModel(device=torch.device('cuda'), **synth.RADARNET_PUBLISHED)
     m.compute_dtype = dtype
     synth.fill_state_dict_([m.encoder, m.decoder], 41)
@@ -241,7 +270,7 @@ def test_config2_radarnet_900x288_patches_against_oracle(env, dtype):
     loss.backward()
     torch.cuda.synchronize()
     g = m._grad_arena[:m._n_used]
-    assert tuple(logits.shape) == (16, 1, 900, 288)
+    assert tuple(logits.shape) == (64, 1, 900, 288)
     assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
     if 'config2' not in _ORACLE_CACHE:
         ora = RadarNetOracle(**synth.RADARNET_PUBLISHED)
@@ -252,7 +281,7 @@ def test_config2_radarnet_900x288_patches_against_oracle(env, dtype):
             _ORACLE_CACHE['config2'] = (ol, float(ora.compute_loss(ol, cb['ground_truth'], cb['validity_map'], 2.0)))
     ol, oloss = _ORACLE_CACHE['config2']
     e = _rel(logits, ol)
-    print('RadarNet %s 4x4 crops of 900x288: logits rel %.2e, loss %.6f vs oracle %.6f' % (dtype, e, float(loss), oloss))
+    print('RadarNet %s 16 images x 4 crops of 900x288: logits rel %.2e, loss %.6f vs oracle %.6f' % (dtype, e, float(loss), oloss))
     if dtype == 'fp32':
         assert e < BAR and abs(float(loss) - oloss) < BAR * abs(oloss)
     else:

@@ -938,3 +938,61 @@ def test_stride2_forward_on_the_three_plane_split_kernel(ops, c1, co, n, h, w, m
         torch.cuda.synchronize()
         errs[flag] = float(((nchw(out).double() - ref).abs() / mag).max())
     assert errs['1'] < 1.5 * errs['0'] + 1e-8 and errs['1'] < 1e-6, errs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,h,w,c', [(8, 900, 1600, 32), (8, 450, 800, 64)])
+def test_batchnorm_reductions_at_batch8_full_resolution(ops, n, h, w, c):
+    '''The cross-image reductions train-mode BatchNorm needs, at the benchmark's own extent (8 x 900 x 1600 x 32: 369 M values, 64-bit
+    offsets): the forward statistics a convolution's epilogue accumulates (sum z, sum z^2 per channel, fp64) and the backward sums
+    (sum g, sum g * xhat) of rcf_bn_act_bwd_reduce, against fp64 torch reductions of the very tensors the kernels read -- the
+    full-batch counterpart of the small-size checks above (the batch-8 eval-mode test in test_configs_gpu.py covers everything that
+    does not reduce over the batch).'''
+    import torch
+    from rcf_amd._lib import RCF_ACT_LEAKY_RELU
+    g = torch.Generator(device='cuda').manual_seed(11)
+    x = torch.rand(n, h, w, c, device='cuda', generator=g) * 2 - 1
+    wt = (torch.rand(c, c, 3, 3, device='cuda', generator=g) * 2 - 1) / (3.0 * c ** 0.5)
+    d = ops.make_fwd_desc(n, h, w, c, 0, c, 3, 1, h, w, 0)
+    info = ops.conv_query(d)
+    packed = torch.empty(info.packed_weight_floats, device='cuda')
+    ops.conv_pack(d, wt, packed)
+    z = torch.empty(n, h, w, c, device='cuda')
+    part = torch.empty(info.n_partials, 2, c, device='cuda', dtype=torch.float64)
+    ops.conv_fwd(d, x, None, packed, z, part)
+    st = part.sum(0)
+    want1 = z.view(-1, c).double().sum(0)
+    want2 = (z.view(-1, c).double() ** 2).sum(0)
+    assert float((st[0] - want1).abs().max()) <= 1e-9 * float(want2.sqrt().max() * (n * h * w) ** 0.5) + 1e-6
+    assert float(((st[1] - want2) / want2).abs().max()) < 1e-12
+    # a few output values of the last image against the fp64 convolution of its neighbourhood (the 64-bit addressing of image 7)
+    ref = torch.nn.functional.conv2d(x[n - 1:, h - 8:, :64].permute(0, 3, 1, 2).double(), wt.double(), padding=1)[:, :, 1:-1, 1:-1]
+    got = z[n - 1:, h - 7:h - 1, 1:63].permute(0, 3, 1, 2).double()
+    assert float((got - ref[:, :, :6]).abs().max()) < 1e-5
+    # BatchNorm coefficients of these statistics, then the backward sums
+    n_pix = n * h * w
+    mean = want1 / n_pix
+    var = want2 / n_pix - mean ** 2
+    invstd = (var + 1e-5).rsqrt()
+    gamma = torch.rand(c, device='cuda', generator=g, dtype=torch.float64) + 0.5
+    beta = torch.rand(c, device='cuda', generator=g, dtype=torch.float64) - 0.5
+    coef = torch.stack([gamma * invstd, beta - mean * gamma * invstd, mean, invstd]).float().contiguous()
+    del x
+    dout = (torch.rand(n, h, w, c, device='cuda', generator=g) * 2 - 1) * 1e-3
+    nb = ops.ew_blocks(n_pix, c)
+    bpart = torch.empty(nb, 2, c, device='cuda', dtype=torch.float64)
+    ops.bn_act_bwd_reduce(dout, z, coef, None, bpart, n_pix, c, RCF_ACT_LEAKY_RELU, False)
+    got_b = bpart.sum(0)
+    s_g = torch.zeros(c, device='cuda', dtype=torch.float64)
+    s_gx = torch.zeros(c, device='cuda', dtype=torch.float64)
+    cf = coef.double()
+    for i in range(n):          # image by image: the fp64 temporaries of one image are 1.5 GB
+        zz, dd = z[i].view(-1, c), dout[i].view(-1, c)
+        y = zz.double() * cf[0] + cf[1]                   # the kernel's v_fma rounds once: its sign is the exact sign
+        gg = (dd * torch.where(y > 0, 1.0, 0.2).float()).double()     # g is an fp32 product in the kernel, summed in fp64
+        xh = ((zz - coef[2]) * coef[3]).double()         # xhat as the kernel forms it (fp32), summed in fp64
+        s_g += gg.sum(0)
+        s_gx += (gg * xh).sum(0)
+    scale = float(dout.double().abs().sum() / c)
+    assert float((got_b[0] - s_g).abs().max()) < 1e-9 * scale
+    assert float((got_b[1] - s_gx).abs().max()) < 1e-9 * scale * 4
