@@ -42,13 +42,19 @@ __host__ __device__ inline RcfScale rcf_scale_of_amax(float amax) {
     c.u = (unsigned)(254 - se) << 23; r.inv = c.f;
     return r;
 }
-// max|x| of a tensor, accumulated by the kernels that write it: wave maximum by shuffles, then ONE atomic per wave on the bit pattern
-// (non-negative floats order like their bit patterns; the slot is zeroed by the host before the producers run) -- skipped when the
-// slot already holds a larger value, which is the common case after the first few waves.
+// max|x| of a tensor, accumulated by the kernels that write it: wave maximum by shuffles, block maximum through LDS, then at most ONE
+// atomic per block on the bit pattern (non-negative floats order like their bit patterns; the slot is zeroed by the host before the
+// producers run) -- skipped when the slot already holds a value at least as large.  Same-address atomics retire one per ~4 ns: one
+// per WAVE (8192 per launch) cost the BatchNorm passes ~30 us per launch, measured in round 3.  All threads of the block must call it.
 __device__ __forceinline__ void rcf_amax_commit(float m, float* amax_slot) {
+    __shared__ float rcf_amax_lds[16];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) rcf_amax_lds[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w) m = fmaxf(m, rcf_amax_lds[w]);
         const unsigned mb = __float_as_uint(m);
         unsigned* slot = reinterpret_cast<unsigned*>(amax_slot);
         if (mb > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, mb);

@@ -449,7 +449,9 @@ int launch_dma(const ConvArgs& a, int ntile_n, hipStream_t st) {
 // wave.  No LDS, no barrier in the main loop.  (The f32-MFMA implicit-GEMM kernel ran these layers at 13-40 TFLOP/s = ~1.2 TB/s.)
 template <int KST_, int NT_>
 struct PwCfg {
-    static constexpr int KST = KST_, NT = NT_, MT = NT_ <= 2 ? 4 : 2;   // k-steps of 16 input channels, 32-co tiles, 32-pixel blocks per trip
+    // k-steps of 16 input channels, 32-co tiles, 32-pixel blocks per trip (one block for 96 / 128 output channels: with two, the
+    // accumulators next to the register-resident weight matrix spilled 60-102 VGPRs)
+    static constexpr int KST = KST_, NT = NT_, MT = NT_ <= 2 ? 4 : 1;
 };
 
 template <class C>
@@ -609,7 +611,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_b16_kernel(ConvArgs a) {
 
 // grid of the pointwise kernel = number of BatchNorm partial rows it writes
 inline int pw_grid(long long npix, int nt) {
-    const int per_trip = 32 * 4 * (nt <= 2 ? 4 : 2);                   // 4 waves x MT blocks of 32 pixels per workgroup trip
+    const int per_trip = 32 * 4 * (nt <= 2 ? 4 : 1);                   // 4 waves x MT blocks of 32 pixels per workgroup trip
     const long long trips = (npix + per_trip - 1) / per_trip;
     long long g = 2 * (long long)num_cus() * 2;                        // two workgroups per CU, two trips' worth of slack
     if (g > trips) g = trips;

@@ -500,13 +500,8 @@ struct SplitCfg {
     static constexpr int COEF_BYTES = 2 * COEF_MAX_C * 4;
     static constexpr int LDS_BYTES = A_BYTES + 2 * B_PIECE_BYTES + COEF_BYTES;
     static constexpr int WCHUNK_BYTES = KSY * B_PIECE_BYTES;   // one chunk of pre-split packed weights
-    // waves per SIMD the kernel is compiled for (= resident workgroups per CU): three for the two-plane 256-pixel tiles when LDS allows
-    // (<= 168 VGPRs), else two
-#ifdef RCF_SPLIT_WPE3
-    static constexpr int WPE = (NPL_ == 2 && MT == 2 && LSTEP_ == 1 && 3 * LDS_BYTES <= 160 * 1024) ? 3 : 2;
-#else
-    static constexpr int WPE = 2;
-#endif
+    // (three resident workgroups per CU fit the LDS of the two-plane 256-pixel tiles, but not the registers: compiled for 168 VGPRs the
+    // 64-co kernels spill 54-136 of them -- measured in round 3, not shipped)
     static_assert(2 * LDS_BYTES <= 160 * 1024 || (LSTEP == 2 && LDS_BYTES <= 160 * 1024), "two workgroups per CU (stride 2, three planes: one)");
 };
 
@@ -532,7 +527,7 @@ __device__ unsigned long long rcf_phase_cycles[8];
 // EPI: inference epilogue -- BatchNorm folded into the weights (scale) and a per-channel bias, LeakyReLU, and the residual tail of
 // ResNetBlock (lrelu(y + res)) applied to the accumulators before the only store; no statistics.
 template <class C, bool EPI = false, class SI = SAct, class SO = SAct>
-__global__ void __launch_bounds__(256, C::WPE) conv_split_kernel(ConvArgs a) {
+__global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
     static_assert(!SI::B16 || C::NPL == 1, "bf16 tensors go with bf16 operands");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char* As = smem_b;

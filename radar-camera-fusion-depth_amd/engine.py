@@ -186,6 +186,10 @@ class Engine(object):
         self._amax_used = 0
         self._wamax_cache = {}
         self._scope = None
+        # inference with frozen weights (FusionNetModel.capture_inference(fold_once=True)): a dict that keeps every weight transform of
+        # the eval forward (BatchNorm coefficients, folded / packed / phase weights) from the first forward on, so that later forwards
+        # -- the recorded one -- launch none of them.  None: transforms are recomputed on every forward (parameters may change).
+        self.frozen = None
 
     # ------------------------------------------------------------------ helpers
     def _new(self, shape, ref):
@@ -257,6 +261,15 @@ class Engine(object):
             desc.precision = RCF_PREC_FP32
         return desc
 
+    def _frozen_get(self, key, make):
+        '''make() once per key while self.frozen is set (inference with frozen weights), every time otherwise.'''
+        if self.frozen is None or self.tape is not None:
+            return make()
+        hit = self.frozen.get(key)
+        if hit is None:
+            hit = self.frozen[key] = make()
+        return hit
+
     # ---- weight transforms (through the step's WeightPlan when it is active: training, tape on)
     def _plan_on(self):
         return self.plan.active
@@ -293,11 +306,18 @@ class Engine(object):
             if e is not None:
                 plan.last_mismatch = (plan.pos - 1, 'pack', 'descriptor' if e['key'] != key else 'source pointer')
             plan.dirty = True
+        if self.frozen is not None and self.tape is None:
+            fkey = ('pack', key, tuple(w.data_ptr() for w in ws))
+            hit = self.frozen.get(fkey)
+            if hit is not None:
+                return hit[0]
         nf = ops.conv_query(desc).packed_weight_floats
         out = self._newf((len(ws) * nf,), like)
         dsts = [out[k * nf:(k + 1) * nf] for k in range(len(ws))]
         for w, dst in zip(ws, dsts):
             ops.conv_pack(desc, w, dst, amax)
+        if self.frozen is not None and self.tape is None:
+            self.frozen[fkey] = (out, list(ws))   # the sources stay alive with the buffer packed from them
         if self._plan_on() and not plan.dirty and plan.state == 'record':
             plan.entries.append({'kind': 'pack', 'desc': desc, 'key': key, 'srcs': list(ws), 'ptrs': [w.data_ptr() for w in ws],
                                  'dsts': dsts, 'out': out, 'amax': amax})
@@ -380,8 +400,11 @@ class Engine(object):
         fused = fold is not None and info.fwd_act and k1 is None and k2 is None
         scales = None
         if fused:
-            packed = self._newf((info.packed_weight_floats,), t1)
-            ops.conv_pack(desc, ops.scale_channels(weight.detach(), fold[0][0]), packed)
+            def fold_pack():
+                buf = self._newf((info.packed_weight_floats,), t1)
+                ops.conv_pack(desc, ops.scale_channels(weight.detach(), fold[0][0]), buf)
+                return buf
+            packed = self._frozen_get(('fold', id(layer), bytes(desc)), fold_pack)
         elif self._two_plane(info.kernel_id):
             wmax = self._w_amax(weight.detach())
             packed = self._pack(desc, weight.detach(), t1, wmax)
@@ -447,7 +470,8 @@ class Engine(object):
                 qi = ops.conv_query(d)
                 n_part = qi.n_partials
                 fused = fold is not None and bool(qi.fwd_act) and fold[1] is None
-                wp = ops.phase_weights(ops.scale_channels(weight.detach(), fold[0][0]), RCF_PHASE_UP2X_FWD) if fused else \
+                wp = self._frozen_get(('fold-phase', id(layer)), lambda: ops.phase_weights(ops.scale_channels(weight.detach(), fold[0][0]),
+                                                                                              RCF_PHASE_UP2X_FWD)) if fused else \
                     self._phase_w(weight.detach(), RCF_PHASE_UP2X_FWD)
                 if self._two_plane(qi.kernel_id):
                     wmax = self._w_amax(wp)   # one maximum for the four phases' pre-summed weights
@@ -483,9 +507,12 @@ class Engine(object):
         d = ops.make_stem_s2d_desc(n, h, w, co)
         info = ops.conv_query(d)
         fused = fold is not None and bool(info.fwd_act) and fold[1] is None
-        w7 = ops.scale_channels(weight.detach(), fold[0][0]) if fused else weight.detach()
-        packed = self._newf((info.packed_weight_floats,), x.s2d)
-        ops.conv_pack(d, ops.stem_weights_s2d(w7), packed)
+        def stem_pack():
+            w7 = ops.scale_channels(weight.detach(), fold[0][0]) if fused else weight.detach()
+            buf = self._newf((info.packed_weight_floats,), x.s2d)
+            ops.conv_pack(d, ops.stem_weights_s2d(w7), buf)
+            return buf
+        packed = self._frozen_get(('stem', id(layer), bool(fused)), stem_pack)
         z = torch.empty((n, d.h_out, d.w_out, co), dtype=torch.bfloat16, device=x.s2d.device)
         partials = torch.empty((info.n_partials, 2, co), dtype=torch.float64, device=z.device) if want_stats else None
         if fused:
@@ -715,11 +742,14 @@ class Engine(object):
 
     def _bn_coef_eval(self, layer, ref):
         bn = layer.batch_norm
-        c = bn.weight.shape[0]
-        coef = self._newf((4, c), ref)
-        ops.bn_finalize(None, 0, c, 1, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS,
-                        False, coef)
-        return coef
+
+        def make():
+            c = bn.weight.shape[0]
+            coef = self._newf((4, c), ref)
+            ops.bn_finalize(None, 0, c, 1, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS,
+                            False, coef)
+            return coef
+        return self._frozen_get(('coef', id(layer)), make)
 
     # ------------------------------------------------------------------ layer ops
     def conv_bn_act(self, layer, x, x2=None, up_hw=None, res=None, feeds_head=False):

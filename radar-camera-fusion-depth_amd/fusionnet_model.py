@@ -459,29 +459,38 @@ class FusionNetModel(object):
             from .parallel import GradientBuckets
             self._dp = GradientBuckets(self)
 
-    def capture_inference(self, image, input_depth, warmup=2):
+    def capture_inference(self, image, input_depth, warmup=2, fold_once=False):
         '''
         Records one eval-mode forward (running-statistics BatchNorm, no tape) for inputs of this shape into a hipGraph and returns
         a callable `run(image, input_depth) -> N x 1 x H x W depth`: each call copies the inputs into the graph's static buffers
         and replays the ~370 kernel launches with one hipGraphLaunch.  The reference's inference loop (src/fusionnet_main.py:
-        708-731, :814) calls model.forward per sample; `run` stands in for that call.  Weight packing is part of the recorded
-        work, so a replay sees the parameters' current values (restore_model after capture is fine); the output tensor is reused
-        by the next replay -- clone it to keep it.
+        708-731, :814) calls model.forward per sample; `run` stands in for that call.  By default weight folding and packing are part
+        of the recorded work, so a replay sees the parameters' current values (restore_model after capture is fine).
+        fold_once=True freezes the weights at capture time instead: BatchNorm folding, phase weights and packing (~190 small
+        launches, ~1.5 of 23 ms at batch 32) run once before the recording and the graph holds the convolutions only -- the
+        deployment form (the reference's run() loads a checkpoint once, src/fusionnet_main.py:694-706); parameters changed
+        afterwards need a new capture.  The output tensor is reused by the next replay -- clone it to keep it.
         '''
         if self._training:
             raise _lib.RcfError('capture_inference records the eval-mode forward: call eval() first')
         if not image.is_cuda:
             raise _lib.RcfError('capture_inference needs CUDA(HIP) tensors (got %s)' % image.device)
         static_image, static_depth = image.detach().clone(), input_depth.detach().clone()
-        side = torch.cuda.Stream(device=image.device)
-        side.wait_stream(torch.cuda.current_stream(image.device))
-        with torch.no_grad(), torch.cuda.stream(side):   # lazy one-time state (function attributes, zero page) before recording
-            for _ in range(max(1, warmup)):
-                self.forward(static_image, static_depth)
-        torch.cuda.current_stream(image.device).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph):
-            static_out = self.forward(static_image, static_depth)
+        frozen = {} if fold_once else None
+        self._engine.frozen = frozen
+        try:
+            side = torch.cuda.Stream(device=image.device)
+            side.wait_stream(torch.cuda.current_stream(image.device))
+            with torch.no_grad(), torch.cuda.stream(side):   # lazy one-time state (function attributes, zero page; with fold_once
+                for _ in range(max(1, warmup)):              # also every weight transform) before recording
+                    self.forward(static_image, static_depth)
+            torch.cuda.current_stream(image.device).wait_stream(side)
+            torch.cuda.synchronize(image.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(graph):
+                static_out = self.forward(static_image, static_depth)
+        finally:
+            self._engine.frozen = None
 
         def run(image, input_depth):
             if image.shape != static_image.shape or input_depth.shape != static_depth.shape:
@@ -492,6 +501,7 @@ class FusionNetModel(object):
             graph.replay()
             return static_out
         run.graph = graph
+        run.frozen_weights = frozen     # fold_once: the folded / packed buffers the recorded launches read stay alive with the graph
         return run
 
     def capture_training_step(self, optimizer, image, input_depth, ground_truth, lidar_map, w_lidar_loss=2.0, outlier_removal=None,

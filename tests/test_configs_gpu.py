@@ -13,7 +13,7 @@ with eval-mode BatchNorm every sample is independent, so the batch-8 gradient is
 batch-8 output rows are the batch-1 outputs (the batch-1 path is pinned to the oracle in tests/test_hip_model.py).
 
 Bars: 1e-3 relative for fp32 (north_star).  bf16 (bf16 tensors in HBM, bf16 MFMA operands, fp32 accumulate) has no bar in
-north_star; the bars below are what the arithmetic allows (one bf16 rounding, 2^-9, per layer over ~40 layers) and are printed
+north_star; the bars below are 1.3 x what round 3 measured (the kernels are deterministic and the seeds fixed) and are printed
 next to the measured error.
 '''
 
@@ -31,8 +31,12 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BAR = 1e-3
-BF16_OUT_BAR = 6e-2     # max |d - d_ref| / max |d_ref| of the output depth
-BF16_LOSS_BAR = 2e-2
+# bf16 bars = 1.3 x the value measured in round 3 (deterministic kernels, fixed seeds), printed next to the measurement:
+BF16_OUT_BAR = 3.6e-2      # FusionNet training output depth, max |d - d_ref| / max |d_ref|   (measured 2.3e-2 / 2.74e-2)
+BF16_INFER_BAR = 1.1e-2    # eval-mode (running statistics) output                            (measured 8.2e-3)
+BF16_LOGIT_BAR = 5.3e-2    # RadarNet logits                                                  (measured 4.08e-2)
+BF16_LOSS_BAR = 3e-5       # losses are means over ~1e5..1e7 pixels                           (measured 7.5e-7 .. 1.8e-5)
+BF16_COS_BAR = 0.9988      # gradient cosine against the fp32 HIP gradient                    (measured 0.9991)
 _ORACLE_CACHE = {}
 
 
@@ -191,7 +195,7 @@ def test_config3_bf16_train_step_900x1600_against_fp32_oracle(env):
           'gradient cosine bf16 vs fp32 %.4f' % (e16, BF16_OUT_BAR, mae16, res['bf16'][1], ref_loss, e32, cos))
     assert e32 < BAR and abs(res['fp32'][1] - ref_loss) < BAR * abs(ref_loss)
     assert e16 < BF16_OUT_BAR and abs(res['bf16'][1] - ref_loss) < BF16_LOSS_BAR * abs(ref_loss)
-    assert cos > 0.9
+    assert cos > BF16_COS_BAR
 
 
 def test_config3_bf16_batch8_900x1600_step_is_the_benchmarked_step(env):
@@ -240,14 +244,23 @@ def test_config4_bf16_batch32_hipgraph_inference_900x1600(env):
         perm = torch.arange(31, -1, -1, device='cuda')
         rep2 = run(img[perm].contiguous(), dep[perm].contiguous()).clone()
         assert torch.equal(rep2, eager[perm])          # samples are independent in eval mode: replay on permuted inputs
+        # the deployment form bench.py times: weights folded / packed once before the recording (fold_once) -- same bits, fewer nodes
+        run1 = m.capture_inference(img, dep, fold_once=True)
+        assert torch.equal(run1(img, dep), eager) and torch.equal(run1(img[perm].contiguous(), dep[perm].contiguous()), eager[perm])
+        assert len(run1.frozen_weights) > 100
+        with torch.no_grad():                          # frozen at capture time: a later parameter change reaches `run`, not `run1`
+            m.decoder.output0.conv.weight.mul_(1.5)
+        assert not torch.equal(run(img, dep), eager) and torch.equal(run1(img, dep), eager)
+        with torch.no_grad():
+            m.decoder.output0.conv.weight.div_(1.5)
     o = _oracle(env, 3)
     o.eval()
     with torch.no_grad():
         ref = o.forward(cb['image'][5:6], cb['input_depth'][5:6])
     e = _rel(eager[5:6], ref)
-    print('batch-32 bf16 hipGraph inference: sample 5 vs fp32 oracle rel %.2e (bar %.0e), MAE %.2f mm'
-          % (e, BF16_OUT_BAR, float((eager[5:6].cpu() - ref).abs().mean()) * 1000.0))
-    assert e < BF16_OUT_BAR
+    print('batch-32 bf16 hipGraph inference: sample 5 vs fp32 oracle rel %.2e (bar %.1e), MAE %.2f mm'
+          % (e, BF16_INFER_BAR, float((eager[5:6].cpu() - ref).abs().mean()) * 1000.0))
+    assert e < BF16_INFER_BAR
 
 
 # ------------------------------------------------------------------------------------------------------------ configs[2]
@@ -285,7 +298,7 @@ def test_config2_radarnet_900x288_patches_against_oracle(env, dtype):
     if dtype == 'fp32':
         assert e < BAR and abs(float(loss) - oloss) < BAR * abs(oloss)
     else:
-        assert e < BF16_OUT_BAR and abs(float(loss) - oloss) < BF16_LOSS_BAR * abs(oloss)
+        assert e < BF16_LOGIT_BAR and abs(float(loss) - oloss) < BF16_LOSS_BAR * abs(oloss)
 
 
 def test_radarnet_frame_with_more_than_64_points(env):

@@ -363,7 +363,7 @@ def test_bench_expected_loss_fixture_is_the_oracle_on_the_bench_inputs(pkg):
 
 # kernels allowed to spill VGPRs / use private scratch: cold variants only (never above 0.2 ms per step in profiles/r03_*_kernels.txt)
 SPILL_ALLOW = [
-    r'conv1x1_b16_kernel<PwCfg<\d, [34]>',                      # bf16 1x1 with 48 / 64 input channels: HBM-bound, 33 us launches
+    r'conv1x1_b16_kernel<PwCfg<[24], 4>',                       # bf16 1x1 onto 128 output channels (2 / 34 VGPRs; was 77 / 102): HBM-bound, ~30 us launches
     r'conv_split_kernel<SplitCfg<3, [12], (16|32), 2, 1, 2>',   # bf16-OPERAND stride 2 on fp32 / bf16 tensors without the DMA path: unused by the shipped configurations
     r'conv_wgrad_dma_kernel<WgCfg<',                            # f32-MFMA weight gradients: RCF_CONV_SPLIT=0 builds and the 1x1 / stride-2 leftovers
     r'conv_fwd_kernel<FwdCfg<2, 2, 0, 1, 32, 32, 36, 2, 32, 2>',  # f32-MFMA 2x2 phases: RCF_CONV_SPLIT=0 only
