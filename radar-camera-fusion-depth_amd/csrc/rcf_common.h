@@ -60,6 +60,21 @@ __device__ __forceinline__ void rcf_amax_commit(float m, float* amax_slot) {
         if (mb > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, mb);
     }
 }
+// Early commit, from wave 0 of a block of a LONG stream only (call it once, after the first loop trip, where all 64 lanes of the wave
+// are still converged): the running maximum of a stationary tensor is within a few per cent of the final one after one trip, so the
+// slot is near its final value long before the blocks reach rcf_amax_commit -- whose guard then skips almost every atomic of the tail
+// (2048 same-address atomics at the end of a launch cost ~8 us; issued mid-stream they retire behind the memory traffic).
+__device__ __forceinline__ void rcf_amax_early(float m, float* amax_slot) {
+    if (threadIdx.x < 64) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (threadIdx.x == 0) {
+            const unsigned mb = __float_as_uint(m);
+            unsigned* slot = reinterpret_cast<unsigned*>(amax_slot);
+            if (mb > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, mb);
+        }
+    }
+}
 __device__ __forceinline__ float rcf_amax4(float m, f32x4 v) {
     return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }

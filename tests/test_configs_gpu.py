@@ -248,11 +248,13 @@ def test_config4_bf16_batch32_hipgraph_inference_900x1600(env):
         run1 = m.capture_inference(img, dep, fold_once=True)
         assert torch.equal(run1(img, dep), eager) and torch.equal(run1(img[perm].contiguous(), dep[perm].contiguous()), eager[perm])
         assert len(run1.frozen_weights) > 100
+        wconv = m.decoder.deconv1.conv.conv.weight      # a convolution weight (folded with its BatchNorm and packed)
+        keep = wconv.detach().clone()
         with torch.no_grad():                          # frozen at capture time: a later parameter change reaches `run`, not `run1`
-            m.decoder.output0.conv.weight.mul_(1.5)
+            wconv.mul_(1.5)
         assert not torch.equal(run(img, dep), eager) and torch.equal(run1(img, dep), eager)
         with torch.no_grad():
-            m.decoder.output0.conv.weight.div_(1.5)
+            wconv.copy_(keep)
     o = _oracle(env, 3)
     o.eval()
     with torch.no_grad():
