@@ -106,33 +106,41 @@ def spawn_ranks(args):
         sys.stderr.write('bench.py: --gpus %d but only %d device(s) visible; refusing to measure fewer GPUs than asked\n'
                          % (args.gpus, n_dev))
         return 2
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ)
-        env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(args.gpus), 'LOCAL_WORLD_SIZE': str(args.gpus),
-                    'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'HSA_ENABLE_IPC_MODE_LEGACY': '0',
-                    'RCF_BENCH_SELF_SPAWNED': '1'})
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    # fail fast: a rank that dies would leave the others waiting in a collective until the backend's (30-minute) timeout
     rc = 0
-    live = list(procs)
-    while live:
-        for p in list(live):
-            code = p.poll()
-            if code is None:
-                continue
-            live.remove(p)
-            if code != 0 and rc == 0:
-                rc = code
-                sys.stderr.write('bench.py: a rank exited with code %d; stopping the other %d\n' % (code, len(live)))
-                for q in live:
-                    q.terminate()
-        if live:
-            time.sleep(0.2)
+    for attempt in range(2):
+        # a free port, found by binding port 0 and closing the socket: another process can take it before the children bind it, so a
+        # run whose ranks die within the rendezvous window is retried once on a fresh port
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        t_start = time.time()
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ)
+            env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(args.gpus), 'LOCAL_WORLD_SIZE': str(args.gpus),
+                        'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'HSA_ENABLE_IPC_MODE_LEGACY': '0',
+                        'RCF_BENCH_SELF_SPAWNED': '1'})
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        # fail fast: a rank that dies would leave the others waiting in a collective until the backend's (30-minute) timeout
+        rc = 0
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    sys.stderr.write('bench.py: a rank exited with code %d; stopping the other %d\n' % (code, len(live)))
+                    for q in live:
+                        q.terminate()
+            if live:
+                time.sleep(0.2)
+        if rc == 0 or attempt == 1 or time.time() - t_start > 180.0 or rc in (2, 3):
+            break   # success, a real failure (the loss check: 3; too few devices: 2), or one that came after the rendezvous
+        sys.stderr.write('bench.py: ranks failed within the rendezvous window (port %d taken?); retrying once on a fresh port\n' % port)
     return rc
 
 

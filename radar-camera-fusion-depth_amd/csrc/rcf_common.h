@@ -45,7 +45,8 @@ __host__ __device__ inline RcfScale rcf_scale_of_amax(float amax) {
 // max|x| of a tensor, accumulated by the kernels that write it: wave maximum by shuffles, block maximum through LDS, then at most ONE
 // atomic per block on the bit pattern (non-negative floats order like their bit patterns; the slot is zeroed by the host before the
 // producers run) -- skipped when the slot already holds a value at least as large.  Same-address atomics retire one per ~4 ns: one
-// per WAVE (8192 per launch) cost the BatchNorm passes ~30 us per launch, measured in round 3.  All threads of the block must call it.
+// per WAVE (8192 per launch) cost the BatchNorm passes ~30 us per launch, measured in round 3 (committing early from inside the stream so
+// that the tail's guard skips did not help further: what is left is the block's own reduce + one L2 round trip).  All threads of the block must call it.
 __device__ __forceinline__ void rcf_amax_commit(float m, float* amax_slot) {
     __shared__ float rcf_amax_lds[16];
 #pragma unroll
@@ -58,21 +59,6 @@ __device__ __forceinline__ void rcf_amax_commit(float m, float* amax_slot) {
         const unsigned mb = __float_as_uint(m);
         unsigned* slot = reinterpret_cast<unsigned*>(amax_slot);
         if (mb > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, mb);
-    }
-}
-// Early commit, from wave 0 of a block of a LONG stream only (call it once, after the first loop trip, where all 64 lanes of the wave
-// are still converged): the running maximum of a stationary tensor is within a few per cent of the final one after one trip, so the
-// slot is near its final value long before the blocks reach rcf_amax_commit -- whose guard then skips almost every atomic of the tail
-// (2048 same-address atomics at the end of a launch cost ~8 us; issued mid-stream they retire behind the memory traffic).
-__device__ __forceinline__ void rcf_amax_early(float m, float* amax_slot) {
-    if (threadIdx.x < 64) {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        if (threadIdx.x == 0) {
-            const unsigned mb = __float_as_uint(m);
-            unsigned* slot = reinterpret_cast<unsigned*>(amax_slot);
-            if (mb > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, mb);
-        }
     }
 }
 __device__ __forceinline__ float rcf_amax4(float m, f32x4 v) {

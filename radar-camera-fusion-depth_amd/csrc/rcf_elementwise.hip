@@ -79,8 +79,6 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
         if (AM) am = rcf_amax4(am, y);
     };
     long long p = (long long)blockIdx.x * ppb + pl;
-    // AM: every thread of the block runs >= 8 unrolled trips (block-uniform), so wave 0 is converged after the first one
-    bool early = AM && n_pix >= 8ll * EW_U * stride + stride;
     for (; p + (EW_U - 1) * stride < n_pix; p += EW_U * stride) {
         f32x4 zz[EW_U], rr[EW_U];
 #pragma unroll
@@ -91,7 +89,6 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
         }
 #pragma unroll
         for (int u = 0; u < EW_U; ++u) one(zz[u], rr[u], (size_t)(p + u * stride) * c + cg * 4);
-        if (AM && early) { early = false; rcf_amax_early(am, amax); }
     }
     for (; p < n_pix; p += stride) {
         const size_t i = (size_t)p * c + cg * 4;
@@ -236,7 +233,6 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const float* __re
         if (AM) am = rcf_amax4(am, r);
     };
     long long p = (long long)blockIdx.x * ppb + pl;
-    bool early = AM && n_pix >= 8ll * EW_U * stride + stride;   // see bn_act_fwd_kernel
     for (; p + (EW_U - 1) * stride < n_pix; p += EW_U * stride) {
         f32x4 g[EW_U], zz[EW_U], o[EW_U], dold[EW_U];
 #pragma unroll
@@ -249,7 +245,6 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const float* __re
         }
 #pragma unroll
         for (int u = 0; u < EW_U; ++u) one(g[u], zz[u], o[u], dold[u], (size_t)(p + u * stride) * c + cg * 4);
-        if (AM && early) { early = false; rcf_amax_early(am, amax); }
     }
     for (; p < n_pix; p += stride) {
         const size_t i = (size_t)p * c + cg * 4;

@@ -36,6 +36,11 @@ class WeightPlan(object):
     buffer.  Any mismatch (another shape, another precision, a model that changed) marks the plan dirty: the rest of that step packs
     one launch at a time again, and the next step records afresh.  Results are bitwise those of the unbatched path.
 
+    Invariant: the parameters must not change between the start of forward() and the end of backward() of a training step (the packed
+    forms are made once, up front).  The reference's loop satisfies it (forward -> loss -> backward -> optimizer.step); code that writes
+    parameters in between (load_state_dict, restore_model, a manual copy_ into a weight) must do so between steps, or switch the
+    batching off (FusionNetModel.batch_weight_packing = False / RCF_BATCH_PACK=0).
+
     Two-plane fp16 arithmetic (RCF_PREC_F16X2) adds a third kind of entry: max|w| of every weight tensor (and phase-weight buffer)
     the split kernels consume, one device scalar each in a persistent arena -- replayed as ONE memset + rcf_amax_batch between the
     phase-weight batch (whose outputs it reads) and the packing batch (which scales by it).
