@@ -12,6 +12,7 @@ LAYERS = [('deconv0.deconv 64->32 450x800 -> 900x1600', 64, 32, 450, 800), ('dec
           ('deconv2.deconv 128->64 113x200 -> 226x400', 128, 64, 113, 200), ('deconv3.deconv 256->128 57x100', 256, 128, 57, 100)]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 dev = 'cuda'
+ops.set_precision(os.environ.get('RCF_BENCH_PREC', 'fp32'))   # 'f16x2': the two-plane kernels (unscaled: randn data sits in fp16's range)
 
 
 def timeit(fn):
