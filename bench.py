@@ -56,7 +56,7 @@ TRAIN_GFLOP_PER_SAMPLE = 994.8  # forward + dgrad + wgrad of the r
 FWD_GFLOP_PER_SAMPLE = 333.09
 KERNEL_NAMES = {
     0: 'conv_fwd_kernel 3x3 s1', 1: 'conv_fwd_kernel 3x3 s2', 2: 'conv_fwd_kernel 1x1', 3: 'conv_fwd_kernel 7x7 s2 stem',
-    5: 'conv_split_kernel 3x3 s1', 9: 'conv_split_kernel 2x2 phases',
+    5: 'conv_split_kernel 3x3 s1', 6: 'conv_split_kernel 3x3 s2', 8: 'conv_split_kernel 4x4 stem on the space-to-depth image', 9: 'conv_split_kernel 2x2 phases',
     10: 'conv_wgrad_kernel 3x3 s1', 11: 'conv_wgrad_kernel 3x3 s2', 12: 'conv_wgrad_kernel 1x1', 13: 'conv_wgrad_kernel 7x7 s2 stem',
 }
 
@@ -458,7 +458,7 @@ def run_rank(args):
     if dom is not None:
         cnt, flops, ms, abytes = fam[dom]
         algorithmic = flops / (ms * 1e-3) / 1e12
-        is_split = dom in (5, 9, 15, 19)
+        is_split = dom in (5, 6, 8, 9, 15, 19)
         # split kernels are bound by the bf16 matrix pipe: price them on the bf16 FLOPs they execute (6 per fp32 MAC)
         achieved = algorithmic * (SPLIT_PRODUCTS[dtype] if is_split else 1)
         peak = BF16_MFMA_PEAK_TFLOPS if is_split else F32_MFMA_PEAK_TFLOPS   # the guide's dense peak is the same for bf16 and fp16

@@ -479,6 +479,10 @@ int rcf_fc_bwd_b16(const float* x, const float* w, const float* y, const float* 
  * over those 16 channels.  The convolution is then rcf_conv2d_fwd with {ksize 4, stride 1, pad 2, pad_x 2, c1 16, storage BF16, h_in /
  * w_in = the space-to-depth extent, h_out / w_out = the stem's output extent}.  Its weight gradient is taken on the 7x7 form. */
 int rcf_s2d_image_b16(const float* img_nchw, void* out, int n, int c, int h, int w, void* stream);
+/* The same image in fp32, [n][ceil(h/2)][ceil(w/2)][16]: the stems of the fp32 configuration on the two-plane fp16 arithmetic
+ * (rcf_conv2d_fwd_scaled with {ksize 4, ..., precision RCF_PREC_F16X2, storage RCF_STORE_FP32}).  amax (nullable): a zeroed device
+ * scalar that receives max|pixel| (see rcf_amax). */
+int rcf_s2d_image_f32(const float* img_nchw, float* out, int n, int c, int h, int w, float* amax, void* stream);
 int rcf_stem_weights_s2d(const float* w7_oihw, float* w4_oihw, int c_out, int c_in, void* stream);
 
 /* dst[i] = (accumulate ? dst[i] : 0) + src[i] for n elements, each side RCF_STORE_FP32 or RCF_STORE_BF16 (torch's .to(dtype) of the

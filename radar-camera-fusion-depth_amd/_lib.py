@@ -135,6 +135,7 @@ _SIGNATURES.update({
 })
 _SIGNATURES['rcf_convert'] = (c_int, [_P, c_int, _P, c_int, c_longlong, c_int, _P])
 _SIGNATURES['rcf_s2d_image_b16'] = (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P])
+_SIGNATURES['rcf_s2d_image_f32'] = (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P])
 _SIGNATURES['rcf_stem_weights_s2d'] = (c_int, [_P, _P, c_int, c_int, _P])
 '''Every symbol include/rcf_hip.h declares, with its ctypes signature.'''
 

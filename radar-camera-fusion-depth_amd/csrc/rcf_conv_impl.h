@@ -2015,7 +2015,7 @@ __global__ void phase_wgrad_gather_s2_kernel(const float* __restrict__ dwp, floa
 
 // ------------------------------------------------------------------------------------------------
 // configuration tables
-enum Kind { K3S1 = 0, K3S2 = 1, K1 = 2, K7S2 = 3, K2S1 = 4, K4S1 = 7 };   // K4S1: the 7x7 stride-2 stem as a 4x4 conv on the space-to-depth image (bf16 tensors)
+enum Kind { K3S1 = 0, K3S2 = 1, K1 = 2, K7S2 = 3, K2S1 = 4, K4S1 = 7 };   // K4S1: the 7x7 stride-2 stem as a 4x4 conv on the space-to-depth image (bf16 tensors; fp32 tensors on two fp16 planes)
 
 struct Sel {
     int kind, ck, nt, px;
@@ -2326,7 +2326,8 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
             return RCF_EUNSUPPORTED;
         s->kind = K7S2; s->ck = 32; s->cst = 4; s->nt = 1; s->t = 7;
     } else if (d->ksize == 4) {
-        if (!SAct::B16 || d->c_out > 32) return RCF_EUNSUPPORTED;   // bf16 tensors only (conv_b16_kernel), one 32-co tile
+        // bf16 tensors (conv_b16_kernel) or fp32 tensors on the two-plane split kernel (RCF_PREC_F16X2), one 32-co tile
+        if ((!SAct::B16 && d->precision != RCF_PREC_F16X2) || d->c_out > 32 || !split_enabled()) return RCF_EUNSUPPORTED;
         s->kind = K4S1; s->t = 16; s->ck = 16; s->cst = 16; s->nt = 1;
     } else if (d->ksize == 2) {
         s->kind = K2S1; s->t = 4; s->ck = 32; s->cst = 32;
@@ -2383,7 +2384,11 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
         s->dma = (s->bf16 && d->c1 % 16 == 0 && d->c2 % 16 == 0 && (e == nullptr || e[0] != '0')) ? 1 : 0;
 #endif
     }
-    if (s->kind == K4S1) { s->split = 1; s->ck = 16; s->cst = 16; s->bf16 = 1; s->npl = 1; s->dma = 1; }
+    if (s->kind == K4S1) {
+        s->split = 1; s->ck = 16; s->cst = 16;
+        if (SAct::B16) { s->bf16 = 1; s->npl = 1; s->dma = 1; }
+        else { s->bf16 = 0; s->npl = 2; s->dma = 0; }
+    }
     double best = -1.0;
     const bool vt_ok = vt_allowed(d);
     const int pxs[3] = {32, 16, 8};
@@ -2493,6 +2498,10 @@ int dispatch_dma(const Sel& s, F&& f) {
 template <int NPL, class F>
 int dispatch_split_planes(const Sel& s, F&& f) {
     const bool p16 = s.px == 16;
+    if (s.kind == K4S1) {   // the stems on the fp32 space-to-depth image: 4x4 taps, 16 channels, <= 32 output channels, two planes only
+        if constexpr (NPL == 2) return p16 ? f(Tag<SplitCfg<4, 1, 16, 0, 2>>{}) : f(Tag<SplitCfg<4, 1, 32, 0, 2>>{});
+        else return RCF_EUNSUPPORTED;
+    }
     if (s.kind == K3S2) {
         if (s.nt == 1) return p16 ? f(Tag<SplitCfg<3, 1, 16, 1, NPL, 2>>{}) : f(Tag<SplitCfg<3, 1, 32, 1, NPL, 2>>{});
         return p16 ? f(Tag<SplitCfg<3, 2, 16, 1, NPL, 2>>{}) : f(Tag<SplitCfg<3, 2, 32, 1, NPL, 2>>{});
@@ -2710,7 +2719,9 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
     info->n_partials = s.split ? dispatch_split(s, [&](auto tag) { return split_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); })
                                : dispatch_fwd(s, [&](auto tag) { return fwd_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
     if (info->n_partials <= 0) return RCF_EUNSUPPORTED;
-    info->kernel_id = s.kind * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0) + (s.small ? 5 : 0) + (s.bf16 ? 20000 : 0) + ((s.split && s.npl == 2) ? 40000 : 0);
+    // (the stem on the space-to-depth image reports kind 3 like the 7x7 stem it stands for: 3000 + 5000 (split) stays below the
+    // weight-gradient ids, 10000 + ...)
+    info->kernel_id = (s.kind == K4S1 ? (int)K7S2 : s.kind) * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0) + (s.small ? 5 : 0) + (s.bf16 ? 20000 : 0) + ((s.split && s.npl == 2) ? 40000 : 0);
     info->wgrad_workspace_floats = 0;
     info->wgrad_kernel_id = 0;
     info->bn_on_load = (s.split && !s.dma && !s.pw && d->w_mode == RCF_W_FORWARD && d->c1 + d->c2 <= 512 && s.npl != 2) ? 1 : 0;   // a DMA cannot transform; fp16 planes need the maximum of the TRANSFORMED tensor
@@ -2871,7 +2882,7 @@ static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float
         return dispatch_dma(s, [&](auto tag) { return launch_dma<typename decltype(tag)::type, false>(a, nn, (hipStream_t)stream); });
     if (s.dma) return RCF_EUNSUPPORTED;   // rcf_conv_info.bn_on_load is 0 for these descriptors (the tile geometry differs)
 #endif
-    if (s.kind == K4S1) return RCF_EUNSUPPORTED;
+    if (s.kind == K4S1 && SAct::B16) return RCF_EUNSUPPORTED;
     if (s.split) return dispatch_split(s, [&](auto tag) { return launch_split<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
     return dispatch_fwd(s, [&](auto tag) { return launch_fwd<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
 }

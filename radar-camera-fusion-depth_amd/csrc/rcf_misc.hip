@@ -1077,6 +1077,30 @@ __global__ void __launch_bounds__(256) s2d_image_kernel(const float* __restrict_
     }
 }
 
+// the same image in fp32 (the two-plane fp16 arithmetic of the fp32 configuration), accumulating max|pixel| for its scale
+__global__ void __launch_bounds__(256) s2d_image_f32_kernel(const float* __restrict__ img, float* __restrict__ out, int n, int c, int h, int w,
+                                                            int hs, int ws, float* __restrict__ amax) {
+    const long long total = (long long)n * hs * ws * 4;   // one thread per (pixel quad, phase): 4 channels = 16 bytes
+    float am = 0.f;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const int ph = (int)(g & 3);
+        const long long q = g >> 2;
+        const int x = (int)(q % ws);
+        const int y = (int)((q / ws) % hs);
+        const int im = (int)(q / ((long long)ws * hs));
+        const int iy = 2 * y + (ph >> 1), ix = 2 * x + (ph & 1);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy < h && ix < w) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+                if (ch < c) v[ch] = img[(((size_t)im * c + ch) * h + iy) * w + ix];
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)q * 16 + ph * 4) = v;
+        am = rcf_amax4(am, v);
+    }
+    if (amax != nullptr) rcf_amax_commit(am, amax);
+}
+
 // W4[co][a * 8 + b * 4 + c][t][u] = W7[co][c][2 t + a - 1][2 u + b - 1] (0 outside the 7x7 kernel or for c >= C)
 __global__ void __launch_bounds__(256) stem_weights_s2d_kernel(const float* __restrict__ w7, float* __restrict__ w4, int co_n, int c) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -1096,6 +1120,15 @@ extern "C" int rcf_s2d_image_b16(const float* img_nchw, void* out, int n, int c,
     const int hs = (h + 1) / 2, ws = (w + 1) / 2;
     unsigned b = nblk((long long)n * hs * ws * 4, 256); if (b > 16384) b = 16384;
     hipLaunchKernelGGL(s2d_image_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, img_nchw, (unsigned short*)out, n, c, h, w, hs, ws);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_s2d_image_f32(const float* img_nchw, float* out, int n, int c, int h, int w, float* amax, void* stream) {
+    if (!img_nchw || !out || n <= 0 || c <= 0 || h <= 0 || w <= 0) return RCF_EINVAL;
+    if (c > 4) return RCF_EUNSUPPORTED;
+    const int hs = (h + 1) / 2, ws = (w + 1) / 2;
+    unsigned b = nblk((long long)n * hs * ws * 4, 256); if (b > 2048) b = 2048;   // one atomic per block when amax is given
+    hipLaunchKernelGGL(s2d_image_f32_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, img_nchw, out, n, c, h, w, hs, ws, amax);
     return rcf_launch_status();
 }
 

@@ -330,8 +330,9 @@ class Engine(object):
 
     @staticmethod
     def _two_plane(kernel_id):
-        '''rcf_conv_info.kernel_id of a forward / input-gradient split kernel on two fp16 planes (ids 40000 .. 49999).'''
-        return 40000 <= kernel_id < 50000
+        '''rcf_conv_info.kernel_id of a forward / input-gradient split kernel on two fp16 planes (ids 40000 .. 59999; the bf16-operand
+        variants end below 40000).'''
+        return 40000 <= kernel_id < 60000
 
     @staticmethod
     def _two_plane_wgrad(kernel_id):
@@ -501,29 +502,53 @@ class Engine(object):
 
     def _conv_stem_s2d(self, layer, x, want_stats, fold=None):
         '''
-        The 7x7 stride-2 stem with bf16 tensors: a 4x4 stride-1 convolution on the space-to-depth image of the network input
-        (ops.s2d_image, built straight from the NCHW input) on the bf16 matrix pipe -- the f32-MFMA stem kernel is compute bound at
-        ~55 TFLOP/s.  The weight gradient (training) is taken on the 7x7 form from the fp32 NHWC input as before.
+        The 7x7 stride-2 stem as a 4x4 stride-1 convolution on the space-to-depth image of the network input (built straight from the
+        NCHW input) on the 16-bit matrix pipe -- the f32-MFMA stem kernel is compute bound at ~55 TFLOP/s.  bf16 tensors: the LDS-DMA
+        kernel on the bf16 image (ops.s2d_image).  fp32 tensors (round 3): the two-plane fp16 split kernel on the fp32 image, scaled
+        by the input's maximum (ops.s2d_image_f32 accumulates it) and the weights' maximum.  The weight gradient (training) is taken
+        on the 7x7 form from the fp32 NHWC input as before.
         '''
         n = x.s2d.shape[0]
         h, w = x.hw
         weight = layer.conv.weight
         co = weight.shape[0]
-        d = ops.make_stem_s2d_desc(n, h, w, co)
+        f32 = x.s2d.dtype == torch.float32
+        d = ops.make_stem_s2d_desc(n, h, w, co, f32=f32)
         info = ops.conv_query(d)
         fused = fold is not None and bool(info.fwd_act) and fold[1] is None
-        def stem_pack():
-            w7 = ops.scale_channels(weight.detach(), fold[0][0]) if fused else weight.detach()
-            buf = self._newf((info.packed_weight_floats,), x.s2d)
-            ops.conv_pack(d, ops.stem_weights_s2d(w7), buf)
-            return buf
-        packed = self._frozen_get(('stem', id(layer), bool(fused)), stem_pack)
-        z = torch.empty((n, d.h_out, d.w_out, co), dtype=torch.bfloat16, device=x.s2d.device)
+
+        def stem_weights():
+            return ops.stem_weights_s2d(ops.scale_channels(weight.detach(), fold[0][0]) if fused else weight.detach())
+
+        scales = None
+        if f32:
+            # two fp16 planes: the 4x4 weights' maximum is computed on the transformed tensor (one small launch; the stems are two layers)
+            def stem_pack32():
+                w4 = stem_weights()
+                wmax = ops.amax(w4)
+                buf = self._newf((info.packed_weight_floats,), x.s2d)
+                ops.conv_pack(d, w4, buf, wmax)
+                return buf, wmax
+            packed, wmax = self._frozen_get(('stem32', id(layer), bool(fused)), stem_pack32)
+            scales = ops.make_scales(x.amax, None, wmax)
+        else:
+            def stem_pack():
+                buf = self._newf((info.packed_weight_floats,), x.s2d)
+                ops.conv_pack(d, stem_weights(), buf)
+                return buf
+            packed = self._frozen_get(('stem', id(layer), bool(fused)), stem_pack)
+        z = torch.empty((n, d.h_out, d.w_out, co), dtype=x.s2d.dtype, device=x.s2d.device)
         partials = torch.empty((info.n_partials, 2, co), dtype=torch.float64, device=z.device) if want_stats else None
+        if self.prof is not None:
+            self.prof.begin(info.kernel_id, 2.0 * n * d.h_out * d.w_out * co * 49 * x.t.shape[3] if x.t is not None else 0.0, d)
         if fused:
+            if f32:
+                raise RuntimeError('the fp32 stem has no fused inference epilogue on two planes')   # fold -> exact arithmetic upstream
             ops.conv_fwd_act(d, x.s2d, None, packed, fold[0][1], None, z)
         else:
-            ops.conv_fwd(d, x.s2d, None, packed, z, partials)
+            ops.conv_fwd(d, x.s2d, None, packed, z, partials, scales=scales)
+        if self.prof is not None:
+            self.prof.end()
 
         class _Info(object):
             pass
@@ -988,6 +1013,8 @@ class Engine(object):
     @staticmethod
     def _input(nhwc, s2d, hw):
         a = Act(nhwc, needs_grad=False)
+        if isinstance(s2d, tuple):      # fp32 space-to-depth image + the device scalar holding max|input| (ops.s2d_image_f32)
+            s2d, a.amax = s2d
         a.s2d, a.hw = s2d, hw
         return a
 

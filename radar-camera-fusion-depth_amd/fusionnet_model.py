@@ -250,6 +250,12 @@ class FusionNetModel(object):
     spread over the step (engine.WeightPlan; bitwise the same results).  RCF_BATCH_PACK=0 switches it off.
     '''
 
+    stems_on_split_pipe = os.environ.get('RCF_STEM_S2D', '1') != '0'
+    '''
+    fp32 training: the two 7x7 stride-2 stems as 4x4 convolutions on the space-to-depth image on the two-plane fp16 split kernels
+    (Engine._conv_stem_s2d) instead of the f32-MFMA stem kernel.  RCF_STEM_S2D=0 switches it off.
+    '''
+
     compute_dtype = 'fp32'
     '''
     'fp32' (default): the reference's arithmetic -- fp32 tensors, fp32-accurate products (ops.precision_of: the 3x3 / 2x2 split
@@ -289,13 +295,20 @@ class FusionNetModel(object):
             if self.batch_weight_packing:
                 self._engine.plan.enable()
             self._engine.plan.begin()
-        if ops.act_dtype() == torch.bfloat16 and image.shape[1] <= 4 and input_depth.shape[1] <= 4:
+        small_c = image.shape[1] <= 4 and input_depth.shape[1] <= 4
+        if ops.act_dtype() == torch.bfloat16 and small_c:
             # bf16 configuration: the stems run on the space-to-depth image, built straight from the NCHW inputs; the fp32 NHWC
             # copies are only read by the stems' weight gradients
             s_img, s_dep = ops.s2d_image(image), ops.s2d_image(input_depth)
             x_img = ops.nchw_to_nhwc(image) if record else None
             x_dep = ops.nchw_to_nhwc(input_depth) if record else None
             out, tape = self._engine.forward(x_img, x_dep, training=training, record=record, image_s2d=s_img, depth_s2d=s_dep, hw=hw)
+        elif ops.get_precision() == _lib.RCF_PREC_F16X2 and small_c and record and self.stems_on_split_pipe:
+            # fp32 configuration on two fp16 planes (training): the same form in fp32 -- (image, max|image|) pairs; the NHWC copies feed
+            # the stems' 7x7 weight gradients
+            s_img, s_dep = ops.s2d_image_f32(image), ops.s2d_image_f32(input_depth)
+            out, tape = self._engine.forward(ops.nchw_to_nhwc(image), ops.nchw_to_nhwc(input_depth), training=training, record=record,
+                                             image_s2d=s_img, depth_s2d=s_dep, hw=hw)
         else:
             x_img = ops.nchw_to_nhwc(image)
             x_dep = ops.nchw_to_nhwc(input_depth)

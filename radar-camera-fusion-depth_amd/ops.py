@@ -718,6 +718,16 @@ def s2d_image(image_nchw):
     return out
 
 
+def s2d_image_f32(image_nchw):
+    """(N, C <= 4, H, W) fp32 -> ((N, ceil(H/2), ceil(W/2), 16) fp32, device scalar max|pixel|): the stems' input of the fp32
+    configuration on the two-plane fp16 arithmetic."""
+    n, c, h, w = image_nchw.shape
+    out = torch.empty((n, (h + 1) // 2, (w + 1) // 2, 16), dtype=torch.float32, device=image_nchw.device)
+    amax = torch.zeros(1, dtype=torch.float32, device=image_nchw.device)
+    check(_lib.load().rcf_s2d_image_f32(_f32(image_nchw), _f32(out), n, c, h, w, _f32(amax), _stream()), 'rcf_s2d_image_f32')
+    return out, amax
+
+
 def stem_weights_s2d(w7):
     """OIHW 7x7 weight (C <= 4 input channels) -> OIHW 4x4 weight over the 16 space-to-depth channels."""
     co, c = w7.shape[0], w7.shape[1]
@@ -726,11 +736,12 @@ def stem_weights_s2d(w7):
     return out
 
 
-def make_stem_s2d_desc(n, h, w, c_out):
-    """The 7x7 stride-2 pad-3 stem on an (h, w) image as a 4x4 stride-1 conv on its space-to-depth image."""
+def make_stem_s2d_desc(n, h, w, c_out, f32=False):
+    """The 7x7 stride-2 pad-3 stem on an (h, w) image as a 4x4 stride-1 conv on its space-to-depth image (bf16 tensors, or with
+    f32=True fp32 tensors on the two-plane fp16 arithmetic)."""
     hs, ws = (h + 1) // 2, (w + 1) // 2
     ho, wo = conv_out_hw(h, w, 7, 2, 3)
     return ConvDesc(n=n, h_in=hs, w_in=ws, c1=16, c2=0, h_src1=hs, w_src1=ws, gather1=RCF_GATHER_DIRECT, h_out=ho, w_out=wo,
                     c_out=c_out, ksize=4, stride=1, pad=2, pad_x=2, w_mode=RCF_W_FORWARD, w_o=c_out, w_i=16, w_i_off=0, accumulate=0,
                     out_stride=1, out_off_y=0, out_off_x=0, out_h_phys=ho, out_w_phys=wo, in_off_y=0, in_off_x=0, phase_sum=0,
-                    precision=_lib.RCF_PREC_BF16, storage=_lib.RCF_STORE_BF16)
+                    precision=_lib.RCF_PREC_F16X2 if f32 else _lib.RCF_PREC_BF16, storage=_lib.RCF_STORE_FP32 if f32 else _lib.RCF_STORE_BF16)

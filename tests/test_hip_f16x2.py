@@ -379,6 +379,41 @@ def test_up2x_conv_as_four_phase_convs(ops, cin, cout, n, hs, ws):
         ops.set_precision('fp32')
 
 
+@pytest.mark.parametrize('c,co,n,h,w', [(3, 32, 2, 70, 102), (2, 16, 1, 45, 81), (3, 32, 1, 224, 384)])
+def test_stem_7x7_stride2_as_4x4_on_the_fp32_space_to_depth_image(ops, c, co, n, h, w):
+    '''The stems of the fp32 configuration (src/networks.py:332-345: 7x7, stride 2, pad 3, 3 / 2 input channels) as a 4x4 stride-1
+    convolution on the fp32 space-to-depth image, two scaled fp16 planes: rcf_s2d_image_f32 (with the image's maximum),
+    rcf_stem_weights_s2d, rcf_conv2d_fwd_scaled with ksize 4 -- against the fp64 7x7 convolution at the exact tier's bar, odd sizes
+    included, and the BatchNorm statistics of the written values.'''
+    x = rnd(n, c, h, w, seed=21) * 0.5 + 0.5            # images live in [0, 1]
+    if c == 2:
+        x = x * 80.0                                     # the radar depth / response channels reach tens of metres
+    wt = rnd(co, c, 7, 7, seed=22, scale=1.0 / np.sqrt(c * 49))
+    ref = F.conv2d(x.double(), wt.double(), stride=2, padding=3)
+    s2d, amax = ops.s2d_image_f32(x.cuda())
+    assert float(amax) == float(x.abs().max())
+    assert tuple(s2d.shape) == (n, (h + 1) // 2, (w + 1) // 2, 16)
+    d = ops.make_stem_s2d_desc(n, h, w, co, f32=True)
+    info = ops.conv_query(d)
+    assert 40000 <= info.kernel_id < 60000
+    w4 = ops.stem_weights_s2d(wt.cuda())
+    wmax = ops.amax(w4)
+    packed = torch.empty(info.packed_weight_floats, device='cuda')
+    ops.conv_pack(d, w4, packed, wmax)
+    out = torch.full((n, d.h_out, d.w_out, co), float('nan'), device='cuda')
+    part = torch.full((info.n_partials, 2, co), float('nan'), device='cuda', dtype=torch.float64)
+    ops.conv_fwd(d, s2d, None, packed, out, part, scales=ops.make_scales(amax, None, wmax))
+    torch.cuda.synchronize()
+    got = nchw(out)
+    assert tuple(got.shape) == tuple(ref.shape)
+    e = rel(got, ref)
+    print('stem %d -> %d at %dx%d on two fp16 planes: rel %.2e' % (c, co, h, w, e))
+    assert e < EXACT_TOL
+    st = part.sum(0).cpu()
+    np.testing.assert_allclose(st[0].numpy(), got.double().sum((0, 2, 3)).numpy(), rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(st[1].numpy(), (got.double() ** 2).sum((0, 2, 3)).numpy(), rtol=1e-9, atol=1e-6)
+
+
 def _named(model):
     out = []
     for prefix, mod in (('encoder.', model.encoder), ('decoder.', model.decoder)):
