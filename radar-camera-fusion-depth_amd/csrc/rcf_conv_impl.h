@@ -1836,6 +1836,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     double s = 0.0;   // the per-workgroup partials cancel heavily for BN-followed convs: sum them in fp64
     if (live) {
         const size_t stride = (size_t)ktot * cop;
+        // eight independent 256-B loads in flight per wave (the adds stay in slot order: the sum is the same)
+#pragma unroll 8
         for (int sl = lane_s; sl < nslot; sl += 4) s += (double)ws[sl * stride + idx];
     }
     sm[lane_s][lane_o] = s;

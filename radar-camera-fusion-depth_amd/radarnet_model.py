@@ -202,10 +202,6 @@ class RadarNetModel(object):
             out, tape = self._engine.forward_radarnet(ops.nchw_to_nhwc(image) if record else None, pts, rois, training=self._training,
                                                       record=record, image_s2d=ops.s2d_image(image),
                                                       hw=(int(image.shape[2]), int(image.shape[3])))
-        elif ops.get_precision() == _lib.RCF_PREC_F16X2 and image.shape[1] <= 4 and record:
-            # fp32 configuration on two fp16 planes: the stem on the fp32 space-to-depth image (FusionNetModel.stems_on_split_pipe)
-            out, tape = self._engine.forward_radarnet(ops.nchw_to_nhwc(image), pts, rois, training=self._training, record=record,
-                                                      image_s2d=ops.s2d_image_f32(image), hw=(int(image.shape[2]), int(image.shape[3])))
         else:
             out, tape = self._engine.forward_radarnet(ops.nchw_to_nhwc(image), pts, rois, training=self._training, record=record)
         if self._training:
