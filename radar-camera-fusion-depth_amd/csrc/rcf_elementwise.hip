@@ -482,7 +482,8 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restri
     double mean, var;
     if (training) {
         double s1 = 0.0, s2 = 0.0;
-        for (int r = threadIdx.x; r < n_partials; r += blockDim.x) {
+#pragma unroll 4
+        for (int r = threadIdx.x; r < n_partials; r += blockDim.x) {   // (a launch of <= 768 rows: latency, not bandwidth)
             s1 += partials[((size_t)r * 2 + 0) * c + ch];
             s2 += partials[((size_t)r * 2 + 1) * c + ch];
         }
