@@ -1,5 +1,6 @@
-'''Loss trajectories of the same training run (published FusionNet, same seeds, same batches) under the three arithmetic tiers:
-fp32 (exact), bf16x3 (two operand planes / three products) and bf16 (bf16 tensors).  GPU box.
+'''Loss trajectories of the same training run (published FusionNet, same seeds, same batches) under the arithmetic tiers: fp32 on
+three bf16 planes (the reference run), the same with another tiling (how far two fp32 runs drift apart on their own), fp32 on two
+scaled fp16 planes (the default of compute_dtype='fp32') and bf16 tensors.  GPU box.
 usage: python tools/trajectory.py [steps] [batch] [height] [width]'''
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,16 +21,16 @@ for i in range(NB):
     batches.append(tuple(b[k].to(dev) for k in ('image', 'input_depth', 'ground_truth', 'lidar_map')))
 outlier = OutlierRemoval(kernel_size=7, threshold=1.5)
 runs = {}
-for mode in ('fp32', 'fp32 other tiling', 'bf16x3', 'bf16'):
+for mode in ('fp32_3plane', 'fp32_3plane other tiling', 'fp32', 'bf16'):
     # 'fp32 other tiling': the same exact-fp32 arithmetic with the virtual-tall tiling off (RCF_NO_VT=1) -- a different fp32
     # summation order only, to show how far two fp32 runs drift apart on their own
-    if mode == 'fp32 other tiling':
+    if mode == 'fp32_3plane other tiling':
         os.environ['RCF_NO_VT'] = '1'
     else:
         os.environ.pop('RCF_NO_VT', None)
     model = train.build_model(synth.PUBLISHED, device=dev)
     synth.fill_state_dict_([model.encoder, model.decoder], 1234)
-    model.compute_dtype = 'fp32' if mode.startswith('fp32') else mode
+    model.compute_dtype = mode.split(' ')[0]
     model.train()
     opt = train.make_optimizer(model, lr=1e-4)
     losses = []
@@ -37,9 +38,9 @@ for mode in ('fp32', 'fp32 other tiling', 'bf16x3', 'bf16'):
         losses.append(float(train.train_step(model, opt, *batches[s % NB], outlier_removal=outlier)[0].detach()))
     runs[mode] = losses
 print('published FusionNet, batch %d, %dx%d, Adam lr 1e-4, %d distinct batches cycled; mean loss over each window of %d steps' % (batch, h, w, NB, NB))
-print('%10s %12s %12s %12s %12s | %10s %10s %10s' % ('steps', 'fp32', 'fp32 tiling2', 'bf16x3', 'bf16', 'fp32b/fp32-1', 'x3/fp32-1', 'bf16/fp32-1'))
+print('%10s %12s %12s %12s %12s | %12s %12s %12s' % ('steps', '3 bf16 pl.', '3pl tiling2', '2 fp16 pl.', 'bf16', 'tiling2/3pl-1', '2pl/3pl-1', 'bf16/3pl-1'))
 for s0 in range(0, steps, max(NB, steps // 10 // NB * NB)):
     win = lambda m: sum(runs[m][s0:s0 + NB]) / len(runs[m][s0:s0 + NB])
-    a, a2, b, c = win('fp32'), win('fp32 other tiling'), win('bf16x3'), win('bf16')
-    print('%4d..%-4d %12.5f %12.5f %12.5f %12.5f | %+10.2e %+10.2e %+10.2e' % (s0, s0 + NB - 1, a, a2, b, c, a2 / a - 1, b / a - 1, c / a - 1))
-print('first step: %.6f %.6f %.6f %.6f' % (runs['fp32'][0], runs['fp32 other tiling'][0], runs['bf16x3'][0], runs['bf16'][0]))
+    a, a2, b, c = win('fp32_3plane'), win('fp32_3plane other tiling'), win('fp32'), win('bf16')
+    print('%4d..%-4d %12.5f %12.5f %12.5f %12.5f | %+12.2e %+12.2e %+12.2e' % (s0, s0 + NB - 1, a, a2, b, c, a2 / a - 1, b / a - 1, c / a - 1))
+print('first step: %.6f %.6f %.6f %.6f' % (runs['fp32_3plane'][0], runs['fp32_3plane other tiling'][0], runs['fp32'][0], runs['bf16'][0]))
