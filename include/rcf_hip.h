@@ -110,6 +110,7 @@ typedef struct rcf_conv_info {
     int bn_on_load;              /* 1: rcf_conv2d_fwd_bn accepts this descriptor (raw conv outputs + BN coefficients as inputs) */
     int wgrad_bn_on_load;        /* 1: rcf_conv2d_wgrad_bn accepts it */
     int fwd_act;                 /* 1: rcf_conv2d_fwd_act accepts it (inference epilogue in the matrix kernel) */
+    int bn_bwd_sums;             /* 1: rcf_conv2d_dgrad_bn_sums accepts it (BatchNorm-backward sums in the input-gradient kernel) */
 } rcf_conv_info;
 
 const char* rcf_version(void);
@@ -165,6 +166,17 @@ int rcf_conv2d_fwd(const rcf_conv_desc* d, const void* in1, const void* in2, con
 /* The same for RCF_PREC_F16X2 descriptors on the split kernels (rcf_conv_info.kernel_id >= 45000), with the operands' maxima. */
 int rcf_conv2d_fwd_scaled(const rcf_conv_desc* d, const void* in1, const void* in2, const float* packed,
                           void* out, double* stat_partials, const rcf_conv_scales* scales, void* stream);
+/* The input gradient of a convolution (w_mode = DGRAD, or the four-phase input gradient of an up-2x convolution) whose output dx
+ * is dY of a BatchNorm + LeakyReLU block -- the gradient w.r.t. the activation net_utils.Conv2d.forward returns
+ * (src/net_utils.py:84-91) -- and that is the ONLY writer of it: besides dx the kernel leaves, per workgroup, the two sums
+ * torch.nn.BatchNorm2d's backward needs, sum g and sum g * xhat with g = dx * lrelu'(bn_z * coef[0] + coef[1]) and
+ * xhat = (bn_z - coef[2]) * coef[3] (bn_z: that block's raw conv output, same shape as dx; bn_coef: its rcf_bn_finalize
+ * coefficients [4][c_out]), in sum_partials [n_partials][2][c_out] fp64 -- what rcf_bn_act_bwd_reduce would produce from a second
+ * pass over dx and bn_z, ready for rcf_bn_bwd_finalize.  scales as for rcf_conv2d_fwd_scaled (nullable members = scale 1).
+ * Only where rcf_conv_info.bn_bwd_sums is set (fp32 tensors, RCF_PREC_F16X2, 3x3 stride 1 / 2x2, plain output tensor);
+ * RCF_EUNSUPPORTED otherwise. */
+int rcf_conv2d_dgrad_bn_sums(const rcf_conv_desc* d, const void* dz, const float* packed, void* dx, const void* bn_z,
+                             const float* bn_coef, double* sum_partials, const rcf_conv_scales* scales, void* stream);
 /* BatchNorm + LeakyReLU of the PRODUCING block applied while the operand is staged ("BN on load"): in1 / in2 are raw conv
  * outputs z and coef1 / coef2 (nullable, one per source) the rcf_bn_finalize coefficients [4][c] of the block that produced
  * them; the kernel uses y = lrelu(z * coef[0][c] + coef[1][c]).  That block's activation tensor (net_utils.Conv2d.forward,

@@ -27,7 +27,7 @@ class ConvDesc(Structure):
 class ConvInfo(Structure):
     _fields_ = [('packed_weight_floats', c_size_t), ('n_partials', c_int),
                 ('wgrad_workspace_floats', c_size_t), ('kernel_id', c_int), ('wgrad_kernel_id', c_int),
-                ('bn_on_load', c_int), ('wgrad_bn_on_load', c_int), ('fwd_act', c_int)]
+                ('bn_on_load', c_int), ('wgrad_bn_on_load', c_int), ('fwd_act', c_int), ('bn_bwd_sums', c_int)]
 
 
 class PackItem(Structure):     # rcf_pack_item
@@ -126,6 +126,7 @@ _SIGNATURES.update({
     'rcf_conv2d_pack_weights_scaled': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P]),
     'rcf_conv2d_fwd_scaled': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, POINTER(ConvScales), _P]),
     'rcf_conv2d_wgrad_scaled': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, POINTER(ConvScales), _P]),
+    'rcf_conv2d_dgrad_bn_sums': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, POINTER(ConvScales), _P]),
     'rcf_amax': (c_int, [_P, c_longlong, _P, _P]),
     'rcf_amax_batch': (c_int, [POINTER(AmaxItem), c_int, _P]),
     'rcf_bn_act_fwd_amax': (c_int, [_P, _P, _P, _P, c_longlong, c_int, c_int, _P, _P]),

@@ -69,6 +69,11 @@ struct ConvArgs {
     const float* amax_a1;
     const float* amax_a2;
     const float* amax_b;
+    // conv_split_kernel<C, false, SI, SO, true> (an input-gradient launch that is the only writer of dY of a BatchNorm + LeakyReLU
+    // block): the block's raw conv output z (same geometry as `out`) and its coefficients [4][c_out] (scale, shift, mean, invstd);
+    // `stats` then receives sum g and sum g * xhat with g = dY * lrelu'(z * scale + shift), xhat = (z - mean) * invstd
+    const float* bz;
+    const float* bk;
     int n, h_in, w_in, c1, c2, h1, w1, gather1;
     int h_out, w_out, c_out, pad, pad_x, stride, gstep, accumulate;
     int os, ooy, oox, ohp, owp;   // output (and wgrad dZ) phase addressing
@@ -526,8 +531,9 @@ __device__ unsigned long long rcf_phase_cycles[8];
 
 // EPI: inference epilogue -- BatchNorm folded into the weights (scale) and a per-channel bias, LeakyReLU, and the residual tail of
 // ResNetBlock (lrelu(y + res)) applied to the accumulators before the only store; no statistics.
-template <class C, bool EPI = false, class SI = SAct, class SO = SAct>
+template <class C, bool EPI = false, class SI = SAct, class SO = SAct, bool BST = false>
 __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
+    static_assert(!(EPI && BST), "the inference epilogue and the BatchNorm-backward sums exclude each other");
     static_assert(!SI::B16 || C::NPL == 1, "bf16 tensors go with bf16 operands");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char* As = smem_b;
@@ -869,6 +875,19 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                         for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(ebias[ni]));
                     }
                     const bool add_old = EPI ? a.res != nullptr : a.accumulate != 0;
+                    float bk[BST ? 2 : 1][C::NT];   // BST: scale, shift of this lane's channels (mean, invstd enter once, at the end)
+                    if constexpr (BST) {
+#pragma unroll
+                        for (int ni = 0; ni < C::NT; ++ni) {
+                            const int co = n0 + ni * 32 + li;
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) bk[e][ni] = a.bk[e * a.c_out + (co < a.c_out ? co : 0)];
+                        }
+#pragma unroll
+                        for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(bk[e][ni]));   // land them here (see `old`)
+                    }
                     if constexpr (C::NPL == 2) {   // undo the operand scales: two exact multiplications by powers of two
 #pragma unroll
                         for (int mi = 0; mi < C::MT; ++mi)
@@ -877,6 +896,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = acc[mi][ni][r] * sc.ia * sc.ib;
                     }
+                    // (BST: taking a group's sums one group later -- z loads in flight behind the next group's stores -- was built and
+                    // measured: the extra live registers spill 11-31 VGPRs in the 3x3 configurations and the step is no faster)
 #pragma unroll
                     for (int mi = 0; mi < C::MT; ++mi) {
 #pragma unroll
@@ -922,6 +943,16 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                     pbase[j] = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
                                 }
                             }
+                            float zv[BST ? 4 : 1][C::NT];
+                            if constexpr (BST) {   // z of the BatchNorm block at the group's outputs, in flight together with `old`
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int ni = 0; ni < C::NT; ++ni) {
+                                        const int co = n0 + ni * 32 + li;
+                                        zv[j][ni] = rcf_ld1<SO>(a.bz, (pok[j] && co < a.c_out) ? pbase[j] + co : 0);
+                                    }
+                            }
                             float old[4][C::NT];
                             if (add_old) {   // all old values of the group in flight together (clamped address)
                                 const auto* addsrc = EPI ? a.res : a.out;
@@ -956,6 +987,12 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
 #pragma unroll
                                     for (int ni = 0; ni < C::NT; ++ni) old[j][ni] = 0.f;
                             }
+                            if constexpr (BST) {   // land the z loads in front of the stores (see the note on `old`)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(zv[j][ni]));
+                            }
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -973,6 +1010,12 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                         }
                                         v = rcf_round_st<SO>(v);   // BatchNorm statistics of the values the tensor holds
                                         rcf_st1<SO>(a.out, pbase[j] + co, v);
+                                        if constexpr (BST) {   // sum g and sum g * z of the gradient the tensor holds, in fp64
+                                            const float zz = zv[j][ni];
+                                            const float g = v * rcf_lrelu_grad(zz * bk[0][ni] + bk[1][ni]);
+                                            st1[ni] += (double)g;
+                                            st2[ni] += (double)g * (double)zz;
+                                        } else
                                         if (want_stats) {   // fp64 per value: E[x^2]-mean^2 must not depend on how tiles group the sum
                                             const double dv = (double)v;
                                             st1[ni] += dv;
@@ -1034,6 +1077,9 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                     t1 += red[(w * C::BN + tid) * 2 + 0];
                     t2 += red[(w * C::BN + tid) * 2 + 1];
                 }
+                // BST: sum g * xhat = invstd * (sum g * z - mean * sum g), formed in fp64 from this workgroup's fp64 sums (the
+                // cancellation costs bits of the 53, not of a float)
+                if constexpr (BST) t2 = (double)a.bk[3 * a.c_out + co] * (t2 - (double)a.bk[2 * a.c_out + co] * t1);
                 a.stats[((size_t)blockIdx.x * 2 + 0) * a.c_out + co] = t1;
                 a.stats[((size_t)blockIdx.x * 2 + 1) * a.c_out + co] = t2;
             }
@@ -2123,6 +2169,20 @@ int launch_split(const ConvArgs& a, int ntile_n, hipStream_t st) {
     return rcf_launch_status();
 }
 
+// the input-gradient launch that also takes the BatchNorm-backward sums of the block whose dY it writes (ConvArgs.bz / bk)
+template <class C>
+int launch_split_bst(const ConvArgs& a, int ntile_n, hipStream_t st) {
+    const int gx = split_grid_x<C>(a.ntiles, ntile_n);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, false, SAct, SAct, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_split_kernel<C, false, SAct, SAct, true>), dim3(gx, ntile_n, 1), dim3(256), C::LDS_BYTES, st, a);
+    return rcf_launch_status();
+}
+
 template <class C>
 int launch_wgrad(const ConvArgs& a, int nsplit, int nchunk, int ncog, hipStream_t st) {
     static bool attr_done = false;
@@ -2422,6 +2482,7 @@ const float* zero_page_ptr() {
 void fill_args(const rcf_conv_desc* d, const Sel& s, ConvArgs* a) {
     a->coef1 = nullptr; a->coef2 = nullptr; a->bias = nullptr; a->res = nullptr;
     a->amax_a1 = nullptr; a->amax_a2 = nullptr; a->amax_b = nullptr;
+    a->bz = nullptr; a->bk = nullptr;
     a->zero = zero_page_ptr();
     a->n = d->n; a->h_in = d->h_in; a->w_in = d->w_in; a->c1 = d->c1; a->c2 = d->c2;
     a->h1 = d->h_src1; a->w1 = d->w_src1; a->gather1 = d->gather1;
@@ -2515,6 +2576,27 @@ int dispatch_split_planes(const Sel& s, F&& f) {
     if (s.nt == 1 && s.small) return p16 ? f(Tag<SplitCfg<3, 1, 16, 2, NPL>>{}) : f(Tag<SplitCfg<3, 1, 32, 2, NPL>>{});
     if (s.nt == 1) return p16 ? f(Tag<SplitCfg<3, 1, 16, 0, NPL>>{}) : f(Tag<SplitCfg<3, 1, 32, 0, NPL>>{});
     return p16 ? f(Tag<SplitCfg<3, 2, 16, 0, NPL>>{}) : f(Tag<SplitCfg<3, 2, 32, 0, NPL>>{});
+}
+
+// configurations that exist with the BatchNorm-backward sums in the epilogue (rcf_conv_info.bn_bwd_sums): fp32 tensors, two fp16
+// planes, 3x3 stride 1 and 2x2 (the four-phase input gradient of an up-2x convolution in one launch)
+bool split_bst_ok(const Sel& s) {
+    return !SAct::B16 && s.split && !s.bf16 && s.npl == 2 && (s.kind == K3S1 || s.kind == K2S1);
+}
+template <class F>
+int dispatch_split_bst(const Sel& s, F&& f) {
+    if constexpr (!SAct::B16) {
+        if (!split_bst_ok(s)) return RCF_EUNSUPPORTED;
+        const bool p16 = s.px == 16;
+        if (s.kind == K2S1) {
+            if (s.nt == 1) return p16 ? f(Tag<SplitCfg<2, 1, 16, 0, 2>>{}) : f(Tag<SplitCfg<2, 1, 32, 0, 2>>{});
+            return p16 ? f(Tag<SplitCfg<2, 2, 16, 0, 2>>{}) : f(Tag<SplitCfg<2, 2, 32, 0, 2>>{});
+        }
+        if (s.nt == 1 && s.small) return p16 ? f(Tag<SplitCfg<3, 1, 16, 2, 2>>{}) : f(Tag<SplitCfg<3, 1, 32, 2, 2>>{});
+        if (s.nt == 1) return p16 ? f(Tag<SplitCfg<3, 1, 16, 0, 2>>{}) : f(Tag<SplitCfg<3, 1, 32, 0, 2>>{});
+        return p16 ? f(Tag<SplitCfg<3, 2, 16, 0, 2>>{}) : f(Tag<SplitCfg<3, 2, 32, 0, 2>>{});
+    }
+    return RCF_EUNSUPPORTED;
 }
 
 template <class F>
@@ -2702,6 +2784,14 @@ extern "C" int rcf_phase_wgrad_gather_s2(const float* dwp, float* dw_oihw, int o
 }
 #endif
 
+// may this descriptor's launch take the BatchNorm-backward sums of the block whose output gradient it writes?  It must write every
+// element of a plain NHWC tensor exactly once (or add to it as the LAST writer: the caller's business), on a kernel that has the
+// epilogue (split_bst_ok), with one source (an input gradient has one) and no statistics of its own
+static bool bn_sums_ok(const rcf_conv_desc* d, const Sel& s) {
+    return split_bst_ok(s) && d->c2 == 0 && d->out_stride == 1 && d->out_off_y == 0 && d->out_off_x == 0 &&
+           d->out_h_phys == d->h_out && d->out_w_phys == d->w_out;
+}
+
 extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* info) {
     RCF_TO_B16(d, rcf_conv2d_query_b16impl(d, info));
     if (!info) return RCF_EINVAL;
@@ -2729,6 +2819,7 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
     info->bn_on_load = (s.split && !s.dma && !s.pw && d->w_mode == RCF_W_FORWARD && d->c1 + d->c2 <= 512 && s.npl != 2) ? 1 : 0;   // a DMA cannot transform; fp16 planes need the maximum of the TRANSFORMED tensor
     info->wgrad_bn_on_load = 0;
     info->fwd_act = (s.split && !s.pw && d->w_mode == RCF_W_FORWARD && !d->accumulate) ? 1 : 0;
+    info->bn_bwd_sums = bn_sums_ok(d, s) ? 1 : 0;
     if (d->w_mode == RCF_W_FORWARD) {
         WSel w;
         if (select_wgrad(d, &w) == RCF_OK) {
@@ -2831,7 +2922,8 @@ extern "C" int RCF_FN(rcf_conv2d_pack_weights_batch)(const rcf_pack_item* items,
 }
 
 static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
-                           const float* packed, float* out, double* stat_partials, void* stream, const rcf_conv_scales* sc = nullptr);
+                           const float* packed, float* out, double* stat_partials, void* stream, const rcf_conv_scales* sc = nullptr,
+                           const float* bn_z = nullptr, const float* bn_coef = nullptr);
 
 extern "C" int RCF_FN(rcf_conv2d_fwd)(const rcf_conv_desc* d, const void* in1, const void* in2, const float* packed, void* out,
                                       double* stat_partials, void* stream) {
@@ -2852,10 +2944,19 @@ extern "C" int rcf_conv2d_fwd_scaled(const rcf_conv_desc* d, const void* in1, co
     if (d != nullptr && (d->storage == RCF_STORE_BF16 || d->precision != RCF_PREC_F16X2)) return RCF_EUNSUPPORTED;
     return conv2d_fwd_impl(d, (const float*)in1, nullptr, (const float*)in2, nullptr, packed, (float*)out, stat_partials, stream, scales);
 }
+
+extern "C" int rcf_conv2d_dgrad_bn_sums(const rcf_conv_desc* d, const void* dz, const float* packed, void* dx, const void* bn_z,
+                                        const float* bn_coef, double* sum_partials, const rcf_conv_scales* scales, void* stream) {
+    if (!bn_z || !bn_coef || !sum_partials) return RCF_EINVAL;
+    if (d != nullptr && (d->storage == RCF_STORE_BF16 || d->precision != RCF_PREC_F16X2)) return RCF_EUNSUPPORTED;
+    return conv2d_fwd_impl(d, (const float*)dz, nullptr, nullptr, nullptr, packed, (float*)dx, sum_partials, stream, scales,
+                           (const float*)bn_z, bn_coef);
+}
 #endif
 
 static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
-                           const float* packed, float* out, double* stat_partials, void* stream, const rcf_conv_scales* sc) {
+                           const float* packed, float* out, double* stat_partials, void* stream, const rcf_conv_scales* sc,
+                           const float* bn_z, const float* bn_coef) {
     if (!in1 || !packed || !out) return RCF_EINVAL;
     Sel s;
     int rc = select_cfg(d, &s);
@@ -2885,6 +2986,11 @@ static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float
     if (s.dma) return RCF_EUNSUPPORTED;   // rcf_conv_info.bn_on_load is 0 for these descriptors (the tile geometry differs)
 #endif
     if (s.kind == K4S1 && SAct::B16) return RCF_EUNSUPPORTED;
+    if (bn_z != nullptr) {   // rcf_conv_info.bn_bwd_sums: an input-gradient launch over a plain (unit-stride, whole) output tensor
+        if (!bn_sums_ok(d, s)) return RCF_EUNSUPPORTED;
+        a.bz = bn_z; a.bk = bn_coef;
+        return dispatch_split_bst(s, [&](auto tag) { return launch_split_bst<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
+    }
     if (s.split) return dispatch_split(s, [&](auto tag) { return launch_split<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
     return dispatch_fwd(s, [&](auto tag) { return launch_fwd<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
 }
@@ -2966,6 +3072,7 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
     ConvArgs a;
     a.bias = nullptr; a.res = nullptr;
     a.amax_a1 = nullptr; a.amax_a2 = nullptr; a.amax_b = nullptr;
+    a.bz = nullptr; a.bk = nullptr;
     if (sc != nullptr) {
         if (!w.split || d->precision != RCF_PREC_F16X2) return RCF_EUNSUPPORTED;
         a.amax_a1 = sc->amax_in1; a.amax_a2 = d->c2 > 0 ? sc->amax_in2 : nullptr; a.amax_b = sc->amax_dz;

@@ -15,6 +15,8 @@ while they load z (the output head; with Engine.bn_on_load also the split conv /
 the tensor is never written; any other consumer materialises it once, on demand (Engine._mat).
 '''
 
+import os
+
 import torch
 
 from . import ops
@@ -142,7 +144,7 @@ BN_MOMENTUM = 0.1
 
 class Act(object):
     '''An activation tensor and (during backward) its gradient accumulator.'''
-    __slots__ = ('t', 'g', 'needs_grad', 'head_fusable', 'g_head', 'z', 'coef', 's2d', 'hw', 'amax')
+    __slots__ = ('t', 'g', 'needs_grad', 'head_fusable', 'g_head', 'z', 'coef', 's2d', 'hw', 'amax', 'bn', 'bsum')
 
     def __init__(self, t, needs_grad=True):
         self.t = t
@@ -155,6 +157,9 @@ class Act(object):
         self.s2d = None             # network input only (bf16 configuration): its space-to-depth image for the stem, and (H, W)
         self.hw = None
         self.amax = None            # two-plane fp16 arithmetic: device scalar holding max|t| (or an upper bound), from its producer
+        self.bn = None              # (z, coef) of the BatchNorm + lrelu block that produced t: an input-gradient kernel that is the
+        self.bsum = None            # only writer of g may leave that block's backward sums here, (partials, rows) -- any later
+                                    # writer of g clears them (stale)
 
 
 class Engine(object):
@@ -175,13 +180,16 @@ class Engine(object):
         # bn_act_fwd pass (-2.4 ms/step) but costs the matrix kernels more in their staging path (+3.6 ms measured): off.  The
         # output head, an HBM-bound kernel with idle VALU, always consumes its input this way.
         self.bn_on_load = False
+        # BatchNorm-backward sums in the epilogue of the input-gradient kernel that writes dY (RCF_BN_SUMS_IN_DGRAD=0: always the
+        # separate reduction pass)
+        self.bn_sums_in_dgrad = os.environ.get('RCF_BN_SUMS_IN_DGRAD', '1') != '0'
+        self.bn_sums_taken = 0   # launches that took the sums since construction (tests; a counter, nothing reads it back)
         # inference (eval mode, no tape): BatchNorm folded into the conv weights, bias + LeakyReLU (+ residual) in the split kernels'
         # epilogue (rcf_conv2d_fwd_act): no z tensor and no BN pass for those layers
         self.fuse_eval = True
         # 3x3 stride-2 weight gradients as four 2x2 phase weight gradients on the bf16 matrix pipe (16 taps computed for 9 used):
         # 3.5x faster than the register-staged f32-MFMA kernel with bf16 tensors, 1 % slower than the LDS-DMA f32-MFMA kernel with
         # fp32 tensors (measured) -- so: None = only in the bf16 configuration; RCF_S2_WGRAD_PHASES=0/1 overrides
-        import os
         e = os.environ.get('RCF_S2_WGRAD_PHASES')
         self.s2_wgrad_phases = None if e is None else (e != '0')
         if os.environ.get('RCF_BN_ON_LOAD') is not None:
@@ -613,6 +621,8 @@ class Engine(object):
         self._wgrad_done(weight)
         if x.needs_grad:
             acc = x.g is not None
+            if acc:
+                x.bsum = None
             if not acc:
                 x.g = self._new(tuple(self._shape(x)), dz)
             dd = ops.make_fwd_desc(virt.n, virt.h_in, virt.w_in, virt.c1, 0, virt.c_out, 3, 2)
@@ -644,6 +654,8 @@ class Engine(object):
         if x.needs_grad:
             wd = self._phase_w(weight.detach(), RCF_PHASE_UP2X_DGRAD)
             acc = x.g is not None
+            if acc:
+                x.bsum = None
             if not acc:
                 x.g = self._new(tuple(self._shape(x)), dz)
             dd = self._exact_unless(ops.make_up2x_dgrad_desc(n, h, w, c1, co, 0, 0, acc, phase_sum=True), dz_amax)
@@ -657,7 +669,8 @@ class Engine(object):
                 packed = self._pack_n(dd, [wd[ph] for ph in range(4)], dz)
             if self.prof is not None:
                 self.prof.begin(qi.kernel_id, ops.algorithmic_flops(dd), dd)
-            ops.conv_fwd(dd, dz, None, packed, x.g, None, scales=scales)
+            if not self._bn_sums_launch(dd, qi, dz, packed, x.g, scales, None if acc else x):
+                ops.conv_fwd(dd, dz, None, packed, x.g, None, scales=scales)
             if self.prof is not None:
                 self.prof.end()
 
@@ -723,12 +736,16 @@ class Engine(object):
                 tmp = self._new((desc.n, desc.h_in, desc.w_in, cnt), dz)
                 self._run_dgrad(dd, weight, dz, tmp, dz_amax)
                 acc = src.g is not None
+                if acc:
+                    src.bsum = None
                 if not acc:
                     src.g = self._new(tuple(self._shape(src)), dz)
                 ops.upsample_nearest_bwd(tmp, src.g, acc)
             elif self.use_phase_convs and desc.stride == 2 and desc.ksize == 3 and x2 is None and desc.c1 % 4 == 0:
                 # transposed convolution in 4 phases (16 of the 36 zero-dilated taps are real)
                 acc = src.g is not None
+                if acc:
+                    src.bsum = None
                 if not acc:
                     src.g = self._new(tuple(self._shape(src)), dz)
                 wd = self._phase_w(weight.detach(), RCF_PHASE_S2_DGRAD)
@@ -740,12 +757,28 @@ class Engine(object):
                     self._run_packed(d, wd[ph], dz, src.g, amax_in=dz_amax, amax_w=wmax)
             else:
                 acc = src.g is not None
+                if acc:
+                    src.bsum = None
                 if not acc:
                     src.g = self._new(tuple(self._shape(src)), dz)
                 dd = ops.make_dgrad_desc(desc, off, cnt, acc)
-                self._run_dgrad(dd, weight, dz, src.g, dz_amax)
+                self._run_dgrad(dd, weight, dz, src.g, dz_amax, sums_for=None if acc else src)
 
-    def _run_dgrad(self, dd, weight, dz, out, dz_amax=None):
+    def _bn_sums_launch(self, dd, info, dz, packed, out, scales, sums_for):
+        '''The input-gradient launch `dd` writes sums_for.g for the first time.  If sums_for is the output of a BatchNorm + lrelu block
+        and the kernel has the epilogue, it also takes that block's backward sums (no bn_act_bwd_reduce pass over dY and z later --
+        unless another consumer adds into the gradient afterwards, which clears Act.bsum again).  -> True if it launched.'''
+        if (sums_for is None or sums_for.bn is None or scales is None or not self.bn_sums_in_dgrad or not info.bn_bwd_sums
+                or tuple(sums_for.bn[0].shape) != tuple(out.shape)):
+            return False
+        z, coef = sums_for.bn
+        part = torch.empty((info.n_partials, 2, dd.c_out), dtype=torch.float64, device=out.device)
+        ops.conv_dgrad_bn_sums(dd, dz, packed, out, z, coef, part, scales)
+        sums_for.bsum = (part, info.n_partials)
+        self.bn_sums_taken += 1
+        return True
+
+    def _run_dgrad(self, dd, weight, dz, out, dz_amax=None, sums_for=None):
         dd = self._exact_unless(dd, dz_amax)
         info = ops.conv_query(dd)
         scales = None
@@ -757,7 +790,8 @@ class Engine(object):
             packed = self._pack(dd, weight.detach(), dz)
         if self.prof is not None:
             self.prof.begin(info.kernel_id, ops.algorithmic_flops(dd), dd)
-        ops.conv_fwd(dd, dz, None, packed, out, None, scales=scales)
+        if not self._bn_sums_launch(dd, info, dz, packed, out, scales, sums_for):
+            ops.conv_fwd(dd, dz, None, packed, out, None, scales=scales)
         if self.prof is not None:
             self.prof.end()
 
@@ -815,6 +849,8 @@ class Engine(object):
             out = Act(torch.empty_like(z))
             out.amax = self._amax_slot() if z.dtype == torch.float32 else None
             ops.bn_act_fwd(z, coef, None if res is None else self._mat(res), out.t, n_pix, c, RCF_ACT_LEAKY_RELU, amax=out.amax)
+            if res is None and self.tape is not None and z.dtype == torch.float32:
+                out.bn = (z, coef)
         out.head_fusable = res is None
         if self.tape is not None:
             bn = layer.batch_norm
@@ -841,10 +877,14 @@ class Engine(object):
                     self._conv_backward(layer, desc, info, x, x2, dz, dz_amax)
                     return
                 dout = out.g
-                nb = ops.ew_blocks(n_pix, c)
-                bpart = torch.empty((nb, 2, c), dtype=torch.float64, device=z.device)
                 has_res = res is not None   # out.t is read only then (a deferred activation has no residual)
-                ops.bn_act_bwd_reduce(dout, z, coef, out.t, bpart, n_pix, c, RCF_ACT_LEAKY_RELU, has_res)
+                if out.bsum is not None:    # the kernel that wrote dout took the sums on its way (Engine._bn_sums_launch)
+                    bpart, nb = out.bsum
+                    out.bsum = None
+                else:
+                    nb = ops.ew_blocks(n_pix, c)
+                    bpart = torch.empty((nb, 2, c), dtype=torch.float64, device=z.device)
+                    ops.bn_act_bwd_reduce(dout, z, coef, out.t, bpart, n_pix, c, RCF_ACT_LEAKY_RELU, has_res)
                 bcoef = self._newf((2, c), z)
                 ops.bn_bwd_finalize(bpart, nb, 2 * c, c, n_pix, bcoef, self.grad_of(bn.weight), self.grad_of(bn.bias))
                 if not batch_stats:
@@ -854,6 +894,8 @@ class Engine(object):
                 dres, dres_acc = None, False
                 if has_res and res.needs_grad:
                     dres_acc = res.g is not None
+                    if dres_acc:
+                        res.bsum = None
                     if not dres_acc:
                         res.g = torch.empty_like(res.t)
                     dres = res.g
@@ -918,6 +960,8 @@ class Engine(object):
                 dimg, dimg_acc = None, False
                 if img.needs_grad:
                     dimg_acc = img.g is not None
+                    if dimg_acc:
+                        img.bsum = None
                     if not dimg_acc:
                         img.g = torch.empty_like(img.t)
                     dimg = img.g
@@ -941,6 +985,8 @@ class Engine(object):
         if self.tape is not None:
             def backward():
                 acc = x.g is not None
+                if acc:
+                    x.bsum = None
                 if not acc:
                     x.g = torch.empty_like(x.t)
                 ops.maxpool_bwd(out.g, idx, x.g, acc)
@@ -1076,6 +1122,7 @@ class Engine(object):
             def backward():
                 if x.needs_grad and out.g is not None:
                     if xt.dtype == torch.float32:
+                        x.bsum = None
                         if x.g is None:
                             x.g = torch.zeros_like(xt)   # rois overlap: scatter-add; later consumers accumulate on top
                         ops.roi_pool_bwd(out.g, argmax, rois, x.g, out_hw, dout_coff=coff)
@@ -1083,6 +1130,8 @@ class Engine(object):
                         tmp = torch.zeros(xt.shape, dtype=torch.float32, device=xt.device)
                         ops.roi_pool_bwd(out.g, argmax, rois, tmp, out_hw, dout_coff=coff)
                         acc = x.g is not None
+                        if acc:
+                            x.bsum = None
                         if not acc:
                             x.g = torch.empty_like(xt)
                         ops.convert(tmp, x.g, accumulate=acc)

@@ -379,6 +379,113 @@ def test_up2x_conv_as_four_phase_convs(ops, cin, cout, n, hs, ws):
         ops.set_precision('fp32')
 
 
+def _bn_coef(c, seed):
+    '''[4][c]: scale, shift, mean, invstd of a BatchNorm layer (rcf_bn_finalize's coefficient rows), with both signs of scale.'''
+    g = torch.Generator().manual_seed(seed)
+    gamma = torch.rand(c, generator=g) * 2 - 1
+    beta = torch.rand(c, generator=g) - 0.5
+    mean = torch.rand(c, generator=g) - 0.5
+    invstd = 0.5 + 2 * torch.rand(c, generator=g)
+    return torch.stack([gamma * invstd, beta - mean * gamma * invstd, mean, invstd]).contiguous().cuda()
+
+
+# (ksize-kind, c_in of the forward conv = channels of dx, c_out of the forward conv, n, h, w)
+SUMS_CASES = [('3x3', 64, 64, 2, 33, 64), ('3x3', 32, 32, 1, 70, 102), ('3x3', 32, 64, 2, 17, 40), ('3x3', 256, 256, 2, 8, 13),
+              ('3x3', 128, 64, 1, 29, 50), ('up2x', 64, 32, 1, 35, 51), ('up2x', 64, 64, 2, 12, 20)]
+
+
+@pytest.mark.parametrize('case', SUMS_CASES, ids=[str(c) for c in SUMS_CASES])
+def test_input_gradient_kernel_takes_the_batchnorm_backward_sums(ops, case):
+    '''rcf_conv2d_dgrad_bn_sums: the input gradient dx of a convolution whose input was the activation of a BatchNorm + LeakyReLU
+    block, written together with that block's backward sums -- against the two-launch form (rcf_conv2d_fwd_scaled, then
+    rcf_bn_act_bwd_reduce over dx and z): dx bitwise the same, the sums (fp64, another order) and everything rcf_bn_bwd_finalize
+    derives from them equal to fp64 rounding; plus an fp64 host evaluation of the sums.'''
+    from rcf_amd._lib import RCF_ACT_LEAKY_RELU, RCF_PHASE_UP2X_DGRAD
+    kind, ci, co, n, h, w = case
+    ops.set_precision('f16x2')
+    try:
+        wt = rnd(co, ci, 3, 3, seed=11, scale=1.0 / np.sqrt(ci * 9)).cuda()
+        if kind == '3x3':
+            d = ops.make_fwd_desc(n, h, w, ci, 0, co, 3, 1)
+            dd = ops.make_dgrad_desc(d, 0, ci, False)
+            dz = nhwc(rnd(n, co, h, w, seed=12))
+            wsrc = [wt]
+        else:   # the four phases of the up-2x input gradient summed in one launch
+            dd = ops.make_up2x_dgrad_desc(n, h, w, ci, co, 0, 0, False, phase_sum=True)
+            dz = nhwc(rnd(n, co, 2 * h, 2 * w, seed=12))
+            wph = ops.phase_weights(wt, RCF_PHASE_UP2X_DGRAD)
+            wsrc = [wph[ph] for ph in range(4)]
+        info = ops.conv_query(dd)
+        assert info.bn_bwd_sums == 1 and 40000 <= info.kernel_id < 50000
+        aw = ops.amax(wt if kind == '3x3' else wph)
+        adz = ops.amax(dz)
+        packed = torch.empty(len(wsrc) * info.packed_weight_floats, device='cuda')
+        for i, wsl in enumerate(wsrc):
+            ops.conv_pack(dd, wsl, packed[i * info.packed_weight_floats:(i + 1) * info.packed_weight_floats], aw)
+        scales = ops.make_scales(adz, None, aw)
+        z = nhwc(rnd(n, ci, h, w, seed=13))
+        coef = _bn_coef(ci, 14)
+        n_pix = n * h * w
+        # two launches
+        dx_ref = torch.full((n, h, w, ci), float('nan'), device='cuda')
+        ops.conv_fwd(dd, dz, None, packed, dx_ref, None, scales=scales)
+        nb = ops.ew_blocks(n_pix, ci)
+        part_ref = torch.empty((nb, 2, ci), dtype=torch.float64, device='cuda')
+        ops.bn_act_bwd_reduce(dx_ref, z, coef, None, part_ref, n_pix, ci, RCF_ACT_LEAKY_RELU, False)
+        # one launch
+        dx = torch.full((n, h, w, ci), float('nan'), device='cuda')
+        part = torch.full((info.n_partials, 2, ci), float('nan'), dtype=torch.float64, device='cuda')
+        ops.conv_dgrad_bn_sums(dd, dz, packed, dx, z, coef, part, scales)
+        torch.cuda.synchronize()
+        assert torch.equal(dx, dx_ref)
+        s_ref, s_new = part_ref.sum(0), part.sum(0)
+        # fp64 host evaluation of the two sums from dx
+        g = dx.double() * torch.where(z * coef[0] + coef[1] > 0, 1.0, 0.2)   # src/net_utils.py:16 negative_slope 0.20; the sign test in fp32 like the kernels'
+        xh = (z.double() - coef[2].double()) * coef[3].double()
+        want = torch.stack([g.sum((0, 1, 2)), (g * xh).sum((0, 1, 2))])
+        mag = torch.stack([g.abs().sum((0, 1, 2)), (g * xh).abs().sum((0, 1, 2))])
+        assert float(((s_new - want).abs() / mag).max()) < 1e-6      # y and xhat are formed in fp32 by both kernels
+        assert float(((s_new - s_ref).abs() / mag).max()) < 2e-7     # the reduce pass rounds xhat to fp32 per term, the epilogue does not
+        outs = []
+        for pt, rows in ((part_ref, nb), (part, info.n_partials)):
+            bcoef = torch.empty((2, ci), device='cuda')
+            dgam, dbet = torch.empty(ci, device='cuda'), torch.empty(ci, device='cuda')
+            ops.bn_bwd_finalize(pt, rows, 2 * ci, ci, n_pix, bcoef, dgam, dbet)
+            outs.append((bcoef, dgam, dbet))
+        for a_, b_ in zip(outs[0], outs[1]):
+            assert float((a_ - b_).abs().max()) <= 1e-6 * float(b_.abs().max())
+    finally:
+        ops.set_precision('fp32')
+
+
+def test_batchnorm_backward_sums_entry_point_rejects_what_it_cannot_do(ops):
+    '''bn_bwd_sums is 0 (and the call answers RCF_EUNSUPPORTED) for strided phase outputs, concat sources, other arithmetic.'''
+    from rcf_amd import _lib
+    ops.set_precision('f16x2')
+    try:
+        d = ops.make_fwd_desc(1, 16, 24, 32, 0, 64, 3, 2)
+        s2 = ops.make_s2_dgrad_desc(d, 0, 1, False)                  # one strided phase of a stride-2 input gradient
+        assert ops.conv_query(s2).bn_bwd_sums == 0
+        cat = ops.make_fwd_desc(1, 16, 24, 32, 32, 64, 3, 1)         # two sources
+        assert ops.conv_query(cat).bn_bwd_sums == 0
+        pw = ops.make_dgrad_desc(ops.make_fwd_desc(1, 16, 24, 32, 0, 64, 1, 1), 0, 32, False)   # 1x1: not a split kernel
+        assert ops.conv_query(pw).bn_bwd_sums == 0
+    finally:
+        ops.set_precision('fp32')
+    ops.set_precision('fp32')   # ops level: the three-plane arithmetic
+    try:
+        d3 = ops.make_dgrad_desc(ops.make_fwd_desc(1, 16, 24, 32, 0, 64, 3, 1), 0, 32, False)
+        assert ops.conv_query(d3).bn_bwd_sums == 0
+        info = ops.conv_query(d3)
+        t = torch.zeros(1, 16, 24, 64, device='cuda')
+        dx = torch.zeros(1, 16, 24, 32, device='cuda')
+        with pytest.raises(_lib.RcfError):
+            ops.conv_dgrad_bn_sums(d3, t, torch.zeros(info.packed_weight_floats, device='cuda'), dx, dx, torch.zeros(4, 32, device='cuda'),
+                                   torch.zeros(info.n_partials, 2, 32, dtype=torch.float64, device='cuda'), ops.make_scales(None, None, None))
+    finally:
+        ops.set_precision('fp32')
+
+
 @pytest.mark.parametrize('c,co,n,h,w', [(3, 32, 2, 70, 102), (2, 16, 1, 45, 81), (3, 32, 1, 224, 384)])
 def test_stem_7x7_stride2_as_4x4_on_the_fp32_space_to_depth_image(ops, c, co, n, h, w):
     '''The stems of the fp32 configuration (src/networks.py:332-345: 7x7, stride 2, pad 3, 3 / 2 input channels) as a 4x4 stride-1
@@ -469,6 +576,42 @@ def test_published_net_train_step_against_the_reference_fixture(env, golden_dir,
         worst = max(worst, abs(got - l2) / max(l2, 1e-6))
     print('worst parameter-gradient norm deviation: %.2e' % worst)
     assert worst < 1e-2
+
+
+@pytest.mark.parametrize('deconv', ['up', 'transpose'])
+def test_batchnorm_sums_from_the_input_gradient_kernels_in_the_published_net(env, golden_dir, deconv):
+    '''The published net's training step with the BatchNorm-backward sums taken by the input-gradient kernels (default) against the
+    same step with the separate reduction pass (Engine.bn_sums_in_dgrad = False): the path is really in use (one launch per eligible
+    block), outputs and loss bitwise the same (the forward does not change), every parameter gradient equal to fp64 rounding of the
+    sums -- and both hold the reference fixture's gradient norms.'''
+    synth, train = env
+    g = np.load(os.path.join(golden_dir, 'T1_published_train.npz' if deconv == 'up' else 'T10_transpose_published_train.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    runs = {}
+    for fused in (True, False):
+        m = train.build_model(synth.PUBLISHED, device='cuda', deconv_type=deconv)
+        synth.fill_state_dict_([m.encoder, m.decoder], wseed)
+        m.train()
+        m._engine.bn_sums_in_dgrad = fused
+        b = {kk: v.cuda() for kk, v in synth.make_batch(n, h, w, k, seed=dseed).items()}
+        out = m.forward(image=b['image'], input_depth=b['input_depth'])
+        loss, _ = m.compute_loss(image=b['image'], output_depth=out, ground_truth=b['ground_truth'], lidar_map=b['lidar_map'],
+                                 loss_func='l1', w_smoothness=0.0, loss_smoothness_kernel_size=-1,
+                                 validity_map_loss_smoothness=None, w_lidar_loss=2.0)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs[fused] = (out.detach().clone(), float(loss.detach()), {kk: p.grad.detach().clone() for kk, p in _named(m) if p.grad is not None},
+                       m._engine.bn_sums_taken)
+    print('launches that took the sums: %d (published net, deconv_type=%s)' % (runs[True][3], deconv))
+    assert runs[False][3] == 0
+    assert runs[True][3] >= (16 if deconv == 'up' else 8)   # conv1 of 16 ResNet blocks (+ the up-conv decoder's deconv / conv layers)
+    assert torch.equal(runs[True][0], runs[False][0]) and runs[True][1] == runs[False][1]
+    worst = max(rel(runs[True][2][kk], runs[False][2][kk]) for kk in runs[False][2])
+    print('worst parameter-gradient difference between the two forms: %.2e' % worst)
+    assert worst < 2e-5
+    for key, l2 in zip(g['grad_keys'].tolist(), g['grad_l2'].tolist()):
+        got = float(runs[True][2][key].double().norm())
+        assert abs(got - l2) < 1e-2 * max(l2, 1e-6)
 
 
 @pytest.mark.parametrize('kind', ['outlier_pixels', 'tiny_inputs', 'huge_inputs'])
