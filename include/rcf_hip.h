@@ -173,8 +173,8 @@ int rcf_conv2d_fwd_scaled(const rcf_conv_desc* d, const void* in1, const void* i
  * xhat = (bn_z - coef[2]) * coef[3] (bn_z: that block's raw conv output, same shape as dx; bn_coef: its rcf_bn_finalize
  * coefficients [4][c_out]), in sum_partials [n_partials][2][c_out] fp64 -- what rcf_bn_act_bwd_reduce would produce from a second
  * pass over dx and bn_z, ready for rcf_bn_bwd_finalize.  scales as for rcf_conv2d_fwd_scaled (nullable members = scale 1).
- * Only where rcf_conv_info.bn_bwd_sums is set (fp32 tensors, RCF_PREC_F16X2, 3x3 stride 1 / 2x2, plain output tensor);
- * RCF_EUNSUPPORTED otherwise. */
+ * Only where rcf_conv_info.bn_bwd_sums is set (3x3 stride 1 / 2x2 with a plain output tensor; fp32 tensors under RCF_PREC_F16X2, or
+ * bf16 tensors -- storage RCF_STORE_BF16: dz, dx and bn_z hold bf16, scales is ignored and may be null); RCF_EUNSUPPORTED otherwise. */
 int rcf_conv2d_dgrad_bn_sums(const rcf_conv_desc* d, const void* dz, const float* packed, void* dx, const void* bn_z,
                              const float* bn_coef, double* sum_partials, const rcf_conv_scales* scales, void* stream);
 /* BatchNorm + LeakyReLU of the PRODUCING block applied while the operand is staged ("BN on load"): in1 / in2 are raw conv

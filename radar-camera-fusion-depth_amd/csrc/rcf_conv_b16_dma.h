@@ -42,8 +42,12 @@ __device__ __forceinline__ unsigned rcf_dpp_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
 
-template <class C, bool EPI>
+// BST (an input-gradient launch that is the only writer of dY of a BatchNorm + LeakyReLU block, ConvArgs.bz / bk): instead of the
+// BatchNorm statistics of its own outputs the kernel leaves that block's backward sums, sum g and sum g * xhat, in `stats`
+// (conv_split_kernel<..., BST> does the same for fp32 tensors; rcf_conv2d_dgrad_bn_sums).
+template <class C, bool EPI, bool BST = false>
 __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
+    static_assert(!(EPI && BST), "the inference epilogue and the BatchNorm-backward sums exclude each other");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     // [A buf 0][A buf 1][B buf 0][B buf 1]
     const int tid = threadIdx.x;
@@ -247,8 +251,24 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
             const int ty = t % a.tiles_y;
             const int img = t / a.tiles_y;
             const int oy0 = ty * C::TH, ox0 = tx * C::PX;
-            const bool want_stats = !EPI && a.stats != nullptr;
+            const bool want_stats = !EPI && !BST && a.stats != nullptr;
             const int odd = li & 1;
+            float bk[BST ? 2 : 1][C::NT][2];   // BST: scale, shift of channels cp, cp + 1
+            if constexpr (BST) {
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni) {
+                    const int cp = (n0 + ni * 32 + li) & ~1;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        bk[e][ni][0] = a.bk[e * a.c_out + (cp < a.c_out ? cp : 0)];
+                        bk[e][ni][1] = a.bk[e * a.c_out + (cp + 1 < a.c_out ? cp + 1 : 0)];
+                    }
+                }
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(bk[e][ni][0]), "+v"(bk[e][ni][1]));
+            }
             unsigned short* outp = reinterpret_cast<unsigned short*>(a.out);
             const unsigned short* addp = reinterpret_cast<const unsigned short*>(EPI ? a.res : a.out);
             const bool do_add = EPI ? a.res != nullptr : a.accumulate != 0;
@@ -301,6 +321,7 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                             pbs[(r0 + jp) >> 1] = base0 + (size_t)(jm * pstep);
                         }
                     }
+                    unsigned zw[BST ? 8 : 1][C::NT];   // BST: z of the BatchNorm block at this lane's stores (two bf16 per dword)
                     unsigned oldw[8][C::NT];
                     if (ADD) {
 #pragma unroll
@@ -317,8 +338,26 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
 #pragma unroll
                             for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(oldw[g][ni]));
                     }
+                    // BST: the z values of GB pixel pairs at a time (all eight at once cost 8 x NT registers)
+                    constexpr int GB = 4;
 #pragma unroll
-                    for (int g = 0; g < 8; ++g) {
+                    for (int gh = 0; gh < 8 / GB; ++gh) {
+                    if constexpr (BST) {
+                        const unsigned short* zp = reinterpret_cast<const unsigned short*>(a.bz);
+#pragma unroll
+                        for (int g = GB * gh; g < GB * gh + GB; ++g)
+#pragma unroll
+                            for (int ni = 0; ni < C::NT; ++ni) {
+                                const int cp = (n0 + ni * 32 + li) & ~1;
+                                zw[g][ni] = *reinterpret_cast<const unsigned*>(zp + ((poks[g] && cp < a.c_out) ? pbs[g] + cp : 0));
+                            }
+#pragma unroll
+                        for (int g = GB * gh; g < GB * gh + GB; ++g)   // one wait for these here (see `oldw`)
+#pragma unroll
+                            for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(zw[g][ni]));
+                    }
+#pragma unroll
+                    for (int g = GB * gh; g < GB * gh + GB; ++g) {
                         const int rj = 2 * g;   // accumulator row of the pair's first pixel
 #pragma unroll
                         for (int ni = 0; ni < C::NT; ++ni) {
@@ -348,6 +387,14 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                             const unsigned pk = rcf_f2b2(lo, hi);
                             if (ok) {
                                 *reinterpret_cast<unsigned*>(outp + pbs[g] + cp) = pk;
+                                if constexpr (BST) {   // of the gradient the tensor holds: g = dY * lrelu'(z * scale + shift); sum g, sum g * z
+                                    const float rlo = __uint_as_float(pk << 16), rhi = __uint_as_float(pk & 0xffff0000u);
+                                    const float zlo = __uint_as_float(zw[g][ni] << 16), zhi = __uint_as_float(zw[g][ni] & 0xffff0000u);
+                                    const float glo = rlo * rcf_lrelu_grad(zlo * bk[0][ni][0] + bk[1][ni][0]);
+                                    const float ghi = rhi * rcf_lrelu_grad(zhi * bk[0][ni][1] + bk[1][ni][1]);
+                                    s1[ni][0] += glo; s2[ni][0] += glo * zlo;
+                                    s1[ni][1] += ghi; s2[ni][1] += ghi * zhi;
+                                }
                                 if (want_stats) {   // of the values the tensor holds
                                     const float rlo = __uint_as_float(pk << 16), rhi = __uint_as_float(pk & 0xffff0000u);
                                     s1[ni][0] += rlo; s2[ni][0] += rlo * rlo;
@@ -356,7 +403,8 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                             }
                         }
                     }
-                    if (want_stats) {
+                    }
+                    if (want_stats || BST) {
 #pragma unroll
                         for (int ni = 0; ni < C::NT; ++ni)
 #pragma unroll
@@ -407,6 +455,8 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                     t1 += red[(w * C::BN + tid) * 2 + 0];
                     t2 += red[(w * C::BN + tid) * 2 + 1];
                 }
+                // BST: sum g * xhat = invstd * (sum g * z - mean * sum g), in fp64 from this workgroup's sums
+                if constexpr (BST) t2 = (double)a.bk[3 * a.c_out + co] * (t2 - (double)a.bk[2 * a.c_out + co] * t1);
                 a.stats[((size_t)blockIdx.x * 2 + 0) * a.c_out + co] = t1;
                 a.stats[((size_t)blockIdx.x * 2 + 1) * a.c_out + co] = t2;
             }
@@ -437,6 +487,19 @@ template <class C, bool EPI = false>
 int launch_dma(const ConvArgs& a, int ntile_n, hipStream_t st) {
     const int gx = dma_grid_x<C>(a.ntiles, ntile_n);
     hipLaunchKernelGGL((conv_b16_kernel<C, EPI>), dim3(gx, ntile_n, 1), dim3(256), C::LDS_BYTES, st, a);
+    return rcf_launch_status();
+}
+
+template <class C>
+int launch_dma_bst(const ConvArgs& a, int ntile_n, hipStream_t st) {
+    const int gx = dma_grid_x<C>(a.ntiles, ntile_n);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b16_kernel<C, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C::LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_b16_kernel<C, false, true>), dim3(gx, ntile_n, 1), dim3(256), C::LDS_BYTES, st, a);
     return rcf_launch_status();
 }
 

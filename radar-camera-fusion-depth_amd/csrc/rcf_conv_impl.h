@@ -2581,7 +2581,13 @@ int dispatch_split_planes(const Sel& s, F&& f) {
 // configurations that exist with the BatchNorm-backward sums in the epilogue (rcf_conv_info.bn_bwd_sums): fp32 tensors, two fp16
 // planes, 3x3 stride 1 and 2x2 (the four-phase input gradient of an up-2x convolution in one launch)
 bool split_bst_ok(const Sel& s) {
-    return !SAct::B16 && s.split && !s.bf16 && s.npl == 2 && (s.kind == K3S1 || s.kind == K2S1);
+#if RCF_CONV_B16
+    // conv_b16_kernel<C, false, true>; not the 64-co x 32-pixel-row 3x3 configuration, whose epilogue sits at the register limit (the
+    // sums would spill 3-8 VGPRs there: those layers keep the reduction pass)
+    return s.dma && !s.pw && (s.kind == K2S1 || (s.kind == K3S1 && !(s.nt == 2 && s.px == 32)));
+#else
+    return s.split && !s.bf16 && s.npl == 2 && (s.kind == K3S1 || s.kind == K2S1);
+#endif
 }
 template <class F>
 int dispatch_split_bst(const Sel& s, F&& f) {
@@ -2720,6 +2726,8 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
     if ((d) != nullptr && (d)->storage == RCF_STORE_BF16) return call
 extern "C" {
 int rcf_conv2d_query_b16impl(const rcf_conv_desc* d, rcf_conv_info* info);
+int rcf_conv2d_dgrad_bn_sums_b16impl(const rcf_conv_desc* d, const void* dz, const float* packed, void* dx, const void* bn_z,
+                                     const float* bn_coef, double* sum_partials, const rcf_conv_scales* scales, void* stream);
 int rcf_conv2d_pack_weights_b16impl(const rcf_conv_desc* d, const float* w_oihw, float* packed, void* stream);
 int rcf_conv2d_fwd_b16impl(const rcf_conv_desc* d, const void* in1, const void* in2, const float* packed, void* out, double* stat_partials,
                            void* stream);
@@ -2944,15 +2952,21 @@ extern "C" int rcf_conv2d_fwd_scaled(const rcf_conv_desc* d, const void* in1, co
     if (d != nullptr && (d->storage == RCF_STORE_BF16 || d->precision != RCF_PREC_F16X2)) return RCF_EUNSUPPORTED;
     return conv2d_fwd_impl(d, (const float*)in1, nullptr, (const float*)in2, nullptr, packed, (float*)out, stat_partials, stream, scales);
 }
+#endif
 
-extern "C" int rcf_conv2d_dgrad_bn_sums(const rcf_conv_desc* d, const void* dz, const float* packed, void* dx, const void* bn_z,
-                                        const float* bn_coef, double* sum_partials, const rcf_conv_scales* scales, void* stream) {
+extern "C" int RCF_FN(rcf_conv2d_dgrad_bn_sums)(const rcf_conv_desc* d, const void* dz, const float* packed, void* dx, const void* bn_z,
+                                                const float* bn_coef, double* sum_partials, const rcf_conv_scales* scales, void* stream) {
+    RCF_TO_B16(d, rcf_conv2d_dgrad_bn_sums_b16impl(d, dz, packed, dx, bn_z, bn_coef, sum_partials, scales, stream));
     if (!bn_z || !bn_coef || !sum_partials) return RCF_EINVAL;
-    if (d != nullptr && (d->storage == RCF_STORE_BF16 || d->precision != RCF_PREC_F16X2)) return RCF_EUNSUPPORTED;
+#if RCF_CONV_B16
+    if (d != nullptr && d->precision != RCF_PREC_BF16) return RCF_EUNSUPPORTED;
+    scales = nullptr;   // bf16 operands carry no per-tensor scale
+#else
+    if (d != nullptr && d->precision != RCF_PREC_F16X2) return RCF_EUNSUPPORTED;
+#endif
     return conv2d_fwd_impl(d, (const float*)dz, nullptr, nullptr, nullptr, packed, (float*)dx, sum_partials, stream, scales,
                            (const float*)bn_z, bn_coef);
 }
-#endif
 
 static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float* coef1, const float* in2, const float* coef2,
                            const float* packed, float* out, double* stat_partials, void* stream, const rcf_conv_scales* sc,
@@ -2980,6 +2994,19 @@ static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float
     if (s.pw) {
         if (coef1 || coef2) return RCF_EUNSUPPORTED;
         return dispatch_pw(d->c1 / 16, s.nt, [&](auto cfg) { return launch_pw<decltype(cfg)>(a, (hipStream_t)stream); });
+    }
+    if (s.dma && bn_z != nullptr) {   // rcf_conv_info.bn_bwd_sums
+        if (!bn_sums_ok(d, s) || coef1 || coef2) return RCF_EUNSUPPORTED;
+        a.bz = bn_z; a.bk = bn_coef;
+        const bool p16 = s.px == 16;
+        hipStream_t st = (hipStream_t)stream;
+        if (s.kind == K2S1) {
+            if (s.nt == 1) return p16 ? launch_dma_bst<D2_1_16>(a, nn, st) : launch_dma_bst<D2_1_32>(a, nn, st);
+            return p16 ? launch_dma_bst<D2_2_16>(a, nn, st) : launch_dma_bst<D2_2_32>(a, nn, st);
+        }
+        if (s.nt == 1 && s.small) return p16 ? launch_dma_bst<D3_1_16s>(a, nn, st) : launch_dma_bst<D3_1_32s>(a, nn, st);
+        if (s.nt == 1) return p16 ? launch_dma_bst<D3_1_16>(a, nn, st) : launch_dma_bst<D3_1_32>(a, nn, st);
+        return launch_dma_bst<D3_2_16>(a, nn, st);   // (split_bst_ok: px == 16 here)
     }
     if (s.dma && !coef1 && !coef2)
         return dispatch_dma(s, [&](auto tag) { return launch_dma<typename decltype(tag)::type, false>(a, nn, (hipStream_t)stream); });

@@ -768,8 +768,8 @@ class Engine(object):
         '''The input-gradient launch `dd` writes sums_for.g for the first time.  If sums_for is the output of a BatchNorm + lrelu block
         and the kernel has the epilogue, it also takes that block's backward sums (no bn_act_bwd_reduce pass over dY and z later --
         unless another consumer adds into the gradient afterwards, which clears Act.bsum again).  -> True if it launched.'''
-        if (sums_for is None or sums_for.bn is None or scales is None or not self.bn_sums_in_dgrad or not info.bn_bwd_sums
-                or tuple(sums_for.bn[0].shape) != tuple(out.shape)):
+        if (sums_for is None or sums_for.bn is None or not self.bn_sums_in_dgrad or not info.bn_bwd_sums
+                or (scales is None and out.dtype != torch.bfloat16) or tuple(sums_for.bn[0].shape) != tuple(out.shape)):
             return False
         z, coef = sums_for.bn
         part = torch.empty((info.n_partials, 2, dd.c_out), dtype=torch.float64, device=out.device)
@@ -849,7 +849,7 @@ class Engine(object):
             out = Act(torch.empty_like(z))
             out.amax = self._amax_slot() if z.dtype == torch.float32 else None
             ops.bn_act_fwd(z, coef, None if res is None else self._mat(res), out.t, n_pix, c, RCF_ACT_LEAKY_RELU, amax=out.amax)
-            if res is None and self.tape is not None and z.dtype == torch.float32:
+            if res is None and self.tape is not None:
                 out.bn = (z, coef)
         out.head_fusable = res is None
         if self.tape is not None:

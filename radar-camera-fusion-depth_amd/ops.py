@@ -332,10 +332,12 @@ def conv_fwd(desc, in1, in2, packed, out, stat_partials=None, coef1=None, coef2=
 
 def conv_dgrad_bn_sums(desc, dz, packed, dx, bn_z, bn_coef, sum_partials, scales):
     """Input gradient dx that is dY of a BatchNorm + LeakyReLU block (raw output bn_z, coefficients bn_coef) and its only writer: also
-    leaves that block's backward sums (sum g, sum g * xhat) in sum_partials [n_partials][2][c]; rcf_conv_info.bn_bwd_sums."""
+    leaves that block's backward sums (sum g, sum g * xhat) in sum_partials [n_partials][2][c]; rcf_conv_info.bn_bwd_sums.
+    scales: make_scales(...) for two-plane fp16 descriptors, None for bf16 tensors."""
     _check_storage(desc, dz, dx, bn_z)
     check(_lib.load().rcf_conv2d_dgrad_bn_sums(ctypes.byref(desc), _a(dz), _f32(packed), _a(dx), _a(bn_z), _f32(bn_coef),
-                                               _f64(sum_partials), ctypes.byref(scales), _stream()), 'rcf_conv2d_dgrad_bn_sums')
+                                               _f64(sum_partials), None if scales is None else ctypes.byref(scales), _stream()),
+          'rcf_conv2d_dgrad_bn_sums')
 
 
 def conv_fwd_act(desc, in1, in2, packed, bias, res, out):

@@ -202,6 +202,61 @@ def test_conv_weight_gradient_bf16_tensors(ops, case):
     assert e < 2e-4, e      # operands are exact: only fp32 accumulation order differs (the gradient itself stays fp32)
 
 
+SUMS_CASES_B16 = [('3x3', 64, 64, 2, 33, 64), ('3x3', 32, 32, 1, 70, 102), ('3x3', 256, 256, 2, 8, 13), ('3x3', 16, 32, 3, 20, 37),
+                  ('up2x', 64, 32, 1, 35, 51), ('up2x', 64, 64, 2, 12, 20)]
+
+
+@pytest.mark.parametrize('case', SUMS_CASES_B16, ids=[str(c) for c in SUMS_CASES_B16])
+def test_input_gradient_kernel_takes_the_batchnorm_backward_sums_bf16_tensors(ops, case):
+    '''rcf_conv2d_dgrad_bn_sums on bf16 tensors (conv_b16_kernel<C, false, true>): the input gradient dx written together with the
+    backward sums of the BatchNorm + LeakyReLU block whose output it is the gradient of -- dx bitwise what rcf_conv2d_fwd writes,
+    the sums equal to rcf_bn_act_bwd_reduce_b16's over dx and z (same terms; the epilogue adds 8 of them in fp32 before the fp64
+    sum) and to an fp64 host evaluation.'''
+    from rcf_amd._lib import RCF_ACT_LEAKY_RELU, RCF_PHASE_UP2X_DGRAD
+    kind, ci, co, n, h, w = case
+    ops.set_precision('bf16')
+    wt = rnd(co, ci, 3, 3, seed=11, scale=1.0 / np.sqrt(ci * 9)).cuda()
+    if kind == '3x3':
+        d = ops.make_fwd_desc(n, h, w, ci, 0, co, 3, 1)
+        dd = ops.make_dgrad_desc(d, 0, ci, False)
+        dz = nhwc_b(rnd(n, co, h, w, seed=12))
+        wsrc = [wt]
+    else:
+        dd = ops.make_up2x_dgrad_desc(n, h, w, ci, co, 0, 0, False, phase_sum=True)
+        dz = nhwc_b(rnd(n, co, 2 * h, 2 * w, seed=12))
+        wph = ops.phase_weights(wt, RCF_PHASE_UP2X_DGRAD)
+        wsrc = [wph[ph] for ph in range(4)]
+    info = ops.conv_query(dd)
+    assert info.bn_bwd_sums == 1
+    packed = torch.empty(len(wsrc) * info.packed_weight_floats, device='cuda')
+    for i, wsl in enumerate(wsrc):
+        ops.conv_pack(dd, wsl, packed[i * info.packed_weight_floats:(i + 1) * info.packed_weight_floats])
+    z = nhwc_b(rnd(n, ci, h, w, seed=13))
+    g_ = torch.Generator().manual_seed(14)
+    gamma, beta = torch.rand(ci, generator=g_) * 2 - 1, torch.rand(ci, generator=g_) - 0.5
+    mean, invstd = torch.rand(ci, generator=g_) - 0.5, 0.5 + 2 * torch.rand(ci, generator=g_)
+    coef = torch.stack([gamma * invstd, beta - mean * gamma * invstd, mean, invstd]).contiguous().cuda()
+    n_pix = n * h * w
+    dx_ref = torch.full((n, h, w, ci), float('nan'), device='cuda', dtype=torch.bfloat16)
+    ops.conv_fwd(dd, dz, None, packed, dx_ref, None)
+    nb = ops.ew_blocks(n_pix, ci)
+    part_ref = torch.empty((nb, 2, ci), dtype=torch.float64, device='cuda')
+    ops.bn_act_bwd_reduce(dx_ref, z, coef, None, part_ref, n_pix, ci, RCF_ACT_LEAKY_RELU, False)
+    dx = torch.full((n, h, w, ci), float('nan'), device='cuda', dtype=torch.bfloat16)
+    part = torch.full((info.n_partials, 2, ci), float('nan'), dtype=torch.float64, device='cuda')
+    ops.conv_dgrad_bn_sums(dd, dz, packed, dx, z, coef, part, None)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref)
+    s_ref, s_new = part_ref.sum(0), part.sum(0)
+    zf = z.float()
+    gd = dx.double() * torch.where(zf * coef[0] + coef[1] > 0, 1.0, 0.2)
+    xh = (zf.double() - coef[2].double()) * coef[3].double()
+    want = torch.stack([gd.sum((0, 1, 2)), (gd * xh).sum((0, 1, 2))])
+    mag = torch.stack([gd.abs().sum((0, 1, 2)), (gd * xh).abs().sum((0, 1, 2))])
+    assert float(((s_new - want).abs() / mag).max()) < 1e-6
+    assert float(((s_new - s_ref).abs() / mag).max()) < 1e-6
+
+
 def test_phase_convolutions_bf16_tensors(ops):
     '''Exact-2x UpConv as four 2x2 phase convolutions, its merged-phase input gradient and its weight gradient on bf16 tensors,
     against the 9-tap reference (phase weights are pre-summed in fp32 and then rounded once: 1 extra bf16 ulp of slack).'''
