@@ -2108,6 +2108,10 @@ using D3S2_1_32 = DmaCfg<3, 1, 32, 1, 2>;
 using D3S2_1_16 = DmaCfg<3, 1, 16, 1, 2>;
 using D4_1_32 = DmaCfg<4, 1, 32, 2>;        // the stems: 4x4 on the 16-channel space-to-depth image, <= 32 output channels
 using D4_1_16 = DmaCfg<4, 1, 16, 2>;
+#else
+}   // namespace
+namespace {
+#include "rcf_conv_pw_f16x2.h"
 #endif
 
 // Persistent grid: one resident wave of workgroups (occupancy API), split between the n-tiles.  Also the number of
@@ -2416,6 +2420,20 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     s->npl = 3;
     s->dma = 0;
     s->pw = 0;
+#if !RCF_CONV_B16
+    {   // fp32 tensors, two fp16 planes: the streaming 1x1 kernel (conv1x1_f16x2_kernel; RCF_F32_PW=0 keeps the f32-MFMA kernel)
+        const char* e = getenv("RCF_F32_PW");
+        if (s->kind == K1 && d->precision == RCF_PREC_F16X2 && d->c2 == 0 && d->c1 % 16 == 0 && d->c1 <= 64 && d->c_out <= 128 &&
+            pw2_cfg_ok(d->c1 / 16, ceil_div(d->c_out, 32)) && d->gather1 == RCF_GATHER_DIRECT && d->out_stride == 1 &&
+            d->out_off_y == 0 && d->out_off_x == 0 && d->out_h_phys == d->h_out && d->out_w_phys == d->w_out &&
+            (d->w_mode == RCF_W_FORWARD || d->stride == 1) && split_enabled() && (e == nullptr || e[0] != '0')) {
+            s->pw = 1; s->split = 1; s->bf16 = 0; s->npl = 2; s->ck = 16; s->cst = 16;
+            s->nt = ceil_div(d->c_out, 32);
+            s->px = 32; s->th = 8; s->bn = 32 * s->nt;
+            return RCF_OK;
+        }
+    }
+#endif
 #if RCF_CONV_B16
     {
         const char* e = getenv("RCF_B16_PW");
@@ -2811,6 +2829,10 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
     const int ntile_n = ceil_div(d->c_out, s.bn);
     info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * s.ck;
     if (s.split) info->packed_weight_floats = (size_t)ntile_n * (a.nchunk1 + a.nchunk2) * s.t * s.bn * 8 * s.npl;   // 16 bf16 x planes per row
+#if !RCF_CONV_B16
+    if (s.pw) info->n_partials = pw2_grid((long long)d->n * d->h_out * d->w_out, d->c1 / 16, s.nt);
+    else
+#endif
 #if RCF_CONV_B16
     if (s.pw) info->n_partials = pw_grid((long long)d->n * d->h_out * d->w_out, s.nt);
     else if (s.dma) info->n_partials = dispatch_dma(s, [&](auto tag) { return dma_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
@@ -3013,6 +3035,12 @@ static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float
     if (s.dma) return RCF_EUNSUPPORTED;   // rcf_conv_info.bn_on_load is 0 for these descriptors (the tile geometry differs)
 #endif
     if (s.kind == K4S1 && SAct::B16) return RCF_EUNSUPPORTED;
+#if !RCF_CONV_B16
+    if (s.pw) {
+        if (coef1 || coef2 || bn_z) return RCF_EUNSUPPORTED;
+        return dispatch_pw2(d->c1 / 16, s.nt, [&](auto cfg) { return launch_pw2<decltype(cfg)>(a, (hipStream_t)stream); });
+    }
+#endif
     if (bn_z != nullptr) {   // rcf_conv_info.bn_bwd_sums: an input-gradient launch over a plain (unit-stride, whole) output tensor
         if (!bn_sums_ok(d, s)) return RCF_EUNSUPPORTED;
         a.bz = bn_z; a.bk = bn_coef;

@@ -96,6 +96,11 @@ CASES = [
     (3, 1, 256, 0, 256, 2, 8, 13, None),        # small layer: 32-co half workgroups
     (3, 2, 32, 0, 64, 2, 45, 80, None),         # stride 2 on the split kernel
     (3, 2, 128, 0, 256, 1, 29, 50, None),
+    (1, 1, 32, 0, 64, 2, 45, 80, None),         # 1x1 (fusion convs): the streaming kernel, operands straight from global memory
+    (1, 1, 16, 0, 32, 2, 35, 51, None),
+    (1, 1, 64, 0, 64, 1, 29, 50, None),         # 4 k-steps x 2 co tiles: the most weight pieces that fit the registers
+    (1, 1, 32, 0, 128, 3, 20, 37, None),        # 2 k-steps x 4 co tiles
+    (1, 2, 32, 0, 64, 2, 45, 80, None),         # projection: stride 2 through the source address
 ]
 
 
@@ -154,7 +159,7 @@ def test_conv_forward_input_gradient_weight_gradient(ops, case):
         ops.conv_wgrad(d, nhwc(x1), None if x2 is None else nhwc(x2), nhwc(dz), dw, wsb,
                        scales=ops.make_scales(ax, ax if x2 is not None else None, None, adz) if two_plane_wgrad else None)
         wg = lambda a, b: torch.nn.grad.conv2d_weight(a, wt.shape, b, stride=s, padding=k // 2)
-        if s == 1:
+        if s == 1 and k != 1:   # (1x1 weight gradients stay on the f32 MFMA)
             assert two_plane_wgrad, info.wgrad_kernel_id
             assert rel(dw.cpu(), x3(wg, xin, dz)) < ORDER_TOL
         assert rel(dw.cpu(), wg(xin.double(), dz.double())) < EXACT_TOL
@@ -163,14 +168,22 @@ def test_conv_forward_input_gradient_weight_gradient(ops, case):
         if s == 1 and up is None:
             dd = ops.make_dgrad_desc(d, 0, c1, False)
             di = ops.conv_query(dd)
-            assert 40000 <= di.kernel_id < 50000
+            two_plane_dgrad = 40000 <= di.kernel_id < 50000
+            assert two_plane_dgrad or (k == 1 and co > 64)    # (a 1x1 input gradient from > 64 channels stays on the f32 MFMA)
             pk = torch.empty(di.packed_weight_floats, device='cuda')
-            ops.conv_pack(dd, wt.cuda(), pk, aw)
+            ops.conv_pack(dd, wt.cuda(), pk, aw if two_plane_dgrad else None)
             dx = torch.full((n, h, w, c1), float('nan'), device='cuda')
-            ops.conv_fwd(dd, nhwc(dz), None, pk, dx, None, scales=ops.make_scales(adz, None, aw))
+            ops.conv_fwd(dd, nhwc(dz), None, pk, dx, None, scales=ops.make_scales(adz, None, aw) if two_plane_dgrad else None)
             dg = lambda a, b: torch.nn.grad.conv2d_input(xin.shape, b, a, stride=1, padding=k // 2)[:, :c1]
-            assert rel(nchw(dx), x3(dg, dz, wt)) < ORDER_TOL
+            if two_plane_dgrad:
+                assert rel(nchw(dx), x3(dg, dz, wt)) < ORDER_TOL
             assert rel(nchw(dx), dg(dz.double(), wt.double())) < EXACT_TOL
+            if two_plane_dgrad and k == 1:   # += into an existing gradient (the second consumer of a tensor)
+                base = rnd(n, c1, h, w, seed=78, scale=1e-3)
+                dx2 = nhwc(base).clone()
+                dda = ops.make_dgrad_desc(d, 0, c1, True)
+                ops.conv_fwd(dda, nhwc(dz), None, pk, dx2, None, scales=ops.make_scales(adz, None, aw))
+                assert rel(nchw(dx2), base.double() + dg(dz.double(), wt.double())) < EXACT_TOL
     finally:
         ops.set_precision('fp32')
 
