@@ -237,7 +237,7 @@ class KernelTimer(object):
         self.bytes = getattr(self, 'bytes', {})
         if desc is not None:
             self.bytes[kid] = self.bytes.get(kid, 0.0) + (algorithmic_bytes(desc) if (kid % 20000) < 10000 else 0.0)
-            tag = '%s %s k%d s%d %d+%d->%d @%dx%d g%d' % (self.scope or '-', 'dgrad' if desc.w_mode == RCF_W_DGRAD else ('wgrad' if kid >= 10000 else 'fwd'),
+            tag = '%s %s k%d s%d %d+%d->%d @%dx%d g%d' % (self.scope or '-', 'dgrad' if desc.w_mode == RCF_W_DGRAD else ('wgrad' if (kid % 20000) >= 10000 else 'fwd'),
                                                          desc.ksize, desc.stride, desc.c1, desc.c2, desc.c_out, desc.h_out, desc.w_out,
                                                          desc.gather1)
         self.cur = (kid, flops, ev, tag)
