@@ -470,6 +470,8 @@ def run_rank(args):
             traffic, traffic_src = None, 'the committed PMC passes (profiles/) were collected on the fp32 step'
             mfma_busy = None
         if is_split:
+            if dtype == 'bf16':
+                kname = kname.replace('conv_split_kernel', 'conv_b16_kernel')   # the bf16-tensor twin of the family (LDS-DMA operands)
             kname += ' (%s)' % TIER_TEXT[dtype]
         conv_ms = sum(r[2] for r in fam.values())
         conv_flops = sum(r[1] for r in fam.values())
@@ -696,6 +698,40 @@ def run_radarnet(args, dev):
         return loss
     dt, loss, n_pre = _time_steps(step, args, torch)
     n_samples = n_img * args.steps
+    # the dominant conv family of this step, from HIP events around its launches on three more (untimed) steps
+    from rcf_amd import ops
+    timer = ops.KernelTimer()
+    m._engine.prof = timer
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    m._engine.prof = None
+    fam = {}
+    for kid, (cnt, flops, ms) in timer.collect().items():
+        kid0 = kid % 20000
+        f = (10 + (kid0 - 10000) // 1000) if kid0 >= 10000 else kid0 // 1000
+        r = fam.setdefault(f, [0, 0.0, 0.0])
+        r[0] += cnt; r[1] += flops; r[2] += ms
+    roofline = None
+    if fam:
+        dom = max(fam, key=lambda f: fam[f][2])
+        cnt, flops, ms = fam[dom]
+        tier = 'bf16' if dtype == 'bf16' else 'f32'
+        is_split = dom in (5, 6, 8, 9, 15, 19)
+        algorithmic = flops / (ms * 1e-3) / 1e12
+        achieved = algorithmic * (SPLIT_PRODUCTS[tier] if is_split else 1)
+        peak = BF16_MFMA_PEAK_TFLOPS if is_split else F32_MFMA_PEAK_TFLOPS
+        conv_ms = sum(r[2] for r in fam.values())
+        kname = KERNEL_NAMES.get(dom, str(dom))
+        if is_split and tier == 'bf16':
+            kname = kname.replace('conv_split_kernel', 'conv_b16_kernel')
+        roofline = {'bound': 'mfma', 'kernel': kname + (' (%s)' % TIER_TEXT[tier] if is_split else ''),
+                    'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+                    'algorithmic_fp32_tflops': round(algorithmic, 2), 'useful_frac': round(algorithmic / peak, 4),
+                    'products_per_multiply': SPLIT_PRODUCTS[tier] if is_split else 1, 'traffic': None,
+                    'events_from': '3 eager steps after the timed region', 'launches_per_step': cnt // 3,
+                    'avg_launch_ms': round(ms / cnt, 4), 'share_of_step_time': round(ms / 3 / (1000.0 * dt / args.steps), 4),
+                    'all_conv_kernels_share_of_step_time': round(conv_ms / 3 / (1000.0 * dt / args.steps), 4)}
     rec = {'metric': 'RadarNet stage-1 train images/sec at 900x1600', 'value': round(n_samples / dt, 3), 'unit': 'images/s', 'n_gpus': 1,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * dt / args.steps, 3), 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
@@ -706,6 +742,8 @@ def run_radarnet(args, dev):
            # 153.8 GF forward per image at K = 4, x3 for forward + dgrad + wgrad
            'algorithmic_tflops': round(3 * 153.8 * n_samples / dt / 1e3, 2),
            'peak_memory_gb': round(torch.cuda.max_memory_allocated() / 1e9, 2)}
+    if roofline is not None:
+        rec['roofline'] = roofline
     print(json.dumps(rec), flush=True)
     return 0
 
