@@ -452,6 +452,14 @@ struct rcf_f16_pair { unsigned p0, p1; };
 // two (already scaled) fp32 values -> (fp16 plane 0, fp16 plane 1) dwords, value `a` in the low half; both planes round to nearest
 // even (v_cvt_pk_f16_f32), the residual a - p0 is exact in fp32
 __device__ __forceinline__ rcf_f16_pair rcf_f16_planes(float a, float b) {
+#ifdef RCF_DIAG_NO_CONVERT
+    // diagnostics build (tools/probe): the split replaced by two byte permutes -- WRONG values, the same data movement: what the
+    // kernels would cost if their operands arrived as planes (the conversion's share of their energy / time)
+    rcf_f16_pair d;
+    d.p0 = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+    d.p1 = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x05040100u);
+    return d;
+#endif
     const rcf_f32x2 v = {a, b};
     const rcf_f16x2 h = __builtin_convertvector(v, rcf_f16x2);
     const rcf_f32x2 r = {a - (float)h[0], b - (float)h[1]};
