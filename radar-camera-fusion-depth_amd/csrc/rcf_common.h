@@ -61,8 +61,16 @@ __device__ __forceinline__ void rcf_amax_commit(float m, float* amax_slot) {
         if (mb > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, mb);
     }
 }
+// |v| of a finite value, 0 for Inf / NaN: the maximum that sets a tensor's scale is taken over its FINITE elements, so one Inf or NaN
+// neither flushes the finite elements' planes to zero (s would be 2^-114) nor is lost -- the element itself still reaches the matrix
+// pipe as an fp16 Inf / NaN plane and makes every output of its receptive field non-finite, like an fp32 convolution does
+// (tests/test_hip_f16x2.py::test_non_finite_operands_propagate)
+__device__ __forceinline__ float rcf_abs_finite(float v) {
+    const float a = fabsf(v);
+    return a <= 3.402823466e+38f ? a : 0.f;
+}
 __device__ __forceinline__ float rcf_amax4(float m, f32x4 v) {
-    return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    return fmaxf(fmaxf(m, fmaxf(rcf_abs_finite(v[0]), rcf_abs_finite(v[1]))), fmaxf(rcf_abs_finite(v[2]), rcf_abs_finite(v[3])));
 }
 
 // ---- storage type of the NHWC activation / gradient tensors -------------------------------------------------------------------

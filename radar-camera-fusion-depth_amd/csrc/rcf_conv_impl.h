@@ -2779,7 +2779,7 @@ extern "C" int rcf_phase_weights(const float* w_oihw, float* out, int o, int i, 
 
 extern "C" int rcf_phase_weights_batch(const rcf_phase_item* items, int n, void* stream) {
     if (!items || n <= 0) return RCF_EINVAL;
-    static PhaseBatch b;
+    static thread_local PhaseBatch b;
     int i = 0;
     while (i < n) {
         b.n = 0;
@@ -2937,7 +2937,7 @@ extern "C" int RCF_FN(rcf_conv2d_pack_weights_batch)(const rcf_pack_item* items,
         }
     }
 #endif
-    static PackBatch b;   // ~3 KB: not on the stack of a ctypes caller's thread; single-threaded use like the rest of the library
+    static thread_local PackBatch b;   // ~3 KB: not on the stack of a ctypes caller's thread; one per host thread
     int i = 0;
     while (i < n) {
         b.n = 0;

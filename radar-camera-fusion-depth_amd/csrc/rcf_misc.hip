@@ -986,9 +986,9 @@ __device__ __forceinline__ void amax_slice(const float* __restrict__ x, long lon
     if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         const long long hi4 = lo + ((hi - lo) & ~3ll);
         for (long long i = lo + 4 * threadIdx.x; i < hi4; i += 1024) m = rcf_amax4(m, *reinterpret_cast<const f32x4*>(x + i));
-        for (long long i = hi4 + threadIdx.x; i < hi; i += 256) m = fmaxf(m, fabsf(x[i]));
+        for (long long i = hi4 + threadIdx.x; i < hi; i += 256) m = fmaxf(m, rcf_abs_finite(x[i]));
     } else {
-        for (long long i = lo + threadIdx.x; i < hi; i += 256) m = fmaxf(m, fabsf(x[i]));
+        for (long long i = lo + threadIdx.x; i < hi; i += 256) m = fmaxf(m, rcf_abs_finite(x[i]));
     }
     rcf_amax_commit(m, amax);
 }
@@ -1023,7 +1023,7 @@ extern "C" int rcf_amax_batch(const rcf_amax_item* items, int n, void* stream) {
     if (!items || n <= 0) return RCF_EINVAL;
     for (int i = 0; i < n; ++i)
         if (!items[i].x || !items[i].amax || items[i].n <= 0) return RCF_EINVAL;
-    static AmaxBatch b;   // ~4 KB: not on a ctypes caller's stack; single-threaded use like the other batch entry points
+    static thread_local AmaxBatch b;   // ~4 KB: not on a ctypes caller's stack; one per host thread (two models on two threads do not race)
     int i = 0;
     while (i < n) {
         b.n = 0;

@@ -226,6 +226,30 @@ def main():
         buf_keys=np.array(list(r[3].keys())),
         buf_l2=np.array([float(b.double().norm()) for b in r[3].values()]))
 
+    # ---------------- T1b: per-element gradient samples of T1's ten largest gradient tensors ----------------
+    # (the tensors are 2.4 - 4.7 MB each: 2048 seeded flat indices per tensor pin them element by element; next to the reference's
+    # fp32 values, the same elements from the oracle run in fp64 -- the oracle equals the reference to 0.00e+00 in fp32 above -- so
+    # that a test can tell an fp32 implementation's LeakyReLU / max-pool decision flips from errors)
+    big = sorted(keys, key=lambda k: -r[2][k].numel())[:10]
+    rs = np.random.RandomState(7)
+    idx = np.stack([rs.choice(r[2][k].numel(), 2048, replace=False) for k in big]).astype(np.int64)
+    ora64 = FusionNetOracle(**synth.PUBLISHED)
+    synth.fill_state_dict_([ora64.encoder, ora64.decoder], 21)
+    for mod in (ora64.encoder, ora64.decoder):
+        mod.double()
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    o64 = one_step(ora64, b64, False)
+    np.savez_compressed(
+        os.path.join(gold, 'T1b_published_grad_samples.npz'),
+        meta=np.array([1, 224, 384, 32, 301, 21]),
+        keys=np.array(big), idx=idx,
+        ref32=np.stack([r[2][k].reshape(-1).numpy()[i] for k, i in zip(big, idx)]).astype(np.float32),
+        fp64=np.stack([o64[2][k].reshape(-1).numpy()[i] for k, i in zip(big, idx)]).astype(np.float64),
+        fp64_absmax=np.array([float(o64[2][k].abs().max()) for k in big]),
+        ref32_rel_err=np.array([relerr(r[2][k], o64[2][k]) for k in big]))
+    print('[T1b] ten largest gradient tensors, reference fp32 vs fp64 (max-norm): '
+          + ', '.join('%.1e' % relerr(r[2][k], o64[2][k]) for k in big))
+
     ref, ora = pair(synth.PUBLISHED, 21)
     ref.eval(); ora.eval()
     with torch.no_grad():

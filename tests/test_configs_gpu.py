@@ -373,19 +373,24 @@ def test_bench_two_ranks_spawned_by_bench_itself():
     assert rec['config']['loss_check']['ok'] is True       # the global masked mean of the two ranks' batches, against the oracle's
 
 
-def test_bench_two_ranks_at_the_headline_shape_pass_their_own_loss_check():
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_bench_two_ranks_at_the_headline_shape_pass_their_own_loss_check(dtype):
     '''`python bench.py --gpus 2` at the DEFAULT shape (published net, per-GPU batch 8, 900x1600) -- what the driver's scaling run
     launches.  Rank r trains on data seed 1234 + r and the loss is the reference's single masked mean over the gathered batch, so the
     first-step loss must equal the oracle's GLOBAL value formed from the per-seed sums of tests/golden/bench_expected.json (round 2
-    compared it with rank 0's own mean and exited 3).  On a 1-GPU box the two ranks share cuda:0 over gloo (2 x 30 GB).'''
+    compared it with rank 0's own mean and exited 3).  On a 1-GPU box the two ranks share cuda:0 over gloo (2 x 30 GB).
+    dtype bf16 = BASELINE configs[3] ("bf16 x DP"): bf16 tensors under the data-parallel exchange -- the loss sums are all-reduced
+    before backward and the fp32 gradient buckets behind it exactly as in fp32; the first-step loss is held to the fp32 oracle's global
+    value within bf16's forward error (measured 3e-6 .. 1e-4 on one rank; bar 5e-3).'''
     two = torch.cuda.device_count() >= 2
     extra_env = {} if two else {'RCF_BENCH_SINGLE_DEVICE': '1', 'RCF_DIST_BACKEND': 'gloo'}
-    args = ['--gpus', '2', '--steps', '2', '--warmup', '1', '--preheat-s', '0', '--no-cpu-baseline']
+    args = ['--gpus', '2', '--steps', '2', '--warmup', '1', '--preheat-s', '0', '--no-cpu-baseline', '--dtype', dtype]
     r, rec = _run_bench(args, extra_env, timeout=900)
     assert r.returncode == 0 and rec is not None, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
-    assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2 and rec['config']['global_batch'] == 16
+    assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2 and rec['config']['global_batch'] == 16 and rec['dtype'] == dtype
     chk = rec['config']['loss_check']
-    assert chk['ok'] is True and chk['rel_err'] < 1e-4, chk
+    print('bench.py --gpus 2 --dtype %s: first-step loss rel err vs the oracle\'s global masked mean %.3e' % (dtype, chk['rel_err']))
+    assert chk['ok'] is True and chk['rel_err'] < (1e-4 if dtype == 'f32' else 5e-3), chk
     single = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_expected.json')))['train_b8_900x1600_p64']['first_step_loss']
     assert abs(chk['oracle_first_step_loss'] - single) > 1e-3 * single     # and the global value is NOT rank 0's own mean
     assert 'overlap_frac' in rec['dp']

@@ -287,6 +287,52 @@ def test_per_tensor_scale_on_hostile_operand_distributions(ops, xkind, wkind, mo
     assert rel(got, ref) < 2.0 * rel(got32, ref) + 1e-7
 
 
+@pytest.mark.parametrize('bad', [float('inf'), float('-inf'), float('nan')])
+def test_non_finite_operands_propagate(ops, bad):
+    '''One Inf / NaN element in the input (and, separately, in the weights) of a two-plane convolution.  The tensor's maximum is taken
+    over its FINITE elements (rcf_abs_finite), so (1) every output outside the element's receptive field is what it is without the
+    element -- held to the exact tier's bar against fp64 -- and (2) every output inside it is non-finite, as in an fp32 convolution
+    (there: +-Inf or NaN; here always NaN -- the second plane of an Inf is Inf - Inf).  Nothing is silently flushed or dropped.'''
+    n, c, co, h, w = 1, 64, 64, 20, 36
+    x = rnd(n, c, h, w, seed=31)
+    wt = rnd(co, c, 3, 3, seed=32, scale=1.0 / 24.0)
+    iy, ix, ic = 7, 11, 5
+    ops.set_precision('f16x2')
+    try:
+        d = ops.make_fwd_desc(n, h, w, c, 0, co, 3, 1, h, w, 0)
+        # (a) the element in the input
+        xb = x.clone()
+        xb[0, ic, iy, ix] = bad
+        amax = dev_amax(ops, xb)
+        assert float(amax) == float(xb[torch.isfinite(xb)].abs().max())   # the maximum of the finite elements
+        got, _, info = _run_fwd(ops, d, xb, None, wt, amax, dev_amax(ops, wt))
+        assert 40000 <= info.kernel_id < 50000
+        x0 = x.clone()
+        x0[0, ic, iy, ix] = 0.0
+        ref = F.conv2d(x0.double(), wt.double(), padding=1)
+        rf = torch.zeros(1, 1, h, w, dtype=torch.bool)
+        rf[0, 0, iy - 1:iy + 2, ix - 1:ix + 2] = True
+        rf = rf.expand(n, co, h, w)
+        assert not bool(torch.isfinite(got[rf]).any()), 'an output inside the receptive field stayed finite'
+        assert bool(torch.isfinite(got[~rf]).all()), 'the element leaked outside its receptive field'
+        assert float((got.double() - ref)[~rf].abs().max()) < EXACT_TOL * float(ref.abs().max())
+        # (b) the element in the weights: every pixel of that output channel, nothing else
+        wb = wt.clone()
+        wb[9, 3, 1, 2] = bad
+        got, _, _ = _run_fwd(ops, d, x, None, wb, dev_amax(ops, x), dev_amax(ops, wb))
+        ref = F.conv2d(x.double(), wt.double(), padding=1)
+        ch = torch.zeros(1, co, 1, 1, dtype=torch.bool)
+        ch[0, 9] = True
+        ch = ch.expand(n, co, h, w)
+        inner = torch.zeros(n, co, h, w, dtype=torch.bool)
+        inner[:, :, 1:-1, 1:-1] = True                     # (the border pixels of the channel miss the tap where padding sits under it)
+        assert not bool(torch.isfinite(got[ch & inner]).any())
+        assert bool(torch.isfinite(got[~ch]).all())
+        assert float((got.double() - ref)[~ch].abs().max()) < EXACT_TOL * float(ref.abs().max())
+    finally:
+        ops.set_precision('fp32')
+
+
 def test_unscaled_call_equals_scale_one_and_amax_entry_points(ops):
     '''rcf_amax accumulates a maximum (several tensors into one slot, misaligned and odd-sized inputs), rcf_amax_batch equals n single
     calls, the _amax variants of the elementwise kernels report the maximum of what they wrote -- and a conv called without maxima
@@ -591,6 +637,42 @@ def test_published_net_train_step_against_the_reference_fixture(env, golden_dir,
     assert worst < 1e-2
 
 
+@pytest.mark.parametrize('tier', ['fp32', 'fp32_3plane'])
+def test_published_net_gradients_element_by_element_against_the_reference_samples(env, golden_dir, tier):
+    '''Fixture T1b (tests/golden/make_golden.py): 2048 seeded elements of each of the ten largest gradient tensors of fixture T1's
+    step, from the REAL reference in fp32, next to the same elements of the fp64 run.  The reference's own fp32 values are 1.5e-3 ..
+    1.9e-2 (max-norm) from fp64 on these tensors -- LeakyReLU / max-pool decisions that differ between any two fp32 evaluations --
+    so the HIP elements are held to fp64 with the reference's own distance as the yardstick: per tensor within 5x, median over the
+    ten within 3x (the rule of tests/test_hip_model.py::_check_gradients_against_fp64), and to the reference's fp32 values themselves
+    within the sum of both distances.'''
+    synth, train = env
+    s = np.load(os.path.join(golden_dir, 'T1b_published_grad_samples.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in s['meta']]
+    m = train.build_model(synth.PUBLISHED, device='cuda')
+    synth.fill_state_dict_([m.encoder, m.decoder], wseed)
+    m.compute_dtype = tier
+    m.train()
+    b = {kk: v.cuda() for kk, v in synth.make_batch(n, h, w, k, seed=dseed).items()}
+    out = m.forward(image=b['image'], input_depth=b['input_depth'])
+    loss, _ = m.compute_loss(image=b['image'], output_depth=out, ground_truth=b['ground_truth'], lidar_map=b['lidar_map'],
+                             loss_func='l1', w_smoothness=0.0, loss_smoothness_kernel_size=-1,
+                             validity_map_loss_smoothness=None, w_lidar_loss=2.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {kk: p.grad for kk, p in _named(m) if p.grad is not None}
+    e_hip, e_ref = [], []
+    for key, idx, ref32, v64, amax in zip(s['keys'].tolist(), s['idx'], s['ref32'], s['fp64'], s['fp64_absmax']):
+        got = grads[key].detach().reshape(-1).cpu().double().numpy()[idx]
+        eh, er = float(np.abs(got - v64).max() / amax), float(np.abs(ref32.astype(np.float64) - v64).max() / amax)
+        e_hip.append(eh)
+        e_ref.append(er)
+        assert eh <= 5.0 * er + 2e-4, (key, eh, er)
+        assert float(np.abs(got - ref32).max() / amax) <= eh + er + 1e-6
+    print('%s: ten largest gradient tensors, sampled elements vs fp64 (max-norm): HIP %s | the reference in fp32 %s'
+          % (tier, ' '.join('%.1e' % e for e in e_hip), ' '.join('%.1e' % e for e in e_ref)))
+    assert np.median(e_hip) <= 3.0 * np.median(e_ref) + 2e-5
+
+
 @pytest.mark.parametrize('deconv', ['up', 'transpose'])
 def test_batchnorm_sums_from_the_input_gradient_kernels_in_the_published_net(env, golden_dir, deconv):
     '''The published net's training step with the BatchNorm-backward sums taken by the input-gradient kernels (default) against the
@@ -627,15 +709,12 @@ def test_batchnorm_sums_from_the_input_gradient_kernels_in_the_published_net(env
         assert abs(got - l2) < 1e-2 * max(l2, 1e-6)
 
 
-@pytest.mark.parametrize('kind', ['outlier_pixels', 'tiny_inputs', 'huge_inputs'])
-def test_training_step_with_hostile_inputs_against_the_oracle(env, kind):
-    '''The whole step (tiny net, train mode) on inputs that stress the per-tensor scales end to end: a few image pixels and radar
-    depths 10^4 times the rest (every tensor downstream of the stems inherits an outlier-dominated maximum until BatchNorm has
-    renormalised it), all inputs scaled by 1e-6, all inputs scaled by 1e+4.  Output, loss and parameter gradients against the fp32
-    CPU oracle at north_star's bar -- the same bar the three-plane arithmetic is held to.'''
-    from oracle.fusionnet_oracle import FusionNetOracle
-    synth, train = env
-    cb = synth.make_batch(2, 70, 102, 8, seed=321)
+HOSTILE_SEEDS = {'outlier_pixels': (321, 322, 323, 324), 'tiny_inputs': (321, 322, 323, 324, 325, 326, 327, 328), 'huge_inputs': (321, 322, 323, 324)}
+FLIPPED = 1e-3   # a tensor this far from fp64 carries a LeakyReLU / max-pool decision that differs from the fp64 run's (bimodal: see below)
+
+
+def _hostile_batch(synth, kind, seed):
+    cb = synth.make_batch(2, 70, 102, 8, seed=seed)
     if kind == 'outlier_pixels':
         cb['image'][0, 1, 10, 17] = 1.0e4
         cb['image'][1, 0, 40, 3] = -3.0e3
@@ -646,10 +725,184 @@ def test_training_step_with_hostile_inputs_against_the_oracle(env, kind):
     else:
         cb['image'] *= 1e4
         cb['input_depth'] *= 1e4
-    res = {}
+    return cb
+
+
+def _hostile_oracle(synth, cb, dtype):
+    from oracle.fusionnet_oracle import FusionNetOracle
+    o = FusionNetOracle(**synth.TINY)
+    synth.fill_state_dict_([o.encoder, o.decoder], 17)
+    for mod in (o.encoder, o.decoder):
+        mod.to(dtype)
+    o.train()
+    r = o.forward(cb['image'].to(dtype), cb['input_depth'].to(dtype))
+    l = o.compute_loss(r, cb['ground_truth'].to(dtype), cb['lidar_map'].to(dtype), 2.0)[0]
+    l.backward()
+    return r.detach(), float(l.detach()), {k: p.grad.double() for k, p in _named(o) if p.grad is not None}
+
+
+def _hostile_hip(synth, train, cb, tier):
+    m = train.build_model(synth.TINY, device='cuda')
+    synth.fill_state_dict_([m.encoder, m.decoder], 17)
+    m.compute_dtype = tier
+    m.train()
+    b = {kk: v.cuda() for kk, v in cb.items()}
+    out = m.forward(image=b['image'], input_depth=b['input_depth'])
+    loss, _ = m.compute_loss(image=b['image'], output_depth=out, ground_truth=b['ground_truth'], lidar_map=b['lidar_map'],
+                             loss_func='l1', w_smoothness=0.0, loss_smoothness_kernel_size=-1,
+                             validity_map_loss_smoothness=None, w_lidar_loss=2.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    return out.detach().cpu(), float(loss.detach()), {k: p.grad.detach().cpu().clone() for k, p in _named(m) if p.grad is not None}
+
+
+@pytest.mark.parametrize('kind', ['outlier_pixels', 'tiny_inputs', 'huge_inputs'])
+def test_training_step_with_hostile_inputs_against_the_oracle(env, kind):
+    '''The whole step (tiny net, train mode) on inputs that stress the per-tensor scales end to end: a few image pixels and radar
+    depths 10^4 times the rest, all inputs scaled by 1e-6, all inputs scaled by 1e+4.  Output and loss against the fp32 CPU oracle at
+    north_star's bar on every seed, for both operand arithmetics.  Parameter gradients against the fp64 oracle with the fp32 CPU
+    oracle's own distance from fp64 as the yardstick -- for EVERY kind, no tier-against-tier stand-in -- judged over a seed sweep:
+
+    round 3 exempted 'tiny_inputs' at its one seed (321: HIP 3.6e-2 from fp64, CPU fp32 4e-4) and blamed the BatchNorm coefficient
+    rows.  Round 4 isolated it (tools/diag_net.py RCF_DIAG_BLOCK, tools/diag_bn_bwd.py, profiles/r04_tiny_inputs_diagnosis.txt): every
+    BatchNorm-backward stage and every input-gradient kernel of that step equals an fp64 evaluation of ITS OWN inputs to ~1e-7
+    (test_batchnorm_backward_stages_on_the_hostile_step below), |mean| * invstd is O(1) in all 53 blocks -- and ONE element of
+    decoder.deconv0.deconv's BatchNorm output (of 57,120) lies within the forward pass's round-off of zero and takes the other
+    LeakyReLU branch than in the fp64 run.  The case is chaotic for ANY fp32 implementation: the stock-PyTorch fp32 oracle is 1e-3 ..
+    8.7e-2 from its own fp64 run on 14 of the 20 data seeds 321..340 (8.7e-2 at 322, 8.3e-2 at 324; 4 of 20 even with unscaled inputs).
+    A seed whose worst tensor is > 1e-3 from fp64 carries such a flipped decision; the distribution is bimodal (<= 4e-4 | >= 1e-3).'''
+    synth, train = env
+    seeds = HOSTILE_SEEDS[kind]
+    rows = []
+    for si, seed in enumerate(seeds):
+        cb = _hostile_batch(synth, kind, seed)
+        ref, rl, g32 = _hostile_oracle(synth, cb, torch.float32)
+        _, _, g64 = _hostile_oracle(synth, cb, torch.float64)
+        e_cpu = {k: rel(g32[k], g64[k]) for k in g64}
+        res = {tier: _hostile_hip(synth, train, cb, tier) for tier in (('fp32', 'fp32_3plane') if si == 0 else ('fp32',))}
+        for tier, (out, loss, grads) in res.items():
+            assert bool(torch.isfinite(out).all())
+            assert rel(out, ref) < NORTH_STAR and abs(loss - rl) < NORTH_STAR * rl, (kind, seed, tier)
+        e_hip = {k: rel(res['fp32'][2][k], g64[k]) for k in g64}
+        row = dict(seed=seed, hip_worst=max(e_hip.values()), cpu_worst=max(e_cpu.values()),
+                   hip_med=float(np.median(list(e_hip.values()))), cpu_med=float(np.median(list(e_cpu.values()))), e_hip=e_hip, e_cpu=e_cpu)
+        if si == 0:
+            e3 = {k: rel(res['fp32_3plane'][2][k], g64[k]) for k in g64}
+            row['hip3_worst'] = max(e3.values())
+            # the two-plane tier is not further from the oracle than the three-plane tier by more than fp32 round-off allows
+            assert rel(res['fp32'][0], ref) < 2.0 * rel(res['fp32_3plane'][0], ref) + 2e-5
+        rows.append(row)
+        print('%s seed %d: gradients vs fp64, worst tensor HIP %.2e (CPU fp32 oracle %.2e), median tensor HIP %.2e (CPU %.2e)%s'
+              % (kind, seed, row['hip_worst'], row['cpu_worst'], row['hip_med'], row['cpu_med'],
+                 '' if si else ', three-plane tier worst %.2e' % row['hip3_worst']))
+    # (1) seeds on which neither run carries a flipped decision: every tensor at the CPU oracle's own distance from fp64
+    calm = [r for r in rows if r['hip_worst'] < FLIPPED and r['cpu_worst'] < FLIPPED]
+    for r in calm:
+        for k, err in r['e_hip'].items():
+            assert err < 3.0 * r['e_cpu'][k] + 1e-5, (kind, r['seed'], k, err, r['e_cpu'][k])
+    # (2) the HIP path takes a differing decision no more often than the fp32 CPU oracle does (both are draws from the same chaos: the
+    # counts are two small binomial samples), and a seed that carries one is moved by what the CPU oracle's own flipped seeds are moved
+    # by (<= 8.7e-2 over seeds 321..340) -- not by more
+    n_hip = sum(r['hip_worst'] >= FLIPPED for r in rows)
+    n_cpu = sum(r['cpu_worst'] >= FLIPPED for r in rows)
+    gm = lambda key: float(np.exp(np.mean([np.log(r[key] + 1e-12) for r in rows])))
+    print('%s: seeds with a flipped decision HIP %d / CPU %d of %d; geometric mean of the worst tensor HIP %.2e / CPU %.2e, of the median '
+          'tensor HIP %.2e / CPU %.2e; %d calm seeds checked tensor by tensor' % (kind, n_hip, n_cpu, len(rows), gm('hip_worst'), gm('cpu_worst'),
+                                                                                 gm('hip_med'), gm('cpu_med'), len(calm)))
+    assert n_hip <= n_cpu + max(2, len(rows) // 3)
+    assert max(r['hip_worst'] for r in rows) < 0.2
+    if kind != 'tiny_inputs':
+        assert calm, 'outlier / huge inputs are not chaotic: at least one seed must be checked tensor by tensor'
+
+
+def test_batchnorm_backward_stages_on_the_hostile_step(env):
+    '''Every BatchNorm-backward launch of the 'tiny_inputs' step (seed 321: the step round 3 exempted), each STAGE against an fp64
+    evaluation of the stage's own inputs: the per-channel sums (reduce + finalize -> mean g, mean g * xhat), the apply pass (dz), and
+    the complete fp64 BatchNorm backward of the same (dout, z) with mean / invstd / xhat formed in fp64 -- i.e. the fp32 coefficient
+    rows (scale, shift, mean, invstd) cost nothing measurable: conditioning |mean| * invstd stays O(1) even here.'''
+    synth, train = env
+    from rcf_amd import engine as eng_mod
+    cb = _hostile_batch(synth, 'tiny_inputs', 321)
+    calls = []
+    orig = eng_mod.ops.bn_act_bwd_apply
+
+    def wrapped(dout, z, coef, out, bcoef, dz, dres, dres_accumulate, n_pix, c, act, has_res, amax=None):
+        orig(dout, z, coef, out, bcoef, dz, dres, dres_accumulate, n_pix, c, act, has_res, amax=amax)
+        torch.cuda.synchronize()
+        g = dout.double().reshape(-1, c)
+        zz = z.double().reshape(-1, c)
+        k = coef.double()
+        if has_res:
+            g = g * torch.where(out.double().reshape(-1, c) > 0, 1.0, 0.2)
+        y32 = z.reshape(-1, c) * coef[0] + coef[1]                       # the kernels' own LeakyReLU decision
+        gp = g * torch.where(y32.double() > 0, 1.0, 0.2)
+        xh_k = (zz - k[2]) * k[3]
+        e_sums = max(rel(bcoef[0], gp.mean(0)), rel(bcoef[1], (gp * xh_k).mean(0)))
+        e_apply = rel(dz.reshape(-1, c), k[0] * (gp - bcoef[0].double() - xh_k * bcoef[1].double()))
+        mean = zz.mean(0)
+        invstd = 1.0 / torch.sqrt(((zz * zz).mean(0) - mean * mean).clamp_min(0) + 1e-5)
+        xh = (zz - mean) * invstd
+        e_ideal = rel(dz.reshape(-1, c), (k[0] / k[3]) * invstd * (gp - gp.mean(0) - xh * (gp * xh).mean(0)))
+        calls.append((e_sums, e_apply, e_ideal, float((mean.abs() * invstd).max())))
+
+    eng_mod.ops.bn_act_bwd_apply = wrapped
+    try:
+        _hostile_hip(synth, train, cb, 'fp32')
+    finally:
+        eng_mod.ops.bn_act_bwd_apply = orig
+    assert len(calls) >= 50
+    worst = [max(c[i] for c in calls) for i in range(4)]
+    print('%d BatchNorm-backward launches: worst sums %.2e, apply %.2e, against the all-fp64 BatchNorm backward %.2e; max |mean| * invstd %.2f'
+          % (len(calls), worst[0], worst[1], worst[2], worst[3]))
+    assert worst[0] < 2e-6 and worst[1] < 2e-6 and worst[2] < 2e-6
+
+
+def test_sparse_radar_channel_and_tiny_beta_against_the_oracle(env):
+    '''The reference's real input statistics where a per-TENSOR scale is weakest: the radar depth / response channels are <= 1 % non-zero
+    (a handful of returns of 1..80 m, zeros elsewhere: every tensor of the depth branch is mostly tiny values under one large
+    maximum), and every BatchNorm beta is shrunk to 1e-4 of its draw, so nothing re-centres the activations away from zero.
+    Published net, train mode, 2 x 96 x 160: output and loss against the fp32 CPU oracle at north_star's bar; parameter gradients
+    against the fp64 oracle, per tensor, with the fp32 CPU oracle's own distance as the yardstick (median within 3x, whole-gradient
+    relative L2 error within 3x) -- on both operand arithmetics.'''
+    from oracle.fusionnet_oracle import FusionNetOracle
+    synth, train = env
+    cb = synth.make_batch(2, 96, 160, 8, seed=77)
+    rs = np.random.RandomState(5)
+    keep = torch.from_numpy(rs.rand(2, 1, 96, 160) < 0.008)
+    depth = torch.from_numpy(rs.uniform(1.0, 80.0, size=(2, 1, 96, 160)).astype(np.float32)) * keep
+    resp = torch.from_numpy(rs.uniform(32.0, 64.0, size=(2, 1, 96, 160)).astype(np.float32)) * keep
+    cb['input_depth'] = torch.cat([depth, resp], 1)
+    assert float((cb['input_depth'] != 0).float().mean()) < 0.01
+
+    def shrink_beta(mods):
+        with torch.no_grad():
+            for mod in mods:
+                for k, p in mod.named_parameters():
+                    if k.endswith('batch_norm.bias'):
+                        p.mul_(1e-4)
+
+    def oracle(dtype):
+        o = FusionNetOracle(**synth.PUBLISHED)
+        synth.fill_state_dict_([o.encoder, o.decoder], 23)
+        shrink_beta([o.encoder, o.decoder])
+        for mod in (o.encoder, o.decoder):
+            mod.to(dtype)
+        o.train()
+        r = o.forward(cb['image'].to(dtype), cb['input_depth'].to(dtype))
+        l = o.compute_loss(r, cb['ground_truth'].to(dtype), cb['lidar_map'].to(dtype), 2.0)[0]
+        l.backward()
+        return r.detach(), float(l.detach()), {k: p.grad.double() for k, p in _named(o) if p.grad is not None}
+    ref, rl, g32 = oracle(torch.float32)
+    _, _, g64 = oracle(torch.float64)
+
+    def l2(g):
+        num = sum(float(((g[k].double().cpu() - g64[k]) ** 2).sum()) for k in g64)
+        return (num / sum(float((g64[k] ** 2).sum()) for k in g64)) ** 0.5
+    e_cpu = np.array([rel(g32[k], g64[k]) for k in g64])
     for tier in ('fp32', 'fp32_3plane'):
-        m = train.build_model(synth.TINY, device='cuda')
-        synth.fill_state_dict_([m.encoder, m.decoder], 17)
+        m = train.build_model(synth.PUBLISHED, device='cuda')
+        synth.fill_state_dict_([m.encoder, m.decoder], 23)
+        shrink_beta([m.encoder, m.decoder])
         m.compute_dtype = tier
         m.train()
         b = {kk: v.cuda() for kk, v in cb.items()}
@@ -659,45 +912,17 @@ def test_training_step_with_hostile_inputs_against_the_oracle(env, kind):
                                  validity_map_loss_smoothness=None, w_lidar_loss=2.0)
         loss.backward()
         torch.cuda.synchronize()
-        res[tier] = (out.detach().cpu(), float(loss.detach()), {k: p.grad.detach().cpu().clone() for k, p in _named(m) if p.grad is not None})
-    def oracle(dtype):
-        o = FusionNetOracle(**synth.TINY)
-        synth.fill_state_dict_([o.encoder, o.decoder], 17)
-        for mod in (o.encoder, o.decoder):
-            mod.to(dtype)
-        o.train()
-        r = o.forward(cb['image'].to(dtype), cb['input_depth'].to(dtype))
-        l = o.compute_loss(r, cb['ground_truth'].to(dtype), cb['lidar_map'].to(dtype), 2.0)[0]
-        l.backward()
-        return r.detach(), float(l), {k: p.grad.double() for k, p in _named(o) if p.grad is not None}
-    ref, rl, g32 = oracle(torch.float32)
-    _, _, g64 = oracle(torch.float64)
-    # gradients are held to fp64 with the fp32 CPU oracle's own per-tensor error as the yardstick.  Exception, found by this test and
-    # NOT a property of the operand arithmetic: with all inputs scaled by 1e-6 the depth branch's BatchNorm inputs are constant to 5-6
-    # digits (std / |mean| ~ 1e-6: the tensors are dominated by the previous layer's beta), and xhat = (z - mean) * invstd with the mean
-    # held in fp32 (rcf_bn_finalize's coefficient rows) is then off by a few per cent in three BatchNorm-weight / stride-2 conv
-    # gradients -- IDENTICALLY on the two-plane and the three-plane arithmetic (3.58e-2; the tiers agree with each other to 2e-4).  DESIGN.md section 4 "numerics
-    # that mattered" records it; for that case the two tiers are compared with each other.
-    e_cpu = {k: rel(g32[k], g64[k]) for k in g64}
-    worsts = {}
-    for tier, (out, loss, grads) in res.items():
-        e = rel(out, ref)
-        errs = sorted(((rel(grads[k], g64[k]), k) for k in g64), reverse=True)
-        worsts[tier] = errs[0][0]
-        print('%s, %s: output rel %.2e, loss rel %.2e, worst gradient tensors vs fp64 %s (CPU fp32 oracle worst %.2e)'
-              % (kind, tier, e, abs(loss - rl) / rl, ['%.2e %s' % ek for ek in errs[:2]], max(e_cpu.values())))
-        assert bool(torch.isfinite(out).all())
-        assert e < NORTH_STAR and abs(loss - rl) < NORTH_STAR * rl
-        if kind != 'tiny_inputs':
-            for err, k in errs:
-                assert err < 5 * NORTH_STAR or err < 3.0 * e_cpu[k] + 1e-5, (tier, k, err, e_cpu[k])
-    if kind == 'tiny_inputs':
-        cross = max(rel(res['fp32'][2][k], res['fp32_3plane'][2][k]) for k in g64)
-        print('tiny_inputs: two-plane vs three-plane gradients, worst tensor rel %.2e' % cross)
-        assert cross < NORTH_STAR
-    # and the two-plane tier is not further from the oracle than the three-plane tier by more than fp32 round-off allows
-    assert rel(res['fp32'][0], ref) < 2.0 * rel(res['fp32_3plane'][0], ref) + 2e-5
-    assert worsts['fp32'] < 2.0 * worsts['fp32_3plane'] + 1e-4
+        grads = {k: p.grad.detach().cpu() for k, p in _named(m) if p.grad is not None}
+        e_hip = np.array([rel(grads[k], g64[k]) for k in g64])
+        print('sparse radar channel, tiny beta, %s: output rel %.2e, loss rel %.2e; gradients vs fp64: median tensor HIP %.2e (CPU fp32 %.2e), '
+              'worst HIP %.2e (CPU %.2e), whole-gradient L2 HIP %.2e (CPU %.2e)'
+              % (tier, rel(out.detach().cpu(), ref), abs(float(loss.detach()) - rl) / rl, np.median(e_hip), np.median(e_cpu), e_hip.max(), e_cpu.max(),
+                 l2(grads), l2(g32)))
+        assert rel(out.detach().cpu(), ref) < NORTH_STAR and abs(float(loss.detach()) - rl) < NORTH_STAR * rl
+        assert np.median(e_hip) <= 3.0 * np.median(e_cpu) + 1e-5
+        assert l2(grads) <= 3.0 * l2(g32) + 1e-5
+        assert e_hip.max() <= 5.0 * e_cpu.max() + 2e-4
+        del m
 
 
 def test_three_adam_steps_follow_the_reference_trajectory(env, golden_dir):

@@ -75,6 +75,12 @@ def test_t1_published_config1(golden_dir):
         assert abs(float(bufs[key].double().norm()) - l2) <= 1e-5 * l2, key
     assert sum(p.numel() for p in m.parameters()) == 14413568
     assert sum(grads[k].numel() for k in g['grad_keys'].tolist()) == 14142208
+    # fixture T1b: 2048 seeded elements of each of the ten largest gradient tensors, element by element against the REAL reference
+    s = np.load(os.path.join(golden_dir, 'T1b_published_grad_samples.npz'))
+    assert [int(v) for v in s['meta']] == [n, h, w, k, dseed, wseed] and len(s['keys']) == 10
+    for key, idx, ref32, amax in zip(s['keys'].tolist(), s['idx'], s['ref32'], s['fp64_absmax']):
+        got = grads[key].grad.reshape(-1).numpy()[idx]
+        assert float(np.abs(got - ref32).max()) <= 2e-4 * float(amax), key
 
 
 def test_t2_tiny_adam_trajectory(golden_dir):
