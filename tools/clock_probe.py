@@ -7,7 +7,8 @@ from rcf_amd import ops
 what = sys.argv[1] if len(sys.argv) > 1 else 'fwd'
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
 dev = 'cuda'
-n, h, w, c = 8, 225, 400, 64
+ops.set_precision(os.environ.get('RCF_BENCH_PREC', 'fp32'))   # f16x2: the fp32 configuration's default arithmetic (unscaled call: scale one)
+n, h, w, c = [int(v) for v in os.environ.get('RCF_PROBE_SHAPE', '8,225,400,64').split(',')]
 d = ops.make_fwd_desc(n, h, w, c, 0, c, 3, 1, h, w, 0)
 info = ops.conv_query(d)
 SC = float(os.environ.get('RCF_BENCH_DATA_SCALE', '1'))   # 0: all-zero operands
@@ -40,4 +41,7 @@ while time.time() - t0 < secs:
 dt = time.time() - t0
 stop = True; t.join()
 print(what, '%.3f ms per launch' % (dt / it * 1e3))
-for s in samples[:12]: print('  ', s[:200])
+import re
+for s in samples[2:8]:
+    m = re.findall(r'\((\d+)Mhz\)', s); w = re.findall(r'Power \(W\): ([0-9.]+)', s)
+    print('   sclk %s MHz, socket power %s W' % (m[0] if m else '?', w[0] if w else '?'))
