@@ -61,6 +61,40 @@ KERNEL_NAMES = {
 }
 
 
+def decode_kernel_id(kid):
+    '''rcf_conv_info.kernel_id / wgrad_kernel_id (csrc/rcf_conv_impl.h: rcf_conv2d_query) -> (kernel class, arithmetic it ran on).
+    forward / input gradient: kind * 1000 + ... (+ 5000 split); weight gradient: 10000 + kind * 1000 + ... (+ 5000 split);
+    + 20000: bf16 operands, + 40000: two scaled fp16 planes.'''
+    tier = kid // 20000
+    base = kid % 20000
+    wgrad = base >= 10000
+    b = base % 10000
+    split = b >= 5000
+    kind = (b - 5000) // 1000 if split else b // 1000
+    kname = {0: '3x3 stride 1', 1: '3x3 stride 2', 2: '1x1', 3: '7x7 stride-2 stems', 4: '2x2 phases'}.get(kind, 'kind %d' % kind)
+    if split:
+        arith = {0: 'three bf16 planes, 6 products per multiply (bf16 MFMA)', 1: 'bf16 operands, 1 product (bf16 MFMA)',
+                 2: 'two scaled fp16 planes, 3 products per multiply (fp16 MFMA)'}[tier]
+    else:
+        arith = 'f32 MFMA (exact fp32 products)'
+    return kname + (' weight gradient' if wgrad else ' forward + input gradient'), arith
+
+
+def arithmetic_of_step(table, n_steps):
+    '''config.arithmetic: which arithmetic each class of convolution launches of the measured step ran on -- generated from the kernel
+    ids the step LAUNCHED (engine -> ops.KernelTimer), not written by hand.  {class: {arithmetic: launches per step}} plus one line.'''
+    by = {}
+    for kid, (cnt, flops, ms) in table.items():
+        k, a = decode_kernel_id(kid)
+        r = by.setdefault(k, {}).setdefault(a, [0, 0.0])
+        r[0] += cnt
+        r[1] += ms
+    out = {k: {a: {'launches_per_step': round(v[0] / float(n_steps), 1), 'ms_per_step': round(v[1] / n_steps, 3)} for a, v in d.items()}
+           for k, d in sorted(by.items())}
+    line = '; '.join('%s: %s' % (k, ' / '.join('%s x %g' % (a.split(',')[0], v['launches_per_step']) for a, v in d.items())) for k, d in out.items())
+    return out, line
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -106,22 +140,26 @@ def spawn_ranks(args):
         sys.stderr.write('bench.py: --gpus %d but only %d device(s) visible; refusing to measure fewer GPUs than asked\n'
                          % (args.gpus, n_dev))
         return 2
+    import tempfile
+    RENDEZVOUS_ERRORS = ('EADDRINUSE', 'ddress already in use', 'failed to bind', 'server socket has failed', 'DistStoreError',
+                         'DistNetworkError', 'connect() timed out', 'Connection refused', 'store timeout')
     rc = 0
     for attempt in range(2):
-        # a free port, found by binding port 0 and closing the socket: another process can take it before the children bind it, so a
-        # run whose ranks die within the rendezvous window is retried once on a fresh port
+        # a free port, found by binding port 0 and closing the socket: another process can take it before the children bind it.  ONLY
+        # that failure -- a rendezvous / bind error in a rank's stderr -- is retried, once, on a fresh port; any other early death (out of
+        # memory, a HIP fault, an import error) is a real failure and is reported as what it is, once
         s = socket.socket()
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
         s.close()
-        t_start = time.time()
-        procs = []
+        procs, logs = [], []
         for r in range(args.gpus):
             env = dict(os.environ)
             env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(args.gpus), 'LOCAL_WORLD_SIZE': str(args.gpus),
                         'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'HSA_ENABLE_IPC_MODE_LEGACY': '0',
                         'RCF_BENCH_SELF_SPAWNED': '1'})
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+            logs.append(tempfile.TemporaryFile(mode='w+'))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stderr=logs[-1]))
         # fail fast: a rank that dies would leave the others waiting in a collective until the backend's (30-minute) timeout
         rc = 0
         live = list(procs)
@@ -138,9 +176,17 @@ def spawn_ranks(args):
                         q.terminate()
             if live:
                 time.sleep(0.2)
-        if rc == 0 or attempt == 1 or time.time() - t_start > 180.0 or rc in (2, 3):
-            break   # success, a real failure (the loss check: 3; too few devices: 2), or one that came after the rendezvous
-        sys.stderr.write('bench.py: ranks failed within the rendezvous window (port %d taken?); retrying once on a fresh port\n' % port)
+        errs = []
+        for f in logs:
+            f.seek(0)
+            errs.append(f.read())
+            f.close()
+        rendezvous = rc != 0 and any(sig in e for e in errs for sig in RENDEZVOUS_ERRORS)
+        if not (rendezvous and attempt == 0):
+            for e in errs:
+                sys.stderr.write(e)
+            break
+        sys.stderr.write('bench.py: the ranks could not rendezvous on port %d (taken between probing and binding?); retrying once on a fresh port\n' % port)
     return rc
 
 
@@ -389,6 +435,7 @@ def run_rank(args):
         r[0] += cnt; r[1] += flops; r[2] += ms; r[3] += getattr(timer, 'bytes', {}).get(kid, 0.0)
     dom = max(fam, key=lambda f: fam[f][2]) if fam else None
     ev_steps = 3 if use_graph else args.steps
+    arith_table, arith_line = arithmetic_of_step(table, ev_steps)
 
     side = None
     if args.side_leg and dtype == 'f32' and world == 1:   # opt-in: the same step on the three-plane bf16 split, beside the metric
@@ -416,6 +463,7 @@ def run_rank(args):
         'scaling': 'weak',
         'vs_baseline': None,
         'dtype': dtype,
+        'arithmetic_tier': {'f32': 'fp32 tensors; split convolutions on two scaled fp16 planes, 3 products per multiply (RCF_PREC_F16X2: fp32-class error vs fp64, not IEEE fp32 products)', 'f32_3plane': 'fp32 tensors; split convolutions on three bf16 planes, 6 products (exact)', 'bf16': 'bf16 tensors and operands'}[dtype],
         'data': 'synthetic',
         'config': {'workload': 'FusionNet %s training, per-GPU batch %d, %dx%d, %d-point radar maps (BASELINE.json %s)'
                                % ({'f32': 'fp32', 'f32_3plane': 'fp32 (split conv kernels on three bf16 planes)'}.get(
@@ -425,12 +473,9 @@ def run_rank(args):
                    'global_batch': world * batch, 'parallelism': 'dp%d' % world,
                    'step': 'forward + outlier removal + masked L1 + backward + Adam, train-mode BatchNorm',
                    'launch': 'one hipGraph replay per step (bitwise the eager step)' if use_graph else (graph_note or 'eager launches'),
-                   'arithmetic': {'f32': 'fp32 tensors; 3x3 / 2x2 convolutions as three fp16-MFMA products of two scaled fp16 planes per operand '
-                                         '(22-23 significant bits, per-tensor power-of-two scales from the producing kernels; error against fp64 within '
-                                         'the f32 MFMA\'s: tests/test_hip_f16x2.py), 1x1 / 7x7 / stride-2 forward on the f32 MFMA, everything '
-                                         'else fp32 with fp64 BatchNorm sums',
-                                  'f32_3plane': 'fp32 tensors; 3x3 / 2x2 convolutions as six bf16-MFMA products of three bf16 planes per operand'}.get(
-                                      dtype, 'bf16 tensors and MFMA operands, fp32 accumulate'),
+                   'arithmetic': ('fp32 tensors' if dtype != 'bf16' else 'bf16 tensors') + ', fp32 accumulate, fp64 BatchNorm sums; convolution launches of the '
+                                 'measured step by the arithmetic they ran on (from their kernel ids): ' + arith_line,
+                   'arithmetic_by_kernel_class': arith_table,
                    'first_step_loss': None if first_loss is None else round(first_loss, 5), 'final_loss': round(final_loss, 5),
                    'preheat_steps': n_pre},
         'rccl_ranks': dist.get_world_size() if world > 1 else 1,
@@ -496,7 +541,7 @@ def run_rank(args):
             'share_of_step_time': round(ms / ev_steps / (1000.0 * dt / args.steps), 4),
             # the subset north_star's ">= 70 % MFMA utilisation" names: the encoder's 3x3 convolutions (ResNet blocks, both branches;
             # forward + input gradient + weight gradient launches), from the same events
-            'encoder_3x3': _encoder_3x3(timer, ev_steps, dtype),
+            'encoder_3x3': dict(_encoder_3x3(timer, ev_steps, dtype) or {}, mfma_busy_pmc_of_its_kernels=(_pmc_value('kernels of the encoder 3x3 convolutions', 'mfma_busy_fraction') if dtype == 'f32' else None)),
             'all_conv_kernels': {'achieved': round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
                                  'share_of_step_time': round(conv_ms / ev_steps / (1000.0 * dt / args.steps), 4),
                                  'gflop_per_sample': round(conv_flops / (batch * ev_steps) / 1e9, 2)},

@@ -59,6 +59,7 @@ class WeightPlan(object):
         self._n_pack = self._n_phase = self._n_amax = 0
         self.wamax = None           # arena of the weight maxima (device scalars) of the recorded step
         self._wamax_used = 0
+        self.wamax_chunks = []
 
     def enable(self):
         if self.state == 'off':
@@ -71,13 +72,14 @@ class WeightPlan(object):
             if self._n_phase:
                 ops.phase_weights_batch(self._phase_items, self._n_phase)
             if self._n_amax:
-                self.wamax.zero_()
+                for chunk in self.wamax_chunks:
+                    chunk.zero_()
                 ops.amax_batch(self._amax_items, self._n_amax)
             if self._n_pack:
                 ops.conv_pack_batch(self._pack_items, self._n_pack)
         else:
             self.state, self.entries, self.dirty = 'record', [], False
-            self.wamax, self._wamax_used = None, 0
+            self.wamax, self._wamax_used, self.wamax_chunks = None, 0, []
         self.pos = 0
         self.active = True
 
@@ -92,10 +94,12 @@ class WeightPlan(object):
 
     def new_wamax_slot(self, like):
         '''A zeroed device scalar of the recorded step's weight-maximum arena.'''
-        if self.wamax is None:
+        if self.wamax is None or self._wamax_used >= self.wamax.numel():
+            # first slot, or the current chunk is full (a net with more weight tensors): another chunk; every chunk is zeroed before
+            # the batched maxima of a replayed step
             self.wamax = torch.zeros(1024, dtype=torch.float32, device=like.device)
-        if self._wamax_used >= self.wamax.numel():
-            raise RuntimeError('weight-maximum arena exhausted')
+            self.wamax_chunks.append(self.wamax)
+            self._wamax_used = 0
         self._wamax_used += 1
         return self.wamax[self._wamax_used - 1:self._wamax_used]
 
@@ -236,7 +240,10 @@ class Engine(object):
         if self._amax_arena is None or not self._f16():
             return None
         if self._amax_used >= self._amax_arena.numel():
-            raise RuntimeError('activation-maximum arena exhausted')
+            # a deeper net, or a second forward before the backward: another zeroed chunk (the full one stays alive through the Acts
+            # that hold views of it)
+            self._amax_arena = torch.zeros(512, dtype=torch.float32, device=self._amax_arena.device)
+            self._amax_used = 0
         self._amax_used += 1
         return self._amax_arena[self._amax_used - 1:self._amax_used]
 

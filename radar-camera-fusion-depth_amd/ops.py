@@ -89,13 +89,22 @@ def precision_of(compute_dtype):
     compute_dtype does the same per model).  Everything else passes through.'''
     import os
     if compute_dtype == 'fp32':
-        return 'fp32' if os.environ.get('RCF_FP32_TIER', FP32_TIER_DEFAULT) == '3plane' else 'f16x2'
+        tier = 'fp32' if os.environ.get('RCF_FP32_TIER', FP32_TIER_DEFAULT) == '3plane' else 'f16x2'
+        if not _TIER_LOGGED[0]:   # once per process: 'fp32' names an accuracy class, this line says which arithmetic delivers it
+            _TIER_LOGGED[0] = True
+            import logging
+            logging.getLogger('rcf_amd').info(
+                "compute_dtype='fp32': fp32 tensors; split convolution kernels on %s (RCF_FP32_TIER=3plane / compute_dtype='fp32_3plane' "
+                "select the exact three-plane bf16 split)", 'two scaled fp16 planes, three products per multiply (RCF_PREC_F16X2)'
+                if tier == 'f16x2' else 'three bf16 planes, six products per multiply (exact)')
+        return tier
     if compute_dtype == 'fp32_3plane':
         return 'fp32'
     return compute_dtype
 
 
 FP32_TIER_DEFAULT = 'f16x2'
+_TIER_LOGGED = [False]
 
 
 def act_dtype():

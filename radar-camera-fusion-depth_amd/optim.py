@@ -67,6 +67,14 @@ class FusedAdam(torch.optim.Optimizer):
                 shared = self._shared_steps.setdefault(key, torch.tensor(0.0, dtype=torch.float32))
                 shared.fill_(float(st['step']))
                 st['step'] = shared
+        # the device-side counters and hyper-parameters of the launched slices follow the loaded state (a captured step replayed after
+        # a resume reads THEM): reseed the step count, and mark the hyper-parameters unknown so the next sync / step copies them
+        for (pid, _, _), ds in self._dev_state.items():
+            shared = self._shared_steps.get(pid)
+            if shared is not None:
+                ds[0][0:1].fill_(float(shared))
+                ds[2] = int(float(shared))
+            ds[1] = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -129,7 +137,7 @@ class FusedAdam(torch.optim.Optimizer):
         if ds is None or ds[2] != step0 - 1:
             # first use, or the host-side step count moved on its own (load_state_dict): (re)seed the device counter
             dev = torch.tensor([float(step0 - 1)] + list(hyper) + [0.0, 0.0], dtype=torch.float32).to(parena.device)
-            ds = [dev, hyper, step0 - 1, group]
+            ds = [dev, hyper, step0 - 1, next(i for i, g in enumerate(self.param_groups) if g is group)]
             self._dev_state[dkey] = ds
         elif ds[1] != hyper:
             ds[0][1:6].copy_(torch.tensor(hyper, dtype=torch.float32))   # learning-rate schedule etc. (never inside a capture)
@@ -143,7 +151,9 @@ class FusedAdam(torch.optim.Optimizer):
         memory, so a change made on the host since the last step (the reference's learning-rate schedule rewrites g['lr'],
         src/fusionnet_main.py:354-362) is copied there now -- outside the graph, on the replay's stream.'''
         for ds in self._dev_state.values():
-            group = ds[3]
+            # the group by INDEX: torch.optim.Optimizer.load_state_dict replaces self.param_groups with new dictionaries, and a
+            # learning-rate schedule after a resume writes into those
+            group = self.param_groups[ds[3]]
             hyper = (float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),
                      float(group['weight_decay']))
             if ds[1] != hyper:

@@ -172,6 +172,21 @@ def test_fused_adam_counts_one_step_per_step_call_with_several_param_groups(pkg,
     opt.sync_hyper_parameters()
     lrs = sorted(float(ds[0][1]) for ds in opt._dev_state.values())
     assert lrs == [pytest.approx(2.5e-4), pytest.approx(1e-3)]
+    # resume: load_state_dict replaces the param-group dictionaries; a schedule that writes into the NEW ones still reaches the device
+    # copies, and the device step counters follow the loaded state
+    sd = opt.state_dict()
+    for st in sd['state'].values():
+        st['step'] = torch.tensor(7.0)
+    old_groups = list(opt.param_groups)
+    opt.load_state_dict(sd)
+    assert all(g is not o for g, o in zip(opt.param_groups, old_groups))
+    opt.param_groups[0]['lr'] = 7.5e-4
+    opt.sync_hyper_parameters()
+    assert sorted(float(ds[0][1]) for ds in opt._dev_state.values()) == [pytest.approx(2.5e-4), pytest.approx(7.5e-4)]
+    assert all(float(ds[0][0]) == 7.0 and ds[2] == 7 for ds in opt._dev_state.values())
+    del seen[:]
+    opt.step()
+    assert [s[1] for s in seen] == [8.0, 8.0] and [s[2] for s in seen] == [pytest.approx(7.5e-4), pytest.approx(2.5e-4)], seen
 
 
 def test_bench_expected_loss_under_data_parallelism_is_the_global_masked_mean(pkg):
