@@ -305,6 +305,24 @@ def _pmc_value(kernel_name, field):
         return None
 
 
+def _pmc_workload(workload, family, field):
+    '''A value of the newest committed profiles/rNN_pmc_<workload>.json (tools/pmc_families.py), or (None, why): only when that profile
+    was taken on the kernel sources this tree builds.'''
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_%s.json' % workload)))
+    if not cands:
+        return None, 'no PMC profile of this workload committed'
+    try:
+        pmc = json.load(open(cands[-1]))
+        meta = pmc.get('_meta', {})
+        src = 'profiles/%s (rocprofv3 --pmc passes of this command, collected at commit %s)' % (os.path.basename(cands[-1]), meta.get('head'))
+        if meta.get('csrc_sha') != _csrc_sha():
+            return None, 'stale: ' + src + ' profiled other kernel sources than this tree'
+        return float(pmc[family][field]), src
+    except Exception:
+        return None, '%s has no such row' % os.path.basename(cands[-1])
+
+
 def _expected_first_loss(key, world=1, w_lidar=2.0):
     '''The CPU oracle's loss of the first step.  Under data parallelism the step computes the reference's ONE masked mean over the
     gathered batch (src/fusionnet_main.py:385, src/fusionnet_model.py:245-253): rank r trains on data seed 1234 + r, so the expected
@@ -368,7 +386,9 @@ def run_rank(args):
 
     step = eager_step
     first_loss = None
-    use_graph = args.graph != 0 and world == 1 and hasattr(model, 'capture_training_step')
+    # world > 1: graph segments between the exchange points -- over RCCL (stream-ordered collectives).  gloo (the 1-GPU test mode) blocks
+    # the host in every collective and two processes time-slice the device: there the eager step is the faster one, measured
+    use_graph = args.graph != 0 and hasattr(model, 'capture_training_step') and (world == 1 or dist.get_backend() == 'nccl')
     graph_note = None
     n_pre = 0
     for i in range(max(args.warmup, 0)):
@@ -383,11 +403,26 @@ def run_rank(args):
     if args.preheat_s > 0:   # untimed: board at its power limit, clocks settled
         torch.cuda.synchronize()
         t_pre = time.time()
-        while time.time() - t_pre < args.preheat_s:
+        if world == 1:
+            while time.time() - t_pre < args.preheat_s:
+                loss = step()
+                if first_loss is None:
+                    first_loss = float(loss.detach())
+                n_pre += 1
+                torch.cuda.synchronize()
+        else:
+            # every rank must run the SAME number of steps (each step is a sequence of collectives): time one, agree on the count
             loss = step()
             if first_loss is None:
                 first_loss = float(loss.detach())
-            n_pre += 1
+            torch.cuda.synchronize()
+            n_pre = 1
+            n_more = int(min(2000, max(0, int(args.preheat_s / max(time.time() - t_pre, 1e-3)))))
+            tn = torch.tensor([n_more], dtype=torch.int64, device=dev)
+            dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+            for _ in range(int(tn.item())):
+                loss = step()
+                n_pre += 1
             torch.cuda.synchronize()
     timer = ops.KernelTimer()
     if not use_graph:
@@ -397,8 +432,11 @@ def run_rank(args):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
+    host_s = 0.0
     for _ in range(args.steps):
+        th = time.time()
         loss = step()
+        host_s += time.time() - th     # host time spent ENQUEUEING the step (nothing in it synchronises)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -416,7 +454,9 @@ def run_rank(args):
         dist.all_gather(gathered, t)
         per_rank_ms = [round(1000.0 * float(g.item()) / args.steps, 3) for g in gathered]
         dt = max(float(g.item()) for g in gathered)
-        dp_info = measure_overlap(model, step, dev, 1000.0 * dt / args.steps)
+        dp_info = measure_overlap(model, eager_step, dev, 1000.0 * dt / args.steps)
+        dp_info['host_ms_per_step'] = round(1000.0 * host_s / args.steps, 3)
+        dp_info['launch'] = ('%d hipGraph segments + the RCCL calls between them per step' % len(step.segments)) if (use_graph and getattr(step, 'segments', None)) else 'eager launches'
 
     table = timer.collect()
     if use_graph:   # a replayed graph has no per-launch events: time the kernel families on a few eager steps after the timed region
@@ -472,7 +512,8 @@ def run_rank(args):
                                   'configs[1]' if dtype in ('f32', 'f32_3plane') else 'configs[3] on %d GPU(s)' % world),
                    'global_batch': world * batch, 'parallelism': 'dp%d' % world,
                    'step': 'forward + outlier removal + masked L1 + backward + Adam, train-mode BatchNorm',
-                   'launch': 'one hipGraph replay per step (bitwise the eager step)' if use_graph else (graph_note or 'eager launches'),
+                   'launch': (('one hipGraph replay per step (bitwise the eager step)' if world == 1 else 'hipGraph segments between the exchange points of the data-parallel step (bitwise the eager step)') if use_graph else (graph_note or 'eager launches')),
+                   'host_ms_per_step': round(1000.0 * host_s / args.steps, 3),
                    'arithmetic': ('fp32 tensors' if dtype != 'bf16' else 'bf16 tensors') + ', fp32 accumulate, fp64 BatchNorm sums; convolution launches of the '
                                  'measured step by the arithmetic they ran on (from their kernel ids): ' + arith_line,
                    'arithmetic_by_kernel_class': arith_table,
@@ -511,8 +552,14 @@ def run_rank(args):
         if dtype == 'f32':
             traffic, traffic_src = _pmc_traffic(kname)
             mfma_busy = _pmc_value(kname, 'mfma_busy_fraction')
-        else:   # the committed PMC passes profile the fp32 step
-            traffic, traffic_src = None, 'the committed PMC passes (profiles/) were collected on the fp32 step'
+        elif dtype == 'bf16':
+            fam_key = kname.replace('conv_split_kernel', 'conv_b16_kernel')
+            traffic, traffic_src = _pmc_workload('bf16_train', fam_key, 'hbm_bytes_per_launch')
+            traffic = None if traffic is None else round(traffic / 1e9, 4)
+            mfma_busy = _pmc_workload('bf16_train', fam_key, 'mfma_busy_fraction')[0]
+            mfma_busy = None if mfma_busy is None else round(mfma_busy, 4)
+        else:   # the committed PMC passes profile the default fp32 step
+            traffic, traffic_src = None, 'the committed PMC passes (profiles/) were collected on the default fp32 step'
             mfma_busy = None
         if is_split:
             if dtype == 'bf16':
@@ -710,8 +757,12 @@ def run_infer(args, dev):
     # forward minimum traffic: every conv input read once + every conv output written once
     gbytes = (2.80 if dtype == 'f32' else 1.40) * (args.height * args.width / 1.44e6)
     ach = gbytes * n_samples / dt
+    traffic, traffic_src = _pmc_workload('bf16_infer' if dtype == 'bf16' else 'f32_infer', 'whole_step', 'hbm_bytes')
+    conv_busy = _pmc_workload('bf16_infer' if dtype == 'bf16' else 'f32_infer', 'conv_b16_kernel 3x3 s1', 'mfma_busy_fraction')[0]
     rec['roofline'] = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                       'traffic': None, 'scope': 'whole forward: algorithmic conv input + output bytes per sample (%.2f GB) x samples / time; '
+                       'traffic': None if traffic is None else round(traffic / 1e9, 3), 'traffic_source': traffic_src,
+                       'traffic_unit': 'HBM GB per batch, all kernels of one forward (algorithmic: %.1f GB)' % (gbytes * batch),
+                       'mfma_busy_pmc_3x3_kernels': None if conv_busy is None else round(conv_busy, 4), 'scope': 'whole forward: algorithmic conv input + output bytes per sample (%.2f GB) x samples / time; '
                                                  'the bf16 layers sit near the MFMA/HBM ridge (SURVEY.md 8d)' % gbytes,
                        'mfma_frac_of_bf16_peak': round(rec['algorithmic_tflops'] / BF16_MFMA_PEAK_TFLOPS, 4)}
     print(json.dumps(rec), flush=True)
@@ -773,7 +824,10 @@ def run_radarnet(args, dev):
         roofline = {'bound': 'mfma', 'kernel': kname + (' (%s)' % TIER_TEXT[tier] if is_split else ''),
                     'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                     'algorithmic_fp32_tflops': round(algorithmic, 2), 'useful_frac': round(algorithmic / peak, 4),
-                    'products_per_multiply': SPLIT_PRODUCTS[tier] if is_split else 1, 'traffic': None,
+                    'products_per_multiply': SPLIT_PRODUCTS[tier] if is_split else 1,
+                    'traffic': (lambda v: None if v is None else round(v / 1e9, 4))(_pmc_workload('bf16_radarnet', kname, 'hbm_bytes_per_launch')[0]) if tier == 'bf16' else None,
+                    'traffic_source': _pmc_workload('bf16_radarnet', kname, 'hbm_bytes_per_launch')[1] if tier == 'bf16' else 'no PMC profile of the fp32 RadarNet step',
+                    'mfma_busy_pmc': (lambda v: None if v is None else round(v, 4))(_pmc_workload('bf16_radarnet', kname, 'mfma_busy_fraction')[0]) if tier == 'bf16' else None,
                     'events_from': '3 eager steps after the timed region', 'launches_per_step': cnt // 3,
                     'avg_launch_ms': round(ms / cnt, 4), 'share_of_step_time': round(ms / 3 / (1000.0 * dt / args.steps), 4),
                     'all_conv_kernels_share_of_step_time': round(conv_ms / 3 / (1000.0 * dt / args.steps), 4)}

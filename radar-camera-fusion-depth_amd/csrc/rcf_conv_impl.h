@@ -2544,7 +2544,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     const bool vt_ok = vt_allowed(d);
     const int pxs[3] = {32, 16, 8};
     // pixels per workgroup tile: 256; 512 for the 32-co 3x3 split layers; 128 for the three-plane stride-2 split kernel
-    const int tile_px = (s->split && s->kind == K3S2 && (!s->bf16 || s->dma)) ? 128 : ((s->split && s->nt == 1 && s->kind == K3S1 && !s->small) ? 512 : 256);
+    const int tile_px = (s->split && s->kind == K3S2 && (!s->bf16 || s->dma)) ? 128 : ((s->split && s->nt == 1 && s->kind == K3S1 && !s->small) ? 512 : 256);   // (64-co bf16 DMA layers on 512-pixel tiles, MT x NT = 4 x 2: 55-109 spilled VGPRs at the 256 limit -- compiled in round 4, not viable)
     for (int i = 0; i < 3; ++i) {
         const int px = pxs[i], th = tile_px / px;
         if (px == 8 && (s->split || !(s->kind == K3S1 && s->ck == 16))) continue;

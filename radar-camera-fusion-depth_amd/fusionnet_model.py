@@ -526,13 +526,16 @@ class FusionNetModel(object):
         replays the ~1100 kernel launches with one hipGraphLaunch (host time per step drops from ~12 ms of Python to well under
         1 ms).  Everything a replay must see fresh lives in device memory: parameters, gradients, Adam moments, the Adam step count
         and hyper-parameters (rcf_adam_step_dev), BatchNorm statistics.  Capturing has no side effect on the training state: the
-        warm-up steps it needs are rolled back.  Single-GPU only (the data-parallel exchange is not recorded); the optimizer must
-        be rcf_amd.optim.FusedAdam.  Passing None for an input reuses what the static buffer holds.
+        warm-up steps it needs are rolled back.  The optimizer must be rcf_amd.optim.FusedAdam.  Passing None for an input reuses
+        what the static buffer holds.
+        Under data parallelism (data_parallel() with torch.distributed initialised) the step is recorded as graph SEGMENTS between
+        its exchange points -- the all-reduce of the loss sums, each gradient bucket, the wait before Adam (parallel.SegmentedCapture)
+        -- and a replay launches segment, RCCL call, segment, ... : about eight hipGraphLaunch + seven collectives of host work per
+        step instead of ~1100 launches, the buckets overlapping the next segment as in the eager step.  Every rank must capture
+        (the warm-up steps run the real collectives) and replay in step with the others.
         '''
         from . import train
         from .optim import FusedAdam
-        if self._dp is not None:
-            raise _lib.RcfError('capture_training_step records the single-GPU step; data-parallel runs launch eagerly')
         if not isinstance(optimizer, FusedAdam):
             raise _lib.RcfError('capture_training_step needs rcf_amd.optim.FusedAdam (step count and hyper-parameters on the device)')
         if not self._training:
@@ -579,9 +582,29 @@ class FusionNetModel(object):
                     one()
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_loss = one()
+            if self._dp is None:
+                segmented = None
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_loss = one()
+            else:
+                import gc
+                from .parallel import SegmentedCapture
+                graph = None
+                segmented = SegmentedCapture()
+                gc.collect()
+                torch.cuda.empty_cache()
+                cap_stream = torch.cuda.Stream(device=dev)
+                cap_stream.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(cap_stream):
+                    self._dp.capture = segmented
+                    try:
+                        segmented.begin()
+                        static_loss = one()
+                        segmented.end()
+                    finally:
+                        self._dp.capture = None
+                torch.cuda.current_stream(dev).wait_stream(cap_stream)
         finally:
             # whether or not the capture succeeded: the profiler hook back, the warm-up steps rolled back (the capture itself executed
             # nothing), so a caller that falls back to eager launches continues from the state it had
@@ -599,10 +622,14 @@ class FusionNetModel(object):
                     raise _lib.RcfError('captured for %s, got %s' % (shp, tuple(src.shape)))
                 dst.copy_(src, non_blocking=True)
             optimizer.sync_hyper_parameters()   # a learning-rate schedule between replays reaches the recorded Adam launch
-            graph.replay()
+            if segmented is None:
+                graph.replay()
+            else:
+                segmented.replay(self._dp)
             optimizer.note_replayed_step()
             return static_loss
         step.graph = graph
+        step.segments = None if segmented is None else segmented.segments
         step.static_inputs = static
         # the recorded launches read and write the weight plan's persistent buffers: keep THESE alive with the graph even if the
         # engine later re-records its plan (another input size run eagerly in between)

@@ -14,7 +14,11 @@ from ._lib import (ConvDesc, ConvInfo, RCF_ACT_LEAKY_RELU, RCF_ACT_NONE, RCF_GAT
                    RCF_W_DGRAD, RCF_W_FORWARD, check)
 
 
+LAUNCHES = [0]   # C-ABI launches enqueued by this module so far (FusionNetModel's segmented capture: "did anything run since the last cut?")
+
+
 def _stream():
+    LAUNCHES[0] += 1
     # the current stream of the CURRENT device: the model entry points (FusionNetModel / RadarNetModel forward, backward, loss) make
     # the tensors' device current for the whole call (torch.cuda.device guard); direct users of this module do the same
     return torch.cuda.current_stream().cuda_stream

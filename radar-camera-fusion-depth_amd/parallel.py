@@ -23,6 +23,7 @@ class GradientBuckets(object):
         self.n_buckets = n_buckets
         self.group = group
         self.handles = []
+        self.capture = None       # a SegmentedCapture while FusionNetModel.capture_training_step records a data-parallel step
         self.rebuild(model)
 
     def rebuild(self, model):
@@ -62,17 +63,83 @@ class GradientBuckets(object):
         self.remaining[b] -= 1
         if self.remaining[b] == 0:
             lo, hi = self.bounds[b]
+            if self.capture is not None:   # recording a segmented step: the exchange becomes a cut between two graph segments
+                self.capture.cut(('bucket', lo, hi))
+                return
             self.handles.append(dist.all_reduce(self.garena[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish_backward(self):
         if any(r != 0 for r in self.remaining):
             raise RuntimeError('gradient buckets incomplete after backward: %s' % self.remaining)
+        if self.capture is not None:
+            self.capture.cut(('wait',))
+            return
         for h in self.handles:
             h.wait()
         self.handles = []
 
     def all_reduce_sums(self, sums):
+        if self.capture is not None:
+            self.capture.cut(('sums', sums))
+            return
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+
+    # ---- replay of a segmented capture (SegmentedCapture below): the collectives between the graph segments, launched eagerly
+    def run_exchange(self, op, handles):
+        if op[0] == 'sums':
+            dist.all_reduce(op[1], op=dist.ReduceOp.SUM, group=self.group)
+        elif op[0] == 'bucket':
+            handles.append(dist.all_reduce(self.garena[op[1]:op[2]], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:   # 'wait': every bucket is back before the optimizer reads the gradients
+            for h in handles:
+                h.wait()
+            del handles[:]
+
+
+class SegmentedCapture(object):
+    '''
+    A data-parallel training step as hipGraph SEGMENTS: the compute between two exchange points (the loss sums before backward, each
+    gradient bucket, the final wait) is recorded into its own graph -- all graphs in one memory pool, so a tensor allocated in one
+    segment is the same storage in the next -- and a replay launches  segment, collective, segment, collective, ...  : the RCCL calls
+    stay ordinary eager launches on RCCL's stream (overlapping the next segment exactly as in the eager step), the ~1100 kernel
+    launches between them cost one hipGraphLaunch per segment.  Same kernels in the same order as the eager data-parallel step:
+    bitwise the same result (tests/test_configs_gpu.py).
+    '''
+
+    def __init__(self):
+        from . import ops
+        self._ops = ops
+        self.pool = torch.cuda.graph_pool_handle()
+        self.segments = []      # [graph, [exchange ops launched after it]]
+        self.graph = None
+        self._mark = 0
+
+    def begin(self):
+        self.graph = torch.cuda.CUDAGraph()
+        # 'relaxed': the cuts inside backward() happen on autograd's worker thread, the first begin and the last end on the caller's --
+        # the other capture modes tie a capture sequence to the thread that began it
+        self.graph.capture_begin(pool=self.pool, capture_error_mode='relaxed')
+        self._mark = self._ops.LAUNCHES[0]
+
+    def cut(self, op):
+        if self._ops.LAUNCHES[0] == self._mark and self.segments:
+            self.segments[-1][1].append(op)   # nothing was launched since the last cut: no empty graph, the exchange joins the previous one
+            return
+        self.graph.capture_end()
+        self.segments.append([self.graph, [op]])
+        self.begin()
+
+    def end(self):
+        self.graph.capture_end()
+        self.segments.append([self.graph, []])
+        self.graph = None
+
+    def replay(self, buckets):
+        handles = []
+        for graph, ops_after in self.segments:
+            graph.replay()
+            for op in ops_after:
+                buckets.run_exchange(op, handles)
 
 
 def init_from_env(backend=None):

@@ -268,16 +268,21 @@ def test_t2_three_adam_steps_match_reference_trajectory(env, golden_dir, fused):
     assert abs(bsum - float(g['buffer_abs_sum'])) < BAR * float(g['buffer_abs_sum'])
 
 
-def test_fresh_seed_odd_size_against_oracle(env):
-    '''Published net at 2 x 113 x 200 (odd sizes at every level), fresh seeds: output and loss against the fp32 and the fp64 oracle for
-    each seed, and the parameter gradients against fp64 next to the CPU fp32 oracle's over a SEED SWEEP.  On this small, chaotic case
-    the per-seed ratio of the two medians is noise -- over seeds 5..12 it runs from 0.1x to 9x for every arithmetic tier of this
-    library, the f32-MFMA-only build included (tools/diag_seeds.py) -- so the bar (the same 3x / 5x as
-    _check_gradients_against_fp64's) is held by the geometric mean over the sweep, not by one draw.'''
+@pytest.mark.parametrize('tier', ['fp32', 'fp32_3plane'])
+def test_fresh_seed_odd_size_against_oracle(env, tier):
+    '''Published net at 2 x 113 x 200 (odd sizes at every level), fresh seeds, on BOTH operand arithmetics of the fp32 configuration
+    (two scaled fp16 planes = the default; three bf16 planes): output and loss against the fp32 and the fp64 oracle for each seed, and
+    the parameter gradients against fp64 next to the CPU fp32 oracle's over a SEED SWEEP.  On this small, chaotic case the per-seed
+    ratio of the per-tensor medians is noise -- over seeds 5..12 it runs from 0.1x to 9x for every arithmetic tier of this library, the
+    f32-MFMA-only build included (tools/diag_seeds.py) -- so the 3x / 5x bar of _check_gradients_against_fp64
+    is held by the geometric mean over the sweep; PER SEED the whole-gradient relative L2 error (all parameters as one vector: a
+    LeakyReLU flip in one small tensor does not move it) is held to 3x the CPU fp32 oracle's + 2e-3, so a moderate loss of accuracy in
+    one tier cannot hide in the sweep.'''
     synth, _ = env
     rows = []
     for wseed in (5, 6, 7, 8):
         m = _build(env, synth.PUBLISHED, wseed)
+        m.compute_dtype = tier
         cb = synth.make_batch(2, 113, 200, 16, seed=wseed + 4)
         b = _gpu_batch(cb)
         m.train()
@@ -289,7 +294,13 @@ def test_fresh_seed_odd_size_against_oracle(env):
         o32, l32, g32 = _oracle_step(synth.PUBLISHED, wseed, cb, torch.float32)
         assert _rel(out, o32) < BAR and _rel(out, o64) < BAR
         assert abs(float(loss) - l32) < BAR * abs(l32)
-        _check_gradients_against_fp64({k: p.grad for k, p in _named(m, 'p')}, g32, g64, 'seed %d, 2x113x200' % wseed, collect=rows)
+        grads = {k: p.grad for k, p in _named(m, 'p')}
+        _check_gradients_against_fp64(grads, g32, g64, '%s, seed %d, 2x113x200' % (tier, wseed), collect=rows)
+        nn = sum(float((g64[k] ** 2).sum()) for k in g64 if g64[k] is not None)
+        l2h = (sum(float(((grads[k].detach().cpu().double() - g64[k]) ** 2).sum()) for k in g64 if g64[k] is not None) / nn) ** 0.5
+        l2c = (sum(float(((g32[k] - g64[k]) ** 2).sum()) for k in g64 if g64[k] is not None) / nn) ** 0.5
+        print('   whole-gradient relative L2 error: HIP %.2e, CPU fp32 %.2e' % (l2h, l2c))
+        assert l2h <= 3.0 * l2c + 2e-3, (tier, wseed, l2h, l2c)
         del m
     r = np.array(rows)
     gm = np.exp(np.log(r).mean(0))
@@ -444,6 +455,131 @@ def test_data_parallel_step_two_ranks_on_one_gpu(env, tmp_path):
         grad += m._grad_arena[:m._n_used]
     assert abs(r[0]['loss'] - want_loss) < 1e-5 * abs(want_loss)
     assert _rel(r[0]['grad'], grad) < 1e-4
+
+
+def _dp_capture_worker(rank, world, port, tmpdir):
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)   # gloo moves CUDA tensors; both ranks share cuda:0
+    import rcf_amd  # noqa: F401
+    from rcf_amd import synth, train
+    batches = [{k: v.cuda() for k, v in synth.make_batch(2, 64, 96, 6, seed=600 + 10 * s + rank).items()} for s in range(3)]
+    res = {}
+    for mode in ('eager', 'segments'):
+        m = train.build_model(synth.TINY, device='cuda')
+        synth.fill_state_dict_([m.encoder, m.decoder], 33)
+        m.data_parallel()
+        assert m._dp is not None
+        opt = train.make_optimizer(m, lr=1e-3)
+        m.train()
+        b0 = batches[0]
+        losses, host = [], 0.0
+        if mode == 'segments':
+            step = m.capture_training_step(opt, b0['image'], b0['input_depth'], b0['ground_truth'], b0['lidar_map'])
+            assert step.segments is not None and len(step.segments) >= 3
+            n_seg = len(step.segments)
+        for b in batches:
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.time()
+            if mode == 'segments':
+                loss = step(b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])
+            else:
+                loss = train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])[0]
+            host += time.time() - t0
+            torch.cuda.synchronize()
+            losses.append(float(loss.detach()))
+        bufs = [v.detach().cpu().clone() for mod in (m.encoder, m.decoder) for k, v in mod.named_buffers()]
+        res[mode] = {'losses': losses, 'param': m._param_arena.detach().cpu().clone(), 'bufs': bufs, 'host_ms': 1000.0 * host / 3,
+                     'steps': [float(st['step']) for st in opt.state_dict()['state'].values()][:1]}
+        if mode == 'segments':
+            res[mode]['n_seg'] = n_seg
+        del m, opt
+    torch.save(res, os.path.join(tmpdir, 'cap%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_data_parallel_step_as_graph_segments_is_bitwise_the_eager_step(env, tmp_path):
+    '''FusionNetModel.capture_training_step under data parallelism (2 ranks sharing cuda:0 over gloo): the step recorded as hipGraph
+    segments between its exchange points -- loss sums, gradient buckets, the wait before Adam -- and replayed with the collectives
+    launched eagerly in between.  Three steps on three different batches: losses, parameters, BatchNorm buffers and the optimizer's
+    step count are BITWISE those of the eager data-parallel steps, on both ranks; the host time of a replayed step is printed next to
+    the eager step's (the verdict's bar: <= 3 ms).'''
+    import torch.multiprocessing as mp
+    port = 29800 + (os.getpid() % 1000)
+    mp.spawn(_dp_capture_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for k in range(2):
+        r = torch.load(os.path.join(str(tmp_path), 'cap%d.pt' % k))
+        e, c = r['eager'], r['segments']
+        print('rank %d: %d segments; host time per step: eager %.2f ms, segments %.2f ms; losses %s' % (k, c['n_seg'], e['host_ms'], c['host_ms'], c['losses']))
+        assert e['losses'] == c['losses']
+        assert torch.equal(e['param'], c['param'])
+        assert all(torch.equal(a, b) for a, b in zip(e['bufs'], c['bufs']))
+        assert e['steps'] == c['steps'] == [3.0]
+        # (no bar on these host times: gloo's collectives on CUDA tensors block the host and two processes time-slice one GPU here;
+        # the host cost of a replayed step is measured over RCCL in test_segmented_step_host_time_over_rccl)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), 'cap%d.pt' % k)) for k in range(2))
+    assert torch.equal(r0['segments']['param'], r1['segments']['param'])     # the replicas stay identical
+
+
+def _rccl_host_time_worker(rank, world, port, tmpdir):
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('nccl', rank=0, world_size=1)     # RCCL's real launch path (stream-ordered collectives), one rank
+    import rcf_amd  # noqa: F401
+    from rcf_amd import synth, train
+    from rcf_amd.parallel import GradientBuckets
+    m = train.build_model(synth.PUBLISHED, device='cuda')
+    synth.fill_state_dict_([m.encoder, m.decoder], 3)
+    m._is_data_parallel = True
+    m._dp = GradientBuckets(m)          # (data_parallel() arms it only for world sizes > 1)
+    opt = train.make_optimizer(m, lr=1e-3)
+    m.train()
+    b = {k: v.cuda() for k, v in synth.make_batch(4, 224, 384, 32, seed=9).items()}
+    args = (b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])
+    for _ in range(2):
+        train.train_step(m, opt, *args)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(5):
+        train.train_step(m, opt, *args)
+    eager_host = (time.time() - t0) / 5 * 1e3
+    torch.cuda.synchronize()
+    step = m.capture_training_step(opt, *args)
+    step(); step()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(5):
+        step()
+    seg_host = (time.time() - t0) / 5 * 1e3
+    torch.cuda.synchronize()
+    seg_wall = (time.time() - t0) / 5 * 1e3
+    torch.save({'eager_host': eager_host, 'seg_host': seg_host, 'seg_wall': seg_wall, 'n_seg': len(step.segments)}, os.path.join(tmpdir, 'host.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_segmented_step_host_time_over_rccl(env, tmp_path):
+    '''Host time of ENQUEUEING one data-parallel training step (published net, batch 4, 224 x 384) with the exchange going through RCCL
+    (one rank: the collectives move nothing, their launch path is the real one): eager ~10 ms of Python and ~1100 launches, as graph
+    segments + the RCCL calls between them <= 3 ms (VERDICT r3 'next' #6).'''
+    import torch.multiprocessing as mp
+    port = 29900 + (os.getpid() % 1000)
+    mp.spawn(_rccl_host_time_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(os.path.join(str(tmp_path), 'host.pt'))
+    print('host time per data-parallel step over RCCL: eager %.2f ms, %d graph segments %.2f ms (wall %.2f ms)' % (r['eager_host'], r['n_seg'], r['seg_host'], r['seg_wall']))
+    assert r['seg_host'] <= 3.0
+    assert r['seg_host'] < r['eager_host']
 
 
 @pytest.mark.timeout(300)

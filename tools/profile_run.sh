@@ -29,6 +29,18 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE";
   RCF_BATCH_PACK=0 rocprofv3 --pmc $set --output-format csv -d $d -o b -- python3 bench.py --graph 0 --steps 1 --warmup 1 --preheat-s 0 --no-cpu-baseline > $d.log 2>&1
 done
 python3 tools/make_profile.py /tmp/trace_$tag $out/pmc $out/trace_bench_line.json $tag $head > $out/make_profile.log 2>&1
+# the bf16 configurations (BASELINE configs 2-4): the same three PMC passes per workload -> profiles/<tag>_pmc_<workload>.json, which their
+# bench lines quote (traffic, MFMA-busy) when the kernel sources match
+for wl in "bf16_train:--dtype bf16" "bf16_infer:--workload infer" "bf16_radarnet:--workload radarnet"; do
+  name=${wl%%:*}; flags=${wl#*:}
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    d=$out/pmc_$name/$(echo $set | cut -d' ' -f1)
+    mkdir -p $out/pmc_$name
+    RCF_BATCH_PACK=0 rocprofv3 --pmc $set --output-format csv -d $d -o b -- python3 bench.py $flags --graph 0 --steps 1 --warmup 1 --preheat-s 0 --no-cpu-baseline > $d.log 2>&1
+  done
+  python3 tools/pmc_families.py $out/pmc_$name $tag $name $head > $out/pmc_$name.log 2>&1
+done
 mkdir -p $out/profiles && cp profiles/${tag}_* $out/profiles/ 2>/dev/null
+cat $out/pmc_bf16_*.log 2>/dev/null | grep -v amdgpu
 tail -2 $out/make_profile.log
 for f in bench_line bench_f32_3plane bench_bf16 bench_infer bench_radarnet bench_infer_f32 bench_radarnet_f32; do tail -1 $out/$f.log | cut -c1-260; done
