@@ -84,7 +84,12 @@ typedef struct rcf_conv_desc {
     int in_off_y, in_off_x;
     /* phase_sum != 0 (ksize 2, RCF_GATHER_STRIDED2): out = sum over the four input phases (a,b) of the 2x2 conv of phase
      * (a,b) with pad (a,b) -- the whole input gradient of an up-2x conv in ONE launch.  `packed` then holds the four
-     * phases' packed weights back to back (each rcf_conv_info.packed_weight_floats long). */
+     * phases' packed weights back to back (each rcf_conv_info.packed_weight_floats long).
+     * phase_sum == 2 (ksize 2, RCF_GATHER_DIRECT, out_stride 2, split / DMA kernels only): the four OUTPUT phases of an up-2x
+     * forward conv3x3(nearest_up2x(x)) (src/net_utils.py:156-198) in ONE launch -- a workgroup runs the four 2x2 phase convolutions
+     * of its tile one after the other (phase (a,b): pad (1-a, 1-b), outputs at (2y+a, 2x+b); pad / out_off_* of the descriptor
+     * are ignored), so x is fetched from HBM once and re-read from L2; `packed` holds the four phases' packed weights back to
+     * back; the BatchNorm statistics cover all four phases. */
     int phase_sum;
     /* RCF_PREC_FP32 (0): fp32 results (the reference's arithmetic; f32 MFMA or the exact 3-plane bf16 split).
      * RCF_PREC_BF16 (1): operands rounded to bf16 (nearest even), fp32 accumulate; honoured by the split kernels, every other

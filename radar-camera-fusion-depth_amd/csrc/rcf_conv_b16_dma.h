@@ -80,7 +80,9 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
         t /= a.tiles_x;
         const int ty = t % a.tiles_y;
         const int img = t / a.tiles_y;
-        const int pa = a.phase_sum ? (ph >> 1) : a.pad, pb = a.phase_sum ? (ph & 1) : a.pad_x;
+        // phase_sum 1: the four INPUT phases of an up-2x input gradient summed; 2: the four OUTPUT phases of an up-2x forward, one after
+        // the other on the same tile (pad 1 - a, 1 - b; the outputs go to (2y + a, 2x + b))
+        const int pa = a.phase_sum == 2 ? 1 - (ph >> 1) : (a.phase_sum ? (ph >> 1) : a.pad), pb = a.phase_sum == 2 ? 1 - (ph & 1) : (a.phase_sum ? (ph & 1) : a.pad_x);
         const int ioy = a.phase_sum ? (ph >> 1) : a.ioy, iox = a.phase_sum ? (ph & 1) : a.iox;
         const int iy0 = ty * C::TH * C::LSTEP - pa;
         const int ix0 = tx * C::PX * C::LSTEP - pb;
@@ -176,7 +178,11 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
         if (more) issue(ntile, nq, buf ^ 1);
         RCF_T(t_w2);
         RCF_TACC(1, t_w2, t_w1);   // 1: address arithmetic + DMA issue of the next item
-        if (q == 0) {
+        // phase_sum == 2 (the four output phases of an up-2x forward in one launch): every phase is a convolution of its own --
+        // accumulators start at its first chunk, the epilogue runs at its last one and writes output pixels (2y + a, 2x + b)
+        const bool phase_out = a.phase_sum == 2;
+        const int oph = phase_out ? q / nchunk : 0;
+        if (phase_out ? (q - oph * nchunk == 0) : (q == 0)) {
 #pragma unroll
             for (int mi = 0; mi < C::MT; ++mi)
 #pragma unroll
@@ -241,7 +247,8 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
         }
         RCF_T(t_w3);
         RCF_TACC(2, t_w3, t_w2);   // 2: accumulator init + MFMAs + LDS reads
-        if (q == nitem - 1) {
+        if (phase_out ? (q - oph * nchunk == nchunk - 1) : (q == nitem - 1)) {
+            const int e_ooy = phase_out ? (oph >> 1) : a.ooy, e_oox = phase_out ? (oph & 1) : a.oox;
             // ---- epilogue.  Lane (li, lh) holds channel co = n0 + ni * 32 + li of 16 pixels per accumulator.  Lanes li (even) and
             // li + 1 exchange one value per pixel pair: the even lane stores channels (co, co + 1) of the pair's first pixel, the odd
             // lane those of the second pixel -- one dword (two bf16) per lane and pixel pair.
@@ -310,7 +317,7 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                             oy -= im * a.hp;
                             if (im >= a.nimg) oy = a.h_out;
                         }
-                        const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+                        const int py = oy * a.os + e_ooy, px = ox * a.os + e_oox;
                         const bool rowvalid = oy < a.h_out && py < a.ohp;
                         const size_t base0 = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
                         const int pstep = a.os * a.c_out;

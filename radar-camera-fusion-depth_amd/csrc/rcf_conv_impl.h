@@ -598,7 +598,9 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
         t /= a.tiles_x;
         const int ty = t % a.tiles_y;
         const int img = t / a.tiles_y;
-        const int pa = a.phase_sum ? (ph >> 1) : a.pad, pb = a.phase_sum ? (ph & 1) : a.pad_x;
+        // phase_sum 1: the four INPUT phases of an up-2x input gradient summed; 2: the four OUTPUT phases of an up-2x forward, one after
+        // the other on the same tile (pad 1 - a, 1 - b; the outputs go to (2y + a, 2x + b))
+        const int pa = a.phase_sum == 2 ? 1 - (ph >> 1) : (a.phase_sum ? (ph >> 1) : a.pad), pb = a.phase_sum == 2 ? 1 - (ph & 1) : (a.phase_sum ? (ph & 1) : a.pad_x);
         const int ioy = a.phase_sum ? (ph >> 1) : a.ioy, iox = a.phase_sum ? (ph & 1) : a.iox;
         const int iy0 = ty * C::TH * C::LSTEP - pa;
         const int ix0 = tx * C::PX * C::LSTEP - pb;
@@ -791,7 +793,11 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
         if (nq == nitem) { nq = 0; ntile = tile + gridDim.x; }
         const bool more = ntile < a.ntiles;
         const unsigned char* cb_next = more ? chunk_base(nq) : wp;
-        if (q == 0) {
+        // phase_sum == 2 (the four output phases of an up-2x forward in one launch): every phase is a convolution of its own --
+        // accumulators start at its first chunk, the epilogue runs at its last one and writes output pixels (2y + a, 2x + b)
+        const bool phase_out = a.phase_sum == 2;
+        const int oph = phase_out ? q / nchunk : 0;
+        if (phase_out ? (q - oph * nchunk == 0) : (q == 0)) {
 #pragma unroll
             for (int mi = 0; mi < C::MT; ++mi)
 #pragma unroll
@@ -859,7 +865,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
             RCF_T(t_row2);
             RCF_TACC(1, t_row2, t_row1);   // 1: the row's MFMAs + interleaved LDS reads
             if (last_row) {
-                if (q == nitem - 1) {
+                if (phase_out ? (q - oph * nchunk == nchunk - 1) : (q == nitem - 1)) {
+                    const int e_ooy = phase_out ? (oph >> 1) : a.ooy, e_oox = phase_out ? (oph & 1) : a.oox;
                     int t = tile;
                     const int tx = t % a.tiles_x;
                     t /= a.tiles_x;
@@ -925,7 +932,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                     oy -= im * a.hp;
                                     if (im >= a.nimg) oy = a.h_out;
                                 }
-                                const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+                                const int py = oy * a.os + e_ooy, px = ox * a.os + e_oox;
                                 const bool rowvalid = oy < a.h_out && py < a.ohp;
                                 const size_t base0 = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
                                 const int pstep = a.os * a.c_out;
@@ -947,7 +954,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                         oy -= im * a.hp;
                                         if (im >= a.nimg) oy = a.h_out;
                                     }
-                                    const int py = oy * a.os + a.ooy, px = ox * a.os + a.oox;
+                                    const int py = oy * a.os + e_ooy, px = ox * a.os + e_oox;
                                     pok[j] = oy < a.h_out && ox < a.w_out && py < a.ohp && px < a.owp;
                                     pbase[j] = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
                                 }
@@ -2439,7 +2446,12 @@ bool valid_desc(const rcf_conv_desc* d) {
     } else if (d->stride != 1 || d->w_mode != RCF_W_FORWARD) {
         return false;
     }
-    if (d->phase_sum && (d->ksize != 2 || d->gather1 != RCF_GATHER_STRIDED2 || d->c2 != 0)) return false;
+    if (d->phase_sum < 0 || d->phase_sum > 2) return false;
+    if (d->phase_sum == 1 && (d->ksize != 2 || d->gather1 != RCF_GATHER_STRIDED2 || d->c2 != 0)) return false;
+    if (d->phase_sum == 2 && (d->ksize != 2 || d->gather1 != RCF_GATHER_DIRECT || d->c2 != 0 || d->out_stride != 2 || d->accumulate ||
+                              d->w_mode != RCF_W_FORWARD || d->h_out != d->h_in || d->w_out != d->w_in || d->out_h_phys != 2 * d->h_out ||
+                              d->out_w_phys != 2 * d->w_out))
+        return false;
     if (d->w_mode == RCF_W_FORWARD) {
         if (d->w_o != d->c_out || d->w_i != d->c1 + d->c2) return false;
     } else if (d->w_mode == RCF_W_DGRAD) {
@@ -2555,6 +2567,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     }
     s->th = tile_px / s->px;
     s->bn = 32 * s->nt;
+    if (d->phase_sum == 2 && !s->split) return RCF_EUNSUPPORTED;   // the four output phases in one launch: conv_split_kernel / conv_b16_kernel only
     return RCF_OK;
 }
 

@@ -293,6 +293,90 @@ __global__ void __launch_bounds__(256) head_fwd_tile_kernel(const float* __restr
     }
 }
 
+// The same forward for C = 32 (the published decoder's last block) and STORED bf16 activations (inference) on the matrix pipe [r4].
+// head_fwd_tile_kernel is VALU-bound -- its nine per-tap dot products need a cross-lane sum each, ~100 VALU per 16 B loaded -- so it takes
+// the same 0.42 ms for a bf16 batch of 8 as for the fp32 one (1.8 TB/s) and 1.4-1.6 ms per bf16 inference batch of 32.
+// T[pixel][tap] = sum_c x[pixel][c] w[tap][c] is a [pixels x 32] x [32 x 9] product: one wave takes 32 halo pixels at a time, lane (i, h) of
+// step s loads the 8 channels [16 s + 8 h, + 8) of pixel i (16 B: exactly its A fragment of v_mfma_f32_32x32x16_bf16), B holds the three
+// exact bf16 planes of the fp32 weights (columns 9..31 zero): products exact, fp32 accumulate, 6 MFMAs per 32 pixels.  The D fragment's
+// column is the lane's tap; the 3x3 gather over T is the tile kernel's.  0.76 ms per batch of 32 (3.9 TB/s).
+// (The same product on v_mfma_f32_32x32x2_f32 for fp32 tensors / BatchNorm-on-load was built and measured: 8-28 % SLOWER than the tile
+// kernel -- 16 f32 MFMAs of 64 cycles per 32 pixels -- and is not in the tree.)
+typedef __bf16 hd_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ void __launch_bounds__(256) head_fwd_mfma_b16_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                                float* __restrict__ logit, float* __restrict__ depth, int n, int h, int w,
+                                                                float dmin, float dmax) {
+    constexpr int C = 32;
+    constexpr int NG = (HT_NP + 31) / 32;   // groups of 32 halo pixels
+    __shared__ float T[NG * 32 * 9];
+    int img, oy0, ox0;
+    head_tile_origin(blockIdx.x, h, w, &img, &oy0, &ox0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    // B fragments of the two 16-channel steps: lane (j = tap, h), k index e of step s <-> channel 16 s + 8 h + e, OIHW [1][c][3][3] ->
+    // wgt[c * 9 + tap]; the three exact planes of w (by truncation: 3 x 8 significant bits)
+    hd_bf16x8 wb[2][3];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        unsigned pl[3][4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = li < 9 ? wgt[(st * 16 + lh * 8 + e) * 9 + li] : 0.f;
+            const unsigned x0 = __float_as_uint(v) & 0xffff0000u;
+            const float r1 = v - __uint_as_float(x0);
+            const unsigned x1 = __float_as_uint(r1) & 0xffff0000u;
+            const unsigned x2 = __float_as_uint(r1 - __uint_as_float(x1)) & 0xffff0000u;
+            const unsigned xs[3] = {x0, x1, x2};
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                if (e & 1) pl[p][e >> 1] |= xs[p];
+                else pl[p][e >> 1] = xs[p] >> 16;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const uint4 u = {pl[p][0], pl[p][1], pl[p][2], pl[p][3]};
+            wb[st][p] = __builtin_bit_cast(hd_bf16x8, u);
+        }
+    }
+    const unsigned short* xb = reinterpret_cast<const unsigned short*>(x);
+    for (int g = wave; g < NG; g += 4) {
+        const int hp = g * 32 + li;
+        const int hy = hp / HT_HX, hx = hp - hy * HT_HX;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        const bool ok = hp < HT_NP && iy >= 0 && iy < h && ix >= 0 && ix < w;
+        const size_t base = (((size_t)img * h + (ok ? iy : 0)) * w + (ok ? ix : 0)) * C;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            uint4 u = *reinterpret_cast<const uint4*>(xb + base + st * 16 + lh * 8);
+            if (!ok) u = uint4{0u, 0u, 0u, 0u};
+            const hd_bf16x8 av = __builtin_bit_cast(hd_bf16x8, u);
+#pragma unroll
+            for (int p = 2; p >= 0; --p) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wb[st][p], acc, 0, 0, 0);   // smallest plane first
+        }
+        if (li < 9) {   // D fragment: value r of lane (tap, lh) is pixel row rcf_mfma_row(r, lh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[(g * 32 + rcf_mfma_row(r, lh)) * 9 + li] = acc[r];
+        }
+    }
+    __syncthreads();
+    const int ty = threadIdx.x / HT_W, tx = threadIdx.x % HT_W;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy < h && ox < w) {
+        float s = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) s += T[((ty + ky) * HT_HX + tx + kx) * 9 + ky * 3 + kx];
+        const size_t p = ((size_t)img * h + oy) * w + ox;
+        logit[p] = s;
+        depth[p] = dmin / (1.f / (1.f + expf(-s)) + dmin / dmax);
+    }
+}
+
 // input gradient: dx[p] = sum_tap dl[p - (ky-1, kx-1)] w[tap]; the dl halo tile sits in LDS, the weights in registers
 template <int C4N, class S>
 __global__ void __launch_bounds__(256) head_bwd_dgrad_tile_kernel(const float* __restrict__ dl, const float* __restrict__ wgt,
@@ -744,6 +828,11 @@ static int head_fwd_core(const float* x, const float* coef, const float* w, floa
     if (!x || !w || !logit || !depth || n <= 0 || h <= 0 || w_ <= 0) return RCF_EINVAL;
     if (!head_c_ok(c)) return RCF_EUNSUPPORTED;
     const int c4n = c >> 2;
+    if (S::B16 && c == 32 && coef == nullptr && getenv("RCF_HEAD_MFMA") == nullptr) {   // stored bf16 activations of the published decoder's
+        const unsigned nt = (unsigned)n * ((h + HT_H - 1) / HT_H) * ((w_ + HT_W - 1) / HT_W);   // head: on the matrix pipe (RCF_HEAD_MFMA=0: tile kernel)
+        hipLaunchKernelGGL(head_fwd_mfma_b16_kernel, dim3(nt), dim3(256), 0, (hipStream_t)stream, x, w, logit, depth, n, h, w_, min_depth, max_depth);
+        return rcf_launch_status();
+    }
     if (c4n <= 16) {
         const unsigned nt = (unsigned)n * ((h + HT_H - 1) / HT_H) * ((w_ + HT_W - 1) / HT_W);
         hipStream_t st = (hipStream_t)stream;

@@ -180,6 +180,12 @@ class Engine(object):
         self.kernel_log = None     # optional list collecting (layer, kernel_id) for profiling
         self.prof = None           # optional KernelTimer: brackets conv launches with events on the launch stream
         self.use_phase_convs = True  # exact-2x UpConv and stride-2 dgrad as 2x2 phase convs (False: 9-tap / zero-insert forms)
+        # the four forward phases of an up-2x conv in ONE launch (rcf_conv_desc.phase_sum == 2).  Measured [r4], same box, whole step: bf16
+        # inference +1.7 %, bf16 training +0.5 % (x is re-read from L2 instead of HBM), fp32 training -0.6 % (its kernels are bound by
+        # board power, not by HBM: nothing to gain, and four short launches pack the chip's tail better than one long one) -- so: on for
+        # bf16 tensors, off for fp32 tensors; RCF_UP2X_ONE_LAUNCH=0/1 overrides
+        e = os.environ.get('RCF_UP2X_ONE_LAUNCH')
+        self.up2x_one_launch = None if e is None else (e != '0')
         # BatchNorm + lrelu applied by the consuming split conv / wgrad kernels as they load z (rcf_conv2d_fwd_bn): saves the
         # bn_act_fwd pass (-2.4 ms/step) but costs the matrix kernels more in their staging path (+3.6 ms measured): off.  The
         # output head, an HBM-bound kernel with idle VALU, always consumes its input this way.
@@ -483,6 +489,19 @@ class Engine(object):
         f16 = self._f16()
         if f16:
             self._mat(x)   # two fp16 planes need max|x|: a deferred activation is materialised (its producer pass supplies it)
+        # the four phases in ONE launch (rcf_conv_desc.phase_sum == 2) where the layer runs on a split / DMA kernel: a workgroup runs the
+        # four 2x2 convolutions of its tile back to back, so x comes from HBM once (the three re-reads hit L2) and three launches go;
+        # the backward pass keeps the four per-phase descriptors (their weight gradients are four launches)
+        if self.up2x_one_launch if self.up2x_one_launch is not None else (ops.act_dtype() == torch.bfloat16):
+            dm = ops.make_up2x_fwd_desc(n, h, w, c1, co, 0, 0, phase_out=True)
+            if f16:
+                dm = self._exact_unless(dm, x.amax, None if fold is not None else 0)
+            try:
+                qm = ops.conv_query(dm)
+            except ops._lib.RcfError:
+                qm = None
+            if qm is not None:
+                return self._conv_up2x_merged(layer, x, dm, qm, want_stats, fold)
         for ph in range(4):
             d = ops.make_up2x_fwd_desc(n, h, w, c1, co, ph >> 1, ph & 1)
             if f16:
@@ -510,6 +529,50 @@ class Engine(object):
             pass
         info = _Info()
         info.n_partials = 4 * n_part
+        info.up2x = descs
+        if fold is not None:
+            return z, None, info, partials, fused
+        return z, None, info, partials
+
+    def _conv_up2x_merged(self, layer, x, dm, qm, want_stats, fold):
+        '''The up-2x forward as one launch over the four output phases (see _conv_up2x); returns what _conv_up2x returns.'''
+        n, h, w, c1 = self._shape(x)
+        weight = layer.conv.weight
+        co = weight.shape[0]
+        fused = fold is not None and bool(qm.fwd_act) and fold[1] is None
+        wp = self._frozen_get(('fold-phase', id(layer)), lambda: ops.phase_weights(ops.scale_channels(weight.detach(), fold[0][0]),
+                                                                                      RCF_PHASE_UP2X_FWD)) if fused else \
+            self._phase_w(weight.detach(), RCF_PHASE_UP2X_FWD)
+        t1, k1 = self._src(x, qm.bn_on_load and not fused)
+        if t1 is None:
+            t1 = self._mat(x)
+        scales = None
+        if self._two_plane(qm.kernel_id):
+            wmax = self._w_amax(wp)   # one maximum for the four phases' pre-summed weights
+            packed = self._pack_n(dm, [wp[ph] for ph in range(4)], t1, wmax)
+            scales = ops.make_scales(x.amax, None, wmax)
+        else:
+            packed = self._pack_n(dm, [wp[ph] for ph in range(4)], t1)
+        z = self._new((n, 2 * h, 2 * w, co), t1)
+        partials = torch.empty((qm.n_partials, 2, co), dtype=torch.float64, device=t1.device) if want_stats else None
+        if self.prof is not None:
+            self.prof.begin(qm.kernel_id, ops.algorithmic_flops(dm), dm)
+        if fused:
+            ops.conv_fwd_act(dm, t1, None, packed, fold[0][1], None, z)
+        else:
+            ops.conv_fwd(dm, t1, None, packed, z, partials, coef1=k1, scales=scales)
+        if self.prof is not None:
+            self.prof.end()
+        descs = []
+        for ph in range(4):   # the backward pass's per-phase descriptors, under the arithmetic the forward ran on
+            d = ops.make_up2x_fwd_desc(n, h, w, c1, co, ph >> 1, ph & 1)
+            d.precision = dm.precision
+            descs.append(d)
+
+        class _Info(object):
+            pass
+        info = _Info()
+        info.n_partials = qm.n_partials
         info.up2x = descs
         if fold is not None:
             return z, None, info, partials, fused

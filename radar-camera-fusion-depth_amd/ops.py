@@ -150,8 +150,15 @@ def make_dgrad_desc(fwd, i_off, i_cnt, accumulate):
 
 
 # ---- 2x2 phase convolutions (include/rcf_hip.h, RCF_PHASE_*) -------------------------------------------------------
-def make_up2x_fwd_desc(n, hs, ws, c_in, c_out, a, b):
-    """Phase (a,b) of conv3x3(nearest-upsample-2x(x)): a 2x2 conv on x writing output pixels (2y+a, 2x+b)."""
+def make_up2x_fwd_desc(n, hs, ws, c_in, c_out, a, b, phase_out=False):
+    """Phase (a,b) of conv3x3(nearest-upsample-2x(x)): a 2x2 conv on x writing output pixels (2y+a, 2x+b).
+    phase_out=True: all four phases in one launch (a, b ignored; weights of the 4 phases packed back to back; phase_sum == 2)."""
+    if phase_out:
+        return ConvDesc(n=n, h_in=hs, w_in=ws, c1=c_in, c2=0, h_src1=hs, w_src1=ws, gather1=RCF_GATHER_DIRECT,
+                        h_out=hs, w_out=ws, c_out=c_out, ksize=2, stride=1, pad=1, pad_x=1,
+                        w_mode=RCF_W_FORWARD, w_o=c_out, w_i=c_in, w_i_off=0, accumulate=0,
+                        out_stride=2, out_off_y=0, out_off_x=0, out_h_phys=2 * hs, out_w_phys=2 * ws, in_off_y=0, in_off_x=0, phase_sum=2,
+                        precision=_PRECISION[0], storage=_STORAGE[0])
     return ConvDesc(n=n, h_in=hs, w_in=ws, c1=c_in, c2=0, h_src1=hs, w_src1=ws, gather1=RCF_GATHER_DIRECT,
                     h_out=hs, w_out=ws, c_out=c_out, ksize=2, stride=1, pad=1 - a, pad_x=1 - b,
                     w_mode=RCF_W_FORWARD, w_o=c_out, w_i=c_in, w_i_off=0, accumulate=0,
@@ -226,7 +233,7 @@ def algorithmic_bytes(desc):
     else:
         in1 = desc.h_src1 * desc.w_src1 * desc.c1
     in2 = desc.h_in * desc.w_in * desc.c2
-    out = desc.h_out * desc.w_out * desc.c_out
+    out = desc.h_out * desc.w_out * desc.c_out * (4 if desc.phase_sum == 2 else 1)    # (the four output phases of an up-2x forward)
     return (2.0 if desc.storage else 4.0) * n * (in1 + in2 + out * (2 if desc.accumulate else 1))
 
 

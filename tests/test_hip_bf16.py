@@ -284,6 +284,20 @@ def test_phase_convolutions_bf16_tensors(ops):
     torch.cuda.synchronize()
     e = float((nchw(z).double() - ref.detach()).abs().max() / ref.detach().abs().max())
     assert e < 3 * BF16_EPS, e
+    # the same four phases in ONE launch (rcf_conv_desc.phase_sum == 2): bitwise the four launches' output, statistics of all of it
+    dm = ops.make_up2x_fwd_desc(n, h, w, c1, co, 0, 0, phase_out=True)
+    im = ops.conv_query(dm)
+    pm = torch.empty(4 * im.packed_weight_floats, device='cuda')
+    for ph in range(4):
+        ops.conv_pack(dm, wp[ph], pm[ph * im.packed_weight_floats:(ph + 1) * im.packed_weight_floats])
+    z1 = torch.full((n, 2 * h, 2 * w, co), float('nan'), device='cuda').bfloat16()
+    part = torch.full((im.n_partials, 2, co), float('nan'), device='cuda', dtype=torch.float64)
+    ops.conv_fwd(dm, xg, None, pm, z1, part)
+    torch.cuda.synchronize()
+    assert torch.equal(z1, z)
+    st = part.sum(0).cpu()
+    np.testing.assert_allclose(st[0].numpy(), nchw(z).double().sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-3)
+    np.testing.assert_allclose(st[1].numpy(), (nchw(z).double() ** 2).sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-3)
     # weight gradient: four 2x2 wgrads folded back to 3x3
     dwp = torch.empty((4, co, c1, 2, 2), device='cuda')
     dzg = nhwc_b(dz)
@@ -408,7 +422,13 @@ def test_head_kernels_bf16_input(ops):
             dw = torch.empty_like(wt)
             ops.head_bwd_wgrad(cast(x), dl, dw, coef=cf)
             outs.append((logit, depth, dw))
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        if cf is None:
+            # stored bf16 activations run on the bf16 MFMA against the three exact bf16 planes of the fp32 weights
+            # (head_fwd_mfma_b16_kernel), fp32 tensors on the tile kernel: the same exact products in another summation order
+            assert float((outs[0][0] - outs[1][0]).abs().max()) <= 2e-6 * float(outs[0][0].abs().max())
+            assert float((outs[0][1] - outs[1][1]).abs().max()) <= 2e-6 * float(outs[0][1].abs().max())
+        else:   # BatchNorm + LeakyReLU on load: both storages feed the same fp32 values to the same f32-MFMA steps
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
         assert float((outs[0][2] - outs[1][2]).abs().max()) <= 1e-6 * float(outs[0][2].abs().max())
     dx_f = torch.empty((n, h, w, c), device='cuda')
     dx_b = torch.empty((n, h, w, c), device='cuda').bfloat16()

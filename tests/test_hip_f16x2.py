@@ -434,6 +434,22 @@ def test_up2x_conv_as_four_phase_convs(ops, cin, cout, n, hs, ws):
                 ops.conv_pack(d, wph[a * 2 + b], packed, aw)
                 ops.conv_fwd(d, nhwc(x), None, packed, out, None, scales=ops.make_scales(ax, None, aw))
         assert rel(nchw(out), ref) < EXACT_TOL
+        # the same four phases in ONE launch (rcf_conv_desc.phase_sum == 2): bitwise the four launches' output, and the BatchNorm
+        # statistics of all four phases in one set of partial rows
+        dm = ops.make_up2x_fwd_desc(n, hs, ws, cin, cout, 0, 0, phase_out=True)
+        im = ops.conv_query(dm)
+        assert 40000 <= im.kernel_id < 50000
+        pm = torch.empty(4 * im.packed_weight_floats, device='cuda')
+        for ph in range(4):
+            ops.conv_pack(dm, wph[ph], pm[ph * im.packed_weight_floats:(ph + 1) * im.packed_weight_floats], aw)
+        out1 = torch.full((n, 2 * hs, 2 * ws, cout), float('nan'), device='cuda')
+        part = torch.full((im.n_partials, 2, cout), float('nan'), device='cuda', dtype=torch.float64)
+        ops.conv_fwd(dm, nhwc(x), None, pm, out1, part, scales=ops.make_scales(ax, None, aw))
+        torch.cuda.synchronize()
+        assert torch.equal(out1, out)
+        st = part.sum(0).cpu()
+        np.testing.assert_allclose(st[0].numpy(), nchw(out).double().sum((0, 2, 3)).numpy(), rtol=1e-9, atol=1e-6)
+        np.testing.assert_allclose(st[1].numpy(), (nchw(out).double() ** 2).sum((0, 2, 3)).numpy(), rtol=1e-9, atol=1e-6)
     finally:
         ops.set_precision('fp32')
 
