@@ -5,7 +5,7 @@ launch, MFMA-busy fraction) and the whole step's HBM bytes.  Same corrections as
 
 <pmc dir>: one sub-directory per pass (FETCH_SIZE, WRITE_SIZE, "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE") of
   rocprofv3 --pmc X --output-format csv -d DIR/X -o b -- python3 bench.py <workload flags> --graph 0 --steps 1 --warmup 1 --preheat-s 0 --no-cpu-baseline
-The second half of the dispatches is the measured step (the first is the warm-up step: same launches).'''
+Per-step figures: totals over the whole run divided by the number of forward passes in it (launches of the head's forward kernel).'''
 import collections, csv, glob, hashlib, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,17 +28,20 @@ def clean(n):
     return re.sub(r'\(ConvArgs\)|\(.*', '', n).strip()
 
 
+# Every dispatch of the run is counted and divided by the number of STEPS the run made = launches of the output head's forward kernel,
+# which runs exactly once per forward pass of every workload (a "second half of the dispatches" rule miscounts runs whose warm-up and
+# measured parts differ in length).
 pm = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+n_steps = 0
 for f in glob.glob(os.path.join(pmc_dir, '**', '*counter_collection.csv'), recursive=True):
     rr = list(csv.DictReader(open(f)))
-    ids = sorted(set(int(r['Dispatch_Id']) for r in rr))
-    cut = ids[len(ids) // 2]
+    first = rr[0]['Counter_Name'] if rr else None
+    n_steps = max(n_steps, sum(1 for r in rr if r['Counter_Name'] == first and re.search(r'head_fwd', r['Kernel_Name'])))
     for r in rr:
-        if int(r['Dispatch_Id']) < cut:
-            continue
         a = pm[clean(r['Kernel_Name'])][r['Counter_Name']]
         a[0] += 1
         a[1] += float(r['Counter_Value'])
+n_steps = max(n_steps, 1)
 kernels = {}
 for n, cs in pm.items():
     e = {'launches': max(v[0] for v in cs.values())}
@@ -57,20 +60,21 @@ def csrc_sha():
 
 def summarise(ks):
     n = sum(kernels[k]['launches'] for k in ks)
-    e = {'launches': n}
+    e = {'launches': n / float(n_steps)}            # per step
     if all('FETCH_SIZE' in kernels[k] and 'WRITE_SIZE' in kernels[k] for k in ks):
-        e['hbm_bytes'] = sum((2.0 * kernels[k]['FETCH_SIZE'] + kernels[k]['WRITE_SIZE']) * 1024.0 for k in ks)
-        e['hbm_bytes_per_launch'] = e['hbm_bytes'] / max(n, 1)
+        tot = sum((2.0 * kernels[k]['FETCH_SIZE'] + kernels[k]['WRITE_SIZE']) * 1024.0 for k in ks)
+        e['hbm_bytes'] = tot / n_steps              # per step
+        e['hbm_bytes_per_launch'] = tot / max(n, 1)
     if all('SQ_VALU_MFMA_BUSY_CYCLES' in kernels[k] and 'GRBM_GUI_ACTIVE' in kernels[k] for k in ks):
         act = sum(kernels[k]['GRBM_GUI_ACTIVE'] for k in ks)
         e['mfma_busy_fraction'] = sum(kernels[k]['SQ_VALU_MFMA_BUSY_CYCLES'] for k in ks) / (act / 8.0 * 1024.0) if act > 0 else None
     return e
 
 
-out = {'_meta': {'head': head, 'csrc_sha': csrc_sha(), 'round': tag, 'workload': workload,
+out = {'_meta': {'head': head, 'csrc_sha': csrc_sha(), 'round': tag, 'workload': workload, 'steps_in_run': n_steps,
                  'corrections': 'FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE doubled (gfx950 tallies the 128-B requests of 16-B/lane reads as 64 B: '
                                 'MI355X_MICROARCH.md, HBM); MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); separate '
-                                '--pmc passes, second half of the dispatches = the measured step'},
+                                '--pmc passes; per-step figures = totals over the run / launches of the head forward kernel (once per step)'},
        'whole_step': summarise(list(kernels))}
 for key, rx in FAMILIES:
     ks = [k for k in kernels if re.match(rx, k)]
@@ -81,5 +85,5 @@ json.dump(out, open(path, 'w'), indent=1, sort_keys=True)
 print('wrote', path)
 for k, v in out.items():
     if k != '_meta':
-        print('%-52s launches %-5d HBM GB %-9s MFMA-busy %s' % (k, v['launches'], '%.3f' % (v['hbm_bytes'] / 1e9) if 'hbm_bytes' in v else '-',
+        print('%-52s launches/step %-7.1f HBM GB/step %-9s MFMA-busy %s' % (k, v['launches'], '%.3f' % (v['hbm_bytes'] / 1e9) if 'hbm_bytes' in v else '-',
                                                              '%.3f' % v['mfma_busy_fraction'] if v.get('mfma_busy_fraction') is not None else '-'))
