@@ -335,6 +335,27 @@ int rcf_l1_loss_value(const double* sums, float w_lidar, float* loss, void* stre
 int rcf_l1_loss_bwd(const float* depth, const float* gt, const float* lidar, const double* sums,
                     const float* upstream, float w_lidar, float* ddepth, long long n_pix, void* stream);
 
+/* The same masked loss for loss_func 'l1' / 'l2' / 'smoothl1' (src/fusionnet_model.py:245-275: F.l1_loss, F.mse_loss, F.smooth_l1_loss
+ * with reduction 'mean' over the valid pixels, src/fusionnet_losses.py:4-46): `kind` selects the per-pixel term (|e|, e^2, Huber with
+ * beta 1) and its slope; sums / workspace / upstream as above; rcf_l1_loss_value turns the sums into the loss for every kind. */
+#define RCF_LOSS_L1 0
+#define RCF_LOSS_L2 1
+#define RCF_LOSS_SMOOTH_L1 2
+int rcf_masked_loss_fwd(const float* depth, const float* gt, const float* lidar, float* workspace,
+                        double* sums, long long n_pix, int kind, void* stream);
+int rcf_masked_loss_bwd(const float* depth, const float* gt, const float* lidar, const double* sums,
+                        const float* upstream, float w_lidar, float* ddepth, long long n_pix, int kind, void* stream);
+
+/* Local smoothness term of compute_loss (w_smoothness > 0, loss_smoothness_kernel_size <= 1: src/fusionnet_model.py:277-281 ->
+ * losses.smoothness_loss_func, src/fusionnet_losses.py:48-72): edge-aware |dP/dx|, |dP/dy| weighted by exp(-mean_c |dI|).
+ * image: N x C x H x W (the public NCHW tensor), depth: [N][H][W].  sums (device, double[4]) = (sum x, count x, sum y, count y), local
+ * to this rank (all-reduce before the backward under data parallelism); value = sums[0]/sums[1] + sums[2]/sums[3].
+ * _bwd ADDS upstream * w_smoothness * d(value)/d(depth) into ddepth (after rcf_masked_loss_bwd wrote it). */
+int rcf_smoothness_loss_fwd(const float* image_nchw, const float* depth, float* workspace, double* sums, int n, int c, int h, int w,
+                            void* stream);
+int rcf_smoothness_loss_bwd(const float* image_nchw, const float* depth, const double* sums, const float* upstream, float w_smoothness,
+                            float* ddepth, int n, int c, int h, int w, void* stream);
+
 /* OutlierRemoval.remove_outliers (src/net_utils.py:591-638; called on the ground truth every training step,
  * src/fusionnet_main.py:377-378): a valid point (depth > 0) is zeroed when some valid point in its k x k window is more
  * than `threshold` metres closer.  depth, out: [N][H][W] (single channel).  scratch: one float (device), used for the

@@ -220,17 +220,27 @@ class FusionNetOracle(object):
         return self.min_predict_depth / (
             torch.sigmoid(out) + self.min_predict_depth / self.max_predict_depth)   # :162-165
 
-    def compute_loss(self, output_depth, ground_truth, lidar_map, w_lidar_loss=2.0):
-        '''src/fusionnet_model.py:209-302, loss_func='l1', w_smoothness=0 (shipped flags).'''
+    def compute_loss(self, output_depth, ground_truth, lidar_map, w_lidar_loss=2.0, loss_func='l1', image=None, w_smoothness=0.0):
+        '''src/fusionnet_model.py:209-302, w_smoothness=0 (shipped flag); loss_func 'l1' (shipped) / 'l2' / 'smoothl1'
+        (:245-275 -> src/fusionnet_losses.py:4-46: F.l1_loss / F.mse_loss / F.smooth_l1_loss, reduction 'mean').'''
+        fn = {'l1': F.l1_loss, 'l2': F.mse_loss, 'smoothl1': F.smooth_l1_loss}[loss_func]
         if w_lidar_loss > 0.0:
             ground_truth = ground_truth * torch.where(
                 lidar_map > 0.0, torch.zeros_like(lidar_map), torch.ones_like(lidar_map))
         vg = ground_truth > 0
         vl = lidar_map > 0
-        loss_sup = F.l1_loss(output_depth[vg], ground_truth[vg], reduction='mean')
+        loss_sup = fn(output_depth[vg], ground_truth[vg], reduction='mean')
         loss_lidar = 0.0
         if w_lidar_loss > 0.0:
-            loss_lidar = F.l1_loss(output_depth[vl], lidar_map[vl], reduction='mean')
+            loss_lidar = fn(output_depth[vl], lidar_map[vl], reduction='mean')
+        if w_smoothness > 0.0:
+            # losses.smoothness_loss_func (src/fusionnet_losses.py:48-72), the loss_smoothness_kernel_size <= 1 branch
+            dy = lambda t: t[:, :, :-1, :] - t[:, :, 1:, :]
+            dx = lambda t: t[:, :, :, :-1] - t[:, :, :, 1:]
+            wx = torch.exp(-torch.mean(torch.abs(dx(image)), dim=1, keepdim=True))
+            wy = torch.exp(-torch.mean(torch.abs(dy(image)), dim=1, keepdim=True))
+            loss_smooth = torch.mean(wx * torch.abs(dx(output_depth))) + torch.mean(wy * torch.abs(dy(output_depth)))
+            return loss_sup + w_smoothness * loss_smooth + w_lidar_loss * loss_lidar, loss_sup, loss_lidar, loss_smooth
         return loss_sup + w_lidar_loss * loss_lidar, loss_sup, loss_lidar
 
     def parameters(self):

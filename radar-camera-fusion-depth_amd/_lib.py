@@ -106,6 +106,10 @@ _SIGNATURES = {
     'rcf_head_bwd_wgrad_bn': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'rcf_loss_workspace_floats': (c_size_t, [c_longlong]),
     'rcf_l1_loss_fwd': (c_int, [_P, _P, _P, _P, _P, c_longlong, _P]),
+    'rcf_masked_loss_fwd': (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, _P]),
+    'rcf_masked_loss_bwd': (c_int, [_P, _P, _P, _P, _P, c_float, _P, c_longlong, c_int, _P]),
+    'rcf_smoothness_loss_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'rcf_smoothness_loss_bwd': (c_int, [_P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, _P]),
     'rcf_l1_loss_value': (c_int, [_P, c_float, _P, _P]),
     'rcf_l1_loss_bwd': (c_int, [_P, _P, _P, _P, _P, c_float, _P, c_longlong, _P]),
     'rcf_outlier_removal': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),

@@ -543,9 +543,24 @@ __global__ void __launch_bounds__(64) head_wgrad_reduce_kernel(const float* __re
     if (threadIdx.x == 0) dw[(e % c) * 9 + e / c] = (float)s;
 }
 
-// ---------------------------------------------------------------- masked L1 loss
+// ---------------------------------------------------------------- masked L1 / L2 / smooth-L1 loss
+// (src/fusionnet_model.py:245-275; src/fusionnet_losses.py:4-46: F.l1_loss / F.mse_loss / F.smooth_l1_loss (beta 1) with reduction 'mean'
+// over the valid pixels).  KIND 0: |e|, 1: e^2, 2: 0.5 e^2 for |e| < 1 else |e| - 0.5.
 constexpr int LOSS_BLOCKS = 1024;
+template <int KIND>
+__device__ __forceinline__ float loss_term(float e) {
+    if (KIND == 1) return e * e;
+    if (KIND == 2) { const float a = fabsf(e); return a < 1.f ? 0.5f * e * e : a - 0.5f; }
+    return fabsf(e);
+}
+template <int KIND>
+__device__ __forceinline__ float loss_slope(float e) {
+    if (KIND == 1) return 2.f * e;
+    if (KIND == 2) return fabsf(e) < 1.f ? e : (e > 0.f ? 1.f : -1.f);
+    return e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
+}
 
+template <int KIND>
 __global__ void __launch_bounds__(256) l1_loss_partial_kernel(const float* __restrict__ d, const float* __restrict__ gt,
                                                               const float* __restrict__ lidar, float* __restrict__ ws,
                                                               long long n) {
@@ -554,8 +569,8 @@ __global__ void __launch_bounds__(256) l1_loss_partial_kernel(const float* __res
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float dv = d[i], l = lidar[i];
         const float g = l > 0.f ? 0.f : gt[i];   // mask out ground truth where lidar is available
-        if (g > 0.f) { s[0] += fabsf(dv - g); s[1] += 1.f; }
-        if (l > 0.f) { s[2] += fabsf(dv - l); s[3] += 1.f; }
+        if (g > 0.f) { s[0] += loss_term<KIND>(dv - g); s[1] += 1.f; }
+        if (l > 0.f) { s[2] += loss_term<KIND>(dv - l); s[3] += 1.f; }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -594,6 +609,7 @@ __global__ void l1_loss_value_kernel(const double* __restrict__ sums, float w_li
     }
 }
 
+template <int KIND>
 __global__ void __launch_bounds__(256) l1_loss_bwd_kernel(const float* __restrict__ d, const float* __restrict__ gt,
                                                           const float* __restrict__ lidar, const double* __restrict__ sums,
                                                           const float* __restrict__ upstream, float w_lidar,
@@ -605,9 +621,67 @@ __global__ void __launch_bounds__(256) l1_loss_bwd_kernel(const float* __restric
         const float dv = d[i], l = lidar[i];
         const float g = l > 0.f ? 0.f : gt[i];
         float r = 0.f;
-        if (g > 0.f) { const float e = dv - g; r += kg * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)); }
-        if (l > 0.f && w_lidar > 0.f) { const float e = dv - l; r += kl * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)); }
+        if (g > 0.f) r += kg * loss_slope<KIND>(dv - g);
+        if (l > 0.f && w_lidar > 0.f) r += kl * loss_slope<KIND>(dv - l);
         dd[i] = r;
+    }
+}
+
+// ---------------------------------------------------------------- local smoothness loss
+// losses.smoothness_loss_func (src/fusionnet_losses.py:48-72; compute_loss with w_smoothness > 0 and loss_smoothness_kernel_size <= 1,
+// src/fusionnet_model.py:277-281): mean over N x H x (W-1) of wx |P[y][x] - P[y][x+1]| + mean over N x (H-1) x W of wy |P[y][x] - P[y+1][x]|,
+// wx = exp(-mean_c |I[c][y][x] - I[c][y][x+1]|) (wy alike).  image: NCHW (the public tensor), P: [N][H][W].
+// Partials (sum x, count x, sum y, count y) per block -> l1_loss_final_kernel -> sums[4] (fp64): local to the rank, like the masked loss.
+__device__ __forceinline__ float smooth_weight(const float* __restrict__ img, size_t i0, size_t i1, int c, size_t cstride) {
+    float a = 0.f;
+    for (int k = 0; k < c; ++k) a += fabsf(img[i0 + k * cstride] - img[i1 + k * cstride]);
+    return expf(-a / (float)c);
+}
+
+__global__ void __launch_bounds__(256) smoothness_partial_kernel(const float* __restrict__ img, const float* __restrict__ p,
+                                                                 float* __restrict__ ws, int n, int c, int h, int w) {
+    __shared__ float sm[4][4];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const long long hw = (long long)h * w, tot = (long long)n * hw;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % w), y = (int)((i / w) % h);
+        const long long im = i / hw;
+        const size_t ib = (size_t)im * c * hw + (size_t)y * w + x;   // channel 0 of this pixel in the NCHW image
+        const float pv = p[i];
+        if (x < w - 1) { s[0] += smooth_weight(img, ib, ib + 1, c, (size_t)hw) * fabsf(pv - p[i + 1]); s[1] += 1.f; }
+        if (y < h - 1) { s[2] += smooth_weight(img, ib, ib + w, c, (size_t)hw) * fabsf(pv - p[i + w]); s[3] += 1.f; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s[q] += __shfl_xor(s[q], off);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        for (int q = 0; q < 4; ++q) sm[wave][q] = s[q];
+    __syncthreads();
+    if (threadIdx.x < 4) ws[blockIdx.x * 4 + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+__device__ __forceinline__ float sgnf(float e) { return e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f); }
+
+// ddepth += upstream * w_smoothness * d(smoothness)/dP
+__global__ void __launch_bounds__(256) smoothness_bwd_kernel(const float* __restrict__ img, const float* __restrict__ p,
+                                                             const double* __restrict__ sums, const float* __restrict__ upstream,
+                                                             float w_smoothness, float* __restrict__ dd, int n, int c, int h, int w) {
+    const float up = (upstream ? upstream[0] : 1.f) * w_smoothness;
+    const float kx = (float)((double)up / sums[1]), ky = (float)((double)up / sums[3]);
+    const long long hw = (long long)h * w, tot = (long long)n * hw;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % w), y = (int)((i / w) % h);
+        const long long im = i / hw;
+        const size_t ib = (size_t)im * c * hw + (size_t)y * w + x;
+        const float pv = p[i];
+        float r = 0.f;
+        if (x < w - 1) r += kx * smooth_weight(img, ib, ib + 1, c, (size_t)hw) * sgnf(pv - p[i + 1]);
+        if (x > 0) r -= kx * smooth_weight(img, ib - 1, ib, c, (size_t)hw) * sgnf(p[i - 1] - pv);
+        if (y < h - 1) r += ky * smooth_weight(img, ib, ib + w, c, (size_t)hw) * sgnf(pv - p[i + w]);
+        if (y > 0) r -= ky * smooth_weight(img, ib - w, ib, c, (size_t)hw) * sgnf(p[i - w] - pv);
+        dd[i] += r;
     }
 }
 
@@ -949,17 +1023,24 @@ extern "C" size_t rcf_loss_workspace_floats(long long n_pix) {
     return (size_t)LOSS_BLOCKS * 4;
 }
 
-extern "C" int rcf_l1_loss_fwd(const float* depth, const float* gt, const float* lidar, float* workspace, double* sums,
-                               long long n_pix, void* stream) {
-    if (!depth || !gt || !lidar || !workspace || !sums || n_pix <= 0) return RCF_EINVAL;
+extern "C" int rcf_masked_loss_fwd(const float* depth, const float* gt, const float* lidar, float* workspace, double* sums,
+                                   long long n_pix, int kind, void* stream) {
+    if (!depth || !gt || !lidar || !workspace || !sums || n_pix <= 0 || kind < 0 || kind > 2) return RCF_EINVAL;
     long long nb = (n_pix + 255) / 256;
     if (nb > LOSS_BLOCKS) nb = LOSS_BLOCKS;
-    hipLaunchKernelGGL(l1_loss_partial_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, depth, gt, lidar, workspace,
-                       n_pix);
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 1) hipLaunchKernelGGL(l1_loss_partial_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, depth, gt, lidar, workspace, n_pix);
+    else if (kind == 2) hipLaunchKernelGGL(l1_loss_partial_kernel<2>, dim3((unsigned)nb), dim3(256), 0, st, depth, gt, lidar, workspace, n_pix);
+    else hipLaunchKernelGGL(l1_loss_partial_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, depth, gt, lidar, workspace, n_pix);
     int rc = rcf_launch_status();
     if (rc != RCF_OK) return rc;
-    hipLaunchKernelGGL(l1_loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, (int)nb, sums);
+    hipLaunchKernelGGL(l1_loss_final_kernel, dim3(1), dim3(256), 0, st, workspace, (int)nb, sums);
     return rcf_launch_status();
+}
+
+extern "C" int rcf_l1_loss_fwd(const float* depth, const float* gt, const float* lidar, float* workspace, double* sums,
+                               long long n_pix, void* stream) {
+    return rcf_masked_loss_fwd(depth, gt, lidar, workspace, sums, n_pix, RCF_LOSS_L1, stream);
 }
 
 extern "C" int rcf_l1_loss_value(const double* sums, float w_lidar, float* loss, void* stream) {
@@ -968,12 +1049,40 @@ extern "C" int rcf_l1_loss_value(const double* sums, float w_lidar, float* loss,
     return rcf_launch_status();
 }
 
+extern "C" int rcf_masked_loss_bwd(const float* depth, const float* gt, const float* lidar, const double* sums, const float* upstream,
+                                   float w_lidar, float* ddepth, long long n_pix, int kind, void* stream) {
+    if (!depth || !gt || !lidar || !sums || !ddepth || n_pix <= 0 || kind < 0 || kind > 2) return RCF_EINVAL;
+    unsigned b = nblk(n_pix, 256); if (b > 8192) b = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 1) hipLaunchKernelGGL(l1_loss_bwd_kernel<1>, dim3(b), dim3(256), 0, st, depth, gt, lidar, sums, upstream, w_lidar, ddepth, n_pix);
+    else if (kind == 2) hipLaunchKernelGGL(l1_loss_bwd_kernel<2>, dim3(b), dim3(256), 0, st, depth, gt, lidar, sums, upstream, w_lidar, ddepth, n_pix);
+    else hipLaunchKernelGGL(l1_loss_bwd_kernel<0>, dim3(b), dim3(256), 0, st, depth, gt, lidar, sums, upstream, w_lidar, ddepth, n_pix);
+    return rcf_launch_status();
+}
+
 extern "C" int rcf_l1_loss_bwd(const float* depth, const float* gt, const float* lidar, const double* sums, const float* upstream,
                                float w_lidar, float* ddepth, long long n_pix, void* stream) {
-    if (!depth || !gt || !lidar || !sums || !ddepth || n_pix <= 0) return RCF_EINVAL;
-    unsigned b = nblk(n_pix, 256); if (b > 8192) b = 8192;
-    hipLaunchKernelGGL(l1_loss_bwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, depth, gt, lidar, sums, upstream, w_lidar,
-                       ddepth, n_pix);
+    return rcf_masked_loss_bwd(depth, gt, lidar, sums, upstream, w_lidar, ddepth, n_pix, RCF_LOSS_L1, stream);
+}
+
+extern "C" int rcf_smoothness_loss_fwd(const float* image_nchw, const float* depth, float* workspace, double* sums, int n, int c, int h,
+                                       int w, void* stream) {
+    if (!image_nchw || !depth || !workspace || !sums || n <= 0 || c <= 0 || h <= 0 || w <= 0) return RCF_EINVAL;
+    long long nb = ((long long)n * h * w + 255) / 256;
+    if (nb > LOSS_BLOCKS) nb = LOSS_BLOCKS;
+    hipLaunchKernelGGL(smoothness_partial_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, image_nchw, depth, workspace, n, c, h, w);
+    int rc = rcf_launch_status();
+    if (rc != RCF_OK) return rc;
+    hipLaunchKernelGGL(l1_loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, (int)nb, sums);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_smoothness_loss_bwd(const float* image_nchw, const float* depth, const double* sums, const float* upstream,
+                                       float w_smoothness, float* ddepth, int n, int c, int h, int w, void* stream) {
+    if (!image_nchw || !depth || !sums || !ddepth || n <= 0 || c <= 0 || h <= 0 || w <= 0) return RCF_EINVAL;
+    unsigned b = nblk((long long)n * h * w, 256); if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(smoothness_bwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, image_nchw, depth, sums, upstream, w_smoothness,
+                       ddepth, n, c, h, w);
     return rcf_launch_status();
 }
 

@@ -48,33 +48,49 @@ class _FusionNetFunction(torch.autograd.Function):
 
 
 class _MaskedL1Function(torch.autograd.Function):
-    '''compute_loss with loss_func='l1' (src/fusionnet_model.py:209-253) on the HIP loss kernels.'''
+    '''compute_loss with loss_func 'l1' / 'l2' / 'smoothl1' (src/fusionnet_model.py:209-275) on the HIP loss kernels.'''
 
     @staticmethod
-    def forward(ctx, output_depth, ground_truth, lidar_map, w_lidar, model):
+    def forward(ctx, output_depth, ground_truth, lidar_map, w_lidar, model, kind='l1', image=None, w_smoothness=0.0):
         d = output_depth.contiguous()
         gt = ground_truth.contiguous()
         lidar = lidar_map.contiguous()
         sums = torch.empty(4, dtype=torch.float64, device=d.device)
         loss = torch.empty(3, dtype=torch.float32, device=d.device)
+        sums_s, smooth = None, None
         with torch.cuda.device(d.device):
-            ops.l1_loss_fwd(d, gt, lidar, sums)
+            ops.l1_loss_fwd(d, gt, lidar, sums, kind)
             if model is not None:
                 model._all_reduce_loss_sums(sums)
             ops.l1_loss_value(sums, float(w_lidar), loss)
-        ctx.save_for_backward(d, gt, lidar, sums)
+            if w_smoothness > 0.0:
+                # the local smoothness term (src/fusionnet_model.py:277-281): its sums travel like the masked loss's (per-rank sums and
+                # counts, all-reduced before the backward: the reference takes ONE mean over the gathered batch)
+                image = image.contiguous()
+                sums_s = torch.empty(4, dtype=torch.float64, device=d.device)
+                ops.smoothness_loss_fwd(image, d, sums_s)
+                if model is not None:
+                    model._all_reduce_loss_sums(sums_s)
+                smooth = (sums_s[0] / sums_s[1] + sums_s[2] / sums_s[3]).to(torch.float32)
+        ctx.save_for_backward(d, gt, lidar, sums, image if sums_s is not None else None, sums_s)
         ctx.w_lidar = float(w_lidar)
-        ctx.mark_non_differentiable(loss)
-        return loss[0].clone(), loss
+        ctx.w_smoothness = float(w_smoothness)
+        ctx.kind = kind
+        total = loss[0].clone() if smooth is None else loss[0] + float(w_smoothness) * smooth
+        terms = loss if smooth is None else torch.cat([loss, smooth.view(1)])   # (total without smoothness, supervised, lidar[, smoothness])
+        ctx.mark_non_differentiable(terms)
+        return total, terms
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_terms):
-        d, gt, lidar, sums = ctx.saved_tensors
+        d, gt, lidar, sums, image, sums_s = ctx.saved_tensors
         dd = torch.empty_like(d)
         up = grad_loss.contiguous().view(1).to(torch.float32)
         with torch.cuda.device(d.device):
-            ops.l1_loss_bwd(d, gt, lidar, sums, up, ctx.w_lidar, dd)
-        return dd, None, None, None, None
+            ops.l1_loss_bwd(d, gt, lidar, sums, up, ctx.w_lidar, dd, ctx.kind)
+            if sums_s is not None:
+                ops.smoothness_loss_bwd(image, d, sums_s, up, ctx.w_smoothness, dd)
+        return dd, None, None, None, None, None, None, None
 
 
 class FusionNetModel(object):
@@ -378,28 +394,28 @@ class FusionNetModel(object):
                      w_lidar_loss):
         '''
         Computes loss function (src/fusionnet_model.py:172-302); returns (loss, loss_info).
-        The HIP path implements the shipped configuration: loss_func 'l1', w_smoothness 0
-        (bash/train_fusionnet_nuscenes.sh:43-45).
+        loss_func 'l1' (shipped, bash/train_fusionnet_nuscenes.sh:43-45), 'l2', 'smoothl1'; w_smoothness > 0 with
+        loss_smoothness_kernel_size <= 1 adds the local smoothness term (src/fusionnet_losses.py:48-72); the Sobel variant raises.
         '''
         if isinstance(output_depth, list):
             if len(output_depth) != 1:
                 raise ValueError('HIP path supports a single output resolution')
             output_depth = output_depth[0]
-        if loss_func != 'l1':
-            if loss_func in ('l2', 'smoothl1'):
-                raise ValueError('Loss not implemented on the HIP path: {}'.format(loss_func))
+        if loss_func not in ('l1', 'l2', 'smoothl1'):
             raise ValueError('No such loss: {}'.format(loss_func))
-        if w_smoothness > 0.0:
-            raise ValueError('Smoothness loss is not implemented on the HIP path (shipped w_smoothness is 0.0)')
+        if w_smoothness > 0.0 and loss_smoothness_kernel_size > 1:
+            raise ValueError('The Sobel smoothness loss (loss_smoothness_kernel_size > 1) is not implemented on the HIP path '
+                             '(shipped: w_smoothness 0.0, loss_smoothness_kernel_size -1)')
         if w_lidar_loss > 0.0:
             lidar = lidar_map
         else:
             lidar = torch.zeros_like(ground_truth)   # no lidar term and no ground-truth masking (:214-221)
-        loss, terms = _MaskedL1Function.apply(output_depth, ground_truth, lidar, float(max(w_lidar_loss, 0.0)), self)
+        loss, terms = _MaskedL1Function.apply(output_depth, ground_truth, lidar, float(max(w_lidar_loss, 0.0)), self, loss_func,
+                                              image if w_smoothness > 0.0 else None, float(max(w_smoothness, 0.0)))
         loss_info = {
             'loss': loss,
             'loss_supervised': terms[1],
-            'loss_smoothness': 0.0,
+            'loss_smoothness': terms[3] if w_smoothness > 0.0 else 0.0,
             'loss_lidar': terms[2] if w_lidar_loss > 0.0 else 0.0,
         }
         return loss, loss_info

@@ -524,21 +524,40 @@ def head_bwd_wgrad(x, dlogit, dw, coef=None):
               'rcf_head_bwd_wgrad_bn')
 
 
-def l1_loss_fwd(depth, gt, lidar, sums):
+LOSS_KINDS = {'l1': 0, 'l2': 1, 'smoothl1': 2}   # RCF_LOSS_* (include/rcf_hip.h): FusionNetModel.compute_loss's loss_func values
+
+
+def l1_loss_fwd(depth, gt, lidar, sums, kind='l1'):
+    """sums[4] (fp64) = (sum of the per-pixel term over gt > 0, count, the same over lidar > 0, count) of the masked loss `kind`."""
     n = depth.numel()
     ws = torch.empty(_lib.load().rcf_loss_workspace_floats(n), dtype=torch.float32, device=depth.device)
     if sums.dtype != torch.float64:
-        raise _lib.RcfError('l1_loss sums must be float64[4]')
-    check(_lib.load().rcf_l1_loss_fwd(_f32(depth), _f32(gt), _f32(lidar), _f32(ws), _p(sums), n, _stream()), 'rcf_l1_loss_fwd')
+        raise _lib.RcfError('loss sums must be float64[4]')
+    check(_lib.load().rcf_masked_loss_fwd(_f32(depth), _f32(gt), _f32(lidar), _f32(ws), _p(sums), n, LOSS_KINDS[kind], _stream()),
+          'rcf_masked_loss_fwd')
+
+
+def smoothness_loss_fwd(image_nchw, depth, sums):
+    """sums[4] (fp64) = (sum_x, count_x, sum_y, count_y) of the local smoothness term (rcf_smoothness_loss_fwd)."""
+    n, c, h, w = image_nchw.shape
+    ws = torch.empty(_lib.load().rcf_loss_workspace_floats(depth.numel()), dtype=torch.float32, device=depth.device)
+    check(_lib.load().rcf_smoothness_loss_fwd(_f32(image_nchw), _f32(depth), _f32(ws), _f64(sums), n, c, h, w, _stream()), 'rcf_smoothness_loss_fwd')
+
+
+def smoothness_loss_bwd(image_nchw, depth, sums, upstream, w_smoothness, ddepth):
+    """ddepth += upstream * w_smoothness * d(smoothness)/d(depth)."""
+    n, c, h, w = image_nchw.shape
+    check(_lib.load().rcf_smoothness_loss_bwd(_f32(image_nchw), _f32(depth), _f64(sums), _f32(upstream), float(w_smoothness), _f32(ddepth),
+                                              n, c, h, w, _stream()), 'rcf_smoothness_loss_bwd')
 
 
 def l1_loss_value(sums, w_lidar, loss):
     check(_lib.load().rcf_l1_loss_value(_p(sums), w_lidar, _f32(loss), _stream()), 'rcf_l1_loss_value')
 
 
-def l1_loss_bwd(depth, gt, lidar, sums, upstream, w_lidar, ddepth):
-    check(_lib.load().rcf_l1_loss_bwd(_f32(depth), _f32(gt), _f32(lidar), _p(sums), _f32(upstream), w_lidar, _f32(ddepth),
-                                      depth.numel(), _stream()), 'rcf_l1_loss_bwd')
+def l1_loss_bwd(depth, gt, lidar, sums, upstream, w_lidar, ddepth, kind='l1'):
+    check(_lib.load().rcf_masked_loss_bwd(_f32(depth), _f32(gt), _f32(lidar), _p(sums), _f32(upstream), w_lidar, _f32(ddepth),
+                                          depth.numel(), LOSS_KINDS[kind], _stream()), 'rcf_masked_loss_bwd')
 
 
 def outlier_removal(depth, kernel_size=7, threshold=1.5):

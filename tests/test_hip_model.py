@@ -309,6 +309,36 @@ def test_fresh_seed_odd_size_against_oracle(env, tier):
     assert gm[1] <= 5.0 * gm[3] + 2e-4
 
 
+@pytest.mark.parametrize('kind', ['l2', 'smoothl1', 'l1+smoothness'])
+def test_loss_variants_against_the_reference_fixture(env, golden_dir, kind):
+    '''compute_loss with loss_func 'l2' / 'smoothl1' (src/fusionnet_model.py:255-275) and with the local smoothness term (w_smoothness
+    0.5, loss_smoothness_kernel_size -1: :277-281) against fixture T12 from the REAL reference: the loss terms, the gradient of the loss
+    with respect to the output depth (the loss kernels alone), and the norm of every parameter gradient of the whole backward pass.'''
+    synth, _ = env
+    g = np.load(os.path.join(golden_dir, 'T12_loss_variants.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    m = _build(env, synth.TINY, wseed)
+    m.train()
+    b = _gpu_batch(synth.make_batch(n, h, w, k, seed=dseed))
+    out = m.forward(image=b['image'], input_depth=b['input_depth'])
+    out.retain_grad()
+    loss, info = m.compute_loss(image=b['image'], output_depth=out, ground_truth=b['ground_truth'], lidar_map=b['lidar_map'],
+                                loss_func=kind.split('+')[0], w_smoothness=0.5 if '+' in kind else 0.0, loss_smoothness_kernel_size=-1,
+                                validity_map_loss_smoothness=None, w_lidar_loss=2.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    got = [float(loss), float(info['loss_supervised']), float(info['loss_lidar']), float(info['loss_smoothness'])]
+    np.testing.assert_allclose(got, g[kind + ':loss'], rtol=BAR, atol=1e-12)
+    assert _rel(out.grad, torch.from_numpy(g[kind + ':dloss_doutput'])) < BAR
+    grads = {kk: p.grad for kk, p in _named(m, 'p') if p.grad is not None}
+    for key, l2 in zip(g[kind + ':grad_keys'].tolist(), g[kind + ':grad_l2'].tolist()):
+        assert abs(float(grads[key].double().norm()) - l2) <= 1e-2 * l2 + 1e-9, (kind, key)
+    if '+' in kind:   # the Sobel variant stays unimplemented and says so
+        with pytest.raises(ValueError):
+            m.compute_loss(image=b['image'], output_depth=out.detach(), ground_truth=b['ground_truth'], lidar_map=b['lidar_map'],
+                           loss_func='l1', w_smoothness=0.5, loss_smoothness_kernel_size=7, validity_map_loss_smoothness=None, w_lidar_loss=2.0)
+
+
 def test_checkpoint_round_trip_and_reference_key_names(env, tmp_path):
     synth, train = env
     m = _build(env, synth.TINY, 3)

@@ -213,3 +213,24 @@ def test_t11_two_replica_data_parallel_step(golden_dir):
     for key in g['grad_keys'].tolist():
         assert _rel(grads[key].grad, g['grad_' + key]) < 2e-4, key
     assert abs(float(loss.detach()) - float(g['single_replica_loss'])) > 1e-4 * float(loss.detach())
+
+
+def test_t12_loss_variants_l2_smooth_l1_and_smoothness(golden_dir):
+    '''Fixture T12 (tests/golden/make_golden_losses.py): the real reference's compute_loss with loss_func 'l2' / 'smoothl1' and with
+    the local smoothness term (w_smoothness 0.5) on the tiny net -- loss terms, d loss / d output and every parameter gradient's norm.'''
+    g = np.load(os.path.join(golden_dir, 'T12_loss_variants.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    b = synth.make_batch(n, h, w, k, seed=dseed)
+    for kind in ('l2', 'smoothl1', 'l1+smoothness'):
+        m = _build(synth.TINY, wseed)
+        m.train()
+        out = m.forward(b['image'], b['input_depth'])
+        out.retain_grad()
+        r = m.compute_loss(out, b['ground_truth'], b['lidar_map'], 2.0, loss_func=kind.split('+')[0], image=b['image'],
+                           w_smoothness=0.5 if '+' in kind else 0.0)
+        r[0].backward()
+        np.testing.assert_allclose([float(v) for v in r] + ([0.0] if len(r) == 3 else []), g[kind + ':loss'], rtol=1e-5)
+        assert _rel(out.grad, g[kind + ':dloss_doutput']) < 1e-5
+        grads = dict(_named(m, 'p'))
+        for key, l2 in zip(g[kind + ':grad_keys'].tolist(), g[kind + ':grad_l2'].tolist()):
+            assert abs(float(grads[key].grad.double().norm()) - l2) <= 2e-4 * l2 + 1e-12, (kind, key)
