@@ -440,15 +440,17 @@ def run_rank(args):
     dt = time.time() - t0
     # host time of ENQUEUEING one step into an empty queue (untimed, after the timed region; inside the timed loop the host runs ahead
     # until the queue pushes back, so per-step host time there is just the GPU's time): what a step costs the host thread
-    host_s = 1e9
-    for _ in range(3):
+    host_s = None
+    if use_graph:   # (eager runs -- the profiled ones -- keep exactly warm-up + timed steps)
+        host_s = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            th = time.time()
+            loss = step()
+            host_s = min(host_s, time.time() - th)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        th = time.time()
-        loss = step()
-        host_s = min(host_s, time.time() - th)
-    torch.cuda.synchronize()
     model._engine.prof = None
     my_ms = 1000.0 * dt / args.steps
     final_loss = float(loss.detach())
@@ -463,7 +465,7 @@ def run_rank(args):
         per_rank_ms = [round(1000.0 * float(g.item()) / args.steps, 3) for g in gathered]
         dt = max(float(g.item()) for g in gathered)
         dp_info = measure_overlap(model, eager_step, dev, 1000.0 * dt / args.steps)
-        dp_info['host_ms_per_step'] = round(1000.0 * host_s, 3)
+        dp_info['host_ms_per_step'] = None if host_s is None else round(1000.0 * host_s, 3)
         dp_info['launch'] = ('%d hipGraph segments + the RCCL calls between them per step' % len(step.segments)) if (use_graph and getattr(step, 'segments', None)) else 'eager launches'
 
     table = timer.collect()
@@ -521,7 +523,7 @@ def run_rank(args):
                    'global_batch': world * batch, 'parallelism': 'dp%d' % world,
                    'step': 'forward + outlier removal + masked L1 + backward + Adam, train-mode BatchNorm',
                    'launch': (('one hipGraph replay per step (bitwise the eager step)' if world == 1 else 'hipGraph segments between the exchange points of the data-parallel step (bitwise the eager step)') if use_graph else (graph_note or 'eager launches')),
-                   'host_enqueue_ms_per_step': round(1000.0 * host_s, 3),
+                   'host_enqueue_ms_per_step': None if host_s is None else round(1000.0 * host_s, 3),
                    'arithmetic': ('fp32 tensors' if dtype != 'bf16' else 'bf16 tensors') + ', fp32 accumulate, fp64 BatchNorm sums; convolution launches of the '
                                  'measured step by the arithmetic they ran on (from their kernel ids): ' + arith_line,
                    'arithmetic_by_kernel_class': arith_table,

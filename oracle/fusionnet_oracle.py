@@ -129,14 +129,16 @@ class DecoderBlock(torch.nn.Module):
 
 class FusionNetEncoder(torch.nn.Module):
     '''src/networks.py:270-1005, fusion_type='weight_and_project' (the shipped flag,
-    bash/train_fusionnet_nuscenes.sh:33), n_layer=18 -> two ResNetBlocks per level.'''
+    bash/train_fusionnet_nuscenes.sh:33); n_layer 18 (shipped: two ResNetBlocks per level) or 34 (3, 4, 6, 3, 3).'''
 
     def __init__(self, input_channels_image, input_channels_depth,
-                 n_filters_encoder_image, n_filters_encoder_depth, use_batch_norm):
+                 n_filters_encoder_image, n_filters_encoder_depth, use_batch_norm, n_layer=18):
         super().__init__()
         fi, fd = list(n_filters_encoder_image), list(n_filters_encoder_depth)
         assert len(fi) == len(fd) and 5 <= len(fi) < 8
         self.n_level = len(fi)
+        n_blocks = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}[n_layer]                          # :305-311
+        n_blocks = n_blocks + [n_blocks[-1]] * (len(fi) - len(n_blocks) - 1)                # :317-318
         bn = use_batch_norm
         self.conv1_image = Conv2d(input_channels_image, fi[0], 7, 2, 'leaky_relu', bn)   # :332
         self.conv1_depth = Conv2d(input_channels_depth, fd[0], 7, 2, 'leaky_relu', bn)   # :341
@@ -147,10 +149,11 @@ class FusionNetEncoder(torch.nn.Module):
             stride = 1 if lvl == 2 else 2                                                 # :414, :479
             ci, co = fi[lvl - 2], fi[lvl - 1]
             di, do = fd[lvl - 2], fd[lvl - 1]
+            nb = n_blocks[lvl - 2]                                                        # _make_layer :767-838
             setattr(self, 'blocks%d_image' % lvl, torch.nn.Sequential(
-                ResNetBlock(ci, co, stride, bn), ResNetBlock(co, co, 1, bn)))
+                *[ResNetBlock(ci if b == 0 else co, co, stride if b == 0 else 1, bn) for b in range(nb)]))
             setattr(self, 'blocks%d_depth' % lvl, torch.nn.Sequential(
-                ResNetBlock(di, do, stride, bn), ResNetBlock(do, do, 1, bn)))
+                *[ResNetBlock(di if b == 0 else do, do, stride if b == 0 else 1, bn) for b in range(nb)]))
             setattr(self, 'conv%d_weight' % lvl, Conv2d(do, co, 1, 1, 'sigmoid', bn))
             setattr(self, 'conv%d_project' % lvl, Conv2d(do, co, 1, 1, 'linear', bn))
 
@@ -205,12 +208,12 @@ class FusionNetOracle(object):
                  n_filters_encoder_depth=(16, 32, 64, 128, 128, 128),
                  n_filters_decoder=(256, 256, 128, 64, 64, 32),
                  encoder_batch_norm=True, decoder_batch_norm=True,
-                 min_predict_depth=1.0, max_predict_depth=100.0, deconv_type='up'):
+                 min_predict_depth=1.0, max_predict_depth=100.0, deconv_type='up', n_layer=18):
         self.min_predict_depth = min_predict_depth
         self.max_predict_depth = max_predict_depth
         fi = list(n_filters_encoder_image)
         self.encoder = FusionNetEncoder(input_channels_image, input_channels_depth,
-                                        fi, list(n_filters_encoder_depth), encoder_batch_norm)
+                                        fi, list(n_filters_encoder_depth), encoder_batch_norm, n_layer)
         n_skips = fi[:-1][::-1] + [0]                                        # :118-119
         self.decoder = MultiScaleDecoder(fi[-1], list(n_filters_decoder), n_skips, decoder_batch_norm, deconv_type)
 

@@ -339,6 +339,33 @@ def test_loss_variants_against_the_reference_fixture(env, golden_dir, kind):
                            loss_func='l1', w_smoothness=0.5, loss_smoothness_kernel_size=7, validity_map_loss_smoothness=None, w_lidar_loss=2.0)
 
 
+def test_fusionnet34_against_the_reference_fixture(env, golden_dir):
+    '''encoder_type ['fusionnet34', 'batch_norm'] (src/fusionnet_model.py:84-90, src/networks.py:305-311: 3, 4, 6, 3, 3 ResNet blocks per
+    level) against fixture T13 from the REAL reference: output, loss terms and the norm of every one of the 317 parameter gradients.'''
+    synth, _ = env
+    from rcf_amd.fusionnet_model import FusionNetModel
+    g = np.load(os.path.join(golden_dir, 'T13_fusionnet34_tiny_train.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    cfg = synth.TINY
+    m = FusionNetModel(cfg['input_channels_image'], cfg['input_channels_depth'], ['fusionnet34', 'batch_norm'], cfg['n_filters_encoder_image'],
+                       cfg['n_filters_encoder_depth'], 'weight_and_project', ['multiscale', 'batch_norm'], 1, cfg['n_filters_decoder'], 'up',
+                       'leaky_relu', 'kaiming_uniform', 1.0, 100.0, device='cuda')
+    synth.fill_state_dict_([m.encoder, m.decoder], wseed)
+    assert sum(p.numel() for p in m.parameters()) == int(g['n_params'])
+    m.train()
+    b = _gpu_batch(synth.make_batch(n, h, w, k, seed=dseed))
+    out = m.forward(image=b['image'], input_depth=b['input_depth'])
+    loss, info = _loss(m, b, out)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert _rel(out, torch.from_numpy(g['output'])) < BAR
+    np.testing.assert_allclose([float(loss), float(info['loss_supervised']), float(info['loss_lidar'])], g['loss'], rtol=BAR)
+    grads = {kk: p.grad for kk, p in _named(m, 'p') if p.grad is not None}
+    assert sorted(grads) == sorted(g['grad_keys'].tolist())
+    for key, l2 in zip(g['grad_keys'].tolist(), g['grad_l2'].tolist()):
+        assert abs(float(grads[key].double().norm()) - l2) <= 1e-2 * l2 + 1e-9, key
+
+
 def test_checkpoint_round_trip_and_reference_key_names(env, tmp_path):
     synth, train = env
     m = _build(env, synth.TINY, 3)

@@ -234,3 +234,22 @@ def test_t12_loss_variants_l2_smooth_l1_and_smoothness(golden_dir):
         grads = dict(_named(m, 'p'))
         for key, l2 in zip(g[kind + ':grad_keys'].tolist(), g[kind + ':grad_l2'].tolist()):
             assert abs(float(grads[key].grad.double().norm()) - l2) <= 2e-4 * l2 + 1e-12, (kind, key)
+
+
+def test_t13_fusionnet34(golden_dir):
+    '''Fixture T13 (tests/golden/make_golden_fusionnet34.py): the real reference with encoder_type 'fusionnet34' (3, 4, 6, 3, 3 blocks).'''
+    g = np.load(os.path.join(golden_dir, 'T13_fusionnet34_tiny_train.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    m = FusionNetOracle(n_layer=34, **synth.TINY)
+    synth.fill_state_dict_([m.encoder, m.decoder], wseed)
+    assert sum(p.numel() for p in m.parameters()) == int(g['n_params'])
+    b = synth.make_batch(n, h, w, k, seed=dseed)
+    m.train()
+    out = m.forward(b['image'], b['input_depth'])
+    loss, ls, ll = m.compute_loss(out, b['ground_truth'], b['lidar_map'], 2.0)
+    loss.backward()
+    assert _rel(out.detach(), g['output']) < 1e-5
+    np.testing.assert_allclose([float(loss), float(ls), float(ll)], g['loss'], rtol=1e-5)
+    grads = dict(_named(m, 'p'))
+    for key, l2 in zip(g['grad_keys'].tolist(), g['grad_l2'].tolist()):
+        assert abs(float(grads[key].grad.double().norm()) - l2) <= 2e-4 * l2 + 1e-12, key
