@@ -158,7 +158,8 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
 #pragma unroll
     for (int ni = 0; ni < C::NT; ++ni) { st1[ni][0] = st1[ni][1] = 0.0; st2[ni][0] = st2[ni][1] = 0.0; }
 
-    int tile = blockIdx.x;
+    TileWalk walk;
+    int tile = walk.first(a);
     int q = 0;
     int buf = 0;
 #ifdef RCF_PHASE_TIMING
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
     if (tile < a.ntiles) issue(tile, 0, 0);
     while (tile < a.ntiles) {
         int ntile = tile, nq = q + 1;
-        if (nq == nitem) { nq = 0; ntile = tile + gridDim.x; }
+        if (nq == nitem) { nq = 0; ntile = walk.next(tile, a); }
         const bool more = ntile < a.ntiles;
         RCF_T(t_w0);
         rcf_wait_dma();       // this item's pieces issued by this wave have landed ...

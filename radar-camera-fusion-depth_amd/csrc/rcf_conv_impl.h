@@ -86,6 +86,32 @@ struct ConvArgs {
     int tiles_x, tiles_y, ntiles;
     int nchunk1, nchunk2;
     int ktot, cop;     // wgrad workspace extents
+    int xcd_band;      // deal the tiles to the workgroups in eight contiguous bands, one per XCD (TileWalk)
+};
+
+// The order in which a persistent workgroup walks the tiles.  Workgroup b runs on XCD b % 8 (observed; MI355X_MICROARCH.md "Workgroup
+// dispatch"), and every XCD has its own L2: dealt round-robin, the two workgroups that share a tile border (3x3: a quarter of a tile's
+// input is halo) sit on different XCDs and both fetch it from HBM / the Infinity Cache.  With xcd_band the tiles are cut into eight
+// contiguous bands -- whole horizontal strips of the batch -- and XCD k walks band k, so neighbours in a strip are in flight on the SAME
+// L2 at about the same time.  Which workgroup computes a tile changes, the tile's result does not.
+struct TileWalk {
+    int step, end;
+    __device__ __forceinline__ int first(const ConvArgs& a) {
+        if (a.xcd_band && (gridDim.x & 7) == 0) {
+            const int band = (a.ntiles + 7) >> 3, x = blockIdx.x & 7;
+            step = gridDim.x >> 3;
+            end = (x + 1) * band < a.ntiles ? (x + 1) * band : a.ntiles;
+            const int t = x * band + (int)(blockIdx.x >> 3);
+            return t < end ? t : a.ntiles;
+        }
+        step = gridDim.x;
+        end = a.ntiles;
+        return blockIdx.x;
+    }
+    __device__ __forceinline__ int next(int tile, const ConvArgs& a) const {
+        const int t = tile + step;
+        return t < end ? t : a.ntiles;
+    }
 };
 
 template <int KSY_, int KSX_, int XEXTRA_, int LSTEP_, int CK_, int CST_, int STRP_, int NT_, int PX_, int MINW_>
@@ -752,7 +778,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
     // Phases: one kernel row (KSX taps) per barrier interval.  During a row's MFMAs the next row's weight piece arrives by DMA in
     // the other LDS slot and (one row before the chunk ends) the next A tile is loaded into registers; the A tile itself is handed
     // over between two barriers at the end of the chunk.  The second resident workgroup of the CU fills the matrix pipe meanwhile.
-    int tile = blockIdx.x;
+    TileWalk walk;
+    int tile = walk.first(a);
     int q = 0;
     int pb = 0;   // LDS slot of the weight piece the current kernel row reads
     bf16x8 av[2][C::NPL][C::MT], bv[2][C::NPL][C::NT];
@@ -790,7 +817,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
     if (tile < a.ntiles) fetch_a(0, 0, 0);
     while (tile < a.ntiles) {
         int ntile = tile, nq = q + 1;
-        if (nq == nitem) { nq = 0; ntile = tile + gridDim.x; }
+        if (nq == nitem) { nq = 0; ntile = walk.next(tile, a); }
         const bool more = ntile < a.ntiles;
         const unsigned char* cb_next = more ? chunk_base(nq) : wp;
         // phase_sum == 2 (the four output phases of an up-2x forward in one launch): every phase is a convolution of its own --
@@ -2607,6 +2634,10 @@ void fill_args(const rcf_conv_desc* d, const Sel& s, ConvArgs* a) {
     }
     a->nchunk1 = ceil_div(d->c1, s.cst);
     a->nchunk2 = d->c2 > 0 ? ceil_div(d->c2, s.cst) : 0;
+    // on by default: same step time within 0.3 %, 8 % (two-plane 3x3) to 15 % (bf16 3x3) fewer bytes fetched past the L2 (PMC, round 4:
+    // profiles/r04_xcd_bands.txt); RCF_XCD_BANDS=0 restores the round-robin deal for an A/B
+    static const int xcd_band = [] { const char* e = getenv("RCF_XCD_BANDS"); return e ? atoi(e) : 1; }();
+    a->xcd_band = xcd_band;
 }
 
 template <class F>
@@ -3241,6 +3272,7 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
     if (d->c2 > 0 && !in2) return RCF_EINVAL;
     if ((coef1 || coef2) && (!w.split || SAct::B16 || (coef2 && d->c2 == 0))) return RCF_EUNSUPPORTED;
     ConvArgs a;
+    a.xcd_band = 0;
     a.bias = nullptr; a.res = nullptr;
     a.amax_a1 = nullptr; a.amax_a2 = nullptr; a.amax_b = nullptr;
     a.bz = nullptr; a.bk = nullptr;
