@@ -479,6 +479,14 @@ int rcf_bn_act_bwd_reduce_b16(const float* dout, const float* z, const float* co
                               int c, int act, int has_res, void* stream);
 int rcf_bn_act_bwd_apply_b16(const float* dout, const float* z, const float* coef, const float* out, const float* bcoef, float* dz,
                              float* dres, int dres_accumulate, long long n_pix, int c, int act, int has_res, void* stream);
+/* Inference form of the 'weight_and_project' fusion (src/networks.py:863-866 with the BatchNorms in eval mode) on bf16 tensors, one
+ * pass:  out = sigmoid(scale_w * (W1 d) + shift_w) * (scale_p * (W2 d) + shift_p) + img.   d [n_pix][c_d], img / out [n_pix][c_i] bf16
+ * NHWC; w1, w2: the 1x1 convolutions' fp32 OIHW weights [c_i][c_d]; coef_w, coef_p: rcf_bn_finalize coefficient tables [4][c_i] (rows
+ * scale, shift used).  Replaces two rcf_conv2d_fwd + rcf_fuse_fwd_b16 when no batch statistics are needed.  c_d in {16, 32, 64, 128},
+ * c_i even (rcf_fuse_wp_infer_supported returns 1); anything else: RCF_EUNSUPPORTED. */
+int rcf_fuse_wp_infer_supported(int c_d, int c_i);
+int rcf_fuse_wp_infer_b16(const float* d, const float* w1, const float* coef_w, const float* w2, const float* coef_p, const float* img,
+                          float* out, long long n_pix, int c_d, int c_i, void* stream);
 int rcf_fuse_bwd_reduce_b16(const float* dout, const float* zw, const float* coef_w, const float* zp, const float* coef_p,
                             double* partials, long long n_pix, int c, void* stream);
 int rcf_fuse_bwd_apply_b16(const float* dout, const float* zw, const float* coef_w, const float* zp, const float* coef_p,

@@ -139,6 +139,8 @@ _SIGNATURES.update({
     'rcf_head_bn_bwd_apply_amax': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
 })
 _SIGNATURES['rcf_convert'] = (c_int, [_P, c_int, _P, c_int, c_longlong, c_int, _P])
+_SIGNATURES['rcf_fuse_wp_infer_supported'] = (c_int, [c_int, c_int])
+_SIGNATURES['rcf_fuse_wp_infer_b16'] = (c_int, [_P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P])
 _SIGNATURES['rcf_s2d_image_b16'] = (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P])
 _SIGNATURES['rcf_s2d_image_f32'] = (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P])
 _SIGNATURES['rcf_stem_weights_s2d'] = (c_int, [_P, _P, c_int, c_int, _P])

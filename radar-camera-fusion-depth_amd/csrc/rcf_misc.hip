@@ -377,6 +377,131 @@ __global__ void __launch_bounds__(256) head_fwd_mfma_b16_kernel(const float* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The encoder's 'weight_and_project' fusion (src/networks.py:863-866) for INFERENCE on stored bf16 tensors, in one pass [r4]:
+//     out = sigmoid(BN_w(W1 d)) * BN_p(W2 d) + img,   BN in eval mode = a per-channel affine map.
+// The training arrangement needs the batch statistics of W1 d and W2 d before it can apply them -- two 1x1 convolutions that write zw, zp
+// and an elementwise pass that reads them back with img: 2 c_d + 6 c_i elements of traffic per pixel.  With the statistics known the
+// two products, the affine maps, the sigmoid gate and the sum are one streaming kernel: c_d + 2 c_i per pixel (2.8x less at
+// c_i = 2 c_d).  Structure of conv1x1_b16_kernel (rcf_conv_b16_dma.h): 32 pixels x 16 channels of an NHWC bf16 tensor are the MFMA's
+// A operand as they lie in memory, both weight matrices (scaled by their BatchNorm scale while they are loaded) live in registers for
+// the wave's lifetime, no LDS, no barrier; blockIdx.y takes 32 NT output channels.  The D fragments of the two products have the
+// same (pixel, channel) layout, so the gate needs no exchange; pairs of lanes swap one value to store one dword per pixel pair.
+template <int CTRL>
+__device__ __forceinline__ unsigned hd_dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+
+template <int KST, int NT, int MT>
+__global__ void __launch_bounds__(256, 2) fuse_wp_b16_kernel(const unsigned short* __restrict__ d, const float* __restrict__ w1,
+                                                             const float* __restrict__ coef_w, const float* __restrict__ w2,
+                                                             const float* __restrict__ coef_p, const unsigned short* __restrict__ img,
+                                                             unsigned short* __restrict__ out, long long npix, int c_i) {
+    constexpr int CD = 16 * KST;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5, odd = li & 1;
+    const int co0 = blockIdx.y * 32 * NT;
+    // B fragments: lane (li = output channel, lh), k index e of step s <-> input channel 16 s + 8 lh + e of OIHW [co][ci][1][1]
+    hd_bf16x8 bw[2][KST][NT];
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+        const float* w = br ? w2 : w1;
+        const float* coef = br ? coef_p : coef_w;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            const int co = co0 + ni * 32 + li;
+            const bool ok = co < c_i;
+            const float sc = ok ? coef[co] : 0.f;   // row 0 of the coefficient table: gamma / sqrt(var + eps)
+#pragma unroll
+            for (int s = 0; s < KST; ++s) {
+                const float* wr = w + (size_t)(ok ? co : 0) * CD + s * 16 + lh * 8;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(wr), hi = *reinterpret_cast<const f32x4*>(wr + 4);
+                const uint4 u = {rcf_f2b2(lo[0] * sc, lo[1] * sc), rcf_f2b2(lo[2] * sc, lo[3] * sc), rcf_f2b2(hi[0] * sc, hi[1] * sc),
+                                 rcf_f2b2(hi[2] * sc, hi[3] * sc)};
+                bw[br][s][ni] = __builtin_bit_cast(hd_bf16x8, u);
+            }
+        }
+    }
+    // shifts (row 1: beta - mean * scale) of the channel pair (cp, cp + 1) this lane stores
+    float sw[NT][2], sp[NT][2];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const int cp = (co0 + ni * 32 + li) & ~1;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            sw[ni][e] = cp + e < c_i ? coef_w[c_i + cp + e] : 0.f;
+            sp[ni][e] = cp + e < c_i ? coef_p[c_i + cp + e] : 0.f;
+        }
+    }
+    const long long nblk32 = (npix + 31) / 32;
+    const long long nwaves = (long long)gridDim.x * 4;
+    for (long long blk0 = ((long long)blockIdx.x * 4 + wave) * MT; blk0 < nblk32; blk0 += nwaves * MT) {
+        // every load of the trip -- the A operands and the image words of all MT blocks -- is in flight before the first MFMA
+        uint4 av[MT][KST];
+        unsigned iw[MT][8][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const long long p = (blk0 + mt) * 32 + li;
+#pragma unroll
+            for (int s = 0; s < KST; ++s)
+                av[mt][s] = p < npix ? *reinterpret_cast<const uint4*>(d + (size_t)p * CD + s * 16 + lh * 8) : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const long long p = (blk0 + mt) * 32 + rcf_mfma_row(2 * g, lh) + odd;
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+                    const int cp = (co0 + ni * 32 + li) & ~1;
+                    iw[mt][g][ni] = *reinterpret_cast<const unsigned*>(img + ((p < npix && cp < c_i) ? (size_t)p * c_i + cp : 0));
+                }
+            }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const long long pb0 = (blk0 + mt) * 32;
+            f32x16 acc[2][NT];
+#pragma unroll
+            for (int br = 0; br < 2; ++br)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[br][ni][r] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KST; ++s)
+                        acc[br][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hd_bf16x8, av[mt][s]), bw[br][s][ni],
+                                                                              acc[br][ni], 0, 0, 0);
+                }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int rj = 2 * g;                                    // accumulator rows rj, rj + 1 are consecutive pixels
+                const long long p = pb0 + rcf_mfma_row(rj, lh) + odd;   // the pixel this lane stores
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+                    const int cp = (co0 + ni * 32 + li) & ~1;
+                    float v[2][2];   // [branch][channel cp, cp + 1] at pixel p
+#pragma unroll
+                    for (int br = 0; br < 2; ++br) {
+                        const float a0 = acc[br][ni][rj], a1 = acc[br][ni][rj + 1];
+                        const float mine = odd ? a1 : a0, give = odd ? a0 : a1;
+                        const float got = __uint_as_float(hd_dpp_u32<0xB1>(__float_as_uint(give)));
+                        v[br][0] = odd ? got : mine;
+                        v[br][1] = odd ? mine : got;
+                    }
+                    const float i0 = __uint_as_float(iw[mt][g][ni] << 16), i1 = __uint_as_float(iw[mt][g][ni] & 0xffff0000u);
+                    // the gate on the hardware's exp2 / reciprocal (1 ulp each; the result is rounded to 8 bits): libm's expf and an IEEE
+                    // division are ~30 VALU instructions per element, which made this HBM kernel VALU-bound
+                    const float g0 = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504f * (v[0][0] + sw[ni][0])));
+                    const float g1 = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504f * (v[0][1] + sw[ni][1])));
+                    const float o0 = g0 * (v[1][0] + sp[ni][0]) + i0;
+                    const float o1 = g1 * (v[1][1] + sp[ni][1]) + i1;
+                    if (p < npix && cp < c_i) *reinterpret_cast<unsigned*>(out + (size_t)p * c_i + cp) = rcf_f2b2(o0, o1);
+                }
+            }
+        }
+    }
+}
+
 // input gradient: dx[p] = sum_tap dl[p - (ky-1, kx-1)] w[tap]; the dl halo tile sits in LDS, the weights in registers
 template <int C4N, class S>
 __global__ void __launch_bounds__(256) head_bwd_dgrad_tile_kernel(const float* __restrict__ dl, const float* __restrict__ wgt,
@@ -1377,6 +1502,43 @@ extern "C" int rcf_upsample_nearest_bwd_b16(const float* dup, float* dsrc, int d
                                         int h_src, int w_src, int c, void* stream) { return upsample_nearest_bwd_impl<StB16>(dup, dsrc, dsrc_accumulate, n, h_up, w_up, h_src, w_src, c, stream); }
 extern "C" int rcf_head_fwd(const float* x, const float* w, float* logit, float* depth, int n, int h, int w_, int c,
                             float min_depth, float max_depth, void* stream) { return head_fwd_impl<StF32>(x, w, logit, depth, n, h, w_, c, min_depth, max_depth, stream); }
+template <int KST, int NT, int MT>
+static int launch_fuse_wp(const float* d, const float* w1, const float* coef_w, const float* w2, const float* coef_p, const float* img,
+                          float* out, long long n_pix, int c_i, void* stream) {
+    const int gy = (c_i + 32 * NT - 1) / (32 * NT);
+    const long long trips = (n_pix + 32 * 4 * MT - 1) / (32 * 4 * MT);
+    static const int ncu = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            return (int)prop.multiProcessorCount;
+        return 256;
+    }();
+    long long gx = (long long)ncu * 4 / gy;   // two workgroups per CU, two trips' worth of slack (pw_grid of the 1x1 kernel)
+    if (gx > trips) gx = trips;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL((fuse_wp_b16_kernel<KST, NT, MT>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned short*>(d), w1, coef_w, w2, coef_p, reinterpret_cast<const unsigned short*>(img),
+                       reinterpret_cast<unsigned short*>(out), n_pix, c_i);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_fuse_wp_infer_supported(int c_d, int c_i) {
+    return (c_d == 16 || c_d == 32 || c_d == 64 || c_d == 128) && c_i >= 2 && c_i % 2 == 0 ? 1 : 0;
+}
+
+extern "C" int rcf_fuse_wp_infer_b16(const float* d, const float* w1, const float* coef_w, const float* w2, const float* coef_p,
+                                     const float* img, float* out, long long n_pix, int c_d, int c_i, void* stream) {
+    if (!d || !w1 || !coef_w || !w2 || !coef_p || !img || !out || n_pix <= 0) return RCF_EINVAL;
+    if (!rcf_fuse_wp_infer_supported(c_d, c_i)) return RCF_EUNSUPPORTED;
+    switch (c_d) {
+        case 16: return launch_fuse_wp<1, 1, 4>(d, w1, coef_w, w2, coef_p, img, out, n_pix, c_i, stream);
+        case 32: return launch_fuse_wp<2, 2, 1>(d, w1, coef_w, w2, coef_p, img, out, n_pix, c_i, stream);
+        case 64: return launch_fuse_wp<4, 2, 1>(d, w1, coef_w, w2, coef_p, img, out, n_pix, c_i, stream);
+        default: return launch_fuse_wp<8, 1, 1>(d, w1, coef_w, w2, coef_p, img, out, n_pix, c_i, stream);
+    }
+}
+
 extern "C" int rcf_head_fwd_b16(const float* x, const float* w, float* logit, float* depth, int n, int h, int w_, int c,
                             float min_depth, float max_depth, void* stream) { return head_fwd_impl<StB16>(x, w, logit, depth, n, h, w_, c, min_depth, max_depth, stream); }
 extern "C" int rcf_head_fwd_bn(const float* z, const float* coef, const float* w, float* logit, float* depth, int n, int h, int w_,

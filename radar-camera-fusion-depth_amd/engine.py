@@ -178,6 +178,7 @@ class Engine(object):
         self.training = True
         self.plan = WeightPlan()   # batched weight transforms of a training step (off until the model enables it)
         self.kernel_log = None     # optional list collecting (layer, kernel_id) for profiling
+        self.fuse_wp_one_pass = os.environ.get('RCF_FUSE_WP_ONE_PASS', '1') != '0'   # inference: the fusion in one kernel (bf16 tensors)
         self.prof = None           # optional KernelTimer: brackets conv launches with events on the launch stream
         self.use_phase_convs = True  # exact-2x UpConv and stride-2 dgrad as 2x2 phase convs (False: 9-tap / zero-insert forms)
         # the four forward phases of an up-2x conv in ONE launch (rcf_conv_desc.phase_sum == 2).  Measured [r4], same box, whole step: bf16
@@ -893,9 +894,11 @@ class Engine(object):
         '''
         if not layer.use_batch_norm or layer.activation_func != 'leaky_relu':
             raise ValueError('conv_bn_act expects a BatchNorm + leaky_relu Conv2d block')
-        if self.fuse_eval and not self.training and self.tape is None and not feeds_head:
+        if self.fuse_eval and not self.training and self.tape is None:
             # inference: eval-mode BatchNorm is affine per channel -> scale into the weights, shift + LeakyReLU (+ residual tail) into the
-            # conv kernel's epilogue; layers whose kernel has no such epilogue (f32-MFMA 1x1 / stride-2 / stem) fall through
+            # conv kernel's epilogue; layers whose kernel has no such epilogue (f32-MFMA 1x1 / stride-2 / stem) fall through.  The block
+            # in front of the output head too: its epilogue is free, and a head that reads finished bf16 activations runs on the matrix
+            # pipe (rcf_head_fwd_b16) -- BatchNorm-on-load in the head is the TRAINING arrangement (the statistics are not known earlier)
             src = x.t if x.t is not None else (x.z if x.z is not None else x.s2d)
             coef = self._bn_coef_eval(layer, src)
             z, desc, info, partials, fused = self._conv(layer, x, x2, up_hw, want_stats=False,
@@ -996,6 +999,17 @@ class Engine(object):
 
     def fuse(self, layer_w, layer_p, dep, img):
         '''conv_weight * conv_project + image (src/networks.py:863-866): sigmoid(BN(W1 d)) * BN(W2 d) + img.'''
+        if (self.fuse_eval and not self.training and self.tape is None and self.fuse_wp_one_pass
+                and layer_w.kernel_size == 1 and layer_p.kernel_size == 1 and layer_w.stride == 1 and layer_p.stride == 1):
+            # inference on bf16 tensors: the BatchNorms are affine maps known up front -- both 1x1 convolutions, the gate and the sum
+            # in one streaming kernel (rcf_fuse_wp_infer_b16: c_d + 2 c_i elements of traffic per pixel instead of 2 c_d + 6 c_i)
+            dt, it = self._mat(dep), self._mat(img)
+            if (dt.dtype == torch.bfloat16 and it.dtype == torch.bfloat16 and tuple(dt.shape[:3]) == tuple(it.shape[:3])
+                    and ops.fuse_wp_infer_supported(dt.shape[3], it.shape[3])):
+                out = Act(torch.empty_like(it))
+                ops.fuse_wp_infer(dt, layer_w.conv.weight.detach(), self._bn_coef_eval(layer_w, it), layer_p.conv.weight.detach(),
+                                  self._bn_coef_eval(layer_p, it), it, out.t)
+                return out
         zw, dw_, iw, pw = self._conv(layer_w, dep, want_stats=self.training)
         zp, dp_, ip, pp = self._conv(layer_p, dep, want_stats=self.training)
         coef_w = self._bn_coef(layer_w, pw, iw, zw)

@@ -413,6 +413,22 @@ def fuse_fwd(zw, coef_w, zp, coef_p, img, out, n_pix, c, amax=None):
                                                 _stream()), 'rcf_fuse_fwd')
 
 
+def fuse_wp_infer_supported(c_d, c_i):
+    return bool(_lib.load().rcf_fuse_wp_infer_supported(int(c_d), int(c_i)))
+
+
+def fuse_wp_infer(d, w1, coef_w, w2, coef_p, img, out):
+    """Inference 'weight_and_project' fusion in one pass (bf16 NHWC tensors): sigmoid(BN_w(W1 d)) * BN_p(W2 d) + img, eval-mode BN."""
+    if d.dtype != torch.bfloat16 or img.dtype != torch.bfloat16 or out.dtype != torch.bfloat16:
+        raise ValueError('fuse_wp_infer takes bf16 activation tensors')
+    c_d, c_i = d.shape[-1], img.shape[-1]
+    if tuple(w1.shape[:2]) != (c_i, c_d) or tuple(w2.shape[:2]) != (c_i, c_d) or tuple(out.shape) != tuple(img.shape):
+        raise ValueError('fuse_wp_infer: shapes disagree')
+    n_pix = img.numel() // c_i
+    check(_lib.load().rcf_fuse_wp_infer_b16(_a(d), _f32(w1), _f32(coef_w), _f32(w2), _f32(coef_p), _a(img), _a(out), n_pix, c_d, c_i,
+                                            _stream()), 'rcf_fuse_wp_infer_b16')
+
+
 def ew_blocks(n_pix, c):
     nb = _lib.load().rcf_ew_blocks(n_pix, c)
     if nb <= 0:

@@ -405,6 +405,64 @@ def test_fusion_twins_equal_fp32_kernels_on_bf16_values(ops):
         assert torch.equal(b[i].float(), f[i].bfloat16().float()), i
 
 
+@pytest.mark.parametrize('c_d,c_i,n,h,w', [(16, 32, 2, 37, 53), (32, 64, 2, 19, 23), (64, 128, 1, 31, 17), (128, 256, 2, 8, 13), (16, 24, 1, 9, 11),
+                                           (64, 70, 1, 5, 7)])
+def test_inference_fusion_in_one_pass(ops, c_d, c_i, n, h, w):
+    '''rcf_fuse_wp_infer_b16 = sigmoid(BN_w(W1 d)) * BN_p(W2 d) + img with eval-mode BatchNorm (src/networks.py:863-866), against (a) fp32
+    torch on the same bf16-rounded operands (scaled weights rounded to bf16 as the kernel's B operand is): one bf16 ulp of the result
+    plus the accumulation order; (b) the three-kernel arrangement it replaces (two 1x1 convolutions that round zw, zp to bf16, then
+    rcf_fuse_fwd_b16): within the bf16 roundings that arrangement adds.  Ragged pixel counts and channel counts off the 32-channel tile.'''
+    d = b16(rnd(n, h, w, c_d, seed=1, scale=2.0))
+    img = b16(rnd(n, h, w, c_i, seed=2))
+    w1 = rnd(c_i, c_d, 1, 1, seed=3, scale=(1.0 / c_d) ** 0.5)
+    w2 = rnd(c_i, c_d, 1, 1, seed=4, scale=(1.0 / c_d) ** 0.5)
+    cw = torch.stack([rnd(c_i, seed=5) * 0.5 + 1.0, rnd(c_i, seed=6) * 0.3, rnd(c_i, seed=7) * 0.1, rnd(c_i, seed=8) * 0.2 + 1.0])
+    cp = torch.stack([rnd(c_i, seed=9) * 0.5 + 1.0, rnd(c_i, seed=10) * 0.3, rnd(c_i, seed=11) * 0.1, rnd(c_i, seed=12) * 0.2 + 1.0])
+    assert ops.fuse_wp_infer_supported(c_d, c_i)
+    out = torch.full((n, h, w, c_i), float('nan'), device='cuda').bfloat16()
+    ops.fuse_wp_infer(d.cuda().bfloat16(), w1.cuda(), cw.cuda(), w2.cuda(), cp.cuda(), img.cuda().bfloat16(), out)
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    ws1 = b16(w1.view(c_i, c_d) * cw[0][:, None]).double()
+    ws2 = b16(w2.view(c_i, c_d) * cp[0][:, None]).double()
+    yw = d.double().view(-1, c_d) @ ws1.t() + cw[1].double()
+    yp = d.double().view(-1, c_d) @ ws2.t() + cp[1].double()
+    want = (torch.sigmoid(yw) * yp + img.double().view(-1, c_i)).view(n, h, w, c_i)
+    err = (got.double() - want).abs()
+    bound = BF16_EPS * want.abs() + 2e-5 * (1.0 + yp.abs().view(n, h, w, c_i))   # one ulp of the result + fp32 accumulation of c_d terms
+    assert (err <= bound).all(), float((err - bound).max())
+    if c_i % 32 == 0:   # (b) the arrangement it replaces (its kernels take whole channel tiles)
+        ops.set_precision('bf16')
+        desc = ops.make_fwd_desc(n, h, w, c_d, 0, c_i, 1, 1, h, w, 0)
+        info = ops.conv_query(desc)
+        zs = []
+        for wt in (w1, w2):
+            packed = torch.empty(info.packed_weight_floats, device='cuda')
+            ops.conv_pack(desc, wt.cuda(), packed)
+            z = torch.empty((n, h, w, c_i), device='cuda').bfloat16()
+            ops.conv_fwd(desc, d.cuda().bfloat16(), None, packed, z, None)
+            zs.append(z)
+        old = torch.empty_like(out)
+        ops.fuse_fwd(zs[0], cw.cuda(), zs[1], cp.cuda(), img.cuda().bfloat16(), old, n * h * w, c_i)
+        torch.cuda.synchronize()
+        rel = float((old.float() - out.float()).norm() / out.float().norm())
+        assert rel < 3 * BF16_EPS, rel
+
+
+def test_inference_fusion_refuses_what_it_does_not_cover(ops):
+    from rcf_amd import _lib
+    assert not ops.fuse_wp_infer_supported(48, 96) and not ops.fuse_wp_infer_supported(16, 31)
+    d = torch.zeros((1, 4, 4, 48), device='cuda').bfloat16()
+    img = torch.zeros((1, 4, 4, 96), device='cuda').bfloat16()
+    coef = torch.zeros((4, 96), device='cuda')
+    wt = torch.zeros((96, 48, 1, 1), device='cuda')
+    with pytest.raises(_lib.RcfError):
+        ops.fuse_wp_infer(d, wt, coef, wt, coef, img, torch.empty_like(img))
+    with pytest.raises(ValueError):
+        ops.fuse_wp_infer(d.float(), wt, coef, wt, coef, img, torch.empty_like(img))
+
+
 def test_head_kernels_bf16_input(ops):
     '''3x3 C->1 head on a bf16 activation (and on a deferred bf16 z + coefficients): logits / depth stay fp32 and equal the fp32
     kernel's on the same values; the input gradient is the fp32 one rounded once.'''
@@ -481,6 +539,40 @@ def test_tiny_network_train_step_bf16_storage_against_oracle(ops):
     cos = num / np.sqrt(den_a * den_b)
     print('gradient cosine vs fp32 oracle %.4f' % cos)
     assert cos > 0.95
+
+
+@pytest.mark.parametrize('cfg', ['tiny', 'published'])
+def test_inference_with_the_one_pass_fusion_against_the_oracle_and_the_three_kernel_form(ops, cfg):
+    '''bf16 inference (eval-mode BatchNorm folded) with the fusion levels the one-pass kernel covers (tiny: the 16-channel depth levels;
+    published: all six) against the fp32 CPU oracle in eval mode and against the same forward with RCF_FUSE_WP_ONE_PASS off.'''
+    from oracle.fusionnet_oracle import FusionNetOracle
+    from rcf_amd import synth, train
+    conf = synth.TINY if cfg == 'tiny' else synth.PUBLISHED
+    m = train.build_model(conf, device='cuda')
+    synth.fill_state_dict_([m.encoder, m.decoder], 7)
+    m.compute_dtype = 'bf16'
+    m.eval()
+    o = FusionNetOracle(**conf)
+    synth.fill_state_dict_([o.encoder, o.decoder], 7)
+    o.eval()
+    cb = synth.make_batch(2, 70, 102, 8, seed=78)
+    calls = []
+    real = ops.fuse_wp_infer
+    ops.fuse_wp_infer = lambda *a: (calls.append(a[0].shape[-1]), real(*a))[1]
+    try:
+        with torch.no_grad():
+            one = m.forward(cb['image'].cuda(), cb['input_depth'].cuda()).float().cpu()
+            n_one = len(calls)
+            m._engine.fuse_wp_one_pass = False
+            three = m.forward(cb['image'].cuda(), cb['input_depth'].cuda()).float().cpu()
+            ref = o.forward(cb['image'], cb['input_depth'])
+    finally:
+        ops.fuse_wp_infer = real
+    assert n_one == (4 if cfg == 'tiny' else 6) and len(calls) == n_one, calls   # tiny: depth filters 4 8 16 16 16 16
+    e_one = float((one - ref).abs().max() / ref.abs().max())
+    e_three = float((three - ref).abs().max() / ref.abs().max())
+    print('%s bf16 inference vs oracle: one-pass fusion %.2e, three kernels %.2e' % (cfg, e_one, e_three))
+    assert e_one < 6e-2 and e_one < 1.5 * e_three + 5e-3
 
 
 @pytest.mark.parametrize('c,co,n,h,w', [(3, 32, 2, 70, 102), (2, 16, 2, 71, 101), (3, 8, 1, 64, 96), (2, 4, 3, 33, 35)])

@@ -297,7 +297,8 @@ def test_every_export_rejects_null_arguments_without_launching(pkg):
     from rcf_amd import _lib
     lib = _lib.load()
     queries = {'rcf_version', 'rcf_device_ok', 'rcf_fc_bwd_workspace_floats', 'rcf_bce_workspace_doubles', 'rcf_transform_workspace_bytes',
-               'rcf_points_to_depth_map_workspace_bytes', 'rcf_head_wgrad_workspace_floats', 'rcf_loss_workspace_floats'}
+               'rcf_points_to_depth_map_workspace_bytes', 'rcf_head_wgrad_workspace_floats', 'rcf_loss_workspace_floats',
+                   'rcf_fuse_wp_infer_supported'}
     n = 0
     for name, (restype, argtypes) in _lib._SIGNATURES.items():
         if name in queries:
