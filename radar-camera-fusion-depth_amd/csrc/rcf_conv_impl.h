@@ -2816,7 +2816,11 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
     w->split = (dma_ok && split_enabled() &&
                 ((w->kind == K3S1 && d->out_stride == 1 && d->out_h_phys == d->h_out && d->out_w_phys == d->w_out &&
                   (d->gather1 == RCF_GATHER_DIRECT || d->gather1 == RCF_GATHER_NEAREST)) ||
-                 (w->kind == K2S1 && (d->gather1 == RCF_GATHER_DIRECT || d->gather1 == RCF_GATHER_STRIDED2)))) ? 1 : 0;
+                 (w->kind == K2S1 && (d->gather1 == RCF_GATHER_DIRECT || d->gather1 == RCF_GATHER_STRIDED2)) ||
+                 // 1x1 (the fusion convs, the stride-1 projections) with bf16 tensors: the same kernel with one tap -- an HBM-bound
+                 // layer that the register-staged f32-MFMA kernel ran at 1.3 TB/s [r4].  fp32 tensors keep the DMA-staged f32 kernel
+                 (w->kind == K1 && SAct::B16 && d->stride == 1 && d->gather1 == RCF_GATHER_DIRECT && d->out_stride == 1 &&
+                  d->out_h_phys == d->h_out && d->out_w_phys == d->w_out))) ? 1 : 0;
     // virtual-tall tiling: the DMA / split kernels address the separator rows, the register-staged kernel (the only f32-MFMA
     // weight-gradient kernel for bf16 tensors) does not
     const bool vt_ok = dma_ok && vt_allowed(d) && (!SAct::B16 || w->split);
@@ -3308,7 +3312,14 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
         const int cfg = w.wci * 10 + w.wco;
         if (d->precision == RCF_PREC_BF16) {
             constexpr int THB = SAct::B16 ? 16 : 8;   // tile rows (select_wgrad: th_split)
-            if (w.kind == K2S1) {
+            if (w.kind == K1) {
+                if constexpr (SAct::B16) {
+                    if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2, 1, 16, 1>>(a, w.nsplit, w.gy, w.gz, st);
+                    else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2, 1, 16, 1>>(a, w.nsplit, w.gy, w.gz, st);
+                    else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 1, 16, 1>>(a, w.nsplit, w.gy, w.gz, st);
+                    else rc = launch_wgrad_split<WsCfg<1, 1, 1, 16, 1>>(a, w.nsplit, w.gy, w.gz, st);
+                } else return RCF_EUNSUPPORTED;
+            } else if (w.kind == K2S1) {
                 if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2, 2, THB, 1>>(a, w.nsplit, w.gy, w.gz, st);
                 else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2, 2, THB, 1>>(a, w.nsplit, w.gy, w.gz, st);
                 else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 2, THB, 1>>(a, w.nsplit, w.gy, w.gz, st);

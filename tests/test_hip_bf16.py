@@ -74,6 +74,9 @@ CASES = [
     (3, 1, 64, 0, 64, 3, 33, 40, None),         # batch 3: virtual-tall tiling
     (3, 2, 32, 0, 64, 2, 45, 80, None),         # stride 2
     (1, 1, 16, 0, 32, 2, 35, 51, None),         # fusion 1x1
+    (1, 1, 32, 0, 64, 3, 33, 40, None),         # fusion / projection 1x1, batch 3 (virtual-tall tiling in the weight gradient)
+    (1, 1, 64, 0, 128, 2, 17, 23, None),
+    (1, 1, 128, 0, 256, 1, 15, 25, None),
     (1, 2, 32, 0, 64, 2, 45, 80, None),         # projection
     (7, 2, 3, 0, 32, 2, 70, 102, None),         # stem: fp32 input, bf16 output
     (7, 2, 2, 0, 16, 2, 70, 102, None),
