@@ -522,7 +522,9 @@ template <int KST_, int NT_>
 struct PwCfg {
     // k-steps of 16 input channels, 32-co tiles, 32-pixel blocks per trip (one block for 96 / 128 output channels: with two, the
     // accumulators next to the register-resident weight matrix spilled 60-102 VGPRs)
-    static constexpr int KST = KST_, NT = NT_, MT = NT_ <= 2 ? 4 : 1;
+    // 128 / 256 input channels (the deep levels' input gradients) [r4]: the weight block of ONE workgroup must stay in registers, so a
+    // workgroup takes 64 (KST 8) or 32 (KST 16) output channels and blockIdx.y walks the rest; the A operand is re-read per y from L2
+    static constexpr int KST = KST_, NT = NT_, MT = KST_ >= 8 ? 1 : (NT_ <= 2 ? 4 : 1);
 };
 
 template <class C>
@@ -535,8 +537,9 @@ __global__ void __launch_bounds__(256, 2) conv1x1_b16_kernel(ConvArgs a) {
     const int odd = li & 1;
     // weights: [chunk s][co][16] bf16, halves swizzled by (co >> 3) & 1 (pack_weights_split_kernel with BN = 32 NT, one n-tile)
     bf16x8 bw[C::KST][C::NT];
+    const int co0 = blockIdx.y * 32 * C::NT;   // this workgroup's n-tile
     {
-        const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.wp);
+        const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.wp) + (size_t)blockIdx.y * (C::KST * 32 * C::NT * 32);
 #pragma unroll
         for (int s = 0; s < C::KST; ++s)
 #pragma unroll
@@ -549,7 +552,8 @@ __global__ void __launch_bounds__(256, 2) conv1x1_b16_kernel(ConvArgs a) {
     const long long nblk32 = (npix + 31) / 32;
     const int nwaves = gridDim.x * 4;
     const unsigned short* src = reinterpret_cast<const unsigned short*>(a.in1);
-    unsigned short* outp = reinterpret_cast<unsigned short*>(a.out);
+    unsigned short* outp = reinterpret_cast<unsigned short*>(a.out) + co0;   // this n-tile's first channel: the epilogue below counts from it
+    const int c_lim = a.c_out - co0;
     const bool want_stats = a.stats != nullptr;
     double st1[C::NT][2], st2[C::NT][2];
 #pragma unroll
@@ -561,10 +565,17 @@ __global__ void __launch_bounds__(256, 2) conv1x1_b16_kernel(ConvArgs a) {
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt) {
             const long long p = (blk0 + mt) * 32 + li;
-            const bool ok = p < npix;
+            bool ok = p < npix;
             size_t sp = 0;
             if (ok) {
-                if (a.stride == 1) sp = (size_t)p;
+                if (a.gather1 == RCF_GATHER_ZERO_INSERT) {   // input gradient of a stride-2 1x1 convolution: dz sits at the even positions
+                    const int ox = (int)(p % a.w_out);
+                    const long long t = p / a.w_out;
+                    const int oy = (int)(t % a.h_out);
+                    const int im = (int)(t / a.h_out);
+                    ok = !((oy | ox) & 1) && (oy >> 1) < a.h1 && (ox >> 1) < a.w1;
+                    sp = ((size_t)im * a.h1 + (size_t)(oy >> 1)) * a.w1 + (size_t)(ox >> 1);
+                } else if (a.stride == 1) sp = (size_t)p;
                 else {
                     const int ox = (int)(p % a.w_out);
                     const long long t = p / a.w_out;
@@ -605,7 +616,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_b16_kernel(ConvArgs a) {
 #pragma unroll
                         for (int ni = 0; ni < C::NT; ++ni) {
                             const int cp = (ni * 32 + li) & ~1;
-                            oldw[g][ni] = *reinterpret_cast<const unsigned*>(outp + ((p < npix && cp < a.c_out) ? (size_t)p * a.c_out + cp : 0));
+                            oldw[g][ni] = *reinterpret_cast<const unsigned*>(outp + ((p < npix && cp < c_lim) ? (size_t)p * a.c_out + cp : 0));
                         }
                     }
 #pragma unroll
@@ -620,7 +631,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_b16_kernel(ConvArgs a) {
 #pragma unroll
                     for (int ni = 0; ni < C::NT; ++ni) {
                         const int cp = (ni * 32 + li) & ~1;
-                        const bool ok = p < npix && cp < a.c_out;
+                        const bool ok = p < npix && cp < c_lim;
                         const float a0 = acc[mt][ni][rj], a1 = acc[mt][ni][rj + 1];
                         const float mine = odd ? a1 : a0, give = odd ? a0 : a1;
                         const float got = __uint_as_float(rcf_dpp_u32<0xB1>(__float_as_uint(give)));
@@ -667,24 +678,32 @@ __global__ void __launch_bounds__(256, 2) conv1x1_b16_kernel(ConvArgs a) {
             }
         }
         __syncthreads();
-        if (tid < 32 * C::NT && tid < a.c_out) {
+        if (tid < 32 * C::NT && tid < c_lim) {
             double t1 = 0.0, t2 = 0.0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 t1 += red[((w * C::NT + tid / 32) * 32 + (tid & 31)) * 2 + 0];
                 t2 += red[((w * C::NT + tid / 32) * 32 + (tid & 31)) * 2 + 1];
             }
-            a.stats[((size_t)blockIdx.x * 2 + 0) * a.c_out + tid] = t1;
-            a.stats[((size_t)blockIdx.x * 2 + 1) * a.c_out + tid] = t2;
+            a.stats[((size_t)blockIdx.x * 2 + 0) * a.c_out + co0 + tid] = t1;
+            a.stats[((size_t)blockIdx.x * 2 + 1) * a.c_out + co0 + tid] = t2;
         }
     }
 }
 
-// grid of the pointwise kernel = number of BatchNorm partial rows it writes
-inline int pw_grid(long long npix, int nt) {
-    const int per_trip = 32 * 4 * (nt <= 2 ? 4 : 1);                   // 4 waves x MT blocks of 32 pixels per workgroup trip
+// output channels one workgroup of the pointwise kernel takes (in 32-channel tiles) and the pixel blocks per trip
+inline int pw_nt(int kst, int nt_total) {
+    if (kst >= 16) return 1;
+    if (kst >= 8 || (kst == 4 && nt_total == 4)) return nt_total < 2 ? nt_total : 2;   // (64 -> 128 in one workgroup spilled 34 VGPRs)
+    return nt_total;
+}
+inline int pw_mt(int kst, int nt) { return kst >= 8 ? 1 : (nt <= 2 ? 4 : 1); }
+
+// grid.x of the pointwise kernel = number of BatchNorm partial rows it writes
+inline int pw_grid(long long npix, int kst, int nt, int gy) {
+    const int per_trip = 32 * 4 * pw_mt(kst, nt);                      // 4 waves x MT blocks of 32 pixels per workgroup trip
     const long long trips = (npix + per_trip - 1) / per_trip;
-    long long g = 2 * (long long)num_cus() * 2;                        // two workgroups per CU, two trips' worth of slack
+    long long g = 2 * (long long)num_cus() * 2 / gy;                   // two workgroups per CU, two trips' worth of slack
     if (g > trips) g = trips;
     if (g < 1) g = 1;
     return (int)g;
@@ -692,8 +711,10 @@ inline int pw_grid(long long npix, int nt) {
 
 template <class C>
 int launch_pw(const ConvArgs& a, hipStream_t st) {
-    const int g = pw_grid((long long)a.n * a.h_out * a.w_out, C::NT);
-    hipLaunchKernelGGL((conv1x1_b16_kernel<C>), dim3(g), dim3(256), 0, st, a);
+    static_assert(C::MT == (C::KST >= 8 ? 1 : (C::NT <= 2 ? 4 : 1)), "pw_mt mirrors PwCfg::MT");
+    const int gy = (a.c_out + 32 * C::NT - 1) / (32 * C::NT);
+    const int g = pw_grid((long long)a.n * a.h_out * a.w_out, C::KST, C::NT, gy);
+    hipLaunchKernelGGL((conv1x1_b16_kernel<C>), dim3(g, gy), dim3(256), 0, st, a);
     return rcf_launch_status();
 }
 
@@ -703,7 +724,8 @@ int dispatch_pw(int kst, int nt, F&& f) {
     RCF_PW(1, 1); RCF_PW(1, 2); RCF_PW(1, 3); RCF_PW(1, 4);
     RCF_PW(2, 1); RCF_PW(2, 2); RCF_PW(2, 3); RCF_PW(2, 4);
     RCF_PW(3, 1); RCF_PW(3, 2);
-    RCF_PW(4, 1); RCF_PW(4, 2); RCF_PW(4, 3); RCF_PW(4, 4);
+    RCF_PW(4, 1); RCF_PW(4, 2); RCF_PW(4, 3);
+    RCF_PW(8, 1); RCF_PW(8, 2); RCF_PW(16, 1);
 #undef RCF_PW
     return RCF_EUNSUPPORTED;
 }

@@ -2544,11 +2544,13 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
 #if RCF_CONV_B16
     {
         const char* e = getenv("RCF_B16_PW");
-        if (s->kind == K1 && d->precision == RCF_PREC_BF16 && d->c2 == 0 && d->c1 % 16 == 0 && d->c1 <= 64 && d->c_out <= 128 &&
-            d->gather1 == RCF_GATHER_DIRECT && d->out_stride == 1 && (d->w_mode == RCF_W_FORWARD || d->stride == 1) &&
-            (e == nullptr || e[0] != '0')) {
+        const bool small_k = d->c1 <= 64 && d->c_out <= 128;
+        const bool big_k = (d->c1 == 128 || d->c1 == 256) && d->c_out <= 256;   // weights of one 64 / 32-channel n-tile in registers
+        if (s->kind == K1 && d->precision == RCF_PREC_BF16 && d->c2 == 0 && d->c1 % 16 == 0 && (small_k || big_k) &&
+            (d->gather1 == RCF_GATHER_DIRECT || (d->gather1 == RCF_GATHER_ZERO_INSERT && d->stride == 1)) && d->out_stride == 1 &&
+            (d->w_mode == RCF_W_FORWARD || d->stride == 1) && (e == nullptr || e[0] != '0')) {
             s->pw = 1; s->split = 1; s->bf16 = 1; s->npl = 1; s->ck = 16; s->cst = 16;
-            s->nt = ceil_div(d->c_out, 32);
+            s->nt = pw_nt(d->c1 / 16, ceil_div(d->c_out, 32));
             s->px = 32; s->th = 8; s->bn = 32 * s->nt;
             return RCF_OK;
         }
@@ -2972,7 +2974,7 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
     else
 #endif
 #if RCF_CONV_B16
-    if (s.pw) info->n_partials = pw_grid((long long)d->n * d->h_out * d->w_out, s.nt);
+    if (s.pw) info->n_partials = pw_grid((long long)d->n * d->h_out * d->w_out, d->c1 / 16, s.nt, ceil_div(d->c_out, 32 * s.nt));
     else if (s.dma) info->n_partials = dispatch_dma(s, [&](auto tag) { return dma_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
     else
 #endif

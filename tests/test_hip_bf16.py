@@ -78,6 +78,7 @@ CASES = [
     (1, 1, 64, 0, 128, 2, 17, 23, None),
     (1, 1, 128, 0, 256, 1, 15, 25, None),
     (1, 2, 32, 0, 64, 2, 45, 80, None),         # projection
+    (1, 2, 128, 0, 256, 2, 29, 50, None),       # deep projection: 128 / 256 channels through the pointwise kernel's n-tiles
     (7, 2, 3, 0, 32, 2, 70, 102, None),         # stem: fp32 input, bf16 output
     (7, 2, 2, 0, 16, 2, 70, 102, None),
 ]
