@@ -2821,11 +2821,12 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
                  (w->kind == K2S1 && (d->gather1 == RCF_GATHER_DIRECT || d->gather1 == RCF_GATHER_STRIDED2)) ||
                  // 1x1 (the fusion convs, the stride-1 projections) with bf16 tensors: the same kernel with one tap -- an HBM-bound
                  // layer that the register-staged f32-MFMA kernel ran at 1.3 TB/s [r4].  fp32 tensors keep the DMA-staged f32 kernel
-                 (w->kind == K1 && SAct::B16 && d->stride == 1 && d->gather1 == RCF_GATHER_DIRECT && d->out_stride == 1 &&
+                 // (a stride-2 projection reads x at the even positions: the kernel's STRIDED2 addressing with zero offsets)
+                 (w->kind == K1 && SAct::B16 && d->gather1 == RCF_GATHER_DIRECT && d->out_stride == 1 &&
                   d->out_h_phys == d->h_out && d->out_w_phys == d->w_out))) ? 1 : 0;
     // virtual-tall tiling: the DMA / split kernels address the separator rows, the register-staged kernel (the only f32-MFMA
     // weight-gradient kernel for bf16 tensors) does not
-    const bool vt_ok = dma_ok && vt_allowed(d) && (!SAct::B16 || w->split);
+    const bool vt_ok = dma_ok && vt_allowed(d) && (!SAct::B16 || w->split) && !(w->kind == K1 && d->stride == 2);
     w->wci = w->wco = 1; w->gy = w->gz = 0;
     if (w->split) {   // channels per workgroup: 64 x 64, 32 x 64, 64 x 32 or 32 x 32 (the last with 16-row tiles)
         w->wco = d->c_out > 32 ? 2 : 1;
@@ -3309,6 +3310,10 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
     const int p16 = w.px == 16;
     const bool dma = !SAct::B16 && w.kind != K7S2 && (d->c1 % 4 == 0) && (d->c2 % 4 == 0);
     if (w.split) {
+        if (w.kind == K1 && d->stride == 2) {   // x at the even positions of the physical h_in x w_in tensor; logical input = output grid
+            a.h_in = d->h_out; a.w_in = d->w_out; a.h1 = d->h_in; a.w1 = d->w_in;
+            a.gather1 = RCF_GATHER_STRIDED2; a.ioy = 0; a.iox = 0;
+        }
         a.nchunk1 = ceil_div(d->c1, 32 * w.wci);
         a.nchunk2 = d->c2 > 0 ? ceil_div(d->c2, 32 * w.wci) : 0;
         const int cfg = w.wci * 10 + w.wco;
