@@ -40,6 +40,9 @@ for wl in "bf16_train:--dtype bf16" "bf16_infer:--workload infer" "bf16_radarnet
   done
   python3 tools/pmc_families.py $out/pmc_$name $tag $name $head > $out/pmc_$name.log 2>&1
 done
+# every convolution launch of one eager step with its kernel id and duration (which layer runs where)
+RCF_DTYPE=fp32 python3 tools/layer_times.py 2>/dev/null | grep -v amdgpu > $out/fp32_train_layers.txt
+RCF_DTYPE=bf16 python3 tools/layer_times.py 2>/dev/null | grep -v amdgpu > $out/bf16_train_layers.txt
 mkdir -p $out/profiles && cp profiles/${tag}_* $out/profiles/ 2>/dev/null
 cat $out/pmc_bf16_*.log 2>/dev/null | grep -v amdgpu
 tail -2 $out/make_profile.log
