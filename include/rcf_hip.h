@@ -398,6 +398,12 @@ int rcf_roi_pool_fwd(const float* in, const float* rois, float* out, int* argmax
 /* din (N,H,W,C) += scatter of dout through argmax (rois overlap: atomic adds; zero din first unless accumulating). */
 int rcf_roi_pool_bwd(const float* dout, const int* argmax, const float* rois, float* din, int n_roi, int n, int h, int w, int c,
                      int pooled_h, int pooled_w, int dout_cstride, int dout_coff, void* stream);
+/* The same gradient as a gather (one thread per input pixel walks the rois of its image and the bins containing the pixel): no
+ * atomics, din (N,H,W,C) is written once -- overwritten, or added to when din_accumulate -- in a fixed summation order; needs the
+ * forward's spatial_scale to rebuild the bin edges.  The _b16 twin takes dout AND din as bf16. */
+int rcf_roi_pool_bwd_gather(const float* dout, const int* argmax, const float* rois, float* din, int din_accumulate, int n_roi, int n,
+                            int h, int w, int c, int pooled_h, int pooled_w, float spatial_scale, int dout_cstride, int dout_coff,
+                            void* stream);
 
 /* net_utils.FullyConnected (src/net_utils.py:201-247): y = act(x W^T + b), x (M,n_in), W (n_out,n_in), any M >= 1
  * (rows are processed in blocks of 64 inside the call; dW and db are summed over all rows).
@@ -471,6 +477,7 @@ int rcf_points_to_depth_map(const float* xs, const float* ys, const float* depth
  *   rcf_maxpool3x3s2_bwd_b16 dout, din | rcf_upsample_nearest_bwd_b16 dup, dsrc | rcf_head_fwd_b16 x | rcf_head_fwd_bn_b16 z |
  *   rcf_head_bwd_dgrad_b16 dx | rcf_head_bwd_wgrad_b16 x | rcf_head_bwd_wgrad_bn_b16 z | rcf_roi_pool_fwd_b16 in, out |
  *   rcf_roi_pool_bwd_b16 dout (din stays fp32: the scatter uses fp32 atomics; add it into a bf16 gradient with rcf_convert) |
+ *   rcf_roi_pool_bwd_gather_b16 dout, din |
  *   rcf_fc_fwd_b16 y | rcf_fc_bwd_b16 y, dy. */
 int rcf_bn_act_fwd_b16(const float* z, const float* coef, const float* res, float* out, long long n_pix, int c, int act, void* stream);
 int rcf_fuse_fwd_b16(const float* zw, const float* coef_w, const float* zp, const float* coef_p, const float* img, float* out,
@@ -509,6 +516,9 @@ int rcf_head_bwd_dgrad_b16(const float* dlogit, const float* w, float* dx, int n
 int rcf_head_bwd_wgrad_b16(const float* x, const float* dlogit, float* dw, float* workspace, int n, int h, int w_, int c, void* stream);
 int rcf_head_bwd_wgrad_bn_b16(const float* z, const float* coef, const float* dlogit, float* dw, float* workspace, int n, int h, int w_,
                               int c, void* stream);
+int rcf_roi_pool_bwd_gather_b16(const float* dout, const int* argmax, const float* rois, float* din, int din_accumulate, int n_roi, int n,
+                                int h, int w, int c, int pooled_h, int pooled_w, float spatial_scale, int dout_cstride, int dout_coff,
+                                void* stream);
 int rcf_roi_pool_fwd_b16(const float* in, const float* rois, float* out, int* argmax, int n_roi, int n, int h, int w, int c,
                          int pooled_h, int pooled_w, float spatial_scale, int out_cstride, int out_coff, void* stream);
 int rcf_roi_pool_bwd_b16(const float* dout, const int* argmax, const float* rois, float* din, int n_roi, int n, int h, int w, int c,

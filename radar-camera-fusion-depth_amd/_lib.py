@@ -75,6 +75,7 @@ _SIGNATURES = {
     'rcf_bn_act_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_longlong, c_int, c_int, c_int, _P]),
     'rcf_roi_pool_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
     'rcf_roi_pool_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'rcf_roi_pool_bwd_gather': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
     'rcf_fc_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'rcf_fc_bwd_workspace_floats': (c_size_t, [c_int, c_int, c_int]),
     'rcf_fc_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
@@ -122,7 +123,7 @@ _SIGNATURES = {
 B16_TWINS = ('rcf_bn_act_fwd', 'rcf_fuse_fwd', 'rcf_bn_act_bwd_reduce', 'rcf_bn_act_bwd_apply', 'rcf_fuse_bwd_reduce', 'rcf_fuse_bwd_apply',
              'rcf_head_bn_bwd_reduce', 'rcf_head_bn_bwd_apply', 'rcf_maxpool3x3s2_fwd', 'rcf_maxpool3x3s2_bwd', 'rcf_upsample_nearest_bwd',
              'rcf_head_fwd', 'rcf_head_fwd_bn', 'rcf_head_bwd_dgrad', 'rcf_head_bwd_wgrad', 'rcf_head_bwd_wgrad_bn', 'rcf_roi_pool_fwd',
-             'rcf_roi_pool_bwd', 'rcf_fc_fwd', 'rcf_fc_bwd')
+             'rcf_roi_pool_bwd', 'rcf_roi_pool_bwd_gather', 'rcf_fc_fwd', 'rcf_fc_bwd')
 for _name in B16_TWINS:   # NAME_b16: same argument list, NHWC activation tensors hold bf16 (include/rcf_hip.h)
     _SIGNATURES[_name + '_b16'] = _SIGNATURES[_name]
 _SIGNATURES.update({

@@ -73,6 +73,61 @@ __global__ void __launch_bounds__(256) roi_pool_bwd_kernel(const float* __restri
     }
 }
 
+// The same backward as a GATHER [r4]: one thread per input pixel and four channels walks the rois of its image and the bins that
+// contain the pixel (the forward's own bin-edge expressions: a pixel sits in 1 bin per axis when the pooled size equals the roi size,
+// in up to ceil(1 / bin) + 1 otherwise), and adds dout where the bin's argmax is this pixel.  No atomics, no zero fill of din, no fp32
+// detour for bf16 gradients (the scatter above moved 3.6 GB per level-1 call of the RadarNet step, 0.74 ms; this form reads dout and
+// argmax once and writes din once), and a fixed summation order (roi, bin row, bin column).
+template <class S>
+__global__ void __launch_bounds__(256) roi_pool_bwd_gather_kernel(const float* __restrict__ dout, const int* __restrict__ argmax,
+                                                                  const float* __restrict__ rois, float* __restrict__ din, int accumulate,
+                                                                  int n_roi, int n, int h, int w, int c, int ph_n, int pw_n, float scale,
+                                                                  int dout_cstride, int dout_coff) {
+    const int c4 = c >> 2;
+    const long long total = (long long)n * h * w * c4;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const int cg = (int)(g % c4);
+        long long t = g / c4;
+        const int x = (int)(t % w);
+        t /= w;
+        const int y = (int)(t % h);
+        const int b = (int)(t / h);
+        const size_t idx = (((size_t)b * h + y) * w + x) * c + cg * 4;
+        f32x4 acc = accumulate ? rcf_ld4<S>(din, idx) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int me = y * w + x;
+        for (int r = 0; r < n_roi; ++r) {
+            const float* roi = rois + (size_t)r * 5;
+            if ((int)roi[0] != b) continue;
+            const int x0 = (int)roundf(roi[1] * scale), y0 = (int)roundf(roi[2] * scale);
+            const int x1 = (int)roundf(roi[3] * scale), y1 = (int)roundf(roi[4] * scale);
+            const int rw = max(x1 - x0 + 1, 1), rh = max(y1 - y0 + 1, 1);
+            const int ty = y - y0, tx = x - x0;
+            if (ty < 0 || ty > rh || tx < 0 || tx > rw) continue;
+            const float bh = (float)rh / (float)ph_n, bw = (float)rw / (float)pw_n;
+            const int ph_lo = max(0, (int)floorf((float)ty / bh) - 1), ph_hi = min(ph_n - 1, (int)floorf((float)(ty + 1) / bh) + 1);
+            const int pw_lo = max(0, (int)floorf((float)tx / bw) - 1), pw_hi = min(pw_n - 1, (int)floorf((float)(tx + 1) / bw) + 1);
+            for (int ph = ph_lo; ph <= ph_hi; ++ph) {
+                int hs = (int)floorf((float)ph * bh), he = (int)ceilf((float)(ph + 1) * bh);   // roi_pool_fwd_kernel's edges
+                hs = min(max(hs + y0, 0), h); he = min(max(he + y0, 0), h);
+                if (y < hs || y >= he) continue;
+                for (int pw = pw_lo; pw <= pw_hi; ++pw) {
+                    int ws = (int)floorf((float)pw * bw), we = (int)ceilf((float)(pw + 1) * bw);
+                    ws = min(max(ws + x0, 0), w); we = min(max(we + x0, 0), w);
+                    if (x < ws || x >= we) continue;
+                    const size_t o = ((size_t)r * ph_n + ph) * pw_n + pw;
+                    const int4 am = *reinterpret_cast<const int4*>(argmax + o * c + cg * 4);
+                    const f32x4 d = rcf_ld4<S>(dout, o * dout_cstride + dout_coff + cg * 4);
+                    if (am.x == me) acc[0] += d[0];
+                    if (am.y == me) acc[1] += d[1];
+                    if (am.z == me) acc[2] += d[2];
+                    if (am.w == me) acc[3] += d[3];
+                }
+            }
+        }
+        rcf_st4<S>(din, idx, acc);
+    }
+}
+
 // ---------------------------------------------------------------- fully connected + bias + LeakyReLU
 // y[m][f] = lrelu(sum_k x[m][k] * W[f][k] + b[f]), M <= FC_MAX_M rows held as per-thread accumulators, one thread per output
 // feature (W is read exactly once, coalesced over k by the wave).  Output address of (m, f): with hw == 1 plain [m][f]; otherwise
@@ -87,10 +142,14 @@ __device__ __forceinline__ size_t fc_addr(int m, int f, int n_out, int hw, int c
 
 template <int MB, class S>
 __global__ void __launch_bounds__(256) fc_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
-                                                     const float* __restrict__ bias, float* __restrict__ y, int m_rows, int n_in,
+                                                     const float* __restrict__ bias, float* __restrict__ y, int m_total, int n_in,
                                                      int n_out, int act, int hw, int cstride, int coff) {
-    extern __shared__ float xs[];   // [m_rows][n_in]
-    for (int i = threadIdx.x; i < m_rows * n_in; i += 256) xs[i] = x[i];
+    // blockIdx.y takes MB rows [r4]: one thread per feature with all 64 rows as accumulators made the small layers of the MLP (n_out
+    // 32 ... 128: ONE workgroup) a 230-us serial loop each; per output the fmaf chain over k is the same
+    extern __shared__ float xs[];   // [rows][n_in]
+    const int m0 = blockIdx.y * MB;
+    const int m_rows = min(MB, m_total - m0);
+    for (int i = threadIdx.x; i < m_rows * n_in; i += 256) xs[i] = x[(size_t)m0 * n_in + i];
     __syncthreads();
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= n_out) return;
@@ -110,18 +169,27 @@ __global__ void __launch_bounds__(256) fc_fwd_kernel(const float* __restrict__ x
         if (m < m_rows) {
             float v = acc[m] + bv;
             if (act) v = rcf_lrelu(v);
-            rcf_st1<S>(y, fc_addr(m, f, n_out, hw, cstride, coff), v);
+            rcf_st1<S>(y, fc_addr(m0 + m, f, n_out, hw, cstride, coff), v);
         }
 }
 
 // Backward: g = dy * lrelu'(y); dW[f][k] = sum_m g[m][f] x[m][k]; db[f] = sum_m g[m][f] (one thread per output feature).
+constexpr int FC_KCH = 8;   // input features per workgroup of fc_bwd_kernel (blockIdx.y)
+
 template <int MB, class S>
 __global__ void __launch_bounds__(256) fc_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                      const float* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db,
                                                      int m_rows, int n_in, int n_out, int act, int hw, int cstride, int coff,
                                                      int accumulate) {
-    extern __shared__ float xs[];   // [m_rows][n_in]
-    for (int i = threadIdx.x; i < m_rows * n_in; i += 256) xs[i] = x[i];
+    // blockIdx.y takes FC_KCH input features [r4]; per dW element the fmaf chain over the rows is the same as with one workgroup per
+    // 256 output features looping over all of n_in
+    extern __shared__ float xs[];   // [m_rows][FC_KCH]
+    const int k0 = blockIdx.y * FC_KCH;
+    const int nk = min(FC_KCH, n_in - k0);
+    for (int i = threadIdx.x; i < m_rows * FC_KCH; i += 256) {
+        const int m = i / FC_KCH, kk = i - m * FC_KCH;
+        xs[i] = kk < nk ? x[(size_t)m * n_in + k0 + kk] : 0.f;
+    }
     __syncthreads();
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= n_out) return;
@@ -136,25 +204,28 @@ __global__ void __launch_bounds__(256) fc_bwd_kernel(const float* __restrict__ x
             gs += g[m];
         }
     }
-    db[f] = accumulate ? db[f] + gs : gs;
-    for (int k = 0; k < n_in; ++k) {
-        float dwv = accumulate ? dw[(size_t)f * n_in + k] : 0.f;   // later row blocks continue the same fmaf chain
+    if (blockIdx.y == 0) db[f] = accumulate ? db[f] + gs : gs;
+    for (int kk = 0; kk < nk; ++kk) {
+        float dwv = accumulate ? dw[(size_t)f * n_in + k0 + kk] : 0.f;   // later row blocks continue the same fmaf chain
 #pragma unroll
         for (int m = 0; m < MB; ++m)
-            if (m < m_rows) dwv = fmaf(g[m], xs[m * n_in + k], dwv);
-        dw[(size_t)f * n_in + k] = dwv;
+            if (m < m_rows) dwv = fmaf(g[m], xs[m * FC_KCH + kk], dwv);
+        dw[(size_t)f * n_in + k0 + kk] = dwv;
     }
 }
 
-// Input gradient dx[m][k] = sum_f g[m][f] W[f][k]: a block takes 256 features, keeps their g in LDS and accumulates its partial
-// [m][k] (thread owns column k = t % n_in... of rows m = t / n_in + j * rows_per_pass); partials are summed by fc_dx_reduce_kernel.
+// Input gradient dx[m][k] = sum_f g[m][f] W[f][k]: a block takes FC_DXF features, keeps their g in LDS and accumulates its partial
+// [m][k]; partials are summed (fp64) by fc_dx_reduce_kernel.  64 features per block [r4]: with 256 the last layer's 261 workgroups ran
+// 8192 dependent fmaf per thread (0.38 ms); four times the workgroups, a quarter of the chain.
+constexpr int FC_DXF = 64;
+
 template <class S>
 __global__ void __launch_bounds__(256) fc_dx_partial_kernel(const float* __restrict__ wgt, const float* __restrict__ y,
                                                             const float* __restrict__ dy, float* __restrict__ part, int m_rows,
                                                             int n_in, int n_out, int act, int hw, int cstride, int coff) {
-    extern __shared__ float gs[];   // [256 features][m_rows]
-    const int f0 = blockIdx.x * 256;
-    for (int i = threadIdx.x; i < 256 * m_rows; i += 256) {
+    extern __shared__ float gs[];   // [FC_DXF features][m_rows]
+    const int f0 = blockIdx.x * FC_DXF;
+    for (int i = threadIdx.x; i < FC_DXF * m_rows; i += 256) {
         const int fl = i / m_rows, m = i - fl * m_rows;
         const int f = f0 + fl;
         float g = 0.f;
@@ -165,7 +236,7 @@ __global__ void __launch_bounds__(256) fc_dx_partial_kernel(const float* __restr
         gs[i] = g;
     }
     __syncthreads();
-    const int nf = min(256, n_out - f0);
+    const int nf = min(FC_DXF, n_out - f0);
     for (int o = threadIdx.x; o < m_rows * n_in; o += 256) {
         const int m = o / n_in, k = o - m * n_in;
         float acc = 0.f;
@@ -268,6 +339,18 @@ static int roi_pool_bwd_impl(const float* dout, const int* argmax, const float* 
     return rcf_launch_status();
 }
 
+template <class S>
+static int roi_pool_bwd_gather_impl(const float* dout, const int* argmax, const float* rois, float* din, int din_accumulate, int n_roi,
+                                       int n, int h, int w, int c, int pooled_h, int pooled_w, float spatial_scale, int dout_cstride,
+                                       int dout_coff, void* stream) {
+    if (!dout || !argmax || !rois || !din || n_roi <= 0 || n <= 0 || h <= 0 || w <= 0 || pooled_h <= 0 || pooled_w <= 0) return RCF_EINVAL;
+    if (c < 4 || (c & 3) || dout_cstride < dout_coff + c || (dout_cstride & 3) || (dout_coff & 3)) return RCF_EUNSUPPORTED;
+    const long long total = (long long)n * h * w * (c >> 2);
+    hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<S>), dim3(grid_for(total, 65536)), dim3(256), 0, (hipStream_t)stream, dout, argmax, rois,
+                       din, din_accumulate, n_roi, n, h, w, c, pooled_h, pooled_w, spatial_scale, dout_cstride, dout_coff);
+    return rcf_launch_status();
+}
+
 // Rows are processed in blocks of at most FC_MAX_M (the per-thread accumulator count): a frame may carry any number of radar
 // points (pipeline.radarnet_forward runs every point of a frame through one call, like src/radarnet_main.py:534-561).
 template <class S>
@@ -276,23 +359,17 @@ static int fc_fwd_impl(const float* x, const float* w, const float* bias, float*
     if (!x || !w || !bias || !y || m_rows <= 0 || n_in <= 0 || n_out <= 0) return RCF_EINVAL;
     if ((size_t)FC_MAX_M * n_in * 4 > 48 * 1024 || (hw > 1 && (n_out % hw != 0 || cstride < coff + n_out / hw))) return RCF_EUNSUPPORTED;
     const unsigned nb = (unsigned)((n_out + 255) / 256);
-    hipStream_t st = (hipStream_t)stream;
-    const size_t ystride = hw > 1 ? (size_t)hw * cstride : (size_t)n_out;   // floats between consecutive rows of y
-    for (int m0 = 0; m0 < m_rows; m0 += FC_MAX_M) {
-        const int mb = m_rows - m0 < FC_MAX_M ? m_rows - m0 : FC_MAX_M;
-        const size_t lds = (size_t)mb * n_in * sizeof(float);
-        const float* xb = x + (size_t)m0 * n_in;
-        float* yb = const_cast<float*>(rcf_at_host<S>(y, (size_t)m0 * ystride));
-        if (mb <= 16) hipLaunchKernelGGL((fc_fwd_kernel<16, S>), dim3(nb), dim3(256), lds, st, xb, w, bias, yb, mb, n_in, n_out, act, hw, cstride, coff);
-        else if (mb <= 32) hipLaunchKernelGGL((fc_fwd_kernel<32, S>), dim3(nb), dim3(256), lds, st, xb, w, bias, yb, mb, n_in, n_out, act, hw, cstride, coff);
-        else hipLaunchKernelGGL((fc_fwd_kernel<64, S>), dim3(nb), dim3(256), lds, st, xb, w, bias, yb, mb, n_in, n_out, act, hw, cstride, coff);
-    }
+    constexpr int ROWS = 16;   // rows per workgroup (blockIdx.y)
+    const unsigned ny = (unsigned)((m_rows + ROWS - 1) / ROWS);
+    if (ny > 65535u) return RCF_EUNSUPPORTED;
+    hipLaunchKernelGGL((fc_fwd_kernel<ROWS, S>), dim3(nb, ny), dim3(256), (size_t)ROWS * n_in * sizeof(float), (hipStream_t)stream, x, w, bias,
+                       y, m_rows, n_in, n_out, act, hw, cstride, coff);
     return rcf_launch_status();
 }
 
 extern "C" size_t rcf_fc_bwd_workspace_floats(int m_rows, int n_in, int n_out) {
     if (m_rows <= 0 || n_in <= 0 || n_out <= 0) return 0;
-    return (size_t)((n_out + 255) / 256) * m_rows * n_in;
+    return (size_t)((n_out + FC_DXF - 1) / FC_DXF) * m_rows * n_in;
 }
 
 template <class S>
@@ -308,27 +385,29 @@ static int fc_bwd_impl(const float* x, const float* w, const float* y, const flo
         static bool attr_done = false;
         if (!attr_done) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_dx_partial_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      256 * FC_MAX_M * (int)sizeof(float));
+                                      FC_DXF * FC_MAX_M * (int)sizeof(float));
             attr_done = true;
         }
     }
     // dW and db are sums over ALL rows: the first block overwrites, later blocks accumulate; dx rows are independent per block
     for (int m0 = 0; m0 < m_rows; m0 += FC_MAX_M) {
         const int mb = m_rows - m0 < FC_MAX_M ? m_rows - m0 : FC_MAX_M;
-        const size_t lds = (size_t)mb * n_in * sizeof(float);
+        const size_t lds = (size_t)mb * FC_KCH * sizeof(float);
         const float* xb = x + (size_t)m0 * n_in;
         const float* yb = rcf_at_host<S>(y, (size_t)m0 * ystride);
         const float* dyb = rcf_at_host<S>(dy, (size_t)m0 * ystride);
         const int acc = m0 > 0 ? 1 : 0;
-        if (mb <= 16) hipLaunchKernelGGL((fc_bwd_kernel<16, S>), dim3(nb), dim3(256), lds, st, xb, yb, dyb, dw, db, mb, n_in, n_out, act, hw, cstride, coff, acc);
-        else if (mb <= 32) hipLaunchKernelGGL((fc_bwd_kernel<32, S>), dim3(nb), dim3(256), lds, st, xb, yb, dyb, dw, db, mb, n_in, n_out, act, hw, cstride, coff, acc);
-        else hipLaunchKernelGGL((fc_bwd_kernel<64, S>), dim3(nb), dim3(256), lds, st, xb, yb, dyb, dw, db, mb, n_in, n_out, act, hw, cstride, coff, acc);
+        const dim3 gb(nb, (unsigned)((n_in + FC_KCH - 1) / FC_KCH));
+        if (mb <= 16) hipLaunchKernelGGL((fc_bwd_kernel<16, S>), gb, dim3(256), lds, st, xb, yb, dyb, dw, db, mb, n_in, n_out, act, hw, cstride, coff, acc);
+        else if (mb <= 32) hipLaunchKernelGGL((fc_bwd_kernel<32, S>), gb, dim3(256), lds, st, xb, yb, dyb, dw, db, mb, n_in, n_out, act, hw, cstride, coff, acc);
+        else hipLaunchKernelGGL((fc_bwd_kernel<64, S>), gb, dim3(256), lds, st, xb, yb, dyb, dw, db, mb, n_in, n_out, act, hw, cstride, coff, acc);
         if (dx) {
-            float* wsb = workspace + (size_t)nb * m0 * n_in;
-            hipLaunchKernelGGL((fc_dx_partial_kernel<S>), dim3(nb), dim3(256), (size_t)256 * mb * sizeof(float), st, w, yb, dyb, wsb, mb,
+            const unsigned nbx = (unsigned)((n_out + FC_DXF - 1) / FC_DXF);
+            float* wsb = workspace + (size_t)nbx * m0 * n_in;
+            hipLaunchKernelGGL((fc_dx_partial_kernel<S>), dim3(nbx), dim3(256), (size_t)FC_DXF * mb * sizeof(float), st, w, yb, dyb, wsb, mb,
                                n_in, n_out, act, hw, cstride, coff);
             const int n = mb * n_in;
-            hipLaunchKernelGGL(fc_dx_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, wsb, dx + (size_t)m0 * n_in, (int)nb, n);
+            hipLaunchKernelGGL(fc_dx_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, wsb, dx + (size_t)m0 * n_in, (int)nbx, n);
         }
     }
     return rcf_launch_status();
@@ -361,6 +440,18 @@ extern "C" int rcf_roi_pool_fwd_b16(const float* in, const float* rois, float* o
                                 int pooled_h, int pooled_w, float spatial_scale, int out_cstride, int out_coff, void* stream) { return roi_pool_fwd_impl<StB16>(in, rois, out, argmax, n_roi, n, h, w, c, pooled_h, pooled_w, spatial_scale, out_cstride, out_coff, stream); }
 extern "C" int rcf_roi_pool_bwd(const float* dout, const int* argmax, const float* rois, float* din, int n_roi, int n, int h, int w,
                                 int c, int pooled_h, int pooled_w, int dout_cstride, int dout_coff, void* stream) { return roi_pool_bwd_impl<StF32>(dout, argmax, rois, din, n_roi, n, h, w, c, pooled_h, pooled_w, dout_cstride, dout_coff, stream); }
+extern "C" int rcf_roi_pool_bwd_gather(const float* dout, const int* argmax, const float* rois, float* din, int din_accumulate, int n_roi,
+                                       int n, int h, int w, int c, int pooled_h, int pooled_w, float spatial_scale, int dout_cstride,
+                                       int dout_coff, void* stream) {
+    return roi_pool_bwd_gather_impl<StF32>(dout, argmax, rois, din, din_accumulate, n_roi, n, h, w, c, pooled_h, pooled_w, spatial_scale,
+                                           dout_cstride, dout_coff, stream);
+}
+extern "C" int rcf_roi_pool_bwd_gather_b16(const float* dout, const int* argmax, const float* rois, float* din, int din_accumulate,
+                                           int n_roi, int n, int h, int w, int c, int pooled_h, int pooled_w, float spatial_scale,
+                                           int dout_cstride, int dout_coff, void* stream) {
+    return roi_pool_bwd_gather_impl<StB16>(dout, argmax, rois, din, din_accumulate, n_roi, n, h, w, c, pooled_h, pooled_w, spatial_scale,
+                                           dout_cstride, dout_coff, stream);
+}
 extern "C" int rcf_roi_pool_bwd_b16(const float* dout, const int* argmax, const float* rois, float* din, int n_roi, int n, int h, int w,
                                 int c, int pooled_h, int pooled_w, int dout_cstride, int dout_coff, void* stream) { return roi_pool_bwd_impl<StB16>(dout, argmax, rois, din, n_roi, n, h, w, c, pooled_h, pooled_w, dout_cstride, dout_coff, stream); }
 extern "C" int rcf_fc_fwd(const float* x, const float* w, const float* bias, float* y, int m_rows, int n_in, int n_out, int act,

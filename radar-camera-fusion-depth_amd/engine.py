@@ -1205,20 +1205,14 @@ class Engine(object):
         if self.tape is not None:
             def backward():
                 if x.needs_grad and out.g is not None:
-                    if xt.dtype == torch.float32:
+                    # gathered per input pixel (rcf_roi_pool_bwd_gather): written once in the tensors' own storage -- the scatter form
+                    # (rcf_roi_pool_bwd: fp32 atomics into a zeroed copy) stays in the ABI
+                    acc = x.g is not None
+                    if acc:
                         x.bsum = None
-                        if x.g is None:
-                            x.g = torch.zeros_like(xt)   # rois overlap: scatter-add; later consumers accumulate on top
-                        ops.roi_pool_bwd(out.g, argmax, rois, x.g, out_hw, dout_coff=coff)
-                    else:   # bf16 tensors: the scatter-add runs on an fp32 copy (fp32 atomics), then joins the bf16 gradient
-                        tmp = torch.zeros(xt.shape, dtype=torch.float32, device=xt.device)
-                        ops.roi_pool_bwd(out.g, argmax, rois, tmp, out_hw, dout_coff=coff)
-                        acc = x.g is not None
-                        if acc:
-                            x.bsum = None
-                        if not acc:
-                            x.g = torch.empty_like(xt)
-                        ops.convert(tmp, x.g, accumulate=acc)
+                    else:
+                        x.g = torch.empty_like(xt)
+                    ops.roi_pool_bwd_gather(out.g, argmax, rois, x.g, acc, out_hw, scale, dout_coff=coff)
             self.tape.append(backward)
         return out
 

@@ -638,6 +638,14 @@ def roi_pool_bwd(dout, argmax, rois, din, pooled_hw, dout_coff=0):
                                         pooled_hw[1], dout.shape[-1], dout_coff, _stream()), 'rcf_roi_pool_bwd')
 
 
+def roi_pool_bwd_gather(dout, argmax, rois, din, accumulate, pooled_hw, scale, dout_coff=0):
+    """din (same storage as dout) = / += the pooled gradient, gathered per input pixel: no atomics, no zero fill."""
+    n, h, w, c = din.shape
+    check(_fn('rcf_roi_pool_bwd_gather', dout, din)(_a(dout), _p(argmax), _f32(rois), _a(din), 1 if accumulate else 0, rois.shape[0], n, h, w,
+                                                    c, pooled_hw[0], pooled_hw[1], float(scale), dout.shape[-1], dout_coff, _stream()),
+          'rcf_roi_pool_bwd_gather')
+
+
 def fc_fwd(x, w, b, y, act, hw=1, cstride=0, coff=0):
     m, n_in = x.shape
     check(_fn('rcf_fc_fwd', y)(_f32(x), _f32(w), _f32(b), _a(y), m, n_in, w.shape[0], 1 if act else 0, hw, cstride, coff,

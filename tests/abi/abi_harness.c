@@ -104,7 +104,7 @@ int main(int argc, char** argv) {
     EXPECT(p_rcf_fc_fwd(poison, poison, poison, poison, 0, 3, 32, 1, 1, 0, 0, NULL), RCF_EINVAL);
     EXPECT(p_rcf_fc_fwd(poison, poison, poison, poison, 4, 3, 30, 1, 7, 64, 0, NULL), RCF_EUNSUPPORTED);   /* 30 features do not tile hw = 7 */
     EXPECT(p_rcf_fc_bwd_workspace_floats(-1, 3, 32), 0);
-    EXPECT(p_rcf_fc_bwd_workspace_floats(100, 3, 300), (size_t)2 * 100 * 3);
+    EXPECT(p_rcf_fc_bwd_workspace_floats(100, 3, 300), (size_t)5 * 100 * 3);   /* one partial [m][k] per 64 output features */
     EXPECT(p_rcf_outlier_removal(poison, poison, poison, 1, 8, 8, 6, 1.5f, NULL) != RCF_OK, 1);              /* even window */
     EXPECT(p_rcf_outlier_removal(poison, NULL, poison, 1, 8, 8, 7, 1.5f, NULL), RCF_EINVAL);
     EXPECT(p_rcf_adam_step(poison, poison, poison, poison, 0, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 1, NULL), RCF_EINVAL);

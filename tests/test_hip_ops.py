@@ -701,7 +701,8 @@ def test_roi_pool_forward_backward_matches_restated_torchvision(ops):
     n, c, h, w = 2, 8, 23, 40
     x = torch.randn(n, c, h, w)
     boxes = [torch.tensor([[3.0, 0.0, 19.0, 22.0], [30.0, 0.0, 46.0, 22.0]]), torch.tensor([[-4.0, 0.0, 12.0, 22.0], [10.5, 2.0, 26.5, 20.0]])]
-    for scale, out_hw in ((1.0, (23, 16)), (0.5, (11, 8)), (0.25, (5, 4))):
+    # (the last two pool sizes are LARGER than the roi at that scale: bins narrower than a pixel, many bins per input pixel)
+    for scale, out_hw in ((1.0, (23, 16)), (0.5, (11, 8)), (0.25, (5, 4)), (0.5, (23, 16)), (0.25, (9, 11))):
         hs, ws_ = max(1, int(h * scale)), max(1, int(w * scale))
         xs = torch.nn.functional.interpolate(x, size=(hs, ws_)).clone().requires_grad_(True)
         ref = roi_pool_ref(xs, boxes, out_hw, scale)
@@ -721,6 +722,19 @@ def test_roi_pool_forward_backward_matches_restated_torchvision(ops):
         din = torch.zeros_like(x_nhwc)
         ops.roi_pool_bwd(dout, am, rois, din, out_hw, dout_coff=coff)
         np.testing.assert_allclose(din.permute(0, 3, 1, 2).cpu().numpy(), xs.grad.numpy(), rtol=1e-5, atol=1e-5)
+        # the gather form (rcf_roi_pool_bwd_gather): overwrite, accumulate on top of an earlier gradient, bf16 tensors
+        ding = torch.full_like(x_nhwc, float('nan'))
+        ops.roi_pool_bwd_gather(dout, am, rois, ding, False, out_hw, scale, dout_coff=coff)
+        np.testing.assert_allclose(ding.permute(0, 3, 1, 2).cpu().numpy(), xs.grad.numpy(), rtol=1e-5, atol=1e-5)
+        prev = torch.randn_like(x_nhwc)
+        dacc = prev.clone()
+        ops.roi_pool_bwd_gather(dout, am, rois, dacc, True, out_hw, scale, dout_coff=coff)
+        np.testing.assert_allclose((dacc - prev).permute(0, 3, 1, 2).cpu().numpy(), xs.grad.numpy(), rtol=1e-5, atol=2e-5)
+        db = torch.empty_like(x_nhwc).bfloat16()
+        ops.roi_pool_bwd_gather(dout.bfloat16(), am, rois, db, False, out_hw, scale, dout_coff=coff)
+        want = torch.zeros_like(x_nhwc)
+        ops.roi_pool_bwd(dout.bfloat16().float(), am, rois, want, out_hw, dout_coff=coff)
+        assert float((db.float() - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max()) + 1e-6
 
 
 @pytest.mark.gpu
