@@ -400,7 +400,8 @@ int rcf_roi_pool_bwd(const float* dout, const int* argmax, const float* rois, fl
                      int pooled_h, int pooled_w, int dout_cstride, int dout_coff, void* stream);
 /* The same gradient as a gather (one thread per input pixel walks the rois of its image and the bins containing the pixel): no
  * atomics, din (N,H,W,C) is written once -- overwritten, or added to when din_accumulate -- in a fixed summation order; needs the
- * forward's spatial_scale to rebuild the bin edges.  The _b16 twin takes dout AND din as bf16. */
+ * forward's spatial_scale to rebuild the bin edges.  n_roi <= 1024 (RCF_EUNSUPPORTED beyond: use rcf_roi_pool_bwd).  The _b16 twin
+ * takes dout AND din as bf16. */
 int rcf_roi_pool_bwd_gather(const float* dout, const int* argmax, const float* rois, float* din, int din_accumulate, int n_roi, int n,
                             int h, int w, int c, int pooled_h, int pooled_w, float spatial_scale, int dout_cstride, int dout_coff,
                             void* stream);

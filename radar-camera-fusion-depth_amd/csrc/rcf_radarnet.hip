@@ -78,32 +78,59 @@ __global__ void __launch_bounds__(256) roi_pool_bwd_kernel(const float* __restri
 // in up to ceil(1 / bin) + 1 otherwise), and adds dout where the bin's argmax is this pixel.  No atomics, no zero fill of din, no fp32
 // detour for bf16 gradients (the scatter above moved 3.6 GB per level-1 call of the RadarNet step, 0.74 ms; this form reads dout and
 // argmax once and writes din once), and a fixed summation order (roi, bin row, bin column).
+constexpr int ROI_GATHER_MAX = 1024;   // rois the gather form keeps in LDS (more: use the scatter form)
+
 template <class S>
 __global__ void __launch_bounds__(256) roi_pool_bwd_gather_kernel(const float* __restrict__ dout, const int* __restrict__ argmax,
                                                                   const float* __restrict__ rois, float* __restrict__ din, int accumulate,
                                                                   int n_roi, int n, int h, int w, int c, int ph_n, int pw_n, float scale,
                                                                   int dout_cstride, int dout_coff) {
+    // blockIdx.y = image.  The rois of this image, in roi order, with their integer box and bin sizes: built once per workgroup (a
+    // per-thread scan of all rois cost one dependent scalar load per roi and pixel group: 1.2 of the kernel's 1.4 ms at level 1)
+    __shared__ int s_flag[ROI_GATHER_MAX];
+    __shared__ int s_r[ROI_GATHER_MAX];
+    __shared__ int s_box[ROI_GATHER_MAX][4];     // x0, y0, rw, rh
+    __shared__ float s_bin[ROI_GATHER_MAX][2];   // bh, bw
+    __shared__ int s_cnt;
+    const int b = blockIdx.y;
+    for (int r = threadIdx.x; r < n_roi; r += 256) s_flag[r] = ((int)rois[(size_t)r * 5] == b) ? 1 : 0;
+    __syncthreads();
+    for (int r = threadIdx.x; r < n_roi; r += 256) {
+        if (!s_flag[r]) continue;
+        int pos = 0;
+        for (int q = 0; q < r; ++q) pos += s_flag[q];
+        const float* roi = rois + (size_t)r * 5;
+        const int x0 = (int)roundf(roi[1] * scale), y0 = (int)roundf(roi[2] * scale);
+        const int x1 = (int)roundf(roi[3] * scale), y1 = (int)roundf(roi[4] * scale);
+        const int rw = max(x1 - x0 + 1, 1), rh = max(y1 - y0 + 1, 1);
+        s_r[pos] = r;
+        s_box[pos][0] = x0; s_box[pos][1] = y0; s_box[pos][2] = rw; s_box[pos][3] = rh;
+        s_bin[pos][0] = (float)rh / (float)ph_n;
+        s_bin[pos][1] = (float)rw / (float)pw_n;
+    }
+    if (threadIdx.x == 0) {
+        int cnt = 0;
+        for (int q = 0; q < n_roi; ++q) cnt += s_flag[q];
+        s_cnt = cnt;
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
     const int c4 = c >> 2;
-    const long long total = (long long)n * h * w * c4;
+    const long long total = (long long)h * w * c4;
     for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
         const int cg = (int)(g % c4);
-        long long t = g / c4;
+        const long long t = g / c4;
         const int x = (int)(t % w);
-        t /= w;
-        const int y = (int)(t % h);
-        const int b = (int)(t / h);
+        const int y = (int)(t / w);
         const size_t idx = (((size_t)b * h + y) * w + x) * c + cg * 4;
         f32x4 acc = accumulate ? rcf_ld4<S>(din, idx) : f32x4{0.f, 0.f, 0.f, 0.f};
         const int me = y * w + x;
-        for (int r = 0; r < n_roi; ++r) {
-            const float* roi = rois + (size_t)r * 5;
-            if ((int)roi[0] != b) continue;
-            const int x0 = (int)roundf(roi[1] * scale), y0 = (int)roundf(roi[2] * scale);
-            const int x1 = (int)roundf(roi[3] * scale), y1 = (int)roundf(roi[4] * scale);
-            const int rw = max(x1 - x0 + 1, 1), rh = max(y1 - y0 + 1, 1);
+        for (int i = 0; i < cnt; ++i) {
+            const int x0 = s_box[i][0], y0 = s_box[i][1], rw = s_box[i][2], rh = s_box[i][3];
             const int ty = y - y0, tx = x - x0;
             if (ty < 0 || ty > rh || tx < 0 || tx > rw) continue;
-            const float bh = (float)rh / (float)ph_n, bw = (float)rw / (float)pw_n;
+            const int r = s_r[i];
+            const float bh = s_bin[i][0], bw = s_bin[i][1];
             const int ph_lo = max(0, (int)floorf((float)ty / bh) - 1), ph_hi = min(ph_n - 1, (int)floorf((float)(ty + 1) / bh) + 1);
             const int pw_lo = max(0, (int)floorf((float)tx / bw) - 1), pw_hi = min(pw_n - 1, (int)floorf((float)(tx + 1) / bw) + 1);
             for (int ph = ph_lo; ph <= ph_hi; ++ph) {
@@ -140,6 +167,15 @@ __device__ __forceinline__ size_t fc_addr(int m, int f, int n_out, int hw, int c
     return ((size_t)m * hw + p) * cstride + coff + cch;
 }
 
+// Which feature a thread owns: with the NHWC output layout (hw > 1) consecutive threads take consecutive CHANNELS of one position, so
+// that their y / dy elements are neighbours in memory (feature order f = c * hw + p would put them a whole pixel row apart: the last
+// layer's backward spent 0.4 ms in 2-byte gathers) [r4]
+__device__ __forceinline__ int fc_feature_of_thread(int t, int n_out, int hw) {
+    if (hw <= 1) return t;
+    const int nc = n_out / hw;
+    return (t % nc) * hw + t / nc;
+}
+
 template <int MB, class S>
 __global__ void __launch_bounds__(256) fc_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
                                                      const float* __restrict__ bias, float* __restrict__ y, int m_total, int n_in,
@@ -151,8 +187,9 @@ __global__ void __launch_bounds__(256) fc_fwd_kernel(const float* __restrict__ x
     const int m_rows = min(MB, m_total - m0);
     for (int i = threadIdx.x; i < m_rows * n_in; i += 256) xs[i] = x[(size_t)m0 * n_in + i];
     __syncthreads();
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= n_out) return;
+    const int tf = blockIdx.x * 256 + threadIdx.x;
+    if (tf >= n_out) return;
+    const int f = fc_feature_of_thread(tf, n_out, hw);
     float acc[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[m] = 0.f;
@@ -191,8 +228,9 @@ __global__ void __launch_bounds__(256) fc_bwd_kernel(const float* __restrict__ x
         xs[i] = kk < nk ? x[(size_t)m * n_in + k0 + kk] : 0.f;
     }
     __syncthreads();
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= n_out) return;
+    const int tf = blockIdx.x * 256 + threadIdx.x;
+    if (tf >= n_out) return;
+    const int f = fc_feature_of_thread(tf, n_out, hw);
     float g[MB];
     float gs = 0.f;
 #pragma unroll
@@ -344,10 +382,12 @@ static int roi_pool_bwd_gather_impl(const float* dout, const int* argmax, const 
                                        int n, int h, int w, int c, int pooled_h, int pooled_w, float spatial_scale, int dout_cstride,
                                        int dout_coff, void* stream) {
     if (!dout || !argmax || !rois || !din || n_roi <= 0 || n <= 0 || h <= 0 || w <= 0 || pooled_h <= 0 || pooled_w <= 0) return RCF_EINVAL;
-    if (c < 4 || (c & 3) || dout_cstride < dout_coff + c || (dout_cstride & 3) || (dout_coff & 3)) return RCF_EUNSUPPORTED;
-    const long long total = (long long)n * h * w * (c >> 2);
-    hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<S>), dim3(grid_for(total, 65536)), dim3(256), 0, (hipStream_t)stream, dout, argmax, rois,
-                       din, din_accumulate, n_roi, n, h, w, c, pooled_h, pooled_w, spatial_scale, dout_cstride, dout_coff);
+    if (c < 4 || (c & 3) || dout_cstride < dout_coff + c || (dout_cstride & 3) || (dout_coff & 3) || n_roi > ROI_GATHER_MAX || n > 65535)
+        return RCF_EUNSUPPORTED;
+    const long long per_image = (long long)h * w * (c >> 2);
+    const unsigned gx = grid_for(per_image, (unsigned)(8192 / n > 1 ? 8192 / n : 1));   // a few pixel groups per workgroup: the roi table is built once
+    hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<S>), dim3(gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, dout, argmax, rois, din,
+                       din_accumulate, n_roi, n, h, w, c, pooled_h, pooled_w, spatial_scale, dout_cstride, dout_coff);
     return rcf_launch_status();
 }
 

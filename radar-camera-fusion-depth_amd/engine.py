@@ -1210,9 +1210,16 @@ class Engine(object):
                     acc = x.g is not None
                     if acc:
                         x.bsum = None
-                    else:
-                        x.g = torch.empty_like(xt)
-                    ops.roi_pool_bwd_gather(out.g, argmax, rois, x.g, acc, out_hw, scale, dout_coff=coff)
+                    if rois.shape[0] <= 1024:
+                        if not acc:
+                            x.g = torch.empty_like(xt)
+                        ops.roi_pool_bwd_gather(out.g, argmax, rois, x.g, acc, out_hw, scale, dout_coff=coff)
+                    else:   # more rois than the gather form's table holds: scatter-add into a zeroed fp32 tensor, then join the gradient
+                        tmp = torch.zeros(xt.shape, dtype=torch.float32, device=xt.device)
+                        ops.roi_pool_bwd(out.g, argmax, rois, tmp, out_hw, dout_coff=coff)
+                        if not acc:
+                            x.g = torch.empty_like(xt)
+                        ops.convert(tmp, x.g, accumulate=acc)
             self.tape.append(backward)
         return out
 
