@@ -178,6 +178,7 @@ class Engine(object):
         self.training = True
         self.plan = WeightPlan()   # batched weight transforms of a training step (off until the model enables it)
         self.kernel_log = None     # optional list collecting (layer, kernel_id) for profiling
+        self.up2x_wgrad_direct = os.environ.get('RCF_UP2X_WGRAD_DIRECT', '0') == '1'
         self.fuse_wp_one_pass = os.environ.get('RCF_FUSE_WP_ONE_PASS', '1') != '0'   # inference: the fusion in one kernel (bf16 tensors)
         self.prof = None           # optional KernelTimer: brackets conv launches with events on the launch stream
         self.use_phase_convs = True  # exact-2x UpConv and stride-2 dgrad as 2x2 phase convs (False: 9-tap / zero-insert forms)
@@ -706,8 +707,17 @@ class Engine(object):
         n, h, w, c1 = self._shape(x)
         weight = layer.conv.weight
         co = weight.shape[0]
-        dwp = self._newf((4, co, c1, 2, 2), dz)
-        for ph, d in enumerate(info.up2x):
+        if self.up2x_wgrad_direct:
+            # A/B switch (RCF_UP2X_WGRAD_DIRECT=1): the weight gradient as ONE 3x3 weight gradient at the upsampled resolution with the
+            # nearest gather (2.25x the MFMA work of the four 2x2 phases, x and dz staged once) -- measured, not faster: DESIGN Appendix A
+            d3 = self._exact_unless(ops.make_fwd_desc(n, 2 * h, 2 * w, c1, 0, co, 3, 1, h, w, RCF_GATHER_NEAREST), x.amax, dz_amax)
+            q3 = ops.conv_query(d3)
+            ws = self._newf((max(1, q3.wgrad_workspace_floats),), dz)
+            scales = ops.make_scales(x.amax, None, None, dz_amax) if self._two_plane_wgrad(q3.wgrad_kernel_id) else None
+            ops.conv_wgrad(d3, self._mat(x), None, dz, self.grad_of(weight), ws, scales=scales)
+            info = None
+        dwp = self._newf((4, co, c1, 2, 2), dz) if info is not None else None
+        for ph, d in enumerate(info.up2x if info is not None else ()):
             d = self._exact_unless(d, x.amax, dz_amax)
             qi = ops.conv_query(d)
             ws = self._newf((max(1, qi.wgrad_workspace_floats),), dz)
@@ -720,7 +730,8 @@ class Engine(object):
             ops.conv_wgrad(d, t1, None, dz, dwp[ph], ws, coef1=k1, scales=scales)
             if self.prof is not None:
                 self.prof.end()
-        ops.phase_wgrad_fold(dwp, self.grad_of(weight))
+        if dwp is not None:
+            ops.phase_wgrad_fold(dwp, self.grad_of(weight))
         self._wgrad_done(weight)
         if x.needs_grad:
             wd = self._phase_w(weight.detach(), RCF_PHASE_UP2X_DGRAD)
