@@ -77,6 +77,8 @@ CASES = [
     (1, 1, 32, 0, 64, 3, 33, 40, None),         # fusion / projection 1x1, batch 3 (virtual-tall tiling in the weight gradient)
     (1, 1, 64, 0, 128, 2, 17, 23, None),
     (1, 1, 128, 0, 256, 1, 15, 25, None),
+    (1, 1, 128, 0, 200, 1, 9, 11, None),        # the last n-tile of the pointwise kernel is partial
+    (1, 1, 48, 0, 40, 2, 13, 17, None),         # channel counts off the 32-channel blocks
     (1, 2, 32, 0, 64, 2, 45, 80, None),         # projection
     (1, 2, 128, 0, 256, 2, 29, 50, None),       # deep projection: 128 / 256 channels through the pointwise kernel's n-tiles
     (7, 2, 3, 0, 32, 2, 70, 102, None),         # stem: fp32 input, bf16 output
