@@ -115,9 +115,10 @@ def parse():
     ap.add_argument('--preheat-s', type=float, default=4.0,
                     help='untimed steps run for this many seconds after the W warm-up steps, so the timed steps see the clocks '
                          'of a board at its power limit and not the boost clocks of a cold one')
-    ap.add_argument('--graph', type=int, default=-1, help='train: replay the step from one hipGraph (1) or launch it eagerly (0); '
-                                                          'default: the graph on one GPU (bitwise the eager step, tests/'
-                                                          'test_hip_model.py), eager under data parallelism')
+    ap.add_argument('--graph', type=int, default=-1, help='train: replay the step from one hipGraph / graph segments (1) or launch it '
+                                                          'eagerly with per-launch events (0: the profiled form); default: eager '
+                                                          'launches with the weight gradients on a side stream -- measured faster than '
+                                                          'the replayed graph, which serialises the two branches (bitwise the same step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--side-leg', action='store_true', help='also time the same step on the three-plane bf16 split (f32_3plane), reported '
                                                             'beside the metric in its own object')
@@ -388,7 +389,11 @@ def run_rank(args):
     first_loss = None
     # world > 1: graph segments between the exchange points -- over RCCL (stream-ordered collectives).  gloo (the 1-GPU test mode) blocks
     # the host in every collective and two processes time-slice the device: there the eager step is the faster one, measured
-    use_graph = args.graph != 0 and hasattr(model, 'capture_training_step') and (world == 1 or dist.get_backend() == 'nccl')
+    use_graph = args.graph == 1 and hasattr(model, 'capture_training_step') and (world == 1 or dist.get_backend() == 'nccl')
+    # the default: eager launches, weight gradients on the engine's side stream (Engine.wgrad_side), no per-launch events in the timed steps
+    fast_eager = args.graph == -1 and bool(getattr(model._engine, 'wgrad_side', False))
+    if args.graph == -1 and not fast_eager:   # side stream switched off (RCF_WGRAD_SIDE_STREAM=0): the captured step is the faster one
+        use_graph = hasattr(model, 'capture_training_step') and (world == 1 or dist.get_backend() == 'nccl')
     graph_note = None
     n_pre = 0
     for i in range(max(args.warmup, 0)):
@@ -425,7 +430,7 @@ def run_rank(args):
                 n_pre += 1
             torch.cuda.synchronize()
     timer = ops.KernelTimer()
-    if not use_graph:
+    if not use_graph and not fast_eager:
         model._engine.prof = timer
 
     if world > 1:
@@ -441,7 +446,7 @@ def run_rank(args):
     # host time of ENQUEUEING one step into an empty queue (untimed, after the timed region; inside the timed loop the host runs ahead
     # until the queue pushes back, so per-step host time there is just the GPU's time): what a step costs the host thread
     host_s = None
-    if use_graph:   # (eager runs -- the profiled ones -- keep exactly warm-up + timed steps)
+    if use_graph or fast_eager:   # (--graph 0 runs -- the profiled ones -- keep exactly warm-up + timed steps)
         host_s = 1e9
         for _ in range(3):
             torch.cuda.synchronize()
@@ -466,15 +471,20 @@ def run_rank(args):
         dt = max(float(g.item()) for g in gathered)
         dp_info = measure_overlap(model, eager_step, dev, 1000.0 * dt / args.steps)
         dp_info['host_ms_per_step'] = None if host_s is None else round(1000.0 * host_s, 3)
-        dp_info['launch'] = ('%d hipGraph segments + the RCCL calls between them per step' % len(step.segments)) if (use_graph and getattr(step, 'segments', None)) else 'eager launches'
+        dp_info['launch'] = ('%d hipGraph segments + the RCCL calls between them per step' % len(step.segments)) if (use_graph and getattr(step, 'segments', None)) else ('eager launches, weight gradients on a side stream' if fast_eager else 'eager launches')
 
     table = timer.collect()
-    if use_graph:   # a replayed graph has no per-launch events: time the kernel families on a few eager steps after the timed region
+    if use_graph or fast_eager:
+        # a replayed graph has no per-launch events, and the default's overlapped streams would time every kernel with its neighbour's
+        # share of the board power: time the kernel families one at a time, on a few single-stream eager steps after the timed region
+        side_was = getattr(model._engine, 'wgrad_side', False)
+        model._engine.wgrad_side = False
         model._engine.prof = timer
         for _ in range(3):
             eager_step()
         torch.cuda.synchronize()
         model._engine.prof = None
+        model._engine.wgrad_side = side_was
         table = timer.collect()
     # aggregate kernel ids (kind*1000 + ck*10 + nt [+100 for the 16x16 tile]; wgrad ids are 10000 + ...) by kernel family
     fam = {}
@@ -484,7 +494,7 @@ def run_rank(args):
         r = fam.setdefault(f, [0, 0.0, 0.0, 0.0])
         r[0] += cnt; r[1] += flops; r[2] += ms; r[3] += getattr(timer, 'bytes', {}).get(kid, 0.0)
     dom = max(fam, key=lambda f: fam[f][2]) if fam else None
-    ev_steps = 3 if use_graph else args.steps
+    ev_steps = 3 if (use_graph or fast_eager) else args.steps
     arith_table, arith_line = arithmetic_of_step(table, ev_steps)
 
     side = None
@@ -522,7 +532,8 @@ def run_rank(args):
                                   'configs[1]' if dtype in ('f32', 'f32_3plane') else 'configs[3] on %d GPU(s)' % world),
                    'global_batch': world * batch, 'parallelism': 'dp%d' % world,
                    'step': 'forward + outlier removal + masked L1 + backward + Adam, train-mode BatchNorm',
-                   'launch': (('one hipGraph replay per step (bitwise the eager step)' if world == 1 else 'hipGraph segments between the exchange points of the data-parallel step (bitwise the eager step)') if use_graph else (graph_note or 'eager launches')),
+                   'launch': (('one hipGraph replay per step (bitwise the eager step)' if world == 1 else 'hipGraph segments between the exchange points of the data-parallel step (bitwise the eager step)') if use_graph
+                              else ('eager launches, weight gradients on a side stream beside the BatchNorm-backward passes (bitwise the single-stream step; --graph 1 replays a hipGraph, whose branches the runtime serialises)' if fast_eager else (graph_note or 'eager launches'))),
                    'host_enqueue_ms_per_step': None if host_s is None else round(1000.0 * host_s, 3),
                    'arithmetic': ('fp32 tensors' if dtype != 'bf16' else 'bf16 tensors') + ', fp32 accumulate, fp64 BatchNorm sums; convolution launches of the '
                                  'measured step by the arithmetic they ran on (from their kernel ids): ' + arith_line,
@@ -588,7 +599,8 @@ def run_rank(args):
             'frac_of_power_limited_peak': round(achieved / BF16_MFMA_SUSTAINED_TFLOPS, 4) if is_split else None,
             'pipe': SPLIT_PIPE[dtype] if is_split else 'f32 MFMA',
             'products_per_multiply': SPLIT_PRODUCTS[dtype] if is_split else 1,
-            'events_from': ('%d eager steps after the timed region (a replayed hipGraph has no per-launch events)' % ev_steps) if use_graph
+            'events_from': ('%d single-stream eager steps after the timed region (every kernel timed alone: no per-launch events in a replayed '
+                            'graph, and overlapped streams share the board power)' % ev_steps) if (use_graph or fast_eager)
                            else 'HIP events around every launch of the family inside the timed steps',
             'traffic': traffic, 'traffic_source': traffic_src,
             'mfma_busy_pmc': mfma_busy,   # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) of the family, same committed passes
@@ -808,10 +820,13 @@ def run_radarnet(args, dev):
     from rcf_amd import ops
     timer = ops.KernelTimer()
     m._engine.prof = timer
+    side_was = getattr(m._engine, 'wgrad_side', False)
+    m._engine.wgrad_side = False   # single stream: every kernel timed alone (the timed steps overlap weight gradients on a side stream)
     for _ in range(3):
         step()
     torch.cuda.synchronize()
     m._engine.prof = None
+    m._engine.wgrad_side = side_was
     fam = {}
     for kid, (cnt, flops, ms) in timer.collect().items():
         kid0 = kid % 20000

@@ -179,6 +179,14 @@ class Engine(object):
         self.plan = WeightPlan()   # batched weight transforms of a training step (off until the model enables it)
         self.kernel_log = None     # optional list collecting (layer, kernel_id) for profiling
         self.up2x_wgrad_direct = os.environ.get('RCF_UP2X_WGRAD_DIRECT', '0') == '1'
+        # weight gradients on a side stream (fork after dZ is written, join before the optimizer / a gradient bucket's exchange): a
+        # weight gradient is off the backward's critical path, and the BatchNorm-backward passes it then overlaps are HBM-bound kernels
+        # that leave board power unused while the convolution kernels run AT the power limit
+        self.wgrad_side = os.environ.get('RCF_WGRAD_SIDE_STREAM', '1') != '0'
+        self._side = None
+        self._side_busy = False
+        self._side_keep = []
+        self.completes_bucket = None   # callable(parameter) -> bool (data parallelism): this gradient finishes a bucket
         self.fuse_wp_one_pass = os.environ.get('RCF_FUSE_WP_ONE_PASS', '1') != '0'   # inference: the fusion in one kernel (bf16 tensors)
         self.prof = None           # optional KernelTimer: brackets conv launches with events on the launch stream
         self.use_phase_convs = True  # exact-2x UpConv and stride-2 dgrad as 2x2 phase convs (False: 9-tap / zero-insert forms)
@@ -384,9 +392,37 @@ class Engine(object):
     def _shape(x):
         return (x.t if x.t is not None else x.z).shape
 
+    def _side_enter(self, *keep):
+        '''Switch to the side stream for a weight gradient (None when the switch is off).  keep: tensors the side-stream kernels read
+        that the main stream's Python flow would free before they ran -- held until side_join().'''
+        if not self.wgrad_side or self.bn_on_load:
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        self._side.wait_stream(torch.cuda.current_stream())
+        self._side_keep.extend(t for t in keep if t is not None)
+        self._side_busy = True
+        ctx = torch.cuda.stream(self._side)
+        ctx.__enter__()
+        return ctx
+
+    @staticmethod
+    def _side_exit(ctx):
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+
+    def side_join(self):
+        '''The main stream waits for every weight gradient enqueued on the side stream; the tensors they read may go.'''
+        if self._side_busy:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_busy = False
+        del self._side_keep[:]
+
     def _wgrad_done(self, *params):
         if self.on_param_grad is not None:
             for p in params:
+                if self._side_busy and (self.completes_bucket is None or self.completes_bucket(p)):
+                    self.side_join()   # the bucket's exchange reads gradients the side stream may still be writing
                 self.on_param_grad(p)
 
     def _conv(self, layer, x, x2=None, up_hw=None, want_stats=False, fold=None):
@@ -707,6 +743,10 @@ class Engine(object):
         n, h, w, c1 = self._shape(x)
         weight = layer.conv.weight
         co = weight.shape[0]
+        side = None
+        if self.wgrad_side and not self.bn_on_load:
+            self._mat(x)
+            side = self._side_enter(dz, x.t)
         if self.up2x_wgrad_direct:
             # A/B switch (RCF_UP2X_WGRAD_DIRECT=1): the weight gradient as ONE 3x3 weight gradient at the upsampled resolution with the
             # nearest gather (2.25x the MFMA work of the four 2x2 phases, x and dz staged once) -- measured, not faster: DESIGN Appendix A
@@ -732,6 +772,7 @@ class Engine(object):
                 self.prof.end()
         if dwp is not None:
             ops.phase_wgrad_fold(dwp, self.grad_of(weight))
+        self._side_exit(side)
         self._wgrad_done(weight)
         if x.needs_grad:
             wd = self._phase_w(weight.detach(), RCF_PHASE_UP2X_DGRAD)
@@ -773,6 +814,12 @@ class Engine(object):
         x_amax = x.amax
         x2_amax = 0 if x2 is None else x2.amax
         s2_phases = self.s2_wgrad_phases if self.s2_wgrad_phases is not None else (ops.act_dtype() == torch.bfloat16 or ops.get_precision() == 2)
+        side = None
+        if self.wgrad_side and not self.bn_on_load:
+            self._mat(x)
+            if x2 is not None:
+                self._mat(x2)
+            side = self._side_enter(dz, x.t, None if x2 is None else x2.t)
         if (self.use_phase_convs and s2_phases and desc.stride == 2 and desc.ksize == 3 and x2 is None and desc.c1 % 4 == 0
                 and desc.c1 >= 16 and desc.gather1 == RCF_GATHER_DIRECT):
             # 3x3 stride-2 weight gradient as four 2x2 weight gradients on the phase images of x (bf16 matrix pipe)
@@ -809,6 +856,7 @@ class Engine(object):
             ops.conv_wgrad(wdesc, t1, t2, dz, dw, ws, coef1=k1, coef2=k2, scales=scales)
             if self.prof is not None:
                 self.prof.end()
+        self._side_exit(side)
         self._wgrad_done(weight)
         for src, off, cnt in ((x, 0, desc.c1), (x2, desc.c1, desc.c2)):
             if src is None or not src.needs_grad:

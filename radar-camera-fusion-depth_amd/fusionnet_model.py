@@ -340,10 +340,12 @@ class FusionNetModel(object):
         if self._dp is not None:
             self._dp.begin_backward()
         self._engine.on_param_grad = self._dp.on_param_grad if self._dp is not None else None
+        self._engine.completes_bucket = self._dp.completes_bucket if self._dp is not None else None
         ops.set_precision(ops.precision_of(self.compute_dtype))
         try:
             with torch.cuda.device(self._grad_arena.device):
                 Engine.backward(out, tape, ddepth)
+                self._engine.side_join()
         finally:
             ops.set_precision('fp32')
         self._engine.plan.end()

@@ -56,6 +56,11 @@ class GradientBuckets(object):
         self.remaining = list(self.members)
         self.handles = []
 
+    def completes_bucket(self, p):
+        '''True when on_param_grad(p) will launch its bucket's exchange (the engine joins its side stream first).'''
+        b = self.bucket_of.get(id(p))
+        return b is not None and self.remaining[b] == 1
+
     def on_param_grad(self, p):
         b = self.bucket_of.get(id(p))
         if b is None:
