@@ -471,20 +471,20 @@ def run_rank(args):
         dt = max(float(g.item()) for g in gathered)
         dp_info = measure_overlap(model, eager_step, dev, 1000.0 * dt / args.steps)
         dp_info['host_ms_per_step'] = None if host_s is None else round(1000.0 * host_s, 3)
-        dp_info['launch'] = ('%d hipGraph segments + the RCCL calls between them per step' % len(step.segments)) if (use_graph and getattr(step, 'segments', None)) else ('eager launches, weight gradients on a side stream' if fast_eager else 'eager launches')
+        dp_info['launch'] = ('%d hipGraph segments + the RCCL calls between them per step' % len(step.segments)) if (use_graph and getattr(step, 'segments', None)) else ('eager launches, weight gradients and the depth branch on side streams' if fast_eager else 'eager launches')
 
     table = timer.collect()
     if use_graph or fast_eager:
         # a replayed graph has no per-launch events, and the default's overlapped streams would time every kernel with its neighbour's
         # share of the board power: time the kernel families one at a time, on a few single-stream eager steps after the timed region
-        side_was = getattr(model._engine, 'wgrad_side', False)
-        model._engine.wgrad_side = False
+        side_was, branch_was = getattr(model._engine, 'wgrad_side', False), getattr(model._engine, 'branch_stream', False)
+        model._engine.wgrad_side = model._engine.branch_stream = False
         model._engine.prof = timer
         for _ in range(3):
             eager_step()
         torch.cuda.synchronize()
         model._engine.prof = None
-        model._engine.wgrad_side = side_was
+        model._engine.wgrad_side, model._engine.branch_stream = side_was, branch_was
         table = timer.collect()
     # aggregate kernel ids (kind*1000 + ck*10 + nt [+100 for the 16x16 tile]; wgrad ids are 10000 + ...) by kernel family
     fam = {}
@@ -533,7 +533,7 @@ def run_rank(args):
                    'global_batch': world * batch, 'parallelism': 'dp%d' % world,
                    'step': 'forward + outlier removal + masked L1 + backward + Adam, train-mode BatchNorm',
                    'launch': (('one hipGraph replay per step (bitwise the eager step)' if world == 1 else 'hipGraph segments between the exchange points of the data-parallel step (bitwise the eager step)') if use_graph
-                              else ('eager launches, weight gradients on a side stream beside the BatchNorm-backward passes (bitwise the single-stream step; --graph 1 replays a hipGraph, whose branches the runtime serialises)' if fast_eager else (graph_note or 'eager launches'))),
+                              else ('eager launches on three streams: the main chain, the weight gradients, the encoder\'s depth branch (bitwise the single-stream step; --graph 1 replays a hipGraph, whose branches the runtime serialises)' if fast_eager else (graph_note or 'eager launches'))),
                    'host_enqueue_ms_per_step': None if host_s is None else round(1000.0 * host_s, 3),
                    'arithmetic': ('fp32 tensors' if dtype != 'bf16' else 'bf16 tensors') + ', fp32 accumulate, fp64 BatchNorm sums; convolution launches of the '
                                  'measured step by the arithmetic they ran on (from their kernel ids): ' + arith_line,
@@ -820,13 +820,13 @@ def run_radarnet(args, dev):
     from rcf_amd import ops
     timer = ops.KernelTimer()
     m._engine.prof = timer
-    side_was = getattr(m._engine, 'wgrad_side', False)
-    m._engine.wgrad_side = False   # single stream: every kernel timed alone (the timed steps overlap weight gradients on a side stream)
+    side_was, branch_was = getattr(m._engine, 'wgrad_side', False), getattr(m._engine, 'branch_stream', False)
+    m._engine.wgrad_side = m._engine.branch_stream = False   # single stream: every kernel timed alone (the timed steps overlap streams)
     for _ in range(3):
         step()
     torch.cuda.synchronize()
     m._engine.prof = None
-    m._engine.wgrad_side = side_was
+    m._engine.wgrad_side, m._engine.branch_stream = side_was, branch_was
     fam = {}
     for kid, (cnt, flops, ms) in timer.collect().items():
         kid0 = kid % 20000

@@ -166,6 +166,29 @@ class Act(object):
                                     # writer of g clears them (stale)
 
 
+class _Tape(list):
+    """The backward tape.  A closure recorded while the engine runs the depth branch on its own stream (Engine._branch_enter) replays
+    on that stream too: the two encoder branches never read each other's gradients (the fusion's backward hands the depth branch its
+    share explicitly), so their backward chains overlap like their forward ones."""
+
+    def __init__(self, engine):
+        list.__init__(self)
+        self.engine = engine
+
+    def append(self, fn):
+        eng = self.engine
+        if eng._in_branch:
+            def on_branch(fn=fn):
+                ctx = eng._branch_enter(first_wait=False)
+                try:
+                    fn()
+                finally:
+                    eng._branch_exit(ctx)
+            list.append(self, on_branch)
+        else:
+            list.append(self, fn)
+
+
 class Engine(object):
     def __init__(self, encoder, decoder, min_predict_depth, max_predict_depth):
         self.encoder = encoder
@@ -182,11 +205,19 @@ class Engine(object):
         # weight gradients on a side stream (fork after dZ is written, join before the optimizer / a gradient bucket's exchange): a
         # weight gradient is off the backward's critical path, and the BatchNorm-backward passes it then overlaps are HBM-bound kernels
         # that leave board power unused while the convolution kernels run AT the power limit
-        self.wgrad_side = os.environ.get('RCF_WGRAD_SIDE_STREAM', '1') != '0'
+        single = os.environ.get('RCF_SINGLE_STREAM', '0') == '1'   # everything on the caller's stream (profiles: a kernel's time is its own)
+        self.wgrad_side = os.environ.get('RCF_WGRAD_SIDE_STREAM', '1') != '0' and not single
         self._side = None
         self._side_busy = False
         self._side_keep = []
         self.completes_bucket = None   # callable(parameter) -> bool (data parallelism): this gradient finishes a bucket
+        # the encoder's depth branch on its own stream (forward and backward): independent of the image branch up to each level's
+        # fusion (RCF_BRANCH_STREAM=0: on the main stream).  fp32 +2.3 %, bf16 +2.9 % on top of the weight-gradient stream
+        self.branch_stream = os.environ.get('RCF_BRANCH_STREAM', '1') != '0' and not single
+        self._branch = None
+        self._branch_busy = False
+        self._in_branch = False
+        self.in_backward = False   # set by the model around Engine.backward
         self.fuse_wp_one_pass = os.environ.get('RCF_FUSE_WP_ONE_PASS', '1') != '0'   # inference: the fusion in one kernel (bf16 tensors)
         self.prof = None           # optional KernelTimer: brackets conv launches with events on the launch stream
         self.use_phase_convs = True  # exact-2x UpConv and stride-2 dgrad as 2x2 phase convs (False: 9-tap / zero-insert forms)
@@ -412,17 +443,55 @@ class Engine(object):
             ctx.__exit__(None, None, None)
 
     def side_join(self):
-        '''The main stream waits for every weight gradient enqueued on the side stream; the tensors they read may go.'''
+        '''The main stream waits for every weight gradient enqueued on the side stream (and for the depth branch's stream); the tensors
+        they read may go.'''
+        if self._branch_busy:
+            torch.cuda.current_stream().wait_stream(self._branch)
+            self._branch_busy = False
         if self._side_busy:
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_busy = False
         del self._side_keep[:]
 
+    def _branch_enter(self, first_wait):
+        '''Run what follows on the depth branch's stream (None: switch off, or already there).  first_wait: the branch stream first waits
+        for the main stream (the step's inputs and weight plan; the fusion's hand-off in backward) -- not on every entry, which would
+        queue each depth block behind the image block enqueued just before it.'''
+        if not self.branch_stream or self._in_branch or (self.in_backward and self.on_param_grad is not None):
+            return None   # (under data parallelism the backward stays on the main stream: a bucket's exchange is launched from it)
+        if self._branch is None:
+            self._branch = torch.cuda.Stream()
+        if first_wait:
+            self._branch.wait_stream(torch.cuda.current_stream())
+        self._branch_busy = True
+        self._in_branch = True
+        ctx = torch.cuda.stream(self._branch)
+        ctx.__enter__()
+        return ctx
+
+    def _branch_exit(self, ctx):
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+            self._in_branch = False
+
+    def _branch_wait(self, dep=None):
+        '''The current (main) stream waits for the depth branch: its activation `dep` is about to be read (fusion).  The tensor was
+        allocated on the branch's stream: without a tape holding it (inference) it is freed as soon as the branch moves on, and the
+        allocator would hand its memory to the branch's next kernel while the fusion on the main stream still reads it --
+        record_stream defers that reuse behind the main stream's work.'''
+        if self._branch_busy and not self._in_branch:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self._branch)
+            if dep is not None:
+                for t in (dep.t, dep.z):
+                    if t is not None:
+                        t.record_stream(cur)
+
     def _wgrad_done(self, *params):
         if self.on_param_grad is not None:
             for p in params:
-                if self._side_busy and (self.completes_bucket is None or self.completes_bucket(p)):
-                    self.side_join()   # the bucket's exchange reads gradients the side stream may still be writing
+                if (self._side_busy or self._branch_busy) and not self._in_branch and (self.completes_bucket is None or self.completes_bucket(p)):
+                    self.side_join()   # the bucket's exchange reads gradients the side streams may still be writing
                 self.on_param_grad(p)
 
     def _conv(self, layer, x, x2=None, up_hw=None, want_stats=False, fold=None):
@@ -1110,8 +1179,13 @@ class Engine(object):
                     dimg = img.g
                 ops.fuse_bwd_apply(dout, zw, coef_w, zp, coef_p, bcw, bcp, dzw, dzp, dimg, dimg_acc, n_pix, c)
                 out.g = None
+                # the two 1x1 convolutions' backward writes the DEPTH branch's gradient: on that branch's stream when it has one
+                br = self._branch_enter(first_wait=True)
+                if br is not None:
+                    self._side_keep.extend((dzw, dzp, zw, zp))
                 self._conv_backward(layer_w, dw_, iw, dep, None, dzw)
                 self._conv_backward(layer_p, dp_, ip, dep, None, dzp)
+                self._branch_exit(br)
 
             self.tape.append(backward)
         return out
@@ -1216,20 +1290,28 @@ class Engine(object):
         '''
         enc, dec = self.encoder, self.decoder
         self.training = bool(training)
-        self.tape = [] if record else None
+        self.tape = _Tape(self) if record else None
         if hw is None:
             hw = tuple(image_nhwc.shape[1:3])
         self._begin_step_scales(image_nhwc if image_nhwc is not None else image_s2d)
         self._set_scope('encoder')
         img = self.conv_bn_act(enc.conv1_image, self._input(image_nhwc, image_s2d, hw))
+        br = self._branch_enter(first_wait=True)     # the depth branch: its own stream up to each level's fusion
         dep = self.conv_bn_act(enc.conv1_depth, self._input(depth_nhwc, depth_s2d, hw))
+        self._branch_exit(br)
+        self._branch_wait(dep)
         layers = [self.fuse(enc.conv1_weight, enc.conv1_project, dep, img)]
         img = self.max_pool(img)
+        br = self._branch_enter(first_wait=False)
         dep = self.max_pool(dep)
+        self._branch_exit(br)
         for lvl in range(2, enc.network_depth + 1):
             for blk_i, blk_d in zip(getattr(enc, 'blocks%d_image' % lvl), getattr(enc, 'blocks%d_depth' % lvl)):
                 img = self.resnet_block(blk_i, img)
+                br = self._branch_enter(first_wait=False)
                 dep = self.resnet_block(blk_d, dep)
+                self._branch_exit(br)
+            self._branch_wait(dep)
             layers.append(self.fuse(getattr(enc, 'conv%d_weight' % lvl), getattr(enc, 'conv%d_project' % lvl), dep, img))
         latent, skips = layers[-1], layers[:-1]
         out = self.head(dec.output0, self._decode(latent, skips, hw))

@@ -344,9 +344,11 @@ class FusionNetModel(object):
         ops.set_precision(ops.precision_of(self.compute_dtype))
         try:
             with torch.cuda.device(self._grad_arena.device):
+                self._engine.in_backward = True
                 Engine.backward(out, tape, ddepth)
                 self._engine.side_join()
         finally:
+            self._engine.in_backward = False
             ops.set_precision('fp32')
         self._engine.plan.end()
         if self._dp is not None:
