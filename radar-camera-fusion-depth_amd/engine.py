@@ -177,7 +177,7 @@ class _Tape(list):
 
     def append(self, fn):
         eng = self.engine
-        if eng._in_branch:
+        if eng._in_branch and not eng._tape_main:
             def on_branch(fn=fn):
                 ctx = eng._branch_enter(first_wait=False)
                 try:
@@ -218,6 +218,10 @@ class Engine(object):
         self._branch_busy = False
         self._in_branch = False
         self.in_backward = False   # set by the model around Engine.backward
+        self._tape_main = False    # closures recorded now replay on the main stream even while the forward is on the branch stream
+        # forward: each level's fusion (two 1x1 convolutions + the gate pass: HBM-bound, needed only by the decoder) on the branch
+        # stream too, beside the next level's blocks (RCF_FUSE_ON_BRANCH=0: on the main stream)
+        self.fuse_on_branch = os.environ.get('RCF_FUSE_ON_BRANCH', '1') != '0' and self.branch_stream
         self.fuse_wp_one_pass = os.environ.get('RCF_FUSE_WP_ONE_PASS', '1') != '0'   # inference: the fusion in one kernel (bf16 tensors)
         self.prof = None           # optional KernelTimer: brackets conv launches with events on the launch stream
         self.use_phase_convs = True  # exact-2x UpConv and stride-2 dgrad as 2x2 phase convs (False: 9-tap / zero-insert forms)
@@ -1299,8 +1303,7 @@ class Engine(object):
         br = self._branch_enter(first_wait=True)     # the depth branch: its own stream up to each level's fusion
         dep = self.conv_bn_act(enc.conv1_depth, self._input(depth_nhwc, depth_s2d, hw))
         self._branch_exit(br)
-        self._branch_wait(dep)
-        layers = [self.fuse(enc.conv1_weight, enc.conv1_project, dep, img)]
+        layers = [self._fuse_level(enc.conv1_weight, enc.conv1_project, dep, img)]
         img = self.max_pool(img)
         br = self._branch_enter(first_wait=False)
         dep = self.max_pool(dep)
@@ -1311,12 +1314,35 @@ class Engine(object):
                 br = self._branch_enter(first_wait=False)
                 dep = self.resnet_block(blk_d, dep)
                 self._branch_exit(br)
-            self._branch_wait(dep)
-            layers.append(self.fuse(getattr(enc, 'conv%d_weight' % lvl), getattr(enc, 'conv%d_project' % lvl), dep, img))
+            layers.append(self._fuse_level(getattr(enc, 'conv%d_weight' % lvl), getattr(enc, 'conv%d_project' % lvl), dep, img))
+        if self.fuse_on_branch and self.branch_stream and self._branch_busy:   # the decoder reads the fused tensors: the main stream joins the branch here
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self._branch)
+            for a in layers:
+                for t in (a.t, a.z):
+                    if t is not None:
+                        t.record_stream(cur)
         latent, skips = layers[-1], layers[:-1]
         out = self.head(dec.output0, self._decode(latent, skips, hw))
         tape, self.tape = self.tape, None
         return out, tape
+
+    def _fuse_level(self, layer_w, layer_p, dep, img):
+        '''One level's fusion.  Default: on the main stream once the depth branch has delivered `dep`.  fuse_on_branch: on the branch
+        stream once the main stream has delivered `img` -- the main stream goes straight on to the next level's image block; the
+        fusion's backward stays a main-stream closure (it adds into the image branch's gradient).'''
+        if not (self.fuse_on_branch and self.branch_stream):
+            self._branch_wait(dep)
+            return self.fuse(layer_w, layer_p, dep, img)
+        br = self._branch_enter(first_wait=True)
+        if br is not None and img.t is not None:
+            img.t.record_stream(self._branch)   # (inference: the image activation is freed by the main stream as soon as it moves on)
+        self._tape_main = True
+        try:
+            return self.fuse(layer_w, layer_p, dep, img)
+        finally:
+            self._tape_main = False
+            self._branch_exit(br)
 
     def _decode(self, latent, skips, shape):
         '''MultiScaleDecoder.forward, n_resolution == 1 (src/networks.py:1571-1657), up to the input of output0.'''
