@@ -118,6 +118,7 @@ with open(os.path.join(prof, tag + '_summary.md'), 'w') as f:
     f.write('`rocprofv3 --kernel-trace --stats -- python3 bench.py --graph 0 --steps %d --warmup %d --preheat-s 0 --no-cpu-baseline` on MI355X (gfx950):\n'
             % (line['steps'], line['warmup']))
     f.write('FusionNet fp32 training, batch 8, 900x1600; %d steps in the trace.\n' % nstep)
+    f.write('The traced and counted runs are SINGLE-STREAM (RCF_SINGLE_STREAM=1): a kernel\'s duration and counters are its own.  The default step runs the weight gradients and the encoder\'s depth branch on two side streams, so its wall clock is SHORTER than the sum of kernel times below.\n')
     f.write('Total kernel time %.1f ms = %.1f ms/step (bench wall clock without the profiler: see %s_bench_line.json).\n\n'
             % (tot / 1e3, tot / 1e3 / nstep, tag))
     rl = line.get('roofline', {})
