@@ -228,6 +228,39 @@ def test_config3_bf16_batch8_900x1600_step_is_the_benchmarked_step(env):
 
 
 # ------------------------------------------------------------------------------------------------------------ configs[4]
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_three_stream_step_is_bitwise_the_single_stream_step_at_900x1600(env, dtype):
+    '''The default schedule (weight gradients on a side stream, the encoder's depth branch and the fusions on another: DESIGN.md
+    section 5 "Three streams") against the same steps with everything on one stream, at the benchmarked shape (batch 4 to keep the
+    test short): output depth, loss and every parameter after each of 3 training steps -- equality, not a tolerance: the same kernels on
+    the same operands in the same summation orders; any cross-stream race (a tensor reused by the allocator while another stream still
+    reads it, a missing join) shows up as a difference at this size, where kernels run for hundreds of microseconds.'''
+    synth, train = env
+    cb = synth.make_batch(4, 900, 1600, 64, seed=2024)
+    b = {k: v.cuda() for k, v in cb.items()}
+    runs = []
+    for single in (True, False):
+        m = _build(env, 11, dtype)
+        eng = m._engine
+        if single:
+            eng.wgrad_side = eng.branch_stream = False
+        else:
+            assert eng.wgrad_side and eng.branch_stream and eng.fuse_on_branch, 'the three-stream schedule is the default'
+        opt = train.make_optimizer(m, lr=1e-3)
+        m.train()
+        trace = []
+        for _ in range(3):
+            loss, _, out = train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])
+            torch.cuda.synchronize()
+            trace.append((out.detach().clone(), float(loss), m._param_arena.detach().clone()))
+        runs.append(trace)
+        del m, opt
+    for step, ((o1, l1, p1), (o3, l3, p3)) in enumerate(zip(*runs)):
+        assert l1 == l3, (step, l1, l3)
+        assert torch.equal(o1, o3), step
+        assert torch.equal(p1, p3), step
+
+
 def test_config4_bf16_batch32_hipgraph_inference_900x1600(env):
     '''Batch 32 at 900x1600, eval-mode BatchNorm folded, bf16: the hipGraph replay is bitwise the eager forward, a second replay on
     new inputs too, and a sample of the batch matches the fp32 CPU oracle's eval-mode output within the bf16 bar.'''
