@@ -400,6 +400,18 @@ def run_rank(args):
         loss = step()
         if i == 0:
             first_loss = float(loss.detach())
+    if fast_eager and world == 1 and args.warmup > 0:
+        # the eager default only holds while the host enqueues a step faster than the GPU runs it: on a slow or loaded host fall back to
+        # the replayed graph (same step, ~1 ms of host time) and say so
+        torch.cuda.synchronize()
+        th = time.time()
+        loss = step()
+        host_probe = time.time() - th
+        torch.cuda.synchronize()
+        gpu_probe = time.time() - th
+        if host_probe > 0.8 * gpu_probe and hasattr(model, 'capture_training_step'):
+            fast_eager, use_graph = False, True
+            graph_note = 'host-bound eager step (%.1f of %.1f ms): replayed graph instead' % (1000 * host_probe, 1000 * gpu_probe)
     if use_graph:
         try:
             step = model.capture_training_step(opt, image, input_depth, gt, lidar, outlier_removal=outlier)
