@@ -546,6 +546,7 @@ def run_rank(args):
                    'step': 'forward + outlier removal + masked L1 + backward + Adam, train-mode BatchNorm',
                    'launch': (('one hipGraph replay per step (bitwise the eager step)' if world == 1 else 'hipGraph segments between the exchange points of the data-parallel step (bitwise the eager step)') if use_graph
                               else ('eager launches on three streams: the main chain, the weight gradients, the encoder\'s depth branch (bitwise the single-stream step; --graph 1 replays a hipGraph, whose branches the runtime serialises)' if fast_eager else (graph_note or 'eager launches'))),
+                   'launch_note': graph_note if use_graph else None,
                    'host_enqueue_ms_per_step': None if host_s is None else round(1000.0 * host_s, 3),
                    'arithmetic': ('fp32 tensors' if dtype != 'bf16' else 'bf16 tensors') + ', fp32 accumulate, fp64 BatchNorm sums; convolution launches of the '
                                  'measured step by the arithmetic they ran on (from their kernel ids): ' + arith_line,
