@@ -60,6 +60,7 @@ class WeightPlan(object):
         self.wamax = None           # arena of the weight maxima (device scalars) of the recorded step
         self._wamax_used = 0
         self.wamax_chunks = []
+        self.fence = None           # callable set by the engine: orders a fresh zero-filled chunk before all of its streams
 
     def enable(self):
         if self.state == 'off':
@@ -100,6 +101,8 @@ class WeightPlan(object):
             self.wamax = torch.zeros(1024, dtype=torch.float32, device=like.device)
             self.wamax_chunks.append(self.wamax)
             self._wamax_used = 0
+            if self.fence is not None:
+                self.fence()        # (Engine._fence_streams: the zero fill is ordered before every stream's use of a slot)
         self._wamax_used += 1
         return self.wamax[self._wamax_used - 1:self._wamax_used]
 
@@ -210,6 +213,7 @@ class Engine(object):
         self._side = None
         self._side_busy = False
         self._side_keep = []
+        self._open_switches = []       # stream switches entered and not yet left (recover() undoes them after an exception)
         self.completes_bucket = None   # callable(parameter) -> bool (data parallelism): this gradient finishes a bucket
         # the encoder's depth branch on its own stream (forward and backward): independent of the image branch up to each level's
         # fusion (RCF_BRANCH_STREAM=0: on the main stream).  fp32 +2.3 %, bf16 +2.9 % on top of the weight-gradient stream
@@ -252,6 +256,9 @@ class Engine(object):
         # two-plane fp16 arithmetic (RCF_PREC_F16X2): per-step arena of activation / gradient maxima, per-step cache of weight maxima
         self._amax_arena = None
         self._amax_used = 0
+        self._amax_total = 0           # slots handed out in this step / the most any step needed (the next arena's size)
+        self._amax_need = 0
+        self._main = None              # the caller's stream, noted at the outermost stream switch
         self._wamax_cache = {}
         self._scope = None
         # inference with frozen weights (FusionNetModel.capture_inference(fold_once=True)): a dict that keeps every weight transform of
@@ -284,7 +291,20 @@ class Engine(object):
     def _begin_step_scales(self, ref):
         self._wamax_cache = {}
         self._amax_used = 0
-        self._amax_arena = torch.zeros(512, dtype=torch.float32, device=ref.device) if self._f16() else None
+        # sized from what the previous step of this engine used, so that a deep net (fusionnet34) overflows in its first step only
+        self._amax_need = max(self._amax_need, self._amax_total)
+        self._amax_total = 0
+        self._amax_arena = torch.zeros(max(512, self._amax_need), dtype=torch.float32, device=ref.device) if self._f16() else None
+        self.plan.fence = self._fence_streams
+
+    def _fence_streams(self):
+        """A buffer was just zero-filled on the CURRENT stream and its slots are about to be handed to kernels on any of the engine's
+        streams (atomicMax into a zeroed scalar): the other streams wait for the fill, or it could land after their maxima."""
+        cur = torch.cuda.current_stream()
+        ev = cur.record_event()
+        for s in (self._main, self._branch, self._side):
+            if s is not None and s != cur:
+                s.wait_event(ev)
 
     def _amax_slot(self):
         '''A zeroed device scalar for the maximum of a tensor this step produces (None outside the fp16 arithmetic).'''
@@ -295,7 +315,9 @@ class Engine(object):
             # that hold views of it)
             self._amax_arena = torch.zeros(512, dtype=torch.float32, device=self._amax_arena.device)
             self._amax_used = 0
+            self._fence_streams()
         self._amax_used += 1
+        self._amax_total += 1
         return self._amax_arena[self._amax_used - 1:self._amax_used]
 
     def _w_amax(self, w):
@@ -437,14 +459,41 @@ class Engine(object):
         self._side.wait_stream(torch.cuda.current_stream())
         self._side_keep.extend(t for t in keep if t is not None)
         self._side_busy = True
-        ctx = torch.cuda.stream(self._side)
+        return self._switch(self._side)
+
+    def _switch(self, stream):
+        """Make `stream` current until _unswitch(ctx).  Open switches are kept on a stack so that recover() can undo them when an
+        exception (RcfError, out of memory) leaves a switched region half-way."""
+        if not self._open_switches:
+            self._main = torch.cuda.current_stream()
+        ctx = torch.cuda.stream(stream)
         ctx.__enter__()
+        self._open_switches.append(ctx)
         return ctx
 
-    @staticmethod
-    def _side_exit(ctx):
+    def _unswitch(self, ctx):
+        ctx.__exit__(None, None, None)
+        if ctx in self._open_switches:
+            self._open_switches.remove(ctx)
+
+    def _side_exit(self, ctx):
         if ctx is not None:
-            ctx.__exit__(None, None, None)
+            self._unswitch(ctx)
+
+    def recover(self):
+        """After an exception inside forward / backward: back to the caller's stream, the side streams joined, no flag left set --
+        a caller that catches and carries on (bench.py falling back from a failed capture to the eager step) runs on a sane engine."""
+        while self._open_switches:
+            self._open_switches.pop().__exit__(None, None, None)
+        self._in_branch = False
+        self._tape_main = False
+        self.in_backward = False
+        self.tape = None
+        try:
+            self.side_join()
+        except RuntimeError:      # (a failed capture: the streams cannot be waited on; their work is gone with the capture)
+            self._branch_busy = self._side_busy = False
+            del self._side_keep[:]
 
     def side_join(self):
         '''The main stream waits for every weight gradient enqueued on the side stream (and for the depth branch's stream); the tensors
@@ -461,8 +510,11 @@ class Engine(object):
         '''Run what follows on the depth branch's stream (None: switch off, or already there).  first_wait: the branch stream first waits
         for the main stream (the step's inputs and weight plan; the fusion's hand-off in backward) -- not on every entry, which would
         queue each depth block behind the image block enqueued just before it.'''
-        if not self.branch_stream or self._in_branch or (self.in_backward and self.on_param_grad is not None):
-            return None   # (under data parallelism the backward stays on the main stream: a bucket's exchange is launched from it)
+        if not self.branch_stream or self.bn_on_load or self._in_branch or (self.in_backward and self.on_param_grad is not None):
+            # (under data parallelism the backward stays on the main stream: a bucket's exchange is launched from it.  bn_on_load: a
+            # deferred activation is materialised by whichever consumer comes first -- the fusion on the branch stream, then max_pool
+            # on the main stream reads it with no event between them -- so that mode runs on one stream, like _side_enter)
+            return None
         if self.tape is None and not self.in_backward:
             # forward only (inference, validation): no tape keeps the activations alive, so every tensor that crosses streams needs
             # record_stream and the allocator's deferred frees -- measured 10 % SLOWER than one stream for eager bf16 inference
@@ -474,13 +526,11 @@ class Engine(object):
             self._branch.wait_stream(torch.cuda.current_stream())
         self._branch_busy = True
         self._in_branch = True
-        ctx = torch.cuda.stream(self._branch)
-        ctx.__enter__()
-        return ctx
+        return self._switch(self._branch)
 
     def _branch_exit(self, ctx):
         if ctx is not None:
-            ctx.__exit__(None, None, None)
+            self._unswitch(ctx)
             self._in_branch = False
 
     def _branch_wait(self, dep=None):
@@ -1336,7 +1386,7 @@ class Engine(object):
         '''One level's fusion.  Default: on the main stream once the depth branch has delivered `dep`.  fuse_on_branch: on the branch
         stream once the main stream has delivered `img` -- the main stream goes straight on to the next level's image block; the
         fusion's backward stays a main-stream closure (it adds into the image branch's gradient).'''
-        if not (self.fuse_on_branch and self.branch_stream):
+        if not (self.fuse_on_branch and self.branch_stream) or self.bn_on_load:
             self._branch_wait(dep)
             return self.fuse(layer_w, layer_p, dep, img)
         br = self._branch_enter(first_wait=True)

@@ -293,6 +293,9 @@ class FusionNetModel(object):
             # call, whatever device the calling thread had selected
             with torch.cuda.device(self._param_arena.device):
                 return self._run_engine_impl(image, input_depth, record)
+        except BaseException:
+            self._engine.recover()      # back on the caller's stream, side streams joined, no engine flag left set
+            raise
         finally:
             ops.set_precision('fp32')
 
@@ -347,6 +350,9 @@ class FusionNetModel(object):
                 self._engine.in_backward = True
                 Engine.backward(out, tape, ddepth)
                 self._engine.side_join()
+        except BaseException:
+            self._engine.recover()
+            raise
         finally:
             self._engine.in_backward = False
             ops.set_precision('fp32')

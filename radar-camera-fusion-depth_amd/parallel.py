@@ -112,24 +112,20 @@ class SegmentedCapture(object):
     '''
 
     def __init__(self):
-        from . import ops
-        self._ops = ops
         self.pool = torch.cuda.graph_pool_handle()
         self.segments = []      # [graph, [exchange ops launched after it]]
         self.graph = None
-        self._mark = 0
 
     def begin(self):
         self.graph = torch.cuda.CUDAGraph()
         # 'relaxed': the cuts inside backward() happen on autograd's worker thread, the first begin and the last end on the caller's --
         # the other capture modes tie a capture sequence to the thread that began it
         self.graph.capture_begin(pool=self.pool, capture_error_mode='relaxed')
-        self._mark = self._ops.LAUNCHES[0]
 
     def cut(self, op):
-        if self._ops.LAUNCHES[0] == self._mark and self.segments:
-            self.segments[-1][1].append(op)   # nothing was launched since the last cut: no empty graph, the exchange joins the previous one
-            return
+        # A cut ALWAYS ends the segment.  (Round 4 skipped the cut when no C-ABI launch had been counted since the last one; torch's own
+        # launches -- zero_(), clone(), the loss arithmetic -- are invisible to that counter and would have slipped behind the exchange.
+        # An empty segment costs one graph launch of nothing.)
         self.graph.capture_end()
         self.segments.append([self.graph, [op]])
         self.begin()

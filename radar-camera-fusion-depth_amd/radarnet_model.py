@@ -187,6 +187,9 @@ class RadarNetModel(object):
         try:
             with torch.cuda.device(self._param_arena.device):   # kernels go to the current stream of the current device
                 return self._run_engine_impl(image, point, rois, record)
+        except BaseException:
+            self._engine.recover()
+            raise
         finally:
             ops.set_precision('fp32')
 

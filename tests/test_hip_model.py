@@ -678,7 +678,9 @@ def test_data_parallel_step_matches_the_reference_fixture(env, golden_dir, tmp_p
 
 def test_t1_with_bn_on_load_in_the_conv_kernels(env, golden_dir):
     '''Engine.bn_on_load (the consuming split conv / wgrad kernels apply BatchNorm + lrelu while they load the raw conv output;
-    off by default because it is slower) gives the same published-net training step: output, loss and gradient norms of T1.'''
+    off by default because it is slower) gives the same published-net training step: output, loss and gradient norms of T1.
+    A deferred activation is materialised by whichever consumer reads it first, so this mode must stay on ONE stream (the
+    fusion on the branch stream materialised the stem's activation that max_pool on the main stream then read unordered).'''
     synth, _ = env
     g = np.load(os.path.join(golden_dir, 'T1_published_train.npz'))
     n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
@@ -690,6 +692,8 @@ def test_t1_with_bn_on_load_in_the_conv_kernels(env, golden_dir):
     loss, info = _loss(m, b, out)
     loss.backward()
     torch.cuda.synchronize()
+    eng = m._engine
+    assert eng._branch is None and eng._side is None, 'bn_on_load ran on a side stream'
     assert _rel(out, g['output']) < BAR
     np.testing.assert_allclose([float(loss.detach()), float(info['loss_supervised']), float(info['loss_lidar'])], g['loss'], rtol=BAR)
     grads = dict(_named(m, 'p'))
