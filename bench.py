@@ -120,9 +120,14 @@ def parse():
                                                           'launches with the weight gradients on a side stream -- measured faster than '
                                                           'the replayed graph, which serialises the two branches (bitwise the same step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--side-leg', action='store_true', help='also time the same step on the three-plane bf16 split (f32_3plane), reported '
-                                                            'beside the metric in its own object')
-    ap.add_argument('--no-side-leg', action='store_true', help='(accepted for older command lines; the side leg is opt-in now)')
+    ap.add_argument('--side-leg', action='store_true', help='(accepted for older command lines: the legs below are the default now)')
+    ap.add_argument('--no-side-leg', action='store_true', help='skip `exact_tier`: the same step on the three-plane bf16 split (f32_3plane), '
+                                                               '20 timed steps after the metric\'s timed region')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip `other_configs`: short legs (10 timed steps / replays each, after the metric\'s timed region, N = 1 only) of '
+                         'BASELINE.json configs[3] per GPU (bf16 training), configs[4] (bf16 inference, batch 32, hipGraph) and configs[2] '
+                         '(RadarNet bf16 training), each checked against the CPU oracle\'s recorded values')
+    ap.add_argument('--leg-steps', type=int, default=10, help='timed steps of each `other_configs` leg (exact_tier: twice that)')
     ap.add_argument('--cpu-baseline-batch8', action='store_true', help='cpu_baseline: add a batch-8 leg (1 warm-up + 2 timed steps, ~3 min)')
     ap.add_argument('--kernel-table', type=str, default='', help='write the per-kernel event table (JSON) here')
     return ap.parse_args()
@@ -400,18 +405,37 @@ def run_rank(args):
         loss = step()
         if i == 0:
             first_loss = float(loss.detach())
-    if fast_eager and world == 1 and args.warmup > 0:
-        # the eager default only holds while the host enqueues a step faster than the GPU runs it: on a slow or loaded host fall back to
-        # the replayed graph (same step, ~1 ms of host time) and say so
+    probe = None
+    if fast_eager and args.warmup > 0:
+        # the eager default only holds while the host enqueues a step faster than the GPU runs it: on a slow or loaded host (or eight
+        # ranks' Python threads on one host) fall back to the replayed graph / graph segments (same step, ~1 ms of host time) and say
+        # so.  N ranks decide TOGETHER (one all-reduce): a step is a sequence of collectives, every rank must launch it the same way
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         th = time.time()
         loss = step()
         host_probe = time.time() - th
         torch.cuda.synchronize()
         gpu_probe = time.time() - th
-        if host_probe > 0.8 * gpu_probe and hasattr(model, 'capture_training_step'):
+        host_bound = host_probe > 0.8 * gpu_probe
+        can_capture = hasattr(model, 'capture_training_step') and (world == 1 or dist.get_backend() == 'nccl')
+        probe = {'host_ms': round(1000 * host_probe, 2), 'step_ms': round(1000 * gpu_probe, 2), 'host_bound': bool(host_bound)}
+        if world > 1:
+            t = torch.tensor([host_probe, gpu_probe, float(host_bound)], dtype=torch.float64, device=dev)
+            gathered = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(gathered, t)
+            host_bound = any(float(g[2]) > 0 for g in gathered)
+            probe = {'host_ms_by_rank': [round(1000 * float(g[0]), 2) for g in gathered],
+                     'step_ms_by_rank': [round(1000 * float(g[1]), 2) for g in gathered],
+                     'host_bound_by_rank': [bool(float(g[2]) > 0) for g in gathered], 'host_bound': bool(host_bound)}
+        if host_bound and can_capture:
             fast_eager, use_graph = False, True
-            graph_note = 'host-bound eager step (%.1f of %.1f ms): replayed graph instead' % (1000 * host_probe, 1000 * gpu_probe)
+            graph_note = 'host-bound eager step (%.1f of %.1f ms on rank %d%s): %s instead' % (
+                1000 * host_probe, 1000 * gpu_probe, rank, '' if world == 1 else '; decided over all ranks',
+                'replayed graph' if world == 1 else 'graph segments between the exchange points')
+        probe['decision'] = ('graph' if world == 1 else 'graph segments') if use_graph else (
+            'eager (host-bound, but %s cannot be captured into segments: host-blocking collectives)' % dist.get_backend() if host_bound else 'eager')
     if use_graph:
         try:
             step = model.capture_training_step(opt, image, input_depth, gt, lidar, outlier_removal=outlier)
@@ -483,6 +507,12 @@ def run_rank(args):
         dt = max(float(g.item()) for g in gathered)
         dp_info = measure_overlap(model, eager_step, dev, 1000.0 * dt / args.steps)
         dp_info['host_ms_per_step'] = None if host_s is None else round(1000.0 * host_s, 3)
+        if host_s is not None:
+            th_ = torch.tensor([host_s], dtype=torch.float64, device=dev)
+            gh = [torch.zeros_like(th_) for _ in range(world)]
+            dist.all_gather(gh, th_)
+            dp_info['host_ms_per_step_by_rank'] = [round(1000.0 * float(g.item()), 3) for g in gh]
+        dp_info['launch_probe'] = probe
         dp_info['launch'] = ('%d hipGraph segments + the RCCL calls between them per step' % len(step.segments)) if (use_graph and getattr(step, 'segments', None)) else ('eager launches, weight gradients and the depth branch on side streams' if fast_eager else 'eager launches')
 
     table = timer.collect()
@@ -510,13 +540,24 @@ def run_rank(args):
     arith_table, arith_line = arithmetic_of_step(table, ev_steps)
 
     side = None
-    if args.side_leg and dtype == 'f32' and world == 1:   # opt-in: the same step on the three-plane bf16 split, beside the metric
+    others = None
+    is_default_run = dtype == 'f32' and world == 1 and (args.height, args.width, args.points, batch) == (900, 1600, 64, 8)
+    if is_default_run and not (args.no_side_leg and args.no_other_configs):
+        # everything the driver's one command should witness, AFTER the metric's timed region: the headline's model goes first (its
+        # activations and the three streams' allocator pools are ~32 GB)
         del step
-        try:
-            side = side_leg(args, dev, world, rank, batch, 'f32_3plane')
-        except Exception as e:
-            side = {'error': str(e)[:200]}
-
+        model._engine.prof = None
+        opt = model = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        if not args.no_side_leg:
+            try:    # the exact tier: the same step, same seeds, split kernels on three bf16 planes (six exact products per multiply)
+                side = train_leg(args, dev, batch, 'f32_3plane', 2 * args.leg_steps)
+            except Exception as e:
+                side = {'error': str(e)[:200]}
+        if not args.no_other_configs:
+            others = other_configs(args, dev)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -546,7 +587,7 @@ def run_rank(args):
                    'step': 'forward + outlier removal + masked L1 + backward + Adam, train-mode BatchNorm',
                    'launch': (('one hipGraph replay per step (bitwise the eager step)' if world == 1 else 'hipGraph segments between the exchange points of the data-parallel step (bitwise the eager step)') if use_graph
                               else ('eager launches on three streams: the main chain, the weight gradients, the encoder\'s depth branch (bitwise the single-stream step; --graph 1 replays a hipGraph, whose branches the runtime serialises)' if fast_eager else (graph_note or 'eager launches'))),
-                   'launch_note': graph_note if use_graph else None,
+                   'launch_note': graph_note if use_graph else None, 'launch_probe': probe,
                    'host_enqueue_ms_per_step': None if host_s is None else round(1000.0 * host_s, 3),
                    'arithmetic': ('fp32 tensors' if dtype != 'bf16' else 'bf16 tensors') + ', fp32 accumulate, fp64 BatchNorm sums; convolution launches of the '
                                  'measured step by the arithmetic they ran on (from their kernel ids): ' + arith_line,
@@ -561,7 +602,9 @@ def run_rank(args):
     if dp_info is not None:
         rec['dp'] = dp_info
     if side is not None:
-        rec['f32_3plane'] = side
+        rec['exact_tier'] = side
+    if others is not None:
+        rec['other_configs'] = others
     # the step that is being timed must be the right step: its first loss against the CPU oracle's value for these seeds
     loss_ok = True
     small = (args.height, args.width, args.points, batch) == (224, 384, 32, 2)   # the shape the 2-rank tests run
@@ -647,61 +690,122 @@ def run_rank(args):
     return 0
 
 
-def side_leg(args, dev, world, rank, batch, dtype):
-    '''The same training step, same seeds, under the other fp32-accurate arithmetic of the split convolution kernels (f32_3plane: three
-    bf16 planes, six products per multiply -- the previous rounds' exact tier), reported BESIDE the metric, never as `value`.  Its own
-    model, warm-up, pre-heat and barrier-bracketed timed region (half the steps).'''
+def _leg_args(args, steps, preheat_s=1.0, warmup=2):
+    import copy
+    a = copy.copy(args)
+    a.steps, a.preheat_s, a.warmup, a.batch, a.dtype = steps, min(args.preheat_s, preheat_s), warmup, 0, None
+    return a
+
+
+def family_roofline(timer, tier, ev_steps, step_ms):
+    '''The dominant convolution family of a leg from its KernelTimer events (single-stream eager steps): compact form of the
+    headline's `roofline` object -- achieved = executed FLOP/s of the family (algorithmic x partial products), priced on its pipe.'''
+    fam = {}
+    for kid, (cnt, flops, ms) in timer.collect().items():
+        kid0 = kid % 20000
+        f = (10 + (kid0 - 10000) // 1000) if kid0 >= 10000 else kid0 // 1000
+        r = fam.setdefault(f, [0, 0.0, 0.0])
+        r[0] += cnt; r[1] += flops; r[2] += ms
+    if not fam:
+        return None
+    dom = max(fam, key=lambda f: fam[f][2])
+    cnt, flops, ms = fam[dom]
+    is_split = dom in (5, 6, 8, 9, 15, 19)
+    algorithmic = flops / (ms * 1e-3) / 1e12
+    achieved = algorithmic * (SPLIT_PRODUCTS[tier] if is_split else 1)
+    peak = BF16_MFMA_PEAK_TFLOPS if is_split else F32_MFMA_PEAK_TFLOPS
+    kname = KERNEL_NAMES.get(dom, str(dom))
+    if is_split and tier == 'bf16':
+        kname = kname.replace('conv_split_kernel', 'conv_b16_kernel')
+    return {'bound': 'mfma', 'kernel': kname + (' (%s)' % TIER_TEXT[tier] if is_split else ''), 'achieved': round(achieved, 2), 'peak': peak,
+            'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'algorithmic_fp32_tflops': round(algorithmic, 2),
+            'products_per_multiply': SPLIT_PRODUCTS[tier] if is_split else 1, 'launches_per_step': cnt // ev_steps,
+            'avg_launch_ms': round(ms / cnt, 4), 'share_of_step_time': round(ms / ev_steps / step_ms, 4),
+            'events_from': '%d single-stream eager steps after the leg\'s timed steps' % ev_steps}
+
+
+def train_leg(args, dev, batch, dtype, steps):
+    '''The FusionNet training step of the metric, same weights and data seeds, under another arithmetic tier -- 'f32_3plane' (three bf16
+    planes, six exact products per multiply: the exact fp32 tier) or 'bf16' (BASELINE.json configs[3], one GPU's share) -- reported
+    BESIDE the metric, never as `value`.  Its own model, 3 warm-up steps, <= 1 s pre-heat, `steps` timed steps between synchronisations,
+    launched like the headline (eager, three streams); the first step's loss is checked against the CPU oracle's recorded value.'''
     import torch
-    import torch.distributed as dist
-    from rcf_amd import synth, train
+    from rcf_amd import ops, synth, train
     from rcf_amd.net_utils import OutlierRemoval
     model = train.build_model(synth.PUBLISHED, device=dev)
     synth.fill_state_dict_([model.encoder, model.decoder], 1234)
-    model.compute_dtype = {'f32_3plane': 'fp32_3plane'}[dtype]
-    if world > 1:
-        model.data_parallel()
+    model.compute_dtype = {'f32_3plane': 'fp32_3plane', 'bf16': 'bf16'}[dtype]
     opt = train.make_optimizer(model, lr=1e-3)
     model.train()
-    b = synth.make_batch(batch, args.height, args.width, args.points, seed=1234 + rank)
+    b = synth.make_batch(batch, args.height, args.width, args.points, seed=1234)
     image, input_depth, gt, lidar = (b[k].to(dev) for k in ('image', 'input_depth', 'ground_truth', 'lidar_map'))
     outlier = OutlierRemoval(kernel_size=7, threshold=1.5)
     step = lambda: train.train_step(model, opt, image, input_depth, gt, lidar, outlier_removal=outlier)[0]
     first_loss = float(step().detach())
     for _ in range(2):
         step()
-    graph = False
-    if args.graph != 0 and world == 1:
-        try:
-            step = model.capture_training_step(opt, image, input_depth, gt, lidar, outlier_removal=outlier)
-            graph = True
-        except Exception:
-            pass
     torch.cuda.synchronize()
     t_pre = time.time()
-    while time.time() - t_pre < min(args.preheat_s, 2.0):
+    while time.time() - t_pre < min(args.preheat_s, 1.0):
         step()
         torch.cuda.synchronize()
-    steps = max(1, args.steps // 2)
-    if world > 1:
-        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
     dt = time.time() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    want = _expected_first_loss('train_b8_900x1600_p64') if (args.height, args.width, args.points, batch) == (900, 1600, 64, 8) else None
-    return {'value': round(world * batch * steps / dt, 4), 'unit': 'samples/s', 'ms_per_step': round(1000.0 * dt / steps, 3), 'steps': steps,
-            'dtype': dtype, 'arithmetic': 'fp32 tensors; split conv kernels on three bf16 planes, six products per multiply, fp32 accumulate',
-            'launch': 'hipGraph replay' if graph else 'eager',
-            'first_step_loss': round(first_loss, 5),
-            'first_step_loss_rel_err_vs_oracle': None if want is None else float('%.3e' % (abs(first_loss - want) / abs(want)))}
+    timer = ops.KernelTimer()
+    eng = model._engine
+    side_was, branch_was = eng.wgrad_side, eng.branch_stream
+    eng.wgrad_side = eng.branch_stream = False
+    eng.prof = timer
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    eng.prof = None
+    eng.wgrad_side, eng.branch_stream = side_was, branch_was
+    want = _expected_first_loss('train_b8_900x1600_p64')
+    tol = 3e-2 if dtype == 'bf16' else 1e-3
+    relerr = None if want is None else abs(first_loss - want) / abs(want)
+    rec = {'value': round(batch * steps / dt, 4), 'unit': 'samples/s', 'ms_per_step': round(1000.0 * dt / steps, 3), 'steps': steps,
+           'dtype': dtype, 'workload': 'FusionNet %s training, batch %d, %dx%d (BASELINE.json %s)' % (
+               {'f32_3plane': 'fp32 (split conv kernels on three bf16 planes, six exact products per multiply)', 'bf16': 'bf16'}[dtype],
+               batch, args.height, args.width, 'configs[1], exact tier' if dtype == 'f32_3plane' else 'configs[3], one GPU\'s share'),
+           'launch': 'eager launches on three streams',
+           'algorithmic_tflops': round(TRAIN_GFLOP_PER_SAMPLE * batch * steps / dt / 1e3, 2),
+           'roofline': family_roofline(timer, dtype, 2, 1000.0 * dt / steps),
+           'check': {'first_step_loss': round(first_loss, 5), 'oracle_first_step_loss': None if want is None else round(want, 5),
+                     'rel_err': None if relerr is None else float('%.3e' % relerr), 'tol': tol, 'ok': None if relerr is None else bool(relerr < tol)}}
+    del step, model, opt
+    return rec
+
+
+def other_configs(args, dev):
+    '''Short legs of the other BASELINE.json configurations on this one GPU, each with its own model, warm-up, <= 1 s pre-heat and
+    `--leg-steps` timed steps / replays, each checked against values the CPU oracle recorded (tests/golden/bench_expected.json).'''
+    import gc
+    import torch
+    out = {}
+    legs = (('configs[3] FusionNet bf16 training, per-GPU batch 8', lambda: train_leg(args, dev, 8, 'bf16', args.leg_steps)),
+            ('configs[4] FusionNet bf16 inference, batch 32, hipGraph', lambda: _compact(run_infer(_leg_args(args, args.leg_steps), dev, emit=False))),
+            ('configs[2] RadarNet bf16 training, 16 images x 4 points', lambda: _compact(run_radarnet(_leg_args(args, args.leg_steps), dev, emit=False))))
+    for name, fn in legs:
+        try:
+            out[name] = fn()
+        except Exception as e:
+            out[name] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
+def _compact(rec):
+    r = rec.get('roofline') or {}
+    return {'value': rec['value'], 'unit': rec['unit'], 'ms_per_step': rec['ms_per_step'], 'steps': rec['steps'], 'dtype': rec['dtype'],
+            'workload': rec['config']['workload'], 'algorithmic_tflops': rec.get('algorithmic_tflops'),
+            'roofline': {k: r.get(k) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac') if k in r},
+            'check': rec['config'].get('check')}
 
 
 def measure_overlap(model, step, dev, dp_ms):
@@ -762,7 +866,7 @@ def _time_steps(fn, args, torch):
     return time.time() - t0, out, n_pre
 
 
-def run_infer(args, dev):
+def run_infer(args, dev, emit=True):
     '''BASELINE.json configs[4]: FusionNet inference, batch 32, 900x1600, eval-mode BatchNorm folded into the convolutions, one
     hipGraph replay per batch (FusionNetModel.capture_inference; the reference loop is src/fusionnet_main.py:794-816).'''
     import torch
@@ -800,11 +904,38 @@ def run_infer(args, dev):
                        'mfma_busy_pmc_3x3_kernels': None if conv_busy is None else round(conv_busy, 4), 'scope': 'whole forward: algorithmic conv input + output bytes per sample (%.2f GB) x samples / time; '
                                                  'the bf16 layers sit near the MFMA/HBM ridge (SURVEY.md 8d)' % gbytes,
                        'mfma_frac_of_bf16_peak': round(rec['algorithmic_tflops'] / BF16_MFMA_PEAK_TFLOPS, 4)}
-    print(json.dumps(rec), flush=True)
-    return 0
+    rec['config']['check'] = _infer_check(out, batch, args)
+    if emit:
+        print(json.dumps(rec), flush=True)
+        return 0 if rec['config']['check'].get('ok', True) else 3
+    return rec
 
 
-def run_radarnet(args, dev):
+def _infer_check(out, batch, args):
+    '''Rows 0 and 31 of the batch against the CPU oracle's eval-mode output of those samples alone (tests/golden/bench_expected.json,
+    'infer_b32_900x1600_p64': mean depth and 64 seeded pixels each).  fp32: 1e-3 of the largest depth; bf16: 1.1e-2 (the bar of
+    tests/test_configs_gpu.py).'''
+    if (batch, args.height, args.width, args.points) != (32, 900, 1600, 64):
+        return {'ok': None, 'why': 'recorded for batch 32, 900x1600, 64 points'}
+    try:
+        exp = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_expected.json')))['infer_b32_900x1600_p64']
+    except Exception:
+        return {'ok': None, 'why': 'no recorded oracle values'}
+    import torch
+    idx = torch.tensor(exp['pixel_index'], device=out.device)
+    worst, means = 0.0, {}
+    for s_, r in exp['samples'].items():
+        flat = out[int(s_)].reshape(-1).float()
+        got = flat[idx].cpu()
+        want = torch.tensor(r['pixels'])
+        worst = max(worst, float((got - want).abs().max() / want.abs().max()))
+        means[s_] = [round(float(flat.double().mean()), 4), round(r['mean_depth'], 4)]
+    tol = 1.1e-2 if (args.dtype or 'bf16') == 'bf16' else 1e-3
+    return {'ok': bool(worst < tol), 'max_rel_err_of_128_pixels': float('%.3e' % worst), 'tol': tol, 'mean_depth_got_vs_oracle': means,
+            'expected': 'CPU oracle, eval mode, samples 0 and 31 of the batch'}
+
+
+def run_radarnet(args, dev, emit=True):
     '''BASELINE.json configs[2]: RadarNet stage-1 training (src/radarnet_main.py:320-403), 16 images x 4 radar points = 64 crops of
     900x288 from 900x1888 edge-padded images; one step = forward + masked BCE + backward + Adam.'''
     import torch
@@ -827,6 +958,7 @@ def run_radarnet(args, dev):
         loss.backward()
         opt.step()
         return loss
+    first_loss = float(step().detach())
     dt, loss, n_pre = _time_steps(step, args, torch)
     n_samples = n_img * args.steps
     # the dominant conv family of this step, from HIP events around its launches on three more (untimed) steps
@@ -881,8 +1013,20 @@ def run_radarnet(args, dev):
            'peak_memory_gb': round(torch.cuda.max_memory_allocated() / 1e9, 2)}
     if roofline is not None:
         rec['roofline'] = roofline
-    print(json.dumps(rec), flush=True)
-    return 0
+    check = {'ok': None, 'first_step_loss': round(first_loss, 6)}
+    if (n_img, k, args.height, args.width) == (16, 4, 900, 1600):
+        try:
+            want = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_expected.json')))['radarnet_b16x4_900x1888']['first_step_loss']
+            tol = 1e-3      # north_star's fp32 bar; the bf16 loss -- a mean over 1.6e7 pixels -- measures <= 2e-5 (tests/test_configs_gpu.py)
+            relerr = abs(first_loss - want) / abs(want)
+            check.update({'oracle_first_step_loss': round(want, 6), 'rel_err': float('%.3e' % relerr), 'tol': tol, 'ok': bool(relerr < tol)})
+        except Exception:
+            check['why'] = 'no recorded oracle value'
+    rec['config']['check'] = check
+    if emit:
+        print(json.dumps(rec), flush=True)
+        return 0 if check.get('ok') is not False else 3
+    return rec
 
 
 def main():

@@ -260,19 +260,23 @@ def _dp_worker(rank, world, port, tmpdir):
 
 
 @pytest.mark.timeout(300)   # a rank that never joins must not hold the suite
-def test_gradient_buckets_all_reduce_two_ranks_gloo(pkg, tmp_path):
+@pytest.mark.parametrize('world', [2, 8])
+def test_gradient_buckets_all_reduce_gloo(pkg, tmp_path, world):
+    '''The exchange logic of the data-parallel step at 2 ranks and at the 8 ranks of BASELINE.json configs[3] (one process per rank over
+    gloo here): SUM over ranks of every bucket with no 1/world factor, unused parameters never exchanged, the four loss sums / valid
+    counts global, buckets launched before the backward ends.'''
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0 = torch.load(os.path.join(str(tmp_path), 'r0.pt'))
-    r1 = torch.load(os.path.join(str(tmp_path), 'r1.pt'))
-    n = r0['n_used']
-    want = r0['local'] + r1['local']
-    for r in (r0, r1):
-        assert torch.allclose(r['reduced'][:n], want[:n])                     # SUM over ranks, no 1/world factor
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(str(tmp_path), 'r%d.pt' % k)) for k in range(world)]
+    n = rs[0]['n_used']
+    want = sum(r['local'].double() for r in rs).float()
+    for r in rs:
+        assert torch.allclose(r['reduced'][:n], want[:n], rtol=1e-6, atol=1e-6)    # SUM over ranks, no 1/world factor
         assert torch.equal(r['reduced'][n:], r['local'][n:])                  # unused parameters are never reduced
-        assert r['sums'].tolist() == [3.0, 20.0, 4.0, 11.0]                   # global loss sums / valid counts
+        assert r['sums'].tolist() == [world + world * (world - 1) / 2.0, 10.0 * world, 2.0 * world, 5.0 * world + world * (world - 1) / 2.0]
         assert r['early'] >= r['n_buckets'] - 1                               # buckets launch before backward ends
+    assert all(torch.equal(r['reduced'][:n], rs[0]['reduced'][:n]) for r in rs[1:])     # every replica holds the same bits afterwards
 
 
 def test_integration_md_struct_stubs_match_the_binding(pkg):
