@@ -505,7 +505,7 @@ def run_rank(args):
         dist.all_gather(gathered, t)
         per_rank_ms = [round(1000.0 * float(g.item()) / args.steps, 3) for g in gathered]
         dt = max(float(g.item()) for g in gathered)
-        dp_info = measure_overlap(model, eager_step, dev, 1000.0 * dt / args.steps)
+        dp_info = measure_overlap(model, eager_step, dev, 1000.0 * dt / args.steps, reps=max(1, min(5, args.steps)))
         dp_info['host_ms_per_step'] = None if host_s is None else round(1000.0 * host_s, 3)
         if host_s is not None:
             th_ = torch.tensor([host_s], dtype=torch.float64, device=dev)
@@ -808,13 +808,12 @@ def _compact(rec):
             'check': rec['config'].get('check')}
 
 
-def measure_overlap(model, step, dev, dp_ms):
+def measure_overlap(model, step, dev, dp_ms, reps=5):
     '''After the timed region (untimed): the gradient buckets all-reduced alone, and the step with the exchange switched off, so
     the exposed communication time and the overlap fraction are numbers and not a design claim.'''
     import torch
     import torch.distributed as dist
     dp = model._dp
-    reps = 5
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.time()

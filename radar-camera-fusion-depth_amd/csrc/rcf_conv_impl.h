@@ -1190,9 +1190,6 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned 
 // Many weight packings in ONE launch (rcf_conv2d_pack_weights_batch): the per-item arguments travel by value in the kernel
 // argument block (<= 4 KB), a workgroup finds its item by its block index.  `split` items run pack_weights_split_body, the others
 // pack_weights_body.
-#if !RCF_CONV_B16 && (defined(RCF_WITH_SPLIT_WS) || defined(RCF_CONV_KERNELS_ONLY))
-#include "rcf_conv_split_ws.h"   // measured, not shipped (DESIGN.md section 6 [r4]): diagnostics builds only
-#endif
 
 struct PackArgs {
     const float* w;
@@ -2237,57 +2234,6 @@ int launch_split_bst(const ConvArgs& a, int ntile_n, hipStream_t st) {
     return rcf_launch_status();
 }
 
-// wave-specialised two-plane split kernels (rcf_conv_split_ws.h): a diagnostics build (-DRCF_WITH_SPLIT_WS) with RCF_SPLIT_WS=1 in
-// the environment runs them instead of conv_split_kernel.  Round 4 measured them 20-30 % SLOWER and the role-isolation experiment
-// (tools/probe/ws_harness.hip) showed why no re-scheduling of these kernels can pay: DESIGN.md section 6.
-bool ws_enabled() {
-#if RCF_CONV_B16 || !defined(RCF_WITH_SPLIT_WS)
-    return false;
-#else
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("RCF_SPLIT_WS");
-        on = (e != nullptr && e[0] == '1') ? 1 : 0;
-    }
-    return on == 1;
-#endif
-}
-// which selections run wave-specialised: every two-plane split configuration but the stride-2 ones (their 65 x 9 halo tile is 19
-// staging loads per producer thread: over the register budget of three waves per SIMD)
-bool ws_applies(const Sel& s) { return s.split && s.npl == 2 && !s.pw && !s.bf16 && s.kind != K3S2 && ws_enabled(); }
-#if !RCF_CONV_B16 && defined(RCF_WITH_SPLIT_WS)
-template <class C>
-int ws_grid_x(int ntiles, int ntile_n) {
-    static int resident = 0;
-    if (resident == 0) {
-        using L = WsLayout<C>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_ws_kernel<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  L::LDS_BYTES);
-        if constexpr (C::KSY != 4)   // (the stems have no BatchNorm-backward variant)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_ws_kernel<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      L::LDS_BYTES);
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_split_ws_kernel<C, false>, WS_THREADS, L::LDS_BYTES) != hipSuccess || per_cu < 1)
-            per_cu = 1;
-        if (per_cu > 2) per_cu = 2;   // three waves per SIMD: the register budget the kernel is compiled for
-        resident = per_cu * num_cus();
-    }
-    int gx = resident / ntile_n;
-    if (gx < 1) gx = 1;
-    if (gx > ntiles) gx = ntiles;
-    return gx;
-}
-template <class C, bool BST>
-int launch_split_ws(const ConvArgs& a, int ntile_n, hipStream_t st) {
-    if constexpr (BST && C::KSY == 4) {
-        return RCF_EUNSUPPORTED;
-    } else {
-        const int gx = ws_grid_x<C>(a.ntiles, ntile_n);
-        hipLaunchKernelGGL((conv_split_ws_kernel<C, BST>), dim3(gx, ntile_n, 1), dim3(WS_THREADS), WsLayout<C>::LDS_BYTES, st, a);
-        return rcf_launch_status();
-    }
-}
-#endif
 
 template <class C>
 int launch_wgrad(const ConvArgs& a, int nsplit, int nchunk, int ncog, hipStream_t st) {
@@ -2568,9 +2514,6 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
         if (s->kind == K3S1 && s->nt == 2 && wgs < num_cus()) { s->small = 1; s->nt = 1; }
         s->bf16 = d->precision == RCF_PREC_BF16 ? 1 : 0;
         s->npl = s->bf16 ? 1 : (d->precision == RCF_PREC_F16X2 ? 2 : 3);
-        // wave-specialised two-plane kernels: the 32-co layers take 256-pixel tiles too (the 512-pixel tile's A buffer cannot be doubled
-        // with two workgroups per CU, and its 20 staging loads per producer thread do not fit three waves per SIMD)
-        if (s->kind == K3S1 && s->nt == 1 && s->npl == 2 && ws_enabled()) s->small = 1;
 #if RCF_CONV_B16
         const char* e = getenv("RCF_B16_DMA");
         s->dma = (s->bf16 && d->c1 % 16 == 0 && d->c2 % 16 == 0 && (e == nullptr || e[0] != '0')) ? 1 : 0;
@@ -2740,24 +2683,6 @@ int dispatch_split_bst(const Sel& s, F&& f) {
     return RCF_EUNSUPPORTED;
 }
 
-// the wave-specialised two-plane configurations (ws_applies): 256-pixel tiles only (rcf_conv_split_ws.h)
-template <class F>
-int dispatch_split_ws(const Sel& s, F&& f) {
-    const bool p16 = s.px == 16;
-    if (s.kind == K4S1) return p16 ? f(Tag<SplitCfg<4, 1, 16, 0, 2>>{}) : f(Tag<SplitCfg<4, 1, 32, 0, 2>>{});
-    if (s.kind == K2S1) {
-        if (s.nt == 1) return p16 ? f(Tag<SplitCfg<2, 1, 16, 0, 2>>{}) : f(Tag<SplitCfg<2, 1, 32, 0, 2>>{});
-        return p16 ? f(Tag<SplitCfg<2, 2, 16, 0, 2>>{}) : f(Tag<SplitCfg<2, 2, 32, 0, 2>>{});
-    }
-    if (s.kind != K3S1) return RCF_EUNSUPPORTED;
-    if (s.nt == 1) return p16 ? f(Tag<SplitCfg<3, 1, 16, 2, 2>>{}) : f(Tag<SplitCfg<3, 1, 32, 2, 2>>{});   // (select_cfg: small = 1)
-    return p16 ? f(Tag<SplitCfg<3, 2, 16, 0, 2>>{}) : f(Tag<SplitCfg<3, 2, 32, 0, 2>>{});
-}
-template <class F>
-int dispatch_split_ws_bst(const Sel& s, F&& f) {
-    if (!split_bst_ok(s) || s.kind == K4S1) return RCF_EUNSUPPORTED;
-    return dispatch_split_ws(s, f);
-}
 
 template <class F>
 int dispatch_split(const Sel& s, F&& f) {
@@ -2979,11 +2904,6 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
     else if (s.dma) info->n_partials = dispatch_dma(s, [&](auto tag) { return dma_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
     else
 #endif
-#if !RCF_CONV_B16 && defined(RCF_WITH_SPLIT_WS)
-    if (ws_applies(s))
-        info->n_partials = dispatch_split_ws(s, [&](auto tag) { return ws_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
-    else
-#endif
     info->n_partials = s.split ? dispatch_split(s, [&](auto tag) { return split_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); })
                                : dispatch_fwd(s, [&](auto tag) { return fwd_grid_x<typename decltype(tag)::type>(a.ntiles, ntile_n); });
     if (info->n_partials <= 0) return RCF_EUNSUPPORTED;
@@ -3190,16 +3110,8 @@ static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float
     if (bn_z != nullptr) {   // rcf_conv_info.bn_bwd_sums: an input-gradient launch over a plain (unit-stride, whole) output tensor
         if (!bn_sums_ok(d, s)) return RCF_EUNSUPPORTED;
         a.bz = bn_z; a.bk = bn_coef;
-#if !RCF_CONV_B16 && defined(RCF_WITH_SPLIT_WS)
-        if (ws_applies(s))
-            return dispatch_split_ws_bst(s, [&](auto tag) { return launch_split_ws<typename decltype(tag)::type, true>(a, nn, (hipStream_t)stream); });
-#endif
         return dispatch_split_bst(s, [&](auto tag) { return launch_split_bst<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
     }
-#if !RCF_CONV_B16 && defined(RCF_WITH_SPLIT_WS)
-    if (ws_applies(s))
-        return dispatch_split_ws(s, [&](auto tag) { return launch_split_ws<typename decltype(tag)::type, false>(a, nn, (hipStream_t)stream); });
-#endif
     if (s.split) return dispatch_split(s, [&](auto tag) { return launch_split<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
     return dispatch_fwd(s, [&](auto tag) { return launch_fwd<typename decltype(tag)::type>(a, nn, (hipStream_t)stream); });
 }

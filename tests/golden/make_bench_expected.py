@@ -74,10 +74,15 @@ def radarnet_expected(n_img=16, k=4, height=900, width=1888):
     synth.fill_state_dict_([ora.encoder, ora.decoder], 41)
     cb = synth.make_radarnet_batch(7, n=n_img, k=k, h=height, w=width, patch_w=288)
     ora.train()
+    import numpy as np
     with torch.no_grad():
         ol = ora.forward(cb['image'], cb['point'], cb['bounding_boxes'])
         loss = float(ora.compute_loss(ol, cb['ground_truth'], cb['validity_map'], 2.0))
-    return {'first_step_loss': loss, 'mean_logit': float(ol.double().mean())}
+    # 4096 seeded logits of the (64, 1, 900, 288) map, for tests/test_configs_gpu.py (the full map is 66 MB)
+    idx = np.random.RandomState(11).randint(0, ol.numel(), size=4096)
+    flat = ol.reshape(-1)
+    return {'first_step_loss': loss, 'mean_logit': float(ol.double().mean()), 'max_abs_logit': float(ol.abs().max()),
+            'logit_index': [int(i) for i in idx], 'logits': [float(flat[int(i)]) for i in idx]}
 
 
 if __name__ == '__main__' and '--legs' in sys.argv:
