@@ -30,6 +30,14 @@ struct DmaCfg {
     static constexpr int HXP = (PX - 1) * LSTEP + KS, HYP = (TH - 1) * LSTEP + KS, NPIX = HXP * HYP;
     static constexpr int NA = (2 * NPIX + 255) / 256;        // LDS-DMA instructions per thread and A tile (one 16-B piece per lane)
     static constexpr int A_BYTES = NA * 256 * 16;            // every lane of every instruction lands somewhere
+    // A-tile layout in LDS.  HP (32-pixel tile rows, stride 1): [halo row][channel half][halo x][16 B].  The 32 lanes of an MFMA row
+    // block read 32 CONSECUTIVE pixels of one halo row and one half, 16 B apart: conflict-free as it stands (16 lanes x 16 B = all 64
+    // banks), and the address of tap (ky, kx) is the lane's base + a compile-time immediate -- no per-read address arithmetic, one
+    // address register per MFMA row block.  A DMA instruction (64 consecutive 16-B slots) still fetches both halves of ~32 pixels, so
+    // it touches as many cache lines as in the pixel-major layout ([half][pixel] would touch twice as many: measured 16 % slower).
+    // Otherwise (16-pixel rows: two tile rows per MFMA row block; stride 2): [pixel][2 x 16 B] with the halves XOR-swizzled by bit 3 of
+    // the pixel index, address recomputed per read.
+    static constexpr bool HP = (PX_ == 32 && LSTEP_ == 1);
     static constexpr int B_BYTES = T * BN * 32;              // one chunk of packed weights
     static constexpr int NKB = B_BYTES / 1024;
     static constexpr int LDS_BYTES = 2 * (A_BYTES + B_BYTES);
@@ -63,7 +71,16 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
         const int tr = (wave * C::MT + mi) * C::PY + li / C::PX;
         const int tc = li % C::PX;
         apix[mi] = tr * C::LSTEP * C::HXP + tc * C::LSTEP;
+        if (C::HP) apix[mi] = ((tr * 2 + lh) * C::HXP + tc) * 16;   // HP layout: the byte offset of tap (0, 0); taps add immediates
     }
+    // byte offset inside the A tile of this lane's operand for MFMA row block mi at tap (ky, kx)
+    auto a_off = [&](int mi, int ky, int kx) __attribute__((always_inline)) -> int {
+        if constexpr (C::HP) return apix[mi] + (ky * 2 * C::HXP + kx) * 16;
+        else {
+            const int p = apix[mi] + ky * C::HXP + kx;
+            return p * 32 + ((lh ^ ((p >> 3) & 1)) * 16);
+        }
+    };
     const int bbase = li * 32 + ((lh ^ ((li >> 3) & 1)) * 16);
 
     f32x16 acc[C::MT][C::NT];
@@ -90,9 +107,17 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
         const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
 #pragma unroll
         for (int i = 0; i < C::NA; ++i) {
-            const int p = (i * 256 + tid) >> 1;
-            const int hy = p / C::HXP;
-            const int hx = p - hy * C::HXP;
+            const int sp = i * 256 + tid;
+            int p = sp >> 1, hy, hx;
+            if constexpr (C::HP) {   // slot sp = (hy, half, hx)
+                hy = sp / (2 * C::HXP);
+                const int rem = sp - hy * (2 * C::HXP);
+                hx = rem >= C::HXP ? rem - C::HXP : rem;
+                p = hy < C::HYP ? hy * C::HXP + hx : C::NPIX;
+            } else {
+                hy = p / C::HXP;
+                hx = p - hy * C::HXP;
+            }
             const int ly = iy0 + hy, lx = ix0 + hx;
             int v = -1;
             if (p < C::NPIX && ly >= 0 && lx >= 0 && lx < a.w_in) {
@@ -136,7 +161,7 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
         for (int i = 0; i < C::NA; ++i) {
             const int s = i * 256 + tid;
             const int p = s >> 1;
-            const int hh = (s & 1) ^ ((p >> 3) & 1);
+            const int hh = C::HP ? ((s % (2 * C::HXP)) >= C::HXP ? 1 : 0) : ((s & 1) ^ ((p >> 3) & 1));
             const unsigned char* g = pix[i] >= 0 ? src + ((size_t)pix[i] * csrc + cb + hh * 8) * 2
                                                  : reinterpret_cast<const unsigned char*>(a.zero);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -191,6 +216,39 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
         }
+        if constexpr (C::MT * C::NT >= 8) {
+            // Register-blocked configurations (MT x NT = 4 x 2: 512 pixels x 64 output channels per workgroup, 128 accumulator registers):
+            // no room for two full operand sets, so the A operands go through a RING of three slots -- step (tap, mi) issues the read of
+            // step + 2 and runs its NT MFMAs -- and only B (NT reads per tap) is double-buffered per tap.  One ds_read_b128 now feeds
+            // NT = 2 MFMAs for A and MT = 4 for B: 6 reads per 8 MFMAs instead of 4 per 4, half the weight DMA and half the barriers per MFMA.
+            const unsigned char* Ab = smem_b + buf * C::A_BYTES;
+            const unsigned char* Bb = smem_b + 2 * C::A_BYTES + buf * C::B_BYTES;
+            constexpr int NS = C::T * C::MT;
+            bf16x8 ar[3], bv[2][C::NT];
+            auto read_a = [&](int st, int slot) __attribute__((always_inline)) {
+                const int tap = st / C::MT, mi = st % C::MT;
+                ar[slot] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ab + a_off(mi, tap / C::KS, tap % C::KS)));
+            };
+            auto read_b = [&](int tap, int ni) __attribute__((always_inline)) {
+                bv[tap & 1][ni] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bb + (tap * C::BN + ni * 32) * 32 + bbase));
+            };
+            read_a(0, 0);
+#pragma unroll
+            for (int ni = 0; ni < C::NT; ++ni) read_b(0, ni);
+            read_a(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const int tap = st / C::MT, mi = st % C::MT;
+                if (st + 2 < NS) read_a(st + 2, (st + 2) % 3);
+                if (mi < C::NT && tap + 1 < C::T) read_b(tap + 1, mi);   // the next tap's B operands behind the first NT steps of this tap
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[st % 3], bv[tap & 1][ni], acc[mi][ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
         {
             const unsigned char* Ab = smem_b + buf * C::A_BYTES;
             const unsigned char* Bb = smem_b + 2 * C::A_BYTES + buf * C::B_BYTES;
@@ -199,8 +257,7 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                 const int ky = tap / C::KS, kx = tap % C::KS;
 #pragma unroll
                 for (int mi = 0; mi < C::MT; ++mi) {
-                    const int p = apix[mi] + ky * C::HXP + kx;
-                    av[slot][mi] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ab + p * 32 + ((lh ^ ((p >> 3) & 1)) * 16)));
+                    av[slot][mi] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ab + a_off(mi, ky, kx)));
                 }
 #pragma unroll
                 for (int ni = 0; ni < C::NT; ++ni)
@@ -231,8 +288,7 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                                 // read order: A tile 0, all B tiles, then the remaining A tiles
                                 if (nr == 0 || nr > C::NT) {
                                     const int rmi = nr == 0 ? 0 : nr - C::NT;
-                                    const int p = apix[rmi] + nky * C::HXP + nkx;
-                                    av[nxt][rmi] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ab + p * 32 + ((lh ^ ((p >> 3) & 1)) * 16)));
+                                    av[nxt][rmi] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ab + a_off(rmi, nky, nkx)));
                                 } else {
                                     const int rni = nr - 1;
                                     bv[nxt][rni] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bb + ((tap + 1) * C::BN + rni * 32) * 32 + bbase));
@@ -420,6 +476,69 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                     }
                 }
             };
+            // Fast path: a tile that lies wholly inside one image and one n-tile of a plain output tensor, nothing to add -- nine tiles in
+            // ten at 900 x 1600.  No per-store bounds, masks or branches: the address is a wave-uniform tile base (SGPRs) + ONE per-lane
+            // register + a wave-uniform (mi, pixel pair, n-tile) offset.  (The general epilogue below spends ~20 instructions and a
+            // branch per store on its bounds: half of this kernel's wave time on the 64-channel 225 x 400 layers, tools/phase_timing.py.)
+            bool fast = !BST && !do_add && a.os == 1 && e_ooy == 0 && e_oox == 0 && a.ohp == a.h_out && a.owp == a.w_out &&
+                        ox0 + C::PX <= a.w_out && n0 + C::BN <= a.c_out;
+            int fy0 = oy0, fim = img;
+            if (a.vt) {
+                fim = (int)(((float)oy0 + 0.5f) * a.inv_hp);
+                fy0 = oy0 - fim * a.hp;
+                fast = fast && fim < a.nimg;
+            }
+            fast = fast && fy0 + C::TH <= a.h_out;
+            if (fast) {
+                unsigned char* tb = reinterpret_cast<unsigned char*>(a.out) + ((((size_t)fim * a.h_out + fy0) * a.w_out + ox0) * a.c_out + n0) * 2;
+                const unsigned pixb = (unsigned)a.c_out * 2u, rowb = (unsigned)a.w_out * pixb;
+                unsigned l0 = (unsigned)(wave_u * C::MT * C::PY) * rowb + (unsigned)(4 * lh + odd) * pixb + (unsigned)(li & ~1) * 2u;
+                // (opaque per tile: left visible, hipcc hoists all 8 x MT x NT store addresses out of the tile loop as 64-bit pairs --
+                // 128 registers it then spills)
+                asm volatile("" : "+v"(l0));
+                auto fast_epilogue = [&](auto stats_tag) __attribute__((always_inline)) {
+                    constexpr bool STATS = decltype(stats_tag)::value;
+#pragma unroll
+                    for (int mi = 0; mi < C::MT; ++mi) {
+                        float s1[C::NT][2], s2[C::NT][2];
+#pragma unroll
+                        for (int ni = 0; ni < C::NT; ++ni) { s1[ni][0] = s1[ni][1] = 0.f; s2[ni][0] = s2[ni][1] = 0.f; }
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) {
+                            const int rj = 2 * g;                 // accumulator rows rj, rj + 1: two consecutive pixels of one tile row
+                            const int rr = 8 * (g >> 1);          // rcf_mfma_row(4 * (g >> 1), 0): the lane part (4 lh) sits in l0
+                            const unsigned soff = (unsigned)(mi * C::PY + rr / C::PX) * rowb + (unsigned)(rr % C::PX + 2 * (g & 1)) * pixb;
+#pragma unroll
+                            for (int ni = 0; ni < C::NT; ++ni) {
+                                const float a0 = acc[mi][ni][rj], a1 = acc[mi][ni][rj + 1];
+                                const float mine = odd ? a1 : a0;
+                                const float give = odd ? a0 : a1;
+                                const float got = __uint_as_float(rcf_dpp_u32<0xB1>(__float_as_uint(give)));
+                                float lo = odd ? got : mine, hi = odd ? mine : got;
+                                if (EPI) {
+                                    lo = rcf_lrelu(lo + eb[ni][0]);
+                                    hi = rcf_lrelu(hi + eb[ni][1]);
+                                }
+                                const unsigned pk = rcf_f2b2(lo, hi);
+                                *reinterpret_cast<unsigned*>(tb + (size_t)(l0 + soff + (unsigned)(ni * 64))) = pk;
+                                if (STATS) {
+                                    const float rlo = __uint_as_float(pk << 16), rhi = __uint_as_float(pk & 0xffff0000u);
+                                    s1[ni][0] += rlo; s2[ni][0] += rlo * rlo;
+                                    s1[ni][1] += rhi; s2[ni][1] += rhi * rhi;
+                                }
+                            }
+                        }
+                        if (STATS) {
+#pragma unroll
+                            for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+                                for (int e = 0; e < 2; ++e) { st1[ni][e] += (double)s1[ni][e]; st2[ni][e] += (double)s2[ni][e]; }
+                        }
+                    }
+                };
+                if (want_stats) fast_epilogue(std::true_type{});
+                else fast_epilogue(std::false_type{});
+            } else
             if (do_add) epilogue(std::true_type{});
             else epilogue(std::false_type{});
         }

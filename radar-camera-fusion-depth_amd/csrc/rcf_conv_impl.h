@@ -2118,6 +2118,7 @@ struct Sel {
     int vt;   // virtual tall image tiling
     int split;   // fp32 on the bf16 matrix pipe (conv_split_kernel)
     int small;   // split 3x3 layer too small to fill the chip with 64-co workgroups: 256-pixel x 32-co workgroups instead
+    int big;     // bf16 DMA kernel, 3x3 stride 1, 64-co n-tiles, enough tiles: 512-pixel x 64-co workgroups (MT x NT = 4 x 2)
     int bf16;    // rcf_conv_desc.precision == RCF_PREC_BF16 and a split kernel: one bf16 plane, one product
     int npl;     // operand planes of a split kernel: 3 (exact fp32), 2 (RCF_PREC_F16X2), 1 (bf16)
     int dma;     // bf16 tensors, channel counts multiples of 16: conv_b16_kernel (operands reach LDS by DMA, rcf_conv_b16_dma.h)
@@ -2141,6 +2142,7 @@ namespace {
 #include "rcf_conv_b16_dma.h"
 using D3_2_32 = DmaCfg<3, 2, 32, 2>;
 using D3_2_16 = DmaCfg<3, 2, 16, 2>;
+using D3_2_32b = DmaCfg<3, 2, 32, 4>;    // 512 pixels x 64 output channels (register-blocked 4 x 2: the ring loop of conv_b16_kernel); 32-pixel rows only (DmaCfg::HP)
 using D3_1_32 = DmaCfg<3, 1, 32, 4>;     // 32-co layers: 512-pixel tiles
 using D3_1_16 = DmaCfg<3, 1, 16, 4>;
 using D3_1_32s = DmaCfg<3, 1, 32, 2>;    // small layers: 256-pixel x 32-co workgroups
@@ -2469,6 +2471,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     s->vt = 0;
     s->split = 0;
     s->small = 0;
+    s->big = 0;
     s->bf16 = 0;
     s->npl = 3;
     s->dma = 0;
@@ -2517,6 +2520,13 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
 #if RCF_CONV_B16
         const char* e = getenv("RCF_B16_DMA");
         s->dma = (s->bf16 && d->c1 % 16 == 0 && d->c2 % 16 == 0 && (e == nullptr || e[0] != '0')) ? 1 : 0;
+        // 512-pixel x 64-co workgroups (MT x NT = 4 x 2) once the layer has two full rounds of them for the resident grid: twice the
+        // MFMAs per staged weight chunk, per barrier and per B read.  RCF_B16_BIG=0 / 1: never / whenever the configuration exists
+        if (s->dma && s->kind == K3S1 && s->nt == 2) {
+            const char* eb = getenv("RCF_B16_BIG");
+            const long long wgs512 = (((long long)d->n * d->h_out * d->w_out + 511) / 512) * ceil_div(d->c_out, 64);
+            s->big = (eb != nullptr) ? (eb[0] == '1') : (wgs512 >= 4LL * num_cus());
+        }
 #endif
     }
     if (s->kind == K4S1) {
@@ -2528,10 +2538,11 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     const bool vt_ok = vt_allowed(d);
     const int pxs[3] = {32, 16, 8};
     // pixels per workgroup tile: 256; 512 for the 32-co 3x3 split layers; 128 for the three-plane stride-2 split kernel
-    const int tile_px = (s->split && s->kind == K3S2 && (!s->bf16 || s->dma)) ? 128 : ((s->split && s->nt == 1 && s->kind == K3S1 && !s->small) ? 512 : 256);   // (64-co bf16 DMA layers on 512-pixel tiles, MT x NT = 4 x 2: 55-109 spilled VGPRs at the 256 limit -- compiled in round 4, not viable)
+    const int tile_px = (s->split && s->kind == K3S2 && (!s->bf16 || s->dma)) ? 128 : ((s->split && ((s->nt == 1 && s->kind == K3S1 && !s->small) || s->big)) ? 512 : 256);
     for (int i = 0; i < 3; ++i) {
         const int px = pxs[i], th = tile_px / px;
         if (px == 8 && (s->split || !(s->kind == K3S1 && s->ck == 16))) continue;
+        if (s->big && px != 32) continue;   // the register-blocked configuration needs the immediate-offset A layout of 32-pixel rows
         for (int vt = 0; vt <= (vt_ok ? 1 : 0); ++vt) {
             const double e = vt ? tile_eff_vt(d->w_out, d->h_out, d->n, px, th) : tile_eff(d->w_out, d->h_out, px, th);
             if (e > best + 1e-9) { best = e; s->px = px; s->vt = vt; }
@@ -2631,6 +2642,7 @@ int dispatch_dma(const Sel& s, F&& f) {
     }
     if (s.nt == 1 && s.small) return p16 ? f(Tag<D3_1_16s>{}) : f(Tag<D3_1_32s>{});
     if (s.nt == 1) return p16 ? f(Tag<D3_1_16>{}) : f(Tag<D3_1_32>{});
+    if (s.big) return f(Tag<D3_2_32b>{});   // (select_cfg: px == 32)
     return p16 ? f(Tag<D3_2_16>{}) : f(Tag<D3_2_32>{});
 }
 #endif
@@ -2662,7 +2674,7 @@ bool split_bst_ok(const Sel& s) {
 #if RCF_CONV_B16
     // conv_b16_kernel<C, false, true>; not the 64-co x 32-pixel-row 3x3 configuration, whose epilogue sits at the register limit (the
     // sums would spill 3-8 VGPRs there: those layers keep the reduction pass)
-    return s.dma && !s.pw && (s.kind == K2S1 || (s.kind == K3S1 && !(s.nt == 2 && s.px == 32)));
+    return s.dma && !s.pw && !s.big && (s.kind == K2S1 || (s.kind == K3S1 && !(s.nt == 2 && s.px == 32)));
 #else
     return s.split && !s.bf16 && s.npl == 2 && (s.kind == K3S1 || s.kind == K2S1);
 #endif
@@ -2909,7 +2921,7 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
     if (info->n_partials <= 0) return RCF_EUNSUPPORTED;
     // (the stem on the space-to-depth image reports kind 3 like the 7x7 stem it stands for: 3000 + 5000 (split) stays below the
     // weight-gradient ids, 10000 + ...)
-    info->kernel_id = (s.kind == K4S1 ? (int)K7S2 : s.kind) * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0) + (s.small ? 5 : 0) + (s.bf16 ? 20000 : 0) + ((s.split && s.npl == 2) ? 40000 : 0);
+    info->kernel_id = (s.kind == K4S1 ? (int)K7S2 : s.kind) * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0) + (s.small ? 5 : 0) + (s.big ? 2 : 0) + (s.bf16 ? 20000 : 0) + ((s.split && s.npl == 2) ? 40000 : 0);
     info->wgrad_workspace_floats = 0;
     info->wgrad_kernel_id = 0;
     info->bn_on_load = (s.split && !s.dma && !s.pw && d->w_mode == RCF_W_FORWARD && d->c1 + d->c2 <= 512 && s.npl != 2) ? 1 : 0;   // a DMA cannot transform; fp16 planes need the maximum of the TRANSFORMED tensor
