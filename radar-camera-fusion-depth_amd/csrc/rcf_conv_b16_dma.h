@@ -216,39 +216,6 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
         }
-        if constexpr (C::MT * C::NT >= 8) {
-            // Register-blocked configurations (MT x NT = 4 x 2: 512 pixels x 64 output channels per workgroup, 128 accumulator registers):
-            // no room for two full operand sets, so the A operands go through a RING of three slots -- step (tap, mi) issues the read of
-            // step + 2 and runs its NT MFMAs -- and only B (NT reads per tap) is double-buffered per tap.  One ds_read_b128 now feeds
-            // NT = 2 MFMAs for A and MT = 4 for B: 6 reads per 8 MFMAs instead of 4 per 4, half the weight DMA and half the barriers per MFMA.
-            const unsigned char* Ab = smem_b + buf * C::A_BYTES;
-            const unsigned char* Bb = smem_b + 2 * C::A_BYTES + buf * C::B_BYTES;
-            constexpr int NS = C::T * C::MT;
-            bf16x8 ar[3], bv[2][C::NT];
-            auto read_a = [&](int st, int slot) __attribute__((always_inline)) {
-                const int tap = st / C::MT, mi = st % C::MT;
-                ar[slot] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ab + a_off(mi, tap / C::KS, tap % C::KS)));
-            };
-            auto read_b = [&](int tap, int ni) __attribute__((always_inline)) {
-                bv[tap & 1][ni] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bb + (tap * C::BN + ni * 32) * 32 + bbase));
-            };
-            read_a(0, 0);
-#pragma unroll
-            for (int ni = 0; ni < C::NT; ++ni) read_b(0, ni);
-            read_a(1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int st = 0; st < NS; ++st) {
-                const int tap = st / C::MT, mi = st % C::MT;
-                if (st + 2 < NS) read_a(st + 2, (st + 2) % 3);
-                if (mi < C::NT && tap + 1 < C::T) read_b(tap + 1, mi);   // the next tap's B operands behind the first NT steps of this tap
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ni = 0; ni < C::NT; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[st % 3], bv[tap & 1][ni], acc[mi][ni], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else
         {
             const unsigned char* Ab = smem_b + buf * C::A_BYTES;
             const unsigned char* Bb = smem_b + 2 * C::A_BYTES + buf * C::B_BYTES;
@@ -333,8 +300,6 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(bk[e][ni][0]), "+v"(bk[e][ni][1]));
             }
-            unsigned short* outp = reinterpret_cast<unsigned short*>(a.out);
-            const unsigned short* addp = reinterpret_cast<const unsigned short*>(EPI ? a.res : a.out);
             const bool do_add = EPI ? a.res != nullptr : a.accumulate != 0;
             float eb[C::NT][2];
             if (EPI) {
@@ -349,126 +314,129 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
 #pragma unroll
                 for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(eb[ni][0]), "+v"(eb[ni][1]));
             }
-            // ADD (accumulate into out / add the residual) is a COMPILE-TIME variant of the loop: the plain path must contain no
-            // load at all -- gfx9 counts stores in vmcnt, so one load in the loop makes hipcc wait for every previous store before
-            // the next one (measured: the epilogue was 55-72 % of the wave time that way).  With ADD all 8 x NT old dwords of an
-            // accumulator row group are requested first and consumed afterwards.
-            auto epilogue = [&](auto add_tag) __attribute__((always_inline)) {
-                constexpr bool ADD = decltype(add_tag)::value;
+            // ---- ONE branch-free path for every tile (interior, image edge, virtual-tall separator rows, strided phase outputs, += /
+            // residual, the BatchNorm-backward sums).  Address = buffer descriptor of the tile's first image (SGPRs) + a wave-uniform
+            // row / pixel-pair / n-tile offset (an SGPR: the instruction's soffset) + ONE per-lane register; a lane whose pixel or
+            // channel pair lies outside gets the offset 0xffffffff, which the buffer unit drops (stores) or answers with 0 (loads).
+            // (Round 4's epilogue computed 64-bit addresses and bounds per store behind an exec-mask branch each: ~20 instructions per
+            // store, 50-56 % of a wave's time on the 64- and 32-channel layers at 225 x 400 and above, tools/phase_timing.py.)
+            // ADD (accumulate into out / add the residual) and the statistics are COMPILE-TIME variants: the plain path contains no
+            // load at all -- gfx9 counts stores in vmcnt, so one load in the loop makes hipcc wait for every previous store.
+            int fim = img;
+            if (a.vt) {
+                fim = (int)(((float)oy0 + 0.5f) * a.inv_hp);
+                fim = fim < a.nimg ? fim : a.nimg - 1;
+            }
+            fim = __builtin_amdgcn_readfirstlane(fim);
+            const size_t img_b = (size_t)a.ohp * a.owp * a.c_out * 2;           // bytes per image
+            const unsigned rowb = (unsigned)a.owp * (unsigned)a.c_out * 2u;     // bytes per physical output row
+            const unsigned pstep = (unsigned)a.os * (unsigned)a.c_out * 2u;     // bytes between neighbouring output pixels
+            unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
+            const unsigned char* addb = reinterpret_cast<const unsigned char*>(EPI ? (a.res != nullptr ? a.res : a.out) : a.out);
+            const unsigned char* zb = reinterpret_cast<const unsigned char*>(BST ? a.bz : a.out);
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(outb + (size_t)fim * img_b, 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(addb) + (size_t)fim * img_b, 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(zb) + (size_t)fim * img_b, 0, 0x7fffffff, 0x00020000);
+            int wlim = a.w_out - ox0;   // columns of this tile that exist: logical (< w_out) and physical (px = (ox0 + c) * os + oox < owp)
+            {
+                const int wphys = (a.owp - e_oox - ox0 * a.os + a.os - 1) / a.os;
+                wlim = wlim < wphys ? wlim : wphys;
+            }
+            const unsigned xoff = (unsigned)(ox0 * a.os + e_oox) * (unsigned)a.c_out * 2u + (unsigned)n0 * 2u;
+            // per lane: byte offset of its dword inside a pixel row block (column 4 lh + odd, channel pair li & ~1), and per n-tile the
+            // number of valid columns left of it (0 for a channel pair outside the tensor): pixel pair g of the lane sits at column
+            // cc + 4 lh + odd with cc = (8 (g >> 1)) % PX + 2 (g & 1), valid iff cc < cl[ni]
+            unsigned l0 = (unsigned)(4 * lh + odd) * pstep + (unsigned)(li & ~1) * 2u;
+            int cl[C::NT];
+#pragma unroll
+            for (int ni = 0; ni < C::NT; ++ni) cl[ni] = (((n0 + ni * 32 + li) & ~1) < a.c_out) ? wlim - (4 * lh + odd) : 0;
+            asm volatile("" : "+v"(l0));   // opaque per tile: visible, hipcc hoists the tile-invariant offset pieces out of the tile loop and spills
+            auto epilogue = [&](auto add_tag, auto stats_tag) __attribute__((always_inline)) {
+                constexpr bool ADD = decltype(add_tag)::value, STATS = decltype(stats_tag)::value;
+                constexpr int GPB = 8 / C::PY;   // pixel pairs of an accumulator per tile row: 8 (32-pixel rows) or 4
 #pragma unroll
                 for (int mi = 0; mi < C::MT; ++mi) {
                     float s1[C::NT][2], s2[C::NT][2];
 #pragma unroll
                     for (int ni = 0; ni < C::NT; ++ni) { s1[ni][0] = s1[ni][1] = 0.f; s2[ni][0] = s2[ni][1] = 0.f; }
-                    size_t pbs[8];
-                    bool poks[8];
 #pragma unroll
-                    for (int r0 = 0; r0 < 16; r0 += 4) {
-                        // rows r0 .. r0 + 3 of a lane are four consecutive pixels of ONE tile row (PX a multiple of 4)
-                        const int row = rcf_mfma_row(r0, lh);
-                        int oy = oy0 + (wave * C::MT + mi) * C::PY + row / C::PX;
-                        const int ox = ox0 + row % C::PX;
+                    for (int rq = 0; rq < C::PY; ++rq) {
+                        // the tile row of this group: wave-uniform image, row, validity and byte offset from the descriptor's base
+                        int oy = oy0 + (wave_u * C::MT + mi) * C::PY + rq;
                         int im = img;
-                        if (a.vt) {   // virtual row -> (image, row); separator rows produce no output
+                        bool rok = true;
+                        if (a.vt) {
                             im = (int)(((float)oy + 0.5f) * a.inv_hp);
                             oy -= im * a.hp;
-                            if (im >= a.nimg) oy = a.h_out;
+                            rok = im < a.nimg;
                         }
-                        const int py = oy * a.os + e_ooy, px = ox * a.os + e_oox;
-                        const bool rowvalid = oy < a.h_out && py < a.ohp;
-                        const size_t base0 = (((size_t)im * a.ohp + py) * a.owp + px) * a.c_out;
-                        const int pstep = a.os * a.c_out;
-#pragma unroll
-                        for (int jp = 0; jp < 4; jp += 2) {
-                            const int jm = jp + odd;                                          // the pixel this lane stores
-                            poks[(r0 + jp) >> 1] = rowvalid && ox + jm < a.w_out && px + jm * a.os < a.owp;
-                            pbs[(r0 + jp) >> 1] = base0 + (size_t)(jm * pstep);
-                        }
-                    }
-                    unsigned zw[BST ? 8 : 1][C::NT];   // BST: z of the BatchNorm block at this lane's stores (two bf16 per dword)
-                    unsigned oldw[8][C::NT];
-                    if (ADD) {
-#pragma unroll
-                        for (int g = 0; g < 8; ++g)
+                        const int py = oy * a.os + e_ooy;
+                        rok = rok && oy < a.h_out && py < a.ohp;
+                        const unsigned rowoff = __builtin_amdgcn_readfirstlane((unsigned)((im - fim) * a.ohp + py) * rowb + xoff);
+                        if (__builtin_amdgcn_readfirstlane((int)rok)) {
 #pragma unroll
                             for (int ni = 0; ni < C::NT; ++ni) {
-                                const int cp = (n0 + ni * 32 + li) & ~1;
-                                oldw[g][ni] = *reinterpret_cast<const unsigned*>(addp + ((poks[g] && cp < a.c_out) ? pbs[g] + cp : 0));
-                            }
-                        // one wait for all of them HERE (the empty asm uses the registers): left to the first use inside the masked
-                        // store blocks below, hipcc waits with vmcnt(0) in every block -- i.e. for the previous block's store too
+                                unsigned zw[BST ? GPB : 1], oldw[ADD ? GPB : 1];
+                                if constexpr (BST || ADD) {
 #pragma unroll
-                        for (int g = 0; g < 8; ++g)
-#pragma unroll
-                            for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(oldw[g][ni]));
-                    }
-                    // BST: the z values of GB pixel pairs at a time (all eight at once cost 8 x NT registers)
-                    constexpr int GB = 4;
-#pragma unroll
-                    for (int gh = 0; gh < 8 / GB; ++gh) {
-                    if constexpr (BST) {
-                        const unsigned short* zp = reinterpret_cast<const unsigned short*>(a.bz);
-#pragma unroll
-                        for (int g = GB * gh; g < GB * gh + GB; ++g)
-#pragma unroll
-                            for (int ni = 0; ni < C::NT; ++ni) {
-                                const int cp = (n0 + ni * 32 + li) & ~1;
-                                zw[g][ni] = *reinterpret_cast<const unsigned*>(zp + ((poks[g] && cp < a.c_out) ? pbs[g] + cp : 0));
-                            }
-#pragma unroll
-                        for (int g = GB * gh; g < GB * gh + GB; ++g)   // one wait for these here (see `oldw`)
-#pragma unroll
-                            for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(zw[g][ni]));
-                    }
-#pragma unroll
-                    for (int g = GB * gh; g < GB * gh + GB; ++g) {
-                        const int rj = 2 * g;   // accumulator row of the pair's first pixel
-#pragma unroll
-                        for (int ni = 0; ni < C::NT; ++ni) {
-                            const int co = n0 + ni * 32 + li;
-                            const int cp = co & ~1;
-                            const bool ok = poks[g] && cp < a.c_out;
-                            // (static register indices + a select: indexing the accumulator with the lane-dependent `odd` makes
-                            // hipcc walk all 16 registers with compare/select pairs -- 60 VALU instructions per value)
-                            const float a0 = acc[mi][ni][rj], a1 = acc[mi][ni][rj + 1];
-                            const float mine = odd ? a1 : a0;                                 // my channel at my pixel
-                            const float give = odd ? a0 : a1;                                 // my channel at the partner's pixel
-                            const float got = __uint_as_float(rcf_dpp_u32<0xB1>(__float_as_uint(give)));   // partner's channel at my pixel
-                            float lo = odd ? got : mine, hi = odd ? mine : got;               // channels cp, cp + 1
-                            float alo = 0.f, ahi = 0.f;
-                            if (ADD) {
-                                alo = __uint_as_float(oldw[g][ni] << 16);
-                                ahi = __uint_as_float(oldw[g][ni] & 0xffff0000u);
-                            }
-                            if (EPI) {
-                                lo = rcf_lrelu(lo + eb[ni][0]);
-                                hi = rcf_lrelu(hi + eb[ni][1]);
-                                if (ADD) { lo = rcf_lrelu(lo + alo); hi = rcf_lrelu(hi + ahi); }
-                            } else if (ADD) {
-                                lo += alo;
-                                hi += ahi;
-                            }
-                            const unsigned pk = rcf_f2b2(lo, hi);
-                            if (ok) {
-                                *reinterpret_cast<unsigned*>(outp + pbs[g] + cp) = pk;
-                                if constexpr (BST) {   // of the gradient the tensor holds: g = dY * lrelu'(z * scale + shift); sum g, sum g * z
-                                    const float rlo = __uint_as_float(pk << 16), rhi = __uint_as_float(pk & 0xffff0000u);
-                                    const float zlo = __uint_as_float(zw[g][ni] << 16), zhi = __uint_as_float(zw[g][ni] & 0xffff0000u);
-                                    const float glo = rlo * rcf_lrelu_grad(zlo * bk[0][ni][0] + bk[1][ni][0]);
-                                    const float ghi = rhi * rcf_lrelu_grad(zhi * bk[0][ni][1] + bk[1][ni][1]);
-                                    s1[ni][0] += glo; s2[ni][0] += glo * zlo;
-                                    s1[ni][1] += ghi; s2[ni][1] += ghi * zhi;
+                                    for (int k = 0; k < GPB; ++k) {
+                                        const int g = rq * GPB + k;
+                                        const int cc = (8 * (g >> 1)) % C::PX + 2 * (g & 1);
+                                        const unsigned vo = cc < cl[ni] ? l0 + (unsigned)(ni * 64) : 0xffffffffu;
+                                        const unsigned so = rowoff + (unsigned)cc * pstep;
+                                        if constexpr (BST) zw[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, vo, so, 0);
+                                        if constexpr (ADD) oldw[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_add, vo, so, 0);
+                                    }
                                 }
-                                if (want_stats) {   // of the values the tensor holds
-                                    const float rlo = __uint_as_float(pk << 16), rhi = __uint_as_float(pk & 0xffff0000u);
-                                    s1[ni][0] += rlo; s2[ni][0] += rlo * rlo;
-                                    s1[ni][1] += rhi; s2[ni][1] += rhi * rhi;
+#pragma unroll
+                                for (int k = 0; k < GPB; ++k) {
+                                    const int g = rq * GPB + k;
+                                    const int rj = 2 * g;   // accumulator rows rj, rj + 1: two consecutive pixels of one tile row
+                                    const int cc = (8 * (g >> 1)) % C::PX + 2 * (g & 1);
+                                    const unsigned so = rowoff + (unsigned)cc * pstep;
+                                    unsigned lv = l0;
+                                    if constexpr (BST || ADD) asm volatile("" : "+v"(lv));   // (or the compiler keeps the offsets of the loads)
+                                    const bool ok = cc < cl[ni];
+                                    const unsigned vo = ok ? lv + (unsigned)(ni * 64) : 0xffffffffu;
+                                    // (static register indices + a select: indexing the accumulator with the lane-dependent `odd` makes
+                                    // hipcc walk all 16 registers with compare/select pairs -- 60 VALU instructions per value)
+                                    const float a0 = acc[mi][ni][rj], a1 = acc[mi][ni][rj + 1];
+                                    const float mine = odd ? a1 : a0;                                 // my channel at my pixel
+                                    const float give = odd ? a0 : a1;                                 // my channel at the partner's pixel
+                                    const float got = __uint_as_float(rcf_dpp_u32<0xB1>(__float_as_uint(give)));   // partner's channel at my pixel
+                                    float lo = odd ? got : mine, hi = odd ? mine : got;               // channels cp, cp + 1
+                                    float alo = 0.f, ahi = 0.f;
+                                    if constexpr (ADD) {
+                                        alo = __uint_as_float(oldw[k] << 16);
+                                        ahi = __uint_as_float(oldw[k] & 0xffff0000u);
+                                    }
+                                    if constexpr (EPI) {
+                                        lo = rcf_lrelu(lo + eb[ni][0]);
+                                        hi = rcf_lrelu(hi + eb[ni][1]);
+                                        if constexpr (ADD) { lo = rcf_lrelu(lo + alo); hi = rcf_lrelu(hi + ahi); }
+                                    } else if constexpr (ADD) {
+                                        lo += alo;
+                                        hi += ahi;
+                                    }
+                                    const unsigned pk = rcf_f2b2(lo, hi);
+                                    __builtin_amdgcn_raw_buffer_store_b32(pk, rs_out, vo, so, 0);
+                                    if constexpr (BST) {   // of the gradient the tensor holds: g = dY * lrelu'(z * scale + shift); sum g, sum g * z
+                                        const float rlo = ok ? __uint_as_float(pk << 16) : 0.f, rhi = ok ? __uint_as_float(pk & 0xffff0000u) : 0.f;
+                                        const float zlo = __uint_as_float(zw[k] << 16), zhi = __uint_as_float(zw[k] & 0xffff0000u);
+                                        const float glo = rlo * rcf_lrelu_grad(zlo * bk[0][ni][0] + bk[1][ni][0]);
+                                        const float ghi = rhi * rcf_lrelu_grad(zhi * bk[0][ni][1] + bk[1][ni][1]);
+                                        s1[ni][0] += glo; s2[ni][0] += glo * zlo;
+                                        s1[ni][1] += ghi; s2[ni][1] += ghi * zhi;
+                                    } else if constexpr (STATS) {   // of the values the tensor holds
+                                        const float rlo = ok ? __uint_as_float(pk << 16) : 0.f, rhi = ok ? __uint_as_float(pk & 0xffff0000u) : 0.f;
+                                        s1[ni][0] += rlo; s2[ni][0] += rlo * rlo;
+                                        s1[ni][1] += rhi; s2[ni][1] += rhi * rhi;
+                                    }
                                 }
                             }
                         }
                     }
-                    }
-                    if (want_stats || BST) {
+                    if constexpr (STATS || BST) {
 #pragma unroll
                         for (int ni = 0; ni < C::NT; ++ni)
 #pragma unroll
@@ -476,71 +444,18 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                     }
                 }
             };
-            // Fast path: a tile that lies wholly inside one image and one n-tile of a plain output tensor, nothing to add -- nine tiles in
-            // ten at 900 x 1600.  No per-store bounds, masks or branches: the address is a wave-uniform tile base (SGPRs) + ONE per-lane
-            // register + a wave-uniform (mi, pixel pair, n-tile) offset.  (The general epilogue below spends ~20 instructions and a
-            // branch per store on its bounds: half of this kernel's wave time on the 64-channel 225 x 400 layers, tools/phase_timing.py.)
-            bool fast = !BST && !do_add && a.os == 1 && e_ooy == 0 && e_oox == 0 && a.ohp == a.h_out && a.owp == a.w_out &&
-                        ox0 + C::PX <= a.w_out && n0 + C::BN <= a.c_out;
-            int fy0 = oy0, fim = img;
-            if (a.vt) {
-                fim = (int)(((float)oy0 + 0.5f) * a.inv_hp);
-                fy0 = oy0 - fim * a.hp;
-                fast = fast && fim < a.nimg;
+            if constexpr (BST) {   // the only writer of dY: nothing to add to, and the sums it takes are the block's, not its own
+                epilogue(std::false_type{}, std::false_type{});
+            } else if constexpr (EPI) {   // inference: no statistics
+                if (do_add) epilogue(std::true_type{}, std::false_type{});
+                else epilogue(std::false_type{}, std::false_type{});
+            } else if (do_add) {
+                if (want_stats) epilogue(std::true_type{}, std::true_type{});
+                else epilogue(std::true_type{}, std::false_type{});
+            } else {
+                if (want_stats) epilogue(std::false_type{}, std::true_type{});
+                else epilogue(std::false_type{}, std::false_type{});
             }
-            fast = fast && fy0 + C::TH <= a.h_out;
-            if (fast) {
-                unsigned char* tb = reinterpret_cast<unsigned char*>(a.out) + ((((size_t)fim * a.h_out + fy0) * a.w_out + ox0) * a.c_out + n0) * 2;
-                const unsigned pixb = (unsigned)a.c_out * 2u, rowb = (unsigned)a.w_out * pixb;
-                unsigned l0 = (unsigned)(wave_u * C::MT * C::PY) * rowb + (unsigned)(4 * lh + odd) * pixb + (unsigned)(li & ~1) * 2u;
-                // (opaque per tile: left visible, hipcc hoists all 8 x MT x NT store addresses out of the tile loop as 64-bit pairs --
-                // 128 registers it then spills)
-                asm volatile("" : "+v"(l0));
-                auto fast_epilogue = [&](auto stats_tag) __attribute__((always_inline)) {
-                    constexpr bool STATS = decltype(stats_tag)::value;
-#pragma unroll
-                    for (int mi = 0; mi < C::MT; ++mi) {
-                        float s1[C::NT][2], s2[C::NT][2];
-#pragma unroll
-                        for (int ni = 0; ni < C::NT; ++ni) { s1[ni][0] = s1[ni][1] = 0.f; s2[ni][0] = s2[ni][1] = 0.f; }
-#pragma unroll
-                        for (int g = 0; g < 8; ++g) {
-                            const int rj = 2 * g;                 // accumulator rows rj, rj + 1: two consecutive pixels of one tile row
-                            const int rr = 8 * (g >> 1);          // rcf_mfma_row(4 * (g >> 1), 0): the lane part (4 lh) sits in l0
-                            const unsigned soff = (unsigned)(mi * C::PY + rr / C::PX) * rowb + (unsigned)(rr % C::PX + 2 * (g & 1)) * pixb;
-#pragma unroll
-                            for (int ni = 0; ni < C::NT; ++ni) {
-                                const float a0 = acc[mi][ni][rj], a1 = acc[mi][ni][rj + 1];
-                                const float mine = odd ? a1 : a0;
-                                const float give = odd ? a0 : a1;
-                                const float got = __uint_as_float(rcf_dpp_u32<0xB1>(__float_as_uint(give)));
-                                float lo = odd ? got : mine, hi = odd ? mine : got;
-                                if (EPI) {
-                                    lo = rcf_lrelu(lo + eb[ni][0]);
-                                    hi = rcf_lrelu(hi + eb[ni][1]);
-                                }
-                                const unsigned pk = rcf_f2b2(lo, hi);
-                                *reinterpret_cast<unsigned*>(tb + (size_t)(l0 + soff + (unsigned)(ni * 64))) = pk;
-                                if (STATS) {
-                                    const float rlo = __uint_as_float(pk << 16), rhi = __uint_as_float(pk & 0xffff0000u);
-                                    s1[ni][0] += rlo; s2[ni][0] += rlo * rlo;
-                                    s1[ni][1] += rhi; s2[ni][1] += rhi * rhi;
-                                }
-                            }
-                        }
-                        if (STATS) {
-#pragma unroll
-                            for (int ni = 0; ni < C::NT; ++ni)
-#pragma unroll
-                                for (int e = 0; e < 2; ++e) { st1[ni][e] += (double)s1[ni][e]; st2[ni][e] += (double)s2[ni][e]; }
-                        }
-                    }
-                };
-                if (want_stats) fast_epilogue(std::true_type{});
-                else fast_epilogue(std::false_type{});
-            } else
-            if (do_add) epilogue(std::true_type{});
-            else epilogue(std::false_type{});
         }
         RCF_T(t_w4);
         RCF_TACC(3, t_w4, t_w3);   // 3: epilogue

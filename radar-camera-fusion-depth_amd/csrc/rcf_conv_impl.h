@@ -532,7 +532,17 @@ struct SplitCfg {
     static constexpr int NT = NT_, BN = 32 * NT_;
     static constexpr int PX = PX_, PY = 32 / PX_, MT = MT_ ? MT_ : ((NT_ == 1 && KS_ == 3) ? 4 : 2), NW = 4, TH = PY * MT * NW;   // 3x3 32-co layers: 512-pixel tiles (2x2 phases: measured 10 % slower with them)
     static constexpr int HXP = (PX - 1) * LSTEP + KS_, HYP = (TH - 1) * LSTEP + KS_, NPIX = HXP * HYP;
-    static constexpr int A_PLANE_BYTES = NPIX * 32;        // 16 bf16 per halo pixel
+    // A-tile layout in LDS (one plane).  HP (stride 1; three planes: 32-pixel rows only, the padded 16-pixel form does not fit the LDS):
+    // [halo row][channel half][halo x][16 B].  The 32 lanes of an MFMA row block read consecutive pixels of one half of one or two
+    // halo rows, 16 B apart -- conflict-free (for 16-pixel rows the row pitch is padded to a multiple of 16 slots so that the second
+    // row's lanes fall on the banks the first row's leave free) -- and the address of tap (ky, kx) is the lane's base + a COMPILE-TIME
+    // immediate: one address register per MFMA row block instead of ~5 VALU instructions per ds_read_b128 (the pixel-major layout
+    // XOR-swizzles the halves by bit 3 of the pixel index, which the tap offset carries into).  These kernels run at the board's power
+    // limit: instructions not issued are energy not spent.  Otherwise (stride 2): [pixel][2 x 16 B], halves swizzled.
+    static constexpr bool HP = (LSTEP_ == 1) && (PX_ == 32 || NPL_ <= 2);
+    static constexpr int HXH = (PX_ == 32) ? HXP : ((HXP + 7) / 8) * 8;   // 16-B slots per half row (16-pixel rows: row pitch 2 * HXH = 0 mod 16)
+    static constexpr int ROWS16 = 2 * HXH;                                // 16-B slots per halo row
+    static constexpr int A_PLANE_BYTES = HP ? HYP * ROWS16 * 16 : NPIX * 32;        // 16 bf16 per halo pixel
     static constexpr int A_BYTES = NPL * A_PLANE_BYTES;
     static constexpr int B_PLANE_BYTES = KSX * BN * 32;    // one kernel row: 16 bf16 per (tap, co)
     static constexpr int B_PIECE_BYTES = NPL * B_PLANE_BYTES;
@@ -602,7 +612,18 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
         const int tr = (wave * C::MT + mi) * C::PY + li / C::PX;
         const int tc = li % C::PX;
         apix[mi] = tr * C::LSTEP * C::HXP + tc * C::LSTEP;
+        if (C::HP) apix[mi] = (tr * C::ROWS16 + lh * C::HXH + tc) * 16;   // HP layout: byte offset of tap (0, 0); taps add immediates
     }
+    // byte offset inside an A plane of this lane's operand for MFMA row block mi at tap (ky, kx)
+    auto a_off = [&](int mi, int ky, int kx) __attribute__((always_inline)) -> int {
+        if constexpr (C::HP) return apix[mi] + (ky * C::ROWS16 + kx) * 16;
+        else {
+            int ap = apix[mi];
+            if (C::MT > 2) asm volatile("" : "+v"(ap));   // recompute the swizzled address per tap: hoisted, the 2 x T addresses cost 18 VGPRs
+            const int p = ap + ky * C::HXP + kx;
+            return p * 32 + ((lh ^ ((p >> 3) & 1)) * 16);
+        }
+    };
     const int bbase = li * 32 + ((lh ^ ((li >> 3) & 1)) * 16);   // row co = ni*32 + li; (ni*32) keeps (co>>3)&1 == (li>>3)&1
 
     f32x16 acc[C::MT][C::NT];
@@ -721,7 +742,15 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                     x2[e] = __float_as_uint(r2);
                 }
                 const int cq = tid & 3;
-                unsigned char* dst = As + p * 32 + (((cq >> 1) ^ ((p >> 3) & 1)) * 16) + (cq & 1) * 8;
+                unsigned char* dst;
+                if constexpr (C::HP) {
+                    int po = p;
+                    asm volatile("" : "+v"(po));   // recomputed per chunk: hoisted, the NA destinations stay live across the whole tile loop (spills)
+                    const int hy = po / C::HXP, hx = po - hy * C::HXP;
+                    dst = As + (hy * C::ROWS16 + (cq >> 1) * C::HXH + hx) * 16 + (cq & 1) * 8;
+                } else {
+                    dst = As + p * 32 + (((cq >> 1) ^ ((p >> 3) & 1)) * 16) + (cq & 1) * 8;
+                }
                 if (C::NPL == 1) {   // bf16 operands: round to nearest even instead of splitting
                     unsigned r[4];
 #pragma unroll
@@ -786,10 +815,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
     auto fetch_a = [&](int ky, int kx, int slot) {
 #pragma unroll
         for (int mi = 0; mi < C::MT; ++mi) {
-            int ap = apix[mi];
-            if (C::MT > 2) asm volatile("" : "+v"(ap));   // recompute the swizzled address per tap: hoisted, the 2 x T addresses cost 18 VGPRs
-            const int p = ap + ky * C::HXP + kx;
-            const int ao = p * 32 + ((lh ^ ((p >> 3) & 1)) * 16);
+            const int ao = a_off(mi, ky, kx);
 #pragma unroll
             for (int pl = 0; pl < C::NPL; ++pl) av[slot][pl][mi] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + pl * C::A_PLANE_BYTES + ao));
         }
@@ -869,12 +895,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                 __builtin_amdgcn_sched_barrier(0);
                                 if (nr < C::NPL * C::MT) {
                                     const int rmi = nr / C::NPL, pl = nr % C::NPL;
-                                    if (pl == 0) {
-                                        int ap = apix[rmi];
-                                        if (C::MT > 2) asm volatile("" : "+v"(ap));
-                                        const int p = ap + ky * C::HXP + kx + 1;
-                                        ao_next[rmi] = p * 32 + ((lh ^ ((p >> 3) & 1)) * 16);
-                                    }
+                                    if (pl == 0) ao_next[rmi] = a_off(rmi, ky, kx + 1);
                                     av[cur ^ 1][pl][rmi] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + pl * C::A_PLANE_BYTES + ao_next[rmi]));
                                 } else {
                                     const int rb = nr - C::NPL * C::MT, pl = rb / C::NT, rni = rb % C::NT;
@@ -939,6 +960,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = acc[mi][ni][r] * sc.ia * sc.ib;
                     }
+                    if constexpr (SO::B16) {   // bf16 tensors that cannot take the DMA kernel (rcf_conv_b16_dma.h): 2-byte stores, bounds per store
                     // (BST: taking a group's sums one group later -- z loads in flight behind the next group's stores -- was built and
                     // measured: the extra live registers spill 11-31 VGPRs in the 3x3 configurations and the step is no faster)
 #pragma unroll
@@ -1067,6 +1089,127 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                     }
                                 }
                         }
+                    }
+                    } else {
+                    // ---- fp32 tensors: ONE branch-free path for every tile (interior, image edge, virtual-tall separator rows, strided phase
+                    // outputs, += / residual, the BatchNorm-backward sums).  Address = buffer descriptor of the tile's first image (SGPRs)
+                    // + a wave-uniform row / pixel / n-tile offset (an SGPR: the instruction's soffset) + ONE per-lane register; a lane
+                    // whose pixel or channel lies outside gets the offset 0xffffffff, which the buffer unit drops (stores) or answers with 0
+                    // (loads).  Two VALU instructions per store.  (Round 4's path computed 64-bit addresses and four bounds per store behind
+                    // an exec-mask branch each -- ~20 instructions per store, 28-31 % of a wave's time on the 64- and 32-channel layers,
+                    // tools/phase_timing.py -- in kernels limited by board power: instructions not issued are energy not spent.)
+                    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+                    int fim = img;
+                    if (a.vt) {
+                        fim = (int)(((float)oy0 + 0.5f) * a.inv_hp);
+                        fim = fim < a.nimg ? fim : a.nimg - 1;
+                    }
+                    fim = __builtin_amdgcn_readfirstlane(fim);
+                    const size_t img_el = (size_t)a.ohp * a.owp * a.c_out;
+                    const unsigned rowb = (unsigned)a.owp * (unsigned)a.c_out * 4u;     // bytes per physical output row
+                    const unsigned pstep = (unsigned)a.os * (unsigned)a.c_out * 4u;     // bytes between neighbouring output pixels
+                    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)fim * img_el, 0, 0x7fffffff, 0x00020000);
+                    const float* addsrc = EPI ? a.res : a.out;
+                    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(addsrc != nullptr ? addsrc : a.out) + (size_t)fim * img_el, 0, 0x7fffffff, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BST ? a.bz : a.out) + (size_t)fim * img_el, 0, 0x7fffffff, 0x00020000);
+                    // columns of this tile that exist: logical (< w_out) and physical (px = (ox0 + c) * os + oox < owp)
+                    int wlim = a.w_out - ox0;
+                    {
+                        const int wphys = (a.owp - e_oox - ox0 * a.os + a.os - 1) / a.os;
+                        wlim = wlim < wphys ? wlim : wphys;
+                    }
+                    const unsigned xoff = (unsigned)(ox0 * a.os + e_oox) * (unsigned)a.c_out * 4u + (unsigned)n0 * 4u;
+                    // per lane: its byte offset inside a pixel row block, and per n-tile the number of valid columns left of it (0 for a
+                    // channel outside the tensor): accumulator row r of the lane is column (rr % PX) + 4 lh, valid iff rr % PX < cl[ni]
+                    unsigned l0 = (unsigned)(4 * lh) * pstep + (unsigned)li * 4u;
+                    int cl[C::NT];
+#pragma unroll
+                    for (int ni = 0; ni < C::NT; ++ni) cl[ni] = (n0 + ni * 32 + li < a.c_out) ? wlim - 4 * lh : 0;
+                    // (opaque per tile: visible, hipcc hoists the tile-invariant pieces of all 16 x MT x NT offsets out of the tile loop and spills)
+                    asm volatile("" : "+v"(l0));
+                    auto epilogue = [&](auto add_tag, auto stats_tag) __attribute__((always_inline)) {
+                        constexpr bool ADD = decltype(add_tag)::value, STATS = decltype(stats_tag)::value;
+                        constexpr int RPB = 16 / C::PY;   // accumulator rows per tile row: 16 (32-pixel rows) or 8
+                        // (the 64-co x 32-pixel-row BatchNorm-sums variants sit at the 256-register limit: four loads in flight there)
+                        constexpr int EB = (BST && C::NT == 2 && C::PX == 32) ? 4 : 8;
+#pragma unroll
+                        for (int mi = 0; mi < C::MT; ++mi)
+#pragma unroll
+                            for (int rq = 0; rq < C::PY; ++rq) {
+                                // the tile row of this group: wave-uniform image, row, validity and byte offset from the descriptor's base
+                                int oy = oy0 + (wave_s * C::MT + mi) * C::PY + rq;
+                                int im = img;
+                                bool rok = true;
+                                if (a.vt) {
+                                    im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                                    oy -= im * a.hp;
+                                    rok = im < a.nimg;
+                                }
+                                const int py = oy * a.os + e_ooy;
+                                rok = rok && oy < a.h_out && py < a.ohp;
+                                const unsigned rowoff = __builtin_amdgcn_readfirstlane((unsigned)((im - fim) * a.ohp + py) * rowb + xoff);
+                                if (__builtin_amdgcn_readfirstlane((int)rok)) {
+#pragma unroll
+                                    for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+                                    for (int kb = 0; kb < RPB; kb += EB) {   // EB outputs at a time: their old values / z in flight together
+                                        // (the masked offset is formed twice -- at the loads and at the store -- rather than kept: eight more live
+                                        // registers put the 64-co x 32-pixel-row BatchNorm-sums variants over the 256 limit)
+                                        float zv[BST ? EB : 1], old[ADD ? EB : 1];
+                                        if constexpr (BST || ADD) {
+#pragma unroll
+                                            for (int k = 0; k < EB; ++k) {
+                                                const int r = rq * RPB + kb + k;
+                                                const int cc = ((r & 3) + 8 * (r >> 2)) % C::PX;   // rcf_mfma_row(r, 0) % PX: the lane part (4 lh) is in l0 / cl
+                                                const unsigned vo = cc < cl[ni] ? l0 + (unsigned)(ni * 128) : 0xffffffffu;
+                                                const unsigned so = rowoff + (unsigned)cc * pstep;
+                                                if constexpr (BST) zv[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_z, vo, so, 0));
+                                                if constexpr (ADD) old[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_add, vo, so, 0));
+                                            }
+                                        }
+#pragma unroll
+                                        for (int k = 0; k < EB; ++k) {
+                                            const int r = rq * RPB + kb + k;
+                                            const int cc = ((r & 3) + 8 * (r >> 2)) % C::PX;
+                                            const unsigned so = rowoff + (unsigned)cc * pstep;
+                                            unsigned lv = l0;
+                                            if constexpr (BST || ADD) asm volatile("" : "+v"(lv));   // (or the compiler keeps the eight offsets of the loads)
+                                            const unsigned vo = cc < cl[ni] ? lv + (unsigned)(ni * 128) : 0xffffffffu;
+                                            float v = acc[mi][ni][r];
+                                            if constexpr (EPI) {
+                                                v = rcf_lrelu(v + ebias[ni]);
+                                                if constexpr (ADD) v = rcf_lrelu(v + old[k]);
+                                            } else if constexpr (ADD) {
+                                                v += old[k];
+                                            }
+                                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, vo, so, 0);
+                                            if constexpr (BST) {   // sum g and sum g * z of the gradient the tensor holds, in fp64
+                                                const float zz = zv[k];
+                                                const float g = cc < cl[ni] ? v * rcf_lrelu_grad(zz * bk[0][ni] + bk[1][ni]) : 0.f;
+                                                st1[ni] += (double)g;
+                                                st2[ni] += (double)g * (double)zz;
+                                            } else if constexpr (STATS) {   // fp64 per value: E[x^2] - mean^2 must not depend on how tiles group the sum
+                                                const double dv = (double)(cc < cl[ni] ? v : 0.f);
+                                                st1[ni] += dv;
+                                                st2[ni] += dv * dv;
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                    };
+                    if constexpr (BST) {   // the only writer of dY: nothing to add to, and the sums it takes are the block's, not its own
+                        epilogue(std::false_type{}, std::false_type{});
+                    } else if constexpr (EPI) {   // inference: no statistics
+                        if (add_old) epilogue(std::true_type{}, std::false_type{});
+                        else epilogue(std::false_type{}, std::false_type{});
+                    } else if (add_old) {
+                        if (want_stats) epilogue(std::true_type{}, std::true_type{});
+                        else epilogue(std::true_type{}, std::false_type{});
+                    } else {
+                        if (want_stats) epilogue(std::false_type{}, std::true_type{});
+                        else epilogue(std::false_type{}, std::false_type{});
+                    }
                     }
                 }
                 RCF_T(t_e0);
@@ -2118,7 +2261,6 @@ struct Sel {
     int vt;   // virtual tall image tiling
     int split;   // fp32 on the bf16 matrix pipe (conv_split_kernel)
     int small;   // split 3x3 layer too small to fill the chip with 64-co workgroups: 256-pixel x 32-co workgroups instead
-    int big;     // bf16 DMA kernel, 3x3 stride 1, 64-co n-tiles, enough tiles: 512-pixel x 64-co workgroups (MT x NT = 4 x 2)
     int bf16;    // rcf_conv_desc.precision == RCF_PREC_BF16 and a split kernel: one bf16 plane, one product
     int npl;     // operand planes of a split kernel: 3 (exact fp32), 2 (RCF_PREC_F16X2), 1 (bf16)
     int dma;     // bf16 tensors, channel counts multiples of 16: conv_b16_kernel (operands reach LDS by DMA, rcf_conv_b16_dma.h)
@@ -2142,7 +2284,6 @@ namespace {
 #include "rcf_conv_b16_dma.h"
 using D3_2_32 = DmaCfg<3, 2, 32, 2>;
 using D3_2_16 = DmaCfg<3, 2, 16, 2>;
-using D3_2_32b = DmaCfg<3, 2, 32, 4>;    // 512 pixels x 64 output channels (register-blocked 4 x 2: the ring loop of conv_b16_kernel); 32-pixel rows only (DmaCfg::HP)
 using D3_1_32 = DmaCfg<3, 1, 32, 4>;     // 32-co layers: 512-pixel tiles
 using D3_1_16 = DmaCfg<3, 1, 16, 4>;
 using D3_1_32s = DmaCfg<3, 1, 32, 2>;    // small layers: 256-pixel x 32-co workgroups
@@ -2471,7 +2612,6 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     s->vt = 0;
     s->split = 0;
     s->small = 0;
-    s->big = 0;
     s->bf16 = 0;
     s->npl = 3;
     s->dma = 0;
@@ -2520,13 +2660,6 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
 #if RCF_CONV_B16
         const char* e = getenv("RCF_B16_DMA");
         s->dma = (s->bf16 && d->c1 % 16 == 0 && d->c2 % 16 == 0 && (e == nullptr || e[0] != '0')) ? 1 : 0;
-        // 512-pixel x 64-co workgroups (MT x NT = 4 x 2) once the layer has two full rounds of them for the resident grid: twice the
-        // MFMAs per staged weight chunk, per barrier and per B read.  RCF_B16_BIG=0 / 1: never / whenever the configuration exists
-        if (s->dma && s->kind == K3S1 && s->nt == 2) {
-            const char* eb = getenv("RCF_B16_BIG");
-            const long long wgs512 = (((long long)d->n * d->h_out * d->w_out + 511) / 512) * ceil_div(d->c_out, 64);
-            s->big = (eb != nullptr) ? (eb[0] == '1') : (wgs512 >= 4LL * num_cus());
-        }
 #endif
     }
     if (s->kind == K4S1) {
@@ -2538,11 +2671,10 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     const bool vt_ok = vt_allowed(d);
     const int pxs[3] = {32, 16, 8};
     // pixels per workgroup tile: 256; 512 for the 32-co 3x3 split layers; 128 for the three-plane stride-2 split kernel
-    const int tile_px = (s->split && s->kind == K3S2 && (!s->bf16 || s->dma)) ? 128 : ((s->split && ((s->nt == 1 && s->kind == K3S1 && !s->small) || s->big)) ? 512 : 256);
+    const int tile_px = (s->split && s->kind == K3S2 && (!s->bf16 || s->dma)) ? 128 : ((s->split && s->nt == 1 && s->kind == K3S1 && !s->small) ? 512 : 256);
     for (int i = 0; i < 3; ++i) {
         const int px = pxs[i], th = tile_px / px;
         if (px == 8 && (s->split || !(s->kind == K3S1 && s->ck == 16))) continue;
-        if (s->big && px != 32) continue;   // the register-blocked configuration needs the immediate-offset A layout of 32-pixel rows
         for (int vt = 0; vt <= (vt_ok ? 1 : 0); ++vt) {
             const double e = vt ? tile_eff_vt(d->w_out, d->h_out, d->n, px, th) : tile_eff(d->w_out, d->h_out, px, th);
             if (e > best + 1e-9) { best = e; s->px = px; s->vt = vt; }
@@ -2642,7 +2774,6 @@ int dispatch_dma(const Sel& s, F&& f) {
     }
     if (s.nt == 1 && s.small) return p16 ? f(Tag<D3_1_16s>{}) : f(Tag<D3_1_32s>{});
     if (s.nt == 1) return p16 ? f(Tag<D3_1_16>{}) : f(Tag<D3_1_32>{});
-    if (s.big) return f(Tag<D3_2_32b>{});   // (select_cfg: px == 32)
     return p16 ? f(Tag<D3_2_16>{}) : f(Tag<D3_2_32>{});
 }
 #endif
@@ -2672,9 +2803,9 @@ int dispatch_split_planes(const Sel& s, F&& f) {
 // planes, 3x3 stride 1 and 2x2 (the four-phase input gradient of an up-2x convolution in one launch)
 bool split_bst_ok(const Sel& s) {
 #if RCF_CONV_B16
-    // conv_b16_kernel<C, false, true>; not the 64-co x 32-pixel-row 3x3 configuration, whose epilogue sits at the register limit (the
-    // sums would spill 3-8 VGPRs there: those layers keep the reduction pass)
-    return s.dma && !s.pw && !s.big && (s.kind == K2S1 || (s.kind == K3S1 && !(s.nt == 2 && s.px == 32)));
+    // conv_b16_kernel<C, false, true>: every 3x3 stride-1 and 2x2 configuration (round 5: the buffer-addressed epilogue freed ~40
+    // registers; the 64-co x 32-pixel-row one had been excluded for its spills)
+    return s.dma && !s.pw && (s.kind == K2S1 || s.kind == K3S1);
 #else
     return s.split && !s.bf16 && s.npl == 2 && (s.kind == K3S1 || s.kind == K2S1);
 #endif
@@ -2892,8 +3023,9 @@ extern "C" int rcf_phase_wgrad_gather_s2(const float* dwp, float* dw_oihw, int o
 // element of a plain NHWC tensor exactly once (or add to it as the LAST writer: the caller's business), on a kernel that has the
 // epilogue (split_bst_ok), with one source (an input gradient has one) and no statistics of its own
 static bool bn_sums_ok(const rcf_conv_desc* d, const Sel& s) {
+    // (not accumulating: the launch is the only writer of dY -- the kernels' BatchNorm-sums variants contain no += path)
     return split_bst_ok(s) && d->c2 == 0 && d->out_stride == 1 && d->out_off_y == 0 && d->out_off_x == 0 &&
-           d->out_h_phys == d->h_out && d->out_w_phys == d->w_out;
+           d->out_h_phys == d->h_out && d->out_w_phys == d->w_out && d->accumulate == 0;
 }
 
 extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* info) {
@@ -2921,7 +3053,7 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
     if (info->n_partials <= 0) return RCF_EUNSUPPORTED;
     // (the stem on the space-to-depth image reports kind 3 like the 7x7 stem it stands for: 3000 + 5000 (split) stays below the
     // weight-gradient ids, 10000 + ...)
-    info->kernel_id = (s.kind == K4S1 ? (int)K7S2 : s.kind) * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0) + (s.small ? 5 : 0) + (s.big ? 2 : 0) + (s.bf16 ? 20000 : 0) + ((s.split && s.npl == 2) ? 40000 : 0);
+    info->kernel_id = (s.kind == K4S1 ? (int)K7S2 : s.kind) * 1000 + s.ck * 10 + s.nt + (s.px == 16 ? 100 : (s.px == 8 ? 200 : 0)) + (s.vt ? 400 : 0) + (s.split ? 5000 : 0) + (s.small ? 5 : 0) + (s.bf16 ? 20000 : 0) + ((s.split && s.npl == 2) ? 40000 : 0);
     info->wgrad_workspace_floats = 0;
     info->wgrad_kernel_id = 0;
     info->bn_on_load = (s.split && !s.dma && !s.pw && d->w_mode == RCF_W_FORWARD && d->c1 + d->c2 <= 512 && s.npl != 2) ? 1 : 0;   // a DMA cannot transform; fp16 planes need the maximum of the TRANSFORMED tensor
@@ -3106,7 +3238,7 @@ static int conv2d_fwd_impl(const rcf_conv_desc* d, const float* in1, const float
         }
         if (s.nt == 1 && s.small) return p16 ? launch_dma_bst<D3_1_16s>(a, nn, st) : launch_dma_bst<D3_1_32s>(a, nn, st);
         if (s.nt == 1) return p16 ? launch_dma_bst<D3_1_16>(a, nn, st) : launch_dma_bst<D3_1_32>(a, nn, st);
-        return launch_dma_bst<D3_2_16>(a, nn, st);   // (split_bst_ok: px == 16 here)
+        return p16 ? launch_dma_bst<D3_2_16>(a, nn, st) : launch_dma_bst<D3_2_32>(a, nn, st);
     }
     if (s.dma && !coef1 && !coef2)
         return dispatch_dma(s, [&](auto tag) { return launch_dma<typename decltype(tag)::type, false>(a, nn, (hipStream_t)stream); });
