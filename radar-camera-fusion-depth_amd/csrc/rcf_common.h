@@ -73,6 +73,20 @@ __device__ __forceinline__ float rcf_amax4(float m, f32x4 v) {
     return fmaxf(fmaxf(m, fmaxf(rcf_abs_finite(v[0]), rcf_abs_finite(v[1]))), fmaxf(rcf_abs_finite(v[2]), rcf_abs_finite(v[3])));
 }
 
+// ---- buffer addressing (gfx950 raw buffers): descriptor over [base, base + 2 GB), byte offsets; a lane whose offset is 0xffffffff is
+// out of range -- its store is dropped, its load (also an LDS-DMA load) returns zeros.  The instruction's soffset (an SGPR) is added
+// to the address but takes no part in the range check.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rcf_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void rcf_buffer_to_lds16(__amdgpu_buffer_rsrc_t r, void* lds, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+typedef unsigned rcf_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 rcf_buffer_load_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
 // ---- storage type of the NHWC activation / gradient tensors -------------------------------------------------------------------
 // StF32: fp32 tensors (the reference's arithmetic).  StB16: bf16 tensors in HBM (BASELINE.json configs 2-4: bf16 storage and MFMA
 // operands, fp32 accumulation, fp32 master weights and BatchNorm statistics).  Kernels are templated on the tag and touch such a

@@ -90,7 +90,11 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
     const int nitem = a.phase_sum ? 4 * nchunk : nchunk;
 
     // A staging: piece s = i * 256 + tid of the tile -> halo pixel s >> 1, LDS half s & 1, source half (s & 1) ^ ((pixel >> 3) & 1)
-    int pix[C::NA];      // element offset (pixel index * channels of the source) of the piece's pixel, -1: zero
+    // byte offset of the piece's 16 B at channel chunk 0, from the start of the tile's first image in the source (a buffer descriptor
+    // built per tile and source, so 32 bits reach); 0xffffffff for padding / outside pieces: the buffer unit answers those with ZEROS,
+    // which land in LDS like data -- no zero page, no select, and the per-chunk address of a piece is this register + an SGPR
+    unsigned pix[C::NA];
+    int fimg = 0;        // that first image (wave-uniform)
     auto setup = [&](int tile, bool first, int ph) {
         int t = tile;
         const int tx = t % a.tiles_x;
@@ -105,6 +109,13 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
         const int ix0 = tx * C::PX * C::LSTEP - pb;
         const int hs = first ? a.h1 : a.h_in, ws = first ? a.w1 : a.w_in;
         const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
+        const unsigned pixb = (unsigned)(first ? a.c1 : a.c2) * 2u;   // bytes per source pixel
+        fimg = img;
+        if (a.vt) {   // the image of the tile's first real halo row
+            fimg = (int)(((float)(iy0 < 0 ? 0 : iy0) + 0.5f) * a.inv_hp);
+            fimg = fimg < a.nimg ? fimg : a.nimg - 1;
+        }
+        fimg = __builtin_amdgcn_readfirstlane(fimg);
 #pragma unroll
         for (int i = 0; i < C::NA; ++i) {
             const int sp = i * 256 + tid;
@@ -124,7 +135,7 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                 if (a.vt) {
                     const int im = (int)(((float)ly + 0.5f) * a.inv_hp);
                     const int y = ly - im * a.hp;
-                    if (im < a.nimg && y < a.h_in) v = (im * hs + y) * ws + lx;
+                    if (im < a.nimg && y < a.h_in) v = ((im - fimg) * hs + y) * ws + lx;
                 } else if (ly < a.h_in) {
                     int py = ly, px = lx;
                     bool ok = true;
@@ -141,10 +152,11 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                         px = lx >> 1;
                         ok = ok && py < hs && px < ws;
                     }
-                    if (ok) v = (img * hs + py) * ws + px;
+                    if (ok) v = py * ws + px;
                 }
             }
-            pix[i] = v;
+            const int hh = C::HP ? ((sp % (2 * C::HXP)) >= C::HXP ? 1 : 0) : ((sp & 1) ^ ((p >> 3) & 1));   // channel half of the piece
+            pix[i] = v >= 0 ? (unsigned)v * pixb + (unsigned)hh * 16u : 0xffffffffu;
         }
     };
     // item -> (phase, chunk); issue the DMA of one item's A tile and weight chunk into buffer `buf`
@@ -155,18 +167,13 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
         if (q == 0 || q == a.nchunk1) setup(tile, first, ph);
         const unsigned char* src = reinterpret_cast<const unsigned char*>(first ? a.in1 : a.in2);
         const int csrc = first ? a.c1 : a.c2;
-        const int cb = (first ? q : q - a.nchunk1) * 16;
+        const int hs = first ? a.h1 : a.h_in, ws = first ? a.w1 : a.w_in;
+        const unsigned cbb = (unsigned)((first ? q : q - a.nchunk1) * 32);   // this chunk's 16 channels: byte offset inside a pixel
+        const __amdgpu_buffer_rsrc_t rsa = rcf_rsrc(src + (size_t)fimg * hs * ws * csrc * 2);
         unsigned char* Ab = smem_b + buf * C::A_BYTES;
 #pragma unroll
-        for (int i = 0; i < C::NA; ++i) {
-            const int s = i * 256 + tid;
-            const int p = s >> 1;
-            const int hh = C::HP ? ((s % (2 * C::HXP)) >= C::HXP ? 1 : 0) : ((s & 1) ^ ((p >> 3) & 1));
-            const unsigned char* g = pix[i] >= 0 ? src + ((size_t)pix[i] * csrc + cb + hh * 8) * 2
-                                                 : reinterpret_cast<const unsigned char*>(a.zero);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(Ab + (i * 256 + wave_u * 64) * 16), 16, 0, 0);
-        }
+        for (int i = 0; i < C::NA; ++i)
+            rcf_buffer_to_lds16(rsa, Ab + (i * 256 + wave_u * 64) * 16, pix[i], cbb);
         const unsigned char* wsrc = wp + (size_t)ph * a.wp_phase_stride * 4 + (size_t)q * C::B_BYTES + lane * 16;
         unsigned char* Bb = smem_b + 2 * C::A_BYTES + buf * C::B_BYTES;
 #pragma unroll

@@ -633,9 +633,14 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
 
     // A staging: thread t owns channel quad t % 4 of halo pixels t / 4 + i * 64
     constexpr int NA = (C::NPIX + 63) / 64;
+    // fp32 tensors: byte offset of the thread's 16 B (its channel quad of halo pixel i) at channel chunk 0, from the start of the tile's
+    // first image in the source -- a buffer descriptor is built per tile and source, so 32 bits reach -- or 0xffffffff for padding /
+    // outside pixels: the buffer unit answers those with zeros, so the plain path needs neither a clamped address nor a select, and
+    // the per-chunk address of a load is this register + an SGPR.  bf16 tensors (the non-DMA fallback): pixel index, -1 = zero.
     int pix[NA];
+    int fimg = 0;        // that first image (wave-uniform)
     f32x4 ra[NA];
-    unsigned okm = 0u;   // bit i: ra[i] holds real data (else the clamped load is replaced by zero at store time)
+    unsigned okm = 0u;   // bit i: ra[i] holds real data (BatchNorm-on-load / bf16 tensors: padding is re-zeroed at store time)
     int tch = 0;         // first channel (in c1 + c2 numbering) of the staged quad, and whether its source is BN-on-load
     bool ttf = false;
 
@@ -653,6 +658,14 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
         const int ix0 = tx * C::PX * C::LSTEP - pb;
         const int hs = first ? a.h1 : a.h_in, ws = first ? a.w1 : a.w_in;
         const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
+        const int pixb = (first ? a.c1 : a.c2) * 4;   // bytes per source pixel (fp32 tensors)
+        fimg = img;
+        if (a.vt) {   // the image of the tile's first real halo row
+            fimg = (int)(((float)(iy0 < 0 ? 0 : iy0) + 0.5f) * a.inv_hp);
+            fimg = fimg < a.nimg ? fimg : a.nimg - 1;
+        }
+        fimg = __builtin_amdgcn_readfirstlane(fimg);
+        const int ibase = SI::B16 ? 0 : fimg;   // pixel indices count from this image
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             int p = (tid >> 2) + i * 64;
@@ -667,7 +680,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                 if (a.vt) {
                     const int im = (int)(((float)ly + 0.5f) * a.inv_hp);
                     const int y = ly - im * a.hp;
-                    if (im < a.nimg && y < a.h_in) v = (im * hs + y) * ws + lx;
+                    if (im < a.nimg && y < a.h_in) v = ((im - ibase) * hs + y) * ws + lx;
                 } else if (ly < a.h_in) {
                     int py = ly, px = lx;
                     bool ok = true;
@@ -684,10 +697,11 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                         px = lx >> 1;
                         ok = ok && py < hs && px < ws;
                     }
-                    if (ok) v = (img * hs + py) * ws + px;
+                    if (ok) v = ((img - ibase) * hs + py) * ws + px;
                 }
             }
-            pix[i] = v;
+            if constexpr (SI::B16) pix[i] = v;
+            else pix[i] = v >= 0 ? v * pixb + (tid & 3) * 16 : -1;   // (-1 = 0xffffffff: out of the descriptor's range)
         }
     };
     const int nitem = a.phase_sum ? 4 * nchunk : nchunk;   // A tiles per output tile
@@ -706,10 +720,22 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
         tch = (first ? 0 : a.c1) + cld;
         ttf = (first ? a.coef1 : a.coef2) != nullptr;
         okm = 0u;
+        if constexpr (SI::B16) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            if (cok && pix[i] >= 0) okm |= 1u << i;
-            ra[i] = rcf_ld4<SI>(src, (size_t)(pix[i] < 0 ? 0 : pix[i]) * csrc + cld);
+            for (int i = 0; i < NA; ++i) {
+                if (cok && pix[i] >= 0) okm |= 1u << i;
+                ra[i] = rcf_ld4<SI>(src, (size_t)(pix[i] < 0 ? 0 : pix[i]) * csrc + cld);
+            }
+        } else {
+            const int hs = first ? a.h1 : a.h_in, ws = first ? a.w1 : a.w_in;
+            const __amdgpu_buffer_rsrc_t rsa = rcf_rsrc(src + (size_t)fimg * hs * ws * csrc);
+            const unsigned cbb = (unsigned)((first ? q : q - a.nchunk1) * 64);   // this chunk's 16 channels: byte offset inside a pixel
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                if (cok && pix[i] != -1) okm |= 1u << i;
+                // (a quad beyond the source's channels -- the last chunk of an 8- or 24-channel source -- is out of range like padding)
+                ra[i] = rcf_buffer_load_f32x4(rsa, cok ? (unsigned)pix[i] : 0xffffffffu, cbb);
+            }
         }
     };
     // BN selects the BatchNorm-on-load variant at COMPILE time: as one code path the compiler if-converts the (wave-uniform) test and
@@ -733,7 +759,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     float xv = ra[i][e];
                     if (BN) xv = rcf_lrelu(xv * tsc[e] + tsh[e]);   // the producer's BatchNorm + LeakyReLU, applied on load
-                    const float x = ((okm >> i) & 1u) ? xv : 0.f;
+                    // (fp32 tensors, plain path: out-of-range loads came back as zeros already)
+                    const float x = (BN || SI::B16) ? (((okm >> i) & 1u) ? xv : 0.f) : xv;
                     xin[e] = x;
                     x0[e] = __float_as_uint(x) & 0xffff0000u;
                     const float r1 = x - __uint_as_float(x0[e]);
