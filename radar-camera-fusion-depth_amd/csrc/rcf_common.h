@@ -87,6 +87,11 @@ __device__ __forceinline__ f32x4 rcf_buffer_load_f32x4(__amdgpu_buffer_rsrc_t r,
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+typedef unsigned rcf_u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rcf_u32x2v rcf_buffer_load_u32x2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+}
+
 // ---- storage type of the NHWC activation / gradient tensors -------------------------------------------------------------------
 // StF32: fp32 tensors (the reference's arithmetic).  StB16: bf16 tensors in HBM (BASELINE.json configs 2-4: bf16 storage and MFMA
 // operands, fp32 accumulation, fp32 master weights and BatchNorm statistics).  Kernels are templated on the tag and touch such a

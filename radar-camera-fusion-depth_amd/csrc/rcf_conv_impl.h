@@ -1829,10 +1829,111 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             }
         }
     };
-    const bool plain_tile = gmode == RCF_GATHER_DIRECT && !a.vt && a.os == 1 && a.ooy == 0 && a.oox == 0;
+    // Every source but the nearest-upsample gather goes through buffer descriptors (round 5): per tile and staging unit three lane
+    // registers -- the byte offset of the unit's first pixel from the start of the tile's first image, its first column, and the
+    // number of valid columns (0 for a row outside the image) -- and per load an add, a compare and a select; a pixel outside gets the
+    // offset 0xffffffff, which the buffer unit answers with zeros.  (The pointer form above costs ~10 VALU instructions per load:
+    // 16-26 % of a wave's time went into "address arithmetic + load issue" with fp32 tensors, 23-46 % with bf16 ones,
+    // tools/phase_timing_wgrad.py -- at one wave per SIMD nothing hides it.)
+    auto load_tile_buf = [&](int tile) __attribute__((always_inline)) {
+        int t = tile;
+        const int tx = t % a.tiles_x;
+        t /= a.tiles_x;
+        const int ty = t % a.tiles_y;
+        const int img = t / a.tiles_y;
+        const int oy0 = ty * C::TH, ox0 = tx * C::PX;
+        const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad_x;
+        const bool s2 = gmode == RCF_GATHER_STRIDED2;
+        const int pm = s2 ? 2 : 1;                                      // source pixels per logical pixel
+        const int ioy = s2 ? a.ioy : 0, iox = s2 ? a.iox : 0;
+        // ---- x: halo tile of the input
+        {
+            int fimg = img;
+            if (a.vt) {
+                fimg = (int)(((float)(iy0 < 0 ? 0 : iy0) + 0.5f) * a.inv_hp);
+                fimg = fimg < a.nimg ? fimg : a.nimg - 1;
+            }
+            fimg = __builtin_amdgcn_readfirstlane(fimg);
+            const unsigned pixb = (unsigned)csrc * SX::BYTES;           // bytes per source pixel
+            const unsigned rowb = (unsigned)ws * pixb;
+            const __amdgpu_buffer_rsrc_t rsx = rcf_rsrc(reinterpret_cast<const unsigned char*>(src) + (size_t)fimg * hs * rowb);
+            int wl = a.w_in;                                             // logical columns that exist in the source
+            if (s2) { const int wph = (ws - iox + 1) / 2; wl = wl < wph ? wl : wph; }
+            const unsigned stepb = (unsigned)pm * pixb;
+            const unsigned cbb = (unsigned)cb * SX::BYTES;
+#pragma unroll
+            for (int i = 0; i < C::RX; ++i) {
+                const int u = tid + 256 * i;
+                const int cq = u % C::CQX, g = (u / C::CQX) % 3, hy = u / (3 * C::CQX);
+                const int ly = iy0 + hy;
+                bool rowok = u < C::NXU && cb + cq * 4 < csrc;
+                int im = img, y = ly;
+                if (a.vt) {
+                    im = (int)(((float)ly + 0.5f) * a.inv_hp);
+                    y = ly - im * a.hp;
+                    rowok = rowok && ly >= 0 && im < a.nimg && y < a.h_in;
+                } else {
+                    rowok = rowok && (unsigned)ly < (unsigned)a.h_in;
+                }
+                const int py = pm * y + ioy;
+                rowok = rowok && py < hs;
+                const int lx0 = ix0 + 8 * g;                             // logical column of the unit's first pixel
+                const unsigned lim = rowok ? (unsigned)wl : 0u;
+                const unsigned v0 = (unsigned)(((im - fimg) * hs + py)) * rowb + (unsigned)(pm * lx0 + iox) * pixb + (unsigned)(cq * 4) * SX::BYTES;
+                unsigned m = 0u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool ok = (unsigned)(lx0 + j) < lim && 8 * g + j < C::HXP;
+                    const unsigned vo = ok ? v0 + (unsigned)j * stepb : 0xffffffffu;
+                    if constexpr (RAWX) rx[i][j] = rcf_buffer_load_u32x2(rsx, vo, cbb);
+                    else rx[i][j] = rcf_buffer_load_f32x4(rsx, vo, cbb);
+                    if (cfx != nullptr) m |= ok ? (1u << j) : 0u;
+                }
+                mx[i] = m;
+            }
+        }
+        // ---- dz: the output-gradient tile (strided rows / columns for the phase convolutions)
+        {
+            int fimg = img;
+            if (a.vt) {
+                fimg = (int)(((float)oy0 + 0.5f) * a.inv_hp);
+                fimg = fimg < a.nimg ? fimg : a.nimg - 1;
+            }
+            fimg = __builtin_amdgcn_readfirstlane(fimg);
+            const unsigned pixb = (unsigned)a.c_out * SD::BYTES;
+            const unsigned rowb = (unsigned)a.owp * pixb;
+            const __amdgpu_buffer_rsrc_t rsd = rcf_rsrc(reinterpret_cast<const unsigned char*>(a.dz) + (size_t)fimg * a.ohp * rowb);
+            int wl = a.w_out;
+            { const int wph = (a.owp - a.oox + a.os - 1) / a.os; wl = wl < wph ? wl : wph; }
+            const unsigned stepb = (unsigned)a.os * pixb;
+#pragma unroll
+            for (int i = 0; i < C::RD; ++i) {
+                const int u = tid + 256 * i;
+                const int cq = u % C::CQD, g = (u / C::CQD) % 2, r = u / (2 * C::CQD);
+                int oy = oy0 + r, im = img;
+                bool rowok = u < C::NDU && co0 + cq * 4 < a.c_out;
+                if (a.vt) {
+                    im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                    oy -= im * a.hp;
+                    rowok = rowok && im < a.nimg;
+                }
+                const int py = oy * a.os + a.ooy;
+                rowok = rowok && oy < a.h_out && py < a.ohp;
+                const int lx0 = ox0 + 8 * g;
+                const unsigned lim = rowok ? (unsigned)wl : 0u;
+                const unsigned v0 = (unsigned)((im - fimg) * a.ohp + py) * rowb + (unsigned)(lx0 * a.os + a.oox) * pixb + (unsigned)(co0 + cq * 4) * SD::BYTES;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned vo = (unsigned)(lx0 + j) < lim ? v0 + (unsigned)j * stepb : 0xffffffffu;
+                    if constexpr (RAWD) rd[i][j] = rcf_buffer_load_u32x2(rsd, vo, 0u);
+                    else rd[i][j] = rcf_buffer_load_f32x4(rsd, vo, 0u);
+                }
+            }
+        }
+    };
     auto load_tile = [&](int tile) __attribute__((always_inline)) {
-        if (plain_tile) load_tile_impl(tile, std::true_type{});
-        else load_tile_impl(tile, std::false_type{});
+        if (gmode == RCF_GATHER_NEAREST) load_tile_impl(tile, std::false_type{});
+        else load_tile_buf(tile);
     };
     // 8 pixels of one channel -> three 16-B bf16 vectors (exact truncation split), written to the channel's LDS row
     // bf16 tensors: 8 pixels of channel e (raw dwords e >> 1, half e & 1) -> one 16-B vector of the channel's LDS row
