@@ -115,7 +115,7 @@ json.dump(line, open(os.path.join(prof, tag + '_bench_line.json'), 'w'), indent=
 # ---- summary
 with open(os.path.join(prof, tag + '_summary.md'), 'w') as f:
     f.write('# %s profile (tree at commit %s, csrc hash %s)\n\n' % (tag, head, out['_meta']['csrc_sha']))
-    f.write('`rocprofv3 --kernel-trace --stats -- python3 bench.py --graph 0 --steps %d --warmup %d --preheat-s 0 --no-cpu-baseline` on MI355X (gfx950):\n'
+    f.write('`rocprofv3 --kernel-trace --stats -- python3 bench.py --graph 0 --steps %d --warmup %d --preheat-s 0 --no-cpu-baseline --no-side-leg --no-other-configs` on MI355X (gfx950):\n'
             % (line['steps'], line['warmup']))
     f.write('FusionNet fp32 training, batch 8, 900x1600; %d steps in the trace.\n' % nstep)
     f.write('The traced and counted runs are SINGLE-STREAM (RCF_SINGLE_STREAM=1): a kernel\'s duration and counters are its own.  The default step runs the weight gradients and the encoder\'s depth branch on two side streams, so its wall clock is SHORTER than the sum of kernel times below.\n')

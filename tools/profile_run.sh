@@ -15,8 +15,10 @@ python3 bench.py --workload infer --steps 20 --warmup 5 > $out/bench_infer.log 2
 python3 bench.py --workload radarnet --steps 10 --warmup 3 > $out/bench_radarnet.log 2>&1
 python3 bench.py --workload infer --dtype f32 --steps 10 --warmup 3 > $out/bench_infer_f32.log 2>&1
 python3 bench.py --workload radarnet --dtype f32 --steps 10 --warmup 3 > $out/bench_radarnet_f32.log 2>&1
+# the traced / counted fp32 runs are the HEADLINE step alone (--no-side-leg --no-other-configs: the default line's extra legs would mix four
+# workloads into one kernel table)
 # eager launches under the profiler (a replayed hipGraph hides the per-launch events bench.py's roofline uses)
-RCF_SINGLE_STREAM=1 rocprofv3 --kernel-trace --stats -d /tmp/trace_$tag -o r -- python3 bench.py --graph 0 --steps 5 --warmup 3 --preheat-s 0 --no-cpu-baseline > $out/trace.log 2>&1
+RCF_SINGLE_STREAM=1 rocprofv3 --kernel-trace --stats -d /tmp/trace_$tag -o r -- python3 bench.py --graph 0 --steps 5 --warmup 3 --preheat-s 0 --no-cpu-baseline --no-side-leg --no-other-configs > $out/trace.log 2>&1
 grep "^{" $out/trace.log | tail -1 > $out/trace_bench_line.json
 python3 tools/trace_summary.py /tmp/trace_$tag 8 60 > $out/fp32_train_kernels.txt
 RCF_SINGLE_STREAM=1 rocprofv3 --kernel-trace --stats -d /tmp/trace_b16_$tag -o r -- python3 bench.py --dtype bf16 --graph 0 --steps 5 --warmup 3 --preheat-s 0 --no-cpu-baseline > $out/trace_b16.log 2>&1
@@ -28,7 +30,7 @@ python3 tools/trace_summary.py /tmp/trace_inf_$tag 8 40 > $out/bf16_infer_kernel
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   d=$out/pmc/$(echo $set | cut -d' ' -f1)
   # RCF_BATCH_PACK=0: the warm-up step and the counted step then issue the same dispatches (make_profile.py takes the second half)
-  RCF_SINGLE_STREAM=1 RCF_BATCH_PACK=0 rocprofv3 --pmc $set --output-format csv -d $d -o b -- python3 bench.py --graph 0 --steps 1 --warmup 1 --preheat-s 0 --no-cpu-baseline > $d.log 2>&1
+  RCF_SINGLE_STREAM=1 RCF_BATCH_PACK=0 rocprofv3 --pmc $set --output-format csv -d $d -o b -- python3 bench.py --graph 0 --steps 1 --warmup 1 --preheat-s 0 --no-cpu-baseline --no-side-leg --no-other-configs > $d.log 2>&1
 done
 python3 tools/make_profile.py /tmp/trace_$tag $out/pmc $out/trace_bench_line.json $tag $head > $out/make_profile.log 2>&1
 # the bf16 configurations (BASELINE configs 2-4): the same three PMC passes per workload -> profiles/<tag>_pmc_<workload>.json, which their
