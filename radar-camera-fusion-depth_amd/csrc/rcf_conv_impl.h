@@ -2657,6 +2657,15 @@ bool s2_split_enabled(const rcf_conv_desc* d) {
     return d->precision != RCF_PREC_FP32;
 }
 
+// The split / DMA kernels address their tensors through buffer descriptors based at the tile's first image, with 32-bit byte offsets
+// checked against a 2 GB range; a tile (incl. its halo) touches at most two consecutive images.  An image of 1 GB or more would put
+// valid offsets out of that range -- where the hardware silently returns zeros / drops stores -- so such shapes are refused loudly.
+bool buffer_range_ok(const rcf_conv_desc* d) {
+    const double lim = 1073741824.0, b = SAct::BYTES;
+    return (double)d->h_src1 * d->w_src1 * d->c1 * b < lim && (double)d->h_in * d->w_in * d->c2 * b < lim &&
+           (double)d->out_h_phys * d->out_w_phys * d->c_out * b < lim;
+}
+
 // stride-1 3x3 conv with pad 1 on directly addressed sources: the separator row is the conv's own zero padding
 bool vt_allowed(const rcf_conv_desc* d) {
     return d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->pad_x == 1 && d->gather1 == RCF_GATHER_DIRECT &&
@@ -2811,6 +2820,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     s->th = tile_px / s->px;
     s->bn = 32 * s->nt;
     if (d->phase_sum == 2 && !s->split) return RCF_EUNSUPPORTED;   // the four output phases in one launch: conv_split_kernel / conv_b16_kernel only
+    if (s->split && !s->pw && !buffer_range_ok(d)) return RCF_EUNSUPPORTED;
     return RCF_OK;
 }
 
@@ -3065,6 +3075,7 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
         if (nsp > w->ntiles) nsp = w->ntiles;
         if (nsp < 1) nsp = 1;
         w->nsplit = nsp;
+        if (!buffer_range_ok(d)) return RCF_EUNSUPPORTED;
     }
     return RCF_OK;
 }

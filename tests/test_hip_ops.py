@@ -1010,3 +1010,16 @@ def test_batchnorm_reductions_at_batch8_full_resolution(ops, n, h, w, c):
     scale = float(dout.double().abs().sum() / c)
     assert float((got_b[0] - s_g).abs().max()) < 1e-9 * scale
     assert float((got_b[1] - s_gx).abs().max()) < 1e-9 * scale * 4
+
+
+def test_images_beyond_the_buffer_range_are_refused_loudly(ops):
+    '''The split / DMA convolution kernels address their tensors through buffer descriptors based at a tile's first image (32-bit byte
+    offsets checked against a 2 GB range, a tile touching at most two consecutive images): an image of 1 GB or more would put valid
+    pixels out of range, where the hardware returns zeros / drops stores SILENTLY -- so such a shape must be refused by the query and
+    by every launch (RCF_EUNSUPPORTED), never computed.  A 900 x 1600 image with 64 channels is 0.37 GB.'''
+    from rcf_amd import _lib
+    ok = ops.make_fwd_desc(1, 900, 1600, 64, 0, 64, 3, 1)
+    assert ops.conv_query(ok).packed_weight_floats > 0
+    big = ops.make_fwd_desc(1, 4096, 4096, 64, 0, 64, 3, 1)          # 4.3 GB per fp32 image
+    with pytest.raises(_lib.RcfError):
+        ops.conv_query(big)
