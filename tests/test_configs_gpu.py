@@ -428,6 +428,10 @@ def test_bench_two_ranks_at_the_headline_shape_pass_their_own_loss_check(dtype):
     single = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_expected.json')))['train_b8_900x1600_p64']['first_step_loss']
     assert abs(chk['oracle_first_step_loss'] - single) > 1e-3 * single     # and the global value is NOT rank 0's own mean
     assert 'overlap_frac' in rec['dp']
+    # the launch mode is decided by all ranks together (round 5): every rank's probe is in the line, and so is the common decision
+    probe = rec['dp']['launch_probe']
+    assert len(probe['host_ms_by_rank']) == 2 and len(probe['host_bound_by_rank']) == 2 and isinstance(probe['decision'], str)
+    assert len(rec['dp']['host_ms_per_step_by_rank']) == 2
 
 
 def test_bench_single_gpu_line_carries_the_contract_fields():
