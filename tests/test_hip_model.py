@@ -398,6 +398,59 @@ def test_checkpoint_round_trip_and_reference_key_names(env, tmp_path):
         assert torch.equal(pa, pb), ka
 
 
+def test_engine_recovers_after_an_exception_on_a_side_stream(env):
+    '''An error raised in the middle of a forward or a backward pass -- here injected into the 3rd / 12th BatchNorm launch, i.e. while
+    the depth branch's stream resp. the weight-gradient stream is current -- must leave the caller on ITS stream with no engine flag
+    set (Engine.recover): the next step of the same model is then bitwise the step of a model that never failed.'''
+    from rcf_amd import ops as _ops
+    from rcf_amd._lib import RcfError
+    synth, train = env
+    b = _gpu_batch(synth.make_batch(2, 70, 102, 6, seed=4))
+    args = (b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])
+
+    def clean_step():
+        m = _build(env, synth.TINY, 9)
+        opt = train.make_optimizer(m, lr=1e-3)
+        m.train()
+        loss, _, out = train.train_step(m, opt, *args)
+        torch.cuda.synchronize()
+        return m, opt, out.detach().clone(), float(loss), m._param_arena.detach().clone()
+
+    _, _, out_ref, loss_ref, params_ref = clean_step()
+    for victim, nth in (('bn_act_fwd', 3), ('bn_act_bwd_apply', 12)):
+        m = _build(env, synth.TINY, 9)
+        opt = train.make_optimizer(m, lr=1e-3)
+        m.train()
+        eng = m._engine
+        assert eng.wgrad_side and eng.branch_stream
+        real = getattr(_ops, victim)
+        calls = [0]
+
+        def failing(*a, **k):
+            calls[0] += 1
+            if calls[0] == nth:
+                raise RcfError('injected failure in %s' % victim)
+            return real(*a, **k)
+        setattr(_ops, victim, failing)
+        try:
+            with pytest.raises(RcfError):
+                train.train_step(m, opt, *args)
+        finally:
+            setattr(_ops, victim, real)
+        torch.cuda.synchronize()
+        assert torch.cuda.current_stream() == torch.cuda.default_stream()
+        assert not eng._in_branch and not eng._side_busy and not eng._branch_busy and not eng._open_switches and not eng.in_backward
+        # the failed step changed nothing that matters: parameters untouched (the optimizer never ran); a fresh step is the clean one
+        m2 = _build(env, synth.TINY, 9)
+        m._param_arena.copy_(m2._param_arena)
+        for (k, buf), (_, buf2) in zip(_named(m, 'b'), _named(m2, 'b')):
+            buf.copy_(buf2)
+        opt = train.make_optimizer(m, lr=1e-3)
+        loss, _, out = train.train_step(m, opt, *args)
+        torch.cuda.synchronize()
+        assert float(loss) == loss_ref and torch.equal(out, out_ref) and torch.equal(m._param_arena, params_ref), victim
+
+
 def test_gradient_accumulation_without_zero_grad(env):
     synth, _ = env
     m = _build(env, synth.TINY, 4)
