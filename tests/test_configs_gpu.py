@@ -463,3 +463,19 @@ def test_bench_single_gpu_line_carries_the_contract_fields():
         assert leg['check']['ok'] is True, (name, leg['check'])
         assert 0 < leg['roofline']['frac'] < 1, (name, leg['roofline'])
     print({k: (v['value'], v['unit'], v['check']) for k, v in others.items()})
+
+
+def test_bench_falls_back_to_the_replayed_graph_on_a_host_bound_box():
+    '''A host that cannot enqueue a step as fast as the GPU runs it (forced here: threshold 0) gets the replayed graph in the headline
+    AND in the training legs, the line says so, and every oracle check still passes.'''
+    r, rec = _run_bench(['--steps', '2', '--warmup', '1', '--preheat-s', '0', '--no-cpu-baseline', '--leg-steps', '2'],
+                        env_extra={'RCF_BENCH_HOST_BOUND_FRAC': '0'}, timeout=900)
+    assert r.returncode == 0 and rec is not None, (r.returncode, r.stderr[-1500:])
+    probe = rec['config']['launch_probe']
+    assert probe['host_bound'] is True and probe['decision'] == 'graph', probe
+    assert rec['config']['loss_check']['ok'] is True
+    assert rec['exact_tier']['launch'].startswith('one hipGraph replay'), rec['exact_tier']
+    assert rec['exact_tier']['check']['ok'] is True
+    leg = rec['other_configs']['configs[3] FusionNet bf16 training, per-GPU batch 8']
+    assert leg['launch'].startswith('one hipGraph replay') and leg['check']['ok'] is True, leg
+    assert 0 < leg['roofline']['frac'] < 1
