@@ -22,12 +22,20 @@
 // transform), channel counts that are not multiples of 16 (those layers stay on conv_split_kernel).
 #pragma once
 
-template <int KS_, int NT_, int PX_, int MT_, int LSTEP_ = 1>
+// P4 (KS = 2 only): the four OUTPUT phases of an up-2x forward (rcf_conv_desc.phase_sum == 2) from ONE staged tile.  Phase (a, b)
+// is a 2x2 convolution of x with pad (1 - a, 1 - b), so the four phases of an output tile read the SAME 3x3-halo tile of x: it is
+// staged once per channel chunk (halo geometry GK = 3) together with the 4 x 4 weight blocks of the chunk, the 16 (phase, tap)
+// products run from it into four accumulator sets, and the epilogue runs once per phase.  (Round 4's one-launch form ran the four
+// 2x2 convolutions back to back, each re-staging its own tile: the re-reads were meant to hit L2 but the PMC counters show x
+// fetched ~4.5 x per launch at 450 x 800, profiles/r05_pmc_bf16_infer.json -- the kernel was HBM-bound on its own re-reads.)
+template <int KS_, int NT_, int PX_, int MT_, int LSTEP_ = 1, bool P4_ = false>
 struct DmaCfg {
-    static constexpr int KS = KS_, T = KS_ * KS_, LSTEP = LSTEP_;
+    static constexpr bool P4 = P4_;
+    static constexpr int KS = KS_, GK = P4_ ? 3 : KS_, T = P4_ ? 16 : KS_ * KS_, NPH = P4_ ? 4 : 1, LSTEP = LSTEP_;
+    static_assert(!P4_ || (KS_ == 2 && LSTEP_ == 1 && PX_ == 32), "P4 is the up-2x forward: 2x2 taps, stride 1, 32-pixel tile rows");
     static constexpr int NT = NT_, BN = 32 * NT_;
     static constexpr int PX = PX_, PY = 32 / PX_, MT = MT_, NW = 4, TH = PY * MT * NW;
-    static constexpr int HXP = (PX - 1) * LSTEP + KS, HYP = (TH - 1) * LSTEP + KS, NPIX = HXP * HYP;
+    static constexpr int HXP = (PX - 1) * LSTEP + GK, HYP = (TH - 1) * LSTEP + GK, NPIX = HXP * HYP;
     static constexpr int NA = (2 * NPIX + 255) / 256;        // LDS-DMA instructions per thread and A tile (one 16-B piece per lane)
     static constexpr int A_BYTES = NA * 256 * 16;            // every lane of every instruction lands somewhere
     // A-tile layout in LDS.  HP (32-pixel tile rows, stride 1): [halo row][channel half][halo x][16 B].  The 32 lanes of an MFMA row
@@ -44,6 +52,25 @@ struct DmaCfg {
     static_assert(B_BYTES % 1024 == 0, "weight chunk must be whole KiB");
     static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 };
+
+// P4: the 16 (phase, tap) products of a chunk ordered by the halo position (ky, kx) they read, so that an A operand is fetched
+// from LDS once per position (9 x MT reads per chunk instead of 16 x MT) -- phase (pa, pb), tap (ty, tx) reads (pa + ty, pb + tx)
+struct P4Tab { int pos[16]; int t16[16]; };
+constexpr P4Tab rcf_p4_tab() {
+    P4Tab t{};
+    int n = 0;
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx)
+            for (int pa = 0; pa < 2; ++pa)
+                for (int pb = 0; pb < 2; ++pb) {
+                    const int ty = ky - pa, tx = kx - pb;
+                    if (ty < 0 || ty > 1 || tx < 0 || tx > 1) continue;
+                    t.pos[n] = ky * 3 + kx;
+                    t.t16[n] = (pa * 2 + pb) * 4 + ty * 2 + tx;
+                    ++n;
+                }
+    return t;
+}
 
 template <int CTRL>
 __device__ __forceinline__ unsigned rcf_dpp_u32(unsigned v) {
@@ -83,11 +110,13 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
     };
     const int bbase = li * 32 + ((lh ^ ((li >> 3) & 1)) * 16);
 
-    f32x16 acc[C::MT][C::NT];
+    f32x16 acc[C::NPH][C::MT][C::NT];
     const int nchunk = a.nchunk1 + a.nchunk2;
-    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.wp) + (size_t)blockIdx.y * nchunk * C::B_BYTES;
+    // (P4: the packed weights keep the per-phase layout [phase][n-tile][chunk][4 taps][co][16]; a chunk's DMA collects its four blocks)
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.wp) + (size_t)blockIdx.y * nchunk * (C::B_BYTES / C::NPH);
     const int n0 = blockIdx.y * C::BN;
-    const int nitem = a.phase_sum ? 4 * nchunk : nchunk;
+    const int psum = C::P4 ? 0 : a.phase_sum;   // P4: one item per chunk, no phase loop
+    const int nitem = psum ? 4 * nchunk : nchunk;
 
     // A staging: piece s = i * 256 + tid of the tile -> halo pixel s >> 1, LDS half s & 1, source half (s & 1) ^ ((pixel >> 3) & 1)
     // byte offset of the piece's 16 B at channel chunk 0, from the start of the tile's first image in the source (a buffer descriptor
@@ -103,8 +132,8 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
         const int img = t / a.tiles_y;
         // phase_sum 1: the four INPUT phases of an up-2x input gradient summed; 2: the four OUTPUT phases of an up-2x forward, one after
         // the other on the same tile (pad 1 - a, 1 - b; the outputs go to (2y + a, 2x + b))
-        const int pa = a.phase_sum == 2 ? 1 - (ph >> 1) : (a.phase_sum ? (ph >> 1) : a.pad), pb = a.phase_sum == 2 ? 1 - (ph & 1) : (a.phase_sum ? (ph & 1) : a.pad_x);
-        const int ioy = a.phase_sum ? (ph >> 1) : a.ioy, iox = a.phase_sum ? (ph & 1) : a.iox;
+        const int pa = C::P4 ? 1 : (psum == 2 ? 1 - (ph >> 1) : (psum ? (ph >> 1) : a.pad)), pb = C::P4 ? 1 : (psum == 2 ? 1 - (ph & 1) : (psum ? (ph & 1) : a.pad_x));
+        const int ioy = psum ? (ph >> 1) : a.ioy, iox = psum ? (ph & 1) : a.iox;
         const int iy0 = ty * C::TH * C::LSTEP - pa;
         const int ix0 = tx * C::PX * C::LSTEP - pb;
         const int hs = first ? a.h1 : a.h_in, ws = first ? a.w1 : a.w_in;
@@ -161,8 +190,8 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
     };
     // item -> (phase, chunk); issue the DMA of one item's A tile and weight chunk into buffer `buf`
     auto issue = [&](int tile, int item, int buf) {
-        const int ph = a.phase_sum ? item / nchunk : 0;
-        const int q = a.phase_sum ? item - ph * nchunk : item;
+        const int ph = psum ? item / nchunk : 0;
+        const int q = psum ? item - ph * nchunk : item;
         const bool first = q < a.nchunk1;
         if (q == 0 || q == a.nchunk1) setup(tile, first, ph);
         const unsigned char* src = reinterpret_cast<const unsigned char*>(first ? a.in1 : a.in2);
@@ -174,8 +203,21 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < C::NA; ++i)
             rcf_buffer_to_lds16(rsa, Ab + (i * 256 + wave_u * 64) * 16, pix[i], cbb);
-        const unsigned char* wsrc = wp + (size_t)ph * a.wp_phase_stride * 4 + (size_t)q * C::B_BYTES + lane * 16;
         unsigned char* Bb = smem_b + 2 * C::A_BYTES + buf * C::B_BYTES;
+        if constexpr (C::P4) {   // the chunk's block of each of the four phases, [phase][tap][co][16] in LDS
+            constexpr int KPP = C::NKB / 4;   // KiB per phase
+            static_assert(C::NKB % 4 == 0, "whole KiB per phase and wave");
+#pragma unroll
+            for (int i = 0; i < C::NKB / 4; ++i) {
+                const int kb = i * 4 + wave_u;
+                const int wph = kb / KPP, k = kb - wph * KPP;
+                const unsigned char* src = wp + (size_t)wph * a.wp_phase_stride * 4 + (size_t)q * (C::B_BYTES / 4) + k * 1024 + lane * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(Bb + kb * 1024), 16, 0, 0);
+            }
+            return;
+        }
+        const unsigned char* wsrc = wp + (size_t)ph * a.wp_phase_stride * 4 + (size_t)q * C::B_BYTES + lane * 16;
 #pragma unroll
         for (int i = 0; i < (C::NKB + 3) / 4; ++i) {
             int kb = i * 4 + wave_u;
@@ -213,17 +255,64 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
         RCF_TACC(1, t_w2, t_w1);   // 1: address arithmetic + DMA issue of the next item
         // phase_sum == 2 (the four output phases of an up-2x forward in one launch): every phase is a convolution of its own --
         // accumulators start at its first chunk, the epilogue runs at its last one and writes output pixels (2y + a, 2x + b)
-        const bool phase_out = a.phase_sum == 2;
+        const bool phase_out = psum == 2;
         const int oph = phase_out ? q / nchunk : 0;
         if (phase_out ? (q - oph * nchunk == 0) : (q == 0)) {
 #pragma unroll
-            for (int mi = 0; mi < C::MT; ++mi)
+            for (int pi = 0; pi < C::NPH; ++pi)
 #pragma unroll
-                for (int ni = 0; ni < C::NT; ++ni)
+                for (int mi = 0; mi < C::MT; ++mi)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+                    for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[pi][mi][ni][r] = 0.f;
         }
-        {
+        if constexpr (C::P4) {
+            const unsigned char* Ab = smem_b + buf * C::A_BYTES;
+            const unsigned char* Bb = smem_b + 2 * C::A_BYTES + buf * C::B_BYTES;
+            constexpr P4Tab TB = rcf_p4_tab();
+            constexpr int MN = C::MT * C::NT;
+            bf16x8 av[2][C::MT], bv[2][C::NT];
+#pragma unroll
+            for (int mi = 0; mi < C::MT; ++mi) av[0][mi] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ab + a_off(mi, 0, 0)));
+#pragma unroll
+            for (int ni = 0; ni < C::NT; ++ni) bv[0][ni] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bb + (TB.t16[0] * C::BN + ni * 32) * 32 + bbase));
+            __builtin_amdgcn_sched_barrier(0);
+            int as = 0;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int bs = s & 1;
+                const bool has_next = s + 1 < 16;
+                const int npos = TB.pos[has_next ? s + 1 : s], nt16 = TB.t16[has_next ? s + 1 : s];
+                const bool new_a = has_next && npos != TB.pos[s];
+                const int nas = new_a ? as ^ 1 : as;
+                const int pi = TB.t16[s] >> 2;
+                const int NRD = has_next ? C::NT + (new_a ? C::MT : 0) : 0;
+                int nr = 0;
+#pragma unroll
+                for (int j = 0; j < MN; ++j) {
+                    const int mi = j / C::NT, ni = j % C::NT;
+                    acc[pi][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[as][mi], bv[bs][ni], acc[pi][mi][ni], 0, 0, 0);
+#pragma unroll
+                    for (int rep = 0; rep < 3; ++rep) {
+                        if (nr < NRD && (MN == 1 || nr * (MN - 1) < (j + 1) * NRD)) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            // read order: the weights of the next product first (always needed), then the A tiles of a new position
+                            if (nr < C::NT) {
+                                bv[bs ^ 1][nr] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bb + (nt16 * C::BN + nr * 32) * 32 + bbase));
+                            } else {
+                                const int rmi = nr - C::NT;
+                                av[nas][rmi] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ab + a_off(rmi, npos / 3, npos % 3)));
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            ++nr;
+                        }
+                    }
+                }
+                as = nas;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
             const unsigned char* Ab = smem_b + buf * C::A_BYTES;
             const unsigned char* Bb = smem_b + 2 * C::A_BYTES + buf * C::B_BYTES;
             bf16x8 av[2][C::MT], bv[2][C::NT];
@@ -253,7 +342,7 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < MN; ++j) {
                     const int mi = j / C::NT, ni = j % C::NT;
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][mi], bv[cur][ni], acc[mi][ni], 0, 0, 0);
+                    acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][mi], bv[cur][ni], acc[0][mi][ni], 0, 0, 0);
                     if (has_next) {
 #pragma unroll
                         for (int rep = 0; rep < 3; ++rep) {
@@ -279,7 +368,129 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
         RCF_T(t_w3);
         RCF_TACC(2, t_w3, t_w2);   // 2: accumulator init + MFMAs + LDS reads
         if (phase_out ? (q - oph * nchunk == nchunk - 1) : (q == nitem - 1)) {
-            const int e_ooy = phase_out ? (oph >> 1) : a.ooy, e_oox = phase_out ? (oph & 1) : a.oox;
+          // P4: the four phases' outputs of the tile.  Phases (a, 0) and (a, 1) hold the two halves of the same output row's pixel
+          // pairs (2x, 2x + 1), so they are stored TOGETHER: lanes li (even) and li + 1 exchange one value per accumulator row -- the
+          // even lane stores channels (co, co + 1) of phase (a, 0)'s pixel, the odd lane those of phase (a, 1)'s -- and the 32 lanes
+          // of a row block write 128 contiguous bytes (with 32 output channels), like a stride-1 layer's store.  (Phase by phase every
+          // store wrote 64-byte halves of four lines: 42 % of the wave time sat in the epilogue, tools/up2x_bench.py.)
+          auto p4_epilogue = [&]() __attribute__((always_inline)) {
+            if constexpr (C::P4) {
+            int t = tile;
+            const int tx = t % a.tiles_x;
+            t /= a.tiles_x;
+            const int ty = t % a.tiles_y;
+            const int img = t / a.tiles_y;
+            const int oy0 = ty * C::TH, ox0 = tx * C::PX;
+            const bool want_stats = !EPI && a.stats != nullptr;
+            const int odd = li & 1;
+            float eb[C::NT][2];
+            if (EPI) {
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni) {
+                    const int cp = (n0 + ni * 32 + li) & ~1;
+                    eb[ni][0] = a.bias[cp < a.c_out ? cp : 0];
+                    eb[ni][1] = a.bias[cp + 1 < a.c_out ? cp + 1 : 0];
+                }
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni) asm volatile("" : "+v"(eb[ni][0]), "+v"(eb[ni][1]));
+            }
+            int fim = img;
+            if (a.vt) {
+                fim = (int)(((float)oy0 + 0.5f) * a.inv_hp);
+                fim = fim < a.nimg ? fim : a.nimg - 1;
+            }
+            fim = __builtin_amdgcn_readfirstlane(fim);
+            const size_t img_b = (size_t)a.ohp * a.owp * a.c_out * 2;           // bytes per image
+            const unsigned pixb = (unsigned)a.c_out * 2u;                       // bytes per output pixel
+            const unsigned rowb = (unsigned)a.owp * pixb;                       // bytes per output row
+            const unsigned pstep = 2u * pixb;                                   // bytes between the pixel pairs of neighbouring x
+            unsigned char* outb = reinterpret_cast<unsigned char*>(a.out);
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(outb + (size_t)fim * img_b, 0, 0x7fffffff, 0x00020000);
+            const int wlim = a.w_out - ox0;   // (the physical width is 2 w_out: valid_desc)
+            const unsigned xoff = (unsigned)(2 * ox0) * pixb + (unsigned)n0 * 2u;
+            // per lane: byte offset of its dword inside a row block (column 4 lh of x, pixel 2x + odd, channel pair li & ~1)
+            unsigned l0 = (unsigned)(4 * lh) * pstep + (unsigned)odd * pixb + (unsigned)(li & ~1) * 2u;
+            int cl[C::NT];
+#pragma unroll
+            for (int ni = 0; ni < C::NT; ++ni) cl[ni] = (((n0 + ni * 32 + li) & ~1) < a.c_out) ? wlim - 4 * lh : 0;
+            asm volatile("" : "+v"(l0));
+            auto pair_rows = [&](auto a_tag, auto stats_tag) __attribute__((always_inline)) {
+                constexpr int A = decltype(a_tag)::value;
+                constexpr bool STATS = decltype(stats_tag)::value;
+                constexpr int RPB = 16 / C::PY;   // accumulator rows per tile row
+#pragma unroll
+                for (int mi = 0; mi < C::MT; ++mi) {
+                    float s1[C::NT][2], s2[C::NT][2];
+#pragma unroll
+                    for (int ni = 0; ni < C::NT; ++ni) { s1[ni][0] = s1[ni][1] = 0.f; s2[ni][0] = s2[ni][1] = 0.f; }
+#pragma unroll
+                    for (int rq = 0; rq < C::PY; ++rq) {
+                        int oy = oy0 + (wave_u * C::MT + mi) * C::PY + rq;
+                        int im = img;
+                        bool rok = true;
+                        if (a.vt) {
+                            im = (int)(((float)oy + 0.5f) * a.inv_hp);
+                            oy -= im * a.hp;
+                            rok = im < a.nimg;
+                        }
+                        const int py = 2 * oy + A;
+                        rok = rok && oy < a.h_out && py < a.ohp;
+                        const unsigned rowoff = __builtin_amdgcn_readfirstlane((unsigned)((im - fim) * a.ohp + py) * rowb + xoff);
+                        if (__builtin_amdgcn_readfirstlane((int)rok)) {
+#pragma unroll
+                            for (int ni = 0; ni < C::NT; ++ni) {
+#pragma unroll
+                                for (int k = 0; k < RPB; ++k) {
+                                    const int r = rq * RPB + k;                       // accumulator row: x column 8 (r >> 2) + (r & 3) + 4 lh
+                                    const int cc = (8 * (r >> 2)) % C::PX + (r & 3);
+                                    const unsigned so = rowoff + (unsigned)cc * pstep;
+                                    const bool ok = cc < cl[ni];
+                                    unsigned lv = l0;
+                                    asm volatile("" : "+v"(lv));   // (or hipcc keeps the 16 x NT offsets of a row block live across the whole epilogue)
+                                    const unsigned vo = ok ? lv + (unsigned)(ni * 64) : 0xffffffffu;
+                                    const float b0 = acc[2 * A][mi][ni][r], b1 = acc[2 * A + 1][mi][ni][r];
+                                    const float mine = odd ? b1 : b0;                                 // my channel at my pixel (2x + odd)
+                                    const float give = odd ? b0 : b1;                                 // my channel at the partner's pixel
+                                    const float got = __uint_as_float(rcf_dpp_u32<0xB1>(__float_as_uint(give)));   // partner's channel at my pixel
+                                    float lo = odd ? got : mine, hi = odd ? mine : got;               // channels cp, cp + 1
+                                    if constexpr (EPI) {
+                                        lo = rcf_lrelu(lo + eb[ni][0]);
+                                        hi = rcf_lrelu(hi + eb[ni][1]);
+                                    }
+                                    const unsigned pk = rcf_f2b2(lo, hi);
+                                    __builtin_amdgcn_raw_buffer_store_b32(pk, rs_out, vo, so, 0);
+                                    if constexpr (STATS) {   // of the values the tensor holds
+                                        const float rlo = ok ? __uint_as_float(pk << 16) : 0.f, rhi = ok ? __uint_as_float(pk & 0xffff0000u) : 0.f;
+                                        s1[ni][0] += rlo; s2[ni][0] += rlo * rlo;
+                                        s1[ni][1] += rhi; s2[ni][1] += rhi * rhi;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if constexpr (STATS) {
+#pragma unroll
+                        for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) { st1[ni][e] += (double)s1[ni][e]; st2[ni][e] += (double)s2[ni][e]; }
+                    }
+                }
+            };
+            if constexpr (EPI || BST) {
+                pair_rows(std::integral_constant<int, 0>{}, std::false_type{});
+                pair_rows(std::integral_constant<int, 1>{}, std::false_type{});
+            } else if (want_stats) {
+                pair_rows(std::integral_constant<int, 0>{}, std::true_type{});
+                pair_rows(std::integral_constant<int, 1>{}, std::true_type{});
+            } else {
+                pair_rows(std::integral_constant<int, 0>{}, std::false_type{});
+                pair_rows(std::integral_constant<int, 1>{}, std::false_type{});
+            }
+            }
+          };
+          // one output tile of accumulator set PI at output offset (e_ooy, e_oox)
+          auto tile_epilogue = [&](auto ph_tag, const int e_ooy, const int e_oox) __attribute__((always_inline)) {
+            constexpr int PI = decltype(ph_tag)::value;
             // ---- epilogue.  Lane (li, lh) holds channel co = n0 + ni * 32 + li of 16 pixels per accumulator.  Lanes li (even) and
             // li + 1 exchange one value per pixel pair: the even lane stores channels (co, co + 1) of the pair's first pixel, the odd
             // lane those of the second pixel -- one dword (two bf16) per lane and pixel pair.
@@ -407,7 +618,7 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                                     const unsigned vo = ok ? lv + (unsigned)(ni * 64) : 0xffffffffu;
                                     // (static register indices + a select: indexing the accumulator with the lane-dependent `odd` makes
                                     // hipcc walk all 16 registers with compare/select pairs -- 60 VALU instructions per value)
-                                    const float a0 = acc[mi][ni][rj], a1 = acc[mi][ni][rj + 1];
+                                    const float a0 = acc[PI][mi][ni][rj], a1 = acc[PI][mi][ni][rj + 1];
                                     const float mine = odd ? a1 : a0;                                 // my channel at my pixel
                                     const float give = odd ? a0 : a1;                                 // my channel at the partner's pixel
                                     const float got = __uint_as_float(rcf_dpp_u32<0xB1>(__float_as_uint(give)));   // partner's channel at my pixel
@@ -463,6 +674,9 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                 if (want_stats) epilogue(std::false_type{}, std::true_type{});
                 else epilogue(std::false_type{}, std::false_type{});
             }
+          };
+          if constexpr (C::P4) p4_epilogue();
+          else tile_epilogue(std::integral_constant<int, 0>{}, phase_out ? (oph >> 1) : a.ooy, phase_out ? (oph & 1) : a.oox);
         }
         RCF_T(t_w4);
         RCF_TACC(3, t_w4, t_w3);   // 3: epilogue

@@ -2393,6 +2393,7 @@ struct Sel {
     int npl;     // operand planes of a split kernel: 3 (exact fp32), 2 (RCF_PREC_F16X2), 1 (bf16)
     int dma;     // bf16 tensors, channel counts multiples of 16: conv_b16_kernel (operands reach LDS by DMA, rcf_conv_b16_dma.h)
     int pw;      // bf16 tensors, 1x1, <= 64 input and <= 128 output channels: conv1x1_b16_kernel (operands straight from global memory)
+    int p4;      // phase_sum == 2 on conv_b16_kernel: the four output phases from one staged tile (DmaCfg<..., P4 = true>)
 };
 
 int num_cus() {
@@ -2420,6 +2421,10 @@ using D2_2_32 = DmaCfg<2, 2, 32, 2>;
 using D2_2_16 = DmaCfg<2, 2, 16, 2>;
 using D2_1_32 = DmaCfg<2, 1, 32, 2>;
 using D2_1_16 = DmaCfg<2, 1, 16, 2>;
+// up-2x forward, four phases from one tile: 256 pixels x 32 co x 4 phases per workgroup, or 128 pixels x 64 co (the four accumulator
+// sets are 128 registers either way).  32-pixel tile rows only: the 16-pixel form (per-read LDS addresses) spills
+using D2P4_1_32 = DmaCfg<2, 1, 32, 2, 1, true>;
+using D2P4_2_32 = DmaCfg<2, 2, 32, 1, 1, true>;
 using D3S2_2_32 = DmaCfg<3, 2, 32, 1, 2>;   // stride 2: 128-pixel tiles (the 65 x 9 halo tile is 18 KB per buffer)
 using D3S2_2_16 = DmaCfg<3, 2, 16, 1, 2>;
 using D3S2_1_32 = DmaCfg<3, 1, 32, 1, 2>;
@@ -2753,6 +2758,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     s->npl = 3;
     s->dma = 0;
     s->pw = 0;
+    s->p4 = 0;
 #if !RCF_CONV_B16
     {   // fp32 tensors, two fp16 planes: the streaming 1x1 kernel (conv1x1_f16x2_kernel; RCF_F32_PW=0 keeps the f32-MFMA kernel)
         const char* e = getenv("RCF_F32_PW");
@@ -2797,6 +2803,9 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
 #if RCF_CONV_B16
         const char* e = getenv("RCF_B16_DMA");
         s->dma = (s->bf16 && d->c1 % 16 == 0 && d->c2 % 16 == 0 && (e == nullptr || e[0] != '0')) ? 1 : 0;
+        // RCF_UP2X_MERGED=0: the four phases back to back, each staging its own tile (round 4's one-launch form), for an A/B
+        static const int merged = [] { const char* m = getenv("RCF_UP2X_MERGED"); return m ? atoi(m) : 1; }();
+        s->p4 = (s->dma && d->phase_sum == 2 && merged) ? 1 : 0;
 #endif
     }
     if (s->kind == K4S1) {
@@ -2808,10 +2817,12 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     const bool vt_ok = vt_allowed(d);
     const int pxs[3] = {32, 16, 8};
     // pixels per workgroup tile: 256; 512 for the 32-co 3x3 split layers; 128 for the three-plane stride-2 split kernel
-    const int tile_px = (s->split && s->kind == K3S2 && (!s->bf16 || s->dma)) ? 128 : ((s->split && s->nt == 1 && s->kind == K3S1 && !s->small) ? 512 : 256);
+    const int tile_px = ((s->split && s->kind == K3S2 && (!s->bf16 || s->dma)) || (s->p4 && s->nt == 2)) ? 128 :
+                        ((s->split && s->nt == 1 && s->kind == K3S1 && !s->small) ? 512 : 256);
     for (int i = 0; i < 3; ++i) {
         const int px = pxs[i], th = tile_px / px;
         if (px == 8 && (s->split || !(s->kind == K3S1 && s->ck == 16))) continue;
+        if (s->p4 && px != 32) continue;
         for (int vt = 0; vt <= (vt_ok ? 1 : 0); ++vt) {
             const double e = vt ? tile_eff_vt(d->w_out, d->h_out, d->n, px, th) : tile_eff(d->w_out, d->h_out, px, th);
             if (e > best + 1e-9) { best = e; s->px = px; s->vt = vt; }
@@ -2901,6 +2912,7 @@ int dispatch_fwd(const Sel& s, F&& f) {
 template <class F>
 int dispatch_dma(const Sel& s, F&& f) {
     const bool p16 = s.px == 16;
+    if (s.kind == K2S1 && s.p4) return s.nt == 1 ? f(Tag<D2P4_1_32>{}) : f(Tag<D2P4_2_32>{});
     if (s.kind == K2S1) {
         if (s.nt == 1) return p16 ? f(Tag<D2_1_16>{}) : f(Tag<D2_1_32>{});
         return p16 ? f(Tag<D2_2_16>{}) : f(Tag<D2_2_32>{});

@@ -263,6 +263,46 @@ def test_input_gradient_kernel_takes_the_batchnorm_backward_sums_bf16_tensors(op
     assert float(((s_new - s_ref).abs() / mag).max()) < 1e-6
 
 
+@pytest.mark.parametrize('c1,co,h,w', [(64, 32, 35, 51), (64, 64, 29, 50), (128, 64, 15, 25), (16, 32, 40, 18), (32, 64, 9, 70), (256, 128, 8, 13)])
+def test_up2x_forward_four_phases_from_one_staged_tile(ops, c1, co, h, w):
+    '''rcf_conv_desc.phase_sum == 2 on bf16 tensors (conv_b16_kernel<DmaCfg<2, ., ., ., 1, true>>): x staged once per channel chunk,
+    the 16 (phase, tap) products into four accumulator sets.  Bitwise the four per-phase launches (same products in the same order
+    per phase), statistics of the whole output; 32- and 64-channel n-tiles, 32- and 16-pixel tile rows, ragged edges.'''
+    from rcf_amd._lib import RCF_PHASE_UP2X_FWD
+    ops.set_precision('bf16')
+    n = 2
+    x = b16(rnd(n, c1, h, w, seed=11))
+    wt = rnd(co, c1, 3, 3, seed=12, scale=1.0 / np.sqrt(c1 * 9))
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2), wt.double(), padding=1)
+    wp = ops.phase_weights(wt.cuda(), RCF_PHASE_UP2X_FWD)
+    xg = nhwc_b(x)
+    z = torch.full((n, 2 * h, 2 * w, co), float('nan'), device='cuda').bfloat16()
+    for ph in range(4):
+        d = ops.make_up2x_fwd_desc(n, h, w, c1, co, ph >> 1, ph & 1)
+        info = ops.conv_query(d)
+        packed = torch.empty(info.packed_weight_floats, device='cuda')
+        ops.conv_pack(d, wp[ph], packed)
+        ops.conv_fwd(d, xg, None, packed, z, None)
+    dm = ops.make_up2x_fwd_desc(n, h, w, c1, co, 0, 0, phase_out=True)
+    im = ops.conv_query(dm)
+    pm = torch.empty(4 * im.packed_weight_floats, device='cuda')
+    for ph in range(4):
+        ops.conv_pack(dm, wp[ph], pm[ph * im.packed_weight_floats:(ph + 1) * im.packed_weight_floats])
+    z1 = torch.full((n, 2 * h, 2 * w, co), float('nan'), device='cuda').bfloat16()
+    part = torch.full((im.n_partials, 2, co), float('nan'), device='cuda', dtype=torch.float64)
+    ops.conv_fwd(dm, xg, None, pm, z1, part)
+    z2 = torch.full((n, 2 * h, 2 * w, co), float('nan'), device='cuda').bfloat16()
+    ops.conv_fwd(dm, xg, None, pm, z2, None)      # without statistics
+    torch.cuda.synchronize()
+    assert not torch.isnan(z1.float()).any()
+    assert torch.equal(z1, z) and torch.equal(z2, z)
+    e = float((nchw(z1).double() - ref).abs().max() / ref.abs().max())
+    assert e < 3 * BF16_EPS, e
+    st = part.sum(0).cpu()
+    np.testing.assert_allclose(st[0].numpy(), nchw(z).double().sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-3)
+    np.testing.assert_allclose(st[1].numpy(), (nchw(z).double() ** 2).sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-3)
+
+
 def test_phase_convolutions_bf16_tensors(ops):
     '''Exact-2x UpConv as four 2x2 phase convolutions, its merged-phase input gradient and its weight gradient on bf16 tensors,
     against the 9-tap reference (phase weights are pre-summed in fp32 and then rounded once: 1 extra bf16 ulp of slack).'''

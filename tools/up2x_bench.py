@@ -1,0 +1,78 @@
+'''Micro-benchmark (GPU box): the exact-2x up-convolutions of the decoder (conv3x3 of a nearest-upsampled x as four 2x2 phase
+convolutions), forward, through the C ABI -- the four per-phase launches against the one-launch form (rcf_conv_desc.phase_sum == 2).
+usage: [RCF_BENCH_PREC=f16x2|fp32|bf16] [RCF_UP2X_MERGED=0|1] python tools/up2x_bench.py [batch] [reps]'''
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import rcf_amd  # noqa: F401
+from rcf_amd import ops
+from rcf_amd._lib import RCF_PHASE_UP2X_FWD
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+ops.set_precision(os.environ.get('RCF_BENCH_PREC', 'bf16'))
+ADT = ops.act_dtype()
+eb = 2 if ADT == torch.bfloat16 else 4
+LAYERS = [(64, 32, 450, 800), (64, 64, 225, 400), (128, 64, 113, 200), (256, 128, 57, 100), (256, 256, 29, 50)]
+
+
+def timeit(fn):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+print('%-26s | %10s %8s | %10s %8s | bitwise' % ('up-2x forward, batch %d' % n, '4 launches', 'TB/s', '1 launch', 'TB/s'))
+for c1, co, h, w in LAYERS:
+    x = torch.randn(n, h, w, c1, device='cuda').to(ADT)
+    wt = torch.randn(co, c1, 3, 3, device='cuda') * 0.05
+    wp = ops.phase_weights(wt, RCF_PHASE_UP2X_FWD)
+    amax = x.float().abs().max().reshape(1) if ops.get_precision() == ops._lib.RCF_PREC_F16X2 else None
+    z4 = torch.empty(n, 2 * h, 2 * w, co, device='cuda', dtype=ADT)
+    z1 = torch.empty_like(z4)
+    descs, packs = [], []
+    for ph in range(4):
+        d = ops.make_up2x_fwd_desc(n, h, w, c1, co, ph >> 1, ph & 1)
+        info = ops.conv_query(d)
+        p = torch.empty(info.packed_weight_floats, device='cuda')
+        ops.conv_pack(d, wp[ph], p)
+        descs.append(d); packs.append(p)
+    part4 = torch.empty(4 * info.n_partials, 2, co, device='cuda', dtype=torch.float64)
+    npart = info.n_partials
+    wmax = wp.abs().max().reshape(1) if amax is not None else None
+    kw = {} if amax is None else {'scales': ops.make_scales(amax, None, wmax)}
+
+    def four():
+        for ph in range(4):
+            ops.conv_fwd(descs[ph], x, None, packs[ph], z4, part4[ph * npart:(ph + 1) * npart], **kw)
+    dm = ops.make_up2x_fwd_desc(n, h, w, c1, co, 0, 0, phase_out=True)
+    try:
+        im = ops.conv_query(dm)
+    except Exception as e:
+        print('%3d->%3d @ %3dx%3d: one-launch form refused (%s)' % (c1, co, h, w, str(e)[:60]))
+        continue
+    pm = torch.empty(4 * im.packed_weight_floats, device='cuda')
+    for ph in range(4):
+        ops.conv_pack(dm, wp[ph], pm[ph * im.packed_weight_floats:(ph + 1) * im.packed_weight_floats])
+    part1 = torch.empty(im.n_partials, 2, co, device='cuda', dtype=torch.float64)
+    one = lambda: ops.conv_fwd(dm, x, None, pm, z1, part1, **kw)
+    t4, t1 = timeit(four), timeit(one)
+    gb = (x.numel() + z4.numel()) * eb / 1e9
+    print('%3d->%3d @ %3dx%3d %8.2f GB | %8.1f us %8.2f | %8.1f us %8.2f | %s' % (c1, co, h, w, gb, 1000 * t4, gb / t4, 1000 * t1, gb / t1,
+                                                                                bool(torch.equal(z1, z4))))
+    if 'timing' in os.environ.get('RCF_HIP_LIB', ''):   # the -DRCF_PHASE_TIMING build (tools/phase_timing.py): where the waves' cycles go
+        import ctypes
+        lib = ops._lib.load()
+        fn = lib.rcf_debug_phase_cycles_b16impl if ADT == torch.bfloat16 else lib.rcf_debug_phase_cycles
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        buf = (ctypes.c_ulonglong * 8)()
+        fn(None, 1)
+        for _ in range(reps):
+            one()
+        fn(buf, 1)
+        print('      one launch, %% of wave cycles: ' + '  '.join('[%d] %.1f' % (i, 100.0 * buf[i] / buf[7]) for i in range(7)))
