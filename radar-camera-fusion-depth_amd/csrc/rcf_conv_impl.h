@@ -525,13 +525,23 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // against fp64 at or below the exact f32-MFMA kernel's error (tests/test_hip_f16x2.py), half the matrix work of the three-plane split.
 // LSTEP_ = 2: stride-2 convolution -- the halo tile holds EVERY input pixel under the tile (a 3-tap kernel at stride 2 touches them
 // all) and neighbouring output pixels read halo pixels two apart; everything else (weights, epilogue) is the stride-1 kernel.
-template <int KS_, int NT_, int PX_, int MT_ = 0, int NPL_ = 3, int LSTEP_ = 1>
+// P4_ (KS_ = 2, two planes): the four OUTPUT phases of an up-2x forward (rcf_conv_desc.phase_sum == 2) from ONE staged tile.  Phase
+// (a, b) is a 2x2 convolution of x with pad (1 - a, 1 - b): the four phases of an output tile read the same 3x3-halo tile of x, so it
+// is loaded, split and written to LDS ONCE per channel chunk (halo geometry GK = 3) and the chunk's eight (phase, kernel row) weight
+// pieces -- the per-phase packed layout as it is -- run over it into four accumulator sets, in the per-phase order (chunk, row, tap):
+// bitwise the four per-phase launches, a quarter of their loads and conversions.
+template <int KS_, int NT_, int PX_, int MT_ = 0, int NPL_ = 3, int LSTEP_ = 1, bool P4_ = false>
 struct SplitCfg {
+    static constexpr bool P4 = P4_;
+    static_assert(!P4_ || (KS_ == 2 && LSTEP_ == 1 && NPL_ == 2), "P4 is the up-2x forward on two planes: 2x2 taps, stride 1");
     static constexpr int NPL = NPL_, NP = NPL_ == 3 ? 6 : (NPL_ == 2 ? 3 : 1);   // operand planes, partial products per MAC
     static constexpr int KSY = KS_, KSX = KS_, T = KS_ * KS_, LSTEP = LSTEP_, CK = 16, CST = 16;
+    static constexpr int GK = P4_ ? 3 : KS_;           // halo geometry
+    static constexpr int NPH = P4_ ? 4 : 1;            // accumulator sets
+    static constexpr int NROW = P4_ ? 8 : KS_;         // barrier intervals (weight pieces) per chunk
     static constexpr int NT = NT_, BN = 32 * NT_;
     static constexpr int PX = PX_, PY = 32 / PX_, MT = MT_ ? MT_ : ((NT_ == 1 && KS_ == 3) ? 4 : 2), NW = 4, TH = PY * MT * NW;   // 3x3 32-co layers: 512-pixel tiles (2x2 phases: measured 10 % slower with them)
-    static constexpr int HXP = (PX - 1) * LSTEP + KS_, HYP = (TH - 1) * LSTEP + KS_, NPIX = HXP * HYP;
+    static constexpr int HXP = (PX - 1) * LSTEP + GK, HYP = (TH - 1) * LSTEP + GK, NPIX = HXP * HYP;
     // A-tile layout in LDS (one plane).  HP (stride 1; three planes: 32-pixel rows only, the padded 16-pixel form does not fit the LDS):
     // [halo row][channel half][halo x][16 B].  The 32 lanes of an MFMA row block read consecutive pixels of one half of one or two
     // halo rows, 16 B apart -- conflict-free (for 16-pixel rows the row pitch is padded to a multiple of 16 slots so that the second
@@ -626,10 +636,11 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
     };
     const int bbase = li * 32 + ((lh ^ ((li >> 3) & 1)) * 16);   // row co = ni*32 + li; (ni*32) keeps (co>>3)&1 == (li>>3)&1
 
-    f32x16 acc[C::MT][C::NT];
+    f32x16 acc[C::NPH][C::MT][C::NT];
     const int nchunk = a.nchunk1 + a.nchunk2;
     const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.wp) + (size_t)blockIdx.y * nchunk * C::WCHUNK_BYTES;
     const int n0 = blockIdx.y * C::BN;
+    const int psum = C::P4 ? 0 : a.phase_sum;   // P4: one item per chunk, the phases live in the row loop
 
     // A staging: thread t owns channel quad t % 4 of halo pixels t / 4 + i * 64
     constexpr int NA = (C::NPIX + 63) / 64;
@@ -652,8 +663,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
         const int img = t / a.tiles_y;
         // phase_sum 1: the four INPUT phases of an up-2x input gradient summed; 2: the four OUTPUT phases of an up-2x forward, one after
         // the other on the same tile (pad 1 - a, 1 - b; the outputs go to (2y + a, 2x + b))
-        const int pa = a.phase_sum == 2 ? 1 - (ph >> 1) : (a.phase_sum ? (ph >> 1) : a.pad), pb = a.phase_sum == 2 ? 1 - (ph & 1) : (a.phase_sum ? (ph & 1) : a.pad_x);
-        const int ioy = a.phase_sum ? (ph >> 1) : a.ioy, iox = a.phase_sum ? (ph & 1) : a.iox;
+        const int pa = C::P4 ? 1 : (psum == 2 ? 1 - (ph >> 1) : (psum ? (ph >> 1) : a.pad)), pb = C::P4 ? 1 : (psum == 2 ? 1 - (ph & 1) : (psum ? (ph & 1) : a.pad_x));
+        const int ioy = psum ? (ph >> 1) : a.ioy, iox = psum ? (ph & 1) : a.iox;
         const int iy0 = ty * C::TH * C::LSTEP - pa;
         const int ix0 = tx * C::PX * C::LSTEP - pb;
         const int hs = first ? a.h1 : a.h_in, ws = first ? a.w1 : a.w_in;
@@ -704,12 +715,12 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
             else pix[i] = v >= 0 ? v * pixb + (tid & 3) * 16 : -1;   // (-1 = 0xffffffff: out of the descriptor's range)
         }
     };
-    const int nitem = a.phase_sum ? 4 * nchunk : nchunk;   // A tiles per output tile
+    const int nitem = psum ? 4 * nchunk : nchunk;   // A tiles per output tile
     // fp32 halo tile of one item -> registers.  Loads are unconditional from a clamped (always valid) address and zero-selected at
     // store time: a branch or a select behind each load makes the compiler wait for it before issuing the next.
     auto load_a = [&](int tile, int item) {
-        const int ph = a.phase_sum ? item / nchunk : 0;
-        const int q = a.phase_sum ? item - ph * nchunk : item;
+        const int ph = psum ? item / nchunk : 0;
+        const int q = psum ? item - ph * nchunk : item;
         const bool first = q < a.nchunk1;
         if (q == 0 || q == a.nchunk1) setup(tile, first, ph);
         const float* src = first ? a.in1 : a.in2;
@@ -809,15 +820,17 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
     // one kernel row of pre-split weights: straight copy global -> LDS piece `buf` by LDS-DMA (each wave instruction moves 1 KiB to a
     // wave-uniform LDS base + 16 B x lane; no staging registers, no ds_write).  hipcc drains vmcnt before the next barrier.
     auto chunk_base = [&](int item) -> const unsigned char* {
-        const int ph = a.phase_sum ? item / nchunk : 0;
-        const int q = a.phase_sum ? item - ph * nchunk : item;
+        const int ph = psum ? item / nchunk : 0;
+        const int q = psum ? item - ph * nchunk : item;
         return wp + (size_t)ph * a.wp_phase_stride * 4 + (size_t)q * C::WCHUNK_BYTES;
     };
+    // (P4: row R of a chunk is kernel row R & 1 of phase R >> 1, each phase's packed weights where the per-phase launches read them)
     auto copy_b = [&](const unsigned char* cbase, int ky, int buf) {
         constexpr int NKB = C::B_PIECE_BYTES / 1024;
         static_assert(C::B_PIECE_BYTES % 1024 == 0, "weight piece must be whole KiB");
         const int w = __builtin_amdgcn_readfirstlane(wave);
-        const unsigned char* wsrc = cbase + (size_t)ky * C::B_PIECE_BYTES + lane * 16;
+        const unsigned char* wsrc = (C::P4 ? cbase + (size_t)(ky >> 1) * a.wp_phase_stride * 4 + (size_t)(ky & 1) * C::B_PIECE_BYTES
+                                           : cbase + (size_t)ky * C::B_PIECE_BYTES) + lane * 16;
 #pragma unroll
         for (int i = 0; i < (NKB + 3) / 4; ++i) {
             int kb = i * 4 + w;
@@ -875,25 +888,29 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
         const unsigned char* cb_next = more ? chunk_base(nq) : wp;
         // phase_sum == 2 (the four output phases of an up-2x forward in one launch): every phase is a convolution of its own --
         // accumulators start at its first chunk, the epilogue runs at its last one and writes output pixels (2y + a, 2x + b)
-        const bool phase_out = a.phase_sum == 2;
+        const bool phase_out = psum == 2;
         const int oph = phase_out ? q / nchunk : 0;
         if (phase_out ? (q - oph * nchunk == 0) : (q == 0)) {
 #pragma unroll
-            for (int mi = 0; mi < C::MT; ++mi)
+            for (int pi = 0; pi < C::NPH; ++pi)
 #pragma unroll
-                for (int ni = 0; ni < C::NT; ++ni)
+                for (int mi = 0; mi < C::MT; ++mi)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+                    for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[pi][mi][ni][r] = 0.f;
         }
-#pragma unroll
-        for (int ky = 0; ky < C::KSY; ++ky) {
-            const bool last_row = ky == C::KSY - 1;
+        auto row_body = [&](const int ky) __attribute__((always_inline)) {
+            const bool last_row = ky == C::NROW - 1;
+            // P4: row ky = (phase, kernel row): accumulator set, and the halo row / first halo column its taps read
+            const int pi = C::P4 ? (ky >> 1) : 0;
+            const int hky = C::P4 ? (ky >> 2) + (ky & 1) : ky, hkx0 = C::P4 ? ((ky >> 1) & 1) : 0;
             // every row starts in register set 0: its A operands were fetched before the barrier that published its weights
             RCF_T(t_row0);
             fetch_b(0, 0, pb);
             if (!last_row) copy_b(cb_cur, ky + 1, pb ^ 1);   // nobody reads that slot during this row
             else if (more) copy_b(cb_next, 0, pb ^ 1);
-            if (ky == (C::KSY >= 2 ? C::KSY - 2 : 0) && more) load_a(ntile, nq);
+            if (ky == (C::NROW >= 2 ? C::NROW - 2 : 0) && more) load_a(ntile, nq);
             __builtin_amdgcn_sched_barrier(0);
             RCF_T(t_row1);
             RCF_TACC(0, t_row1, t_row0);   // 0: row prologue (first B reads, DMA / global-load issue)
@@ -914,7 +931,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                     constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};                    // two planes: a1b0, a0b1, a0b0
                     const int pj = j / MN, mi = (j % MN) / C::NT, ni = j % C::NT;
                     const int pa = C::NPL == 3 ? PA[pj] : (C::NPL == 2 ? PA2[pj % 3] : 0), pbl = C::NPL == 3 ? PB[pj] : (C::NPL == 2 ? PB2[pj % 3] : 0);
-                    acc[mi][ni] = rcf_mfma_split<C::NPL>(av[cur][pa][mi], bv[cur][pbl][ni], acc[mi][ni]);
+                    acc[pi][mi][ni] = rcf_mfma_split<C::NPL>(av[cur][pa][mi], bv[cur][pbl][ni], acc[pi][mi][ni]);
                     if (has_next) {
 #pragma unroll
                         for (int rep = 0; rep < 3; ++rep) {
@@ -922,7 +939,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                 __builtin_amdgcn_sched_barrier(0);
                                 if (nr < C::NPL * C::MT) {
                                     const int rmi = nr / C::NPL, pl = nr % C::NPL;
-                                    if (pl == 0) ao_next[rmi] = a_off(rmi, ky, kx + 1);
+                                    if (pl == 0) ao_next[rmi] = a_off(rmi, hky, hkx0 + kx + 1);
                                     av[cur ^ 1][pl][rmi] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + pl * C::A_PLANE_BYTES + ao_next[rmi]));
                                 } else {
                                     const int rb = nr - C::NPL * C::MT, pl = rb / C::NT, rni = rb % C::NT;
@@ -941,7 +958,10 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
             RCF_TACC(1, t_row2, t_row1);   // 1: the row's MFMAs + interleaved LDS reads
             if (last_row) {
                 if (phase_out ? (q - oph * nchunk == nchunk - 1) : (q == nitem - 1)) {
-                    const int e_ooy = phase_out ? (oph >> 1) : a.ooy, e_oox = phase_out ? (oph & 1) : a.oox;
+                  // one output tile of accumulator set PI at output offset (e_ooy, e_oox); P4 runs it once per phase (with 32 fp32
+                  // output channels a pixel is one 128-byte line: the strided phase stores are whole lines already)
+                  auto tile_epilogue = [&](auto ph_tag, const int e_ooy, const int e_oox) __attribute__((always_inline)) {
+                    constexpr int PI = decltype(ph_tag)::value;
                     int t = tile;
                     const int tx = t % a.tiles_x;
                     t /= a.tiles_x;
@@ -985,7 +1005,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
 #pragma unroll
                             for (int ni = 0; ni < C::NT; ++ni)
 #pragma unroll
-                                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = acc[mi][ni][r] * sc.ia * sc.ib;
+                                for (int r = 0; r < 16; ++r) acc[PI][mi][ni][r] = acc[PI][mi][ni][r] * sc.ia * sc.ib;
                     }
                     if constexpr (SO::B16) {   // bf16 tensors that cannot take the DMA kernel (rcf_conv_b16_dma.h): 2-byte stores, bounds per store
                     // (BST: taking a group's sums one group later -- z loads in flight behind the next group's stores -- was built and
@@ -1059,7 +1079,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
 #pragma unroll
                                     for (int j = 0; j < 4; ++j)
 #pragma unroll
-                                        for (int ni = 0; ni < C::NT; ++ni) acc[mi][ni][r0 + j] += old[j][ni];
+                                        for (int ni = 0; ni < C::NT; ++ni) acc[PI][mi][ni][r0 + j] += old[j][ni];
                                 }
                                 // Land the loads INSIDE this branch (training: by adding them into the accumulators here; inference: the
                                 // empty asm below uses the registers -- either way the s_waitcnt goes here).
@@ -1095,7 +1115,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
 #else
                                     if (pok[j] && co < a.c_out) {
 #endif
-                                        float v = acc[mi][ni][r0 + j];
+                                        float v = acc[PI][mi][ni][r0 + j];
                                         if (EPI) {
                                             v = rcf_lrelu(v + ebias[ni]);
                                             if (a.res != nullptr) v = rcf_lrelu(v + old[j][ni]);
@@ -1202,7 +1222,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                                             unsigned lv = l0;
                                             if constexpr (BST || ADD) asm volatile("" : "+v"(lv));   // (or the compiler keeps the eight offsets of the loads)
                                             const unsigned vo = cc < cl[ni] ? lv + (unsigned)(ni * 128) : 0xffffffffu;
-                                            float v = acc[mi][ni][r];
+                                            float v = acc[PI][mi][ni][r];
                                             if constexpr (EPI) {
                                                 v = rcf_lrelu(v + ebias[ni]);
                                                 if constexpr (ADD) v = rcf_lrelu(v + old[k]);
@@ -1238,6 +1258,15 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                         else epilogue(std::false_type{}, std::false_type{});
                     }
                     }
+                  };
+                  if constexpr (C::P4) {
+                      tile_epilogue(std::integral_constant<int, 0>{}, 0, 0);
+                      tile_epilogue(std::integral_constant<int, 1>{}, 0, 1);
+                      tile_epilogue(std::integral_constant<int, 2>{}, 1, 0);
+                      tile_epilogue(std::integral_constant<int, 3>{}, 1, 1);
+                  } else {
+                      tile_epilogue(std::integral_constant<int, 0>{}, phase_out ? (oph >> 1) : a.ooy, phase_out ? (oph & 1) : a.oox);
+                  }
                 }
                 RCF_T(t_e0);
                 RCF_TACC(2, t_e0, t_row2);     // 2: output epilogue (last chunk of a tile only)
@@ -1248,15 +1277,25 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                 RCF_T(t_e2);
                 RCF_TACC(4, t_e2, t_e1);       // 4: store_a (wait for the global loads, split, ds_write)
             } else {
-                fetch_a(ky + 1, 0, 0);   // next row's first A operands: the tile does not change inside a chunk
+                // next row's first A operands: the tile does not change inside a chunk
+                if constexpr (C::P4) fetch_a(((ky + 1) >> 2) + ((ky + 1) & 1), ((ky + 1) >> 1) & 1, 0);
+                else fetch_a(ky + 1, 0, 0);
             }
             RCF_T(t_b0);
             rcf_wait_dma();   // the next weight piece has landed
             __syncthreads();
             RCF_T(t_b1);
             RCF_TACC(last_row ? 5 : 6, t_b1, t_b0);   // 5: DMA wait + publishing barrier after store_a; 6: the same between rows
-            if (last_row && more) fetch_a(0, 0, 0);
+            if (last_row && more) fetch_a(0, 0, 0);   // (P4: row 0 is phase (0, 0), kernel row 0: halo (0, 0) too)
             pb ^= 1;
+        };
+        if constexpr (C::P4) {
+            // eight rows x four epilogues exceed hipcc's full-unroll budget, and a rolled row loop would index the accumulator sets
+            // dynamically (scratch): spelled out instead
+            row_body(0); row_body(1); row_body(2); row_body(3); row_body(4); row_body(5); row_body(6); row_body(7);
+        } else {
+#pragma unroll
+            for (int ky = 0; ky < C::NROW; ++ky) row_body(ky);
         }
         tile = ntile;
         q = nq;
@@ -2803,10 +2842,12 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
 #if RCF_CONV_B16
         const char* e = getenv("RCF_B16_DMA");
         s->dma = (s->bf16 && d->c1 % 16 == 0 && d->c2 % 16 == 0 && (e == nullptr || e[0] != '0')) ? 1 : 0;
-        // RCF_UP2X_MERGED=0: the four phases back to back, each staging its own tile (round 4's one-launch form), for an A/B
-        static const int merged = [] { const char* m = getenv("RCF_UP2X_MERGED"); return m ? atoi(m) : 1; }();
-        s->p4 = (s->dma && d->phase_sum == 2 && merged) ? 1 : 0;
 #endif
+        // the four output phases of an up-2x forward from one staged tile: conv_b16_kernel (bf16 tensors) and the two-plane
+        // conv_split_kernel (fp32 tensors).  RCF_UP2X_MERGED=0: the four phases back to back, each staging its own tile (round 4's
+        // one-launch form), for an A/B
+        static const int merged = [] { const char* m = getenv("RCF_UP2X_MERGED"); return m ? atoi(m) : 1; }();
+        s->p4 = (d->phase_sum == 2 && merged && (s->dma || (!s->bf16 && s->npl == 2))) ? 1 : 0;
     }
     if (s->kind == K4S1) {
         s->split = 1; s->ck = 16; s->cst = 16;
@@ -2939,6 +2980,10 @@ int dispatch_split_planes(const Sel& s, F&& f) {
     if (s.kind == K3S2) {
         if (s.nt == 1) return p16 ? f(Tag<SplitCfg<3, 1, 16, 1, NPL, 2>>{}) : f(Tag<SplitCfg<3, 1, 32, 1, NPL, 2>>{});
         return p16 ? f(Tag<SplitCfg<3, 2, 16, 1, NPL, 2>>{}) : f(Tag<SplitCfg<3, 2, 32, 1, NPL, 2>>{});
+    }
+    if (s.kind == K2S1 && s.p4) {   // (select_cfg: two planes, 32-pixel tile rows; 64 co: 128-pixel tiles -- four accumulator sets)
+        if constexpr (NPL == 2) return s.nt == 1 ? f(Tag<SplitCfg<2, 1, 32, 0, 2, 1, true>>{}) : f(Tag<SplitCfg<2, 2, 32, 1, 2, 1, true>>{});
+        else return RCF_EUNSUPPORTED;
     }
     if (s.kind == K2S1) {
         if (s.nt == 1) return p16 ? f(Tag<SplitCfg<2, 1, 16, 0, NPL>>{}) : f(Tag<SplitCfg<2, 1, 32, 0, NPL>>{});

@@ -229,10 +229,11 @@ class Engine(object):
         self.fuse_wp_one_pass = os.environ.get('RCF_FUSE_WP_ONE_PASS', '1') != '0'   # inference: the fusion in one kernel (bf16 tensors)
         self.prof = None           # optional KernelTimer: brackets conv launches with events on the launch stream
         self.use_phase_convs = True  # exact-2x UpConv and stride-2 dgrad as 2x2 phase convs (False: 9-tap / zero-insert forms)
-        # the four forward phases of an up-2x conv in ONE launch (rcf_conv_desc.phase_sum == 2).  Measured [r4], same box, whole step: bf16
-        # inference +1.7 %, bf16 training +0.5 % (x is re-read from L2 instead of HBM), fp32 training -0.6 % (its kernels are bound by
-        # board power, not by HBM: nothing to gain, and four short launches pack the chip's tail better than one long one) -- so: on for
-        # bf16 tensors, off for fp32 tensors; RCF_UP2X_ONE_LAUNCH=0/1 overrides
+        # the four forward phases of an up-2x conv in ONE launch (rcf_conv_desc.phase_sum == 2).  Round 5: the kernels stage x once per
+        # channel chunk and run all four phases from that tile (bf16 tensors: conv_b16_kernel; fp32 tensors on two fp16 planes:
+        # conv_split_kernel) -- a quarter of the loads (and, for fp32, of the plane conversions) of the four launches.  On for those two;
+        # the exact three-plane tier keeps the four launches (its one-launch form re-stages the tile per phase: measured slower in
+        # round 4).  RCF_UP2X_ONE_LAUNCH=0/1 overrides
         e = os.environ.get('RCF_UP2X_ONE_LAUNCH')
         self.up2x_one_launch = None if e is None else (e != '0')
         # BatchNorm + lrelu applied by the consuming split conv / wgrad kernels as they load z (rcf_conv2d_fwd_bn): saves the
@@ -658,14 +659,16 @@ class Engine(object):
         # the four phases in ONE launch (rcf_conv_desc.phase_sum == 2) where the layer runs on a split / DMA kernel: a workgroup runs the
         # four 2x2 convolutions of its tile back to back, so x comes from HBM once (the three re-reads hit L2) and three launches go;
         # the backward pass keeps the four per-phase descriptors (their weight gradients are four launches)
-        if self.up2x_one_launch if self.up2x_one_launch is not None else (ops.act_dtype() == torch.bfloat16):
+        if self.up2x_one_launch is not False:
             dm = ops.make_up2x_fwd_desc(n, h, w, c1, co, 0, 0, phase_out=True)
             if f16:
                 dm = self._exact_unless(dm, x.amax, None if fold is not None else 0)
-            try:
-                qm = ops.conv_query(dm)
-            except ops._lib.RcfError:
-                qm = None
+            qm = None
+            if self.up2x_one_launch or ops.act_dtype() == torch.bfloat16 or dm.precision == RCF_PREC_F16X2:
+                try:
+                    qm = ops.conv_query(dm)
+                except ops._lib.RcfError:
+                    qm = None
             if qm is not None:
                 return self._conv_up2x_merged(layer, x, dm, qm, want_stats, fold)
         for ph in range(4):

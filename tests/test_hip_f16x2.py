@@ -412,10 +412,12 @@ def test_precision_levels_are_distinct_and_ordered(ops):
     assert 100 * err['f16x2'] < err['bf16_operands'] < 1e-2
 
 
-@pytest.mark.parametrize('cin,cout,n,hs,ws', [(64, 32, 1, 35, 51), (64, 64, 2, 12, 20)])
+@pytest.mark.parametrize('cin,cout,n,hs,ws', [(64, 32, 1, 35, 51), (64, 64, 2, 12, 20), (128, 64, 2, 15, 25), (32, 64, 1, 9, 70), (256, 128, 1, 8, 13),
+                                              (16, 32, 2, 40, 18), (64, 32, 2, 64, 96)])
 def test_up2x_conv_as_four_phase_convs(ops, cin, cout, n, hs, ws):
     '''The exact-2x UpConv (nearest upsample + 3x3) as four 2x2 phase convolutions writing the strided output (RCF_PHASE_UP2X_FWD);
-    the four phases' pre-summed weights share one maximum.'''
+    the four phases' pre-summed weights share one maximum.  The one-launch form (conv_split_kernel<SplitCfg<2, ., 32, ., 2, 1, true>>:
+    x staged and split once per channel chunk, four accumulator sets) is bitwise the four launches.'''
     x = rnd(n, cin, hs, ws, seed=3)
     wt = rnd(cout, cin, 3, 3, seed=4, scale=1.0 / np.sqrt(cin * 9))
     ref = F.conv2d(F.interpolate(x.double(), scale_factor=2), wt.double(), padding=1)
