@@ -86,10 +86,13 @@ typedef struct rcf_conv_desc {
      * (a,b) with pad (a,b) -- the whole input gradient of an up-2x conv in ONE launch.  `packed` then holds the four
      * phases' packed weights back to back (each rcf_conv_info.packed_weight_floats long).
      * phase_sum == 2 (ksize 2, RCF_GATHER_DIRECT, out_stride 2, split / DMA kernels only): the four OUTPUT phases of an up-2x
-     * forward conv3x3(nearest_up2x(x)) (src/net_utils.py:156-198) in ONE launch -- a workgroup runs the four 2x2 phase convolutions
-     * of its tile one after the other (phase (a,b): pad (1-a, 1-b), outputs at (2y+a, 2x+b); pad / out_off_* of the descriptor
-     * are ignored), so x is fetched from HBM once and re-read from L2; `packed` holds the four phases' packed weights back to
-     * back; the BatchNorm statistics cover all four phases. */
+     * forward conv3x3(nearest_up2x(x)) (src/net_utils.py:156-198) in ONE launch (phase (a,b): pad (1-a, 1-b), outputs at
+     * (2y+a, 2x+b); pad / out_off_* of the descriptor are ignored): the 3x3-halo tile of x is staged once per channel chunk and all
+     * four 2x2 phase convolutions run from it (bf16 tensors; fp32 tensors under RCF_PREC_F16X2), bitwise the four per-phase launches;
+     * `packed` holds the four phases' packed weights back to back; the BatchNorm statistics cover all four phases.
+     * rcf_conv2d_wgrad on such a descriptor: the four phases' weight gradients in ONE launch, dw = [4][c_out][c_in][2][2] (what
+     * rcf_phase_wgrad_fold takes), bitwise the four per-phase calls; the four phases of a tile run on one XCD at the same time, so
+     * x is fetched from HBM once and from that L2 three times.  Split weight-gradient kernels only (RCF_EUNSUPPORTED otherwise). */
     int phase_sum;
     /* RCF_PREC_FP32 (0): fp32 results (the reference's arithmetic; f32 MFMA or the exact 3-plane bf16 split).
      * RCF_PREC_BF16 (1): operands rounded to bf16 (nearest even), fp32 accumulate; honoured by the split kernels, every other

@@ -1762,6 +1762,22 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
     const int ws = first ? a.w1 : a.w_in;
     const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
     const int co0 = blockIdx.z * C::NCO;
+    // slot of this workgroup (it owns tiles slot, slot + nslot, ... and one workspace row block) and the phase geometry.
+    // phase_sum == 2: the four phase weight gradients of an up-2x convolution in ONE launch -- workgroup (slot, phase) is an ordinary
+    // phase launch's workgroup (pad 1 - a, 1 - b on x; dz read at (2y + a, 2x + b)), and the four phases of a slot sit on the SAME XCD
+    // (blocks are dealt to the eight XCDs round-robin: block b -> XCD b % 8, phase (b / 8) % 4, slot b % 8 + 8 (b / 32)), working through
+    // the same x tiles at the same pace: x comes from HBM once and from that XCD's L2 three times instead of four times from HBM
+    int slot = blockIdx.x, nslot = gridDim.x;
+    int pad_y = a.pad, pad_x = a.pad_x, ooy = a.ooy, oox = a.oox;
+    int wslot = blockIdx.x;
+    if (a.phase_sum == 2) {
+        nslot = gridDim.x >> 2;
+        int ph;
+        if ((nslot & 7) == 0) { ph = (blockIdx.x >> 3) & 3; slot = (blockIdx.x & 7) + 8 * (blockIdx.x >> 5); }
+        else { ph = blockIdx.x & 3; slot = blockIdx.x >> 2; }
+        pad_y = 1 - (ph >> 1); pad_x = 1 - (ph & 1); ooy = ph >> 1; oox = ph & 1;
+        wslot = ph * nslot + slot;
+    }
 
     f32x16 acc[C::T];
 #pragma unroll
@@ -1803,7 +1819,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
         const int ty = t % a.tiles_y;
         const int img = t / a.tiles_y;
         const int oy0 = ty * C::TH, ox0 = tx * C::PX;
-        const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad_x;
+        const int iy0 = oy0 - pad_y, ix0 = ox0 - pad_x;
 #pragma unroll
         for (int i = 0; i < C::RX; ++i) {
             const int u = tid + 256 * i;
@@ -1856,13 +1872,13 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 oy -= im * a.hp;
                 if (im >= a.nimg) oy = a.h_out;
             }
-            const int py = FAST ? oy : oy * a.os + a.ooy;   // strided output rows/columns of the phase convolutions
+            const int py = FAST ? oy : oy * a.os + ooy;   // strided output rows/columns of the phase convolutions
             const bool rowok = u < C::NDU && dc < a.c_out && oy < a.h_out && py < a.ohp;
             const float* rowptr = rcf_at<SD>(a.dz, (size_t)(rowok ? (im * a.ohp + py) * a.owp : 0) * a.c_out + (rowok ? dc : 0));
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int ox = ox0 + 8 * g + j;
-                const int px = FAST ? ox : ox * a.os + a.oox;
+                const int px = FAST ? ox : ox * a.os + oox;
                 if constexpr (RAWD) rd[i][j] = *reinterpret_cast<const u32x2*>((rowok && ox < a.w_out && px < a.owp) ? rcf_at<SD>(rowptr, px * a.c_out) : a.zero);
                 else rd[i][j] = rcf_ld4<SD>((rowok && ox < a.w_out && px < a.owp) ? rcf_at<SD>(rowptr, px * a.c_out) : a.zero, 0);
             }
@@ -1881,7 +1897,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
         const int ty = t % a.tiles_y;
         const int img = t / a.tiles_y;
         const int oy0 = ty * C::TH, ox0 = tx * C::PX;
-        const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad_x;
+        const int iy0 = oy0 - pad_y, ix0 = ox0 - pad_x;
         const bool s2 = gmode == RCF_GATHER_STRIDED2;
         const int pm = s2 ? 2 : 1;                                      // source pixels per logical pixel
         const int ioy = s2 ? a.ioy : 0, iox = s2 ? a.iox : 0;
@@ -1943,7 +1959,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             const unsigned rowb = (unsigned)a.owp * pixb;
             const __amdgpu_buffer_rsrc_t rsd = rcf_rsrc(reinterpret_cast<const unsigned char*>(a.dz) + (size_t)fimg * a.ohp * rowb);
             int wl = a.w_out;
-            { const int wph = (a.owp - a.oox + a.os - 1) / a.os; wl = wl < wph ? wl : wph; }
+            { const int wph = (a.owp - oox + a.os - 1) / a.os; wl = wl < wph ? wl : wph; }
             const unsigned stepb = (unsigned)a.os * pixb;
 #pragma unroll
             for (int i = 0; i < C::RD; ++i) {
@@ -1956,11 +1972,11 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                     oy -= im * a.hp;
                     rowok = rowok && im < a.nimg;
                 }
-                const int py = oy * a.os + a.ooy;
+                const int py = oy * a.os + ooy;
                 rowok = rowok && oy < a.h_out && py < a.ohp;
                 const int lx0 = ox0 + 8 * g;
                 const unsigned lim = rowok ? (unsigned)wl : 0u;
-                const unsigned v0 = (unsigned)((im - fimg) * a.ohp + py) * rowb + (unsigned)(lx0 * a.os + a.oox) * pixb + (unsigned)(co0 + cq * 4) * SD::BYTES;
+                const unsigned v0 = (unsigned)((im - fimg) * a.ohp + py) * rowb + (unsigned)(lx0 * a.os + oox) * pixb + (unsigned)(co0 + cq * 4) * SD::BYTES;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const unsigned vo = (unsigned)(lx0 + j) < lim ? v0 + (unsigned)j * stepb : 0xffffffffu;
@@ -2067,7 +2083,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
     u32x4 dzv[2][NPL];         // [set][plane]
     u32x4 xs1[KS][NPL];        // kx = 1 operands of the current step
 
-    int tile = blockIdx.x;
+    int tile = slot;
 #ifdef RCF_PHASE_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
@@ -2084,7 +2100,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
         __syncthreads();
         RCF_T(t_g3);
         RCF_TACC(2, t_g3, t_g2);   // 2: publishing barrier
-        const int ntile = tile + gridDim.x;
+        const int ntile = tile + nslot;
         // (issuing these loads in slices between the MFMA steps below was tried twice -- as flat loads and, after the zero page
         // became a kernel argument, as global loads -- and is NOT faster: +-2 % with fp32 tensors, -6...-15 % with bf16 tensors)
         if (ntile < a.ntiles) load_tile(ntile);
@@ -2200,7 +2216,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
         }
     }
     if (wk == 0) {
-        float* wsp = a.ws + (size_t)blockIdx.x * a.ktot * a.cop;
+        float* wsp = a.ws + (size_t)wslot * a.ktot * a.cop;
         const int q32_0 = first ? 0 : (a.c1 + 31) / 32;   // 32-channel chunk index of this source's first chunk in k
         const int rdz = wj * 32 + li;
         const int co = co0 + (rdz % C::CQD) * 4 + rdz / C::CQD;
@@ -3550,6 +3566,17 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
     a.os = d->out_stride; a.ooy = d->out_off_y; a.oox = d->out_off_x; a.ohp = d->out_h_phys; a.owp = d->out_w_phys;
     a.ioy = d->in_off_y; a.iox = d->in_off_x;
     a.phase_sum = 0; a.wp_phase_stride = 0;
+    // phase_sum == 2 (the merged up-2x forward descriptor): the four phases' weight gradients in one launch of the split kernel, into
+    // dw[4][c_out][c_in][2][2]; each phase keeps its own workspace rows and its own reduction
+    int nslot4 = 0;
+    if (d->phase_sum == 2) {
+        if (!w.split || w.kind != K2S1) return RCF_EUNSUPPORTED;
+        nslot4 = w.nsplit / 4;
+        if (nslot4 >= 8) nslot4 &= ~7;   // whole rounds of the eight XCDs: the four phases of a slot share an XCD (its L2 holds their x tile)
+        if (nslot4 < 1) nslot4 = 1;
+        a.phase_sum = 2;
+        w.nsplit = 4 * nslot4;
+    }
     a.vt = w.vt; a.hp = d->h_out + 1; a.nimg = d->n; a.inv_hp = 1.0f / (float)(d->h_out + 1);
     a.sy = (float)d->h_src1 / (float)d->h_in;
     a.sx = (float)d->w_src1 / (float)d->w_in;
@@ -3615,6 +3642,13 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
     if (rc != RCF_OK) return rc;
     const int total = w.ktot * w.cop;
     const int ksx = w.kind == K7S2 ? 1 : d->ksize;
+    if (nslot4 > 0) {
+        for (int ph = 0; ph < 4; ++ph)
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, workspace + (size_t)ph * nslot4 * total,
+                               dw_oihw + (size_t)ph * d->c_out * (d->c1 + d->c2) * 4, nslot4, w.ktot, w.cop, d->c_out, d->c1, d->c2,
+                               w.nchunk1, w.t, ksx, 0);
+        return rcf_launch_status();
+    }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, workspace, dw_oihw, w.nsplit, w.ktot,
                        w.cop, d->c_out, d->c1, d->c2, w.nchunk1, w.t, ksx, w.kind == K7S2 ? 1 : 0);
     return rcf_launch_status();

@@ -205,6 +205,8 @@ class Engine(object):
         self.plan = WeightPlan()   # batched weight transforms of a training step (off until the model enables it)
         self.kernel_log = None     # optional list collecting (layer, kernel_id) for profiling
         self.up2x_wgrad_direct = os.environ.get('RCF_UP2X_WGRAD_DIRECT', '0') == '1'
+        self.up2x_wgrad_one_launch = os.environ.get('RCF_UP2X_WGRAD_ONE_LAUNCH', '1') != '0'
+        self._up2x_wgrad_ok = {}
         # weight gradients on a side stream (fork after dZ is written, join before the optimizer / a gradient bucket's exchange): a
         # weight gradient is off the backward's critical path, and the BatchNorm-backward passes it then overlaps are HBM-bound kernels
         # that leave board power unused while the convolution kernels run AT the power limit
@@ -870,6 +872,38 @@ class Engine(object):
             wmax = self._w_amax(weight.detach()) if self._two_plane(ops.conv_query(dd).kernel_id) else None
             self._run_packed(dd, weight.detach(), dz, x.g, amax_in=dz_amax, amax_w=wmax)
 
+    def _up2x_wgrad_merged(self, info, x, dz, dz_amax, dwp):
+        '''The four phase weight gradients of an up-2x convolution from ONE launch (rcf_conv2d_wgrad on the phase_sum == 2 descriptor:
+        split weight-gradient kernels only; the four phases of a tile share an XCD, so x is fetched from HBM once).  Returns False where
+        the library has no such launch for this layer (remembered per shape) -- the caller then runs the four per-phase calls.
+        RCF_UP2X_WGRAD_ONE_LAUNCH=0 switches it off.'''
+        if not self.up2x_wgrad_one_launch or self.bn_on_load:   # (BatchNorm-on-load sources keep the per-phase calls)
+            return False
+        n, h, w, c1 = self._shape(x)
+        co = dwp.shape[1]
+        d0 = self._exact_unless(info.up2x[0], x.amax, dz_amax)
+        key = (n, h, w, c1, co, d0.precision, d0.storage)
+        if self._up2x_wgrad_ok.get(key) is False:
+            return False
+        dm = ops.make_up2x_fwd_desc(n, h, w, c1, co, 0, 0, phase_out=True)
+        dm.precision = d0.precision
+        try:
+            qm = ops.conv_query(dm)
+            ws = self._newf((max(1, qm.wgrad_workspace_floats),), dz)
+            scales = ops.make_scales(x.amax, None, None, dz_amax) if self._two_plane_wgrad(qm.wgrad_kernel_id) else None
+            if self.prof is not None:
+                self.prof.begin(qm.wgrad_kernel_id, 4.0 * ops.algorithmic_flops(info.up2x[0]), dm)
+            try:
+                ops.conv_wgrad(dm, self._mat(x), None, dz, dwp, ws, scales=scales)
+            finally:
+                if self.prof is not None:
+                    self.prof.end()
+        except ops._lib.RcfError:
+            self._up2x_wgrad_ok[key] = False
+            return False
+        self._up2x_wgrad_ok[key] = True
+        return True
+
     def _conv_up2x_backward(self, layer, info, x, dz, dz_amax=None):
         n, h, w, c1 = self._shape(x)
         weight = layer.conv.weight
@@ -888,6 +922,8 @@ class Engine(object):
             ops.conv_wgrad(d3, self._mat(x), None, dz, self.grad_of(weight), ws, scales=scales)
             info = None
         dwp = self._newf((4, co, c1, 2, 2), dz) if info is not None else None
+        if info is not None and self._up2x_wgrad_merged(info, x, dz, dz_amax, dwp):
+            info = None   # the four phases' weight gradients came from one launch
         for ph, d in enumerate(info.up2x if info is not None else ()):
             d = self._exact_unless(d, x.amax, dz_amax)
             qi = ops.conv_query(d)

@@ -671,3 +671,29 @@ def test_bf16_training_trajectory_tracks_fp32(ops):
     print('loss fp32 %s\nloss bf16 %s' % (np.round(f, 3), np.round(h, 3)))
     assert f[-1] < 0.8 * f[0] and h[-1] < 0.8 * h[0]
     assert np.max(np.abs(h - f) / f) < 0.05
+
+
+@pytest.mark.parametrize('c1,co,h,w', [(64, 32, 35, 51), (64, 64, 24, 40), (128, 64, 15, 25), (256, 256, 8, 13)])
+def test_up2x_weight_gradient_four_phases_in_one_launch_bf16(ops, c1, co, h, w):
+    '''rcf_conv2d_wgrad on the merged up-2x descriptor (phase_sum == 2), bf16 tensors: the four phase weight gradients from one launch,
+    equal to the four per-phase calls within fp32 summation order (the products are the same bf16 x bf16 ones).'''
+    ops.set_precision('bf16')
+    n = 2
+    x = b16(rnd(n, c1, h, w, seed=31))
+    dz = b16(rnd(n, co, 2 * h, 2 * w, seed=32, scale=1e-2))
+    xg, dzg = nhwc_b(x), nhwc_b(dz)
+    dwp = torch.full((4, co, c1, 2, 2), float('nan'), device='cuda')
+    for ph in range(4):
+        d = ops.make_up2x_fwd_desc(n, h, w, c1, co, ph >> 1, ph & 1)
+        qi = ops.conv_query(d)
+        ws = torch.empty(max(1, qi.wgrad_workspace_floats), device='cuda')
+        ops.conv_wgrad(d, xg, None, dzg, dwp[ph], ws)
+    dm = ops.make_up2x_fwd_desc(n, h, w, c1, co, 0, 0, phase_out=True)
+    qm = ops.conv_query(dm)
+    wsm = torch.full((max(1, qm.wgrad_workspace_floats),), float('nan'), device='cuda')
+    dwm = torch.full((4, co, c1, 2, 2), float('nan'), device='cuda')
+    ops.conv_wgrad(dm, xg, None, dzg, dwm, wsm)
+    torch.cuda.synchronize()
+    assert not torch.isnan(dwm).any()
+    e = float((dwm.double() - dwp.double()).abs().max() / dwp.double().abs().max())
+    assert e < 2e-6, e

@@ -985,3 +985,41 @@ def test_captured_training_step_is_bitwise_the_eager_step(env, golden_dir):
     assert res[0][0] == res[1][0]
     for a, c in zip(res[0][1], res[1][1]):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize('prec', ['f16x2', 'fp32'])
+@pytest.mark.parametrize('cin,cout,n,hs,ws', [(64, 32, 2, 35, 51), (64, 64, 2, 24, 40), (128, 64, 1, 15, 25), (256, 256, 2, 8, 13), (32, 64, 1, 40, 70)])
+def test_up2x_weight_gradient_four_phases_in_one_launch(ops, prec, cin, cout, n, hs, ws):
+    '''rcf_conv2d_wgrad on the merged up-2x descriptor (phase_sum == 2): the four phase weight gradients [4][co][ci][2][2] from ONE
+    launch of the split kernel (workgroup = (slot, phase); the four phases of a slot share an XCD).  Same products as the four
+    per-phase calls, summed over fewer tile slots per phase: equal to them within fp32 summation order, and the folded 3x3 gradient
+    within the tier's bar of the fp64 reference.'''
+    x = rnd(n, cin, hs, ws, seed=21)
+    dz = rnd(n, cout, 2 * hs, 2 * ws, seed=22, scale=1e-3)
+    wshape = (cout, cin, 3, 3)
+    ref = torch.nn.grad.conv2d_weight(F.interpolate(x.double(), scale_factor=2), wshape, dz.double(), padding=1)
+    ops.set_precision(prec)
+    try:
+        ax, adz = dev_amax(ops, x), dev_amax(ops, dz)
+        xg, dzg = nhwc(x), nhwc(dz)
+        dwp = torch.full((4, cout, cin, 2, 2), float('nan'), device='cuda')
+        for ph in range(4):
+            d = ops.make_up2x_fwd_desc(n, hs, ws, cin, cout, ph >> 1, ph & 1)
+            qi = ops.conv_query(d)
+            wsb = torch.empty(max(1, qi.wgrad_workspace_floats), device='cuda')
+            two = qi.wgrad_kernel_id >= 50000
+            ops.conv_wgrad(d, xg, None, dzg, dwp[ph], wsb, scales=ops.make_scales(ax, None, None, adz) if (two and prec == 'f16x2') else None)
+        dm = ops.make_up2x_fwd_desc(n, hs, ws, cin, cout, 0, 0, phase_out=True)
+        qm = ops.conv_query(dm)
+        wsm = torch.full((max(1, qm.wgrad_workspace_floats),), float('nan'), device='cuda')
+        dwm = torch.full((4, cout, cin, 2, 2), float('nan'), device='cuda')
+        ops.conv_wgrad(dm, xg, None, dzg, dwm, wsm, scales=ops.make_scales(ax, None, None, adz) if (qm.wgrad_kernel_id >= 50000 and prec == 'f16x2') else None)
+        torch.cuda.synchronize()
+        assert not torch.isnan(dwm).any()
+        assert rel(dwm.cpu(), dwp.cpu().double()) < 2e-6
+        dw = torch.empty(wshape, device='cuda')
+        ops.phase_wgrad_fold(dwm, dw)
+        torch.cuda.synchronize()
+        assert rel(dw.cpu(), ref) < EXACT_TOL
+    finally:
+        ops.set_precision('fp32')

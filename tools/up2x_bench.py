@@ -76,3 +76,36 @@ for c1, co, h, w in LAYERS:
             one()
         fn(buf, 1)
         print('      one launch, %% of wave cycles: ' + '  '.join('[%d] %.1f' % (i, 100.0 * buf[i] / buf[7]) for i in range(7)))
+
+print()
+print('%-26s | %10s %8s | %10s %8s | max rel diff' % ('up-2x weight grad, batch %d' % n, '4 launches', 'TB/s', '1 launch', 'TB/s'))
+for c1, co, h, w in LAYERS:
+    x = torch.randn(n, h, w, c1, device='cuda').to(ADT)
+    dz = (torch.randn(n, 2 * h, 2 * w, co, device='cuda') * 1e-2).to(ADT)
+    f16 = ops.get_precision() == ops._lib.RCF_PREC_F16X2
+    ax = x.float().abs().max().reshape(1) if f16 else None
+    adz = dz.float().abs().max().reshape(1) if f16 else None
+    dwp = torch.empty(4, co, c1, 2, 2, device='cuda')
+    dwm = torch.empty_like(dwp)
+    descs, wss = [], []
+    for ph in range(4):
+        d = ops.make_up2x_fwd_desc(n, h, w, c1, co, ph >> 1, ph & 1)
+        qi = ops.conv_query(d)
+        descs.append(d); wss.append(torch.empty(max(1, qi.wgrad_workspace_floats), device='cuda'))
+    kw = {'scales': ops.make_scales(ax, None, None, adz)} if (f16 and qi.wgrad_kernel_id >= 50000) else {}
+
+    def four():
+        for ph in range(4):
+            ops.conv_wgrad(descs[ph], x, None, dz, dwp[ph], wss[ph], **kw)
+    dm = ops.make_up2x_fwd_desc(n, h, w, c1, co, 0, 0, phase_out=True)
+    qm = ops.conv_query(dm)
+    wsm = torch.empty(max(1, qm.wgrad_workspace_floats), device='cuda')
+    one = lambda: ops.conv_wgrad(dm, x, None, dz, dwm, wsm, **kw)
+    try:
+        t4, t1 = timeit(four), timeit(one)
+    except Exception as e:
+        print('%3d->%3d @ %3dx%3d: %s' % (c1, co, h, w, str(e)[:80]))
+        continue
+    gb = (x.numel() + dz.numel()) * eb / 1e9
+    diff = float((dwm.double() - dwp.double()).abs().max() / dwp.double().abs().max())
+    print('%3d->%3d @ %3dx%3d %8.2f GB | %8.1f us %8.2f | %8.1f us %8.2f | %.2e' % (c1, co, h, w, gb, 1000 * t4, gb / t4, 1000 * t1, gb / t1, diff))
