@@ -28,11 +28,17 @@
 // products run from it into four accumulator sets, and the epilogue runs once per phase.  (Round 4's one-launch form ran the four
 // 2x2 convolutions back to back, each re-staging its own tile: the re-reads were meant to hit L2 but the PMC counters show x
 // fetched ~4.5 x per launch at 450 x 800, profiles/r05_pmc_bf16_infer.json -- the kernel was HBM-bound on its own re-reads.)
-template <int KS_, int NT_, int PX_, int MT_, int LSTEP_ = 1, bool P4_ = false>
+// PM_ = 2: the four OUTPUT phases of a 3x3 stride-2 convolution's input gradient (phase_sum == 3) the same way.  Phase (a, b) writes
+// dx(2y + a, 2x + b) and is a 2x2 convolution of dz with pad 0 whose taps (ty, tx) exist only for ty <= a, tx <= b (1 + 2 + 2 + 4 = 9
+// of the 16: the per-phase launches multiply the other seven by zero weights): the tile of dz (halo of a 2x2) is staged once and the
+// nine real (phase, tap) products run from it -- 9/16 of the matrix work and a quarter of the loads of the four launches.
+template <int KS_, int NT_, int PX_, int MT_, int LSTEP_ = 1, int PM_ = 0>
 struct DmaCfg {
-    static constexpr bool P4 = P4_;
-    static constexpr int KS = KS_, GK = P4_ ? 3 : KS_, T = P4_ ? 16 : KS_ * KS_, NPH = P4_ ? 4 : 1, LSTEP = LSTEP_;
-    static_assert(!P4_ || (KS_ == 2 && LSTEP_ == 1 && PX_ == 32), "P4 is the up-2x forward: 2x2 taps, stride 1, 32-pixel tile rows");
+    static constexpr int PM = PM_;          // 0: one convolution; 1: up-2x forward phases; 2: stride-2 input-gradient phases
+    static constexpr bool P4 = PM_ != 0;
+    static constexpr int KS = KS_, GK = PM_ == 1 ? 3 : KS_, T = P4 ? 16 : KS_ * KS_, NPH = P4 ? 4 : 1, LSTEP = LSTEP_;
+    static constexpr int NSTEP = PM_ == 2 ? 9 : 16;   // (phase, tap) products per chunk
+    static_assert(!P4 || (KS_ == 2 && LSTEP_ == 1 && PX_ == 32), "phase merging: 2x2 taps, stride 1, 32-pixel tile rows");
     static constexpr int NT = NT_, BN = 32 * NT_;
     static constexpr int PX = PX_, PY = 32 / PX_, MT = MT_, NW = 4, TH = PY * MT * NW;
     static constexpr int HXP = (PX - 1) * LSTEP + GK, HYP = (TH - 1) * LSTEP + GK, NPIX = HXP * HYP;
@@ -56,6 +62,21 @@ struct DmaCfg {
 // P4: the 16 (phase, tap) products of a chunk ordered by the halo position (ky, kx) they read, so that an A operand is fetched
 // from LDS once per position (9 x MT reads per chunk instead of 16 x MT) -- phase (pa, pb), tap (ty, tx) reads (pa + ty, pb + tx)
 struct P4Tab { int pos[16]; int t16[16]; };
+// stride-2 input gradient: position = tap (ty, tx) of the 2x2 halo, shared by the phases it exists for (ty <= a, tx <= b)
+constexpr P4Tab rcf_p4_tab_s2() {
+    P4Tab t{};
+    int n = 0;
+    for (int ty = 0; ty < 2; ++ty)
+        for (int tx = 0; tx < 2; ++tx)
+            for (int pa = 0; pa < 2; ++pa)
+                for (int pb = 0; pb < 2; ++pb) {
+                    if (ty > pa || tx > pb) continue;
+                    t.pos[n] = ty * 2 + tx;
+                    t.t16[n] = (pa * 2 + pb) * 4 + ty * 2 + tx;
+                    ++n;
+                }
+    return t;
+}
 constexpr P4Tab rcf_p4_tab() {
     P4Tab t{};
     int n = 0;
@@ -132,7 +153,7 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
         const int img = t / a.tiles_y;
         // phase_sum 1: the four INPUT phases of an up-2x input gradient summed; 2: the four OUTPUT phases of an up-2x forward, one after
         // the other on the same tile (pad 1 - a, 1 - b; the outputs go to (2y + a, 2x + b))
-        const int pa = C::P4 ? 1 : (psum == 2 ? 1 - (ph >> 1) : (psum ? (ph >> 1) : a.pad)), pb = C::P4 ? 1 : (psum == 2 ? 1 - (ph & 1) : (psum ? (ph & 1) : a.pad_x));
+        const int pa = C::P4 ? (C::PM == 1 ? 1 : 0) : (psum == 2 ? 1 - (ph >> 1) : (psum ? (ph >> 1) : a.pad)), pb = C::P4 ? (C::PM == 1 ? 1 : 0) : (psum == 2 ? 1 - (ph & 1) : (psum ? (ph & 1) : a.pad_x));
         const int ioy = psum ? (ph >> 1) : a.ioy, iox = psum ? (ph & 1) : a.iox;
         const int iy0 = ty * C::TH * C::LSTEP - pa;
         const int ix0 = tx * C::PX * C::LSTEP - pb;
@@ -270,7 +291,8 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
         if constexpr (C::P4) {
             const unsigned char* Ab = smem_b + buf * C::A_BYTES;
             const unsigned char* Bb = smem_b + 2 * C::A_BYTES + buf * C::B_BYTES;
-            constexpr P4Tab TB = rcf_p4_tab();
+            constexpr P4Tab TB = C::PM == 2 ? rcf_p4_tab_s2() : rcf_p4_tab();
+            constexpr int PW = C::PM == 2 ? 2 : 3;   // positions per halo row
             constexpr int MN = C::MT * C::NT;
             bf16x8 av[2][C::MT], bv[2][C::NT];
 #pragma unroll
@@ -280,9 +302,9 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             int as = 0;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
+            for (int s = 0; s < C::NSTEP; ++s) {
                 const int bs = s & 1;
-                const bool has_next = s + 1 < 16;
+                const bool has_next = s + 1 < C::NSTEP;
                 const int npos = TB.pos[has_next ? s + 1 : s], nt16 = TB.t16[has_next ? s + 1 : s];
                 const bool new_a = has_next && npos != TB.pos[s];
                 const int nas = new_a ? as ^ 1 : as;
@@ -302,7 +324,7 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                                 bv[bs ^ 1][nr] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bb + (nt16 * C::BN + nr * 32) * 32 + bbase));
                             } else {
                                 const int rmi = nr - C::NT;
-                                av[nas][rmi] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ab + a_off(rmi, npos / 3, npos % 3)));
+                                av[nas][rmi] = as_bf16x8(*reinterpret_cast<const u32x4*>(Ab + a_off(rmi, npos / PW, npos % PW)));
                             }
                             __builtin_amdgcn_sched_barrier(0);
                             ++nr;
@@ -374,7 +396,7 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
           // of a row block write 128 contiguous bytes (with 32 output channels), like a stride-1 layer's store.  (Phase by phase every
           // store wrote 64-byte halves of four lines: 42 % of the wave time sat in the epilogue, tools/up2x_bench.py.)
           auto p4_epilogue = [&]() __attribute__((always_inline)) {
-            if constexpr (C::P4) {
+            if constexpr (C::PM == 1) {
             int t = tile;
             const int tx = t % a.tiles_x;
             t /= a.tiles_x;
@@ -662,7 +684,10 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                     }
                 }
             };
-            if constexpr (BST) {   // the only writer of dY: nothing to add to, and the sums it takes are the block's, not its own
+            if constexpr (C::PM == 2) {   // four phases x the variants: an input gradient takes no statistics
+                if (do_add) epilogue(std::true_type{}, std::false_type{});
+                else epilogue(std::false_type{}, std::false_type{});
+            } else if constexpr (BST) {   // the only writer of dY: nothing to add to, and the sums it takes are the block's, not its own
                 epilogue(std::false_type{}, std::false_type{});
             } else if constexpr (EPI) {   // inference: no statistics
                 if (do_add) epilogue(std::true_type{}, std::false_type{});
@@ -675,8 +700,13 @@ __global__ void __launch_bounds__(256, 2) conv_b16_kernel(ConvArgs a) {
                 else epilogue(std::false_type{}, std::false_type{});
             }
           };
-          if constexpr (C::P4) p4_epilogue();
-          else tile_epilogue(std::integral_constant<int, 0>{}, phase_out ? (oph >> 1) : a.ooy, phase_out ? (oph & 1) : a.oox);
+          if constexpr (C::PM == 1) p4_epilogue();
+          else if constexpr (C::PM == 2) {   // (phase by phase: these accumulate into dx where it has a second consumer, and odd sizes give the phases different extents)
+              tile_epilogue(std::integral_constant<int, 0>{}, 0, 0);
+              tile_epilogue(std::integral_constant<int, 1>{}, 0, 1);
+              tile_epilogue(std::integral_constant<int, 2>{}, 1, 0);
+              tile_epilogue(std::integral_constant<int, 3>{}, 1, 1);
+          } else tile_epilogue(std::integral_constant<int, 0>{}, phase_out ? (oph >> 1) : a.ooy, phase_out ? (oph & 1) : a.oox);
         }
         RCF_T(t_w4);
         RCF_TACC(3, t_w4, t_w3);   // 3: epilogue

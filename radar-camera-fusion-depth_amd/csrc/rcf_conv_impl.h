@@ -530,15 +530,19 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // is loaded, split and written to LDS ONCE per channel chunk (halo geometry GK = 3) and the chunk's eight (phase, kernel row) weight
 // pieces -- the per-phase packed layout as it is -- run over it into four accumulator sets, in the per-phase order (chunk, row, tap):
 // bitwise the four per-phase launches, a quarter of their loads and conversions.
-template <int KS_, int NT_, int PX_, int MT_ = 0, int NPL_ = 3, int LSTEP_ = 1, bool P4_ = false>
+// PM_ = 2: the four OUTPUT phases of a 3x3 stride-2 convolution's input gradient (phase_sum == 3).  Phase (a, b) is a 2x2 convolution
+// of dz with pad 0 whose taps (ty, tx) exist only for ty <= a, tx <= b (9 of 16; the per-phase launches multiply the other seven by
+// zero weights): the dz tile is staged once per chunk and only the six real (phase, kernel row) pieces run, one or two taps each.
+template <int KS_, int NT_, int PX_, int MT_ = 0, int NPL_ = 3, int LSTEP_ = 1, int PM_ = 0>
 struct SplitCfg {
-    static constexpr bool P4 = P4_;
-    static_assert(!P4_ || (KS_ == 2 && LSTEP_ == 1 && NPL_ == 2), "P4 is the up-2x forward on two planes: 2x2 taps, stride 1");
+    static constexpr int PM = PM_;           // 0: one convolution; 1: up-2x forward phases; 2: stride-2 input-gradient phases
+    static constexpr bool P4 = PM_ != 0;
+    static_assert(!P4 || (KS_ == 2 && LSTEP_ == 1 && NPL_ == 2), "phase merging runs on two planes: 2x2 taps, stride 1");
     static constexpr int NPL = NPL_, NP = NPL_ == 3 ? 6 : (NPL_ == 2 ? 3 : 1);   // operand planes, partial products per MAC
     static constexpr int KSY = KS_, KSX = KS_, T = KS_ * KS_, LSTEP = LSTEP_, CK = 16, CST = 16;
-    static constexpr int GK = P4_ ? 3 : KS_;           // halo geometry
-    static constexpr int NPH = P4_ ? 4 : 1;            // accumulator sets
-    static constexpr int NROW = P4_ ? 8 : KS_;         // barrier intervals (weight pieces) per chunk
+    static constexpr int GK = PM_ == 1 ? 3 : KS_;      // halo geometry
+    static constexpr int NPH = P4 ? 4 : 1;             // accumulator sets
+    static constexpr int NROW = P4 ? 8 : KS_;          // (phase, kernel row) weight pieces per chunk (PM_ = 2 runs six of them)
     static constexpr int NT = NT_, BN = 32 * NT_;
     static constexpr int PX = PX_, PY = 32 / PX_, MT = MT_ ? MT_ : ((NT_ == 1 && KS_ == 3) ? 4 : 2), NW = 4, TH = PY * MT * NW;   // 3x3 32-co layers: 512-pixel tiles (2x2 phases: measured 10 % slower with them)
     static constexpr int HXP = (PX - 1) * LSTEP + GK, HYP = (TH - 1) * LSTEP + GK, NPIX = HXP * HYP;
@@ -663,7 +667,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
         const int img = t / a.tiles_y;
         // phase_sum 1: the four INPUT phases of an up-2x input gradient summed; 2: the four OUTPUT phases of an up-2x forward, one after
         // the other on the same tile (pad 1 - a, 1 - b; the outputs go to (2y + a, 2x + b))
-        const int pa = C::P4 ? 1 : (psum == 2 ? 1 - (ph >> 1) : (psum ? (ph >> 1) : a.pad)), pb = C::P4 ? 1 : (psum == 2 ? 1 - (ph & 1) : (psum ? (ph & 1) : a.pad_x));
+        const int pa = C::P4 ? (C::PM == 1 ? 1 : 0) : (psum == 2 ? 1 - (ph >> 1) : (psum ? (ph >> 1) : a.pad)),
+                  pb = C::P4 ? (C::PM == 1 ? 1 : 0) : (psum == 2 ? 1 - (ph & 1) : (psum ? (ph & 1) : a.pad_x));
         const int ioy = psum ? (ph >> 1) : a.ioy, iox = psum ? (ph & 1) : a.iox;
         const int iy0 = ty * C::TH * C::LSTEP - pa;
         const int ix0 = tx * C::PX * C::LSTEP - pb;
@@ -900,29 +905,35 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[pi][mi][ni][r] = 0.f;
         }
-        auto row_body = [&](const int ky) __attribute__((always_inline)) {
-            const bool last_row = ky == C::NROW - 1;
-            // P4: row ky = (phase, kernel row): accumulator set, and the halo row / first halo column its taps read
+        // phase merging: row ky = (phase ky >> 1, kernel row ky & 1) -- the halo row and first halo column its taps read, and how
+        // many taps it has (stride-2 input gradient: phase (a, b) has the taps ty <= a, tx <= b only)
+        auto halo_row = [](int ky) { return C::PM == 1 ? (ky >> 2) + (ky & 1) : (C::PM == 2 ? (ky & 1) : ky); };
+        auto halo_col0 = [](int ky) { return C::PM == 1 ? ((ky >> 1) & 1) : 0; };
+        // ky: this row; kyn: the row after it (-1: none, this is the chunk's last); load_row: the next item's A tile is loaded here
+        auto row_body = [&](const int ky, const int kyn, const bool load_row) __attribute__((always_inline)) {
+            const bool last_row = kyn < 0;
             const int pi = C::P4 ? (ky >> 1) : 0;
-            const int hky = C::P4 ? (ky >> 2) + (ky & 1) : ky, hkx0 = C::P4 ? ((ky >> 1) & 1) : 0;
+            const int hky = halo_row(ky), hkx0 = halo_col0(ky);
+            const int ntap = (C::PM == 2 && ((ky >> 1) & 1) == 0) ? 1 : C::KSX;
             // every row starts in register set 0: its A operands were fetched before the barrier that published its weights
             RCF_T(t_row0);
             fetch_b(0, 0, pb);
-            if (!last_row) copy_b(cb_cur, ky + 1, pb ^ 1);   // nobody reads that slot during this row
+            if (!last_row) copy_b(cb_cur, kyn, pb ^ 1);   // nobody reads that slot during this row
             else if (more) copy_b(cb_next, 0, pb ^ 1);
-            if (ky == (C::NROW >= 2 ? C::NROW - 2 : 0) && more) load_a(ntile, nq);
+            if (load_row && more) load_a(ntile, nq);
             __builtin_amdgcn_sched_barrier(0);
             RCF_T(t_row1);
             RCF_TACC(0, t_row1, t_row0);   // 0: row prologue (first B reads, DMA / global-load issue)
 #pragma unroll
             for (int kx = 0; kx < C::KSX; ++kx) {
+                if (kx >= ntap) break;
                 const int cur = kx & 1;
                 // The 6 x MT x NT MFMAs of this tap in product-major, accumulator-round-robin order (dependent MFMAs stay MT x NT
                 // apart), with the next tap's LDS reads issued ONE AT A TIME between them: issued as a block, the reads stall the
                 // wave's MFMA issue for as long as the LDS queue takes them, and the partner wave on the SIMD tends to be doing
                 // the same.  sched_barrier pins the hand-written order.
                 constexpr int MN = C::MT * C::NT, NMF = C::NP * MN, NRD = C::NPL * (C::MT + C::NT);
-                const bool has_next = kx + 1 < C::KSX;
+                const bool has_next = kx + 1 < ntap;
                 int nr = 0;
                 int ao_next[C::MT];
 #pragma unroll
@@ -1259,7 +1270,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                     }
                     }
                   };
-                  if constexpr (C::P4) {
+                  if constexpr (C::P4) {   // (stride-2 input gradient: odd sizes give the phases different extents -- the bounds of each store handle it)
                       tile_epilogue(std::integral_constant<int, 0>{}, 0, 0);
                       tile_epilogue(std::integral_constant<int, 1>{}, 0, 1);
                       tile_epilogue(std::integral_constant<int, 2>{}, 1, 0);
@@ -1278,8 +1289,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
                 RCF_TACC(4, t_e2, t_e1);       // 4: store_a (wait for the global loads, split, ds_write)
             } else {
                 // next row's first A operands: the tile does not change inside a chunk
-                if constexpr (C::P4) fetch_a(((ky + 1) >> 2) + ((ky + 1) & 1), ((ky + 1) >> 1) & 1, 0);
-                else fetch_a(ky + 1, 0, 0);
+                fetch_a(halo_row(kyn), halo_col0(kyn), 0);
             }
             RCF_T(t_b0);
             rcf_wait_dma();   // the next weight piece has landed
@@ -1289,13 +1299,16 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(ConvArgs a) {
             if (last_row && more) fetch_a(0, 0, 0);   // (P4: row 0 is phase (0, 0), kernel row 0: halo (0, 0) too)
             pb ^= 1;
         };
-        if constexpr (C::P4) {
+        if constexpr (C::PM == 1) {
             // eight rows x four epilogues exceed hipcc's full-unroll budget, and a rolled row loop would index the accumulator sets
             // dynamically (scratch): spelled out instead
-            row_body(0); row_body(1); row_body(2); row_body(3); row_body(4); row_body(5); row_body(6); row_body(7);
+            row_body(0, 1, false); row_body(1, 2, false); row_body(2, 3, false); row_body(3, 4, false);
+            row_body(4, 5, false); row_body(5, 6, false); row_body(6, 7, true); row_body(7, -1, false);
+        } else if constexpr (C::PM == 2) {   // the six real rows: phases (0,0) and (0,1) have kernel row 0 only
+            row_body(0, 2, false); row_body(2, 4, false); row_body(4, 5, false); row_body(5, 6, false); row_body(6, 7, true); row_body(7, -1, false);
         } else {
 #pragma unroll
-            for (int ky = 0; ky < C::NROW; ++ky) row_body(ky);
+            for (int ky = 0; ky < C::NROW; ++ky) row_body(ky, ky + 1 < C::NROW ? ky + 1 : -1, ky == (C::NROW >= 2 ? C::NROW - 2 : 0));
         }
         tile = ntile;
         q = nq;
@@ -2448,7 +2461,7 @@ struct Sel {
     int npl;     // operand planes of a split kernel: 3 (exact fp32), 2 (RCF_PREC_F16X2), 1 (bf16)
     int dma;     // bf16 tensors, channel counts multiples of 16: conv_b16_kernel (operands reach LDS by DMA, rcf_conv_b16_dma.h)
     int pw;      // bf16 tensors, 1x1, <= 64 input and <= 128 output channels: conv1x1_b16_kernel (operands straight from global memory)
-    int p4;      // phase_sum == 2 on conv_b16_kernel: the four output phases from one staged tile (DmaCfg<..., P4 = true>)
+    int p4;      // four output phases from one staged tile (DmaCfg / SplitCfg PM): 1 = up-2x forward (phase_sum 2), 2 = stride-2 input gradient (phase_sum 3)
 };
 
 int num_cus() {
@@ -2478,8 +2491,10 @@ using D2_1_32 = DmaCfg<2, 1, 32, 2>;
 using D2_1_16 = DmaCfg<2, 1, 16, 2>;
 // up-2x forward, four phases from one tile: 256 pixels x 32 co x 4 phases per workgroup, or 128 pixels x 64 co (the four accumulator
 // sets are 128 registers either way).  32-pixel tile rows only: the 16-pixel form (per-read LDS addresses) spills
-using D2P4_1_32 = DmaCfg<2, 1, 32, 2, 1, true>;
-using D2P4_2_32 = DmaCfg<2, 2, 32, 1, 1, true>;
+using D2P4_1_32 = DmaCfg<2, 1, 32, 2, 1, 1>;
+using D2P4_2_32 = DmaCfg<2, 2, 32, 1, 1, 1>;
+using D2S2_1_32 = DmaCfg<2, 1, 32, 2, 1, 2>;   // stride-2 input gradient, four output phases from one dz tile
+using D2S2_2_32 = DmaCfg<2, 2, 32, 1, 1, 2>;
 using D3S2_2_32 = DmaCfg<3, 2, 32, 1, 2>;   // stride 2: 128-pixel tiles (the 65 x 9 halo tile is 18 KB per buffer)
 using D3S2_2_16 = DmaCfg<3, 2, 16, 1, 2>;
 using D3S2_1_32 = DmaCfg<3, 1, 32, 1, 2>;
@@ -2759,7 +2774,10 @@ bool valid_desc(const rcf_conv_desc* d) {
     } else if (d->stride != 1 || d->w_mode != RCF_W_FORWARD) {
         return false;
     }
-    if (d->phase_sum < 0 || d->phase_sum > 2) return false;
+    if (d->phase_sum < 0 || d->phase_sum > 3) return false;
+    if (d->phase_sum == 3 && (d->ksize != 2 || d->gather1 != RCF_GATHER_DIRECT || d->c2 != 0 || d->out_stride != 2 || d->pad != 0 || d->pad_x != 0 ||
+                              d->w_mode != RCF_W_FORWARD || d->h_out != (d->out_h_phys + 1) / 2 || d->w_out != (d->out_w_phys + 1) / 2))
+        return false;
     if (d->phase_sum == 1 && (d->ksize != 2 || d->gather1 != RCF_GATHER_STRIDED2 || d->c2 != 0)) return false;
     if (d->phase_sum == 2 && (d->ksize != 2 || d->gather1 != RCF_GATHER_DIRECT || d->c2 != 0 || d->out_stride != 2 || d->accumulate ||
                               d->w_mode != RCF_W_FORWARD || d->h_out != d->h_in || d->w_out != d->w_in || d->out_h_phys != 2 * d->h_out ||
@@ -2863,7 +2881,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
         // conv_split_kernel (fp32 tensors).  RCF_UP2X_MERGED=0: the four phases back to back, each staging its own tile (round 4's
         // one-launch form), for an A/B
         static const int merged = [] { const char* m = getenv("RCF_UP2X_MERGED"); return m ? atoi(m) : 1; }();
-        s->p4 = (d->phase_sum == 2 && merged && (s->dma || (!s->bf16 && s->npl == 2))) ? 1 : 0;
+        s->p4 = (d->phase_sum >= 2 && merged && (s->dma || (!s->bf16 && s->npl == 2))) ? d->phase_sum - 1 : 0;   // 1: up-2x forward, 2: stride-2 input gradient
     }
     if (s->kind == K4S1) {
         s->split = 1; s->ck = 16; s->cst = 16;
@@ -2888,6 +2906,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     s->th = tile_px / s->px;
     s->bn = 32 * s->nt;
     if (d->phase_sum == 2 && !s->split) return RCF_EUNSUPPORTED;   // the four output phases in one launch: conv_split_kernel / conv_b16_kernel only
+    if (d->phase_sum == 3 && s->p4 != 2) return RCF_EUNSUPPORTED;  // the stride-2 input gradient's phases exist only as the merged kernels
     if (s->split && !s->pw && !buffer_range_ok(d)) return RCF_EUNSUPPORTED;
     return RCF_OK;
 }
@@ -2969,6 +2988,7 @@ int dispatch_fwd(const Sel& s, F&& f) {
 template <class F>
 int dispatch_dma(const Sel& s, F&& f) {
     const bool p16 = s.px == 16;
+    if (s.kind == K2S1 && s.p4 == 2) return s.nt == 1 ? f(Tag<D2S2_1_32>{}) : f(Tag<D2S2_2_32>{});
     if (s.kind == K2S1 && s.p4) return s.nt == 1 ? f(Tag<D2P4_1_32>{}) : f(Tag<D2P4_2_32>{});
     if (s.kind == K2S1) {
         if (s.nt == 1) return p16 ? f(Tag<D2_1_16>{}) : f(Tag<D2_1_32>{});
@@ -2998,8 +3018,10 @@ int dispatch_split_planes(const Sel& s, F&& f) {
         return p16 ? f(Tag<SplitCfg<3, 2, 16, 1, NPL, 2>>{}) : f(Tag<SplitCfg<3, 2, 32, 1, NPL, 2>>{});
     }
     if (s.kind == K2S1 && s.p4) {   // (select_cfg: two planes, 32-pixel tile rows; 64 co: 128-pixel tiles -- four accumulator sets)
-        if constexpr (NPL == 2) return s.nt == 1 ? f(Tag<SplitCfg<2, 1, 32, 0, 2, 1, true>>{}) : f(Tag<SplitCfg<2, 2, 32, 1, 2, 1, true>>{});
-        else return RCF_EUNSUPPORTED;
+        if constexpr (NPL == 2) {
+            if (s.p4 == 2) return s.nt == 1 ? f(Tag<SplitCfg<2, 1, 32, 0, 2, 1, 2>>{}) : f(Tag<SplitCfg<2, 2, 32, 1, 2, 1, 2>>{});
+            return s.nt == 1 ? f(Tag<SplitCfg<2, 1, 32, 0, 2, 1, 1>>{}) : f(Tag<SplitCfg<2, 2, 32, 1, 2, 1, 1>>{});
+        } else return RCF_EUNSUPPORTED;
     }
     if (s.kind == K2S1) {
         if (s.nt == 1) return p16 ? f(Tag<SplitCfg<2, 1, 16, 0, NPL>>{}) : f(Tag<SplitCfg<2, 1, 32, 0, NPL>>{});
@@ -3076,6 +3098,7 @@ struct WSel { int kind, px, th, t, cst, nchunk1, nchunk2, ncog, nsplit, ktot, co
 
 int select_wgrad(const rcf_conv_desc* d, WSel* w) {
     if (!valid_desc(d) || d->w_mode != RCF_W_FORWARD) return RCF_EINVAL;
+    if (d->phase_sum == 3) return RCF_EUNSUPPORTED;   // (an input-gradient descriptor: it has no weight gradient of its own)
     if (d->c_out % 4 != 0) return RCF_EUNSUPPORTED;
     if (d->ksize == 4) return RCF_EUNSUPPORTED;   // the stem's weight gradient is taken on the 7x7 form (fp32 NHWC input)
     if (d->ksize == 7) {

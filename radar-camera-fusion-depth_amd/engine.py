@@ -207,6 +207,8 @@ class Engine(object):
         self.up2x_wgrad_direct = os.environ.get('RCF_UP2X_WGRAD_DIRECT', '0') == '1'
         self.up2x_wgrad_one_launch = os.environ.get('RCF_UP2X_WGRAD_ONE_LAUNCH', '1') != '0'
         self._up2x_wgrad_ok = {}
+        self.s2_dgrad_one_launch = os.environ.get('RCF_S2_DGRAD_ONE_LAUNCH', '1') != '0'
+        self._s2_dgrad_ok = {}
         # weight gradients on a side stream (fork after dZ is written, join before the optimizer / a gradient bucket's exchange): a
         # weight gradient is off the backward's critical path, and the BatchNorm-backward passes it then overlaps are HBM-bound kernels
         # that leave board power unused while the convolution kernels run AT the power limit
@@ -872,6 +874,37 @@ class Engine(object):
             wmax = self._w_amax(weight.detach()) if self._two_plane(ops.conv_query(dd).kernel_id) else None
             self._run_packed(dd, weight.detach(), dz, x.g, amax_in=dz_amax, amax_w=wmax)
 
+    def _s2_dgrad_merged(self, fwd, wd, dz, dx, acc, dz_amax):
+        '''The input gradient of a 3x3 stride-2 convolution as ONE launch over its four output phases (rcf_conv_desc.phase_sum == 3: dz
+        staged once per channel chunk, only the 1 + 2 + 2 + 4 taps that exist -- the four per-phase launches multiply the other seven
+        by zero weights).  bf16 tensors and fp32 tensors on two fp16 planes; returns False elsewhere (remembered per shape) and the
+        caller runs the four launches.  RCF_S2_DGRAD_ONE_LAUNCH=0 switches it off.'''
+        if not self.s2_dgrad_one_launch:
+            return False
+        dm = self._exact_unless(ops.make_s2_dgrad_desc(fwd, 0, 0, acc, phase_out=True), dz_amax)
+        key = bytes(dm)
+        if self._s2_dgrad_ok.get(key) is False:
+            return False
+        try:
+            qm = ops.conv_query(dm)
+        except ops._lib.RcfError:
+            self._s2_dgrad_ok[key] = False
+            return False
+        self._s2_dgrad_ok[key] = True
+        scales = None
+        if self._two_plane(qm.kernel_id):
+            wmax = self._w_amax(wd)
+            packed = self._pack_n(dm, [wd[ph] for ph in range(4)], dz, wmax)
+            scales = ops.make_scales(dz_amax, None, wmax)
+        else:
+            packed = self._pack_n(dm, [wd[ph] for ph in range(4)], dz)
+        if self.prof is not None:
+            self.prof.begin(qm.kernel_id, ops.algorithmic_flops(dm), dm)
+        ops.conv_fwd(dm, dz, None, packed, dx, None, scales=scales)
+        if self.prof is not None:
+            self.prof.end()
+        return True
+
     def _up2x_wgrad_merged(self, info, x, dz, dz_amax, dwp):
         '''The four phase weight gradients of an up-2x convolution from ONE launch (rcf_conv2d_wgrad on the phase_sum == 2 descriptor:
         split weight-gradient kernels only; the four phases of a tile share an XCD, so x is fetched from HBM once).  Returns False where
@@ -1047,6 +1080,8 @@ class Engine(object):
                     src.g = self._new(tuple(self._shape(src)), dz)
                 wd = self._phase_w(weight.detach(), RCF_PHASE_S2_DGRAD)
                 wmax = None
+                if self._s2_dgrad_merged(desc, wd, dz, src.g, acc, dz_amax):
+                    continue
                 for ph in range(4):
                     d = self._exact_unless(ops.make_s2_dgrad_desc(desc, ph >> 1, ph & 1, acc), dz_amax)
                     if ph == 0 and self._two_plane(ops.conv_query(d).kernel_id):

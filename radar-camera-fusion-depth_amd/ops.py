@@ -175,8 +175,16 @@ def make_up2x_dgrad_desc(n, hs, ws, c_in, c_out, a, b, accumulate, phase_sum=Fal
                     phase_sum=1 if phase_sum else 0, precision=_PRECISION[0], storage=_STORAGE[0])
 
 
-def make_s2_dgrad_desc(fwd, a, b, accumulate):
-    """Input gradient of a 3x3 stride-2 conv for input pixels (2y+a, 2x+b): a 2x2 conv on dZ (a transposed conv, 4 phases)."""
+def make_s2_dgrad_desc(fwd, a, b, accumulate, phase_out=False):
+    """Input gradient of a 3x3 stride-2 conv for input pixels (2y+a, 2x+b): a 2x2 conv on dZ (a transposed conv, 4 phases).
+    phase_out=True: all four phases in one launch (a, b ignored; the output grid is phase (0, 0)'s, the largest; weights of the 4
+    phases packed back to back; phase_sum == 3: dZ staged once, only the nine taps that exist)."""
+    if phase_out:
+        return ConvDesc(n=fwd.n, h_in=fwd.h_out, w_in=fwd.w_out, c1=fwd.c_out, c2=0, h_src1=fwd.h_out, w_src1=fwd.w_out,
+                        gather1=RCF_GATHER_DIRECT, h_out=(fwd.h_in + 1) // 2, w_out=(fwd.w_in + 1) // 2, c_out=fwd.c1, ksize=2, stride=1, pad=0, pad_x=0,
+                        w_mode=RCF_W_FORWARD, w_o=fwd.c1, w_i=fwd.c_out, w_i_off=0, accumulate=1 if accumulate else 0,
+                        out_stride=2, out_off_y=0, out_off_x=0, out_h_phys=fwd.h_in, out_w_phys=fwd.w_in, in_off_y=0, in_off_x=0, phase_sum=3,
+                        precision=_PRECISION[0], storage=_STORAGE[0])
     hy = (fwd.h_in - a + 1) // 2
     wx = (fwd.w_in - b + 1) // 2
     return ConvDesc(n=fwd.n, h_in=fwd.h_out, w_in=fwd.w_out, c1=fwd.c_out, c2=0, h_src1=fwd.h_out, w_src1=fwd.w_out,
@@ -218,7 +226,8 @@ def algorithmic_flops(desc):
     output grid (a stride-2 input gradient counts the forward conv's MACs, not the zero-dilated ones)."""
     k2 = desc.ksize * desc.ksize
     if desc.ksize == 2:     # a phase conv: count what it executes (its 4 phases together do 4/9 resp. 16/36 of the 3x3 MACs)
-        return 2.0 * desc.n * desc.h_out * desc.w_out * desc.c_out * k2 * desc.c1 * (4 if desc.phase_sum else 1)
+        # (phase_sum == 3, the merged stride-2 input gradient: the nine taps that exist, on phase (0, 0)'s grid)
+        return 2.0 * desc.n * desc.h_out * desc.w_out * desc.c_out * desc.c1 * (9 if desc.phase_sum == 3 else k2 * (4 if desc.phase_sum else 1))
     if desc.w_mode == RCF_W_DGRAD:
         return 2.0 * desc.n * desc.h_src1 * desc.w_src1 * desc.c1 * k2 * desc.c_out
     return 2.0 * desc.n * desc.h_out * desc.w_out * desc.c_out * k2 * (desc.c1 + desc.c2)
@@ -233,7 +242,7 @@ def algorithmic_bytes(desc):
     else:
         in1 = desc.h_src1 * desc.w_src1 * desc.c1
     in2 = desc.h_in * desc.w_in * desc.c2
-    out = desc.h_out * desc.w_out * desc.c_out * (4 if desc.phase_sum == 2 else 1)    # (the four output phases of an up-2x forward)
+    out = desc.h_out * desc.w_out * desc.c_out * (4 if desc.phase_sum >= 2 else 1)    # (the four output phases of an up-2x forward)
     return (2.0 if desc.storage else 4.0) * n * (in1 + in2 + out * (2 if desc.accumulate else 1))
 
 

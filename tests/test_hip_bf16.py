@@ -697,3 +697,41 @@ def test_up2x_weight_gradient_four_phases_in_one_launch_bf16(ops, c1, co, h, w):
     assert not torch.isnan(dwm).any()
     e = float((dwm.double() - dwp.double()).abs().max() / dwp.double().abs().max())
     assert e < 2e-6, e
+
+
+@pytest.mark.parametrize('cin,cout,h,w', [(32, 64, 45, 80), (64, 128, 35, 51), (128, 256, 29, 50), (256, 256, 8, 6)])
+def test_stride2_input_gradient_four_phases_from_one_staged_tile_bf16(ops, cin, cout, h, w):
+    '''rcf_conv_desc.phase_sum == 3 on bf16 tensors (conv_b16_kernel<DmaCfg<2, ., 32, ., 1, 2>>): dz staged once per chunk, the nine
+    (phase, tap) products that exist; bitwise the four per-phase launches, with and without accumulation, odd and even extents.'''
+    from rcf_amd._lib import RCF_PHASE_S2_DGRAD
+    ops.set_precision('bf16')
+    n = 2
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=1.0 / np.sqrt(cin * 9))
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    dz = b16(rnd(n, cout, ho, wo, seed=3))
+    ref = torch.nn.grad.conv2d_input((n, cin, h, w), wt.double(), dz.double(), stride=2, padding=1)
+    fwd = ops.make_fwd_desc(n, h, w, cin, 0, cout, 3, 2)
+    wd = ops.phase_weights(wt.cuda(), RCF_PHASE_S2_DGRAD)
+    dzg = nhwc_b(dz)
+    for accumulate in (False, True):
+        base = b16(rnd(n, cin, h, w, seed=7)) if accumulate else None
+        dx4 = nhwc_b(base) if accumulate else torch.full((n, h, w, cin), float('nan'), device='cuda').bfloat16()
+        dx1 = dx4.clone()
+        for ph in range(4):
+            dd = ops.make_s2_dgrad_desc(fwd, ph >> 1, ph & 1, accumulate)
+            info = ops.conv_query(dd)
+            packed = torch.empty(info.packed_weight_floats, device='cuda')
+            ops.conv_pack(dd, wd[ph], packed)
+            ops.conv_fwd(dd, dzg, None, packed, dx4, None)
+        dm = ops.make_s2_dgrad_desc(fwd, 0, 0, accumulate, phase_out=True)
+        im = ops.conv_query(dm)
+        pm = torch.empty(4 * im.packed_weight_floats, device='cuda')
+        for ph in range(4):
+            ops.conv_pack(dm, wd[ph], pm[ph * im.packed_weight_floats:(ph + 1) * im.packed_weight_floats])
+        ops.conv_fwd(dm, dzg, None, pm, dx1, None)
+        torch.cuda.synchronize()
+        assert not torch.isnan(dx1.float()).any()
+        assert torch.equal(dx1, dx4), accumulate
+        if not accumulate:
+            e = float((nchw(dx1).double() - ref).abs().max() / ref.abs().max())
+            assert e < 3 * BF16_EPS, e

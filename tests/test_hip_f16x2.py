@@ -1023,3 +1023,56 @@ def test_up2x_weight_gradient_four_phases_in_one_launch(ops, prec, cin, cout, n,
         assert rel(dw.cpu(), ref) < EXACT_TOL
     finally:
         ops.set_precision('fp32')
+
+
+@pytest.mark.parametrize('cin,cout,n,h,w', [(32, 64, 2, 45, 80), (64, 128, 2, 35, 51), (128, 256, 1, 29, 50), (256, 256, 1, 8, 6), (64, 64, 1, 64, 96)])
+def test_stride2_input_gradient_four_phases_from_one_staged_tile(ops, cin, cout, n, h, w):
+    '''rcf_conv_desc.phase_sum == 3 on fp32 tensors / two fp16 planes (conv_split_kernel<SplitCfg<2, ., 32, ., 2, 1, 2>>): dz staged and
+    split once per chunk, the nine (phase, tap) products that exist.  Bitwise the four per-phase launches (which multiply the other
+    seven taps by zero weights), with and without accumulation, odd and even extents; against fp64 within the tier's bar.'''
+    from rcf_amd._lib import RCF_PHASE_S2_DGRAD
+    x = rnd(n, cin, h, w, seed=1).double().requires_grad_(True)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=1.0 / np.sqrt(cin * 9))
+    ref = F.conv2d(x, wt.double(), stride=2, padding=1)
+    dz = rnd(*ref.shape, seed=3, scale=1e-3)
+    (ref * dz.double()).sum().backward()
+    ops.set_precision('f16x2')
+    try:
+        fwd = ops.make_fwd_desc(n, h, w, cin, 0, cout, 3, 2)
+        wd = ops.phase_weights(wt.cuda(), RCF_PHASE_S2_DGRAD)
+        adz, aw = dev_amax(ops, dz), ops.amax(wd)
+        sc = ops.make_scales(adz, None, aw)
+        for accumulate in (False, True):
+            base = rnd(n, cin, h, w, seed=7, scale=1e-3) if accumulate else torch.zeros(n, cin, h, w)
+            dx4 = nhwc(base) if accumulate else torch.full((n, h, w, cin), float('nan'), device='cuda')
+            dx1 = dx4.clone()
+            for ph in range(4):
+                dd = ops.make_s2_dgrad_desc(fwd, ph >> 1, ph & 1, accumulate)
+                info = ops.conv_query(dd)
+                assert 40000 <= info.kernel_id < 50000
+                packed = torch.empty(info.packed_weight_floats, device='cuda')
+                ops.conv_pack(dd, wd[ph], packed, aw)
+                ops.conv_fwd(dd, nhwc(dz), None, packed, dx4, None, scales=sc)
+            dm = ops.make_s2_dgrad_desc(fwd, 0, 0, accumulate, phase_out=True)
+            im = ops.conv_query(dm)
+            assert 40000 <= im.kernel_id < 50000
+            pm = torch.empty(4 * im.packed_weight_floats, device='cuda')
+            for ph in range(4):
+                ops.conv_pack(dm, wd[ph], pm[ph * im.packed_weight_floats:(ph + 1) * im.packed_weight_floats], aw)
+            ops.conv_fwd(dm, nhwc(dz), None, pm, dx1, None, scales=sc)
+            torch.cuda.synchronize()
+            assert not torch.isnan(dx1).any()
+            assert torch.equal(dx1, dx4), accumulate
+            assert rel(nchw(dx1), x.grad + base.double()) < EXACT_TOL, accumulate
+    finally:
+        ops.set_precision('fp32')
+
+
+def test_stride2_input_gradient_merged_form_is_refused_on_the_exact_tier(ops):
+    '''phase_sum == 3 exists as the merged kernels only (two planes / bf16 tensors): the exact three-plane tier answers RCF_EUNSUPPORTED
+    and the engine keeps the four launches there.'''
+    ops.set_precision('fp32')
+    fwd = ops.make_fwd_desc(1, 32, 48, 64, 0, 128, 3, 2)
+    dm = ops.make_s2_dgrad_desc(fwd, 0, 0, False, phase_out=True)
+    with pytest.raises(ops._lib.RcfError):
+        ops.conv_query(dm)

@@ -109,3 +109,44 @@ for c1, co, h, w in LAYERS:
     gb = (x.numel() + dz.numel()) * eb / 1e9
     diff = float((dwm.double() - dwp.double()).abs().max() / dwp.double().abs().max())
     print('%3d->%3d @ %3dx%3d %8.2f GB | %8.1f us %8.2f | %8.1f us %8.2f | %.2e' % (c1, co, h, w, gb, 1000 * t4, gb / t4, 1000 * t1, gb / t1, diff))
+
+print()
+print('%-30s | %10s %8s | %10s %8s | bitwise' % ('stride-2 input grad, batch %d' % n, '4 launches', 'TB/s', '1 launch', 'TB/s'))
+from rcf_amd._lib import RCF_PHASE_S2_DGRAD
+for cin, cout, h, w in [(32, 64, 450, 800), (64, 128, 225, 400), (128, 256, 113, 200), (256, 256, 57, 100), (256, 256, 29, 50)]:
+    fwd = ops.make_fwd_desc(n, h, w, cin, 0, cout, 3, 2)
+    dz = (torch.randn(n, fwd.h_out, fwd.w_out, cout, device='cuda') * 1e-2).to(ADT)
+    wt = torch.randn(cout, cin, 3, 3, device='cuda') * 0.05
+    wd = ops.phase_weights(wt, RCF_PHASE_S2_DGRAD)
+    f16 = ops.get_precision() == ops._lib.RCF_PREC_F16X2
+    adz = dz.float().abs().max().reshape(1) if f16 else None
+    aw = wd.abs().max().reshape(1) if f16 else None
+    kw = {'scales': ops.make_scales(adz, None, aw)} if f16 else {}
+    dx4 = torch.empty(n, h, w, cin, device='cuda', dtype=ADT)
+    dx1 = torch.empty_like(dx4)
+    descs, packs = [], []
+    for ph in range(4):
+        d = ops.make_s2_dgrad_desc(fwd, ph >> 1, ph & 1, False)
+        info = ops.conv_query(d)
+        p = torch.empty(info.packed_weight_floats, device='cuda')
+        ops.conv_pack(d, wd[ph], p, aw) if f16 else ops.conv_pack(d, wd[ph], p)
+        descs.append(d); packs.append(p)
+
+    def four():
+        for ph in range(4):
+            ops.conv_fwd(descs[ph], dz, None, packs[ph], dx4, None, **kw)
+    dm = ops.make_s2_dgrad_desc(fwd, 0, 0, False, phase_out=True)
+    try:
+        im = ops.conv_query(dm)
+    except Exception as e:
+        print('%3d->%3d @ %3dx%3d: merged form refused (%s)' % (cin, cout, h, w, str(e)[:60]))
+        continue
+    pm = torch.empty(4 * im.packed_weight_floats, device='cuda')
+    for ph in range(4):
+        dst = pm[ph * im.packed_weight_floats:(ph + 1) * im.packed_weight_floats]
+        ops.conv_pack(dm, wd[ph], dst, aw) if f16 else ops.conv_pack(dm, wd[ph], dst)
+    one = lambda: ops.conv_fwd(dm, dz, None, pm, dx1, None, **kw)
+    t4, t1 = timeit(four), timeit(one)
+    gb = (dz.numel() + dx4.numel()) * eb / 1e9
+    print('%3d<-%3d @ %3dx%3d %8.2f GB | %8.1f us %8.2f | %8.1f us %8.2f | %s' % (cin, cout, h, w, gb, 1000 * t4, gb / t4, 1000 * t1, gb / t1,
+                                                                                bool(torch.equal(dx1, dx4))))
