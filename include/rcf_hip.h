@@ -92,7 +92,14 @@ typedef struct rcf_conv_desc {
      * `packed` holds the four phases' packed weights back to back; the BatchNorm statistics cover all four phases.
      * rcf_conv2d_wgrad on such a descriptor: the four phases' weight gradients in ONE launch, dw = [4][c_out][c_in][2][2] (what
      * rcf_phase_wgrad_fold takes), bitwise the four per-phase calls; the four phases of a tile run on one XCD at the same time, so
-     * x is fetched from HBM once and from that L2 three times.  Split weight-gradient kernels only (RCF_EUNSUPPORTED otherwise). */
+     * x is fetched from HBM once and from that L2 three times.  Split weight-gradient kernels only (RCF_EUNSUPPORTED otherwise).
+     * phase_sum == 3 (ksize 2, RCF_GATHER_DIRECT, pad 0, out_stride 2, h_out / w_out = ceil(out_*_phys / 2)): the four OUTPUT phases of
+     * the input gradient of a 3x3 stride-2 convolution (the transposed convolution behind loss.backward() of the encoder's stride-2
+     * layers) in ONE launch: in1 = dZ, out = dX (out_h_phys x out_w_phys = the forward input), phase (a,b) writes dX(2y+a, 2x+b) from
+     * the taps (ty,tx) with ty <= a, tx <= b of its 2x2 phase weights (RCF_PHASE_S2_DGRAD; the other 7 of the 16 are zero by
+     * construction and are not multiplied); `packed` = the four phases' packed weights back to back; accumulate allowed.  Bitwise
+     * the four per-phase launches.  bf16 tensors and fp32 tensors under RCF_PREC_F16X2 only (RCF_EUNSUPPORTED otherwise: callers
+     * keep the four launches there); no weight gradient (RCF_EUNSUPPORTED). */
     int phase_sum;
     /* RCF_PREC_FP32 (0): fp32 results (the reference's arithmetic; f32 MFMA or the exact 3-plane bf16 split).
      * RCF_PREC_BF16 (1): operands rounded to bf16 (nearest even), fp32 accumulate; honoured by the split kernels, every other

@@ -16,8 +16,8 @@ prof = os.path.join(ROOT, 'profiles')
 
 FAMILIES = [   # (bench.py KERNEL_NAMES entry, regular expression on the cleaned kernel name).  The event families of bench.py are kernel-id
     # families: 3x3 stride 1 and 3x3 stride 2 are different ids, so they are different rows here too (SplitCfg's last parameter is LSTEP)
-    ('conv_split_kernel 3x3 s1', r'conv_split_kernel<SplitCfg<3, \d+, \d+, \d+, \d+, 1>'),
-    ('conv_split_kernel 3x3 s2', r'conv_split_kernel<SplitCfg<3, \d+, \d+, \d+, \d+, 2>'),
+    ('conv_split_kernel 3x3 s1', r'conv_split_kernel<SplitCfg<3, \d+, \d+, \d+, \d+, 1(, \d+)?>'),
+    ('conv_split_kernel 3x3 s2', r'conv_split_kernel<SplitCfg<3, \d+, \d+, \d+, \d+, 2(, \d+)?>'),
     ('conv_split_kernel 2x2 phases', r'conv_split_kernel<SplitCfg<2,'),
     ('conv_split_kernel 4x4 stem on the space-to-depth image', r'conv_split_kernel<SplitCfg<4,'),
     ('conv_wgrad_split_kernel', r'conv_wgrad_split_kernel<'),
@@ -25,7 +25,7 @@ FAMILIES = [   # (bench.py KERNEL_NAMES entry, regular expression on the cleaned
     ('conv_fwd_kernel 3x3 s1', r'conv_fwd_kernel<FwdCfg<3, 3, 0, 1'),
     # the kernels north_star's "3x3 encoder convs" run on: 3x3 forward / input gradient (64-co and small-layer tiles, both strides) and
     # the 3x3 weight gradients -- the decoder's launches of the same kernels are in this row too (PMC rows are per kernel, not per layer)
-    ('kernels of the encoder 3x3 convolutions', r'conv_split_kernel<SplitCfg<3, 2,|conv_split_kernel<SplitCfg<3, 1, \d+, 2,|conv_split_kernel<SplitCfg<3, \d+, \d+, \d+, \d+, 2>|conv_wgrad_split_kernel<WsCfg<\d+, \d+, 3,'),
+    ('kernels of the encoder 3x3 convolutions', r'conv_split_kernel<SplitCfg<3, 2,|conv_split_kernel<SplitCfg<3, 1, \d+, 2,|conv_split_kernel<SplitCfg<3, \d+, \d+, \d+, \d+, 2(, \d+)?>|conv_wgrad_split_kernel<WsCfg<\d+, \d+, 3,'),
 ]
 
 

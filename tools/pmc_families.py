@@ -12,8 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pmc_dir, tag, workload = sys.argv[1:4]
 head = sys.argv[4] if len(sys.argv) > 4 else 'unknown'
 FAMILIES = [
-    ('conv_b16_kernel 3x3 s1', r'conv_b16_kernel<DmaCfg<3, \d+, \d+, \d+, 1>'),
-    ('conv_b16_kernel 3x3 s2', r'conv_b16_kernel<DmaCfg<3, \d+, \d+, \d+, 2>'),
+    ('conv_b16_kernel 3x3 s1', r'conv_b16_kernel<DmaCfg<3, \d+, \d+, \d+, 1(, \d+)?>'),
+    ('conv_b16_kernel 3x3 s2', r'conv_b16_kernel<DmaCfg<3, \d+, \d+, \d+, 2(, \d+)?>'),
     ('conv_b16_kernel 2x2 phases', r'conv_b16_kernel<DmaCfg<2,'),
     ('conv_b16_kernel 4x4 stem on the space-to-depth image', r'conv_b16_kernel<DmaCfg<4,'),
     ('conv1x1_b16_kernel', r'conv1x1_b16_kernel<'),
