@@ -84,7 +84,9 @@ typedef struct rcf_conv_desc {
     int in_off_y, in_off_x;
     /* phase_sum != 0 (ksize 2, RCF_GATHER_STRIDED2): out = sum over the four input phases (a,b) of the 2x2 conv of phase
      * (a,b) with pad (a,b) -- the whole input gradient of an up-2x conv in ONE launch.  `packed` then holds the four
-     * phases' packed weights back to back (each rcf_conv_info.packed_weight_floats long).
+     * phases' packed weights back to back (each rcf_conv_info.packed_weight_floats long).  rcf_conv2d_wgrad on a phase_sum == 1
+     * descriptor (in_off_* ignored): the four phase weight gradients of a 3x3 stride-2 convolution -- x gathered at (2y+a, 2x+b),
+     * the same dZ -- in ONE launch, dw = [4][c_out][c_in][2][2] (what rcf_phase_wgrad_gather_s2 takes); split kernels only.
      * phase_sum == 2 (ksize 2, RCF_GATHER_DIRECT, out_stride 2, split / DMA kernels only): the four OUTPUT phases of an up-2x
      * forward conv3x3(nearest_up2x(x)) (src/net_utils.py:156-198) in ONE launch (phase (a,b): pad (1-a, 1-b), outputs at
      * (2y+a, 2x+b); pad / out_off_* of the descriptor are ignored): the 3x3-halo tile of x is staged once per channel chunk and all

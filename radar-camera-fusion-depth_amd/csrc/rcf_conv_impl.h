@@ -1780,15 +1780,18 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
     // phase launch's workgroup (pad 1 - a, 1 - b on x; dz read at (2y + a, 2x + b)), and the four phases of a slot sit on the SAME XCD
     // (blocks are dealt to the eight XCDs round-robin: block b -> XCD b % 8, phase (b / 8) % 4, slot b % 8 + 8 (b / 32)), working through
     // the same x tiles at the same pace: x comes from HBM once and from that XCD's L2 three times instead of four times from HBM
+    // phase_sum == 1: the four phase weight gradients of a 3x3 stride-2 convolution the same way -- workgroup (slot, phase) gathers x
+    // at (2y + a, 2x + b) against the SAME dz tile, which the four phases of a slot then share in their XCD's L2
     int slot = blockIdx.x, nslot = gridDim.x;
-    int pad_y = a.pad, pad_x = a.pad_x, ooy = a.ooy, oox = a.oox;
+    int pad_y = a.pad, pad_x = a.pad_x, ooy = a.ooy, oox = a.oox, g_ioy = a.ioy, g_iox = a.iox;
     int wslot = blockIdx.x;
-    if (a.phase_sum == 2) {
+    if (a.phase_sum != 0) {
         nslot = gridDim.x >> 2;
         int ph;
         if ((nslot & 7) == 0) { ph = (blockIdx.x >> 3) & 3; slot = (blockIdx.x & 7) + 8 * (blockIdx.x >> 5); }
         else { ph = blockIdx.x & 3; slot = blockIdx.x >> 2; }
-        pad_y = 1 - (ph >> 1); pad_x = 1 - (ph & 1); ooy = ph >> 1; oox = ph & 1;
+        if (a.phase_sum == 2) { pad_y = 1 - (ph >> 1); pad_x = 1 - (ph & 1); ooy = ph >> 1; oox = ph & 1; }
+        else { g_ioy = ph >> 1; g_iox = ph & 1; }
         wslot = ph * nslot + slot;
     }
 
@@ -1913,7 +1916,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
         const int iy0 = oy0 - pad_y, ix0 = ox0 - pad_x;
         const bool s2 = gmode == RCF_GATHER_STRIDED2;
         const int pm = s2 ? 2 : 1;                                      // source pixels per logical pixel
-        const int ioy = s2 ? a.ioy : 0, iox = s2 ? a.iox : 0;
+        const int ioy = s2 ? g_ioy : 0, iox = s2 ? g_iox : 0;
         // ---- x: halo tile of the input
         {
             int fimg = img;
@@ -3096,6 +3099,14 @@ double wgrad_vt_bias(int split) {
 // wgrad tiling for the forward descriptor
 struct WSel { int kind, px, th, t, cst, nchunk1, nchunk2, ncog, nsplit, ktot, cop, tiles_x, tiles_y, ntiles, vt, split, wci, wco, gy, gz; };
 
+// tile slots per phase of a four-phase weight-gradient launch (phase_sum 1 / 2) given the slots of a single-phase one: a quarter,
+// in whole rounds of the eight XCDs where there are that many (the four phases of a slot then share an XCD and its L2), at least one
+int wgrad_phase_slots(int nsplit) {
+    int n = nsplit / 4;
+    if (n >= 8) n &= ~7;
+    return n < 1 ? 1 : n;
+}
+
 int select_wgrad(const rcf_conv_desc* d, WSel* w) {
     if (!valid_desc(d) || d->w_mode != RCF_W_FORWARD) return RCF_EINVAL;
     if (d->phase_sum == 3) return RCF_EUNSUPPORTED;   // (an input-gradient descriptor: it has no weight gradient of its own)
@@ -3298,7 +3309,9 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
     if (d->w_mode == RCF_W_FORWARD) {
         WSel w;
         if (select_wgrad(d, &w) == RCF_OK) {
-            info->wgrad_workspace_floats = (size_t)w.nsplit * w.ktot * w.cop + 64;   // + a zero page for the DMA path
+            // (the four-phase launches -- phase_sum 1 / 2 -- keep one row block per (phase, slot): wgrad_phase_slots)
+            const int nrows = (d->phase_sum == 1 || d->phase_sum == 2) ? 4 * wgrad_phase_slots(w.nsplit) : w.nsplit;
+            info->wgrad_workspace_floats = (size_t)nrows * w.ktot * w.cop + 64;   // + a zero page for the DMA path
             info->wgrad_bn_on_load = (w.split && !SAct::B16 && d->precision != RCF_PREC_F16X2) ? 1 : 0;   // bf16 tensors are staged raw: nothing to apply BatchNorm to
             info->wgrad_kernel_id = 10000 + w.kind * 1000 + (w.px == 16 ? 100 : (w.px == 8 ? 200 : 0)) + (w.vt ? 400 : 0) +
                                     (w.split ? 5000 + w.wci * 10 + w.wco : 0) + ((w.split && d->precision == RCF_PREC_BF16) ? 20000 : 0) +
@@ -3591,13 +3604,13 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
     a.phase_sum = 0; a.wp_phase_stride = 0;
     // phase_sum == 2 (the merged up-2x forward descriptor): the four phases' weight gradients in one launch of the split kernel, into
     // dw[4][c_out][c_in][2][2]; each phase keeps its own workspace rows and its own reduction
+    // phase_sum == 1 on a RCF_GATHER_STRIDED2 descriptor (in_off_* ignored): the four phase weight gradients of a 3x3 stride-2
+    // convolution (x gathered at (2y + a, 2x + b), the same dz) in one launch, into dw[4][c_out][c_in][2][2]
     int nslot4 = 0;
-    if (d->phase_sum == 2) {
-        if (!w.split || w.kind != K2S1) return RCF_EUNSUPPORTED;
-        nslot4 = w.nsplit / 4;
-        if (nslot4 >= 8) nslot4 &= ~7;   // whole rounds of the eight XCDs: the four phases of a slot share an XCD (its L2 holds their x tile)
-        if (nslot4 < 1) nslot4 = 1;
-        a.phase_sum = 2;
+    if (d->phase_sum == 1 || d->phase_sum == 2) {
+        if (!w.split || w.kind != K2S1 || (d->phase_sum == 1 && d->gather1 != RCF_GATHER_STRIDED2)) return RCF_EUNSUPPORTED;
+        nslot4 = wgrad_phase_slots(w.nsplit);
+        a.phase_sum = d->phase_sum;
         w.nsplit = 4 * nslot4;
     }
     a.vt = w.vt; a.hp = d->h_out + 1; a.nimg = d->n; a.inv_hp = 1.0f / (float)(d->h_out + 1);

@@ -209,6 +209,8 @@ class Engine(object):
         self._up2x_wgrad_ok = {}
         self.s2_dgrad_one_launch = os.environ.get('RCF_S2_DGRAD_ONE_LAUNCH', '1') != '0'
         self._s2_dgrad_ok = {}
+        self.s2_wgrad_one_launch = os.environ.get('RCF_S2_WGRAD_ONE_LAUNCH', '1') != '0'
+        self._s2_wgrad_ok = {}
         # weight gradients on a side stream (fork after dZ is written, join before the optimizer / a gradient bucket's exchange): a
         # weight gradient is off the backward's critical path, and the BatchNorm-backward passes it then overlaps are HBM-bound kernels
         # that leave board power unused while the convolution kernels run AT the power limit
@@ -905,6 +907,33 @@ class Engine(object):
             self.prof.end()
         return True
 
+    def _s2_wgrad_merged(self, fwd, t1, dz, dwp, x_amax, dz_amax):
+        '''The four phase weight gradients of a 3x3 stride-2 convolution from ONE launch (rcf_conv2d_wgrad on the phase_sum == 1
+        descriptor; the four phases of a tile share an XCD and with it the dz tile).  False where the library has no such launch
+        (remembered per shape): the caller runs the four per-phase calls.  RCF_S2_WGRAD_ONE_LAUNCH=0 switches it off.'''
+        if not self.s2_wgrad_one_launch:
+            return False
+        dm = self._exact_unless(ops.make_s2_wgrad_desc(fwd, 0, 0, all_phases=True), x_amax, dz_amax)
+        key = bytes(dm)
+        if self._s2_wgrad_ok.get(key) is False:
+            return False
+        try:
+            qm = ops.conv_query(dm)
+            ws = self._newf((max(1, qm.wgrad_workspace_floats),), dz)
+            scales = ops.make_scales(x_amax, None, None, dz_amax) if self._two_plane_wgrad(qm.wgrad_kernel_id) else None
+            if self.prof is not None:
+                self.prof.begin(qm.wgrad_kernel_id, 4.0 * ops.algorithmic_flops(ops.make_s2_wgrad_desc(fwd, 0, 0)), dm)
+            try:
+                ops.conv_wgrad(dm, t1, None, dz, dwp, ws, scales=scales)
+            finally:
+                if self.prof is not None:
+                    self.prof.end()
+        except ops._lib.RcfError:
+            self._s2_wgrad_ok[key] = False
+            return False
+        self._s2_wgrad_ok[key] = True
+        return True
+
     def _up2x_wgrad_merged(self, info, x, dz, dz_amax, dwp):
         '''The four phase weight gradients of an up-2x convolution from ONE launch (rcf_conv2d_wgrad on the phase_sum == 2 descriptor:
         split weight-gradient kernels only; the four phases of a tile share an XCD, so x is fetched from HBM once).  Returns False where
@@ -1025,7 +1054,7 @@ class Engine(object):
             # 3x3 stride-2 weight gradient as four 2x2 weight gradients on the phase images of x (bf16 matrix pipe)
             t1 = self._mat(x)
             dwp = self._newf((4, desc.c_out, desc.c1, 2, 2), dz)
-            for ph in range(4):
+            for ph in (() if self._s2_wgrad_merged(desc, t1, dz, dwp, x_amax, dz_amax) else range(4)):
                 d = self._exact_unless(ops.make_s2_wgrad_desc(desc, ph >> 1, ph & 1), x_amax, dz_amax)
                 qi = ops.conv_query(d)
                 wsp = self._newf((max(1, qi.wgrad_workspace_floats),), dz)

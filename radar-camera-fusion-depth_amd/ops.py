@@ -193,9 +193,14 @@ def make_s2_dgrad_desc(fwd, a, b, accumulate, phase_out=False):
                     out_stride=2, out_off_y=a, out_off_x=b, out_h_phys=fwd.h_in, out_w_phys=fwd.w_in, in_off_y=0, in_off_x=0, phase_sum=0, precision=_PRECISION[0], storage=_STORAGE[0])
 
 
-def make_s2_wgrad_desc(fwd, a, b):
+def make_s2_wgrad_desc(fwd, a, b, all_phases=False):
     """Phase (a,b) of the weight gradient of the 3x3 stride-2 conv `fwd`: a 2x2 weight gradient on the phase image
-    x[2y+a, 2x+b] of its input against the same dZ (rcf_phase_wgrad_gather_s2 picks the nine real taps)."""
+    x[2y+a, 2x+b] of its input against the same dZ (rcf_phase_wgrad_gather_s2 picks the nine real taps).
+    all_phases=True: the four phases in one conv_wgrad launch (a, b ignored; phase_sum == 1; dw = [4][co][ci][2][2])."""
+    if all_phases:
+        d = make_s2_wgrad_desc(fwd, 0, 0)
+        d.phase_sum = 1
+        return d
     return ConvDesc(n=fwd.n, h_in=fwd.h_out, w_in=fwd.w_out, c1=fwd.c1, c2=0, h_src1=fwd.h_in, w_src1=fwd.w_in,
                     gather1=RCF_GATHER_STRIDED2, h_out=fwd.h_out, w_out=fwd.w_out, c_out=fwd.c_out, ksize=2, stride=1, pad=1, pad_x=1,
                     w_mode=RCF_W_FORWARD, w_o=fwd.c_out, w_i=fwd.c1, w_i_off=0, accumulate=0,

@@ -735,3 +735,31 @@ def test_stride2_input_gradient_four_phases_from_one_staged_tile_bf16(ops, cin, 
         if not accumulate:
             e = float((nchw(dx1).double() - ref).abs().max() / ref.abs().max())
             assert e < 3 * BF16_EPS, e
+
+
+@pytest.mark.parametrize('cin,cout,h,w', [(32, 64, 45, 80), (64, 128, 35, 51), (256, 256, 15, 25)])
+def test_stride2_weight_gradient_four_phases_in_one_launch_bf16(ops, cin, cout, h, w):
+    '''rcf_conv2d_wgrad on the phase_sum == 1 descriptor, bf16 tensors: one launch, equal to the four per-phase calls within fp32
+    summation order.'''
+    ops.set_precision('bf16')
+    n = 2
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    x = b16(rnd(n, cin, h, w, seed=51))
+    dz = b16(rnd(n, cout, ho, wo, seed=52, scale=1e-2))
+    fwd = ops.make_fwd_desc(n, h, w, cin, 0, cout, 3, 2)
+    xg, dzg = nhwc_b(x), nhwc_b(dz)
+    dwp = torch.full((4, cout, cin, 2, 2), float('nan'), device='cuda')
+    for ph in range(4):
+        d = ops.make_s2_wgrad_desc(fwd, ph >> 1, ph & 1)
+        qi = ops.conv_query(d)
+        ws = torch.empty(max(1, qi.wgrad_workspace_floats), device='cuda')
+        ops.conv_wgrad(d, xg, None, dzg, dwp[ph], ws)
+    dm = ops.make_s2_wgrad_desc(fwd, 0, 0, all_phases=True)
+    qm = ops.conv_query(dm)
+    wsm = torch.full((max(1, qm.wgrad_workspace_floats),), float('nan'), device='cuda')
+    dwm = torch.full((4, cout, cin, 2, 2), float('nan'), device='cuda')
+    ops.conv_wgrad(dm, xg, None, dzg, dwm, wsm)
+    torch.cuda.synchronize()
+    assert not torch.isnan(dwm).any()
+    e = float((dwm.double() - dwp.double()).abs().max() / dwp.double().abs().max())
+    assert e < 2e-6, e

@@ -988,7 +988,8 @@ def test_captured_training_step_is_bitwise_the_eager_step(env, golden_dir):
 
 
 @pytest.mark.parametrize('prec', ['f16x2', 'fp32'])
-@pytest.mark.parametrize('cin,cout,n,hs,ws', [(64, 32, 2, 35, 51), (64, 64, 2, 24, 40), (128, 64, 1, 15, 25), (256, 256, 2, 8, 13), (32, 64, 1, 40, 70)])
+@pytest.mark.parametrize('cin,cout,n,hs,ws', [(64, 32, 2, 35, 51), (64, 64, 2, 24, 40), (128, 64, 1, 15, 25), (256, 256, 2, 8, 13), (32, 64, 1, 40, 70), (256, 256, 1, 7, 12),
+                                              (64, 32, 1, 7, 12)])
 def test_up2x_weight_gradient_four_phases_in_one_launch(ops, prec, cin, cout, n, hs, ws):
     '''rcf_conv2d_wgrad on the merged up-2x descriptor (phase_sum == 2): the four phase weight gradients [4][co][ci][2][2] from ONE
     launch of the split kernel (workgroup = (slot, phase); the four phases of a slot share an XCD).  Same products as the four
@@ -1011,10 +1012,13 @@ def test_up2x_weight_gradient_four_phases_in_one_launch(ops, prec, cin, cout, n,
             ops.conv_wgrad(d, xg, None, dzg, dwp[ph], wsb, scales=ops.make_scales(ax, None, None, adz) if (two and prec == 'f16x2') else None)
         dm = ops.make_up2x_fwd_desc(n, hs, ws, cin, cout, 0, 0, phase_out=True)
         qm = ops.conv_query(dm)
-        wsm = torch.full((max(1, qm.wgrad_workspace_floats),), float('nan'), device='cuda')
+        nws = max(1, qm.wgrad_workspace_floats)
+        guard = torch.full((nws + 65536,), 123.0, device='cuda')     # the launch must stay inside the workspace the query asked for
+        wsm = guard[:nws]
         dwm = torch.full((4, cout, cin, 2, 2), float('nan'), device='cuda')
         ops.conv_wgrad(dm, xg, None, dzg, dwm, wsm, scales=ops.make_scales(ax, None, None, adz) if (qm.wgrad_kernel_id >= 50000 and prec == 'f16x2') else None)
         torch.cuda.synchronize()
+        assert bool((guard[nws:] == 123.0).all())
         assert not torch.isnan(dwm).any()
         assert rel(dwm.cpu(), dwp.cpu().double()) < 2e-6
         dw = torch.empty(wshape, device='cuda')
@@ -1076,3 +1080,45 @@ def test_stride2_input_gradient_merged_form_is_refused_on_the_exact_tier(ops):
     dm = ops.make_s2_dgrad_desc(fwd, 0, 0, False, phase_out=True)
     with pytest.raises(ops._lib.RcfError):
         ops.conv_query(dm)
+
+
+@pytest.mark.parametrize('prec', ['f16x2', 'fp32'])
+@pytest.mark.parametrize('cin,cout,n,h,w', [(32, 64, 2, 45, 80), (64, 128, 2, 35, 51), (128, 256, 1, 29, 50), (256, 256, 2, 15, 25), (256, 256, 1, 14, 24)])
+def test_stride2_weight_gradient_four_phases_in_one_launch(ops, prec, cin, cout, n, h, w):
+    '''rcf_conv2d_wgrad on the phase_sum == 1 descriptor: the four phase weight gradients of a 3x3 stride-2 convolution from ONE launch
+    (workgroup = (slot, phase), the phases of a slot on one XCD sharing the dz tile); equal to the four per-phase calls within fp32
+    summation order, and the gathered 3x3 gradient within the tier's bar of fp64.'''
+    x = rnd(n, cin, h, w, seed=41)
+    wshape = (cout, cin, 3, 3)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    dz = rnd(n, cout, ho, wo, seed=42, scale=1e-3)
+    ref = torch.nn.grad.conv2d_weight(x.double(), wshape, dz.double(), stride=2, padding=1)
+    ops.set_precision(prec)
+    try:
+        fwd = ops.make_fwd_desc(n, h, w, cin, 0, cout, 3, 2)
+        ax, adz = dev_amax(ops, x), dev_amax(ops, dz)
+        xg, dzg = nhwc(x), nhwc(dz)
+        dwp = torch.full((4, cout, cin, 2, 2), float('nan'), device='cuda')
+        for ph in range(4):
+            d = ops.make_s2_wgrad_desc(fwd, ph >> 1, ph & 1)
+            qi = ops.conv_query(d)
+            wsb = torch.empty(max(1, qi.wgrad_workspace_floats), device='cuda')
+            two = qi.wgrad_kernel_id >= 50000 and prec == 'f16x2'
+            ops.conv_wgrad(d, xg, None, dzg, dwp[ph], wsb, scales=ops.make_scales(ax, None, None, adz) if two else None)
+        dm = ops.make_s2_wgrad_desc(fwd, 0, 0, all_phases=True)
+        qm = ops.conv_query(dm)
+        nws = max(1, qm.wgrad_workspace_floats)
+        guard = torch.full((nws + 65536,), 123.0, device='cuda')     # the launch must stay inside the workspace the query asked for
+        wsm = guard[:nws]
+        dwm = torch.full((4, cout, cin, 2, 2), float('nan'), device='cuda')
+        ops.conv_wgrad(dm, xg, None, dzg, dwm, wsm, scales=ops.make_scales(ax, None, None, adz) if (qm.wgrad_kernel_id >= 50000 and prec == 'f16x2') else None)
+        torch.cuda.synchronize()
+        assert bool((guard[nws:] == 123.0).all())
+        assert not torch.isnan(dwm).any()
+        assert rel(dwm.cpu(), dwp.cpu().double()) < 2e-6
+        dw = torch.empty(wshape, device='cuda')
+        ops.phase_wgrad_gather_s2(dwm, dw)
+        torch.cuda.synchronize()
+        assert rel(dw.cpu(), ref) < EXACT_TOL
+    finally:
+        ops.set_precision('fp32')
