@@ -1732,22 +1732,30 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_dma_kernel(ConvArgs a) {
 // channel quads) land on adjacent rows: with a row pitch of 16 B mod 128 B both the writes and the reads are conflict-free.
 constexpr int ws_pitch(int bytes) { return ((bytes - 16 + 127) / 128) * 128 + 16; }   // >= bytes and == 16 (mod 128)
 
-template <int WCI_, int WCO_, int KS_ = 3, int TH_ = 8, int NPL_ = 3>
+// PAIR_ (KS_ = 2; the up-2x weight gradient, phase_sum == 2): phases (a, 0) and (a, 1) of an up-2x convolution from ONE x tile.
+// Phase (a, b) pairs x(y - (1 - a) + ty, x - (1 - b) + tx) with dz(2y + a, 2x + b): with the x tile staged at pad (1 - a, 1) the two
+// phases read its columns kx = b + tx in {0, 1, 2} -- the three operand shifts the 3x3 kernel builds anyway -- against their own dz
+// tile: eight accumulators (ty, {(kx 0, b 0), (kx 1, b 0), (kx 1, b 1), (kx 2, b 1)}), x loaded, split and transposed once for both.
+template <int WCI_, int WCO_, int KS_ = 3, int TH_ = 8, int NPL_ = 3, bool PAIR_ = false>
 struct WsCfg {
-    static constexpr int KS = KS_, T = KS_ * KS_;
+    static constexpr bool PAIR = PAIR_;
+    static_assert(!PAIR_ || KS_ == 2, "PAIR is the up-2x weight gradient: 2x2 taps");
+    static constexpr int KS = KS_, T = PAIR_ ? 8 : KS_ * KS_;
+    static constexpr int KXN = PAIR_ ? 3 : KS_;       // column shifts of a tile row's x operand
+    static constexpr int NDP = PAIR_ ? 2 : 1;         // dz phase tiles
     static constexpr int NPL = NPL_, NP = NPL_ == 3 ? 6 : (NPL_ == 2 ? 3 : 1);   // operand planes / partial products (1: RCF_PREC_BF16, 2: RCF_PREC_F16X2)
     static constexpr int WCI = WCI_, WCO = WCO_, KSPLIT = 4 / (WCI_ * WCO_);
     static constexpr int NCI = 32 * WCI_, NCO = 32 * WCO_;
-    static constexpr int PX = 16, TH = TH_, HXP = PX + KS - 1, HYP = TH + KS - 1;
+    static constexpr int PX = 16, TH = TH_, HXP = PX + KXN - 1, HYP = TH + KS - 1;
     static constexpr int XROW = 48, DROW = 32;     // bytes per tile row of one channel: 24 px (18 used) / 16 px
     static constexpr int SX = ws_pitch(HYP * XROW), SD = ws_pitch(TH * DROW);   // bytes per channel and plane
     static constexpr int XPL = NCI * SX, DPL = NCO * SD;
-    static constexpr int X_BYTES = NPL * XPL, D_BYTES = NPL * DPL;
+    static constexpr int X_BYTES = NPL * XPL, D_BYTES = NDP * NPL * DPL;
     static constexpr int RED_BYTES = (KSPLIT > 1) ? WCI * WCO * T * 16 * 64 * 4 : 0;
     static constexpr int COEF_BYTES = 2 * NCI * 4;   // BN-on-load table of this workgroup's input channels: scale, shift
     static constexpr int LDS_BYTES = ((X_BYTES + D_BYTES) > RED_BYTES ? (X_BYTES + D_BYTES) : RED_BYTES) + COEF_BYTES;
     static constexpr int CQX = 8 * WCI, CQD = 8 * WCO;
-    static constexpr int NXU = HYP * 3 * CQX, NDU = TH * 2 * CQD;     // 8-pixel x 4-channel staging units
+    static constexpr int NXU = HYP * 3 * CQX, NDU = NDP * TH * 2 * CQD;     // 8-pixel x 4-channel staging units
     static constexpr int RX = (NXU + 255) / 256, RD = (NDU + 255) / 256;
     static constexpr int NS = TH / KSPLIT;         // MFMA steps (tile rows) per wave and tile
     static_assert(HYP * XROW <= SX && TH * DROW <= SD && LDS_BYTES <= 160 * 1024, "tile rows must fit the channel pitch / LDS");
@@ -1785,6 +1793,14 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
     int slot = blockIdx.x, nslot = gridDim.x;
     int pad_y = a.pad, pad_x = a.pad_x, ooy = a.ooy, oox = a.oox, g_ioy = a.ioy, g_iox = a.iox;
     int wslot = blockIdx.x;
+    if (C::PAIR) {   // workgroup (slot, a): phases (a, 0) and (a, 1); the two a of a slot share an XCD
+        nslot = gridDim.x >> 1;
+        int pa;
+        if ((nslot & 7) == 0) { pa = (blockIdx.x >> 3) & 1; slot = (blockIdx.x & 7) + 8 * (blockIdx.x >> 4); }
+        else { pa = blockIdx.x & 1; slot = blockIdx.x >> 1; }
+        pad_y = 1 - pa; pad_x = 1; ooy = pa; oox = 0;
+        wslot = 2 * pa * nslot + slot;   // phase (a, b): row block (2 a + b) * nslot + slot
+    } else
     if (a.phase_sum != 0) {
         nslot = gridDim.x >> 2;
         int ph;
@@ -1974,13 +1990,14 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
             const unsigned pixb = (unsigned)a.c_out * SD::BYTES;
             const unsigned rowb = (unsigned)a.owp * pixb;
             const __amdgpu_buffer_rsrc_t rsd = rcf_rsrc(reinterpret_cast<const unsigned char*>(a.dz) + (size_t)fimg * a.ohp * rowb);
-            int wl = a.w_out;
-            { const int wph = (a.owp - oox + a.os - 1) / a.os; wl = wl < wph ? wl : wph; }
             const unsigned stepb = (unsigned)a.os * pixb;
 #pragma unroll
             for (int i = 0; i < C::RD; ++i) {
                 const int u = tid + 256 * i;
-                const int cq = u % C::CQD, g = (u / C::CQD) % 2, r = u / (2 * C::CQD);
+                const int cq = u % C::CQD, g = (u / C::CQD) % 2, r = (u / (2 * C::CQD)) % C::TH;
+                const int uox = C::PAIR ? u / (2 * C::CQD * C::TH) : oox;   // PAIR: the unit's phase b = its dz tile
+                int wl = a.w_out;
+                { const int wph = (a.owp - uox + a.os - 1) / a.os; wl = wl < wph ? wl : wph; }
                 int oy = oy0 + r, im = img;
                 bool rowok = u < C::NDU && co0 + cq * 4 < a.c_out;
                 if (a.vt) {
@@ -1992,7 +2009,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 rowok = rowok && oy < a.h_out && py < a.ohp;
                 const int lx0 = ox0 + 8 * g;
                 const unsigned lim = rowok ? (unsigned)wl : 0u;
-                const unsigned v0 = (unsigned)((im - fimg) * a.ohp + py) * rowb + (unsigned)(lx0 * a.os + oox) * pixb + (unsigned)(co0 + cq * 4) * SD::BYTES;
+                const unsigned v0 = (unsigned)((im - fimg) * a.ohp + py) * rowb + (unsigned)(lx0 * a.os + uox) * pixb + (unsigned)(co0 + cq * 4) * SD::BYTES;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const unsigned vo = (unsigned)(lx0 + j) < lim ? v0 + (unsigned)j * stepb : 0xffffffffu;
@@ -2072,11 +2089,12 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
         for (int i = 0; i < C::RD; ++i) {
             const int u = tid + 256 * i;
             if (C::NDU % 256 == 0 || u < C::NDU) {
-                const int cq = u % C::CQD, g = (u / C::CQD) % 2, r = u / (2 * C::CQD);
+                const int cq = u % C::CQD, g = (u / C::CQD) % 2, r = (u / (2 * C::CQD)) % C::TH;
+                unsigned char* Dp = Ds + (C::PAIR ? (u / (2 * C::CQD * C::TH)) * (C::NPL * C::DPL) : 0);   // [phase b][plane][channel][row]
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if constexpr (RAWD) pack8(rd[i], e, Ds + (e * C::CQD + cq) * C::SD + r * C::DROW + g * 16);
-                    else split8(rd[i], e, Ds + (e * C::CQD + cq) * C::SD + r * C::DROW + g * 16, C::DPL, sc.sb);
+                    if constexpr (RAWD) pack8(rd[i], e, Dp + (e * C::CQD + cq) * C::SD + r * C::DROW + g * 16);
+                    else split8(rd[i], e, Dp + (e * C::CQD + cq) * C::SD + r * C::DROW + g * 16, C::DPL, sc.sb);
             }
         }
     };
@@ -2092,11 +2110,12 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
     constexpr int NSLOT = ROLL ? KS + 1 : 2 * KS;
     constexpr int NEWROWS = ROLL ? 1 : KS;          // halo rows fetched per step
     constexpr int NPL = C::NPL, NP = C::NP;
-    constexpr int NRD = NEWROWS * 2 * NPL + NPL;    // LDS reads per step: (b128 + b32) x planes per row, + planes of dz
+    constexpr int NDP = C::NDP;
+    constexpr int NRD = NEWROWS * 2 * NPL + NDP * NPL;    // LDS reads per step: (b128 + b32) x planes per row, + planes of dz (per phase tile)
     constexpr int NMF = NP * C::T;                  // MFMAs per step
     u32x4 xlo[NSLOT][NPL];     // [row slot][plane]  pixels 8h .. 8h+7
     unsigned xhi[NSLOT][NPL];  //                    pixels 8h+8, 8h+9
-    u32x4 dzv[2][NPL];         // [set][plane]
+    u32x4 dzv[2][NDP][NPL];    // [set][phase tile][plane]
     u32x4 xs1[KS][NPL];        // kx = 1 operands of the current step
 
     int tile = slot;
@@ -2132,7 +2151,9 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 xhi[ky][pl] = *reinterpret_cast<const unsigned*>(xb + pl * C::XPL + ky * C::XROW + 16);
             }
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) dzv[0][pl] = *reinterpret_cast<const u32x4*>(db + pl * C::DPL);
+        for (int bq = 0; bq < NDP; ++bq)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) dzv[0][bq][pl] = *reinterpret_cast<const u32x4*>(db + (bq * NPL + pl) * C::DPL);
         __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
@@ -2147,8 +2168,13 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                 constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
                 constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
                 constexpr int KXO[3] = {0, KS == 3 ? 2 : 1, 1};
-                const int kx = KXO[j / (NP * KS)], pj = (j % (NP * KS)) / KS, ky = j % KS;
-                const int tap = ky * KS + kx;
+                // PAIR: four groups m = (kx, b) in the order (0, 0), (2, 1), then the two that need the shifted operand: (1, 0), (1, 1)
+                constexpr int MORD[4] = {0, 3, 1, 2}, KXM[4] = {0, 1, 1, 2};
+                const int grp = j / (NP * KS), pj = (j % (NP * KS)) / KS, ky = j % KS;
+                const int pm = C::PAIR ? MORD[grp] : 0;
+                const int kx = C::PAIR ? KXM[pm] : KXO[grp];
+                const int tap = C::PAIR ? ky * 4 + pm : ky * KS + kx;
+                const int bq = C::PAIR ? (pm >> 1) : 0;
                 const int sl = ROLL ? (s + ky) % (KS + 1) : cur * KS + ky;
                 const int pa = NPL == 3 ? PA[pj] : (NPL == 2 ? PA2[pj % 3] : 0), pbl = NPL == 3 ? PB[pj] : (NPL == 2 ? PB2[pj % 3] : 0);
                 u32x4 av;
@@ -2158,7 +2184,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                     const u32x4 lo = xlo[sl][pa];
                     av[0] = lo[1]; av[1] = lo[2]; av[2] = lo[3]; av[3] = xhi[sl][pa];
                 }
-                acc[tap] = rcf_mfma_split<NPL>(as_bf16x8(av), as_bf16x8(dzv[cur][pbl]), acc[tap]);
+                acc[tap] = rcf_mfma_split<NPL>(as_bf16x8(av), as_bf16x8(dzv[cur][bq][pbl]), acc[tap]);
                 // one kx = 1 operand (4 v_alignbit) behind each of the first NPL * KS even (three planes) / consecutive (one plane)
                 // MFMAs: all of them before the kx = 1 group starts
                 constexpr int SHS = NPL == 3 ? 2 : 1;
@@ -2189,8 +2215,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
                         if ((nr & 1) == 0) xlo[nsl][rpl] = *reinterpret_cast<const u32x4*>(g);
                         else xhi[nsl][rpl] = *reinterpret_cast<const unsigned*>(g + 16);
                     } else {
-                        const int rpl = nr - NEWROWS * 2 * NPL;
-                        dzv[nxt][rpl] = *reinterpret_cast<const u32x4*>(db + rpl * C::DPL + rn * C::DROW);
+                        const int rdp = nr - NEWROWS * 2 * NPL;   // (phase tile, plane)
+                        dzv[nxt][rdp / NPL][rdp % NPL] = *reinterpret_cast<const u32x4*>(db + rdp * C::DPL + rn * C::DROW);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -2232,21 +2258,25 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
         }
     }
     if (wk == 0) {
-        float* wsp = a.ws + (size_t)wslot * a.ktot * a.cop;
         const int q32_0 = first ? 0 : (a.c1 + 31) / 32;   // 32-channel chunk index of this source's first chunk in k
         const int rdz = wj * 32 + li;
         const int co = co0 + (rdz % C::CQD) * 4 + rdz / C::CQD;
+        constexpr int TP = KS * KS;   // taps of one phase's weight gradient (the reduction's k layout)
 #pragma unroll
-        for (int tap = 0; tap < C::T; ++tap)
+        for (int tap = 0; tap < C::T; ++tap) {
+            // PAIR: accumulator (ty, m) belongs to phase b = m >> 1 (its own workspace row block), tap (ty, tx = m & 1)
+            const int ptap = C::PAIR ? (tap >> 2) * 2 + (tap & 1) : tap;
+            float* wsp = a.ws + ((size_t)wslot + (C::PAIR ? (size_t)((tap >> 1) & 1) * nslot : 0)) * a.ktot * a.cop;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rxr = wi * 32 + rcf_mfma_row(r, lh);
                 const int ch = cb + (rxr % C::CQX) * 4 + rxr / C::CQX;   // channel inside its source
                 if ((ch & ~31) < csrc && co < a.cop) {
-                    const int k = ((q32_0 + (ch >> 5)) * C::T + tap) * 32 + (ch & 31);
+                    const int k = ((q32_0 + (ch >> 5)) * TP + ptap) * 32 + (ch & 31);
                     wsp[(size_t)k * a.cop + co] = acc[tap][r];
                 }
             }
+        }
     }
 #ifdef RCF_PHASE_TIMING
     tacc[5] = __builtin_amdgcn_s_memtime() - t_loop;   // 5: slice reduction + partial write
@@ -3101,8 +3131,11 @@ struct WSel { int kind, px, th, t, cst, nchunk1, nchunk2, ncog, nsplit, ktot, co
 
 // tile slots per phase of a four-phase weight-gradient launch (phase_sum 1 / 2) given the slots of a single-phase one: a quarter,
 // in whole rounds of the eight XCDs where there are that many (the four phases of a slot then share an XCD and its L2), at least one
-int wgrad_phase_slots(int nsplit) {
-    int n = nsplit / 4;
+// (the up-2x weight gradient on one or two operand planes runs phase PAIRS: a workgroup owns (a, 0) and (a, 1) -- half the slots, two
+// row blocks each; the three-plane tier has no LDS for two dz tiles and keeps (slot, phase) workgroups)
+bool wgrad_phase_pairs(const rcf_conv_desc* d) { return d->phase_sum == 2 && d->precision != RCF_PREC_FP32; }
+int wgrad_phase_slots(int nsplit, const rcf_conv_desc* d) {
+    int n = nsplit / (wgrad_phase_pairs(d) ? 2 : 4);
     if (n >= 8) n &= ~7;
     return n < 1 ? 1 : n;
 }
@@ -3310,7 +3343,7 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
         WSel w;
         if (select_wgrad(d, &w) == RCF_OK) {
             // (the four-phase launches -- phase_sum 1 / 2 -- keep one row block per (phase, slot): wgrad_phase_slots)
-            const int nrows = (d->phase_sum == 1 || d->phase_sum == 2) ? 4 * wgrad_phase_slots(w.nsplit) : w.nsplit;
+            const int nrows = (d->phase_sum == 1 || d->phase_sum == 2) ? 4 * wgrad_phase_slots(w.nsplit, d) : w.nsplit;
             info->wgrad_workspace_floats = (size_t)nrows * w.ktot * w.cop + 64;   // + a zero page for the DMA path
             info->wgrad_bn_on_load = (w.split && !SAct::B16 && d->precision != RCF_PREC_F16X2) ? 1 : 0;   // bf16 tensors are staged raw: nothing to apply BatchNorm to
             info->wgrad_kernel_id = 10000 + w.kind * 1000 + (w.px == 16 ? 100 : (w.px == 8 ? 200 : 0)) + (w.vt ? 400 : 0) +
@@ -3538,6 +3571,13 @@ extern "C" int RCF_FN(rcf_conv2d_fwd_act)(const rcf_conv_desc* d, const void* in
 // split weight-gradient kernels on fp32 tensors: NPL = 3 (exact) or 2 (RCF_PREC_F16X2); same tilings (select_wgrad)
 template <int NPL>
 static int launch_wgrad_split_planes(const ConvArgs& a, const WSel& w, int cfg, hipStream_t st) {
+    if constexpr (NPL == 2)
+    if (w.kind == K2S1 && a.phase_sum == 2) {   // the up-2x weight gradient: phase pairs from one x tile
+        if (cfg == 22) return launch_wgrad_split<WsCfg<2, 2, 2, 8, NPL, true>>(a, w.nsplit, w.gy, w.gz, st);
+        if (cfg == 12) return launch_wgrad_split<WsCfg<1, 2, 2, 8, NPL, true>>(a, w.nsplit, w.gy, w.gz, st);
+        if (cfg == 21) return launch_wgrad_split<WsCfg<2, 1, 2, 8, NPL, true>>(a, w.nsplit, w.gy, w.gz, st);
+        return launch_wgrad_split<WsCfg<1, 1, 2, 16, NPL, true>>(a, w.nsplit, w.gy, w.gz, st);
+    }
     if (w.kind == K2S1) {
         if (cfg == 22) return launch_wgrad_split<WsCfg<2, 2, 2, 8, NPL>>(a, w.nsplit, w.gy, w.gz, st);
         if (cfg == 12) return launch_wgrad_split<WsCfg<1, 2, 2, 8, NPL>>(a, w.nsplit, w.gy, w.gz, st);
@@ -3609,9 +3649,9 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
     int nslot4 = 0;
     if (d->phase_sum == 1 || d->phase_sum == 2) {
         if (!w.split || w.kind != K2S1 || (d->phase_sum == 1 && d->gather1 != RCF_GATHER_STRIDED2)) return RCF_EUNSUPPORTED;
-        nslot4 = wgrad_phase_slots(w.nsplit);
+        nslot4 = wgrad_phase_slots(w.nsplit, d);
         a.phase_sum = d->phase_sum;
-        w.nsplit = 4 * nslot4;
+        w.nsplit = (wgrad_phase_pairs(d) ? 2 : 4) * nslot4;   // workgroups: (slot, a) pairs / (slot, phase)
     }
     a.vt = w.vt; a.hp = d->h_out + 1; a.nimg = d->n; a.inv_hp = 1.0f / (float)(d->h_out + 1);
     a.sy = (float)d->h_src1 / (float)d->h_in;
@@ -3641,6 +3681,11 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
                     else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 1, 16, 1>>(a, w.nsplit, w.gy, w.gz, st);
                     else rc = launch_wgrad_split<WsCfg<1, 1, 1, 16, 1>>(a, w.nsplit, w.gy, w.gz, st);
                 } else return RCF_EUNSUPPORTED;
+            } else if (w.kind == K2S1 && a.phase_sum == 2) {
+                if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2, 2, THB, 1, true>>(a, w.nsplit, w.gy, w.gz, st);
+                else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2, 2, THB, 1, true>>(a, w.nsplit, w.gy, w.gz, st);
+                else if (cfg == 21) rc = launch_wgrad_split<WsCfg<2, 1, 2, THB, 1, true>>(a, w.nsplit, w.gy, w.gz, st);
+                else rc = launch_wgrad_split<WsCfg<1, 1, 2, 16, 1, true>>(a, w.nsplit, w.gy, w.gz, st);
             } else if (w.kind == K2S1) {
                 if (cfg == 22) rc = launch_wgrad_split<WsCfg<2, 2, 2, THB, 1>>(a, w.nsplit, w.gy, w.gz, st);
                 else if (cfg == 12) rc = launch_wgrad_split<WsCfg<1, 2, 2, THB, 1>>(a, w.nsplit, w.gy, w.gz, st);
