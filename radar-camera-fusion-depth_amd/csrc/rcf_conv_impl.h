@@ -2291,6 +2291,9 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslot, int ktot,
                                                            int cop, int c_out, int c1, int c2, int nchunk1, int T, int ksx, int kind) {
     __shared__ double sm[4][64];
+    // blockIdx.y: phase of a four-phase weight gradient (its own workspace row blocks, its own dw[co][ci][T] slab); 0 otherwise
+    ws += (size_t)blockIdx.y * nslot * ktot * cop;
+    dw += (size_t)blockIdx.y * c_out * (c1 + c2) * T;
     const int lane_o = threadIdx.x & 63;     // 64 consecutive (k, co) outputs per block: coalesced 256-B reads per slot
     const int lane_s = threadIdx.x >> 6;     // 4 slot lanes
     const int idx = blockIdx.x * 64 + lane_o;
@@ -3723,11 +3726,9 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
     if (rc != RCF_OK) return rc;
     const int total = w.ktot * w.cop;
     const int ksx = w.kind == K7S2 ? 1 : d->ksize;
-    if (nslot4 > 0) {
-        for (int ph = 0; ph < 4; ++ph)
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, workspace + (size_t)ph * nslot4 * total,
-                               dw_oihw + (size_t)ph * d->c_out * (d->c1 + d->c2) * 4, nslot4, w.ktot, w.cop, d->c_out, d->c1, d->c2,
-                               w.nchunk1, w.t, ksx, 0);
+    if (nslot4 > 0) {   // the four phases' reductions in one launch (grid y = phase)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64, 4), dim3(256), 0, st, workspace, dw_oihw, nslot4, w.ktot, w.cop,
+                           d->c_out, d->c1, d->c2, w.nchunk1, w.t, ksx, 0);
         return rcf_launch_status();
     }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, workspace, dw_oihw, w.nsplit, w.ktot,
