@@ -2286,6 +2286,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_split_kernel(ConvArgs a) {
 #endif
 }
 
+#include "rcf_conv_wgrad_tr.h"
+
 // workspace [nslot][ktot][cop] -> dW in OIHW.  One thread per (k, co), co fastest (coalesced reads).
 // kind: 0 generic (k = (q*T+tap)*32 + channel-in-chunk), 1 stem (k = tap(ky)*32 + kx*4 + c).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslot, int ktot,
@@ -2639,6 +2641,18 @@ int launch_wgrad_split(const ConvArgs& a, int nsplit, int gy, int gz, hipStream_
         attr_done = true;
     }
     hipLaunchKernelGGL((conv_wgrad_split_kernel<C>), dim3(nsplit, gy, gz), dim3(256), C::LDS_BYTES, st, a);
+    return rcf_launch_status();
+}
+
+template <class C>
+int launch_wgrad_tr(const ConvArgs& a, int nsplit, int gy, int gz, hipStream_t st) {
+    constexpr int lds = C::template lds_bytes<SAct::B16>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_tr_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<C>), dim3(nsplit, gy, gz), dim3(512), lds, st, a);
     return rcf_launch_status();
 }
 
@@ -3223,6 +3237,21 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
     return RCF_OK;
 }
 
+// conv_wgrad_tr_kernel (rcf_conv_wgrad_tr.h: producer / consumer waves, transposing LDS reads) serves the split weight gradients
+// of plain 3x3 / 2x2 (/ 1x1 with bf16 tensors) layers on one bf16 plane (bf16 tensors) or two fp16 planes (fp32 tensors); the
+// nearest-upsample gather, the merged phase forms, BatchNorm-on-load and the three-plane tier keep conv_wgrad_split_kernel.
+// RCF_WGRAD_TR=0 switches it off (same-box A/B, bitwise tests).
+bool wgrad_tr_ok(const rcf_conv_desc* d, const WSel& w) {
+    const char* e = getenv("RCF_WGRAD_TR");   // read per call: tests toggle it inside one process
+    if ((e != nullptr && e[0] == '0') || !w.split || d->phase_sum != 0) return false;
+    if (d->gather1 == RCF_GATHER_NEAREST) return false;
+    if (SAct::B16) {
+        if (d->precision != RCF_PREC_BF16 || d->c1 % 8 != 0 || d->c2 % 8 != 0 || d->c_out % 8 != 0) return false;
+        return w.kind == K3S1 || w.kind == K2S1 || (w.kind == K1 && d->stride == 1);
+    }
+    return d->precision == RCF_PREC_F16X2 && (w.kind == K3S1 || w.kind == K2S1);
+}
+
 }   // namespace
 
 // ---- entry points.  The fp32 unit owns the public names and hands descriptors with storage == RCF_STORE_BF16 to the bf16 unit.
@@ -3349,7 +3378,7 @@ extern "C" int RCF_FN(rcf_conv2d_query)(const rcf_conv_desc* d, rcf_conv_info* i
             const int nrows = (d->phase_sum == 1 || d->phase_sum == 2) ? 4 * wgrad_phase_slots(w.nsplit, d) : w.nsplit;
             info->wgrad_workspace_floats = (size_t)nrows * w.ktot * w.cop + 64;   // + a zero page for the DMA path
             info->wgrad_bn_on_load = (w.split && !SAct::B16 && d->precision != RCF_PREC_F16X2) ? 1 : 0;   // bf16 tensors are staged raw: nothing to apply BatchNorm to
-            info->wgrad_kernel_id = 10000 + w.kind * 1000 + (w.px == 16 ? 100 : (w.px == 8 ? 200 : 0)) + (w.vt ? 400 : 0) +
+            info->wgrad_kernel_id = 10000 + w.kind * 1000 + (w.px == 16 ? 100 : (w.px == 8 ? 200 : 0)) + (w.vt ? 400 : 0) + (wgrad_tr_ok(d, w) ? 200 : 0) +
                                     (w.split ? 5000 + w.wci * 10 + w.wco : 0) + ((w.split && d->precision == RCF_PREC_BF16) ? 20000 : 0) +
                                     ((w.split && d->precision == RCF_PREC_F16X2) ? 40000 : 0);
         }
@@ -3675,6 +3704,22 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
         a.nchunk1 = ceil_div(d->c1, 32 * w.wci);
         a.nchunk2 = d->c2 > 0 ? ceil_div(d->c2, 32 * w.wci) : 0;
         const int cfg = w.wci * 10 + w.wco;
+        if (wgrad_tr_ok(d, w) && !coef1 && !coef2) {
+            constexpr int NPT = SAct::B16 ? 1 : 2;       // operand planes
+            constexpr int THT = SAct::B16 ? 16 : 8;      // tile rows of the 64-channel configurations (select_wgrad: th_split)
+            const int ks = w.kind == K3S1 ? 3 : (w.kind == K2S1 ? 2 : 1);
+#define RCF_TR_KS(KSV)                                                                                                  \
+            if (cfg == 22) rc = launch_wgrad_tr<WtCfg<2, 2, KSV, THT, NPT>>(a, w.nsplit, w.gy, w.gz, st);               \
+            else if (cfg == 12) rc = launch_wgrad_tr<WtCfg<1, 2, KSV, THT, NPT>>(a, w.nsplit, w.gy, w.gz, st);          \
+            else if (cfg == 21) rc = launch_wgrad_tr<WtCfg<2, 1, KSV, THT, NPT>>(a, w.nsplit, w.gy, w.gz, st);          \
+            else rc = launch_wgrad_tr<WtCfg<1, 1, KSV, 16, NPT>>(a, w.nsplit, w.gy, w.gz, st);
+            if (ks == 3) { RCF_TR_KS(3) }
+            else if (ks == 2) { RCF_TR_KS(2) }
+            else {
+                if constexpr (SAct::B16) { RCF_TR_KS(1) } else return RCF_EUNSUPPORTED;
+            }
+#undef RCF_TR_KS
+        } else
         if (d->precision == RCF_PREC_BF16) {
             constexpr int THB = SAct::B16 ? 16 : 8;   // tile rows (select_wgrad: th_split)
             if (w.kind == K1) {
