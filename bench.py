@@ -255,6 +255,8 @@ def cpu_baseline(height, width, points, batch8=False):
 def _csrc_sha():
     h = hashlib.sha256()
     for name in sorted(os.listdir(os.path.join(ROOT, 'radar-camera-fusion-depth_amd', 'csrc'))):
+        if not name.endswith(('.h', '.hip')):
+            continue      # (a stray cache directory is not a kernel source)
         h.update(open(os.path.join(ROOT, 'radar-camera-fusion-depth_amd', 'csrc', name), 'rb').read())
     return h.hexdigest()[:16]
 

@@ -151,7 +151,13 @@ _lib = None
 
 
 class RcfError(RuntimeError):
-    pass
+    """code: the library's return value (-1 RCF_EINVAL, -2 RCF_EUNSUPPORTED, > 0 a hipError_t); None for host-side failures."""
+    code = None
+
+
+class RcfUnsupported(RcfError):
+    """RCF_EUNSUPPORTED: the shape / mode has no kernel -- the only error a caller may answer with another form of the same op."""
+    code = -2
 
 
 def load():
@@ -177,4 +183,6 @@ def load():
 def check(rc, what):
     if rc != 0:
         kind = {-1: 'invalid argument', -2: 'unsupported shape'}.get(rc, 'hipError_t %d' % rc)
-        raise RcfError('%s failed: %s' % (what, kind))
+        e = (RcfUnsupported if rc == -2 else RcfError)('%s failed: %s' % (what, kind))
+        e.code = rc
+        raise e

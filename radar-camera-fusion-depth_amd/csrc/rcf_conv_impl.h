@@ -2785,8 +2785,12 @@ bool s2_split_enabled(const rcf_conv_desc* d) {
 // The split / DMA kernels address their tensors through buffer descriptors based at the tile's first image, with 32-bit byte offsets
 // checked against a 2 GB range; a tile (incl. its halo) touches at most two consecutive images.  An image of 1 GB or more would put
 // valid offsets out of that range -- where the hardware silently returns zeros / drops stores -- so such shapes are refused loudly.
-bool buffer_range_ok(const rcf_conv_desc* d) {
-    const double lim = 1073741824.0, b = SAct::BYTES;
+// Virtual tall image (vt): a tile of up to 34 rows (32-row tiles + halo) spans ceil(34 / (h + 1)) + 1 images when the image is lower
+// than the tile, all of them addressed from the first one's descriptor: the bound per image shrinks accordingly.
+bool buffer_range_ok(const rcf_conv_desc* d, bool vt = false) {
+    double lim = 1073741824.0;
+    const double b = SAct::BYTES;
+    if (vt) lim = 2147483648.0 / (double)((34 + d->h_out) / (d->h_out + 1) + 1);
     return (double)d->h_src1 * d->w_src1 * d->c1 * b < lim && (double)d->h_in * d->w_in * d->c2 * b < lim &&
            (double)d->out_h_phys * d->out_w_phys * d->c_out * b < lim;
 }
@@ -2957,7 +2961,7 @@ int select_cfg(const rcf_conv_desc* d, Sel* s) {
     s->bn = 32 * s->nt;
     if (d->phase_sum == 2 && !s->split) return RCF_EUNSUPPORTED;   // the four output phases in one launch: conv_split_kernel / conv_b16_kernel only
     if (d->phase_sum == 3 && s->p4 != 2) return RCF_EUNSUPPORTED;  // the stride-2 input gradient's phases exist only as the merged kernels
-    if (s->split && !s->pw && !buffer_range_ok(d)) return RCF_EUNSUPPORTED;
+    if (s->split && !s->pw && !buffer_range_ok(d, s->vt != 0)) return RCF_EUNSUPPORTED;
     return RCF_OK;
 }
 
@@ -3232,19 +3236,21 @@ int select_wgrad(const rcf_conv_desc* d, WSel* w) {
         if (nsp > w->ntiles) nsp = w->ntiles;
         if (nsp < 1) nsp = 1;
         w->nsplit = nsp;
-        if (!buffer_range_ok(d)) return RCF_EUNSUPPORTED;
+        if (!buffer_range_ok(d, w->vt != 0)) return RCF_EUNSUPPORTED;
     }
     return RCF_OK;
 }
 
 // conv_wgrad_tr_kernel (rcf_conv_wgrad_tr.h: producer / consumer waves, transposing LDS reads) serves the split weight gradients
 // of plain 3x3 / 2x2 (/ 1x1 with bf16 tensors) layers on one bf16 plane (bf16 tensors) or two fp16 planes (fp32 tensors); the
-// nearest-upsample gather, the merged phase forms, BatchNorm-on-load and the three-plane tier keep conv_wgrad_split_kernel.
+// merged up-2x phase pairs, BatchNorm-on-load and the three-plane tier keep conv_wgrad_split_kernel.
 // RCF_WGRAD_TR=0 switches it off (same-box A/B, bitwise tests).
 bool wgrad_tr_ok(const rcf_conv_desc* d, const WSel& w) {
     const char* e = getenv("RCF_WGRAD_TR");   // read per call: tests toggle it inside one process
-    if ((e != nullptr && e[0] == '0') || !w.split || d->phase_sum != 0) return false;
-    if (d->gather1 == RCF_GATHER_NEAREST) return false;
+    if ((e != nullptr && e[0] == '0') || !w.split) return false;
+    // phase_sum 1: the four phases of a stride-2 weight gradient as (slot, phase) workgroups; 2 (the up-2x phase pairs from one x
+    // tile, eight accumulators and two dz tiles) stays on conv_wgrad_split_kernel
+    if (d->phase_sum != 0 && !(d->phase_sum == 1 && w.kind == K2S1 && d->gather1 == RCF_GATHER_STRIDED2)) return false;
     if (SAct::B16) {
         if (d->precision != RCF_PREC_BF16 || d->c1 % 8 != 0 || d->c2 % 8 != 0 || d->c_out % 8 != 0) return false;
         return w.kind == K3S1 || w.kind == K2S1 || (w.kind == K1 && d->stride == 1);
@@ -3705,6 +3711,9 @@ static int conv2d_wgrad_impl(const rcf_conv_desc* d, const float* in1, const flo
         a.nchunk2 = d->c2 > 0 ? ceil_div(d->c2, 32 * w.wci) : 0;
         const int cfg = w.wci * 10 + w.wco;
         if (wgrad_tr_ok(d, w) && !coef1 && !coef2) {
+#ifdef RCF_WGRAD_DIAG
+            { const char* dg = getenv("RCF_WGRAD_DIAG"); if (dg && dg[0] >= '1' && dg[0] <= '3') a.xcd_band = 76 + (dg[0] - '0'); }
+#endif
             constexpr int NPT = SAct::B16 ? 1 : 2;       // operand planes
             constexpr int THT = SAct::B16 ? 16 : 8;      // tile rows of the 64-channel configurations (select_wgrad: th_split)
             const int ks = w.kind == K3S1 ? 3 : (w.kind == K2S1 ? 2 : 1);

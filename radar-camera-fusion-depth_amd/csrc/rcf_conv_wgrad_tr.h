@@ -26,6 +26,15 @@
 //    outside elements get offset 0xffffffff, which the buffer unit answers with zeros (also through LDS-DMA).
 #pragma once
 
+// Diagnostics build only (-DRCF_WGRAD_DIAG, tools/probe/wgrad_diag.py; WRONG results): the environment variable RCF_WGRAD_DIAG = 1 drops
+// the per-workgroup partial write, 2 the staging after the first tile (consumers alone), 3 the MFMA steps (producers alone).  Round 6,
+// fp32 tensors, 64 -> 64 @225x400: whole kernel 152 us, consumers alone 128, producers alone 93, partial write ~3: the matrix loop
+// itself -- 216 MFMAs, 80 transposing reads and 96 operand shifts per tile on one wave per SIMD -- is what bounds the kernel.
+#ifdef RCF_WGRAD_DIAG
+#define RCF_WDIAG(cond) (cond)
+#else
+#define RCF_WDIAG(cond) true
+#endif
 typedef short rcf_s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x2 rcf_lds_tr16(const unsigned char* p) {
     return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rcf_s16x4*)p));
@@ -75,9 +84,23 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_tr_kernel(ConvArgs a) {
     const int cb = (first ? Q : Q - a.nchunk1) * C::NCI;   // first channel of this chunk inside its source
     const int hs = first ? a.h1 : a.h_in;
     const int ws = first ? a.w1 : a.w_in;
-    const bool s2 = (first ? a.gather1 : RCF_GATHER_DIRECT) == RCF_GATHER_STRIDED2;
+    const int gmode = first ? a.gather1 : RCF_GATHER_DIRECT;
+    const bool s2 = gmode == RCF_GATHER_STRIDED2;
+    const bool nearest = gmode == RCF_GATHER_NEAREST;   // F.interpolate's floor(dst * in / out): general path only
     const int co0 = blockIdx.z * C::NCO;
-    const int slot = blockIdx.x, nslot = gridDim.x;
+    // phase_sum == 1: the four phase weight gradients of a 3x3 stride-2 convolution in ONE launch -- workgroup (slot, phase) gathers
+    // x at (2y + a, 2x + b) against the SAME dz tile, the four phases of a slot on the same XCD (block b -> XCD b % 8) sharing it in
+    // that L2; each phase keeps its own workspace row block (conv_wgrad_split_kernel's decode)
+    int slot = blockIdx.x, nslot = gridDim.x, wslot = blockIdx.x;
+    int ph_ioy = a.ioy, ph_iox = a.iox;
+    if (a.phase_sum == 1) {
+        nslot = gridDim.x >> 2;
+        int ph;
+        if ((nslot & 7) == 0) { ph = (blockIdx.x >> 3) & 3; slot = (blockIdx.x & 7) + 8 * (blockIdx.x >> 5); }
+        else { ph = blockIdx.x & 3; slot = blockIdx.x >> 2; }
+        ph_ioy = ph >> 1; ph_iox = ph & 1;
+        wslot = ph * nslot + slot;
+    }
 
 #ifdef RCF_PHASE_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -87,7 +110,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_tr_kernel(ConvArgs a) {
     // ================================================================ producers: tile -> LDS buffer
     // geometry shared by both staging forms (wave-uniform)
     const int pm = s2 ? 2 : 1;                                      // source pixels per logical pixel
-    const int g_ioy = s2 ? a.ioy : 0, g_iox = s2 ? a.iox : 0;
+    const int g_ioy = s2 ? ph_ioy : 0, g_iox = s2 ? ph_iox : 0;
     const unsigned pixbx = (unsigned)csrc * SX::BYTES, rowbx = (unsigned)ws * pixbx;
     const unsigned pixbd = (unsigned)a.c_out * SD::BYTES, rowbd = (unsigned)a.owp * pixbd;
     int wlx = a.w_in;                                               // logical columns that exist in the source
@@ -120,9 +143,13 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_tr_kernel(ConvArgs a) {
         } else {
             ok = ok && (unsigned)ly < (unsigned)a.h_in;
         }
-        const int py = pm * y + g_ioy;
+        int py = pm * y + g_ioy, px = pm * lx + g_iox;
+        if (nearest) {   // (never with the virtual tall image: select_wgrad)
+            py = min((int)floorf((float)ly * a.sy), hs - 1);
+            px = min((int)floorf((float)lx * a.sx), ws - 1);
+        }
         ok = ok && py < hs;
-        return ok ? (unsigned)((im - fimg) * hs + py) * rowbx + (unsigned)(pm * lx + g_iox) * pixbx + chb : 0xffffffffu;
+        return ok ? (unsigned)((im - fimg) * hs + py) * rowbx + (unsigned)px * pixbx + chb : 0xffffffffu;
     };
     auto doff_general = [&](const TileGeo& g, int fimg, int r, int x, bool ok, unsigned chb) -> unsigned {
         int oy = g.oy0 + r, im = g.img;
@@ -155,7 +182,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_tr_kernel(ConvArgs a) {
     };
     auto x_interior = [&](const TileGeo& g, int fimg, int& y0) {   // y0: first halo row inside image fimg
         y0 = a.vt ? g.iy0 - fimg * a.hp : g.iy0;
-        return y0 >= 0 && y0 + HYP <= a.h_in && pm * (y0 + HYP - 1) + g_ioy < hs && g.ix0 >= 0 && g.ix0 + HXP <= wlx;
+        return !nearest && y0 >= 0 && y0 + HYP <= a.h_in && pm * (y0 + HYP - 1) + g_ioy < hs && g.ix0 >= 0 && g.ix0 + HXP <= wlx;
     };
     auto d_interior = [&](const TileGeo& g, int fimg, int& y0) {
         y0 = a.vt ? g.oy0 - fimg * a.hp : g.oy0;
@@ -181,8 +208,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_tr_kernel(ConvArgs a) {
     if (producer) {
         if constexpr (B16) {
             // per-lane constants of this wave's instructions
-            unsigned kx[NJX], kd[NJD];
-            int phx[NJX], phd[NJD];   // packed (hy << 8 | hx) and validity in bit 31 for the general path
+            unsigned kx[NJX], kd[NJD];   // (the general path recomputes a unit's place in the tile from k and the lane: rare, and 14 registers fewer)
 #pragma unroll
             for (int j = 0; j < NJX; ++j) {
                 const int k = pw + 4 * j, blk = k / IPBX, kk = k % IPBX;
@@ -190,7 +216,6 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_tr_kernel(ConvArgs a) {
                 const int hy = pix / HXP, hx = pix - hy * HXP;
                 const bool ok = k < NIX && pix < C::NXP && cb + blk * 32 + q * 8 < csrc;
                 kx[j] = ok ? (unsigned)(pm * hy) * rowbx + (unsigned)(pm * hx) * pixbx + (unsigned)(blk * 32 + q * 8) * 2u : 0xffffffffu;
-                phx[j] = (hy << 8) | hx | (ok ? 0 : (int)0x80000000);
             }
 #pragma unroll
             for (int j = 0; j < NJD; ++j) {
@@ -198,7 +223,6 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_tr_kernel(ConvArgs a) {
                 const int x = lane >> 2, q = lane & 3;
                 const bool ok = k < NID && co0 + blk * 32 + q * 8 < a.c_out;
                 kd[j] = ok ? (unsigned)(a.os * kk) * rowbd + (unsigned)(a.os * x) * pixbd + (unsigned)(blk * 32 + q * 8) * 2u : 0xffffffffu;
-                phd[j] = (kk << 8) | x | (ok ? 0 : (int)0x80000000);
             }
             auto stage = [&](int tile, int buf) {
                 const TileGeo g = geo(tile);
@@ -219,8 +243,9 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_tr_kernel(ConvArgs a) {
 #pragma unroll
                         for (int j = 0; j < NJX; ++j) {
                             const int k = pw + 4 * j;
+                            const int pix = 16 * (k % IPBX) + (lane >> 2), hy = pix / HXP, hx = pix - hy * HXP;
                             const unsigned chb = (unsigned)((k / IPBX) * 32 + (lane & 3) * 8) * 2u;
-                            const unsigned vo = xoff_general(g, fimg, (phx[j] >> 8) & 0xff, phx[j] & 0xff, phx[j] >= 0, chb);
+                            const unsigned vo = xoff_general(g, fimg, hy, hx, kx[j] != 0xffffffffu, chb);
                             if (k < NIX) rcf_buffer_to_lds16(rs, Xb + (k / IPBX) * XBLK + (k % IPBX) * 1024, vo, cbb);
                         }
                     }
@@ -241,7 +266,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_tr_kernel(ConvArgs a) {
                         for (int j = 0; j < NJD; ++j) {
                             const int k = pw + 4 * j;
                             const unsigned chb = (unsigned)((k / IPBD) * 32 + (lane & 3) * 8) * 2u;
-                            const unsigned vo = doff_general(g, fimg, (phd[j] >> 8) & 0xff, phd[j] & 0xff, phd[j] >= 0, chb);
+                            const unsigned vo = doff_general(g, fimg, k % IPBD, lane >> 2, kd[j] != 0xffffffffu, chb);
                             if (k < NID) rcf_buffer_to_lds16(rs, Db + (k / IPBD) * DBLK + (k % IPBD) * 1024, vo, cob);
                         }
                     }
@@ -255,7 +280,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_tr_kernel(ConvArgs a) {
             while (tile < a.ntiles) {
                 RCF_T(t_p0);
                 const int ntile = tile + nslot;
-                if (ntile < a.ntiles) stage(ntile, buf ^ 1);
+                if (ntile < a.ntiles && RCF_WDIAG(a.xcd_band != 78)) stage(ntile, buf ^ 1);
                 RCF_T(t_p1);
                 RCF_TACC(1, t_p1, t_p0);   // 1: producer: address arithmetic + DMA issue
                 rcf_wait_dma();
@@ -289,7 +314,12 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_tr_kernel(ConvArgs a) {
             const unsigned kd0 = cvd ? (unsigned)(a.os * prd) * rowbd + (unsigned)(a.os * pcd) * pixbd + chbd : 0xffffffffu;
             const int ldsd0 = (cqd >> 3) * DBLK + (prd * 16 + pcd) * 64 + (cqd & 7) * 8;
 
-            f32x4 rx[NMX + NEX], rd[NMD];
+            // two register sets: the loads of tile t + 2 are in flight while tile t + 1 is split and written -- a tile's HBM latency
+            // (2-3 us under load, about one tile's MFMA time) is hidden behind a whole tile instead of sitting in front of the
+            // conversion.  Every issue() is unconditional straight-line code (beyond the last tile it re-reads the workgroup's first
+            // one), so the compiler's s_waitcnt before a commit() counts exactly the newer set's loads.
+            constexpr int NRX = NMX + NEX;
+            f32x4 rxa[NRX], rda[NMD], rxb[NRX], rdb[NMD];
             auto put = [&](unsigned char* dst, int plane_bytes, const f32x4& v, float scale) {
                 if constexpr (C::NPL == 1) {   // bf16 operands: round to nearest even
                     u32x2 w;
@@ -306,46 +336,56 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_tr_kernel(ConvArgs a) {
                     *reinterpret_cast<u32x2*>(dst + plane_bytes) = w1;
                 }
             };
-            auto stage = [&](int tile, int buf) {
-                const TileGeo g = geo(tile);
+            // (offsets first -- the interior / general decision is a wave-uniform branch around ARITHMETIC only -- then all loads of
+            // the tile in one basic block: with loads inside the two branches the compiler's wait-count state at the join made the
+            // commit of the OLDER set wait for the newer set's loads too, vmcnt(0), and the second register set bought nothing)
+            auto issue = [&](int tile_, f32x4 (&rx)[NRX], f32x4 (&rd)[NMD]) __attribute__((always_inline)) {
+                const TileGeo g = geo(tile_ < a.ntiles ? tile_ : slot);
+                unsigned vox[NRX], vod[NMD];
+                unsigned sox, sod, stepx, stepd;
+                const int fimgx = x_first_img(g), fimgd = d_first_img(g);
+                int y0;
+                if (x_interior(g, fimgx, y0)) {
+                    sox = (unsigned)(pm * y0 + g_ioy) * rowbx + (unsigned)(pm * g.ix0 + g_iox) * pixbx + cbb;
+                    stepx = (unsigned)(RPR * pm) * rowbx;
+#pragma unroll
+                    for (int i = 0; i < NMX; ++i) {
+                        const bool partial = RPR * i + RPR > HYP;   // compile-time: only the last round of an odd HYP
+                        vox[i] = (partial && RPR * i + prow >= HYP) ? 0xffffffffu : kx0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NEX; ++j) vox[NMX + j] = kxe[j];
+                } else {
+                    sox = cbb;
+                    stepx = 0u;
+#pragma unroll
+                    for (int i = 0; i < NMX; ++i) vox[i] = xoff_general(g, fimgx, RPR * i + prow, pcol, cvx && RPR * i + prow < HYP, chbx);
+#pragma unroll
+                    for (int j = 0; j < NEX; ++j) vox[NMX + j] = xoff_general(g, fimgx, (phe[j] >> 8) & 0xff, phe[j] & 0xff, phe[j] >= 0, chbx);
+                }
+                if (d_interior(g, fimgd, y0)) {
+                    sod = (unsigned)(y0 * a.os + a.ooy) * rowbd + (unsigned)(g.ox0 * a.os + a.oox) * pixbd + cob;
+                    stepd = (unsigned)(RPRD * a.os) * rowbd;
+#pragma unroll
+                    for (int i = 0; i < NMD; ++i) vod[i] = kd0;
+                } else {
+                    sod = cob;
+                    stepd = 0u;
+#pragma unroll
+                    for (int i = 0; i < NMD; ++i) vod[i] = doff_general(g, fimgd, RPRD * i + prd, pcd, cvd, chbd);
+                }
+                const __amdgpu_buffer_rsrc_t rsx = rcf_rsrc(src + (size_t)fimgx * hs * rowbx);
+                const __amdgpu_buffer_rsrc_t rsd = rcf_rsrc(reinterpret_cast<const unsigned char*>(a.dz) + (size_t)fimgd * a.ohp * rowbd);
+#pragma unroll
+                for (int i = 0; i < NMX; ++i) rx[i] = rcf_buffer_load_f32x4(rsx, vox[i], sox + (unsigned)i * stepx);
+#pragma unroll
+                for (int j = 0; j < NEX; ++j) rx[NMX + j] = rcf_buffer_load_f32x4(rsx, vox[NMX + j], sox);
+#pragma unroll
+                for (int i = 0; i < NMD; ++i) rd[i] = rcf_buffer_load_f32x4(rsd, vod[i], sod + (unsigned)i * stepd);
+            };
+            auto commit = [&](int buf, const f32x4 (&rx)[NRX], const f32x4 (&rd)[NMD]) __attribute__((always_inline)) {
                 unsigned char* Xb = smem_b + buf * BUF;
                 unsigned char* Db = Xb + XBYTES;
-                {
-                    const int fimg = x_first_img(g);
-                    const __amdgpu_buffer_rsrc_t rs = rcf_rsrc(src + (size_t)fimg * hs * rowbx);
-                    int y0;
-                    if (x_interior(g, fimg, y0)) {
-                        const unsigned so = (unsigned)(pm * y0 + g_ioy) * rowbx + (unsigned)(pm * g.ix0 + g_iox) * pixbx + cbb;
-#pragma unroll
-                        for (int i = 0; i < NMX; ++i) {
-                            const bool partial = RPR * i + RPR > HYP;   // compile-time: only the last round of an odd HYP
-                            const unsigned vo = (partial && RPR * i + prow >= HYP) ? 0xffffffffu : kx0;
-                            rx[i] = rcf_buffer_load_f32x4(rs, vo, so + (unsigned)(i * RPR * pm) * rowbx);
-                        }
-#pragma unroll
-                        for (int j = 0; j < NEX; ++j) rx[NMX + j] = rcf_buffer_load_f32x4(rs, kxe[j], so);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < NMX; ++i)
-                            rx[i] = rcf_buffer_load_f32x4(rs, xoff_general(g, fimg, RPR * i + prow, pcol, cvx && RPR * i + prow < HYP, chbx), cbb);
-#pragma unroll
-                        for (int j = 0; j < NEX; ++j)
-                            rx[NMX + j] = rcf_buffer_load_f32x4(rs, xoff_general(g, fimg, (phe[j] >> 8) & 0xff, phe[j] & 0xff, phe[j] >= 0, chbx), cbb);
-                    }
-                }
-                {
-                    const int fimg = d_first_img(g);
-                    const __amdgpu_buffer_rsrc_t rs = rcf_rsrc(reinterpret_cast<const unsigned char*>(a.dz) + (size_t)fimg * a.ohp * rowbd);
-                    int y0;
-                    if (d_interior(g, fimg, y0)) {
-                        const unsigned so = (unsigned)(y0 * a.os + a.ooy) * rowbd + (unsigned)(g.ox0 * a.os + a.oox) * pixbd + cob;
-#pragma unroll
-                        for (int i = 0; i < NMD; ++i) rd[i] = rcf_buffer_load_f32x4(rs, kd0, so + (unsigned)(i * RPRD * a.os) * rowbd);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < NMD; ++i) rd[i] = rcf_buffer_load_f32x4(rs, doff_general(g, fimg, RPRD * i + prd, pcd, cvd, chbd), cob);
-                    }
-                }
 #pragma unroll
                 for (int i = 0; i < NMX; ++i)
                     if (RPR * i + RPR <= HYP || RPR * i + prow < HYP) put(Xb + ldsx0 + i * RPR * HXP * 64, XPL, rx[i], sc.sa);
@@ -356,20 +396,39 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_tr_kernel(ConvArgs a) {
                 for (int i = 0; i < NMD; ++i) put(Db + ldsd0 + i * RPRD * 1024, DPL, rd[i], sc.sb);
             };
             int tile = slot;
-            if (tile < a.ntiles) stage(tile, 0);
+            issue(tile, rxa, rda);
+            issue(tile + nslot, rxb, rdb);
+            commit(0, rxa, rda);
             __syncthreads();
             int buf = 0;
+            // iteration of tile t (the consumers multiply it from `buf`): loads of t + 2 into the set committed last time, then tile
+            // t + 1 (loaded a whole iteration ago) -> the other buffer.  Unrolled by two so that the register sets are static.
             while (tile < a.ntiles) {
-                RCF_T(t_p0);
-                const int ntile = tile + nslot;
-                if (ntile < a.ntiles) stage(ntile, buf ^ 1);
-                RCF_T(t_p1);
-                RCF_TACC(1, t_p1, t_p0);   // 1: producer: loads, plane split, LDS writes of the next tile
-                __syncthreads();
-                RCF_T(t_p2);
-                RCF_TACC(2, t_p2, t_p1);   // 2: producer: barrier (idle while the consumers multiply)
-                tile = ntile;
-                buf ^= 1;
+                {
+                    RCF_T(t_p0);
+                    if (RCF_WDIAG(a.xcd_band != 78)) issue(tile + 2 * nslot, rxa, rda);
+                    if (tile + nslot < a.ntiles && RCF_WDIAG(a.xcd_band != 78)) commit(buf ^ 1, rxb, rdb);
+                    RCF_T(t_p1);
+                    RCF_TACC(1, t_p1, t_p0);   // 1: producer: load issue of tile t + 2, plane split + LDS writes of tile t + 1
+                    __syncthreads();
+                    RCF_T(t_p2);
+                    RCF_TACC(2, t_p2, t_p1);   // 2: producer: barrier (idle while the consumers multiply)
+                    tile += nslot;
+                    buf ^= 1;
+                }
+                if (tile >= a.ntiles) break;
+                {
+                    RCF_T(t_p0);
+                    if (RCF_WDIAG(a.xcd_band != 78)) issue(tile + 2 * nslot, rxb, rdb);
+                    if (tile + nslot < a.ntiles && RCF_WDIAG(a.xcd_band != 78)) commit(buf ^ 1, rxa, rda);
+                    RCF_T(t_p1);
+                    RCF_TACC(1, t_p1, t_p0);
+                    __syncthreads();
+                    RCF_T(t_p2);
+                    RCF_TACC(2, t_p2, t_p1);
+                    tile += nslot;
+                    buf ^= 1;
+                }
             }
         }
         // the consumers' slice reduction below passes KSPLIT - 1 barrier pairs
@@ -438,6 +497,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_tr_kernel(ConvArgs a) {
         for (int pl = 0; pl < NPL; ++pl) { rd_d(db, 0, pl, 0, 0); rd_d(db, 0, pl, 0, 1); }
         __builtin_amdgcn_sched_barrier(0);
 
+        if (RCF_WDIAG(a.xcd_band != 79))
 #pragma unroll
         for (int s = 0; s < C::NS; ++s) {
             const int cur = s & 1, nxt = cur ^ 1;
@@ -534,10 +594,10 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_tr_kernel(ConvArgs a) {
             }
         }
     }
-    if (wk == 0) {
+    if (wk == 0 && RCF_WDIAG(a.xcd_band != 77)) {
         const int q32_0 = first ? 0 : (a.c1 + 31) / 32;   // 32-channel chunk index of this source's first chunk in k
         const int co = co0 + wj * 32 + li;
-        float* wsp = a.ws + (size_t)slot * a.ktot * a.cop;
+        float* wsp = a.ws + (size_t)wslot * a.ktot * a.cop;
 #pragma unroll
         for (int tap = 0; tap < C::T; ++tap) {
 #pragma unroll

@@ -308,10 +308,18 @@ class Engine(object):
         """A buffer was just zero-filled on the CURRENT stream and its slots are about to be handed to kernels on any of the engine's
         streams (atomicMax into a zeroed scalar): the other streams wait for the fill, or it could land after their maxima."""
         cur = torch.cuda.current_stream()
+        if not self._open_switches:
+            self._main = cur      # no switch open: the current stream IS the step's main stream (not a stale one from an earlier step)
         ev = cur.record_event()
         for s in (self._main, self._branch, self._side):
             if s is not None and s != cur:
                 s.wait_event(ev)
+        # a stream that was made to wait has pending work from the main stream's point of view: side_join() must rejoin it (inside
+        # a hipGraph capture an unjoined stream fails capture_end)
+        if self._branch is not None and self._branch != cur:
+            self._branch_busy = True
+        if self._side is not None and self._side != cur:
+            self._side_busy = True
 
     def _amax_slot(self):
         '''A zeroed device scalar for the maximum of a tensor this step produces (None outside the fp16 arithmetic).'''
@@ -673,7 +681,7 @@ class Engine(object):
             if self.up2x_one_launch or ops.act_dtype() == torch.bfloat16 or dm.precision == RCF_PREC_F16X2:
                 try:
                     qm = ops.conv_query(dm)
-                except ops._lib.RcfError:
+                except ops._lib.RcfUnsupported:   # no kernel for this form (any other error -- a launch failure -- propagates)
                     qm = None
             if qm is not None:
                 return self._conv_up2x_merged(layer, x, dm, qm, want_stats, fold)
@@ -889,7 +897,7 @@ class Engine(object):
             return False
         try:
             qm = ops.conv_query(dm)
-        except ops._lib.RcfError:
+        except ops._lib.RcfUnsupported:   # no kernel for this form (any other error -- a launch failure -- propagates)
             self._s2_dgrad_ok[key] = False
             return False
         self._s2_dgrad_ok[key] = True
@@ -928,7 +936,7 @@ class Engine(object):
             finally:
                 if self.prof is not None:
                     self.prof.end()
-        except ops._lib.RcfError:
+        except ops._lib.RcfUnsupported:   # no kernel for this form (any other error -- a launch failure -- propagates)
             self._s2_wgrad_ok[key] = False
             return False
         self._s2_wgrad_ok[key] = True
@@ -960,7 +968,7 @@ class Engine(object):
             finally:
                 if self.prof is not None:
                     self.prof.end()
-        except ops._lib.RcfError:
+        except ops._lib.RcfUnsupported:   # no kernel for this form (any other error -- a launch failure -- propagates)
             self._up2x_wgrad_ok[key] = False
             return False
         self._up2x_wgrad_ok[key] = True

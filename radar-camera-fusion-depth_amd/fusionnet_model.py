@@ -294,7 +294,8 @@ class FusionNetModel(object):
             with torch.cuda.device(self._param_arena.device):
                 return self._run_engine_impl(image, input_depth, record)
         except BaseException:
-            self._engine.recover()      # back on the caller's stream, side streams joined, no engine flag left set
+            with torch.cuda.device(self._param_arena.device):   # the engine's streams belong to the model's device
+                self._engine.recover()      # back on the caller's stream, side streams joined, no engine flag left set
             raise
         finally:
             ops.set_precision('fp32')
@@ -351,7 +352,8 @@ class FusionNetModel(object):
                 Engine.backward(out, tape, ddepth)
                 self._engine.side_join()
         except BaseException:
-            self._engine.recover()
+            with torch.cuda.device(self._param_arena.device):   # the engine's streams belong to the model's device
+                self._engine.recover()
             raise
         finally:
             self._engine.in_backward = False

@@ -188,7 +188,8 @@ class RadarNetModel(object):
             with torch.cuda.device(self._param_arena.device):   # kernels go to the current stream of the current device
                 return self._run_engine_impl(image, point, rois, record)
         except BaseException:
-            self._engine.recover()
+            with torch.cuda.device(self._param_arena.device):   # the engine's streams belong to the model's device
+                self._engine.recover()
             raise
         finally:
             ops.set_precision('fp32')

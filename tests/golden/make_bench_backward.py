@@ -71,6 +71,19 @@ def checkpoint_blocks(model):
             mod.forward = (lambda f: (lambda *a, **kw: checkpoint(f, *a, use_reentrant=False, **kw)))(inner)
 
 
+def conv_per_sample():
+    '''fp64 only: stock PyTorch has no fast fp64 convolution on the CPU; its fallback builds an im2col buffer of C_in x 9 x H x W
+    elements PER SAMPLE, one per thread in parallel over the batch -- 8 x 6.6 GB for the 64-channel 900x1600 layer.  One sample per call
+    keeps one buffer alive (the GEMM inside still uses every thread); the results are the same convolutions.'''
+    orig = torch.nn.Conv2d.forward
+
+    def forward(self, x):
+        if x.dtype == torch.float64 and x.shape[0] > 1:
+            return torch.cat([orig(self, x[i:i + 1]) for i in range(x.shape[0])], 0)
+        return orig(self, x)
+    torch.nn.Conv2d.forward = forward
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -79,6 +92,7 @@ def main():
         rec = dict(np.load(PATH))
         model, b, gt = build(torch.float64)
         checkpoint_blocks(model)
+        conv_per_sample()
         out = model.forward(b['image'], b['input_depth'])
         loss = model.compute_loss(out, gt, b['lidar_map'], 2.0)[0]
         loss.backward()

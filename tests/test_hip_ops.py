@@ -1023,3 +1023,11 @@ def test_images_beyond_the_buffer_range_are_refused_loudly(ops):
     big = ops.make_fwd_desc(1, 4096, 4096, 64, 0, 64, 3, 1)          # 4.3 GB per fp32 image
     with pytest.raises(_lib.RcfError):
         ops.conv_query(big)
+    # virtual tall image (batch > 1, 3x3 stride 1): a tile higher than the image spans ceil(34 / (h + 1)) + 1 images from ONE descriptor
+    # -- 8 rows: 5 images, so 0.43 GB per image is the limit.  0.54 GB images (8 x 131072 x 128 fp32) would overflow the 2 GB range
+    wide = ops.make_fwd_desc(2, 8, 131072, 128, 0, 128, 3, 1)
+    try:
+        info = ops.conv_query(wide)
+        assert (info.kernel_id // 100) % 10 < 4, 'a virtual-tall tiling was chosen for 0.54 GB images of 8 rows: %d' % info.kernel_id
+    except _lib.RcfUnsupported:
+        pass

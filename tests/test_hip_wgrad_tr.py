@@ -87,7 +87,8 @@ def _run(ops, prec, k, c1, c2, co, n, h, w, tr, desc_fn=None, seed=30):
     if prec == 'f16x2':
         a1 = ops.amax(g1)
         a2 = ops.amax(g2) if g2 is not None else None
-        scales = ops.make_scales(a1, a2, None, ops.amax(gz))
+        az = ops.amax(gz)   # (all three kept alive until the launch: rcf_conv_scales holds raw device pointers)
+        scales = ops.make_scales(a1, a2, None, az)
     ops.conv_wgrad(d, g1, g2, gz, dw, ws, scales=scales)
     torch.cuda.synchronize()
     return dw.cpu(), (x1, x2, dz), info.wgrad_kernel_id
@@ -142,7 +143,8 @@ def test_tr_weight_gradient_of_an_up2x_phase_reads_dz_strided(ops, prec, a, b):
         info = ops.conv_query(d)
         wsb = torch.empty(max(1, info.wgrad_workspace_floats), device='cuda')
         dw = torch.full((co, ci, 2, 2), float('nan'), device='cuda')
-        scales = ops.make_scales(ops.amax(gx), None, None, ops.amax(gz)) if prec == 'f16x2' else None
+        amx, amz = (ops.amax(gx), ops.amax(gz)) if prec == 'f16x2' else (None, None)   # (kept alive: rcf_conv_scales holds raw device pointers)
+        scales = ops.make_scales(amx, None, None, amz) if prec == 'f16x2' else None
         ops.conv_wgrad(d, gx, None, gz, dw, wsb, scales=scales)
         torch.cuda.synchronize()
         outs[tr] = (dw.cpu(), info.wgrad_kernel_id)
@@ -181,7 +183,8 @@ def test_tr_weight_gradient_of_a_stride2_phase_reads_x_strided(ops, prec, a, b):
         info = ops.conv_query(d)
         wsb = torch.empty(max(1, info.wgrad_workspace_floats), device='cuda')
         dw = torch.full((co, ci, 2, 2), float('nan'), device='cuda')
-        scales = ops.make_scales(ops.amax(gx), None, None, ops.amax(gz)) if prec == 'f16x2' else None
+        amx, amz = (ops.amax(gx), ops.amax(gz)) if prec == 'f16x2' else (None, None)   # (kept alive: rcf_conv_scales holds raw device pointers)
+        scales = ops.make_scales(amx, None, None, amz) if prec == 'f16x2' else None
         ops.conv_wgrad(d, gx, None, gz, dw, wsb, scales=scales)
         torch.cuda.synchronize()
         outs[tr] = (dw.cpu(), info.wgrad_kernel_id)
@@ -226,12 +229,90 @@ def test_tr_weight_gradient_1x1_with_bf16_tensors(ops, case):
     assert torch.equal(outs[True][0], outs[False][0])
 
 
+@pytest.mark.parametrize('prec', ['f16x2', 'bf16'])
+@pytest.mark.parametrize('case', [(64, 64, 2, 29, 50, 15, 25), (128, 64, 1, 57, 100, 29, 50), (32, 32, 2, 35, 70, 15, 29)], ids=lambda c: str(c))
+def test_tr_weight_gradient_with_the_nearest_upsample_gather(ops, prec, case):
+    '''UpConv2d's convolution (src/net_utils.py:193-198): x is F.interpolate(source, size=(h, w)) (nearest), gathered while staging.'''
+    c1, co, n, h, w, hs, ws = case
+    ops.set_precision(prec)
+    b16 = prec == 'bf16'
+    dt = torch.bfloat16 if b16 else torch.float32
+    x = rnd(n, c1, hs, ws, seed=9)
+    dz = rnd(n, co, h, w, seed=10)
+    if b16:
+        x, dz = x.bfloat16().float(), dz.bfloat16().float()
+    to = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda().to(dt)
+    gx, gz = to(x), to(dz)
+    outs = {}
+    for tr in (True, False):
+        os.environ['RCF_WGRAD_TR'] = '1' if tr else '0'
+        d = ops.make_fwd_desc(n, h, w, c1, 0, co, 3, 1, hs, ws, 1)
+        info = ops.conv_query(d)
+        wsb = torch.empty(max(1, info.wgrad_workspace_floats), device='cuda')
+        dw = torch.full((co, c1, 3, 3), float('nan'), device='cuda')
+        amx, amz = (ops.amax(gx), ops.amax(gz)) if prec == 'f16x2' else (None, None)   # (kept alive: rcf_conv_scales holds raw device pointers)
+        scales = ops.make_scales(amx, None, None, amz) if prec == 'f16x2' else None
+        ops.conv_wgrad(d, gx, None, gz, dw, wsb, scales=scales)
+        torch.cuda.synchronize()
+        outs[tr] = (dw.cpu(), info.wgrad_kernel_id)
+    wt = torch.zeros(co, c1, 3, 3, requires_grad=True)
+    out = F.conv2d(F.interpolate(x, size=(h, w)), wt, padding=1)
+    (out * dz).sum().backward()
+    e = rel(outs[True][0], wt.grad)
+    print('%s nearest %s: ids %d / %d, vs CPU %.2e' % (prec, case, outs[True][1], outs[False][1], e))
+    assert (outs[True][1] // 100) % 10 in (3, 7)
+    assert e < (1e-4 if prec == 'f16x2' else 3e-5)
+    assert torch.equal(outs[True][0], outs[False][0])
+
+
+@pytest.mark.parametrize('prec', ['f16x2', 'bf16'])
+@pytest.mark.parametrize('case', [(64, 128, 2, 45, 63), (32, 64, 8, 57, 100), (128, 256, 2, 29, 50)], ids=lambda c: str(c))
+def test_tr_four_phase_stride2_weight_gradient_in_one_launch(ops, prec, case):
+    '''phase_sum == 1 (ops.make_s2_wgrad_desc(all_phases=True)): (slot, phase) workgroups, dw = [4][co][ci][2][2] -- bitwise the
+    previous kernel's one-launch form, and each phase equal to its single-phase launch.'''
+    ci, co, n, h, w = case
+    ops.set_precision(prec)
+    b16 = prec == 'bf16'
+    dt = torch.bfloat16 if b16 else torch.float32
+    fwd = ops.make_fwd_desc(n, h, w, ci, 0, co, 3, 2)
+    x = rnd(n, ci, h, w, seed=11)
+    dz = rnd(n, co, fwd.h_out, fwd.w_out, seed=12)
+    if b16:
+        x, dz = x.bfloat16().float(), dz.bfloat16().float()
+    to = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda().to(dt)
+    gx, gz = to(x), to(dz)
+    amx, amz = (ops.amax(gx), ops.amax(gz)) if prec == 'f16x2' else (None, None)   # (kept alive: rcf_conv_scales holds raw device pointers)
+    scales = ops.make_scales(amx, None, None, amz) if prec == 'f16x2' else None
+    outs = {}
+    for tr in (True, False):
+        os.environ['RCF_WGRAD_TR'] = '1' if tr else '0'
+        d = ops.make_s2_wgrad_desc(fwd, 0, 0, all_phases=True)
+        info = ops.conv_query(d)
+        wsb = torch.empty(max(1, info.wgrad_workspace_floats), device='cuda')
+        dw = torch.full((4, co, ci, 2, 2), float('nan'), device='cuda')
+        ops.conv_wgrad(d, gx, None, gz, dw, wsb, scales=scales)
+        torch.cuda.synchronize()
+        outs[tr] = (dw.cpu(), info.wgrad_kernel_id)
+    assert (outs[True][1] // 100) % 10 in (3, 7) and (outs[False][1] // 100) % 10 in (1, 5)
+    assert torch.isfinite(outs[True][0]).all()
+    assert torch.equal(outs[True][0], outs[False][0])
+    os.environ['RCF_WGRAD_TR'] = '1'
+    worst = 0.0
+    for a in (0, 1):
+        for b in (0, 1):
+            xph = x[:, :, a::2, b::2]
+            xph = F.pad(xph, (1, fwd.w_out - xph.shape[3], 1, fwd.h_out - xph.shape[2]))
+            wt = torch.zeros(co, ci, 2, 2, requires_grad=True)
+            (F.conv2d(xph, wt) * dz).sum().backward()
+            worst = max(worst, rel(outs[True][0][2 * a + b], wt.grad))
+    print('%s four-phase stride-2 weight gradient %s: ids %d / %d, worst phase vs CPU %.2e' % (prec, case, outs[True][1], outs[False][1], worst))
+    assert worst < (1e-4 if prec == 'f16x2' else 3e-5)
+
+
 def test_tr_kernel_is_not_taken_where_it_does_not_apply(ops):
-    '''Nearest-upsample gather, the merged phase forms and the exact three-plane tier keep conv_wgrad_split_kernel.'''
+    '''The merged up-2x phase pairs and the exact three-plane tier keep conv_wgrad_split_kernel.'''
     os.environ['RCF_WGRAD_TR'] = '1'
     ops.set_precision('f16x2')
-    d = ops.make_fwd_desc(2, 29, 50, 64, 0, 64, 3, 1, 15, 25, 1)    # nearest gather
-    assert (ops.conv_query(d).wgrad_kernel_id // 100) % 10 in (1, 5)
     d = ops.make_up2x_fwd_desc(2, 20, 30, 64, 32, 0, 0, phase_out=True)
     assert (ops.conv_query(d).wgrad_kernel_id // 100) % 10 in (1, 5)
     ops.set_precision('fp32')

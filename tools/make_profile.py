@@ -22,10 +22,12 @@ FAMILIES = [   # (bench.py KERNEL_NAMES entry, regular expression on the cleaned
     ('conv_split_kernel 4x4 stem on the space-to-depth image', r'conv_split_kernel<SplitCfg<4,'),
     ('conv_wgrad_split_kernel', r'conv_wgrad_split_kernel<'),
     ('conv_wgrad_split_kernel 3x3', r'conv_wgrad_split_kernel<WsCfg<\d+, \d+, 3,'),
+    ('conv_wgrad_tr_kernel', r'conv_wgrad_tr_kernel<'),
+    ('conv_wgrad_tr_kernel 3x3', r'conv_wgrad_tr_kernel<WtCfg<\d+, \d+, 3,'),
     ('conv_fwd_kernel 3x3 s1', r'conv_fwd_kernel<FwdCfg<3, 3, 0, 1'),
     # the kernels north_star's "3x3 encoder convs" run on: 3x3 forward / input gradient (64-co and small-layer tiles, both strides) and
     # the 3x3 weight gradients -- the decoder's launches of the same kernels are in this row too (PMC rows are per kernel, not per layer)
-    ('kernels of the encoder 3x3 convolutions', r'conv_split_kernel<SplitCfg<3, 2,|conv_split_kernel<SplitCfg<3, 1, \d+, 2,|conv_split_kernel<SplitCfg<3, \d+, \d+, \d+, \d+, 2(, \d+)?>|conv_wgrad_split_kernel<WsCfg<\d+, \d+, 3,'),
+    ('kernels of the encoder 3x3 convolutions', r'conv_split_kernel<SplitCfg<3, 2,|conv_split_kernel<SplitCfg<3, 1, \d+, 2,|conv_split_kernel<SplitCfg<3, \d+, \d+, \d+, \d+, 2(, \d+)?>|conv_wgrad_split_kernel<WsCfg<\d+, \d+, 3,|conv_wgrad_tr_kernel<WtCfg<\d+, \d+, 3,'),
 ]
 
 
@@ -80,6 +82,8 @@ def _csrc_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, 'radar-camera-fusion-depth_amd', 'csrc')
     for name in sorted(os.listdir(d)):
+        if not name.endswith(('.h', '.hip')):
+            continue      # (a stray cache directory is not a kernel source)
         h.update(open(os.path.join(d, name), 'rb').read())
     return h.hexdigest()[:16]
 try:

@@ -18,6 +18,7 @@ FAMILIES = [
     ('conv_b16_kernel 4x4 stem on the space-to-depth image', r'conv_b16_kernel<DmaCfg<4,'),
     ('conv1x1_b16_kernel', r'conv1x1_b16_kernel<'),
     ('conv_wgrad_split_kernel', r'conv_wgrad_split_kernel<'),
+    ('conv_wgrad_tr_kernel', r'conv_wgrad_tr_kernel<'),
     ('conv_split_kernel (bf16 operands)', r'conv_split_kernel<'),
     ('BatchNorm / activation / fusion elementwise', r'(bn_act_|fuse_|head_bn_)'),
 ]
@@ -54,6 +55,8 @@ def csrc_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, 'radar-camera-fusion-depth_amd', 'csrc')
     for name in sorted(os.listdir(d)):
+        if not name.endswith(('.h', '.hip')):
+            continue      # (a stray cache directory is not a kernel source)
         h.update(open(os.path.join(d, name), 'rb').read())
     return h.hexdigest()[:16]
 

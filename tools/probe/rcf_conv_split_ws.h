@@ -17,7 +17,7 @@
 // Barrier discipline: both roles walk the same (tile, chunk, kernel row) sequence and execute the same barriers.
 #pragma once
 #ifndef RCF_WS_VARIANT
-#define RCF_WS_VARIANT 0      // probe builds only (tools/probe/ws_harness.hip): bit flags that cut parts of the consumer away (wrong results)
+#define RCF_WS_VARIANT 0      // probe builds only (the harness that instantiated this kernel went with the round-4 A-tile layout it targets; kept as the record of the experiment, not built): bit flags that cut parts of the consumer away (wrong results)
 #endif
 #ifndef RCF_WS_PROBE_ROLE
 #define RCF_WS_PROBE_ROLE 0   // probe builds only (tools/probe): 1 = compile the consumer role alone, 2 = the producer role alone

@@ -73,3 +73,22 @@ for prec in ('f16x2', 'bf16'):
               % (name, gf, t['0'], gf / t['0'] * 1e3, t['1'], gf / t['1'] * 1e3, t['1'] / t['0'], same, res['0'][1], res['1'][1]))
     print('%-40s %9s | %9.1f %7s | %9.1f %7s | %6.3f' % ('sum', '', tot[0], '', tot[1], '', tot[1] / max(tot[0], 1e-9)))
 os.environ.pop('RCF_WGRAD_TR', None)
+
+# fixed cost per launch (everything that does not scale with the pixels: launch, per-workgroup partial write, reduction kernel):
+# T(n) = fixed + n * per_image  =>  fixed = 2 T(n) - T(2 n)
+if os.environ.get('RCF_WGRAD_BENCH_SWEEP', '1') != '0':
+    for prec in ('f16x2', 'bf16'):
+        ops.set_precision(prec)
+        adt = ops.act_dtype()
+        for name, k, c1, co, h, w in (('64->64 @225x400', 3, 64, 64, 225, 400), ('256->256 @57x100', 3, 256, 256, 57, 100)):
+            ts = {}
+            for n in (4, 8, 16):
+                d = ops.make_fwd_desc(n, h, w, c1, 0, co, k, 1)
+                x1 = torch.randn(n, h, w, c1, device='cuda').to(adt)
+                dz = torch.randn(n, h, w, co, device='cuda').to(adt)
+                info = ops.conv_query(d)
+                wsb = torch.empty(max(1, info.wgrad_workspace_floats), device='cuda')
+                dw = torch.empty(co, c1, k, k, device='cuda')
+                ts[n] = min(timeit(lambda: ops.conv_wgrad(d, x1, None, dz, dw, wsb)) for _ in range(3))
+            print('%s %s: n=4 %.1f us, n=8 %.1f us, n=16 %.1f us -> fixed cost per launch %.1f us (from 4, 8) / %.1f us (from 8, 16)'
+                  % (prec, name, ts[4], ts[8], ts[16], 2 * ts[4] - ts[8], 2 * ts[8] - ts[16]))
