@@ -398,6 +398,12 @@ int rcf_nhwc_to_nchw(const float* in, float* out, int n, int c, int h, int w, vo
  * 0 gives depth = z[argmax].  points: [K][3] (x px, y px, z m).  depth/response: [H][W]. */
 int rcf_radar_scatter(const float* crops, const float* points, int k, int h, int w, int wc,
                       int strict_reference, float* depth, float* response, void* stream);
+/* The same from the correspondence LOGITS (what RadarNetModel.forward(return_logits=True) returns; src/radarnet_main.py:556-567 applies
+ * torch.sigmoid and then zeroes responses < 0.5): the threshold is taken on the sign of the logit -- sigmoid(l) >= 0.5 exactly when
+ * l >= 0 -- and response = 1 / (1 + expf(-l)) of the survivors, so the keep / drop decision of a pixel cannot depend on an ulp of this
+ * device's sigmoid.  (The reference's fp32 CPU sigmoid rounds logits in (-6e-8, 0) up to 0.5 and keeps them; this entry drops them.) */
+int rcf_radar_scatter_logits(const float* logits, const float* points, int k, int h, int w, int wc,
+                             int strict_reference, float* depth, float* response, void* stream);
 
 /* ---- RadarNet stage 1: ops FusionNet does not have --------------------------------------------------------- */
 

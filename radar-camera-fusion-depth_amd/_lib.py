@@ -119,6 +119,7 @@ _SIGNATURES = {
     'rcf_nchw_to_nhwc': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     'rcf_nhwc_to_nchw': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     'rcf_radar_scatter': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    'rcf_radar_scatter_logits': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
 }
 B16_TWINS = ('rcf_bn_act_fwd', 'rcf_fuse_fwd', 'rcf_bn_act_bwd_reduce', 'rcf_bn_act_bwd_apply', 'rcf_fuse_bwd_reduce', 'rcf_fuse_bwd_apply',
              'rcf_head_bn_bwd_reduce', 'rcf_head_bn_bwd_apply', 'rcf_maxpool3x3s2_fwd', 'rcf_maxpool3x3s2_bwd', 'rcf_upsample_nearest_bwd',

@@ -588,9 +588,19 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_tr_kernel(ConvArgs a) {
             __syncthreads();
             if (wk == s - 1) {
 #pragma unroll
-                for (int tap = 0; tap < C::T; ++tap)
+                for (int tap = 0; tap < C::T; ++tap) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[tap][r] += red[(tap * 16 + r) * 64 + lane];
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[tap][r] + red[(tap * 16 + r) * 64 + lane];
+                        // the sum is pinned HERE (an empty asm that "uses" the register: no instruction).  Left alone, the adds are sunk
+                        // into the partial-write block below (their only use) and all 144 reads end up in flight at once -- beside 144
+                        // accumulators that does not fit the 256 registers of a two-waves-per-SIMD kernel (39 spilled VGPRs in the 16-row
+                        // bf16 variants)
+                        __asm__ volatile("" : "+v"(v));
+                        acc[tap][r] = v;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // one tap's 16 reads at a time
+                }
             }
         }
     }

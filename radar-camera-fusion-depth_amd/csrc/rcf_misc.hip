@@ -920,6 +920,12 @@ __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* __restri
 // One thread per output pixel, looping over the K points in order (K <= ~100).  The canvas is W + 2*pad wide
 // (pad = Wc/2); crop k occupies canvas columns [int(x_k) - pad, int(x_k) + pad); the output is canvas columns
 // [pad, pad + W).  Crop rows are the bottom `hc` rows of the canvas.
+// LOGITS: `crops` holds the correspondence LOGITS (RadarNetModel.forward(return_logits=True)).  The reference thresholds
+// sigmoid(logit) < 0.5 (src/radarnet_main.py:563-567); sigmoid is monotonic with sigmoid(0) = 0.5, so the decision is taken on the SIGN of
+// the logit -- no transcendental near the threshold, nothing that could differ by an ulp between this device's sigmoid and the CPU's --
+// and the response written is 1 / (1 + expf(-logit)) of the surviving values (the maximum over points is still taken on the responses,
+// like the reference: saturated responses tie, and the first point wins).
+template <bool LOGITS>
 __global__ void __launch_bounds__(256) radar_scatter_kernel(const float* __restrict__ crops, const float* __restrict__ pts, int k,
                                                             int h, int w, int hc, int wc, int strict, float* __restrict__ depth,
                                                             float* __restrict__ resp) {
@@ -939,7 +945,8 @@ __global__ void __launch_bounds__(256) radar_scatter_kernel(const float* __restr
             const int u = cx - x0;
             if (cy >= 0 && u >= 0 && u < 2 * pad && u < wc) {
                 v = crops[((size_t)i * hc + cy) * wc + u];
-                if (v < 0.5f) v = 0.f;    // thresholding any response less than 0.5 to 0
+                if (LOGITS) v = v >= 0.f ? 1.f / (1.f + expf(-v)) : 0.f;
+                else if (v < 0.5f) v = 0.f;    // thresholding any response less than 0.5 to 0
             }
             if (first || v > best) { best = v; arg = i; first = false; }
         }
@@ -1272,7 +1279,17 @@ extern "C" int rcf_radar_scatter(const float* crops, const float* points, int k,
     if (!crops || !points || !depth || !response || k <= 0 || h <= 0 || w <= 0 || wc <= 0 || (wc & 1)) return RCF_EINVAL;
     const long long total = (long long)h * w;
     unsigned b = nblk(total, 256); if (b > 8192) b = 8192;
-    hipLaunchKernelGGL(radar_scatter_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, crops, points, k, h, w, h, wc,
+    hipLaunchKernelGGL(radar_scatter_kernel<false>, dim3(b), dim3(256), 0, (hipStream_t)stream, crops, points, k, h, w, h, wc,
+                       strict_reference, depth, response);
+    return rcf_launch_status();
+}
+
+extern "C" int rcf_radar_scatter_logits(const float* logits, const float* points, int k, int h, int w, int wc, int strict_reference,
+                                        float* depth, float* response, void* stream) {
+    if (!logits || !points || !depth || !response || k <= 0 || h <= 0 || w <= 0 || wc <= 0 || (wc & 1)) return RCF_EINVAL;
+    const long long total = (long long)h * w;
+    unsigned b = nblk(total, 256); if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(radar_scatter_kernel<true>, dim3(b), dim3(256), 0, (hipStream_t)stream, logits, points, k, h, w, h, wc,
                        strict_reference, depth, response);
     return rcf_launch_status();
 }

@@ -626,12 +626,14 @@ def nhwc_to_nchw(x):
     return out
 
 
-def radar_scatter(crops, points, width, strict_reference=True):
+def radar_scatter(crops, points, width, strict_reference=True, logits=False):
+    """crops: sigmoid responses (K, H, Wc); logits=True: the correspondence logits instead (threshold on their sign, rcf_radar_scatter_logits)."""
     k, h, wc = crops.shape
     depth = torch.empty((h, width), dtype=torch.float32, device=crops.device)
     resp = torch.empty((h, width), dtype=torch.float32, device=crops.device)
-    check(_lib.load().rcf_radar_scatter(_f32(crops), _f32(points), k, h, width, wc, 1 if strict_reference else 0,
-                                        _f32(depth), _f32(resp), _stream()), 'rcf_radar_scatter')
+    fn = _lib.load().rcf_radar_scatter_logits if logits else _lib.load().rcf_radar_scatter
+    check(fn(_f32(crops), _f32(points), k, h, width, wc, 1 if strict_reference else 0, _f32(depth), _f32(resp), _stream()),
+          'rcf_radar_scatter_logits' if logits else 'rcf_radar_scatter')
     return depth, resp
 
 

@@ -1,7 +1,8 @@
 '''
 Stage 1 -> stage 2 glue of the method: from an image and its radar points to the dense radar depth / response maps that
 FusionNet consumes -- radarnet_main.forward (src/radarnet_main.py:534-591) on the HIP path: RadarNetModel.forward on the
-edge-padded image for all points at once, then rcf_radar_scatter (thresholding at 0.5, max / argmax over the points' canvases,
+edge-padded image for all points at once, then rcf_radar_scatter_logits (sigmoid and the 0.5 threshold, taken on the logit's sign, max /
+argmax over the points' canvases,
 and the reference's int64 index -> depth replacement chain, quirks included).
 '''
 import torch
@@ -33,9 +34,10 @@ def radarnet_forward(model, image, radar_points, bounding_boxes_list):
     height, width = image.shape[-2], image.shape[-1]
     crop_height = height - int(patch[0])
     with torch.no_grad():
-        crops = model.forward(image=image_p, point=radar_points, bounding_boxes=bounding_boxes_list, return_logits=False)
-    depth, resp = ops.radar_scatter(crops[:, 0].contiguous(), radar_points.contiguous().to(torch.float32), width,
-                                    strict_reference=True)
+        # logits, not torch.sigmoid(logits): the 0.5 threshold of :563-567 is taken on the sign of the logit inside the scatter kernel
+        logits = model.forward(image=image_p, point=radar_points, bounding_boxes=bounding_boxes_list, return_logits=True)
+    depth, resp = ops.radar_scatter(logits[:, 0].contiguous(), radar_points.contiguous().to(torch.float32), width,
+                                    strict_reference=True, logits=True)
     if crop_height > 0:   # crops cover the bottom patch_height rows (:566-569); nothing is predicted above them
         top = torch.zeros((crop_height, width), dtype=torch.float32, device=depth.device)
         depth, resp = torch.cat([top, depth], 0), torch.cat([top, resp], 0)

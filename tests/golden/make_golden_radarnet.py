@@ -51,6 +51,7 @@ def import_reference():
 
 def main():
     torch.manual_seed(0)
+    torch.set_num_threads(8)   # the fixtures regenerate bit-identically only at a fixed intra-op thread count (oneDNN reduction order)
     from rcf_amd import synth
     ref_mod = import_reference()
     gold = os.path.dirname(os.path.abspath(__file__))

@@ -167,6 +167,80 @@ def test_config1_fp32_batch8_gradients_are_the_sum_of_batch1_gradients(env, tier
     assert worst < 2e-4
 
 
+def _named_params(m):
+    out = []
+    for prefix, mod in (('encoder.', m.encoder), ('decoder.', m.decoder)):
+        for k, p in mod.named_parameters():
+            out.append((prefix + k, p))
+    return out
+
+
+@pytest.mark.parametrize('tier', ['fp32', 'fp32_3plane', 'bf16'])
+def test_config1_headline_backward_and_three_adam_steps_against_the_oracle(env, tier):
+    '''The BACKWARD the metric times, at the metric's own workload: bench.py's step (published net, weights seed 1234, data seed 1234,
+    batch 8, 900x1600, train-mode BatchNorm over the eight images, outlier removal (7, 1.5), masked L1 + 2.0 x lidar, Adam lr 1e-3)
+    against tests/golden/bench_backward_b8.npz -- the CPU oracle's gradients of that step (make_bench_backward.py; the oracle is pinned
+    to the real reference at 0.00e+00 by make_golden.py), with the fp64 run of the same step as yardstick.
+      * every parameter gradient's L2 norm: 1e-3 of the oracle's where the fp32 oracle itself is that close to fp64, else within 3 x the
+        oracle's own distance from fp64 (fp32 gradients of this net carry LeakyReLU / max-pool decision flips: DESIGN.md 2);
+      * 2048 sampled elements of each of the ten largest gradient tensors against fp64, T1b's rule: per tensor within 5 x the fp32
+        oracle's own max-norm distance, the median over the ten within 3 x;
+      * the losses of the first three optimizer steps (the trajectory through two Adam updates) at 1e-3.
+    bf16 tensors: cosine of every sampled tensor against fp64 and the loss trajectory at the bf16 bars.'''
+    from rcf_amd.net_utils import OutlierRemoval
+    synth, train = env
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'bench_backward_b8.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    b = {kk: v.cuda() for kk, v in synth.make_batch(n, h, w, k, seed=dseed).items()}
+    m = _build(env, wseed, tier)
+    opt = train.make_optimizer(m, lr=1e-3)
+    m.train()
+    outl = OutlierRemoval(7, 1.5)
+    losses = []
+    for step in range(3):
+        loss, _, out = train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'], outlier_removal=outl)
+        torch.cuda.synchronize()
+        losses.append(float(loss.detach()))
+        if step == 0:
+            # (the gradient arena still holds step 1's gradients: optimizer.step() does not touch them)
+            grads = {kk: p.grad.detach().double().cpu() for kk, p in _named_params(m) if p.grad is not None}
+            out_mean = float(out.detach().double().mean())
+    lbar = BF16_LOSS_BAR * 40 if tier == 'bf16' else BAR   # (bf16: after two Adam updates the trajectories of two arithmetics part)
+    print('%s losses %s vs oracle %s' % (tier, ['%.5f' % v for v in losses], ['%.5f' % v for v in g['losses']]))
+    for got, want in zip(losses, g['losses']):
+        assert abs(got - want) < lbar * want, (tier, losses, g['losses'].tolist())
+    assert abs(out_mean - float(g['output_mean'])) < (3e-3 if tier == 'bf16' else 1e-4) * float(g['output_mean'])
+    assert set(grads.keys()) == set(g['grad_keys'].tolist())
+    # ---- sampled elements against fp64
+    e_hip, e_ref, cosines = [], [], []
+    for key, idx, ref32, v64, amax in zip(g['keys'].tolist(), g['idx'], g['ref32'], g['fp64'], g['fp64_absmax']):
+        got = grads[key].reshape(-1).numpy()[idx]
+        e_hip.append(float(np.abs(got - v64).max() / amax))
+        e_ref.append(float(np.abs(ref32.astype(np.float64) - v64).max() / amax))
+        cosines.append(float(np.dot(got, v64) / (np.linalg.norm(got) * np.linalg.norm(v64))))
+    print('%s sampled gradient elements vs fp64 (max-norm): HIP %s | the fp32 oracle %s | cosines min %.5f'
+          % (tier, ' '.join('%.1e' % e for e in e_hip), ' '.join('%.1e' % e for e in e_ref), min(cosines)))
+    if tier == 'bf16':
+        assert min(cosines) > 0.99
+    else:
+        for key, eh, er in zip(g['keys'].tolist(), e_hip, e_ref):
+            assert eh <= 5.0 * er + 2e-4, (key, eh, er)
+        assert np.median(e_hip) <= 3.0 * np.median(e_ref) + 2e-5
+    # ---- every parameter gradient's norm
+    worst, worst_key, n_loose = 0.0, None, 0
+    for key, l2, l64 in zip(g['grad_keys'].tolist(), g['grad_l2'], g['grad_l2_fp64']):
+        got = float(grads[key].norm())
+        ref_dist = abs(l2 - l64) / max(l64, 1e-30)          # the fp32 oracle's own distance from fp64 on this norm
+        e = abs(got - l64) / max(l64, 1e-30)
+        bar = (4e-2 if tier == 'bf16' else max(BAR, 3.0 * ref_dist))
+        n_loose += bar > BAR
+        if e / bar > worst:
+            worst, worst_key = e / bar, key
+        assert e < bar, (tier, key, got, l64, l2)
+    print('%s: %d parameter-gradient norms vs fp64, worst at %.2f of its bar (%s); %d of them judged by the oracle's own distance from fp64'
+          % (tier, len(g['grad_keys']), worst, worst_key, n_loose))
+
+
 # ------------------------------------------------------------------------------------------------------------ configs[3]
 def test_config3_bf16_train_step_900x1600_against_fp32_oracle(env):
     '''bf16 training arithmetic at the benchmark resolution (batch 2 so the batch statistics are over more than one image)

@@ -478,6 +478,30 @@ def test_radar_scatter_matches_reference_golden_and_oracle(ops, golden_dir):
             assert np.array_equal(depth.cpu().numpy(), od) and np.array_equal(resp.cpu().numpy(), orr), (k, h, w, strict)
 
 
+def test_radar_scatter_from_logits_thresholds_on_the_sign(ops):
+    '''rcf_radar_scatter_logits (what pipeline.radarnet_forward calls): sigmoid + the 0.5 threshold of src/radarnet_main.py:563-567 taken
+    inside the kernel on the SIGN of the logit.  Against the oracle run on the CPU's torch.sigmoid of the same logits: the integer depth
+    map and the kept / dropped pattern must be identical, the responses equal to an ulp of expf; logits placed at 0, +-1e-3 and beyond
+    sigmoid's saturation (ties between points: the first one wins, like torch.max).'''
+    from oracle.radar_scatter_oracle import radar_scatter
+    rs = np.random.RandomState(5)
+    for (k, h, w, wc) in ((24, 40, 200, 32), (64, 96, 400, 72)):
+        logits = (rs.randn(k, h, wc) * 3.0).astype(np.float32)
+        logits[0, 0, :8] = [0.0, 1e-3, -1e-3, 20.0, 25.0, 88.0, -0.0, -30.0]
+        logits[1, 0, 3:6] = [20.0, 25.0, 88.0]            # saturated ties with point 0 where the crops overlap
+        pts = np.stack([rs.randint(0, w, size=k).astype(np.float32), np.zeros(k, np.float32), rs.uniform(1.0, 80.0, size=k).astype(np.float32)], 1)
+        pts[1, 0] = pts[0, 0]                                # the two points' crops coincide
+        depth, resp = ops.radar_scatter(torch.from_numpy(logits).cuda(), torch.from_numpy(pts).cuda(), w, True, logits=True)
+        torch.cuda.synchronize()
+        cpu_resp = torch.sigmoid(torch.from_numpy(logits)).numpy()
+        assert not np.any((logits < 0) & (cpu_resp >= 0.5)), 'test logits must stay out of (-6e-8, 0)'
+        od, orr = radar_scatter(cpu_resp, pts, w, strict_reference=True)
+        assert np.array_equal(depth.cpu().numpy(), od)
+        got = resp.cpu().numpy()
+        assert np.array_equal(got > 0, orr > 0)
+        assert float(np.abs(got - orr).max()) <= 2.4e-7
+
+
 @pytest.mark.parametrize('n,h,w,ks,thr', [(2, 37, 53, 7, 1.5), (1, 900 // 4, 1600 // 4, 7, 1.5), (3, 20, 31, 5, 0.5), (1, 9, 70, 3, 2.0)])
 def test_outlier_removal_bit_exact(ops, n, h, w, ks, thr):
     '''Comparisons and copies only: bit-exact against the oracle (itself pinned to the reference class by make_golden.py).'''

@@ -253,3 +253,20 @@ def test_t13_fusionnet34(golden_dir):
     grads = dict(_named(m, 'p'))
     for key, l2 in zip(g['grad_keys'].tolist(), g['grad_l2'].tolist()):
         assert abs(float(grads[key].grad.double().norm()) - l2) <= 2e-4 * l2 + 1e-12, key
+
+
+def test_headline_backward_fixture_is_consistent(golden_dir):
+    '''tests/golden/bench_backward_b8.npz (make_bench_backward.py): the oracle's batch-8 900x1600 training step.  CPU-side checks that
+    need no 45 GB run: the recorded first loss is the one bench_expected.json holds for the same step, the fp64 loss agrees with it to
+    fp32 rounding, the sampled fp32 elements sit at the recorded distance from fp64, and the losses fall.'''
+    import json
+    g = np.load(os.path.join(golden_dir, 'bench_backward_b8.npz'))
+    rec = json.load(open(os.path.join(golden_dir, 'bench_expected.json')))['train_b8_900x1600_p64']
+    assert [int(v) for v in g['meta']] == [8, 900, 1600, 64, 1234, 1234]
+    assert abs(float(g['losses'][0]) - rec['first_step_loss']) < 1e-6 * rec['first_step_loss']
+    assert abs(float(g['fp64_loss']) - float(g['losses'][0])) < 1e-6 * float(g['losses'][0])
+    assert g['losses'][0] > g['losses'][1] > g['losses'][2]
+    assert len(g['grad_keys']) == 209 and g['idx'].shape == (10, 2048)
+    for r32, v64, amax, rel in zip(g['ref32'], g['fp64'], g['fp64_absmax'], g['ref32_rel_err']):
+        assert abs(float(np.abs(r32.astype(np.float64) - v64).max() / amax) - float(rel)) < 1e-12
+        assert 1e-5 < rel < 2e-2      # fp32 gradients of this net: decision flips, not rounding (DESIGN.md 2)
