@@ -237,7 +237,7 @@ def test_config1_headline_backward_and_three_adam_steps_against_the_oracle(env, 
         if e / bar > worst:
             worst, worst_key = e / bar, key
         assert e < bar, (tier, key, got, l64, l2)
-    print('%s: %d parameter-gradient norms vs fp64, worst at %.2f of its bar (%s); %d of them judged by the oracle's own distance from fp64'
+    print('%s: %d parameter-gradient norms vs fp64, worst at %.2f of its bar (%s); %d of them judged by the own distance of the oracle from fp64'
           % (tier, len(g['grad_keys']), worst, worst_key, n_loose))
 
 
