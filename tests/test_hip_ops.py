@@ -489,7 +489,8 @@ def test_radar_scatter_from_logits_thresholds_on_the_sign(ops):
         logits = (rs.randn(k, h, wc) * 3.0).astype(np.float32)
         logits[0, 0, :8] = [0.0, 1e-3, -1e-3, 20.0, 25.0, 88.0, -0.0, -30.0]
         logits[1, 0, 3:6] = [20.0, 25.0, 88.0]            # saturated ties with point 0 where the crops overlap
-        pts = np.stack([rs.randint(0, w, size=k).astype(np.float32), np.zeros(k, np.float32), rs.uniform(1.0, 80.0, size=k).astype(np.float32)], 1)
+        pts = np.stack([rs.randint(wc // 2, wc // 2 + w, size=k).astype(np.float32), np.zeros(k, np.float32),
+                        rs.uniform(1.0, 80.0, size=k).astype(np.float32)], 1)   # x in the PADDED canvas, as the reference passes it
         pts[1, 0] = pts[0, 0]                                # the two points' crops coincide
         depth, resp = ops.radar_scatter(torch.from_numpy(logits).cuda(), torch.from_numpy(pts).cuda(), w, True, logits=True)
         torch.cuda.synchronize()
