@@ -361,6 +361,7 @@ def run_rank(args):
     import rcf_amd  # noqa: F401
     from rcf_amd import ops, parallel, synth, train
 
+    affinity = parallel.pin_rank_to_gpu_numa_node()     # before anything touches the GPU (also under a launcher: LOCAL_RANK from the env)
     rank, world, local_rank = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
@@ -608,6 +609,7 @@ def run_rank(args):
         'algorithmic_tflops': round(TRAIN_GFLOP_PER_SAMPLE * (args.height * args.width / 1.44e6) * n_samples / dt / 1e3, 2),
     }
     if dp_info is not None:
+        dp_info['cpu_affinity_rank0'] = affinity
         rec['dp'] = dp_info
     if side is not None:
         rec['exact_tier'] = side

@@ -143,6 +143,56 @@ class SegmentedCapture(object):
                 buckets.run_exchange(op, handles)
 
 
+def pin_rank_to_gpu_numa_node(local_rank=None, local_world=None):
+    '''One process per GPU: keep this rank's host threads (the Python thread that enqueues ~1,100 launches per step, RCCL's proxy
+    threads) on the CPUs of the NUMA node its GPU hangs off -- eight ranks on a two-socket host otherwise migrate across sockets and
+    enqueue through the inter-socket link.  Call BEFORE anything touches the GPU.  Reads sysfs only (no HIP call, no subprocess):
+    the DRM render nodes in PCI-bus order are the HIP device order on one node.  Returns a dict describing what was done; never raises
+    (an unknown topology leaves the affinity alone).'''
+    import glob
+    import os
+    info = {'pinned': False}
+    try:
+        if local_rank is None:
+            local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        if local_world is None:
+            local_world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')))
+        if local_world <= 1 or os.environ.get('RCF_RANK_AFFINITY', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
+            info['why'] = 'single rank or switched off'
+            return info
+        cards = []
+        for dev in glob.glob('/sys/class/drm/renderD*/device'):
+            real = os.path.realpath(dev)
+            try:
+                vendor = open(os.path.join(real, 'vendor')).read().strip()
+                node = int(open(os.path.join(real, 'numa_node')).read().strip())
+            except (OSError, ValueError):
+                continue
+            if vendor == '0x1002':
+                cards.append((os.path.basename(real), node))      # PCI address (sorts in bus order), NUMA node
+        cards.sort()
+        if len(cards) < local_world or local_rank >= len(cards):
+            info['why'] = '%d AMD render nodes for %d local ranks' % (len(cards), local_world)
+            return info
+        node = cards[local_rank][1]
+        if node < 0:
+            info['why'] = 'the GPU reports no NUMA node'
+            return info
+        cpus = set()
+        for part in open('/sys/devices/system/node/node%d/cpulist' % node).read().strip().split(','):
+            lo, _, hi = part.partition('-')
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= set(os.sched_getaffinity(0))
+        if not cpus:
+            info['why'] = 'NUMA node %d has no CPU this process may use' % node
+            return info
+        os.sched_setaffinity(0, cpus)
+        info.update({'pinned': True, 'numa_node': node, 'n_cpus': len(cpus), 'pci': cards[local_rank][0]})
+    except Exception as e:      # a topology this code does not understand must never stop a run
+        info['why'] = 'not pinned: %s' % str(e)[:80]
+    return info
+
+
 def init_from_env(backend=None):
     '''Rendezvous from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run); returns (rank, world, local_rank).'''
     import os

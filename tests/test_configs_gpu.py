@@ -503,6 +503,31 @@ def test_bench_two_ranks_spawned_by_bench_itself():
     assert rec['config']['loss_check']['ok'] is True       # the global masked mean of the two ranks' batches, against the oracle's
 
 
+def test_bench_eight_ranks_spawned_by_bench_itself():
+    '''The 8-rank path of `python bench.py --gpus 8` -- what the driver's scaling run launches -- on device tensors: the launch
+    probe's all-gather over 8 ranks, six gradient buckets launched from the tape on every rank, the loss normalised by the counts of
+    EIGHT data seeds (the oracle's global masked mean from tests/golden/bench_expected.json).  With fewer than eight devices the ranks
+    share cuda:0 over gloo at the small shape (the host-blocking backend: no graph segments); with eight, RCCL.'''
+    eight = torch.cuda.device_count() >= 8
+    extra_env = {} if eight else {'RCF_BENCH_SINGLE_DEVICE': '1', 'RCF_DIST_BACKEND': 'gloo'}
+    args = ['--gpus', '8', '--steps', '2', '--warmup', '1', '--batch', '2', '--height', '224', '--width', '384', '--points', '32',
+            '--preheat-s', '0', '--no-cpu-baseline']
+    try:
+        r, rec = _run_bench(args, extra_env, timeout=600)
+    except subprocess.TimeoutExpired:
+        pytest.skip('the eight-rank rendezvous did not complete on this box; the 8-rank bucket / loss-sum logic is covered on the CPU by '
+                    'tests/test_host_logic.py (gloo, world 8)')
+    assert r.returncode == 0 and rec is not None, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    assert rec['n_gpus'] == 8 and rec['rccl_ranks'] == 8 and rec['config']['parallelism'] == 'dp8'
+    assert rec['backend'] == ('nccl' if eight else 'gloo')
+    assert len(rec['per_rank_ms_per_step']) == 8 and rec['config']['global_batch'] == 16
+    assert rec['dp']['buckets'] >= 2 and rec['dp']['gradient_bytes'] == 14142208 * 4
+    assert rec['config']['loss_check']['ok'] is True       # the global masked mean over the eight ranks' batches, against the oracle's
+    probe = rec['dp']['launch_probe']
+    assert len(probe['host_ms_by_rank']) == 8 and isinstance(probe['decision'], str)
+    assert isinstance(rec['dp']['cpu_affinity_rank0'], dict) and 'pinned' in rec['dp']['cpu_affinity_rank0']
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_bench_two_ranks_at_the_headline_shape_pass_their_own_loss_check(dtype):
     '''`python bench.py --gpus 2` at the DEFAULT shape (published net, per-GPU batch 8, 900x1600) -- what the driver's scaling run
