@@ -1294,7 +1294,7 @@ extern "C" int rcf_radar_scatter_logits(const float* logits, const float* points
     return rcf_launch_status();
 }
 
-extern "C" const char* rcf_version(void) { return "rcf_hip 0.2.0 (gfx950; fp32 results from v_mfma_f32_32x32x16_bf16 with an exact 3-plane operand split, v_mfma_f32_32x32x2_f32 for 1x1 / stems; bf16 storage mode)"; }
+extern "C" const char* rcf_version(void) { return "rcf_hip 0.3.0 (gfx950; fp32 results from v_mfma_f32_32x32x16_f16 on two scaled fp16 operand planes, or _bf16 on an exact 3-plane split; v_mfma_f32_32x32x2_f32 for 1x1 / stems; bf16 storage mode; weight gradients with producer / consumer waves and ds_read_b64_tr_b16)"; }
 
 extern "C" int rcf_device_ok(void) {
     int n = 0;
