@@ -220,6 +220,8 @@ class Engine(object):
         self._side_busy = False
         self._side_keep = []
         self._open_switches = []       # stream switches entered and not yet left (recover() undoes them after an exception)
+        self.amax_chunk = 512          # slots per zero-filled chunk of the per-step maxima arena (two-plane fp16 arithmetic)
+        self.amax_arena_cap = None     # tests only: never size the arena above this many slots
         self.completes_bucket = None   # callable(parameter) -> bool (data parallelism): this gradient finishes a bucket
         # the encoder's depth branch on its own stream (forward and backward): independent of the image branch up to each level's
         # fusion (RCF_BRANCH_STREAM=0: on the main stream).  fp32 +2.3 %, bf16 +2.9 % on top of the weight-gradient stream
@@ -301,7 +303,10 @@ class Engine(object):
         # sized from what the previous step of this engine used, so that a deep net (fusionnet34) overflows in its first step only
         self._amax_need = max(self._amax_need, self._amax_total)
         self._amax_total = 0
-        self._amax_arena = torch.zeros(max(512, self._amax_need), dtype=torch.float32, device=ref.device) if self._f16() else None
+        n = max(self.amax_chunk, self._amax_need)
+        if self.amax_arena_cap is not None:     # tests: a small cap makes every step run through the mid-step overflow path
+            n = min(n, self.amax_arena_cap)
+        self._amax_arena = torch.zeros(n, dtype=torch.float32, device=ref.device) if self._f16() else None
         self.plan.fence = self._fence_streams
 
     def _fence_streams(self):
@@ -328,7 +333,8 @@ class Engine(object):
         if self._amax_used >= self._amax_arena.numel():
             # a deeper net, or a second forward before the backward: another zeroed chunk (the full one stays alive through the Acts
             # that hold views of it)
-            self._amax_arena = torch.zeros(512, dtype=torch.float32, device=self._amax_arena.device)
+            n = self.amax_chunk if self.amax_arena_cap is None else min(self.amax_chunk, self.amax_arena_cap)
+            self._amax_arena = torch.zeros(n, dtype=torch.float32, device=self._amax_arena.device)
             self._amax_used = 0
             self._fence_streams()
         self._amax_used += 1

@@ -933,6 +933,40 @@ def test_hipgraph_captured_training_step_is_bitwise_the_eager_step(env, golden_d
     np.testing.assert_allclose(gr[0], g['losses'], rtol=BAR)      # and it is the reference's trajectory (without outlier removal)
 
 
+def test_captured_training_step_with_the_maxima_arena_overflowing_mid_step(env, golden_dir):
+    '''The per-step arena of operand maxima (two-plane fp16 arithmetic) is zero-filled in chunks; a chunk that runs out in the middle
+    of a step is replaced by a fresh one and every engine stream is fenced behind the fill (Engine._fence_streams).  With the arena
+    capped at 8 slots every step goes through that path dozens of times -- in forward, in backward, on the side streams.  Captured
+    (the fence must leave the capture joinable: the streams it made wait are rejoined by side_join) and eager, against the uncapped
+    eager step: bitwise the same losses and parameters.'''
+    synth, train = env
+    g = np.load(os.path.join(golden_dir, 'T2_tiny_adam3.npz'))
+    n, h, w, k, dseed, wseed = [int(v) for v in g['meta']]
+    batches = [_gpu_batch(synth.make_batch(n, h, w, k, seed=dseed + i)) for i in range(3)]
+    runs = {}
+    for mode in ('reference', 'eager', 'graph'):
+        m = _build(env, synth.TINY, wseed)
+        opt = train.make_optimizer(m, lr=1e-3)
+        m.train()
+        if mode != 'reference':
+            m._engine.amax_arena_cap = 8
+        if mode == 'graph':
+            b0 = batches[0]
+            step = m.capture_training_step(opt, b0['image'], b0['input_depth'], b0['ground_truth'], b0['lidar_map'])
+        losses = []
+        for b in batches:
+            if mode == 'graph':
+                loss = step(b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])
+            else:
+                loss = train.train_step(m, opt, b['image'], b['input_depth'], b['ground_truth'], b['lidar_map'])[0]
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        runs[mode] = (losses, m._param_arena.clone())
+    for mode in ('eager', 'graph'):
+        assert runs[mode][0] == runs['reference'][0], (mode, runs[mode][0], runs['reference'][0])
+        assert torch.equal(runs[mode][1], runs['reference'][1]), mode
+
+
 def test_captured_training_step_follows_a_learning_rate_schedule_and_two_param_groups(env, golden_dir):
     '''The reference loop rewrites g['lr'] on its schedule (src/fusionnet_main.py:354-362).  A replayed step must see that: the
     recorded Adam launch reads its hyper-parameters from device memory, refreshed before each replay.  Also two param groups on the
