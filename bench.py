@@ -301,6 +301,29 @@ def _encoder_3x3(timer, ev_steps, dtype):
                     'partial products (the few stride-2 forward launches on the f32 MFMA are priced the same way)' % prod}
 
 
+def _wgrad_3x3(timer, ev_steps, dtype):
+    '''The 3x3 / 2x2 weight-gradient launches on the 16-bit matrix pipe (kernel ids 10000 + ... + 5000 split): round 6 rebuilt this family
+    (csrc/rcf_conv_wgrad_tr.h, ids with the hundreds digit 3 / 7), so the driver's line carries its rate next to the forward family's.'''
+    flops = ms = 0.0
+    n = n_tr = 0
+    for (kid, tag), (c, f, m) in getattr(timer, 'layers', {}).items():
+        base = kid % 20000
+        if base >= 15000 and (' k3 ' in tag or ' k2 ' in tag):      # a split weight-gradient kernel
+            flops += f; ms += m; n += c
+            if (kid // 100) % 10 in (3, 7):
+                n_tr += c
+    if ms <= 0.0:
+        return None
+    tf = flops / (ms * 1e-3) / 1e12
+    prod = SPLIT_PRODUCTS[dtype]
+    return {'launches_per_step': n // max(1, ev_steps), 'on_conv_wgrad_tr_kernel': n_tr // max(1, ev_steps),
+            'gflop_per_step': round(flops / max(1, ev_steps) / 1e9, 1), 'ms_per_step': round(ms / max(1, ev_steps), 3),
+            'tflops_algorithmic': round(tf, 2), 'tflops_executed': round(tf * prod, 1),
+            'frac_of_pipe_peak': round(tf * prod / BF16_MFMA_PEAK_TFLOPS, 4),
+            'note': 'kernel + reduction per launch, single-stream events; the family runs at 1.57-1.65 GHz at the 1400 W cap '
+                    '(profiles/r06_power_bound.txt): frac_of_pipe_peak is against the 2.4 GHz peak'}
+
+
 def _pmc_value(kernel_name, field):
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_bench.json')))
@@ -677,6 +700,7 @@ def run_rank(args):
             # the subset north_star's ">= 70 % MFMA utilisation" names: the encoder's 3x3 convolutions (ResNet blocks, both branches;
             # forward + input gradient + weight gradient launches), from the same events
             'encoder_3x3': dict(_encoder_3x3(timer, ev_steps, dtype) or {}, mfma_busy_pmc_of_its_kernels=(_pmc_value('kernels of the encoder 3x3 convolutions', 'mfma_busy_fraction') if dtype == 'f32' else None)),
+            'weight_gradients': dict(_wgrad_3x3(timer, ev_steps, dtype) or {}, mfma_busy_pmc=(_pmc_value('conv_wgrad_tr_kernel', 'mfma_busy_fraction') if dtype == 'f32' else None)),
             'all_conv_kernels': {'achieved': round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
                                  'share_of_step_time': round(conv_ms / ev_steps / (1000.0 * dt / args.steps), 4),
                                  'gflop_per_sample': round(conv_flops / (batch * ev_steps) / 1e9, 2)},
