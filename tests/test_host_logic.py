@@ -422,3 +422,38 @@ def test_generated_code_of_the_small_units_is_clean():
     assert len(lines) == 3, r.stdout[-800:]
     for ln in lines:
         assert ln.endswith(' 0 flagged'), r.stdout[-1500:]
+
+
+def test_error_codes_map_to_exception_types(pkg):
+    '''_lib.check: RCF_EUNSUPPORTED (-2) raises RcfUnsupported -- the only error the engine answers with another form of the same
+    operation (merged phase forms -> per-phase launches); RCF_EINVAL and hipError_t codes raise plain RcfError and propagate.'''
+    from rcf_amd import _lib
+    assert issubclass(_lib.RcfUnsupported, _lib.RcfError)
+    _lib.check(0, 'ok')
+    with pytest.raises(_lib.RcfUnsupported) as e:
+        _lib.check(-2, 'rcf_conv2d_query')
+    assert e.value.code == -2
+    for rc in (-1, 719, 98):
+        with pytest.raises(_lib.RcfError) as e:
+            _lib.check(rc, 'rcf_conv2d_wgrad')
+        assert not isinstance(e.value, _lib.RcfUnsupported) and e.value.code == rc
+
+
+def test_rank_pinning_never_raises_and_reports(pkg, monkeypatch):
+    '''parallel.pin_rank_to_gpu_numa_node (called by bench.py before anything touches the GPU): sysfs only; on a box without AMD render
+    nodes, with a single rank, or switched off it leaves the affinity alone and says why.'''
+    import os
+    from rcf_amd import parallel
+    before = os.sched_getaffinity(0)
+    info = parallel.pin_rank_to_gpu_numa_node(local_rank=0, local_world=1)
+    assert info['pinned'] is False and 'why' in info
+    monkeypatch.setenv('RCF_RANK_AFFINITY', '0')
+    info = parallel.pin_rank_to_gpu_numa_node(local_rank=3, local_world=8)
+    assert info['pinned'] is False
+    monkeypatch.delenv('RCF_RANK_AFFINITY')
+    info = parallel.pin_rank_to_gpu_numa_node(local_rank=7, local_world=8)      # this container: no GPU, no render nodes
+    assert isinstance(info, dict) and 'pinned' in info
+    if not info['pinned']:
+        assert os.sched_getaffinity(0) == before
+    else:
+        os.sched_setaffinity(0, before)
