@@ -220,6 +220,8 @@ class Engine(object):
         self._side_busy = False
         self._side_keep = []
         self._open_switches = []       # stream switches entered and not yet left (recover() undoes them after an exception)
+        self.pw_s2_dgrad_lowres = os.environ.get('RCF_PW_S2_DGRAD', '1') != '0'
+        self._pw_s2_ok = {}
         self.amax_chunk = 512          # slots per zero-filled chunk of the per-step maxima arena (two-plane fp16 arithmetic)
         self.amax_arena_cap = None     # tests only: never size the arena above this many slots
         self.completes_bucket = None   # callable(parameter) -> bool (data parallelism): this gradient finishes a bucket
@@ -1134,10 +1136,45 @@ class Engine(object):
                 acc = src.g is not None
                 if acc:
                     src.bsum = None
+                if desc.ksize == 1 and desc.stride == 2 and x2 is None and self._pw_s2_dgrad(desc, weight, dz, src, acc, dz_amax):
+                    continue
                 if not acc:
                     src.g = self._new(tuple(self._shape(src)), dz)
                 dd = ops.make_dgrad_desc(desc, off, cnt, acc)
                 self._run_dgrad(dd, weight, dz, src.g, dz_amax, sums_for=None if acc else src)
+
+    def _pw_s2_dgrad(self, desc, weight, dz, src, acc, dz_amax):
+        '''The input gradient of a 1x1 stride-2 convolution at dZ's resolution (ops.make_pw_s2_dgrad_desc): W^T dZ written to the even
+        positions of a zero-filled (or accumulated-into) dX -- a quarter of the dense form's pixels, bitwise its result.  Returns False
+        where no kernel takes the strided-output form (remembered per shape); RCF_PW_S2_DGRAD=0 switches it off.'''
+        if not self.pw_s2_dgrad_lowres or ops.act_dtype() != torch.float32:
+            # (bf16 tensors: conv1x1_b16_kernel already skips the zeros of the dilated dZ; the strided-output form measured 0.3 % slower)
+            return False
+        dd = self._exact_unless(ops.make_pw_s2_dgrad_desc(desc, acc), dz_amax)
+        key = bytes(dd)
+        if self._pw_s2_ok.get(key) is False:
+            return False
+        try:
+            info = ops.conv_query(dd)
+        except ops._lib.RcfUnsupported:
+            self._pw_s2_ok[key] = False
+            return False
+        self._pw_s2_ok[key] = True
+        if not acc:
+            src.g = torch.zeros(tuple(self._shape(src)), dtype=ops.act_dtype(), device=dz.device)   # the odd positions stay zero
+        scales = None
+        if self._two_plane(info.kernel_id):
+            wmax = self._w_amax(weight.detach())
+            packed = self._pack(dd, weight.detach(), dz, wmax)
+            scales = ops.make_scales(dz_amax, None, wmax)
+        else:
+            packed = self._pack(dd, weight.detach(), dz)
+        if self.prof is not None:
+            self.prof.begin(info.kernel_id, ops.algorithmic_flops(dd), dd)
+        ops.conv_fwd(dd, dz, None, packed, src.g, None, scales=scales)
+        if self.prof is not None:
+            self.prof.end()
+        return True
 
     def _bn_sums_launch(self, dd, info, dz, packed, out, scales, sums_for):
         '''The input-gradient launch `dd` writes sums_for.g for the first time.  If sums_for is the output of a BatchNorm + lrelu block

@@ -158,6 +158,21 @@ def make_dgrad_desc(fwd, i_off, i_cnt, accumulate):
                     out_stride=1, out_off_y=0, out_off_x=0, out_h_phys=fwd.h_in, out_w_phys=fwd.w_in, in_off_y=0, in_off_x=0, phase_sum=0, precision=_PRECISION[0], storage=_STORAGE[0])
 
 
+def make_pw_s2_dgrad_desc(fwd, accumulate):
+    '''The input gradient of a 1x1 STRIDE-2 convolution `fwd` (the ResNet projections, src/net_utils.py:300-307) at the resolution of dZ:
+    dX(2y, 2x) = W^T dZ(y, x) and dX is zero everywhere else, so instead of a dense 1x1 convolution over the zero-dilated dZ at the input
+    resolution (make_dgrad_desc: four times the pixels, three quarters of them zeros) this is a plain 1x1 convolution of dZ whose outputs
+    land at the even positions of dX (out_stride 2).  The caller zero-fills dX first unless it accumulates.  Same kernel, same dot
+    products: bitwise the dense form.'''
+    if fwd.ksize != 1 or fwd.stride != 2 or fwd.c2 != 0:
+        raise ValueError('a 1x1 stride-2 forward descriptor is required')
+    return ConvDesc(n=fwd.n, h_in=fwd.h_out, w_in=fwd.w_out, c1=fwd.c_out, c2=0, h_src1=fwd.h_out, w_src1=fwd.w_out,
+                    gather1=RCF_GATHER_DIRECT, h_out=fwd.h_out, w_out=fwd.w_out, c_out=fwd.c1, ksize=1, stride=1, pad=0, pad_x=0,
+                    w_mode=RCF_W_DGRAD, w_o=fwd.w_o, w_i=fwd.w_i, w_i_off=0, accumulate=1 if accumulate else 0,
+                    out_stride=2, out_off_y=0, out_off_x=0, out_h_phys=fwd.h_in, out_w_phys=fwd.w_in, in_off_y=0, in_off_x=0, phase_sum=0,
+                    precision=_PRECISION[0], storage=_STORAGE[0])
+
+
 # ---- 2x2 phase convolutions (include/rcf_hip.h, RCF_PHASE_*) -------------------------------------------------------
 def make_up2x_fwd_desc(n, hs, ws, c_in, c_out, a, b, phase_out=False):
     """Phase (a,b) of conv3x3(nearest-upsample-2x(x)): a 2x2 conv on x writing output pixels (2y+a, 2x+b).

@@ -457,6 +457,40 @@ def test_stride2_input_gradient_as_four_phase_convs(ops, cin, cout, n, h, w):
         assert rel(nchw(dx), x.grad + base) < TOL, accumulate
 
 
+@pytest.mark.parametrize('case', [(64, 128, 2, 45, 63), (128, 256, 2, 29, 50), (32, 64, 3, 36, 52), (256, 256, 1, 15, 25)], ids=lambda c: str(c))
+def test_1x1_stride2_input_gradient_at_dz_resolution_is_bitwise_the_dense_form(ops, case):
+    '''The ResNet projections' input gradient (1x1, stride 2): dX(2y, 2x) = W^T dZ(y, x), zero elsewhere.  ops.make_pw_s2_dgrad_desc runs
+    it as a 1x1 convolution of dZ with out_stride 2 into a zero-filled dX (a quarter of the pixels of the zero-dilated dense form the
+    engine used before round 6); same kernel, same dot products: bitwise, also when accumulating.  Odd input sizes: the last even row /
+    column exists, the one after it does not.'''
+    c1, co, n, h, w = case
+    x = rnd(n, c1, h, w, seed=50)
+    x.requires_grad_(True)
+    wt = rnd(co, c1, 1, 1, seed=51, scale=0.2)
+    ref = F.conv2d(x, wt, stride=2)
+    dz = rnd(*ref.shape, seed=52)
+    (ref * dz).sum().backward()
+    fwd = ops.make_fwd_desc(n, h, w, c1, 0, co, 1, 2)
+    dzg = nhwc(dz)
+    for acc in (False, True):
+        base = rnd(n, c1, h, w, seed=53) if acc else torch.zeros(n, c1, h, w)
+        dd = ops.make_dgrad_desc(fwd, 0, c1, acc)
+        info = ops.conv_query(dd)
+        packed = torch.empty(info.packed_weight_floats, device='cuda')
+        ops.conv_pack(dd, dev(wt), packed)
+        dense = nhwc(base) if acc else torch.full((n, h, w, c1), float('nan'), device='cuda')
+        ops.conv_fwd(dd, dzg, None, packed, dense, None)
+        dl = ops.make_pw_s2_dgrad_desc(fwd, acc)
+        il = ops.conv_query(dl)
+        packed_l = torch.empty(il.packed_weight_floats, device='cuda')
+        ops.conv_pack(dl, dev(wt), packed_l)
+        low = nhwc(base) if acc else torch.zeros((n, h, w, c1), device='cuda')
+        ops.conv_fwd(dl, dzg, None, packed_l, low, None)
+        torch.cuda.synchronize()
+        assert rel(nchw(low), x.grad + base) < TOL, acc
+        assert torch.equal(low, dense), acc
+
+
 def test_radar_scatter_matches_reference_golden_and_oracle(ops, golden_dir):
     '''Bit-exact (integer/index work): golden vectors from the real radarnet_main.forward, then larger seeded cases vs the oracle.'''
     import os
